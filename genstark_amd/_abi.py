@@ -1,0 +1,150 @@
+"""ctypes binding of include/gstark.h.
+
+The product path loads exactly one library: genstark_amd/csrc/libgstark_hip.so (hand-written HIP for
+gfx950).  There is no CPU fallback: if the library is missing, is not the HIP build, or no MI355X is
+visible, construction raises.  (tests/ may pass an explicit `lib_path` with `allow_test_double=True`
+to run the host logic against the CPU oracle's implementation of the same ABI; nothing in this
+package ever does.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, 'csrc', 'libgstark_hip.so')
+
+GS_OK = 0
+HASH_ALGS = {'sha256': 0, 'blake2s256': 1}  # gs_hash_alg; lib/Stark.ts:19
+
+_vp, _u64, _u32, _int = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+_pvp = C.POINTER(C.c_void_p)
+_bytes = C.c_char_p  # host byte strings (const uint8_t *)
+
+_SIGNATURES = {
+    'gs_abi_version': (_int, []),
+    'gs_backend_name': (C.c_char_p, []),
+    'gs_ctx_create': (_int, [_int, _vp, _pvp]),
+    'gs_ctx_destroy': (None, [_vp]),
+    'gs_last_error': (C.c_char_p, [_vp]),
+    'gs_sync': (_int, [_vp]),
+    'gs_stream': (_vp, [_vp]),
+    'gs_field_modulus': (_int, [_vp]),
+    'gs_alloc': (_int, [_vp, _u64, _pvp]),
+    'gs_free': (_int, [_vp, _vp]),
+    'gs_upload': (_int, [_vp, _vp, _bytes, _u64]),
+    'gs_download': (_int, [_vp, _vp, _vp, _u64]),
+    'gs_copy': (_int, [_vp, _vp, _vp, _u64]),
+    'gs_gather': (_int, [_vp, _vp, _u64, C.POINTER(_u64), _u64, _vp]),
+    'gs_power_series': (_int, [_vp, _bytes, _u64, _vp]),
+    'gs_vec_add': (_int, [_vp, _vp, _vp, _u64, _vp]),
+    'gs_vec_sub': (_int, [_vp, _vp, _vp, _u64, _vp]),
+    'gs_vec_mul': (_int, [_vp, _vp, _vp, _u64, _vp]),
+    'gs_vec_add_scalar': (_int, [_vp, _vp, _bytes, _u64, _vp]),
+    'gs_vec_sub_scalar': (_int, [_vp, _vp, _bytes, _u64, _vp]),
+    'gs_vec_mul_scalar': (_int, [_vp, _vp, _bytes, _u64, _vp]),
+    'gs_vec_inv': (_int, [_vp, _vp, _u64, _vp]),
+    'gs_vec_div': (_int, [_vp, _vp, _vp, _u64, _vp]),
+    'gs_vec_exp': (_int, [_vp, _vp, _bytes, _u64, _vp]),
+    'gs_combine_many': (_int, [_vp, _pvp, _bytes, _u32, _u64, _vp]),
+    'gs_combine': (_int, [_vp, _vp, _vp, _u64, _vp]),
+    'gs_pluck': (_int, [_vp, _vp, _u64, _u64, _u64, _vp]),
+    'gs_transpose_vector': (_int, [_vp, _vp, _u64, _u32, _u64, _vp]),
+    'gs_transpose_matrix': (_int, [_vp, _vp, _u64, _u64, _vp]),
+    'gs_sub_matrix_from_vectors': (_int, [_vp, _pvp, _vp, _u32, _u64, _vp]),
+    'gs_eval_polys_at_roots': (_int, [_vp, _vp, _u32, _u64, _bytes, _u64, _vp]),
+    'gs_interpolate_roots': (_int, [_vp, _vp, _u32, _bytes, _u64, _vp]),
+    'gs_eval_poly_at': (_int, [_vp, _vp, _u64, _bytes, _vp]),
+    'gs_interpolate_quartic_batch': (_int, [_vp, _vp, _vp, _u64, _vp]),
+    'gs_interpolate_quartic_domain': (_int, [_vp, _bytes, _u64, _u64, _vp, _u64, _vp]),
+    'gs_eval_quartic_batch': (_int, [_vp, _vp, _u64, _bytes, _vp]),
+    'gs_hash_digest': (_int, [_vp, _int, _bytes, _u64, _vp]),
+    'gs_hash_merge_rows': (_int, [_vp, _int, _pvp, _u32, _u64, _vp]),
+    'gs_hash_digest_values': (_int, [_vp, _int, _vp, _u64, _u64, _vp]),
+    'gs_merkle_build': (_int, [_vp, _int, _vp, _u64, _vp]),
+    'gs_mimc_trace': (_int, [_vp, _bytes, _bytes, _u32, _u64, _vp]),
+    'gs_mimc_constraints': (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class GstarkError(RuntimeError):
+    pass
+
+
+def load_library(path):
+    if not os.path.exists(path):
+        raise GstarkError(
+            f'{path} not found: the HIP backend is not built (run `python -c "import __graft_entry__ as g; g.build()"`).'
+            ' There is no CPU fallback.')
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+class Backend:
+    """One gs_ctx (one device, one HIP stream).  All device work of the package goes through it."""
+
+    def __init__(self, device=0, stream=None, lib_path=None, allow_test_double=False):
+        self.lib = load_library(lib_path or HIP_LIB_PATH)
+        self.name = self.lib.gs_backend_name().decode()
+        if self.name != 'hip-gfx950' and not allow_test_double:
+            raise GstarkError(f'refusing backend {self.name!r}: the product path runs on hip-gfx950 only')
+        if self.lib.gs_abi_version() != 1:
+            raise GstarkError('gstark ABI version mismatch')
+        ctx = C.c_void_p()
+        rc = self.lib.gs_ctx_create(int(device), C.c_void_p(stream), C.byref(ctx))
+        if rc != GS_OK or not ctx.value:
+            raise GstarkError(f'gs_ctx_create(device={device}) failed with {rc}: no gfx950 device? (no CPU fallback)')
+        self.ctx = ctx
+        self.device = device
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.lib.gs_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(self.ctx, *args)
+        if rc != GS_OK:
+            raise GstarkError(f'{name} failed ({rc}): {self.lib.gs_last_error(self.ctx).decode()}')
+
+    # ---- memory
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self.call('gs_alloc', int(nbytes), C.byref(p))
+        return p.value
+
+    def free(self, ptr):
+        if self.ctx:
+            self.lib.gs_free(self.ctx, C.c_void_p(ptr))
+
+    def upload(self, ptr, data):
+        self.call('gs_upload', C.c_void_p(ptr), bytes(data), len(data))
+
+    def download(self, ptr, nbytes, offset=0):
+        buf = C.create_string_buffer(int(nbytes))
+        self.call('gs_download', C.cast(buf, C.c_void_p), C.c_void_p(ptr + offset), int(nbytes))
+        return buf.raw
+
+    def gather(self, ptr, rec_bytes, indexes):
+        n = len(indexes)
+        if n == 0:
+            return []
+        idx = (C.c_uint64 * n)(*indexes)
+        buf = C.create_string_buffer(n * rec_bytes)
+        self.call('gs_gather', C.c_void_p(ptr), rec_bytes, idx, n, C.cast(buf, C.c_void_p))
+        raw = buf.raw
+        return [raw[i * rec_bytes:(i + 1) * rec_bytes] for i in range(n)]
+
+    def sync(self):
+        self.call('gs_sync')
+
+    @property
+    def stream(self):
+        return self.lib.gs_stream(self.ctx)
+
+    @staticmethod
+    def ptr_array(ptrs):
+        return (C.c_void_p * len(ptrs))(*ptrs)

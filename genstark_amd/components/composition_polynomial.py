@@ -1,0 +1,116 @@
+"""Mirror of lib/components/CompositionPolynomial.ts — C(x) = D(x) + B(x), D = Q / Z.
+
+evaluateAll (:71-146) is the prover's heaviest phase: every step below is one device call through
+the galois-shaped field object (NTT / pointwise / batch inversion kernels)."""
+import math
+
+from .boundary_constraints import BoundaryConstraints
+from .zero_polynomial import ZeroPolynomial
+
+
+def getCombinationDegree(constraints, traceLength):  # :196-204
+    maxConstraintDegree = max([1] + [c['degree'] for c in constraints])
+    return 2 ** math.ceil(math.log2(maxConstraintDegree)) * traceLength
+
+
+def groupTransitionConstraints(constraints, traceLength):  # :206-225
+    groups = {}
+    for i, c in enumerate(constraints):
+        groups.setdefault(c['degree'] * traceLength, []).append(i)
+    return [{'degree': d, 'indexes': ix} for d, ix in groups.items()]
+
+
+class CompositionPolynomial:
+    def __init__(self, assertions, seed, context, logger=None):  # :29-61
+        f = self.field = context.field
+        self.bPoly = BoundaryConstraints(assertions, context)
+        self.zPoly = ZeroPolynomial(context)
+        self.log = logger or (lambda msg: None)
+        self.combinationDegree = getCombinationDegree(context.constraints, context.traceLength)
+        self.compositionDegree = max(self.combinationDegree - context.traceLength, context.traceLength)
+        self.constraintGroups = groupTransitionConstraints(context.constraints, context.traceLength)
+        dCoefficientCount = len(context.constraints)
+        for g in self.constraintGroups:
+            if g['degree'] < self.combinationDegree:
+                dCoefficientCount += len(g['indexes'])
+        bCoefficientCount = self.bPoly.count
+        if self.compositionDegree > context.traceLength:
+            bCoefficientCount *= 2
+        coefficients = f.prng(seed, dCoefficientCount + bCoefficientCount).toValues()
+        self.dCoefficients = coefficients[:dCoefficientCount]
+        self.bCoefficients = coefficients[dCoefficientCount:]
+
+    @property
+    def coefficientCount(self):
+        return len(self.dCoefficients) + len(self.bCoefficients)
+
+    def evaluateAll(self, pPolys, pEvaluations, context):  # :71-146
+        f = self.field
+        # 1 ----- transition constraints over the composition domain
+        qEvaluations = context.evaluateTransitionConstraints(pPolys)
+        self.log('Computed transition constraint polynomials Q(x)')
+        # 2 ----- adjust degrees
+        compositionFactor = context.evaluationDomain.length // context.compositionDomain.length
+        compositionRou = f.exp(context.rootOfUnity, compositionFactor)
+        qaEvaluations = f.matrixRowsToVectors(qEvaluations)
+        for g in self.constraintGroups:
+            if g['degree'] == self.combinationDegree:
+                continue
+            powerSeed = f.exp(compositionRou, self.combinationDegree - g['degree'])
+            powers = f.getPowerSeries(powerSeed, context.compositionDomain.length)
+            for i in g['indexes']:
+                qaEvaluations.append(f.mulVectorElements(qaEvaluations[i], powers))
+        self.log('Adjusted degrees of Q(x) polynomials')
+        # 3 ----- merge into one polynomial and extend to the evaluation domain
+        qcEvaluations = f.combineManyVectors(qaEvaluations, self.dCoefficients)
+        self.log('Computed linear combination of Q(x) polynomials')
+        qcPoly = f.interpolateRoots(context.compositionDomain, qcEvaluations)
+        qeEvaluations = f.evalPolyAtRoots(qcPoly, context.evaluationDomain)
+        self.log('Performed low degree extensions of Q(x) polynomial')
+        # 4 ----- D(x) = Q(x) / Z(x)
+        zEvaluations = self.zPoly.evaluateAll(context.evaluationDomain)
+        self.log('Computed Z(x) polynomial')
+        zInverses = f.divVectorElements(zEvaluations['denominators'], zEvaluations['numerators'])  # 1/Z = den/num (:117)
+        self.log('Computed Z(x) inverses')
+        dEvaluations = f.mulVectorElements(qeEvaluations, zInverses)
+        self.log('Computed D(x) polynomial')
+        # 5 ----- boundary constraints
+        bEvaluations = self.bPoly.evaluateAll(pEvaluations, context.evaluationDomain)
+        self.log('Computed boundary constraint polynomials B(x)')
+        # 6 ----- adjust degrees of boundary constraints
+        baEvaluations = f.matrixRowsToVectors(bEvaluations)
+        bIncrementalDegree = self.compositionDegree - context.traceLength
+        if bIncrementalDegree > 0:
+            powerSeed = f.exp(context.rootOfUnity, bIncrementalDegree)
+            psbPowers = f.getPowerSeries(powerSeed, context.evaluationDomain.length)
+            for i in range(self.bPoly.count):
+                baEvaluations.append(f.mulVectorElements(baEvaluations[i], psbPowers))
+        self.log('Adjusted degrees of B(x) polynomials')
+        # 7 ----- merge
+        bcEvaluations = f.combineManyVectors(baEvaluations, self.bCoefficients)
+        self.log('Computed linear combination of B(x) polynomials')
+        return f.addVectorElements(dEvaluations, bcEvaluations)
+
+    def evaluateAt(self, x, pValues, nValues, hValues, context):  # :150-191 (verifier, scalars)
+        f = self.field
+        qValues = context.evaluateConstraintsAt(x, pValues, nValues, hValues)
+        for g in self.constraintGroups:
+            if g['degree'] == self.combinationDegree:
+                continue
+            power = f.exp(x, self.combinationDegree - g['degree'])
+            for i in g['indexes']:
+                qValues.append(f.mul(qValues[i], power))
+        qcValue = 0
+        for v, k in zip(qValues, self.dCoefficients):
+            qcValue = f.add(qcValue, f.mul(v, k))
+        dValue = f.div(qcValue, self.zPoly.evaluateAt(x))
+        bValues = self.bPoly.evaluateAt(pValues, x)
+        bIncrementalDegree = self.compositionDegree - context.traceLength
+        if bIncrementalDegree > 0:
+            power = f.exp(x, bIncrementalDegree)
+            for i in range(self.bPoly.count):
+                bValues.append(f.mul(bValues[i], power))
+        bValue = 0
+        for v, k in zip(bValues, self.bCoefficients):
+            bValue = f.add(bValue, f.mul(v, k))
+        return f.add(dValue, bValue)

@@ -1,0 +1,396 @@
+"""Host mirror of the `@guildofweavers/galois` surface genSTARK calls (FiniteField / Vector / Matrix).
+
+Member names and argument meaning follow the TypeScript interface so that the callers
+(genstark_amd/stark.py, genstark_amd/components/*.py — mirrors of lib/Stark.ts and
+lib/components/*.ts) read like the reference.  Vectors and matrices are device-resident; every
+vector/matrix/polynomial operation is one call into the C ABI (include/gstark.h -> HIP kernels).
+Scalar (single bigint) operations and Lagrange interpolation of a handful of points are host
+integer arithmetic, exactly as in the reference's JS layer.
+
+Call sites of every member: SURVEY.md section 8(b).
+"""
+import ctypes as C
+import hashlib
+
+from ._abi import Backend, GstarkError
+
+ELEMENT_SIZE = 16
+MODULUS = 2**128 - 9 * 2**32 + 1
+
+
+def _le(v):
+    return int(v).to_bytes(ELEMENT_SIZE, 'little')
+
+
+def sha256_bigint(value):
+    """galois utils.sha256 (same helper as lib/components/QueryIndexGenerator.ts:61-67): a bigint is
+    hashed as Buffer.from(value.toString(16), 'hex') — no leading zeros, odd trailing nibble dropped."""
+    if isinstance(value, int):
+        h = format(value, 'x')
+        value = bytes.fromhex(h[: len(h) // 2 * 2])
+    return int.from_bytes(hashlib.sha256(bytes(value)).digest(), 'big')
+
+
+class _DeviceBuffer:
+    """Owns one gs_alloc'd range; freed when the last Vector/Matrix viewing it is collected."""
+
+    def __init__(self, backend, nbytes):
+        self.backend, self.nbytes = backend, nbytes
+        self.ptr = backend.alloc(max(nbytes, 16))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.backend.free(self.ptr)
+                self.ptr = 0
+        except Exception:
+            pass
+
+
+class Vector:
+    """galois Vector: `length` elements of `elementSize` bytes, little-endian."""
+
+    def __init__(self, backend, length, owner=None, offset=0, element_size=ELEMENT_SIZE):
+        self.backend, self.length, self.elementSize = backend, int(length), element_size
+        self._owner = owner or _DeviceBuffer(backend, self.length * element_size)
+        self._offset = offset
+        self.series_base = None  # set when the vector is known to be {base^i}: lets NTT calls skip a readback
+
+    @property
+    def ptr(self):
+        return self._owner.ptr + self._offset
+
+    @property
+    def byteLength(self):
+        return self.length * self.elementSize
+
+    def getValue(self, index):
+        return int.from_bytes(self.backend.download(self.ptr, self.elementSize, index * self.elementSize), 'little')
+
+    def toValues(self):
+        raw = self.toBuffer()
+        es = self.elementSize
+        return [int.from_bytes(raw[i * es:(i + 1) * es], 'little') for i in range(self.length)]
+
+    def toBuffer(self, start=0, count=None):
+        count = self.length - start if count is None else count
+        return self.backend.download(self.ptr, count * self.elementSize, start * self.elementSize)
+
+    def copyValue(self, index, destination, offset):
+        """lib/Stark.ts:290 — writes element `index` into `destination` (bytearray), returns bytes written."""
+        destination[offset:offset + self.elementSize] = self.backend.download(
+            self.ptr, self.elementSize, index * self.elementSize)
+        return self.elementSize
+
+    def valuesAt(self, indexes):
+        """Batched copyValue: the raw bytes of the elements at `indexes` (one device gather)."""
+        return self.backend.gather(self.ptr, self.elementSize, list(indexes))
+
+
+class Matrix:
+    """galois Matrix: rowCount x colCount elements, row-major contiguous (LowDegreeProver.ts:45)."""
+
+    def __init__(self, backend, rows, cols, owner=None, offset=0):
+        self.backend, self.rowCount, self.colCount, self.elementSize = backend, int(rows), int(cols), ELEMENT_SIZE
+        self._owner = owner or _DeviceBuffer(backend, self.rowCount * self.colCount * ELEMENT_SIZE)
+        self._offset = offset
+        self.quartic_domain = None  # (omega, n, step) when built by transposeVector(power series, 4, step)
+
+    @property
+    def ptr(self):
+        return self._owner.ptr + self._offset
+
+    def getValue(self, row, col):
+        off = (row * self.colCount + col) * ELEMENT_SIZE
+        return int.from_bytes(self.backend.download(self.ptr, ELEMENT_SIZE, off), 'little')
+
+    def toValues(self):
+        raw = self.toBuffer()
+        c = self.colCount
+        return [[int.from_bytes(raw[(r * c + k) * 16:(r * c + k + 1) * 16], 'little') for k in range(c)]
+                for r in range(self.rowCount)]
+
+    def toBuffer(self):
+        return self.backend.download(self.ptr, self.rowCount * self.colCount * ELEMENT_SIZE)
+
+    def rowsToBuffers(self, indexes):
+        """LowDegreeProver.ts:53,214,217 — one Buffer (colCount*16 bytes) per requested row."""
+        return self.backend.gather(self.ptr, self.colCount * ELEMENT_SIZE, list(indexes))
+
+    def row(self, r):
+        return Vector(self.backend, self.colCount, owner=self._owner, offset=self._offset + r * self.colCount * ELEMENT_SIZE)
+
+
+class PrimeField:
+    """createPrimeField(modulus[, wasmOptions]) — index.ts:14; lib/Stark.ts:40."""
+
+    def __init__(self, modulus=MODULUS, backend=None):
+        if modulus != MODULUS:
+            raise GstarkError('this build accelerates the 128-bit field 2^128 - 9*2^32 + 1 only')
+        self.backend = backend or Backend()
+        buf = C.create_string_buffer(16)
+        self.backend.lib.gs_field_modulus(C.cast(buf, C.c_void_p))
+        assert int.from_bytes(buf.raw, 'little') == modulus
+        self.modulus = modulus
+        self.elementSize = ELEMENT_SIZE
+        self.isOptimized = True       # lib/Stark.ts:41,49
+        self.zero, self.one = 0, 1
+
+    # ---- scalar arithmetic (bigint in, bigint out)
+    def mod(self, v): return v % self.modulus
+    def add(self, a, b): return (a + b) % self.modulus
+    def sub(self, a, b): return (a - b) % self.modulus
+    def mul(self, a, b): return (a * b) % self.modulus
+    def neg(self, a): return (-a) % self.modulus
+    def inv(self, a): return pow(a, self.modulus - 2, self.modulus) if a % self.modulus else 0
+    def div(self, a, b): return a * self.inv(b) % self.modulus
+
+    def exp(self, base, exponent):
+        if exponent < 0:  # examples/rescue/hash4x128.ts:14 passes a negative exponent
+            return pow(self.inv(base), -exponent, self.modulus)
+        return pow(base, exponent, self.modulus)
+
+    def prng(self, seed, length=None):
+        """FiniteField.prng (CompositionPolynomial.ts:58; LinearCombination.ts:58; LowDegreeProver.ts:194).
+        Construction restated from galois' documented behaviour (UNVERIFIED)."""
+        if length is None:
+            return sha256_bigint(seed) % self.modulus
+        out, state = [], sha256_bigint(seed)
+        for _ in range(length):
+            out.append(state % self.modulus)
+            state = sha256_bigint(state)
+        return self.newVectorFrom(out)
+
+    def getRootOfUnity(self, order):
+        """First i^((p-1)/order), i = 2,3,..., of exact order `order` (UNVERIFIED)."""
+        if order <= 0 or order & (order - 1) or (self.modulus - 1) % order:
+            raise GstarkError(f'Order {order} of root of unity is invalid')
+        for i in range(2, 1 << 16):
+            g = pow(i, (self.modulus - 1) // order, self.modulus)
+            if pow(g, order, self.modulus) == 1 and (order == 1 or pow(g, order // 2, self.modulus) != 1):
+                return g
+        raise GstarkError(f'Root of unity for order {order} was not found')
+
+    # ---- construction
+    def newVector(self, length):
+        return Vector(self.backend, length)
+
+    def newVectorFrom(self, values):
+        v = Vector(self.backend, len(values))
+        if values:
+            self.backend.upload(v.ptr, b''.join(_le(x % self.modulus) for x in values))
+        return v
+
+    def newMatrix(self, rows, cols):
+        return Matrix(self.backend, rows, cols)
+
+    def newMatrixFrom(self, values):
+        rows, cols = len(values), len(values[0]) if values else 0
+        m = Matrix(self.backend, rows, cols)
+        if rows * cols:
+            self.backend.upload(m.ptr, b''.join(_le(x % self.modulus) for r in values for x in r))
+        return m
+
+    def newMatrixFromVectors(self, vectors):
+        cols = vectors[0].length
+        m = Matrix(self.backend, len(vectors), cols)
+        for r, v in enumerate(vectors):
+            if v.length != cols:
+                raise GstarkError('Cannot create a matrix from vectors of different lengths')
+            self.backend.call('gs_copy', C.c_void_p(m.ptr + r * cols * 16), C.c_void_p(v.ptr), cols * 16)
+        return m
+
+    def matrixRowsToVectors(self, matrix):
+        return [matrix.row(r) for r in range(matrix.rowCount)]
+
+    # ---- vector operations
+    def _binary(self, fn_vec, fn_scalar, a, b):
+        out = Vector(self.backend, a.length)
+        if isinstance(b, int):
+            self.backend.call(fn_scalar, C.c_void_p(a.ptr), _le(b % self.modulus), a.length, C.c_void_p(out.ptr))
+        else:
+            if a.length != b.length:
+                raise GstarkError('Cannot combine vector elements: vectors have different lengths')
+            self.backend.call(fn_vec, C.c_void_p(a.ptr), C.c_void_p(b.ptr), a.length, C.c_void_p(out.ptr))
+        return out
+
+    def addVectorElements(self, a, b): return self._binary('gs_vec_add', 'gs_vec_add_scalar', a, b)
+    def subVectorElements(self, a, b): return self._binary('gs_vec_sub', 'gs_vec_sub_scalar', a, b)
+    def mulVectorElements(self, a, b): return self._binary('gs_vec_mul', 'gs_vec_mul_scalar', a, b)
+
+    def divVectorElements(self, a, b):
+        if isinstance(b, int):
+            return self.mulVectorElements(a, self.inv(b))
+        if a.length != b.length:
+            raise GstarkError('Cannot divide vector elements: vectors have different lengths')
+        out = Vector(self.backend, a.length)
+        self.backend.call('gs_vec_div', C.c_void_p(a.ptr), C.c_void_p(b.ptr), a.length, C.c_void_p(out.ptr))
+        return out
+
+    def invVectorElements(self, a):
+        out = Vector(self.backend, a.length)
+        self.backend.call('gs_vec_inv', C.c_void_p(a.ptr), a.length, C.c_void_p(out.ptr))
+        return out
+
+    def expVectorElements(self, a, e):
+        out = Vector(self.backend, a.length)
+        if e < 0:
+            a, e = self.invVectorElements(a), -e
+        self.backend.call('gs_vec_exp', C.c_void_p(a.ptr), _le(e), a.length, C.c_void_p(out.ptr))
+        return out
+
+    def combineVectors(self, a, b):
+        if a.length != b.length:
+            raise GstarkError('Cannot combine vectors: vectors have different lengths')
+        buf = C.create_string_buffer(16)
+        self.backend.call('gs_combine', C.c_void_p(a.ptr), C.c_void_p(b.ptr), a.length, C.cast(buf, C.c_void_p))
+        return int.from_bytes(buf.raw, 'little')
+
+    def combineManyVectors(self, vectors, coefficients):
+        ks = coefficients.toValues() if isinstance(coefficients, Vector) else list(coefficients)
+        if len(ks) != len(vectors):
+            raise GstarkError('Number of coefficients must be the same as the number of vectors')
+        n = vectors[0].length
+        out = Vector(self.backend, n)
+        self.backend.call('gs_combine_many', Backend.ptr_array([v.ptr for v in vectors]),
+                          b''.join(_le(k) for k in ks), len(vectors), n, C.c_void_p(out.ptr))
+        return out
+
+    def getPowerSeries(self, base, length):
+        out = Vector(self.backend, length)
+        self.backend.call('gs_power_series', _le(base), length, C.c_void_p(out.ptr))
+        out.series_base = base % self.modulus
+        return out
+
+    def pluckVector(self, v, skip, times):
+        out = Vector(self.backend, times)
+        self.backend.call('gs_pluck', C.c_void_p(v.ptr), v.length, skip, times, C.c_void_p(out.ptr))
+        return out
+
+    def transposeVector(self, v, columns, step=1):
+        if v.length % (columns * step):
+            raise GstarkError('Number of columns must evenly divide vector length')
+        rows = v.length // (columns * step)
+        m = Matrix(self.backend, rows, columns)
+        self.backend.call('gs_transpose_vector', C.c_void_p(v.ptr), v.length, columns, step, C.c_void_p(m.ptr))
+        if columns == 4 and v.series_base is not None:
+            m.quartic_domain = (v.series_base, v.length, step)
+        return m
+
+    # ---- matrix operations
+    def transposeMatrix(self, m):
+        out = Matrix(self.backend, m.colCount, m.rowCount)
+        self.backend.call('gs_transpose_matrix', C.c_void_p(m.ptr), m.rowCount, m.colCount, C.c_void_p(out.ptr))
+        return out
+
+    def joinMatrixRows(self, m):
+        return Vector(self.backend, m.rowCount * m.colCount, owner=m._owner, offset=m._offset)
+
+    def subMatrixElementsFromVectors(self, vectors, m):
+        out = Matrix(self.backend, m.rowCount, m.colCount)
+        self.backend.call('gs_sub_matrix_from_vectors', Backend.ptr_array([v.ptr for v in vectors]),
+                          C.c_void_p(m.ptr), m.rowCount, m.colCount, C.c_void_p(out.ptr))
+        return out
+
+    def divMatrixElements(self, a, b):
+        out = Matrix(self.backend, a.rowCount, a.colCount)
+        self.backend.call('gs_vec_div', C.c_void_p(a.ptr), C.c_void_p(b.ptr), a.rowCount * a.colCount, C.c_void_p(out.ptr))
+        return out
+
+    # ---- polynomials
+    def _omega_of(self, roots):
+        if roots.series_base is not None:
+            return roots.series_base
+        return roots.getValue(1) if roots.length > 1 else 1
+
+    def evalPolyAtRoots(self, poly, roots):
+        """CompositionPolynomial.ts:110 — NTT of `poly` (zero-extended) over the roots-of-unity vector."""
+        if poly.length > roots.length:
+            raise GstarkError('Number of roots of unity cannot be smaller than number of values')
+        out = Vector(self.backend, roots.length)
+        self.backend.call('gs_eval_polys_at_roots', C.c_void_p(poly.ptr), 1, poly.length, _le(self._omega_of(roots)),
+                          roots.length, C.c_void_p(out.ptr))
+        return out
+
+    def evalPolysAtRoots(self, polys, roots):
+        """lib/Stark.ts:109; BoundaryConstraints.ts:87-88."""
+        if polys.colCount > roots.length:
+            raise GstarkError('Number of roots of unity cannot be smaller than number of values')
+        out = Matrix(self.backend, polys.rowCount, roots.length)
+        self.backend.call('gs_eval_polys_at_roots', C.c_void_p(polys.ptr), polys.rowCount, polys.colCount,
+                          _le(self._omega_of(roots)), roots.length, C.c_void_p(out.ptr))
+        return out
+
+    def interpolateRoots(self, roots, ys):
+        """lib/Stark.ts:106; CompositionPolynomial.ts:109 — inverse NTT (Vector or Matrix of rows)."""
+        n = roots.length
+        if isinstance(ys, Matrix):
+            if ys.colCount != n:
+                raise GstarkError('Number of roots of unity must be the same as the number of y coordinates')
+            out = Matrix(self.backend, ys.rowCount, n)
+            rows = ys.rowCount
+        else:
+            if ys.length != n:
+                raise GstarkError('Number of roots of unity must be the same as the number of y coordinates')
+            out, rows = Vector(self.backend, n), 1
+        self.backend.call('gs_interpolate_roots', C.c_void_p(ys.ptr), rows, _le(self._omega_of(roots)), n, C.c_void_p(out.ptr))
+        return out
+
+    def evalPolyAt(self, poly, x):
+        buf = C.create_string_buffer(16)
+        self.backend.call('gs_eval_poly_at', C.c_void_p(poly.ptr), poly.length, _le(x), C.cast(buf, C.c_void_p))
+        return int.from_bytes(buf.raw, 'little')
+
+    def mulPolys(self, a, b):
+        """BoundaryConstraints.ts:30 — product of two tiny polynomials (degree <= #assertions)."""
+        av, bv = a.toValues(), b.toValues()
+        out = [0] * (len(av) + len(bv) - 1)
+        for i, x in enumerate(av):
+            for j, y in enumerate(bv):
+                out[i + j] = (out[i + j] + x * y) % self.modulus
+        return self.newVectorFrom(out)
+
+    def interpolate(self, xs, ys):
+        """BoundaryConstraints.ts:42; LowDegreeProver.ts:243 — Lagrange through a handful of points."""
+        xv, yv = xs.toValues(), ys.toValues()
+        n, p = len(xv), self.modulus
+        out = [0] * n
+        for j in range(n):
+            num, den = [1], 1
+            for m in range(n):
+                if m == j:
+                    continue
+                nxt = [0] * (len(num) + 1)
+                for d, c in enumerate(num):
+                    nxt[d] = (nxt[d] - c * xv[m]) % p
+                    nxt[d + 1] = (nxt[d + 1] + c) % p
+                num = nxt
+                den = den * (xv[j] - xv[m]) % p
+            s = yv[j] * self.inv(den) % p
+            for d in range(n):
+                out[d] = (out[d] + num[d] * s) % p
+        return self.newVectorFrom(out)
+
+    def interpolateQuarticBatch(self, xs, ys):
+        """LowDegreeProver.ts:137,191 — one cubic per row.  When xs is the transposed power-series domain
+        the prover builds (LowDegreeProver.ts:190) the x coordinates are regenerated on the fly."""
+        if xs.rowCount != ys.rowCount or xs.colCount != 4 or ys.colCount != 4:
+            raise GstarkError('X and Y coordinate matrixes must have the same shape with 4 columns')
+        out = Matrix(self.backend, ys.rowCount, 4)
+        if xs.quartic_domain is not None:
+            omega, n, step = xs.quartic_domain
+            self.backend.call('gs_interpolate_quartic_domain', _le(omega), n, step, C.c_void_p(ys.ptr), ys.rowCount,
+                              C.c_void_p(out.ptr))
+        else:
+            self.backend.call('gs_interpolate_quartic_batch', C.c_void_p(xs.ptr), C.c_void_p(ys.ptr), ys.rowCount,
+                              C.c_void_p(out.ptr))
+        return out
+
+    def evalQuarticBatch(self, polys, x):
+        out = Vector(self.backend, polys.rowCount)
+        self.backend.call('gs_eval_quartic_batch', C.c_void_p(polys.ptr), polys.rowCount, _le(x), C.c_void_p(out.ptr))
+        return out
+
+
+def createPrimeField(modulus=MODULUS, backend=None):
+    return PrimeField(modulus, backend)

@@ -1,0 +1,176 @@
+/*
+ * gstark.h — flat C ABI of the MI355X-native prime-field polynomial + Merkle-hash backend
+ * that sits behind genSTARK's prove() pipeline.
+ *
+ * Every entry point replaces one member of the TypeScript surface that genSTARK calls on
+ * `@guildofweavers/galois` (FiniteField / Vector / Matrix), `@guildofweavers/merkle`
+ * (Hash / MerkleTree) and `@guildofweavers/air-assembly` (ProvingContext) — the packages whose
+ * wasm/JS arithmetic this library replaces.  The reference call site (file:line under the genSTARK
+ * checkout) is given next to each function.  An N-API addon (napi/) and the Python host mirror
+ * (genstark_amd/) bind exactly these symbols; nothing else is exported.
+ *
+ * Conventions
+ *  - A field element is 16 bytes, little-endian, canonical (value < p),
+ *    p = 2^128 - 9*2^32 + 1 (the 128-bit field galois accelerates; examples/mimc/mimc128.ts:13).
+ *    This is the byte layout `Vector.copyValue` / `Matrix.rowsToBuffers` hand to the proof
+ *    (lib/Stark.ts:284-296, lib/utils/serialization.ts:131-146).
+ *  - A Vector is n contiguous elements.  A Matrix is rows*cols elements, row-major, contiguous
+ *    (`Matrix.toBuffer()` must be row-contiguous: lib/components/LowDegreeProver.ts:45).
+ *  - A digest is 32 bytes.  A digest Vector is n contiguous digests.
+ *  - `void *` buffer arguments are DEVICE pointers obtained from gs_alloc (or any hipMalloc'd /
+ *    torch-owned device memory); `const uint8_t x[16]`-style arguments and everything documented
+ *    "host" are HOST pointers.
+ *  - All calls are asynchronous on the context's HIP stream and ordered on it; gs_download,
+ *    gs_gather and gs_sync block until the stream is drained.  Like the reference (synchronous,
+ *    single-threaded JS) a context must not be used from two threads at once.
+ *  - Every function returns GS_OK (0) or a negative gs_status; gs_last_error(ctx) describes it.
+ *    There is NO CPU fallback: without a gfx950 device gs_ctx_create fails.
+ */
+#ifndef GSTARK_H
+#define GSTARK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_ABI_VERSION 1
+
+typedef enum gs_status {
+    GS_OK = 0,
+    GS_ERR_ARG = -1,          /* bad argument (size not a power of two, null pointer, ...) */
+    GS_ERR_DEVICE = -2,       /* HIP runtime error / no gfx950 device */
+    GS_ERR_UNSUPPORTED = -3,  /* valid request this build does not implement */
+    GS_ERR_OOM = -4
+} gs_status;
+
+typedef enum gs_hash_alg {    /* createHash(algorithm, useWasm): lib/Stark.ts:19-20,50 */
+    GS_HASH_SHA256 = 0,
+    GS_HASH_BLAKE2S256 = 1
+} gs_hash_alg;
+
+typedef struct gs_ctx gs_ctx;
+
+#define GS_ELEMENT_BYTES 16
+#define GS_DIGEST_BYTES 32
+#define GS_MAX_COMBINE 64     /* max vectors in gs_combine_many / gs_hash_merge_rows */
+
+/* ---- context / memory -------------------------------------------------------------------------
+ * Replaces: the galois wasm linear memory handed over as `wasmOptions.memory`
+ * (lib/Stark.ts:37-40,346-354) and the JS-GC ownership of Vector/Matrix objects. */
+int gs_abi_version(void);
+const char *gs_backend_name(void);                     /* "hip-gfx950" for the product library */
+int gs_ctx_create(int device, void *hip_stream /* NULL: library-owned stream */, gs_ctx **out);
+void gs_ctx_destroy(gs_ctx *ctx);
+const char *gs_last_error(const gs_ctx *ctx);
+int gs_sync(gs_ctx *ctx);
+void *gs_stream(gs_ctx *ctx);                          /* the hipStream_t the kernels run on */
+int gs_field_modulus(uint8_t out_le[16]);              /* FiniteField.modulus */
+
+int gs_alloc(gs_ctx *ctx, uint64_t bytes, void **dptr);
+int gs_free(gs_ctx *ctx, void *dptr);
+int gs_upload(gs_ctx *ctx, void *dst, const void *host_src, uint64_t bytes);   /* newVectorFrom: BoundaryConstraints.ts:24,40 */
+int gs_download(gs_ctx *ctx, void *host_dst, const void *src, uint64_t bytes); /* toValues / toBuffer: CompositionPolynomial.ts:58 */
+int gs_copy(gs_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+/* rowsToBuffers / copyValue / MerkleTree node reads: lib/Stark.ts:290, LowDegreeProver.ts:53,214,217.
+ * Copies `count` records of `rec_bytes` at record indices idx[] (host) from src to host_out. */
+int gs_gather(gs_ctx *ctx, const void *src, uint64_t rec_bytes, const uint64_t *idx_host,
+              uint64_t count, void *host_out);
+
+/* ---- vector arithmetic (FiniteField vector ops) ------------------------------------------------ */
+/* getPowerSeries(base, n): out[i] = base^i.  CompositionPolynomial.ts:94,132; LinearCombination.ts:46;
+ * also how air-assembly builds execution/evaluation/composition domains (lib/Stark.ts:90-91). */
+int gs_power_series(gs_ctx *ctx, const uint8_t base[16], uint64_t n, void *out);
+/* addVectorElements(a, b): CompositionPolynomial.ts:145; LinearCombination.ts:63 */
+int gs_vec_add(gs_ctx *ctx, const void *a, const void *b, uint64_t n, void *out);
+/* subVectorElements(a, b: Vector): ZeroPolynomial.ts:41-42 (Vector form) */
+int gs_vec_sub(gs_ctx *ctx, const void *a, const void *b, uint64_t n, void *out);
+/* mulVectorElements(a, b: Vector): CompositionPolynomial.ts:98,120,136; LinearCombination.ts:50 */
+int gs_vec_mul(gs_ctx *ctx, const void *a, const void *b, uint64_t n, void *out);
+/* scalar forms — (a, b: bigint): ZeroPolynomial.ts:41-42; LinearCombination.ts:75 */
+int gs_vec_add_scalar(gs_ctx *ctx, const void *a, const uint8_t s[16], uint64_t n, void *out);
+int gs_vec_sub_scalar(gs_ctx *ctx, const void *a, const uint8_t s[16], uint64_t n, void *out);
+int gs_vec_mul_scalar(gs_ctx *ctx, const void *a, const uint8_t s[16], uint64_t n, void *out);
+/* invVectorElements: out[i] = a[i]^-1, with 0^-1 := 0 (batch inversion) */
+int gs_vec_inv(gs_ctx *ctx, const void *a, uint64_t n, void *out);
+/* divVectorElements(a, b): out[i] = a[i] * b[i]^-1.  CompositionPolynomial.ts:117;
+ * divMatrixElements (BoundaryConstraints.ts:92) is the same call over rows*cols elements. */
+int gs_vec_div(gs_ctx *ctx, const void *a, const void *b, uint64_t n, void *out);
+/* expVectorElements(a, e): out[i] = a[i]^e (examples/poseidon/utils.ts:34) */
+int gs_vec_exp(gs_ctx *ctx, const void *a, const uint8_t e[16], uint64_t n, void *out);
+/* combineManyVectors(v[], k): out[i] = sum_j v_j[i] * k_j.  vecs_host: host array of `count`
+ * device pointers; coeffs_host: count*16 bytes.  CompositionPolynomial.ts:105,142; LinearCombination.ts:60 */
+int gs_combine_many(gs_ctx *ctx, const void *const *vecs_host, const uint8_t *coeffs_host,
+                    uint32_t count, uint64_t n, void *out);
+/* combineVectors(a, b) -> scalar sum_i a[i]*b[i] (host out).  CompositionPolynomial.ts:168,188 */
+int gs_combine(gs_ctx *ctx, const void *a, const void *b, uint64_t n, uint8_t out_host[16]);
+/* pluckVector(v, skip, times): out[i] = v[(i*skip) mod vlen], i < times.  ZeroPolynomial.ts:40 */
+int gs_pluck(gs_ctx *ctx, const void *v, uint64_t vlen, uint64_t skip, uint64_t times, void *out);
+/* transposeVector(v, cols, step): rows = n/(cols*step); out[r*cols+c] = v[(r + c*rows)*step].
+ * LowDegreeProver.ts:42,162,190,198 */
+int gs_transpose_vector(gs_ctx *ctx, const void *v, uint64_t n, uint32_t cols, uint64_t step, void *out);
+/* transposeMatrix(m): out[c*rows+r] = m[r*cols+c].  LowDegreeProver.ts:181 (joinMatrixRows is a no-op view) */
+int gs_transpose_matrix(gs_ctx *ctx, const void *m, uint64_t rows, uint64_t cols, void *out);
+/* subMatrixElementsFromVectors(vectors[], m): out[r][i] = v_r[i] - m[r][i].  BoundaryConstraints.ts:91 */
+int gs_sub_matrix_from_vectors(gs_ctx *ctx, const void *const *vecs_host, const void *m,
+                               uint32_t rows, uint64_t cols, void *out);
+
+/* ---- polynomial ops ---------------------------------------------------------------------------- */
+/* evalPolysAtRoots(polys: Matrix, roots) / evalPolyAtRoots(poly, roots): forward NTT of each of
+ * `rows` polynomials with `poly_len` (<= n) coefficients, zero-extended, at the n-th roots
+ * {omega^i}; out is rows*n, natural order (out[r][i] = p_r(omega^i)).
+ * lib/Stark.ts:109; CompositionPolynomial.ts:110; BoundaryConstraints.ts:87-88 */
+int gs_eval_polys_at_roots(gs_ctx *ctx, const void *polys, uint32_t rows, uint64_t poly_len,
+                           const uint8_t omega[16], uint64_t n, void *out);
+/* interpolateRoots(roots, ys: Vector|Matrix): inverse NTT of each row; out[r] = coefficients of the
+ * unique deg<n polynomial with p(omega^i) = ys[r][i].  lib/Stark.ts:106; CompositionPolynomial.ts:109 */
+int gs_interpolate_roots(gs_ctx *ctx, const void *ys, uint32_t rows, const uint8_t omega[16],
+                         uint64_t n, void *out);
+/* evalPolyAt(poly, x) -> scalar.  BoundaryConstraints.ts:59-60; LowDegreeProver.ts:248 */
+int gs_eval_poly_at(gs_ctx *ctx, const void *poly, uint64_t len, const uint8_t x[16], uint8_t out_host[16]);
+/* interpolateQuarticBatch(xs, ys): per row, the cubic through (xs[r][c], ys[r][c]), c<4; out rows*4
+ * coefficients (ascending).  LowDegreeProver.ts:137,191 */
+int gs_interpolate_quartic_batch(gs_ctx *ctx, const void *xs, const void *ys, uint64_t rows, void *out);
+/* Same result as gs_interpolate_quartic_batch when xs = transposeVector(powerSeries(omega, n), 4, step)
+ * (the only shape the prover builds: LowDegreeProver.ts:190-191): xs[r][c] = omega^((r + c*rows)*step),
+ * rows*4*step == n.  xs is never materialised. */
+int gs_interpolate_quartic_domain(gs_ctx *ctx, const uint8_t omega[16], uint64_t n, uint64_t step,
+                                  const void *ys, uint64_t rows, void *out);
+/* evalQuarticBatch(polys, x) -> Vector of rows values.  LowDegreeProver.ts:140,195 */
+int gs_eval_quartic_batch(gs_ctx *ctx, const void *polys, uint64_t rows, const uint8_t x[16], void *out);
+
+/* ---- hashing / Merkle (merkle package) --------------------------------------------------------- */
+/* Hash.digest(Buffer) on host bytes (verifier side; lib/utils/index.ts:37) — runs on the device
+ * like every other hash so that prover and verifier share one implementation. */
+int gs_hash_digest(gs_ctx *ctx, gs_hash_alg alg, const uint8_t *msg_host, uint64_t len, uint8_t out_host[32]);
+/* Hash.mergeVectorRows(vectors): out[i] = H(v_0[i] || ... || v_{k-1}[i]).  lib/Stark.ts:115 */
+int gs_hash_merge_rows(gs_ctx *ctx, gs_hash_alg alg, const void *const *vecs_host, uint32_t count,
+                       uint64_t n, void *out_digests);
+/* Hash.digestValues(buf, valueSize): out[i] = H(buf[i*valueSize .. (i+1)*valueSize)).
+ * LowDegreeProver.ts:45,163,201 */
+int gs_hash_digest_values(gs_ctx *ctx, gs_hash_alg alg, const void *buf, uint64_t value_size,
+                          uint64_t count, void *out_digests);
+/* MerkleTree.create(leaves, hash): nodes is n digests in heap order — nodes[1] is the root,
+ * nodes[i] = H(nodes[2i] || nodes[2i+1]) for i < n/2, nodes[n/2 + i] = H(leaf[2i] || leaf[2i+1]);
+ * nodes[0] is zero.  n must be a power of two >= 2.  lib/Stark.ts:118; LowDegreeProver.ts:46,164,202.
+ * (.root / .proveBatch read nodes through gs_gather.) */
+int gs_merkle_build(gs_ctx *ctx, gs_hash_alg alg, const void *leaves, uint64_t n, void *nodes);
+
+/* ---- AIR (air-assembly ProvingContext, MiMC instance) ------------------------------------------ */
+/* context.generateExecutionTrace() for the MiMC AIR of examples/mimc/mimc128Assembly.ts:28-51:
+ * trace[0] = seed, trace[i+1] = trace[i]^3 + rc[i mod nrc] (examples/mimc/utils.ts:7-15).
+ * Inherently sequential: computed on the host CPU, then copied to `out` (steps elements). */
+int gs_mimc_trace(gs_ctx *ctx, const uint8_t seed[16], const uint8_t *rc_host, uint32_t nrc,
+                  uint64_t steps, void *out);
+/* context.evaluateTransitionConstraints(pPolys) body for that AIR over the composition domain
+ * (CompositionPolynomial.ts:76): q[j] = p[(j + shift) mod nc] - (p[j]^3 + k[j mod klen]),
+ * p = P on the composition domain, shift = nc/steps, k = cyclic static register values. */
+int gs_mimc_constraints(gs_ctx *ctx, const void *p_comp, uint64_t nc, uint64_t shift,
+                        const void *k_table, uint64_t klen, void *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSTARK_H */

@@ -1,0 +1,322 @@
+/*
+ * oracle/oracle_abi.c — TEST INFRASTRUCTURE (CPU oracle).
+ *
+ * A host-memory restatement of every entry point of include/gstark.h, used only as the checker:
+ * tests/ run the same call through the HIP library and through this file and compare bytes, and
+ * the "not gpu" tests run the Python host mirror on top of it.  The product never loads it
+ * (genstark_amd/_abi.py refuses any backend whose gs_backend_name() is not "hip-gfx950" unless a
+ * test injects it).  "Device pointers" here are plain malloc'd host pointers.
+ *
+ * Each function follows the mathematical definition of the galois/merkle member named in
+ * gstark.h (the packages themselves are absent from /root/reference), using
+ * the simplest algorithm available (radix-2 NTT, serial Montgomery-trick inversion, one hash at a
+ * time) so that it shares no structure with the HIP kernels it checks.
+ *
+ * parity unpinned (see gf128.h).
+ */
+#include "../include/gstark.h"
+#include "gf128.h"
+#include "hashes.h"
+#include <stdio.h>
+#include <stdlib.h>
+
+struct gs_ctx {
+    char err[256];
+};
+
+static int fail(gs_ctx *c, int code, const char *msg) {
+    if (c) snprintf(c->err, sizeof c->err, "%s", msg);
+    return code;
+}
+static int is_pow2(uint64_t x) { return x && !(x & (x - 1)); }
+
+int gs_abi_version(void) { return GS_ABI_VERSION; }
+const char *gs_backend_name(void) { return "oracle-cpu"; }
+int gs_ctx_create(int device, void *stream, gs_ctx **out) {
+    (void)device; (void)stream;
+    gs_ctx *c = (gs_ctx *)calloc(1, sizeof *c);
+    if (!c) return GS_ERR_OOM;
+    *out = c;
+    return GS_OK;
+}
+void gs_ctx_destroy(gs_ctx *c) { free(c); }
+const char *gs_last_error(const gs_ctx *c) { return c ? c->err : "null context"; }
+int gs_sync(gs_ctx *c) { (void)c; return GS_OK; }
+void *gs_stream(gs_ctx *c) { (void)c; return NULL; }
+int gs_field_modulus(uint8_t out[16]) { fe_store(out, fe_p()); return GS_OK; }
+
+int gs_alloc(gs_ctx *c, uint64_t bytes, void **p) {
+    *p = malloc(bytes ? bytes : 1);
+    return *p ? GS_OK : fail(c, GS_ERR_OOM, "malloc failed");
+}
+int gs_free(gs_ctx *c, void *p) { (void)c; free(p); return GS_OK; }
+int gs_upload(gs_ctx *c, void *d, const void *s, uint64_t n) { (void)c; memcpy(d, s, n); return GS_OK; }
+int gs_download(gs_ctx *c, void *d, const void *s, uint64_t n) { (void)c; memcpy(d, s, n); return GS_OK; }
+int gs_copy(gs_ctx *c, void *d, const void *s, uint64_t n) { (void)c; memmove(d, s, n); return GS_OK; }
+int gs_gather(gs_ctx *c, const void *src, uint64_t rec, const uint64_t *idx, uint64_t count, void *out) {
+    (void)c;
+    for (uint64_t i = 0; i < count; i++) memcpy((uint8_t *)out + i * rec, (const uint8_t *)src + idx[i] * rec, rec);
+    return GS_OK;
+}
+
+#define EL(p, i) fe_load((const uint8_t *)(p) + 16 * (uint64_t)(i))
+#define ST(p, i, v) fe_store((uint8_t *)(p) + 16 * (uint64_t)(i), (v))
+
+int gs_power_series(gs_ctx *c, const uint8_t base[16], uint64_t n, void *out) {
+    (void)c;
+    fe b = fe_load(base), x = 1;
+    for (uint64_t i = 0; i < n; i++) { ST(out, i, x); x = fe_mul(x, b); }
+    return GS_OK;
+}
+int gs_vec_add(gs_ctx *c, const void *a, const void *b, uint64_t n, void *o) {
+    (void)c; for (uint64_t i = 0; i < n; i++) ST(o, i, fe_add(EL(a, i), EL(b, i))); return GS_OK;
+}
+int gs_vec_sub(gs_ctx *c, const void *a, const void *b, uint64_t n, void *o) {
+    (void)c; for (uint64_t i = 0; i < n; i++) ST(o, i, fe_sub(EL(a, i), EL(b, i))); return GS_OK;
+}
+int gs_vec_mul(gs_ctx *c, const void *a, const void *b, uint64_t n, void *o) {
+    (void)c; for (uint64_t i = 0; i < n; i++) ST(o, i, fe_mul(EL(a, i), EL(b, i))); return GS_OK;
+}
+int gs_vec_add_scalar(gs_ctx *c, const void *a, const uint8_t s[16], uint64_t n, void *o) {
+    (void)c; fe k = fe_load(s); for (uint64_t i = 0; i < n; i++) ST(o, i, fe_add(EL(a, i), k)); return GS_OK;
+}
+int gs_vec_sub_scalar(gs_ctx *c, const void *a, const uint8_t s[16], uint64_t n, void *o) {
+    (void)c; fe k = fe_load(s); for (uint64_t i = 0; i < n; i++) ST(o, i, fe_sub(EL(a, i), k)); return GS_OK;
+}
+int gs_vec_mul_scalar(gs_ctx *c, const void *a, const uint8_t s[16], uint64_t n, void *o) {
+    (void)c; fe k = fe_load(s); for (uint64_t i = 0; i < n; i++) ST(o, i, fe_mul(EL(a, i), k)); return GS_OK;
+}
+
+/* serial Montgomery-trick inversion, zeros map to zero */
+static int batch_inv(const void *a, uint64_t n, fe *out) {
+    fe acc = 1;
+    for (uint64_t i = 0; i < n; i++) {
+        out[i] = acc;
+        fe v = EL(a, i);
+        if (v) acc = fe_mul(acc, v);
+    }
+    fe inv = fe_inv(acc);
+    for (uint64_t i = n; i-- > 0;) {
+        fe v = EL(a, i);
+        if (v) {
+            fe r = fe_mul(out[i], inv);
+            inv = fe_mul(inv, v);
+            out[i] = r;
+        } else out[i] = 0;
+    }
+    return 0;
+}
+int gs_vec_inv(gs_ctx *c, const void *a, uint64_t n, void *o) {
+    fe *t = (fe *)malloc((n ? n : 1) * sizeof(fe));
+    if (!t) return fail(c, GS_ERR_OOM, "malloc failed");
+    batch_inv(a, n, t);
+    for (uint64_t i = 0; i < n; i++) ST(o, i, t[i]);
+    free(t);
+    return GS_OK;
+}
+int gs_vec_div(gs_ctx *c, const void *a, const void *b, uint64_t n, void *o) {
+    fe *t = (fe *)malloc((n ? n : 1) * sizeof(fe));
+    if (!t) return fail(c, GS_ERR_OOM, "malloc failed");
+    batch_inv(b, n, t);
+    for (uint64_t i = 0; i < n; i++) ST(o, i, fe_mul(EL(a, i), t[i]));
+    free(t);
+    return GS_OK;
+}
+int gs_vec_exp(gs_ctx *c, const void *a, const uint8_t e[16], uint64_t n, void *o) {
+    (void)c; u128 ee = fe_load(e);
+    for (uint64_t i = 0; i < n; i++) ST(o, i, fe_exp(EL(a, i), ee));
+    return GS_OK;
+}
+int gs_combine_many(gs_ctx *c, const void *const *vecs, const uint8_t *coeffs, uint32_t count, uint64_t n, void *o) {
+    if (count == 0 || count > GS_MAX_COMBINE) return fail(c, GS_ERR_ARG, "combine_many: bad count");
+    for (uint64_t i = 0; i < n; i++) {
+        fe s = 0;
+        for (uint32_t j = 0; j < count; j++) s = fe_add(s, fe_mul(EL(vecs[j], i), fe_load(coeffs + 16 * j)));
+        ST(o, i, s);
+    }
+    return GS_OK;
+}
+int gs_combine(gs_ctx *c, const void *a, const void *b, uint64_t n, uint8_t out[16]) {
+    (void)c; fe s = 0;
+    for (uint64_t i = 0; i < n; i++) s = fe_add(s, fe_mul(EL(a, i), EL(b, i)));
+    fe_store(out, s);
+    return GS_OK;
+}
+int gs_pluck(gs_ctx *c, const void *v, uint64_t vlen, uint64_t skip, uint64_t times, void *o) {
+    if (!vlen) return fail(c, GS_ERR_ARG, "pluck: empty vector");
+    for (uint64_t i = 0; i < times; i++) ST(o, i, EL(v, (i * skip) % vlen));
+    return GS_OK;
+}
+int gs_transpose_vector(gs_ctx *c, const void *v, uint64_t n, uint32_t cols, uint64_t step, void *o) {
+    if (!cols || !step || n % ((uint64_t)cols * step)) return fail(c, GS_ERR_ARG, "transpose_vector: n %% (cols*step) != 0");
+    uint64_t rows = n / ((uint64_t)cols * step);
+    for (uint64_t r = 0; r < rows; r++)
+        for (uint32_t k = 0; k < cols; k++) ST(o, r * cols + k, EL(v, (r + (uint64_t)k * rows) * step));
+    return GS_OK;
+}
+int gs_transpose_matrix(gs_ctx *c, const void *m, uint64_t rows, uint64_t cols, void *o) {
+    (void)c;
+    for (uint64_t r = 0; r < rows; r++)
+        for (uint64_t k = 0; k < cols; k++) ST(o, k * rows + r, EL(m, r * cols + k));
+    return GS_OK;
+}
+int gs_sub_matrix_from_vectors(gs_ctx *c, const void *const *vecs, const void *m, uint32_t rows, uint64_t cols, void *o) {
+    (void)c;
+    for (uint32_t r = 0; r < rows; r++)
+        for (uint64_t i = 0; i < cols; i++) ST(o, (uint64_t)r * cols + i, fe_sub(EL(vecs[r], i), EL(m, (uint64_t)r * cols + i)));
+    return GS_OK;
+}
+
+/* in-place iterative radix-2 decimation-in-time NTT over natural-order input */
+static void ntt_inplace(fe *a, uint64_t n, fe omega) {
+    for (uint64_t i = 1, j = 0; i < n; i++) { /* bit reversal */
+        uint64_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { fe t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+    for (uint64_t len = 2; len <= n; len <<= 1) {
+        fe wl = fe_exp(omega, n / len);
+        for (uint64_t i = 0; i < n; i += len) {
+            fe w = 1;
+            for (uint64_t j = 0; j < len / 2; j++) {
+                fe u = a[i + j], v = fe_mul(a[i + j + len / 2], w);
+                a[i + j] = fe_add(u, v);
+                a[i + j + len / 2] = fe_sub(u, v);
+                w = fe_mul(w, wl);
+            }
+        }
+    }
+}
+int gs_eval_polys_at_roots(gs_ctx *c, const void *polys, uint32_t rows, uint64_t plen, const uint8_t omega[16],
+                           uint64_t n, void *out) {
+    if (!is_pow2(n) || plen > n) return fail(c, GS_ERR_ARG, "eval_polys_at_roots: n must be a power of two >= poly_len");
+    fe *t = (fe *)malloc(n * sizeof(fe));
+    if (!t) return fail(c, GS_ERR_OOM, "malloc failed");
+    fe w = fe_load(omega);
+    for (uint32_t r = 0; r < rows; r++) {
+        for (uint64_t i = 0; i < n; i++) t[i] = i < plen ? EL(polys, (uint64_t)r * plen + i) : 0;
+        ntt_inplace(t, n, w);
+        for (uint64_t i = 0; i < n; i++) ST(out, (uint64_t)r * n + i, t[i]);
+    }
+    free(t);
+    return GS_OK;
+}
+int gs_interpolate_roots(gs_ctx *c, const void *ys, uint32_t rows, const uint8_t omega[16], uint64_t n, void *out) {
+    if (!is_pow2(n)) return fail(c, GS_ERR_ARG, "interpolate_roots: n must be a power of two");
+    fe *t = (fe *)malloc(n * sizeof(fe));
+    if (!t) return fail(c, GS_ERR_OOM, "malloc failed");
+    fe winv = fe_inv(fe_load(omega)), ninv = fe_inv((fe)n);
+    for (uint32_t r = 0; r < rows; r++) {
+        for (uint64_t i = 0; i < n; i++) t[i] = EL(ys, (uint64_t)r * n + i);
+        ntt_inplace(t, n, winv);
+        for (uint64_t i = 0; i < n; i++) ST(out, (uint64_t)r * n + i, fe_mul(t[i], ninv));
+    }
+    free(t);
+    return GS_OK;
+}
+int gs_eval_poly_at(gs_ctx *c, const void *poly, uint64_t len, const uint8_t x[16], uint8_t out[16]) {
+    (void)c; fe xx = fe_load(x), s = 0;
+    for (uint64_t i = len; i-- > 0;) s = fe_add(fe_mul(s, xx), EL(poly, i));
+    fe_store(out, s);
+    return GS_OK;
+}
+
+/* cubic through 4 points by Lagrange basis expansion */
+static void lagrange4(const fe x[4], const fe y[4], fe cof[4]) {
+    cof[0] = cof[1] = cof[2] = cof[3] = 0;
+    for (int j = 0; j < 4; j++) {
+        fe num[4] = {1, 0, 0, 0}; /* prod_{m != j} (X - x_m), ascending coefficients */
+        int deg = 0;
+        fe den = 1;
+        for (int m = 0; m < 4; m++) {
+            if (m == j) continue;
+            fe nx = fe_neg(x[m]), nw[4] = {0, 0, 0, 0};
+            for (int d = 0; d <= deg; d++) { /* num *= (X - x_m) */
+                nw[d] = fe_add(nw[d], fe_mul(num[d], nx));
+                nw[d + 1] = fe_add(nw[d + 1], num[d]);
+            }
+            deg++;
+            for (int d = 0; d <= deg; d++) num[d] = nw[d];
+            den = fe_mul(den, fe_sub(x[j], x[m]));
+        }
+        fe s = fe_mul(y[j], fe_inv(den));
+        for (int d = 0; d < 4; d++) cof[d] = fe_add(cof[d], fe_mul(num[d], s));
+    }
+}
+int gs_interpolate_quartic_batch(gs_ctx *c, const void *xs, const void *ys, uint64_t rows, void *out) {
+    (void)c;
+    for (uint64_t r = 0; r < rows; r++) {
+        fe x[4], y[4], k[4];
+        for (int j = 0; j < 4; j++) { x[j] = EL(xs, r * 4 + j); y[j] = EL(ys, r * 4 + j); }
+        lagrange4(x, y, k);
+        for (int j = 0; j < 4; j++) ST(out, r * 4 + j, k[j]);
+    }
+    return GS_OK;
+}
+int gs_interpolate_quartic_domain(gs_ctx *c, const uint8_t omega[16], uint64_t n, uint64_t step, const void *ys,
+                                  uint64_t rows, void *out) {
+    if (rows * 4 * step != n) return fail(c, GS_ERR_ARG, "interpolate_quartic_domain: rows*4*step != n");
+    fe w = fe_load(omega);
+    for (uint64_t r = 0; r < rows; r++) {
+        fe x[4], y[4], k[4];
+        for (int j = 0; j < 4; j++) { x[j] = fe_exp(w, (u128)((r + (uint64_t)j * rows) * step)); y[j] = EL(ys, r * 4 + j); }
+        lagrange4(x, y, k);
+        for (int j = 0; j < 4; j++) ST(out, r * 4 + j, k[j]);
+    }
+    return GS_OK;
+}
+int gs_eval_quartic_batch(gs_ctx *c, const void *polys, uint64_t rows, const uint8_t x[16], void *out) {
+    (void)c; fe xx = fe_load(x);
+    for (uint64_t r = 0; r < rows; r++) {
+        fe s = EL(polys, r * 4 + 3);
+        for (int j = 2; j >= 0; j--) s = fe_add(fe_mul(s, xx), EL(polys, r * 4 + j));
+        ST(out, r, s);
+    }
+    return GS_OK;
+}
+
+int gs_hash_digest(gs_ctx *c, gs_hash_alg alg, const uint8_t *msg, uint64_t len, uint8_t out[32]) {
+    (void)c; orc_hash((int)alg, msg, (size_t)len, out); return GS_OK;
+}
+int gs_hash_merge_rows(gs_ctx *c, gs_hash_alg alg, const void *const *vecs, uint32_t count, uint64_t n, void *out) {
+    if (count == 0 || count > GS_MAX_COMBINE) return fail(c, GS_ERR_ARG, "hash_merge_rows: bad count");
+    uint8_t buf[16 * GS_MAX_COMBINE];
+    for (uint64_t i = 0; i < n; i++) {
+        for (uint32_t j = 0; j < count; j++) memcpy(buf + 16 * j, (const uint8_t *)vecs[j] + 16 * i, 16);
+        orc_hash((int)alg, buf, 16 * (size_t)count, (uint8_t *)out + 32 * i);
+    }
+    return GS_OK;
+}
+int gs_hash_digest_values(gs_ctx *c, gs_hash_alg alg, const void *buf, uint64_t vs, uint64_t count, void *out) {
+    (void)c;
+    for (uint64_t i = 0; i < count; i++) orc_hash((int)alg, (const uint8_t *)buf + vs * i, (size_t)vs, (uint8_t *)out + 32 * i);
+    return GS_OK;
+}
+int gs_merkle_build(gs_ctx *c, gs_hash_alg alg, const void *leaves, uint64_t n, void *nodes) {
+    if (!is_pow2(n) || n < 2) return fail(c, GS_ERR_ARG, "merkle_build: n must be a power of two >= 2");
+    uint8_t *nd = (uint8_t *)nodes;
+    memset(nd, 0, 32);
+    for (uint64_t i = 0; i < n / 2; i++) orc_hash((int)alg, (const uint8_t *)leaves + 64 * i, 64, nd + 32 * (n / 2 + i));
+    for (uint64_t i = n / 2; i-- > 1;) orc_hash((int)alg, nd + 64 * i, 64, nd + 32 * i);
+    return GS_OK;
+}
+
+int gs_mimc_trace(gs_ctx *c, const uint8_t seed[16], const uint8_t *rc, uint32_t nrc, uint64_t steps, void *out) {
+    if (!nrc || !steps) return fail(c, GS_ERR_ARG, "mimc_trace: empty");
+    fe x = fe_load(seed);
+    for (uint64_t i = 0; i < steps; i++) {
+        ST(out, i, x);
+        x = fe_add(fe_mul(fe_mul(x, x), x), fe_load(rc + 16 * (i % nrc)));
+    }
+    return GS_OK;
+}
+int gs_mimc_constraints(gs_ctx *c, const void *p, uint64_t nc, uint64_t shift, const void *k, uint64_t klen, void *out) {
+    if (!klen || !nc) return fail(c, GS_ERR_ARG, "mimc_constraints: empty");
+    for (uint64_t j = 0; j < nc; j++) {
+        fe x = EL(p, j), nx = EL(p, (j + shift) % nc);
+        fe t = fe_add(fe_mul(fe_mul(x, x), x), EL(k, j % klen));
+        ST(out, j, fe_sub(nx, t));
+    }
+    return GS_OK;
+}
