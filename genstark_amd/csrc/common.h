@@ -1,0 +1,68 @@
+// common.h — context, error handling and launch helpers shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gstark.h"
+#include "gf128.cuh"
+
+struct NttPlan;  // ntt.hip
+
+struct gs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    char err[512] = {0};
+    // size-bucketed cache of device blocks: gs_free parks a block here instead of hipFree (which would
+    // synchronise the device); every consumer is ordered on `stream`, so immediate reuse is safe.
+    std::multimap<uint64_t, void *> free_blocks;
+    std::map<void *, uint64_t> live_blocks;
+    uint64_t cached_bytes = 0;
+    // twiddle tables per (omega, n)
+    std::map<std::string, NttPlan *> plans;
+    // pinned host staging + small device scratch for scalars / index lists / pointer tables
+    void *h_stage = nullptr;
+    void *d_stage = nullptr;
+    uint64_t stage_bytes = 0;
+};
+
+int gs_fail(gs_ctx *c, int code, const char *fmt, ...);
+
+#define GS_HIP(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return gs_fail((c), GS_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+#define GS_LAUNCH_CHECK(c) GS_HIP(c, hipGetLastError())
+
+static inline bool gs_is_pow2(uint64_t x) { return x && !(x & (x - 1)); }
+static inline int gs_log2(uint64_t x) { int l = 0; while ((1ull << l) < x) l++; return l; }
+
+static inline fe fe_from_bytes(const uint8_t *b) { fe r; memcpy(&r, b, 16); return r; }
+static inline void fe_to_bytes(uint8_t *b, const fe &v) { memcpy(b, &v, 16); }
+static inline fe fe_from_u64(uint64_t v) { return fe_make((uint32_t)v, (uint32_t)(v >> 32), 0, 0); }
+
+// staging helpers (ctx.hip)
+int gs_stage_reserve(gs_ctx *c, uint64_t bytes);
+// temp device block from the cache (same lifetime rules as gs_alloc/gs_free)
+int gs_tmp_alloc(gs_ctx *c, uint64_t bytes, void **p);
+void gs_tmp_free(gs_ctx *c, void *p);
+
+// grid sizing for streaming kernels: enough 256-thread blocks to fill 256 CUs x 8, grid-stride the rest
+static inline unsigned gs_grid(uint64_t work_items, unsigned block = 256, unsigned cap = 256 * 8) {
+    uint64_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+// NTT entry points implemented in ntt.hip and used by other units
+void gs_plans_destroy(gs_ctx *c);
+int gs_plan_pow_tables(gs_ctx *c, const fe &omega, uint64_t n, const fe **tw_lo, const fe **tw_hi, int *log_lo);

@@ -1,0 +1,200 @@
+// ctx.hip — context, device memory cache, host<->device copies, gather.  C ABI: include/gstark.h.
+#include <stdarg.h>
+
+#include "common.h"
+
+int gs_fail(gs_ctx *c, int code, const char *fmt, ...) {
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof c->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+extern "C" {
+
+int gs_abi_version(void) { return GS_ABI_VERSION; }
+const char *gs_backend_name(void) { return "hip-gfx950"; }
+
+int gs_field_modulus(uint8_t out_le[16]) {
+    fe p = fe_make(GF_P0, GF_P1, GF_P2, GF_P3);
+    memcpy(out_le, &p, 16);
+    return GS_OK;
+}
+
+int gs_ctx_create(int device, void *hip_stream, gs_ctx **out) {
+    if (!out) return GS_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return GS_ERR_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return GS_ERR_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return GS_ERR_DEVICE;  // kernels are built for gfx950 only
+    if (hipSetDevice(device) != hipSuccess) return GS_ERR_DEVICE;
+    gs_ctx *c = new gs_ctx();
+    c->device = device;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GS_ERR_DEVICE; }
+        c->own_stream = true;
+    }
+    *out = c;
+    return GS_OK;
+}
+
+void gs_ctx_destroy(gs_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    gs_plans_destroy(c);
+    for (auto &kv : c->free_blocks) hipFree(kv.second);
+    for (auto &kv : c->live_blocks) hipFree(kv.first);
+    if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->d_stage) hipFree(c->d_stage);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *gs_last_error(const gs_ctx *c) { return c ? c->err : "null context"; }
+void *gs_stream(gs_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int gs_sync(gs_ctx *c) {
+    if (!c) return GS_ERR_ARG;
+    GS_HIP(c, hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+static uint64_t round_block(uint64_t bytes) {
+    if (bytes < 256) return 256;
+    return (bytes + 255) & ~(uint64_t)255;
+}
+
+int gs_alloc(gs_ctx *c, uint64_t bytes, void **dptr) {
+    if (!c || !dptr) return GS_ERR_ARG;
+    uint64_t sz = round_block(bytes);
+    auto it = c->free_blocks.find(sz);
+    void *p = nullptr;
+    if (it != c->free_blocks.end()) {
+        p = it->second;
+        c->free_blocks.erase(it);
+        c->cached_bytes -= sz;
+    } else {
+        GS_HIP(c, hipSetDevice(c->device));
+        hipError_t e = hipMalloc(&p, sz);
+        if (e != hipSuccess) {
+            // release the cache and retry once
+            hipStreamSynchronize(c->stream);
+            for (auto &kv : c->free_blocks) hipFree(kv.second);
+            c->free_blocks.clear();
+            c->cached_bytes = 0;
+            e = hipMalloc(&p, sz);
+            if (e != hipSuccess) return gs_fail(c, GS_ERR_OOM, "hipMalloc(%llu): %s", (unsigned long long)sz, hipGetErrorString(e));
+        }
+    }
+    c->live_blocks[p] = sz;
+    *dptr = p;
+    return GS_OK;
+}
+
+int gs_free(gs_ctx *c, void *dptr) {
+    if (!c) return GS_ERR_ARG;
+    if (!dptr) return GS_OK;
+    auto it = c->live_blocks.find(dptr);
+    if (it == c->live_blocks.end()) return gs_fail(c, GS_ERR_ARG, "gs_free: pointer was not allocated by gs_alloc");
+    c->free_blocks.insert({it->second, dptr});
+    c->cached_bytes += it->second;
+    c->live_blocks.erase(it);
+    return GS_OK;
+}
+
+int gs_upload(gs_ctx *c, void *dst, const void *host_src, uint64_t bytes) {
+    if (!c || (!dst && bytes) || (!host_src && bytes)) return GS_ERR_ARG;
+    if (!bytes) return GS_OK;
+    // pageable source: the runtime stages the copy; synchronise so the caller may reuse host_src at once
+    GS_HIP(c, hipMemcpyAsync(dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
+    GS_HIP(c, hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+int gs_download(gs_ctx *c, void *host_dst, const void *src, uint64_t bytes) {
+    if (!c || (!host_dst && bytes) || (!src && bytes)) return GS_ERR_ARG;
+    if (!bytes) return GS_OK;
+    GS_HIP(c, hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP(c, hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+int gs_copy(gs_ctx *c, void *dst, const void *src, uint64_t bytes) {
+    if (!c || (!dst && bytes) || (!src && bytes)) return GS_ERR_ARG;
+    if (!bytes) return GS_OK;
+    GS_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return GS_OK;
+}
+
+}  // extern "C"
+
+int gs_stage_reserve(gs_ctx *c, uint64_t bytes) {
+    if (bytes <= c->stage_bytes) return GS_OK;
+    uint64_t nb = 1 << 16;
+    while (nb < bytes) nb <<= 1;
+    GS_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->d_stage) hipFree(c->d_stage);
+    c->h_stage = c->d_stage = nullptr;
+    c->stage_bytes = 0;
+    GS_HIP(c, hipHostMalloc(&c->h_stage, nb, hipHostMallocDefault));
+    GS_HIP(c, hipMalloc(&c->d_stage, nb));
+    c->stage_bytes = nb;
+    return GS_OK;
+}
+
+int gs_tmp_alloc(gs_ctx *c, uint64_t bytes, void **p) { return gs_alloc(c, bytes, p); }
+void gs_tmp_free(gs_ctx *c, void *p) { gs_free(c, p); }
+
+// out[i] = src[idx[i]] for records of rec16*16 bytes (rec_bytes is a multiple of 16 on every call site;
+// other sizes take the byte path)
+__global__ void k_gather16(const uint4 *__restrict__ src, const uint64_t *__restrict__ idx, uint64_t count, uint32_t rec16,
+                           uint4 *__restrict__ out) {
+    uint64_t total = count * rec16;
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t r = t / rec16, o = t % rec16;
+        out[t] = src[idx[r] * rec16 + o];
+    }
+}
+__global__ void k_gather_bytes(const uint8_t *__restrict__ src, const uint64_t *__restrict__ idx, uint64_t count, uint64_t rec,
+                               uint8_t *__restrict__ out) {
+    uint64_t total = count * rec;
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t r = t / rec, o = t % rec;
+        out[t] = src[idx[r] * rec + o];
+    }
+}
+
+extern "C" int gs_gather(gs_ctx *c, const void *src, uint64_t rec_bytes, const uint64_t *idx_host, uint64_t count,
+                         void *host_out) {
+    if (!c || !src || !rec_bytes || (!idx_host && count) || (!host_out && count)) return GS_ERR_ARG;
+    if (!count) return GS_OK;
+    uint64_t idx_bytes = (count * 8 + 255) & ~(uint64_t)255, data_bytes = count * rec_bytes;
+    int rc = gs_stage_reserve(c, idx_bytes + data_bytes);
+    if (rc) return rc;
+    memcpy(c->h_stage, idx_host, count * 8);
+    GS_HIP(c, hipMemcpyAsync(c->d_stage, c->h_stage, count * 8, hipMemcpyHostToDevice, c->stream));
+    uint8_t *d_out = (uint8_t *)c->d_stage + idx_bytes;
+    if (rec_bytes % 16 == 0 && ((uintptr_t)src % 16) == 0) {
+        uint32_t rec16 = (uint32_t)(rec_bytes / 16);
+        hipLaunchKernelGGL(k_gather16, dim3(gs_grid(count * rec16)), dim3(256), 0, c->stream, (const uint4 *)src,
+                           (const uint64_t *)c->d_stage, count, rec16, (uint4 *)d_out);
+    } else {
+        hipLaunchKernelGGL(k_gather_bytes, dim3(gs_grid(data_bytes)), dim3(256), 0, c->stream, (const uint8_t *)src,
+                           (const uint64_t *)c->d_stage, count, rec_bytes, d_out);
+    }
+    GS_LAUNCH_CHECK(c);
+    uint8_t *h_out = (uint8_t *)c->h_stage + idx_bytes;
+    GS_HIP(c, hipMemcpyAsync(h_out, d_out, data_bytes, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP(c, hipStreamSynchronize(c->stream));
+    memcpy(host_out, h_out, data_bytes);
+    return GS_OK;
+}

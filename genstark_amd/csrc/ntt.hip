@@ -1,0 +1,373 @@
+// ntt.hip — forward / inverse number-theoretic transform over GF(p) for gfx950.
+//
+// Replaces FiniteField.evalPolyAtRoots / evalPolysAtRoots / interpolateRoots of @guildofweavers/galois
+// (call sites: lib/Stark.ts:106,109; lib/components/CompositionPolynomial.ts:109-110;
+// lib/components/BoundaryConstraints.ts:87-88).  Natural order in, natural order out.
+//
+// Structure (designed for CDNA4, not translated from anything):
+//   * Stockham autosort decomposition n = R_0 * R_1 * ... with 2..3 HBM passes for n up to 2^24
+//     (radix R_i = 2^L_i, 16 <= R_i <= 256).  Every pass reads and writes each element once with
+//     128-bit (dwordx4) accesses in >= 256-byte contiguous segments.
+//   * Inside a pass a 256-thread workgroup owns a tile of R x Wj elements (R*Wj = 4096 = 64 KiB).
+//     Each thread keeps 16 elements (64 VGPRs) in registers and runs a fully unrolled radix-16
+//     butterfly network on them (stage A), the tile is exchanged once through LDS (conflict-free:
+//     consecutive lanes touch consecutive 16-byte slots), and a radix-RB network (RB = R/16) finishes
+//     the pass (stage B).  8 butterfly levels per HBM round trip, one LDS round trip.
+//   * Twiddles are never read from a domain vector: inter-pass twiddles come from a two-level
+//     power table of omega (2 x <= 4096 entries, L2 resident) + a running product, the in-register
+//     radix-16 twiddles sit in SGPRs (kernel arguments).
+//   * Zero-extension (low-degree extension of a T-coefficient polynomial to n points) is folded
+//     into the first pass: out-of-range loads are predicated off, nothing is padded in memory.
+//   * The inverse transform is the same kernel on omega^-1 with the 1/n scale fused into the last
+//     pass's stores.
+#include "common.h"
+
+struct NttPlan {
+    fe omega;
+    uint64_t n = 0;
+    int logn = 0, log_lo = 0;
+    fe *tw_lo = nullptr;  // omega^i, i < 2^log_lo
+    fe *tw_hi = nullptr;  // omega^(i << log_lo), i < n >> log_lo
+    int npass = 0;
+    int L[4] = {0, 0, 0, 0};
+    fe *wR[4] = {nullptr, nullptr, nullptr, nullptr};  // (omega^(n/R))^i, i < R, per pass
+    fe w16[8];                                         // omega_16^i
+};
+
+struct PassArgs {
+    uint64_t n, in_len, in_stride, out_stride;
+    int logn, logNs, logWj, log_lo, scale;
+    const fe *tw_lo, *tw_hi, *wR;
+    fe w16[8];
+    fe ninv;
+};
+
+int gs_power_series_dev(gs_ctx *c, const fe &base, uint64_t n, fe *out);  // pointwise.hip
+
+__device__ __forceinline__ fe pow_lookup(const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn,
+                                         uint64_t e) {
+    fe x = tw_lo[e & ((1ull << log_lo) - 1)];
+    if (logn > log_lo) x = fe_mul(x, tw_hi[e >> log_lo]);  // wave-uniform
+    return x;
+}
+
+__host__ __device__ constexpr int brev(int i, int bits) {
+    int r = 0;
+    for (int b = 0; b < bits; b++) r |= ((i >> b) & 1) << (bits - 1 - b);
+    return r;
+}
+
+// Fully unrolled decimation-in-frequency network on N = 2^LOGN registers.  w16[i] = omega_16^i.
+// Result is bit-reversed: X[q] = x[brev(q, LOGN)].
+template <int LOGN>
+__device__ __forceinline__ void ntt_dif_reg(fe (&x)[1 << LOGN], const fe (&w16)[8]) {
+    constexpr int N = 1 << LOGN;
+#pragma unroll
+    for (int s = N / 2; s >= 1; s >>= 1) {
+#pragma unroll
+        for (int b = 0; b < N; b += 2 * s) {
+#pragma unroll
+            for (int i = 0; i < s; i++) {
+                fe u = x[b + i], v = x[b + i + s];
+                x[b + i] = fe_add(u, v);
+                fe d = fe_sub(u, v);
+                const int tw = i * (N / 2 / s) * (16 / N);
+                x[b + i + s] = tw ? fe_mul(d, w16[tw]) : d;
+            }
+        }
+    }
+}
+
+template <int LB>
+__global__ __launch_bounds__(256) void k_ntt_pass(const fe *__restrict__ in, fe *__restrict__ out, PassArgs a) {
+    constexpr int RB = 1 << LB, R = 16 * RB, GB = 16 / RB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    fe *lds = reinterpret_cast<fe *>(lds_raw);
+
+    const int t = threadIdx.x;
+    const int Wj = 1 << a.logWj;
+    const int jj = t & (Wj - 1);
+    const int kk = t >> a.logWj;  // < RB
+    const uint64_t j = (uint64_t)blockIdx.x * Wj + jj;
+    const uint64_t nR = a.n >> (4 + LB);
+    const fe *src = in + (uint64_t)blockIdx.y * a.in_stride;
+    fe *dst = out + (uint64_t)blockIdx.y * a.out_stride;
+
+    // ---- stage A: 16 strided loads (coalesced across jj), Stockham input twiddle, radix-16 in registers
+    fe v[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        uint64_t idx = j + (uint64_t)(kk + RB * m) * nR;
+        v[m] = idx < a.in_len ? src[idx] : fe_zero();
+    }
+    const uint64_t Ns = 1ull << a.logNs;
+    const uint64_t jq = j & (Ns - 1);
+    if (a.logNs > 0) {
+        // v[m] *= omega_{Ns*R}^(jq * (kk + RB*m)) : start value + running product
+        const uint64_t eu = a.n >> (a.logNs + 4 + LB);
+        fe cur = pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * kk * eu);
+        const fe step = pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * RB * eu);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            v[m] = fe_mul(v[m], cur);
+            if (m < 15) cur = fe_mul(cur, step);
+        }
+    }
+    ntt_dif_reg<4>(v, a.w16);  // A[qa] = v[brev(qa,4)]
+
+    const uint64_t jbase = (j - jq) * R + jq;
+    const bool first = (a.logNs == 0);  // first pass: the tile's output is one contiguous block of R*Wj elements
+
+    if constexpr (RB == 1) {
+        if (!first) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                fe x = v[brev(q, 4)];
+                if (a.scale) x = fe_mul(x, a.ninv);
+                dst[jbase + (uint64_t)q * Ns] = x;
+            }
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            fe x = v[brev(q, 4)];
+            if (a.scale) x = fe_mul(x, a.ninv);
+            lds[jj * (R + 1) + q] = x;
+        }
+    } else {
+        // ---- exchange through LDS with the A->B twiddle omega_R^(kk*qa)
+#pragma unroll
+        for (int qa = 0; qa < 16; qa++) {
+            fe x = v[brev(qa, 4)];
+            if (qa != 0 && kk != 0) x = fe_mul(x, a.wR[(kk * qa) & (R - 1)]);
+            lds[(qa * RB + kk) * Wj + jj] = x;
+        }
+        __syncthreads();
+        // ---- stage B: GB radix-RB networks per thread (g = kk indexes the group of qa values)
+        fe xb[GB][RB];
+#pragma unroll
+        for (int u = 0; u < GB; u++) {
+            const int qa = kk * GB + u;
+#pragma unroll
+            for (int k2 = 0; k2 < RB; k2++) xb[u][k2] = lds[(qa * RB + k2) * Wj + jj];
+        }
+        if (first) __syncthreads();  // the exchange buffer is reused for the output transpose below
+#pragma unroll
+        for (int u = 0; u < GB; u++) {
+            const int qa = kk * GB + u;
+            ntt_dif_reg<LB>(xb[u], a.w16);
+#pragma unroll
+            for (int qb = 0; qb < RB; qb++) {
+                fe x = xb[u][brev(qb, LB)];
+                if (a.scale) x = fe_mul(x, a.ninv);
+                const int q = qa + 16 * qb;
+                if (first) lds[jj * (R + 1) + q] = x;
+                else dst[jbase + (uint64_t)q * Ns] = x;
+            }
+        }
+        if (!first) return;
+    }
+    // ---- first pass only: y[j*R + q] for the tile is contiguous; stream it out of LDS coalesced
+    __syncthreads();
+    const int T = RB * Wj;  // threads in this block
+    fe *tile = dst + (uint64_t)blockIdx.x * Wj * R;
+#pragma unroll 4
+    for (int e = t; e < R * Wj; e += T) {
+        const int ej = e / R, eq = e % R;
+        tile[e] = lds[ej * (R + 1) + eq];
+    }
+}
+
+// out[r][i] = scale * sum_c in[r][c] * (omega^i)^c  — short polynomials / tiny domains (Horner per point)
+__global__ void k_eval_horner(const fe *__restrict__ in, fe *__restrict__ out, uint64_t n, uint64_t in_len, uint64_t in_stride,
+                              const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn, int scale, fe ninv) {
+    const fe *src = in + (uint64_t)blockIdx.y * in_stride;
+    fe *dst = out + (uint64_t)blockIdx.y * n;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        fe x = pow_lookup(tw_lo, tw_hi, log_lo, logn, i);
+        fe s = fe_zero();
+        for (uint64_t c = in_len; c-- > 0;) s = fe_add(fe_mul(s, x), src[c]);
+        if (scale) s = fe_mul(s, ninv);
+        dst[i] = s;
+    }
+}
+
+static std::string plan_key(const fe &omega, uint64_t n) {
+    char buf[96];
+    snprintf(buf, sizeof buf, "%08x%08x%08x%08x:%llu", omega.w3, omega.w2, omega.w1, omega.w0, (unsigned long long)n);
+    return buf;
+}
+
+static int plan_get(gs_ctx *c, const fe &omega, uint64_t n, NttPlan **out) {
+    std::string key = plan_key(omega, n);
+    auto it = c->plans.find(key);
+    if (it != c->plans.end()) { *out = it->second; return GS_OK; }
+    // omega must be a primitive n-th root of unity for the decomposition to hold
+    if (n > 1) {
+        fe h = fe_pow_u64(omega, n / 2);
+        fe m1 = fe_sub(fe_zero(), fe_one());
+        if (!fe_eq(h, m1)) return gs_fail(c, GS_ERR_ARG, "ntt: omega is not a primitive %llu-th root of unity", (unsigned long long)n);
+    } else if (!fe_eq(omega, fe_one())) return gs_fail(c, GS_ERR_ARG, "ntt: omega must be 1 for n = 1");
+    NttPlan *p = new NttPlan();
+    p->omega = omega;
+    p->n = n;
+    p->logn = gs_log2(n);
+    p->log_lo = p->logn < 12 ? p->logn : 12;
+    int rc;
+    void *q = nullptr;
+    if ((rc = gs_alloc(c, (1ull << p->log_lo) * 16, &q))) { delete p; return rc; }
+    p->tw_lo = (fe *)q;
+    if ((rc = gs_power_series_dev(c, omega, 1ull << p->log_lo, p->tw_lo))) { delete p; return rc; }
+    if (p->logn > p->log_lo) {
+        uint64_t nhi = n >> p->log_lo;
+        if ((rc = gs_alloc(c, nhi * 16, &q))) { delete p; return rc; }
+        p->tw_hi = (fe *)q;
+        if ((rc = gs_power_series_dev(c, fe_pow_u64(omega, 1ull << p->log_lo), nhi, p->tw_hi))) { delete p; return rc; }
+    } else {
+        p->tw_hi = p->tw_lo;
+    }
+    if (p->logn >= 8) {
+        int np = (p->logn + 7) / 8, base = p->logn / np, extra = p->logn % np;
+        p->npass = np;
+        fe w16 = fe_pow_u64(omega, n / 16), cur = fe_one();
+        for (int i = 0; i < 8; i++) { p->w16[i] = cur; cur = fe_mul(cur, w16); }
+        for (int i = 0; i < np; i++) {
+            p->L[i] = base + (i < extra ? 1 : 0);
+            uint64_t R = 1ull << p->L[i];
+            if (R > 16) {
+                // share tables between passes of equal radix
+                for (int k = 0; k < i; k++)
+                    if (p->L[k] == p->L[i]) p->wR[i] = p->wR[k];
+                if (!p->wR[i]) {
+                    if ((rc = gs_alloc(c, R * 16, &q))) { delete p; return rc; }
+                    p->wR[i] = (fe *)q;
+                    if ((rc = gs_power_series_dev(c, fe_pow_u64(omega, n / R), R, p->wR[i]))) { delete p; return rc; }
+                }
+            }
+        }
+    }
+    c->plans[key] = p;
+    *out = p;
+    return GS_OK;
+}
+
+void gs_plans_destroy(gs_ctx *c) {
+    for (auto &kv : c->plans) delete kv.second;  // device tables are owned by the block cache
+    c->plans.clear();
+}
+
+int gs_plan_pow_tables(gs_ctx *c, const fe &omega, uint64_t n, const fe **tw_lo, const fe **tw_hi, int *log_lo) {
+    NttPlan *p;
+    int rc = plan_get(c, omega, n, &p);
+    if (rc) return rc;
+    *tw_lo = p->tw_lo;
+    *tw_hi = p->tw_hi;
+    *log_lo = p->log_lo;
+    return GS_OK;
+}
+
+template <int LB>
+static void launch_pass(gs_ctx *c, const fe *in, fe *out, const PassArgs &a, uint32_t rows) {
+    constexpr int RB = 1 << LB, R = 16 * RB;
+    const int Wj = 1 << a.logWj;
+    const uint64_t tiles = (a.n / R) / Wj;
+    const bool need_lds = (RB > 1) || (a.logNs == 0);
+    const size_t lds = need_lds ? (size_t)Wj * (R + 1) * 16 : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass<LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_ntt_pass<LB>, dim3((unsigned)tiles, rows), dim3(RB * Wj), lds, c->stream, in, out, a);
+}
+
+// rows transforms of size n; row r reads in[r*in_stride .. +in_len) (zero-extended) and writes out[r*n .. +n)
+static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint64_t in_stride, const fe &omega, uint64_t n,
+                   bool inverse, fe *out) {
+    if (!gs_is_pow2(n) || in_len > n) return gs_fail(c, GS_ERR_ARG, "ntt: n must be a power of two >= input length");
+    if (rows == 0) return GS_OK;
+    if (rows > 65535) return gs_fail(c, GS_ERR_ARG, "ntt: at most 65535 rows per call");
+    const uint64_t total = (uint64_t)rows * n;
+    {   // output must not overlap the input (the passes are out of place)
+        const uint8_t *i0 = (const uint8_t *)in, *i1 = i0 + ((uint64_t)(rows - 1) * in_stride + in_len) * 16;
+        const uint8_t *o0 = (const uint8_t *)out, *o1 = o0 + total * 16;
+        if (i0 < o1 && o0 < i1) return gs_fail(c, GS_ERR_ARG, "ntt: output overlaps input");
+    }
+    fe w = inverse ? fe_inv(omega) : omega;
+    NttPlan *p;
+    int rc = plan_get(c, w, n, &p);
+    if (rc) return rc;
+    fe ninv = inverse ? fe_inv(fe_from_u64(n)) : fe_one();
+
+    if (n < 256 || in_len <= 8) {
+        dim3 grid(gs_grid(n, 256, 1024), rows);
+        hipLaunchKernelGGL(k_eval_horner, grid, dim3(256), 0, c->stream, in, out, n, in_len, in_stride, p->tw_lo, p->tw_hi, p->log_lo,
+                           p->logn, inverse ? 1 : 0, ninv);
+        GS_LAUNCH_CHECK(c);
+        return GS_OK;
+    }
+
+    fe *tmp = nullptr;
+    if (p->npass >= 2) {
+        void *q;
+        if ((rc = gs_tmp_alloc(c, total * 16, &q))) return rc;
+        tmp = (fe *)q;
+    }
+    // ping-pong so that the last pass lands in `out`:  1: in->out   2: in->tmp->out   3: in->out->tmp->out   4: in->tmp->out->tmp->out
+    const fe *src = in;
+    int logNs = 0;
+    for (int i = 0; i < p->npass; i++) {
+        const int remaining = p->npass - 1 - i;
+        fe *dst = (remaining % 2 == 0) ? out : tmp;
+        PassArgs a;
+        a.n = n;
+        a.in_len = (i == 0) ? in_len : n;
+        a.in_stride = (i == 0) ? in_stride : n;
+        a.out_stride = n;
+        a.logn = p->logn;
+        a.logNs = logNs;
+        const int LB = p->L[i] - 4;
+        const uint64_t R = 1ull << p->L[i];
+        uint64_t Wj = 256 >> LB;
+        if (Wj > n / R) Wj = n / R;
+        a.logWj = gs_log2(Wj);
+        a.log_lo = p->log_lo;
+        a.scale = (inverse && i == p->npass - 1) ? 1 : 0;
+        a.tw_lo = p->tw_lo;
+        a.tw_hi = p->tw_hi;
+        a.wR = p->wR[i];
+        for (int k = 0; k < 8; k++) a.w16[k] = p->w16[k];
+        a.ninv = ninv;
+        switch (LB) {
+            case 0: launch_pass<0>(c, src, dst, a, rows); break;
+            case 1: launch_pass<1>(c, src, dst, a, rows); break;
+            case 2: launch_pass<2>(c, src, dst, a, rows); break;
+            case 3: launch_pass<3>(c, src, dst, a, rows); break;
+            default: launch_pass<4>(c, src, dst, a, rows); break;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            if (tmp) gs_tmp_free(c, tmp);
+            return gs_fail(c, GS_ERR_DEVICE, "ntt pass %d launch: %s", i, hipGetErrorString(e));
+        }
+        src = dst;
+        logNs += p->L[i];
+    }
+    if (tmp) gs_tmp_free(c, tmp);
+    return GS_OK;
+}
+
+extern "C" {
+
+int gs_eval_polys_at_roots(gs_ctx *c, const void *polys, uint32_t rows, uint64_t poly_len, const uint8_t omega[16], uint64_t n,
+                           void *out) {
+    if (!c || !polys || !omega || !out) return GS_ERR_ARG;
+    return ntt_run(c, (const fe *)polys, rows, poly_len, poly_len, fe_from_bytes(omega), n, false, (fe *)out);
+}
+
+int gs_interpolate_roots(gs_ctx *c, const void *ys, uint32_t rows, const uint8_t omega[16], uint64_t n, void *out) {
+    if (!c || !ys || !omega || !out) return GS_ERR_ARG;
+    return ntt_run(c, (const fe *)ys, rows, n, n, fe_from_bytes(omega), n, true, (fe *)out);
+}
+
+}  // extern "C"

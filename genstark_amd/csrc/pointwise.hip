@@ -1,0 +1,445 @@
+// pointwise.hip — streaming vector kernels over GF(p): the FiniteField vector/matrix members that are
+// embarrassingly parallel over the domain index.
+//
+// All of them are HBM-streaming kernels: one 128-bit load/store per element per operand, consecutive
+// lanes on consecutive elements, grid capped at 2048 workgroups with a grid-stride loop.
+#include "common.h"
+
+// ---- power series: out[i] = base^i -----------------------------------------------------------------
+// thread t owns i = t, t + TOT, t + 2*TOT, ...: one exponentiation for base^t, then one multiplication
+// by base^TOT per element; stores stay coalesced.
+__global__ void k_power_series(fe base, fe step, uint64_t n, uint64_t tot, fe *__restrict__ out) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= tot || t >= n) return;
+    fe cur = fe_pow_u64(base, t);
+    for (uint64_t i = t; i < n; i += tot) {
+        out[i] = cur;
+        cur = fe_mul(cur, step);
+    }
+}
+
+int gs_power_series_dev(gs_ctx *c, const fe &base, uint64_t n, fe *out) {
+    if (n == 0) return GS_OK;
+    uint64_t tot = n < 65536 ? n : 65536;
+    fe step = fe_pow_u64(base, tot);
+    unsigned blocks = (unsigned)((tot + 255) / 256);
+    hipLaunchKernelGGL(k_power_series, dim3(blocks), dim3(256), 0, c->stream, base, step, n, tot, out);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
+// ---- elementwise ------------------------------------------------------------------------------------
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2 };
+
+template <int OP>
+__device__ __forceinline__ fe apply_op(const fe &x, const fe &y) {
+    if (OP == OP_ADD) return fe_add(x, y);
+    if (OP == OP_SUB) return fe_sub(x, y);
+    return fe_mul(x, y);
+}
+
+template <int OP>
+__global__ void k_vec_vec(const fe *__restrict__ a, const fe *__restrict__ b, uint64_t n, fe *__restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = apply_op<OP>(a[i], b[i]);
+}
+template <int OP>
+__global__ void k_vec_scalar(const fe *__restrict__ a, fe s, uint64_t n, fe *__restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = apply_op<OP>(a[i], s);
+}
+__global__ void k_vec_exp(const fe *__restrict__ a, fe e, uint64_t n, fe *__restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = fe_pow(a[i], e);
+}
+
+// ---- batch inversion (Montgomery's trick), 0 -> 0 ------------------------------------------------------
+// thread t owns the strided subsequence i = t + m*tot (coalesced).  Pass 1 writes running products into
+// out[], one Fermat inversion per thread, pass 2 walks back.  `num` (optional) fuses the division
+// out[i] = num[i] * a[i]^-1 (divVectorElements).
+__global__ void k_batch_inv(const fe *__restrict__ a, const fe *__restrict__ num, uint64_t n, uint64_t tot, fe *__restrict__ out) {
+    uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (t >= tot || t >= n) return;
+    fe acc = fe_one();
+    uint64_t last = t;
+    for (uint64_t i = t; i < n; i += tot) {
+        out[i] = acc;
+        fe v = a[i];
+        if (!fe_is_zero(v)) acc = fe_mul(acc, v);
+        last = i;
+    }
+    fe inv = fe_inv(acc);
+    for (uint64_t i = last;; i -= tot) {
+        fe v = a[i];
+        fe r = fe_zero();
+        if (!fe_is_zero(v)) {
+            r = fe_mul(out[i], inv);
+            inv = fe_mul(inv, v);
+            if (num) r = fe_mul(r, num[i]);
+        }
+        out[i] = r;
+        if (i < tot) break;
+    }
+}
+
+static int launch_batch_inv(gs_ctx *c, const fe *a, const fe *num, uint64_t n, fe *out) {
+    if (n == 0) return GS_OK;
+    if ((const void *)a == (const void *)out || (num && (const void *)num == (const void *)out))
+        return gs_fail(c, GS_ERR_ARG, "vec_inv/vec_div: output must not alias an input");
+    // 32 elements per thread once there is enough work to fill the chip
+    uint64_t tot = n / 32;
+    if (tot < 16384) tot = n < 16384 ? n : 16384;
+    unsigned blocks = (unsigned)((tot + 255) / 256);
+    hipLaunchKernelGGL(k_batch_inv, dim3(blocks), dim3(256), 0, c->stream, a, num, n, tot, out);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
+// ---- linear combination of many vectors --------------------------------------------------------------
+struct PtrArgs {
+    const fe *v[GS_MAX_COMBINE];
+};
+struct CombineArgs {  // vector pointers and coefficients travel as kernel arguments (1.5 KB): no staging copy, no sync
+    const fe *v[GS_MAX_COMBINE];
+    fe k[GS_MAX_COMBINE];
+};
+__global__ void k_combine_many(CombineArgs va, uint32_t count, uint64_t n, fe *__restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        fe s = fe_mul(va.v[0][i], va.k[0]);
+        for (uint32_t j = 1; j < count; j++) s = fe_add(s, fe_mul(va.v[j][i], va.k[j]));
+        out[i] = s;
+    }
+}
+
+// ---- dot product -> one element ---------------------------------------------------------------------
+__device__ __forceinline__ fe block_reduce_add(fe s, fe *sh) {
+    // wave reduce via shuffles, then one LDS step across the (<= 4) waves of the block
+    for (int off = 32; off >= 1; off >>= 1) {
+        fe o;
+        o.w0 = __shfl_down(s.w0, off);
+        o.w1 = __shfl_down(s.w1, off);
+        o.w2 = __shfl_down(s.w2, off);
+        o.w3 = __shfl_down(s.w3, off);
+        s = fe_add(s, o);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int w = 1; w < nw; w++) s = fe_add(s, sh[w]);
+    }
+    return s;
+}
+__global__ void k_dot_partial(const fe *__restrict__ a, const fe *__restrict__ b, uint64_t n, fe *__restrict__ partial) {
+    __shared__ fe sh[4];
+    fe s = fe_zero();
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        s = fe_add(s, fe_mul(a[i], b[i]));
+    s = block_reduce_add(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ void k_sum_final(const fe *__restrict__ partial, uint32_t count, fe *__restrict__ out) {
+    __shared__ fe sh[4];
+    fe s = fe_zero();
+    for (uint32_t i = threadIdx.x; i < count; i += blockDim.x) s = fe_add(s, partial[i]);
+    s = block_reduce_add(s, sh);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// ---- index shuffles -------------------------------------------------------------------------------------
+__global__ void k_pluck(const fe *__restrict__ v, uint64_t vlen, uint64_t skip, uint64_t times, fe *__restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < times; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = v[(i * skip) % vlen];
+}
+// out[r*cols + k] = v[(r + k*rows)*step]; one thread per output element, lanes walk r for a fixed k so
+// the (large) reads stay coalesced when step == 1
+__global__ void k_transpose_vector(const fe *__restrict__ v, uint64_t rows, uint32_t cols, uint64_t step, fe *__restrict__ out) {
+    uint64_t total = rows * cols;
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t k = t / rows, r = t % rows;
+        out[r * cols + k] = v[(r + k * rows) * step];
+    }
+}
+// cols == 4 specialisation: thread per row, 4 coalesced 16-byte loads, one 64-byte row store
+__global__ void k_transpose_vector4(const fe *__restrict__ v, uint64_t rows, uint64_t step, fe *__restrict__ out) {
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * blockDim.x) {
+        fe x0 = v[r * step], x1 = v[(r + rows) * step], x2 = v[(r + 2 * rows) * step], x3 = v[(r + 3 * rows) * step];
+        fe *o = out + r * 4;
+        o[0] = x0; o[1] = x1; o[2] = x2; o[3] = x3;
+    }
+}
+__global__ void k_transpose_matrix(const fe *__restrict__ m, uint64_t rows, uint64_t cols, fe *__restrict__ out) {
+    uint64_t total = rows * cols;
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t r = t / cols, k = t % cols;
+        out[k * rows + r] = m[t];
+    }
+}
+__global__ void k_sub_matrix_from_vectors(PtrArgs va, const fe *__restrict__ m, uint64_t cols, fe *__restrict__ out) {
+    const fe *v = va.v[blockIdx.y];
+    const fe *mr = m + (uint64_t)blockIdx.y * cols;
+    fe *o = out + (uint64_t)blockIdx.y * cols;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < cols; i += (uint64_t)gridDim.x * blockDim.x)
+        o[i] = fe_sub(v[i], mr[i]);
+}
+
+// ---- FRI row polynomials ------------------------------------------------------------------------------
+// General Lagrange interpolation through 4 arbitrary points per row (verifier-side shape).
+__global__ void k_quartic_interp_generic(const fe *__restrict__ xs, const fe *__restrict__ ys, uint64_t rows, fe *__restrict__ out) {
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * blockDim.x) {
+        fe x[4], y[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { x[j] = xs[r * 4 + j]; y[j] = ys[r * 4 + j]; }
+        // denominators d_j = prod_{m != j} (x_j - x_m); invert all four with one inversion
+        fe d[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            fe p = fe_one();
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                if (m != j) p = fe_mul(p, fe_sub(x[j], x[m]));
+            d[j] = p;
+        }
+        fe p01 = fe_mul(d[0], d[1]), p012 = fe_mul(p01, d[2]), all = fe_mul(p012, d[3]);
+        fe inv = fe_inv(all);
+        fe i3 = fe_mul(inv, p012);
+        inv = fe_mul(inv, d[3]);
+        fe i2 = fe_mul(inv, p01);
+        inv = fe_mul(inv, d[2]);
+        fe i1 = fe_mul(inv, d[0]);
+        fe i0 = fe_mul(inv, d[1]);
+        fe s[4] = {fe_mul(y[0], i0), fe_mul(y[1], i1), fe_mul(y[2], i2), fe_mul(y[3], i3)};
+        fe c0 = fe_zero(), c1 = fe_zero(), c2 = fe_zero(), c3 = fe_zero();
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // numerator prod_{m != j} (X - x_m) = X^3 - e1 X^2 + e2 X - e3 over the three other points
+            fe a = x[(j + 1) & 3], b = x[(j + 2) & 3], cc = x[(j + 3) & 3];
+            fe e1 = fe_add(fe_add(a, b), cc);
+            fe ab = fe_mul(a, b);
+            fe e2 = fe_add(ab, fe_mul(cc, fe_add(a, b)));
+            fe e3 = fe_mul(ab, cc);
+            c3 = fe_add(c3, s[j]);
+            c2 = fe_sub(c2, fe_mul(s[j], e1));
+            c1 = fe_add(c1, fe_mul(s[j], e2));
+            c0 = fe_sub(c0, fe_mul(s[j], e3));
+        }
+        fe *o = out + r * 4;
+        o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+    }
+}
+
+// Prover-side shape: row r has x-coordinates x, zeta*x, zeta^2*x, zeta^3*x with x = omega^(r*step),
+// zeta = omega^(n/4).  Then u_k = c_k x^k is the inverse 4-point DFT of the row and no inversion is needed:
+// x^-1 = omega^(n - r*step) comes from the power tables.
+__global__ void k_quartic_interp_domain(const fe *__restrict__ ys, uint64_t rows, uint64_t step, uint64_t n,
+                                        const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn,
+                                        fe zeta_inv, fe inv4, fe *__restrict__ out) {
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * blockDim.x) {
+        const fe *y = ys + r * 4;
+        fe y0 = y[0], y1 = y[1], y2 = y[2], y3 = y[3];
+        fe s0 = fe_add(y0, y2), s1 = fe_sub(y0, y2), s2 = fe_add(y1, y3);
+        fe s3 = fe_mul(fe_sub(y1, y3), zeta_inv);
+        fe u0 = fe_add(s0, s2), u2 = fe_sub(s0, s2), u1 = fe_add(s1, s3), u3 = fe_sub(s1, s3);
+        uint64_t e = (r * step) & (n - 1);
+        e = e ? n - e : 0;
+        fe xi = e ? fe_make(0, 0, 0, 0) : fe_one();
+        if (e) {
+            xi = tw_lo[e & ((1ull << log_lo) - 1)];
+            if (logn > log_lo) xi = fe_mul(xi, tw_hi[e >> log_lo]);
+        }
+        fe q1 = fe_mul(xi, inv4), q2 = fe_mul(q1, xi), q3 = fe_mul(q2, xi);
+        fe *o = out + r * 4;
+        o[0] = fe_mul(u0, inv4);
+        o[1] = fe_mul(u1, q1);
+        o[2] = fe_mul(u2, q2);
+        o[3] = fe_mul(u3, q3);
+    }
+}
+
+__global__ void k_quartic_eval(const fe *__restrict__ polys, uint64_t rows, fe x, fe *__restrict__ out) {
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * blockDim.x) {
+        const fe *p = polys + r * 4;
+        fe s = p[3];
+        s = fe_add(fe_mul(s, x), p[2]);
+        s = fe_add(fe_mul(s, x), p[1]);
+        s = fe_add(fe_mul(s, x), p[0]);
+        out[r] = s;
+    }
+}
+
+// ---- C ABI ----------------------------------------------------------------------------------------------
+#define CHECK3(c, a, b, o) \
+    if (!(c) || !(a) || !(b) || !(o)) return GS_ERR_ARG
+
+static int dot_to_host(gs_ctx *c, const fe *a, const fe *b, uint64_t n, uint8_t out_host[16]) {
+    unsigned blocks = gs_grid(n, 256, 1024);
+    int rc = gs_stage_reserve(c, (uint64_t)(blocks + 1) * 16);
+    if (rc) return rc;
+    fe *partial = (fe *)c->d_stage;
+    hipLaunchKernelGGL(k_dot_partial, dim3(blocks), dim3(256), 0, c->stream, a, b, n, partial + 1);
+    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, c->stream, partial + 1, blocks, partial);
+    GS_LAUNCH_CHECK(c);
+    GS_HIP(c, hipMemcpyAsync(c->h_stage, partial, 16, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP(c, hipStreamSynchronize(c->stream));
+    memcpy(out_host, c->h_stage, 16);
+    return GS_OK;
+}
+
+extern "C" {
+
+int gs_power_series(gs_ctx *c, const uint8_t base[16], uint64_t n, void *out) {
+    if (!c || !base || (!out && n)) return GS_ERR_ARG;
+    return gs_power_series_dev(c, fe_from_bytes(base), n, (fe *)out);
+}
+
+#define VEC_VEC(NAME, OP)                                                                                  \
+    int NAME(gs_ctx *c, const void *a, const void *b, uint64_t n, void *out) {                             \
+        CHECK3(c, a, b, out);                                                                              \
+        if (!n) return GS_OK;                                                                              \
+        hipLaunchKernelGGL(k_vec_vec<OP>, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const fe *)a, (const fe *)b, n, (fe *)out); \
+        GS_LAUNCH_CHECK(c);                                                                                \
+        return GS_OK;                                                                                      \
+    }
+#define VEC_SCALAR(NAME, OP)                                                                               \
+    int NAME(gs_ctx *c, const void *a, const uint8_t s[16], uint64_t n, void *out) {                       \
+        CHECK3(c, a, s, out);                                                                              \
+        if (!n) return GS_OK;                                                                              \
+        hipLaunchKernelGGL(k_vec_scalar<OP>, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const fe *)a, fe_from_bytes(s), n, (fe *)out); \
+        GS_LAUNCH_CHECK(c);                                                                                \
+        return GS_OK;                                                                                      \
+    }
+VEC_VEC(gs_vec_add, OP_ADD)
+VEC_VEC(gs_vec_sub, OP_SUB)
+VEC_VEC(gs_vec_mul, OP_MUL)
+VEC_SCALAR(gs_vec_add_scalar, OP_ADD)
+VEC_SCALAR(gs_vec_sub_scalar, OP_SUB)
+VEC_SCALAR(gs_vec_mul_scalar, OP_MUL)
+
+int gs_vec_inv(gs_ctx *c, const void *a, uint64_t n, void *out) {
+    if (!c || !a || !out) return GS_ERR_ARG;
+    return launch_batch_inv(c, (const fe *)a, nullptr, n, (fe *)out);
+}
+int gs_vec_div(gs_ctx *c, const void *a, const void *b, uint64_t n, void *out) {
+    CHECK3(c, a, b, out);
+    return launch_batch_inv(c, (const fe *)b, (const fe *)a, n, (fe *)out);
+}
+int gs_vec_exp(gs_ctx *c, const void *a, const uint8_t e[16], uint64_t n, void *out) {
+    CHECK3(c, a, e, out);
+    if (!n) return GS_OK;
+    hipLaunchKernelGGL(k_vec_exp, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const fe *)a, fe_from_bytes(e), n, (fe *)out);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
+int gs_combine_many(gs_ctx *c, const void *const *vecs_host, const uint8_t *coeffs_host, uint32_t count, uint64_t n, void *out) {
+    if (!c || !vecs_host || !coeffs_host || !out) return GS_ERR_ARG;
+    if (count == 0 || count > GS_MAX_COMBINE) return gs_fail(c, GS_ERR_ARG, "combine_many: count must be in 1..%d", GS_MAX_COMBINE);
+    if (!n) return GS_OK;
+    CombineArgs va;
+    for (uint32_t j = 0; j < GS_MAX_COMBINE; j++) {
+        va.v[j] = (const fe *)vecs_host[j < count ? j : 0];
+        va.k[j] = j < count ? fe_from_bytes(coeffs_host + 16 * j) : fe_zero();
+    }
+    hipLaunchKernelGGL(k_combine_many, dim3(gs_grid(n)), dim3(256), 0, c->stream, va, count, n, (fe *)out);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
+int gs_combine(gs_ctx *c, const void *a, const void *b, uint64_t n, uint8_t out_host[16]) {
+    CHECK3(c, a, b, out_host);
+    if (!n) { memset(out_host, 0, 16); return GS_OK; }
+    return dot_to_host(c, (const fe *)a, (const fe *)b, n, out_host);
+}
+
+int gs_pluck(gs_ctx *c, const void *v, uint64_t vlen, uint64_t skip, uint64_t times, void *out) {
+    if (!c || !v || !out) return GS_ERR_ARG;
+    if (!vlen) return gs_fail(c, GS_ERR_ARG, "pluck: empty vector");
+    if (!times) return GS_OK;
+    hipLaunchKernelGGL(k_pluck, dim3(gs_grid(times)), dim3(256), 0, c->stream, (const fe *)v, vlen, skip, times, (fe *)out);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
+int gs_transpose_vector(gs_ctx *c, const void *v, uint64_t n, uint32_t cols, uint64_t step, void *out) {
+    if (!c || !v || !out) return GS_ERR_ARG;
+    if (!cols || !step || n % ((uint64_t)cols * step)) return gs_fail(c, GS_ERR_ARG, "transpose_vector: n %% (cols*step) != 0");
+    uint64_t rows = n / ((uint64_t)cols * step);
+    if (!rows) return GS_OK;
+    if (cols == 4)
+        hipLaunchKernelGGL(k_transpose_vector4, dim3(gs_grid(rows)), dim3(256), 0, c->stream, (const fe *)v, rows, step, (fe *)out);
+    else
+        hipLaunchKernelGGL(k_transpose_vector, dim3(gs_grid(rows * cols)), dim3(256), 0, c->stream, (const fe *)v, rows, cols, step,
+                           (fe *)out);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
+int gs_transpose_matrix(gs_ctx *c, const void *m, uint64_t rows, uint64_t cols, void *out) {
+    if (!c || !m || !out) return GS_ERR_ARG;
+    if (!rows || !cols) return GS_OK;
+    hipLaunchKernelGGL(k_transpose_matrix, dim3(gs_grid(rows * cols)), dim3(256), 0, c->stream, (const fe *)m, rows, cols, (fe *)out);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
+int gs_sub_matrix_from_vectors(gs_ctx *c, const void *const *vecs_host, const void *m, uint32_t rows, uint64_t cols, void *out) {
+    if (!c || !vecs_host || !m || !out) return GS_ERR_ARG;
+    if (rows == 0 || rows > GS_MAX_COMBINE) return gs_fail(c, GS_ERR_ARG, "sub_matrix_from_vectors: rows must be in 1..%d", GS_MAX_COMBINE);
+    if (!cols) return GS_OK;
+    PtrArgs va;
+    for (uint32_t j = 0; j < GS_MAX_COMBINE; j++) va.v[j] = (const fe *)vecs_host[j < rows ? j : 0];
+    hipLaunchKernelGGL(k_sub_matrix_from_vectors, dim3(gs_grid(cols), rows), dim3(256), 0, c->stream, va, (const fe *)m, cols, (fe *)out);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
+int gs_eval_poly_at(gs_ctx *c, const void *poly, uint64_t len, const uint8_t x[16], uint8_t out_host[16]) {
+    if (!c || !x || !out_host || (!poly && len)) return GS_ERR_ARG;
+    if (!len) { memset(out_host, 0, 16); return GS_OK; }
+    // sum_i poly[i] * x^i as a dot product with the power series of x
+    void *pw;
+    int rc = gs_tmp_alloc(c, len * 16, &pw);
+    if (rc) return rc;
+    rc = gs_power_series_dev(c, fe_from_bytes(x), len, (fe *)pw);
+    if (!rc) rc = dot_to_host(c, (const fe *)poly, (const fe *)pw, len, out_host);
+    gs_tmp_free(c, pw);
+    return rc;
+}
+
+int gs_interpolate_quartic_batch(gs_ctx *c, const void *xs, const void *ys, uint64_t rows, void *out) {
+    CHECK3(c, xs, ys, out);
+    if (!rows) return GS_OK;
+    hipLaunchKernelGGL(k_quartic_interp_generic, dim3(gs_grid(rows)), dim3(256), 0, c->stream, (const fe *)xs, (const fe *)ys, rows,
+                       (fe *)out);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
+int gs_interpolate_quartic_domain(gs_ctx *c, const uint8_t omega[16], uint64_t n, uint64_t step, const void *ys, uint64_t rows,
+                                  void *out) {
+    CHECK3(c, omega, ys, out);
+    if (!gs_is_pow2(n) || n < 4 || rows * 4 * step != n) return gs_fail(c, GS_ERR_ARG, "interpolate_quartic_domain: rows*4*step != n");
+    fe w = fe_from_bytes(omega);
+    const fe *lo, *hi;
+    int log_lo;
+    int rc = gs_plan_pow_tables(c, w, n, &lo, &hi, &log_lo);
+    if (rc) return rc;
+    fe zeta = fe_pow_u64(w, n / 4);
+    fe zeta_inv = fe_mul(fe_mul(zeta, zeta), zeta);  // zeta^3 = zeta^-1
+    fe inv4 = fe_inv(fe_from_u64(4));
+    hipLaunchKernelGGL(k_quartic_interp_domain, dim3(gs_grid(rows)), dim3(256), 0, c->stream, (const fe *)ys, rows, step, n, lo, hi,
+                       log_lo, gs_log2(n), zeta_inv, inv4, (fe *)out);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
+int gs_eval_quartic_batch(gs_ctx *c, const void *polys, uint64_t rows, const uint8_t x[16], void *out) {
+    CHECK3(c, polys, x, out);
+    if (!rows) return GS_OK;
+    hipLaunchKernelGGL(k_quartic_eval, dim3(gs_grid(rows)), dim3(256), 0, c->stream, (const fe *)polys, rows, fe_from_bytes(x), (fe *)out);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
+}  // extern "C"

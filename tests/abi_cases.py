@@ -1,0 +1,263 @@
+"""Shared op-level checks of include/gstark.h: every function is driven through the galois/merkle-shaped
+host mirror on a given backend and compared with an independent expectation (Python big-int arithmetic,
+hashlib, oracle/pyref.py).  Used with the CPU oracle backend (-m "not gpu": pins the oracle) and with the
+HIP backend (-m gpu: the parity tests proper, which additionally compare HIP bytes with oracle bytes)."""
+import hashlib
+
+from conftest import P, from_bytes, rand_elements, to_bytes
+from genstark_amd.field import PrimeField
+from genstark_amd.merkle import MerkleTree, createHash
+from oracle import pyref
+
+PF = pyref.Field()
+
+
+def field_for(backend):
+    return PrimeField(backend=backend)
+
+
+def check_pointwise(backend, rng, n):
+    f = field_for(backend)
+    a, b = rand_elements(rng, n), rand_elements(rng, n)
+    va, vb = f.newVectorFrom(a), f.newVectorFrom(b)
+    s = rng.randrange(P)
+    assert f.addVectorElements(va, vb).toValues() == [(x + y) % P for x, y in zip(a, b)]
+    assert f.subVectorElements(va, vb).toValues() == [(x - y) % P for x, y in zip(a, b)]
+    assert f.mulVectorElements(va, vb).toValues() == [(x * y) % P for x, y in zip(a, b)]
+    assert f.addVectorElements(va, s).toValues() == [(x + s) % P for x in a]
+    assert f.subVectorElements(va, s).toValues() == [(x - s) % P for x in a]
+    assert f.mulVectorElements(va, s).toValues() == [(x * s) % P for x in a]
+    inv = lambda x: pow(x, P - 2, P) if x else 0
+    assert f.invVectorElements(va).toValues() == [inv(x) for x in a]
+    assert f.divVectorElements(va, vb).toValues() == [x * inv(y) % P for x, y in zip(a, b)]
+    assert f.combineVectors(va, vb) == sum(x * y for x, y in zip(a, b)) % P
+
+
+def check_inverse_with_zeros(backend, rng, n):
+    f = field_for(backend)
+    a = rand_elements(rng, n)
+    for i in range(0, n, 3):
+        a[i] = 0
+    got = f.invVectorElements(f.newVectorFrom(a)).toValues()
+    assert got == [pow(x, P - 2, P) if x else 0 for x in a]
+    zeros = f.invVectorElements(f.newVectorFrom([0] * n)).toValues()
+    assert zeros == [0] * n
+
+
+def check_power_series_and_shuffles(backend, rng, n):
+    f = field_for(backend)
+    base = rng.randrange(2, P)
+    ps = f.getPowerSeries(base, n)
+    assert ps.toValues() == PF.power_series(base, n)
+    a = rand_elements(rng, n)
+    va = f.newVectorFrom(a)
+    if n >= 8:
+        skip, times = n // 8, n
+        assert f.pluckVector(va, skip, times).toValues() == [a[(i * skip) % n] for i in range(times)]
+        for cols, step in [(4, 1), (4, 2), (2, 1), (8, 1)]:
+            if n % (cols * step) == 0:
+                rows = n // (cols * step)
+                m = f.transposeVector(va, cols, step)
+                assert (m.rowCount, m.colCount) == (rows, cols)
+                assert m.toValues() == [[a[(r + c * rows) * step] for c in range(cols)] for r in range(rows)]
+        m = f.transposeVector(va, 4)
+        t = f.transposeMatrix(m)
+        assert f.joinMatrixRows(t).toValues() == a
+    e = rng.randrange(P)
+    small = va if n <= 64 else f.newVectorFrom(a[:64])
+    assert f.expVectorElements(small, e).toValues() == [pow(x, e, P) for x in a[:small.length]]
+
+
+def check_combine_many(backend, rng, n, k):
+    f = field_for(backend)
+    vecs = [rand_elements(rng, n) for _ in range(k)]
+    coeffs = rand_elements(rng, k)
+    got = f.combineManyVectors([f.newVectorFrom(v) for v in vecs], coeffs).toValues()
+    assert got == [sum(v[i] * c for v, c in zip(vecs, coeffs)) % P for i in range(n)]
+    m = f.newMatrixFrom(vecs[:2])
+    sub = f.subMatrixElementsFromVectors([f.newVectorFrom(vecs[-1]), f.newVectorFrom(vecs[-2])], m)
+    assert sub.toValues() == [[(x - y) % P for x, y in zip(vecs[-1], vecs[0])], [(x - y) % P for x, y in zip(vecs[-2], vecs[1])]]
+
+
+def naive_eval(coeffs, w, n, points):
+    return {q: sum(c * pow(w, i * q, P) for i, c in enumerate(coeffs)) % P for q in points}
+
+
+def check_ntt(backend, rng, logn, poly_len=None, rows=1, full=False):
+    """evalPolysAtRoots vs direct evaluation at sampled points (or pyref's recursive FFT when `full`),
+    interpolateRoots as its exact inverse."""
+    f = field_for(backend)
+    n = 1 << logn
+    w = PF.get_root_of_unity(n)
+    plen = n if poly_len is None else poly_len
+    polys = [rand_elements(rng, plen) for _ in range(rows)]
+    roots = f.getPowerSeries(w, n)
+    ev = f.evalPolysAtRoots(f.newMatrixFrom(polys), roots)
+    assert (ev.rowCount, ev.colCount) == (rows, n)
+    got = ev.toValues()
+    for r in range(rows):
+        if full:
+            assert got[r] == PF.ntt(polys[r], w, n)
+        else:
+            pts = sorted(set([0, 1, n - 1, n // 2] + [rng.randrange(n) for _ in range(6)]))
+            if plen <= 4096:
+                want = naive_eval(polys[r], w, n, pts)
+                for q in pts:
+                    assert got[r][q] == want[q], (logn, plen, r, q)
+    # inverse: interpolate the evaluations back
+    back = f.interpolateRoots(roots, ev).toValues()
+    for r in range(rows):
+        assert back[r][:plen] == polys[r]
+        assert all(v == 0 for v in back[r][plen:])
+    # Vector forms
+    v = f.evalPolyAtRoots(f.newVectorFrom(polys[0]), roots)
+    assert v.toValues() == got[0]
+    assert f.interpolateRoots(roots, v).toValues()[:plen] == polys[0]
+    return got
+
+
+def check_small_polys(backend, rng):
+    f = field_for(backend)
+    xs, ys = rand_elements(rng, 3, edge=0), rand_elements(rng, 3)
+    ip = f.interpolate(f.newVectorFrom(xs), f.newVectorFrom(ys))
+    for x, y in zip(xs, ys):
+        assert f.evalPolyAt(ip, x) == y
+    assert ip.toValues() == PF.interpolate(xs, ys)
+    a, b = rand_elements(rng, 3), rand_elements(rng, 2)
+    assert f.mulPolys(f.newVectorFrom(a), f.newVectorFrom(b)).toValues() == PF.mul_polys(a, b)
+    big = rand_elements(rng, 300)
+    x = rng.randrange(P)
+    assert f.evalPolyAt(f.newVectorFrom(big), x) == PF.eval_poly_at(big, x)
+
+
+def check_quartic(backend, rng, logn, depth):
+    """interpolateQuarticBatch (domain fast path and generic path) + evalQuarticBatch vs Lagrange."""
+    f = field_for(backend)
+    n = 1 << logn
+    step = 4 ** depth
+    w = PF.get_root_of_unity(n)
+    domain = f.getPowerSeries(w, n)
+    rows = n // (4 * step)
+    ys = [rand_elements(rng, 4) for _ in range(rows)]
+    xs_m = f.transposeVector(domain, 4, step)
+    assert xs_m.quartic_domain == (w, n, step)
+    ys_m = f.newMatrixFrom(ys)
+    fast = f.interpolateQuarticBatch(xs_m, ys_m).toValues()
+    xs_vals = xs_m.toValues()
+    generic = f.interpolateQuarticBatch(f.newMatrixFrom(xs_vals), ys_m).toValues()
+    assert fast == generic
+    for r in sorted(set([0, rows - 1] + [rng.randrange(rows) for _ in range(8)])):
+        assert xs_vals[r] == [pow(w, (r + c * rows) * step, P) for c in range(4)]
+        assert fast[r] == PF.interpolate(xs_vals[r], ys[r])
+    x = rng.randrange(P)
+    col = f.evalQuarticBatch(f.newMatrixFrom(fast), x).toValues()
+    assert col == [PF.eval_poly_at(p, x) for p in fast]
+
+
+def _h(alg):
+    return (lambda b: hashlib.sha256(b).digest()) if alg == 'sha256' else (lambda b: hashlib.blake2s(b, digest_size=32).digest())
+
+
+def check_hashing(backend, rng, alg, n):
+    f = field_for(backend)
+    h = createHash(alg, backend)
+    H = _h(alg)
+    for size in (16, 32, 64, 96, 128, 192):
+        msg = bytes(rng.randrange(256) for _ in range(size))
+        assert h.digest(msg) == H(msg)
+    for k in (1, 2, 3, 6, 12):
+        cols = [rand_elements(rng, n) for _ in range(k)]
+        got = h.mergeVectorRows([f.newVectorFrom(c) for c in cols]).toBuffer()
+        for i in sorted(set([0, n - 1] + [rng.randrange(n) for _ in range(8)])):
+            assert got[32 * i:32 * i + 32] == H(b''.join(c[i].to_bytes(16, 'little') for c in cols)), (alg, k, i)
+    vals = rand_elements(rng, n)
+    m = f.transposeVector(f.newVectorFrom(vals), 4)
+    raw = m.toBuffer()
+    dig = h.digestValues(m, 64).toBuffer()
+    assert len(dig) == 32 * (n // 4)
+    assert all(dig[32 * i:32 * i + 32] == H(raw[64 * i:64 * i + 64]) for i in range(n // 4))
+    dig2 = h.digestValues(raw, 64).toBuffer()
+    assert dig2 == dig
+    for vs in (16, 32, 48, 128):
+        if len(raw) % vs == 0:
+            d = h.digestValues(raw, vs).toBuffer()
+            cnt = len(raw) // vs
+            for i in sorted(set([0, cnt - 1, cnt // 2])):
+                assert d[32 * i:32 * i + 32] == H(raw[vs * i:vs * i + vs])
+
+
+def check_merkle(backend, rng, alg, logn):
+    f = field_for(backend)
+    h = createHash(alg, backend)
+    H = _h(alg)
+    n = 1 << logn
+    leaves_v = h.mergeVectorRows([f.newVectorFrom(rand_elements(rng, n))])
+    raw = leaves_v.toBuffer()
+    leaves = [raw[32 * i:32 * i + 32] for i in range(n)]
+    tree = MerkleTree.create(leaves_v, h)
+    ref = pyref.MerkleTree(leaves, H)
+    assert tree.root == ref.root
+    nodes = tree.nodes.toBuffer()
+    assert nodes[:32] == b'\0' * 32
+    assert [nodes[32 * i:32 * i + 32] for i in range(1, n)] == ref.nodes[1:]
+    for count in sorted(set(min(c, n) for c in (1, 2, 5, max(1, min(40, n // 2))))):
+        idx = rng.sample(range(n), count)
+        proof = tree.proveBatch(idx)
+        want = ref.prove_batch(idx)
+        assert proof['values'] == want['values'] and proof['nodes'] == want['nodes'] and proof['depth'] == want['depth']
+        assert MerkleTree.verifyBatch(tree.root, idx, proof, h)
+        assert pyref.MerkleTree.verify_batch(ref.root, idx, want, H)
+        bad = dict(proof)
+        bad['values'] = [bytes(32)] + proof['values'][1:]
+        assert not MerkleTree.verifyBatch(tree.root, idx, bad, h)
+
+
+def check_mimc_air(backend, rng, steps):
+    from genstark_amd.air import MimcAir, runMimc
+    f = field_for(backend)
+    air = MimcAir(steps, 16, f)
+    ctx = air.initProvingContext([], [3])
+    trace = ctx.generateExecutionTrace()
+    want = runMimc(f, steps, air.roundConstants, 3)
+    assert trace.toValues() == [want]
+    assert want == pyref.run_mimc(PF, steps, pyref.mimc_round_constants(PF), 3)
+    p_polys = f.interpolateRoots(ctx.executionDomain, trace)
+    q = ctx.evaluateTransitionConstraints(p_polys).toValues()[0]
+    nc = steps * 4
+    # Q vanishes on the execution domain except at the last step
+    for s in range(steps - 1):
+        assert q[s * 4] == 0
+    assert q[(steps - 1) * 4] != 0
+    # and matches the verifier-side scalar evaluation at arbitrary points
+    vctx = air.initVerificationContext()
+    wc = ctx.compositionDomain.series_base
+    pv = PF.ntt(p_polys.toValues()[0], wc, nc)
+    for j in sorted(set([1, 2, 3, nc - 1] + [rng.randrange(nc) for _ in range(6)])):
+        x = pow(wc, j, P)
+        assert q[j] == vctx.evaluateConstraintsAt(x, [pv[j]], [pv[(j + 4) % nc]], [])[0]
+
+
+class VecScalarField:
+    """Scalar field ops routed through 1-element device vectors: lets a known-answer computation written
+    against add/mul/exp exercise the backend's arithmetic kernels instead of Python integers."""
+
+    def __init__(self, backend):
+        self.f = field_for(backend)
+
+    def _v(self, x):
+        return self.f.newVectorFrom([x % P])
+
+    def add(self, a, b):
+        return self.f.addVectorElements(self._v(a), self._v(b)).toValues()[0]
+
+    def mul(self, a, b):
+        return self.f.mulVectorElements(self._v(a), self._v(b)).toValues()[0]
+
+    def exp(self, a, e):
+        return self.f.expVectorElements(self._v(a), e).toValues()[0]
+
+
+def check_rescue_kat(backend):
+    import rescue_kat
+    assert rescue_kat.run(VecScalarField(backend)) == (302524937772545017647250309501879538110,
+                                                       205025454306577433144586673939030012640)

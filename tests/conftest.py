@@ -1,0 +1,58 @@
+import os
+import random
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+P = 2**128 - 9 * 2**32 + 1
+ORACLE_LIB = os.path.join(ROOT, 'oracle', 'liboracle.so')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def _build_oracle():
+    src = [os.path.join(ROOT, 'oracle', f) for f in ('oracle_abi.c', 'hashes.c', 'gf128.h', 'hashes.h')]
+    if not os.path.exists(ORACLE_LIB) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_LIB) for s in src):
+        subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), '-s'])
+    return ORACLE_LIB
+
+
+@pytest.fixture(scope='session')
+def oracle_backend():
+    """The CPU oracle's implementation of include/gstark.h (test double; never used by the product)."""
+    from genstark_amd._abi import Backend
+    return Backend(lib_path=_build_oracle(), allow_test_double=True)
+
+
+@pytest.fixture(scope='session')
+def hip_backend():
+    """The product backend: libgstark_hip.so on cuda:0 (raises without an MI355X)."""
+    from genstark_amd._abi import Backend
+    return Backend(device=0)
+
+
+def rand_elements(rng, n, edge=0.1):
+    edges = [0, 1, 2, P - 1, P - 2, 2**32 - 1, 2**32, 2**64 - 1, 2**64, 2**96, 2**127, 9 * 2**32 - 1, P - 9 * 2**32, P >> 1]
+    out = []
+    for _ in range(n):
+        out.append(rng.choice(edges) if rng.random() < edge else rng.randrange(P))
+    return out
+
+
+def to_bytes(vals):
+    return b''.join(int(v).to_bytes(16, 'little') for v in vals)
+
+
+def from_bytes(raw):
+    return [int.from_bytes(raw[i:i + 16], 'little') for i in range(0, len(raw), 16)]
+
+
+@pytest.fixture
+def rng():
+    return random.Random(0x4d694d43)

@@ -1,0 +1,87 @@
+"""tests/golden/make_golden.py — regenerates the committed fixtures.  Run in the BUILD container:
+
+    python tests/golden/make_golden.py
+
+1. oracle_proofs.json   — proofs, roots and positions produced by THIS repo's oracle (oracle/pyref.py) for
+                          small MiMC instances: the byte-exact targets of the GPU path.
+2. reference_vectors.json — outputs of the reference's OWN compiled modules that can run here
+                          (QueryIndexGenerator, Serializer, sizeOf, powLog2, read/writeBigInt), produced by
+                          gen_reference_vectors.js under node with /root/reference/bin/lib.  The reference's
+                          arithmetic packages are absent, so nothing else of the reference can be executed.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import pyref  # noqa: E402
+
+CASES = [
+    dict(name='mimc_T64_E16_blake2s', steps=64, extension_factor=16, exe_query_count=48, fri_query_count=24, hash_algorithm='blake2s256'),
+    dict(name='mimc_T64_E8_sha256', steps=64, extension_factor=8, exe_query_count=80, fri_query_count=40, hash_algorithm='sha256'),
+    dict(name='mimc_T256_E16_blake2s', steps=256, extension_factor=16, exe_query_count=48, fri_query_count=24, hash_algorithm='blake2s256'),
+    dict(name='mimc_T1024_E8_blake2s', steps=1024, extension_factor=8, exe_query_count=48, fri_query_count=24, hash_algorithm='blake2s256'),
+    dict(name='mimc_T1024_E16_sha256', steps=1024, extension_factor=16, exe_query_count=48, fri_query_count=64, hash_algorithm='sha256'),
+]
+
+
+def hexify_merkle(p):
+    return {'values': [v.hex() for v in p['values']], 'nodes': [[x.hex() for x in c] for c in p['nodes']], 'depth': p['depth']}
+
+
+def hexify(proof):
+    ld = proof['ldProof']
+    return {'evRoot': proof['evRoot'].hex(), 'evProof': hexify_merkle(proof['evProof']),
+            'ldProof': {'lcRoot': ld['lcRoot'].hex(), 'lcProof': hexify_merkle(ld['lcProof']),
+                        'components': [{'columnRoot': c['columnRoot'].hex(), 'columnProof': hexify_merkle(c['columnProof']),
+                                        'polyProof': hexify_merkle(c['polyProof'])} for c in ld['components']],
+                        'remainder': [str(v) for v in ld['remainder']]},
+            'iShapes': proof['iShapes']}
+
+
+def main():
+    oracle_out, for_node = [], []
+    for case in CASES:
+        kw = {k: v for k, v in case.items() if k != 'name'}
+        cfg = pyref.MimcConfig(**kw)
+        assertions = pyref.mimc_assertions(cfg)
+        proof, info = pyref.prove(cfg, assertions)
+        buf = pyref.serialize(cfg, proof)
+        assert len(buf) == pyref.size_of(proof)
+        assert pyref.verify(cfg, assertions, pyref.parse(cfg, buf))
+        rec = dict(case)
+        rec.update(seed=cfg.seed, root_of_unity=str(cfg.root), round_constants_sha256=hashlib.sha256(
+            b''.join(pyref.to_bytes(k) for k in cfg.rc)).hexdigest(),
+            assertions=[{'step': a['step'], 'register': a['register'], 'value': str(a['value'])} for a in assertions],
+            evRoot=info['evRoot'].hex(), lcRoot=info['lcRoot'].hex(), columnRoots=[r.hex() for r in info['columnRoots']],
+            exePositions=info['exePositions'], remainderLength=len(proof['ldProof']['remainder']),
+            friLayers=len(proof['ldProof']['components']), proofSize=len(buf),
+            proofSha256=hashlib.sha256(buf).hexdigest(), proofHex=buf.hex())
+        oracle_out.append(rec)
+        for_node.append({'name': case['name'], 'elementSize': 16, 'digestSize': 32, 'traceRegisterCount': 1, 'secretInputCount': 0,
+                         'proof': hexify(proof)})
+        print(case['name'], 'size', len(buf), 'layers', rec['friLayers'])
+    # a structurally richer synthetic proof for the wire-format test: 2 trace + 1 secret register, input shapes
+    syn = json.loads(json.dumps(for_node[0]))
+    syn['name'] = 'synthetic_shapes'
+    syn['traceRegisterCount'], syn['secretInputCount'] = 2, 1
+    syn['proof']['iShapes'] = [[1], [2, 4], []]
+    syn['proof']['evProof']['values'] = [(v * 3) for v in syn['proof']['evProof']['values']]  # 48-byte leaves
+    for_node.append(syn)
+    with open(os.path.join(HERE, 'oracle_proofs.json'), 'w') as f:
+        json.dump(oracle_out, f)
+    tmp = os.path.join(HERE, '_proofs_for_node.json')
+    with open(tmp, 'w') as f:
+        json.dump(for_node, f)
+    ref = os.environ.get('GENSTARK_REFERENCE', '/root/reference')
+    subprocess.check_call(['node', os.path.join(HERE, 'gen_reference_vectors.js'), os.path.join(ref, 'bin', 'lib'), tmp,
+                           os.path.join(HERE, 'reference_vectors.json')])
+    os.remove(tmp)
+
+
+if __name__ == '__main__':
+    main()

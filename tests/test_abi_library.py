@@ -1,0 +1,71 @@
+"""The C-ABI shared library loads and exports every symbol include/gstark.h declares (no compute calls:
+runs without a GPU).  Also unit-tests the device arithmetic header on the host."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import P, ROOT, rand_elements, to_bytes
+from genstark_amd import _abi
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'gstark.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(gs_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_and_binding_agree():
+    assert header_symbols() == sorted(_abi.EXPORTED_SYMBOLS)
+
+
+def test_hip_library_exports_every_symbol():
+    assert os.path.exists(_abi.HIP_LIB_PATH), 'run __graft_entry__.build() first'
+    lib = ctypes.CDLL(_abi.HIP_LIB_PATH)
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+    lib.gs_backend_name.restype = ctypes.c_char_p
+    assert lib.gs_backend_name() == b'hip-gfx950'
+    assert lib.gs_abi_version() == 1
+    buf = ctypes.create_string_buffer(16)
+    lib.gs_field_modulus(buf)
+    assert int.from_bytes(buf.raw, 'little') == P
+
+
+def test_product_refuses_the_oracle_backend(oracle_backend):
+    from conftest import ORACLE_LIB
+    with pytest.raises(_abi.GstarkError, match='refusing backend'):
+        _abi.Backend(lib_path=ORACLE_LIB)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(_abi.GstarkError, match='no CPU fallback|not found'):
+        _abi.Backend(lib_path=str(tmp_path / 'nope.so'))
+
+
+@pytest.mark.parametrize('compiler', ['g++', '/opt/rocm/lib/llvm/bin/clang++'])
+def test_device_field_header_on_host(tmp_path, compiler, rng):
+    """genstark_amd/csrc/gf128.cuh (the arithmetic every kernel uses) compiled for the host: both the
+    portable carry path (g++) and the __builtin_addc path the device build takes (clang)."""
+    if not os.path.exists(compiler) and compiler != 'g++':
+        pytest.skip('ROCm clang not present')
+    so = str(tmp_path / 'gf128_host.so')
+    subprocess.check_call([compiler, '-O2', '-shared', '-fPIC', '-o', so, os.path.join(ROOT, 'tests', 'host_harness', 'gf128_host.cpp')])
+    lib = ctypes.CDLL(so)
+    n = 20000
+    a, b = rand_elements(rng, n, edge=0.3), rand_elements(rng, n, edge=0.3)
+    A, B = to_bytes(a), to_bytes(b)
+
+    def run(fn, count, *bufs):
+        o = ctypes.create_string_buffer(16 * count)
+        getattr(lib, fn)(*bufs, o, count)
+        return [int.from_bytes(o.raw[16 * i:16 * i + 16], 'little') for i in range(count)]
+
+    assert run('h_mul', n, A, B) == [x * y % P for x, y in zip(a, b)]
+    assert run('h_add', n, A, B) == [(x + y) % P for x, y in zip(a, b)]
+    assert run('h_sub', n, A, B) == [(x - y) % P for x, y in zip(a, b)]
+    m = 300
+    assert run('h_inv', m, A[:16 * m]) == [pow(x, P - 2, P) for x in a[:m]]
+    assert run('h_pow', m, A[:16 * m], B[:16 * m]) == [pow(x, y, P) for x, y in zip(a[:m], b[:m])]
