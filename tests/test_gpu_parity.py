@@ -162,7 +162,7 @@ def test_prove_2p13_equals_oracle_and_verifies(hip_backend, oracle_backend, step
         datas.append(data)
         if be is hip_backend:
             assert stark.verify(assertions, stark.parse(data))
-            assert stark.securityLevel == (96 if ef == 16 else 72)
+            assert stark.securityLevel == (96 if ef == 16 else 67)   # floor(min(48*log2(E/3), 24*log2 E, 128)), lib/Stark.ts:62-77
     assert datas[0] == datas[1]
 
 

@@ -1,0 +1,19 @@
+"""tools/ntt_only.py — a few 2^24-point NTTs and nothing else (target for rocprofv3 --pmc passes)."""
+import ctypes as C
+import sys
+
+sys.path.insert(0, '.')
+from genstark_amd._abi import Backend  # noqa: E402
+from genstark_amd.field import PrimeField  # noqa: E402
+
+logn = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+be = Backend()
+f = PrimeField(backend=be)
+n = 1 << logn
+w = f.getRootOfUnity(n)
+a = f.getPowerSeries(0x123456789abcdef123, n)
+out = f.newVector(n)
+for _ in range(4):
+    be.call('gs_eval_polys_at_roots', C.c_void_p(a.ptr), 1, n, w.to_bytes(16, 'little'), n, C.c_void_p(out.ptr))
+be.sync()
+print('done')
