@@ -99,7 +99,10 @@ def main():
         torch.cuda.set_device(local_rank)
     assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
-    stream = torch.cuda.current_stream()
+    # a non-default torch stream: the library launches every kernel on it, so torch.cuda.Event timings see them
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     backend = Backend(device=local_rank, stream=stream.cuda_stream)
     steps, ef, fri = 1 << args.log_trace, args.extension_factor, args.fri_queries
     n = steps * ef
@@ -140,7 +143,7 @@ def main():
         logger = ga.Logger(echo=False, sync=backend.sync)
         s2 = make_stark(ga, backend, steps, ef, fri, logger)
         s2.prove(a, [], [seed])
-        phases = {label: round(ms, 3) for label, ms in logger.phases if not label.startswith('  ')}
+        phases = {label.strip(): round(ms, 3) for label, ms in logger.phases}
 
         # ---- roofline of the dominant kernel: one radix-256 NTT pass over n = T*E points
         import ctypes as C
