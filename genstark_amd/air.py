@@ -36,7 +36,9 @@ class _Context:
         self.constraints = [{'degree': 3}]
         self.inputShapes = []
         n = trace_length * air.extensionFactor
-        self.rootOfUnity = f.getRootOfUnity(n)
+        if air._rootOfUnity is None:
+            air._rootOfUnity = f.getRootOfUnity(n)
+        self.rootOfUnity = air._rootOfUnity
         self.compositionFactor = 4  # 2^ceil(log2(max constraint degree))
         self.roundConstants = air.roundConstants
         nk = len(self.roundConstants)
@@ -45,10 +47,15 @@ class _Context:
         self.cycleCount = trace_length // nk
         # cyclic register polynomial K (degree < nk) with K(g^i) = k_i, g of order nk: the register's
         # value on any x is K(x^cycleCount)
-        g = f.exp(self.rootOfUnity, air.extensionFactor * self.cycleCount)
-        ginv, ninv = f.inv(g), f.inv(nk)
-        self.kPoly = [sum(self.roundConstants[i] * f.exp(ginv, i * j) for i in range(nk)) * ninv % f.modulus
-                      for j in range(nk)]
+        if air._kPoly is None:
+            g = f.exp(self.rootOfUnity, air.extensionFactor * self.cycleCount)
+            ginv, ninv = f.inv(g), f.inv(nk)
+            pw = [1] * nk
+            for i in range(1, nk):
+                pw[i] = pw[i - 1] * ginv % f.modulus
+            air._kPoly = [sum(self.roundConstants[i] * pw[(i * j) % nk] for i in range(nk)) * ninv % f.modulus
+                          for j in range(nk)]
+        self.kPoly = air._kPoly
 
 
 class VerificationContext(_Context):
@@ -121,6 +128,8 @@ class MimcAir:
         if ef & (ef - 1) or ef < 2 * 2 ** 2 or ef > 32:
             raise GstarkError('Extension factor must be a power of 2 at least 2x the constraint degree and at most 32')
         self.roundConstants = sha256_prng(MIMC_SEED, constantCount, self.field)
+        self._rootOfUnity = None   # constants of the instantiated module, computed on first use
+        self._kPoly = None
 
     def initProvingContext(self, inputs=None, seed=None):
         if not seed:

@@ -136,7 +136,7 @@ class LowDegreeProver:
         self.verifyRemainder(proof['remainder'], maxDegreePlus1, rootOfUnity)
         return True
 
-    def verifyRemainder(self, remainder, maxDegreePlus1, rootOfUnity):  # :223-252 (<= 256 values, host scalars)
+    def verifyRemainder(self, remainder, maxDegreePlus1, rootOfUnity):  # :223-252 (<= 256 values)
         f = self.field
         ef = self.idxGenerator.extensionFactor
         positions = [i for i in range(len(remainder)) if not ef or i % ef]
@@ -146,13 +146,11 @@ class LowDegreeProver:
             x = f.mul(x, rootOfUnity)
         xs = [domain[positions[i]] for i in range(maxDegreePlus1)]
         ys = [remainder[positions[i]] for i in range(maxDegreePlus1)]
-        poly = f.interpolate(f.newVectorFrom(xs), f.newVectorFrom(ys)).toValues()
-        for i in range(maxDegreePlus1, len(positions)):
-            p = positions[i]
-            acc = 0
-            for c in reversed(poly):
-                acc = (acc * domain[p] + c) % f.modulus
-            if acc != remainder[p]:
+        poly = f.interpolateValues(xs, ys)
+        rest = positions[maxDegreePlus1:]
+        values = f.evalPolyAtMany(poly, [domain[p] for p in rest])
+        for p, v in zip(rest, values):
+            if v != remainder[p]:
                 raise StarkError(f'Remainder is not a valid degree {maxDegreePlus1 - 1} polynomial')
 
     # ---- parsers (:256-282)

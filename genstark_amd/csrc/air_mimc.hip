@@ -2,6 +2,7 @@
 // (examples/mimc/mimc128Assembly.ts:28-51): execution trace generation and transition-constraint
 // evaluation over the composition domain (lib/Stark.ts:97; lib/components/CompositionPolynomial.ts:76).
 #include "common.h"
+#include "host_field.h"
 
 // q[j] = p[(j + shift) mod nc] - (p[j]^3 + k[j mod klen])
 __global__ void k_mimc_constraints(const fe *__restrict__ p, uint64_t nc, uint64_t shift, const fe *__restrict__ k, uint64_t klen,
@@ -16,59 +17,28 @@ __global__ void k_mimc_constraints(const fe *__restrict__ p, uint64_t nc, uint64
 }
 
 // The MiMC recurrence x <- x^3 + k is a serial dependency chain (examples/mimc/utils.ts:7-15): like
-// the reference (generated JS over one input) it runs on one host core, here on native 64-bit limbs.
-typedef unsigned __int128 u128;
-static inline u128 host_reduce(u128 hi, u128 lo) {
-    const u128 C = (u128)0x8FFFFFFFFull;  // 2^128 mod p
-    const u128 P = ((u128)0xFFFFFFFFFFFFFFFFull << 64) | 0xFFFFFFF700000001ull;
-    u128 m0 = (u128)(uint64_t)hi * C, m1 = (u128)(uint64_t)(hi >> 64) * C;
-    u128 tl = m0 + (m1 << 64);
-    u128 th = (m1 >> 64) + (tl < m0);
-    u128 s = tl + lo;
-    unsigned k = s < tl;
-    u128 s2 = s + th * C;
-    k += s2 < s;
-    while (k) { u128 s3 = s2 + C; k -= 1; k += s3 < s2; s2 = s3; }
-    while (s2 >= P) s2 -= P;
-    return s2;
-}
-static inline u128 host_mul(u128 a, u128 b) {
-    uint64_t a0 = (uint64_t)a, a1 = (uint64_t)(a >> 64), b0 = (uint64_t)b, b1 = (uint64_t)(b >> 64);
-    u128 p00 = (u128)a0 * b0, p01 = (u128)a0 * b1, p10 = (u128)a1 * b0, p11 = (u128)a1 * b1;
-    u128 mid = p01 + p10, midc = mid < p01;
-    u128 lo = p00 + (mid << 64), c1 = lo < p00;
-    u128 hi = p11 + (mid >> 64) + (midc << 64) + c1;
-    return host_reduce(hi, lo);
-}
-static inline u128 host_add(u128 a, u128 b) {
-    const u128 P = ((u128)0xFFFFFFFFFFFFFFFFull << 64) | 0xFFFFFFF700000001ull;
-    u128 s = a + b;
-    if (s < a || s >= P) s -= P;
-    return s;
-}
-
+// the reference (generated JS over one input) it runs on one host core, here on native 64-bit limbs
+// (host_field.h), written straight into a pinned staging buffer that is then copied to the device.
 extern "C" {
 
 int gs_mimc_trace(gs_ctx *c, const uint8_t seed[16], const uint8_t *rc_host, uint32_t nrc, uint64_t steps, void *out) {
     if (!c || !seed || !rc_host || !out) return GS_ERR_ARG;
     if (!nrc || !steps) return gs_fail(c, GS_ERR_ARG, "mimc_trace: empty");
-    std::vector<u128> rc(nrc);
-    for (uint32_t i = 0; i < nrc; i++) memcpy(&rc[i], rc_host + 16 * i, 16);
-    void *h = nullptr;
-    GS_HIP(c, hipHostMalloc(&h, steps * 16, hipHostMallocDefault));
-    u128 *t = (u128 *)h;
-    u128 x;
-    memcpy(&x, seed, 16);
+    std::vector<hu128> rc(nrc);
+    for (uint32_t i = 0; i < nrc; i++) rc[i] = hf_load(rc_host + 16 * i);
+    int rcode = gs_stage_reserve(c, steps * 16);  // pinned, grow-only: no per-call page pinning
+    if (rcode) return rcode;
+    GS_HIP(c, hipStreamSynchronize(c->stream));   // earlier users of the staging buffer are done
+    hu128 *t = (hu128 *)c->h_stage;
+    hu128 x = hf_load(seed);
     uint32_t ri = 0;
     for (uint64_t i = 0; i < steps; i++) {
         t[i] = x;
-        x = host_add(host_mul(host_mul(x, x), x), rc[ri]);
+        x = hf_add(hf_mul(hf_mul(x, x), x), rc[ri]);
         if (++ri == nrc) ri = 0;
     }
-    hipError_t e = hipMemcpyAsync(out, h, steps * 16, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipHostFree(h);
-    if (e != hipSuccess) return gs_fail(c, GS_ERR_DEVICE, "mimc_trace copy: %s", hipGetErrorString(e));
+    GS_HIP(c, hipMemcpyAsync(out, c->h_stage, steps * 16, hipMemcpyHostToDevice, c->stream));
+    GS_HIP(c, hipStreamSynchronize(c->stream));
     return GS_OK;
 }
 

@@ -1,0 +1,50 @@
+// host_field.h — GF(p) arithmetic on native 64-bit limbs for the few HOST-side pieces of the library:
+// the serial MiMC recurrence (air_mimc.hip) and O(n^2) Lagrange interpolation of <= a few hundred points
+// (small.hip).  Same modulus and canonical representation as gf128.cuh.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+typedef unsigned __int128 hu128;
+
+static inline hu128 hf_p() { return ((hu128)0xFFFFFFFFFFFFFFFFull << 64) | 0xFFFFFFF700000001ull; }
+static const hu128 HF_C = (hu128)0x8FFFFFFFFull;  // 2^128 mod p
+
+static inline hu128 hf_reduce(hu128 hi, hu128 lo) {
+    hu128 m0 = (hu128)(uint64_t)hi * HF_C, m1 = (hu128)(uint64_t)(hi >> 64) * HF_C;
+    hu128 tl = m0 + (m1 << 64);
+    hu128 th = (m1 >> 64) + (tl < m0);
+    hu128 s = tl + lo;
+    unsigned k = s < tl;
+    hu128 s2 = s + th * HF_C;
+    k += s2 < s;
+    while (k) { hu128 s3 = s2 + HF_C; k -= 1; k += s3 < s2; s2 = s3; }
+    while (s2 >= hf_p()) s2 -= hf_p();
+    return s2;
+}
+static inline hu128 hf_mul(hu128 a, hu128 b) {
+    uint64_t a0 = (uint64_t)a, a1 = (uint64_t)(a >> 64), b0 = (uint64_t)b, b1 = (uint64_t)(b >> 64);
+    hu128 p00 = (hu128)a0 * b0, p01 = (hu128)a0 * b1, p10 = (hu128)a1 * b0, p11 = (hu128)a1 * b1;
+    hu128 mid = p01 + p10, midc = mid < p01;
+    hu128 lo = p00 + (mid << 64), c1 = lo < p00;
+    hu128 hi = p11 + (mid >> 64) + (midc << 64) + c1;
+    return hf_reduce(hi, lo);
+}
+static inline hu128 hf_add(hu128 a, hu128 b) {
+    hu128 s = a + b;
+    if (s < a || s >= hf_p()) s -= hf_p();
+    return s;
+}
+static inline hu128 hf_sub(hu128 a, hu128 b) { return a >= b ? a - b : a - b + hf_p(); }
+static inline hu128 hf_pow(hu128 b, hu128 e) {
+    hu128 r = 1;
+    while (e) {
+        if (e & 1) r = hf_mul(r, b);
+        b = hf_mul(b, b);
+        e >>= 1;
+    }
+    return r;
+}
+static inline hu128 hf_inv(hu128 a) { return a ? hf_pow(a, hf_p() - 2) : 0; }
+static inline hu128 hf_load(const uint8_t *b) { hu128 v; memcpy(&v, b, 16); return v; }
+static inline void hf_store(uint8_t *b, hu128 v) { memcpy(b, &v, 16); }

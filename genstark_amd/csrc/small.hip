@@ -1,0 +1,124 @@
+// small.hip — host-side pieces of the galois / merkle surface that only ever see a few hundred values:
+//   * FiniteField.interpolate(xs, ys) — general Lagrange interpolation (BoundaryConstraints.ts:42: one point per
+//     assertion; LowDegreeProver.ts:243: <= 256 remainder values) and evalPolyAt over a point list (:248).
+//     O(n^2) on native 64-bit limbs; the reference does the same work in its JS layer.
+//   * MerkleTree.proveBatch(indexes) — the authentication-path PLAN is host logic over <= 256 indexes; the digests it
+//     selects are fetched from the device-resident tree by ONE gather kernel and one device->host copy.
+#include <algorithm>
+
+#include "common.h"
+#include "host_field.h"
+
+extern "C" {
+
+int gs_small_interpolate(const uint8_t *xs_host, const uint8_t *ys_host, uint32_t n, uint8_t *coeffs_out) {
+    if (!xs_host || !ys_host || !coeffs_out || n == 0 || n > 4096) return GS_ERR_ARG;
+    std::vector<hu128> x(n), y(n), master(n + 1, 0), q(n), out(n, 0);
+    for (uint32_t i = 0; i < n; i++) { x[i] = hf_load(xs_host + 16 * i); y[i] = hf_load(ys_host + 16 * i); }
+    // master polynomial M(X) = prod (X - x_i)
+    master[0] = 1;
+    for (uint32_t i = 0; i < n; i++) {
+        hu128 nx = hf_sub(0, x[i]);
+        for (uint32_t d = i + 1; d >= 1; d--) master[d] = hf_add(master[d - 1], hf_mul(master[d], nx));
+        master[0] = hf_mul(master[0], nx);
+    }
+    for (uint32_t j = 0; j < n; j++) {
+        // q = M / (X - x_j) by synthetic division; the Lagrange denominator is q(x_j)
+        hu128 carry = 0;
+        for (uint32_t d = n; d >= 1; d--) {
+            carry = hf_add(master[d], hf_mul(carry, x[j]));
+            q[d - 1] = carry;
+        }
+        hu128 den = 0;
+        for (uint32_t d = n; d-- > 0;) den = hf_add(hf_mul(den, x[j]), q[d]);
+        hu128 s = hf_mul(y[j], hf_inv(den));
+        for (uint32_t d = 0; d < n; d++) out[d] = hf_add(out[d], hf_mul(q[d], s));
+    }
+    for (uint32_t d = 0; d < n; d++) hf_store(coeffs_out + 16 * d, out[d]);
+    return GS_OK;
+}
+
+int gs_small_eval_poly(const uint8_t *poly_host, uint32_t len, const uint8_t *xs_host, uint32_t m, uint8_t *out_host) {
+    if ((!poly_host && len) || (!xs_host && m) || (!out_host && m)) return GS_ERR_ARG;
+    std::vector<hu128> p(len);
+    for (uint32_t i = 0; i < len; i++) p[i] = hf_load(poly_host + 16 * i);
+    for (uint32_t i = 0; i < m; i++) {
+        hu128 x = hf_load(xs_host + 16 * i), s = 0;
+        for (uint32_t k = len; k-- > 0;) s = hf_add(hf_mul(s, x), p[k]);
+        hf_store(out_host + 16 * i, s);
+    }
+    return GS_OK;
+}
+
+}  // extern "C"
+
+// digest j of the output comes from leaves (src_sel = 0) or nodes (src_sel = 1) at index idx
+__global__ void k_gather_digests(const uint4 *__restrict__ leaves, const uint4 *__restrict__ nodes,
+                                 const uint64_t *__restrict__ sel_idx, uint32_t count, uint4 *__restrict__ out) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * 2) return;
+    uint64_t e = sel_idx[t >> 1];
+    const uint4 *src = (e >> 63) ? nodes : leaves;
+    out[t] = src[((e & ~(1ull << 63)) << 1) + (t & 1)];
+}
+
+extern "C" int gs_merkle_prove_batch(gs_ctx *c, const void *leaves, const void *nodes, uint64_t n, const uint64_t *idx_host,
+                                     uint32_t count, uint8_t *values_out, uint32_t *ncols_out, uint32_t *col_lens_out,
+                                     uint8_t *nodes_out, uint64_t nodes_cap) {
+    if (!c || !leaves || !nodes || !idx_host || !values_out || !ncols_out || !col_lens_out || !nodes_out) return GS_ERR_ARG;
+    if (!gs_is_pow2(n) || n < 2 || count == 0) return gs_fail(c, GS_ERR_ARG, "merkle_prove_batch: n must be a power of two >= 2, count > 0");
+    const int depth = gs_log2(n);
+    const uint64_t NODE = 1ull << 63;
+    std::vector<uint64_t> sorted(idx_host, idx_host + count);
+    for (uint32_t i = 0; i < count; i++)
+        if (idx_host[i] >= n) return gs_fail(c, GS_ERR_ARG, "merkle_prove_batch: index %llu out of range", (unsigned long long)idx_host[i]);
+    std::sort(sorted.begin(), sorted.end());
+    for (uint32_t i = 1; i < count; i++)
+        if (sorted[i] == sorted[i - 1]) return gs_fail(c, GS_ERR_ARG, "merkle_prove_batch: repeating indexes");
+    // fetch list: first the requested leaves (request order), then the column entries in column-major order
+    std::vector<uint64_t> fetch(idx_host, idx_host + count);
+    std::vector<uint64_t> cur;
+    std::vector<std::vector<uint64_t>> cols;
+    for (uint32_t i = 0; i < count;) {
+        uint64_t e = sorted[i] & ~1ull;
+        bool has0 = false, has1 = false;
+        while (i < count && (sorted[i] & ~1ull) == e) { (sorted[i] & 1 ? has1 : has0) = true; i++; }
+        cols.emplace_back();
+        if (has0 && !has1) cols.back().push_back(e + 1);
+        else if (!has0 && has1) cols.back().push_back(e);
+        cur.push_back((e + n) >> 1);
+    }
+    std::vector<uint64_t> nxt;
+    for (int d = depth - 1; d > 0; d--) {
+        nxt.clear();
+        for (size_t i = 0; i < cur.size(); i++) {
+            uint64_t sib = cur[i] ^ 1;
+            if (i + 1 < cur.size() && cur[i + 1] == sib) i++;
+            else cols[i].push_back(sib | NODE);
+            nxt.push_back(sib >> 1);
+        }
+        cur.swap(nxt);
+    }
+    uint64_t total = 0;
+    for (auto &col : cols) total += col.size();
+    if (total > nodes_cap) return gs_fail(c, GS_ERR_ARG, "merkle_prove_batch: nodes_out too small (%llu digests needed)", (unsigned long long)total);
+    for (auto &col : cols) fetch.insert(fetch.end(), col.begin(), col.end());
+    const uint64_t nf = fetch.size();
+    const uint64_t idx_bytes = (nf * 8 + 255) & ~(uint64_t)255, data_bytes = nf * 32;
+    int rc = gs_stage_reserve(c, idx_bytes + data_bytes);
+    if (rc) return rc;
+    memcpy(c->h_stage, fetch.data(), nf * 8);
+    GS_HIP(c, hipMemcpyAsync(c->d_stage, c->h_stage, nf * 8, hipMemcpyHostToDevice, c->stream));
+    uint8_t *d_out = (uint8_t *)c->d_stage + idx_bytes;
+    hipLaunchKernelGGL(k_gather_digests, dim3((unsigned)((nf * 2 + 255) / 256)), dim3(256), 0, c->stream, (const uint4 *)leaves,
+                       (const uint4 *)nodes, (const uint64_t *)c->d_stage, (uint32_t)nf, (uint4 *)d_out);
+    GS_LAUNCH_CHECK(c);
+    uint8_t *h_out = (uint8_t *)c->h_stage + idx_bytes;
+    GS_HIP(c, hipMemcpyAsync(h_out, d_out, data_bytes, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP(c, hipStreamSynchronize(c->stream));
+    memcpy(values_out, h_out, (size_t)count * 32);
+    memcpy(nodes_out, h_out + (size_t)count * 32, (size_t)total * 32);
+    *ncols_out = (uint32_t)cols.size();
+    for (size_t i = 0; i < cols.size(); i++) col_lens_out[i] = (uint32_t)cols[i].size();
+    return GS_OK;
+}

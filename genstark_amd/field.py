@@ -351,25 +351,34 @@ class PrimeField:
         return self.newVectorFrom(out)
 
     def interpolate(self, xs, ys):
-        """BoundaryConstraints.ts:42; LowDegreeProver.ts:243 — Lagrange through a handful of points."""
-        xv, yv = xs.toValues(), ys.toValues()
-        n, p = len(xv), self.modulus
-        out = [0] * n
-        for j in range(n):
-            num, den = [1], 1
-            for m in range(n):
-                if m == j:
-                    continue
-                nxt = [0] * (len(num) + 1)
-                for d, c in enumerate(num):
-                    nxt[d] = (nxt[d] - c * xv[m]) % p
-                    nxt[d + 1] = (nxt[d + 1] + c) % p
-                num = nxt
-                den = den * (xv[j] - xv[m]) % p
-            s = yv[j] * self.inv(den) % p
-            for d in range(n):
-                out[d] = (out[d] + num[d] * s) % p
-        return self.newVectorFrom(out)
+        """BoundaryConstraints.ts:42; LowDegreeProver.ts:243 — Lagrange through a handful of points: O(n^2) host
+        arithmetic inside the library (gs_small_interpolate), as in the reference's JS layer."""
+        xv = xs if isinstance(xs, (list, tuple)) else xs.toValues()
+        yv = ys if isinstance(ys, (list, tuple)) else ys.toValues()
+        if len(xv) != len(yv):
+            raise GstarkError('Number of x coordinates must be the same as number of y coordinates')
+        return self.newVectorFrom(self.interpolateValues(xv, yv))
+
+    def interpolateValues(self, xv, yv):
+        n = len(xv)
+        out = C.create_string_buffer(16 * n)
+        rc = self.backend.lib.gs_small_interpolate(b''.join(_le(x % self.modulus) for x in xv),
+                                                   b''.join(_le(y % self.modulus) for y in yv), n, C.cast(out, C.c_void_p))
+        if rc:
+            raise GstarkError(f'gs_small_interpolate failed ({rc})')
+        raw = out.raw
+        return [int.from_bytes(raw[16 * i:16 * i + 16], 'little') for i in range(n)]
+
+    def evalPolyAtMany(self, poly_values, xs):
+        """evalPolyAt over a list of points (LowDegreeProver.ts:246-251), host arithmetic inside the library."""
+        m = len(xs)
+        out = C.create_string_buffer(16 * max(m, 1))
+        rc = self.backend.lib.gs_small_eval_poly(b''.join(_le(c) for c in poly_values), len(poly_values),
+                                                 b''.join(_le(x) for x in xs), m, C.cast(out, C.c_void_p))
+        if rc:
+            raise GstarkError(f'gs_small_eval_poly failed ({rc})')
+        raw = out.raw
+        return [int.from_bytes(raw[16 * i:16 * i + 16], 'little') for i in range(m)]
 
     def interpolateQuarticBatch(self, xs, ys):
         """LowDegreeProver.ts:137,191 — one cubic per row.  When xs is the transposed power-series domain

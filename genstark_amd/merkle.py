@@ -103,46 +103,33 @@ class MerkleTree:
         return self._root
 
     def proveBatch(self, indexes):
-        """lib/Stark.ts:150; LowDegreeProver.ts:52,213,216 -> {values, nodes, depth}.  Layout restated
-        from the merkle package's documented batch proof (node ORDER UNVERIFIED):
-        values in request order; one node column per distinct leaf pair (ascending), holding the
-        sibling leaf when it was not requested, then, level by level, the siblings that cannot be
-        recomputed from other requested paths."""
+        """lib/Stark.ts:150; LowDegreeProver.ts:52,213,216 -> {values, nodes, depth}.  One library call: the
+        authentication-path plan is computed on the host, every digest it needs is fetched from the device-resident
+        tree by one gather.  Layout restated from the merkle package's documented batch proof (node ORDER
+        UNVERIFIED): values in request order; one node column per distinct leaf pair
+        (ascending), holding the sibling leaf when it was not requested, then, level by level, the siblings that
+        cannot be recomputed from other requested paths."""
         n = self.values.length
-        index_map = _map_indexes(indexes, n - 1)
-        norm = _normalize(indexes)
-        # pass 1: decide which leaves / nodes are needed (host), then fetch them in two gathers
-        leaf_need, node_need = [], []
-        plan_values = [None] * len(indexes)
-        plan_nodes = [[] for _ in norm]
-        nxt = []
-        for i, ix in enumerate(norm):
-            i1, i2 = index_map.get(ix), index_map.get(ix + 1)
-            if i1 is not None:
-                plan_values[i1] = len(leaf_need); leaf_need.append(ix)
-                if i2 is not None:
-                    plan_values[i2] = len(leaf_need); leaf_need.append(ix + 1)
-                else:
-                    plan_nodes[i].append(('leaf', len(leaf_need))); leaf_need.append(ix + 1)
-            else:
-                plan_values[i2] = len(leaf_need); leaf_need.append(ix + 1)
-                plan_nodes[i].append(('leaf', len(leaf_need))); leaf_need.append(ix)
-            nxt.append((ix + n) >> 1)
-        for _ in range(self.depth - 1, 0, -1):
-            cur, nxt, i = nxt, [], 0
-            while i < len(cur):
-                sib = cur[i] ^ 1
-                if i + 1 < len(cur) and cur[i + 1] == sib:
-                    i += 1
-                else:
-                    plan_nodes[i].append(('node', len(node_need))); node_need.append(sib)
-                nxt.append(sib >> 1)
-                i += 1
-        leaves = self.values.valuesAt(leaf_need)
-        nodes = self.nodes.valuesAt(node_need)
-        pick = lambda t: leaves[t[1]] if t[0] == 'leaf' else nodes[t[1]]
-        return {'values': [leaves[k] for k in plan_values],
-                'nodes': [[pick(t) for t in col] for col in plan_nodes],
+        indexes = list(indexes)
+        _map_indexes(indexes, n - 1)
+        count = len(indexes)
+        if count == 0:
+            return {'values': [], 'nodes': [], 'depth': self.depth}
+        idx = (C.c_uint64 * count)(*indexes)
+        values = C.create_string_buffer(count * DIGEST_SIZE)
+        cap = count * max(self.depth, 1)
+        nodes = C.create_string_buffer(cap * DIGEST_SIZE)
+        ncols = C.c_uint32()
+        col_lens = (C.c_uint32 * count)()
+        self.hash.backend.call('gs_merkle_prove_batch', C.c_void_p(self.values.ptr), C.c_void_p(self.nodes.ptr), n, idx, count,
+                               C.cast(values, C.c_void_p), C.byref(ncols), col_lens, C.cast(nodes, C.c_void_p), cap)
+        vraw, nraw = values.raw, nodes.raw
+        out_nodes, o = [], 0
+        for i in range(ncols.value):
+            k = col_lens[i]
+            out_nodes.append([nraw[(o + t) * DIGEST_SIZE:(o + t + 1) * DIGEST_SIZE] for t in range(k)])
+            o += k
+        return {'values': [vraw[i * DIGEST_SIZE:(i + 1) * DIGEST_SIZE] for i in range(count)], 'nodes': out_nodes,
                 'depth': self.depth}
 
     @staticmethod

@@ -158,6 +158,24 @@ int gs_hash_digest_values(gs_ctx *ctx, gs_hash_alg alg, const void *buf, uint64_
  * (.root / .proveBatch read nodes through gs_gather.) */
 int gs_merkle_build(gs_ctx *ctx, gs_hash_alg alg, const void *leaves, uint64_t n, void *nodes);
 
+/* MerkleTree.proveBatch(indexes): lib/Stark.ts:150; LowDegreeProver.ts:52,213,216.  Plans the batch proof on the
+ * host and fetches every needed digest in one device gather.  Outputs (host): values_out = count digests in
+ * REQUEST order; *ncols_out = number of node columns (one per distinct leaf pair, ascending); col_lens_out[i] =
+ * digests in column i (capacity `count` entries); nodes_out = the columns concatenated (capacity nodes_cap digests,
+ * count * log2(n) always suffices).  Column layout: SURVEY.md appendix A.7 (sibling leaf first when it was not
+ * itself requested, then per level the sibling nodes that are not on another requested path). */
+int gs_merkle_prove_batch(gs_ctx *ctx, const void *leaves, const void *nodes, uint64_t n, const uint64_t *idx_host,
+                          uint32_t count, uint8_t *values_out, uint32_t *ncols_out, uint32_t *col_lens_out,
+                          uint8_t *nodes_out, uint64_t nodes_cap);
+
+/* ---- small-polynomial host arithmetic ----------------------------------------------------------------
+ * FiniteField.interpolate(xs, ys) (Lagrange; BoundaryConstraints.ts:42, LowDegreeProver.ts:243) and evalPolyAt over a
+ * list of points (LowDegreeProver.ts:248) are only ever called with at most a few hundred points (#assertions,
+ * <= 256 remainder values).  They are O(n^2) host arithmetic in the reference's JS layer and stay host arithmetic
+ * here (native 64-bit limbs); all pointers are HOST pointers, n <= 4096. */
+int gs_small_interpolate(const uint8_t *xs_host, const uint8_t *ys_host, uint32_t n, uint8_t *coeffs_out);
+int gs_small_eval_poly(const uint8_t *poly_host, uint32_t len, const uint8_t *xs_host, uint32_t m, uint8_t *out_host);
+
 /* ---- AIR (air-assembly ProvingContext, MiMC instance) ------------------------------------------ */
 /* context.generateExecutionTrace() for the MiMC AIR of examples/mimc/mimc128Assembly.ts:28-51:
  * trace[0] = seed, trace[i+1] = trace[i]^3 + rc[i mod nrc] (examples/mimc/utils.ts:7-15).

@@ -320,3 +320,105 @@ int gs_mimc_constraints(gs_ctx *c, const void *p, uint64_t nc, uint64_t shift, c
     }
     return GS_OK;
 }
+
+/* ---- MerkleTree.proveBatch restated (same layout as oracle/pyref.py MerkleTree.prove_batch) ---- */
+static int cmp_u64(const void *a, const void *b) {
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : x > y;
+}
+int gs_merkle_prove_batch(gs_ctx *c, const void *leaves, const void *nodes, uint64_t n, const uint64_t *idx, uint32_t count,
+                          uint8_t *values_out, uint32_t *ncols_out, uint32_t *col_lens, uint8_t *nodes_out, uint64_t cap) {
+    if (!is_pow2(n) || n < 2 || !count) return fail(c, GS_ERR_ARG, "merkle_prove_batch: bad arguments");
+    const uint8_t *lv = (const uint8_t *)leaves, *nd = (const uint8_t *)nodes;
+    uint64_t *sorted = (uint64_t *)malloc(count * sizeof(uint64_t) * 4);
+    if (!sorted) return fail(c, GS_ERR_OOM, "malloc failed");
+    uint64_t *norm = sorted + count, *cur = norm + count, *nxt = cur + count;
+    for (uint32_t i = 0; i < count; i++) {
+        if (idx[i] >= n) { free(sorted); return fail(c, GS_ERR_ARG, "merkle_prove_batch: index out of range"); }
+        sorted[i] = idx[i];
+        memcpy(values_out + 32 * (uint64_t)i, lv + 32 * idx[i], 32);
+    }
+    qsort(sorted, count, sizeof(uint64_t), cmp_u64);
+    uint32_t ncols = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        if (i && sorted[i] == sorted[i - 1]) { free(sorted); return fail(c, GS_ERR_ARG, "merkle_prove_batch: repeating indexes"); }
+        uint64_t e = sorted[i] & ~1ull;
+        if (!ncols || norm[ncols - 1] != e) norm[ncols++] = e;
+    }
+    /* column storage: per column up to depth digests */
+    int depth = 0;
+    while ((1ull << depth) < n) depth++;
+    uint8_t *cols = (uint8_t *)malloc((size_t)ncols * depth * 32);
+    if (!cols) { free(sorted); return fail(c, GS_ERR_OOM, "malloc failed"); }
+    for (uint32_t i = 0; i < ncols; i++) col_lens[i] = 0;
+#define PUSH(col, src) do { memcpy(cols + ((size_t)(col) * depth + col_lens[col]) * 32, (src), 32); col_lens[col]++; } while (0)
+    uint32_t pos = 0; /* walk sorted[] alongside norm[] to know which of the pair was requested */
+    for (uint32_t i = 0; i < ncols; i++) {
+        uint64_t e = norm[i];
+        int has0 = 0, has1 = 0;
+        while (pos < count && (sorted[pos] & ~1ull) == e) { if (sorted[pos] & 1) has1 = 1; else has0 = 1; pos++; }
+        if (has0 && !has1) PUSH(i, lv + 32 * (e + 1));
+        else if (!has0 && has1) PUSH(i, lv + 32 * e);
+        cur[i] = (e + n) >> 1;
+    }
+    uint32_t len = ncols;
+    for (int d = depth - 1; d > 0; d--) {
+        uint32_t nl = 0;
+        for (uint32_t i = 0; i < len; i++) {
+            uint64_t sib = cur[i] ^ 1;
+            if (i + 1 < len && cur[i + 1] == sib) i++;
+            else PUSH(i, nd + 32 * sib);
+            nxt[nl++] = sib >> 1;
+        }
+        uint64_t *t = cur; cur = nxt; nxt = t;
+        len = nl;
+    }
+#undef PUSH
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < ncols; i++) total += col_lens[i];
+    int rc = GS_OK;
+    if (total > cap) rc = fail(c, GS_ERR_ARG, "merkle_prove_batch: nodes_out too small");
+    else {
+        uint64_t o = 0;
+        for (uint32_t i = 0; i < ncols; i++) { memcpy(nodes_out + 32 * o, cols + (size_t)i * depth * 32, 32 * (size_t)col_lens[i]); o += col_lens[i]; }
+        *ncols_out = ncols;
+    }
+    free(cols);
+    free(sorted);
+    return rc;
+}
+
+int gs_small_interpolate(const uint8_t *xs, const uint8_t *ys, uint32_t n, uint8_t *out) {
+    if (n == 0 || n > 4096) return GS_ERR_ARG;
+    fe *x = (fe *)malloc(sizeof(fe) * n * 4);
+    if (!x) return GS_ERR_OOM;
+    fe *y = x + n, *num = y + n, *acc = num + n;
+    for (uint32_t i = 0; i < n; i++) { x[i] = fe_load(xs + 16 * i); y[i] = fe_load(ys + 16 * i); acc[i] = 0; }
+    for (uint32_t j = 0; j < n; j++) { /* plain O(n^2)-per-basis Lagrange: rebuild each numerator from scratch */
+        uint32_t deg = 0;
+        fe den = 1;
+        num[0] = 1;
+        for (uint32_t m = 0; m < n; m++) {
+            if (m == j) continue;
+            fe nx = fe_neg(x[m]);
+            num[deg + 1] = num[deg];
+            for (uint32_t d = deg; d >= 1; d--) num[d] = fe_add(num[d - 1], fe_mul(num[d], nx));
+            num[0] = fe_mul(num[0], nx);
+            deg++;
+            den = fe_mul(den, fe_sub(x[j], x[m]));
+        }
+        fe s = fe_mul(y[j], fe_inv(den));
+        for (uint32_t d = 0; d < n; d++) acc[d] = fe_add(acc[d], fe_mul(num[d], s));
+    }
+    for (uint32_t d = 0; d < n; d++) fe_store(out + 16 * d, acc[d]);
+    free(x);
+    return GS_OK;
+}
+int gs_small_eval_poly(const uint8_t *poly, uint32_t len, const uint8_t *xs, uint32_t m, uint8_t *out) {
+    for (uint32_t i = 0; i < m; i++) {
+        fe x = fe_load(xs + 16 * i), s = 0;
+        for (uint32_t k = len; k-- > 0;) s = fe_add(fe_mul(s, x), fe_load(poly + 16 * k));
+        fe_store(out + 16 * i, s);
+    }
+    return GS_OK;
+}
