@@ -80,7 +80,10 @@ def main():
     ap.add_argument('--fri-queries', type=int, default=64)
     ap.add_argument('--cpu-log-trace', type=int, default=16, help='trace length of the bounded CPU-baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    # test-only: drive the distributed harness on CPU (gloo) against the oracle's implementation of the C ABI
+    ap.add_argument('--test-double-lib', default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    cpu_mode = args.test_double_lib is not None
 
     import torch
     import genstark_amd as ga
@@ -92,27 +95,37 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if cpu_mode:
+            dist.init_process_group('gloo')
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # nccl == RCCL on ROCm
     else:
         dist = None
-        torch.cuda.set_device(local_rank)
+        if not cpu_mode:
+            torch.cuda.set_device(local_rank)
     assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
-    # a non-default torch stream: the library launches every kernel on it, so torch.cuda.Event timings see them
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
-    backend = Backend(device=local_rank, stream=stream.cuda_stream)
+    if cpu_mode:
+        stream = None
+        backend = Backend(lib_path=args.test_double_lib, allow_test_double=True)
+    else:
+        # a non-default torch stream: the library launches every kernel on it, so torch.cuda.Event timings see them
+        stream = torch.cuda.Stream()
+        torch.cuda.set_stream(stream)
+        assert stream.cuda_stream != 0
+        backend = Backend(device=local_rank, stream=stream.cuda_stream)
     steps, ef, fri = 1 << args.log_trace, args.extension_factor, args.fri_queries
     n = steps * ef
     seed = 3 + rank
 
     def barrier():
-        torch.cuda.synchronize()
+        if not cpu_mode:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not cpu_mode:
+            torch.cuda.synchronize()
 
     stark = make_stark(ga, backend, steps, ef, fri)
     a = assertions_for(stark, steps, seed)
@@ -126,7 +139,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        t = torch.tensor([elapsed], device='cpu' if cpu_mode else 'cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -134,11 +147,22 @@ def main():
     # outside the timed region: the proof is valid and the wire format is consistent (reference acceptance criterion)
     data = stark.serialize(proof)
     assert len(data) == stark.sizeOf(proof)
-    if rank == 0:
+    if rank == 0 or cpu_mode:
         assert stark.verify(a, stark.parse(data))
+    if dist is not None:
+        # every rank proved its OWN trace: the evaluation roots must all differ (no rank idled or duplicated work)
+        roots = [None] * world
+        dist.all_gather_object(roots, proof['evRoot'].hex())
+        assert len(set(roots)) == world, 'ranks produced identical proofs'
 
     out = None
-    if rank == 0:
+    if rank == 0 and cpu_mode:
+        points = ntt_points_per_prove(steps, ef)
+        out = {'metric': 'NTT GF(p) elements/sec over whole prove() (MiMC-128)', 'value': points * world / (ms_per_step * 1e-3),
+               'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'data': 'synthetic', 'test_double': True,
+               'config': {'workload': f'MiMC-128 prove(), 2^{args.log_trace} steps', 'ntt_points_per_prove': points}}
+    elif rank == 0:
         # ---- per-phase breakdown (labels of README.md:62-73), one extra instrumented prove() outside the timed region
         logger = ga.Logger(echo=False, sync=backend.sync)
         s2 = make_stark(ga, backend, steps, ef, fri, logger)

@@ -1,0 +1,270 @@
+'use strict';
+// js/galois.js — drop-in for the `@guildofweavers/galois` surface genSTARK uses (SURVEY.md section 8b):
+// createPrimeField(modulus) -> FiniteField whose Vector / Matrix objects live in MI355X HBM and whose vector,
+// matrix and polynomial members each forward to one entry point of include/gstark.h through the N-API shim
+// (napi/gstark_napi.node -> libgstark_hip.so).  Scalar bigint members stay JS BigInt arithmetic, as upstream.
+const crypto = require('crypto');
+const path = require('path');
+
+const MODULUS = 2n ** 128n - 9n * 2n ** 32n + 1n;
+const ELEMENT_SIZE = 16;
+
+let addon = null;
+function native() {
+    if (!addon) {
+        addon = require(path.join(__dirname, '..', 'napi', 'gstark_napi.node'));
+        const lib = process.env.GSTARK_LIB || path.join(__dirname, '..', 'genstark_amd', 'csrc', 'libgstark_hip.so');
+        const name = addon.load(lib);
+        if (name !== 'hip-gfx950' && process.env.GSTARK_ALLOW_TEST_DOUBLE !== '1') {
+            throw new Error(`refusing backend ${name}: the product path runs on hip-gfx950 only (no CPU fallback)`);
+        }
+    }
+    return addon;
+}
+
+function le(v) {  // bigint -> 16-byte little-endian Buffer (lib/utils/serialization.ts:140-146 layout)
+    const b = Buffer.alloc(ELEMENT_SIZE);
+    let x = BigInt(v);
+    for (let i = 0; i < ELEMENT_SIZE; i++) { b[i] = Number(x & 0xFFn); x >>= 8n; }
+    return b;
+}
+function fromLe(buf, off = 0, size = ELEMENT_SIZE) {
+    let v = 0n;
+    for (let i = size - 1; i >= 0; i--) v = (v << 8n) | BigInt(buf[off + i]);
+    return v;
+}
+function sha256(value) {  // same helper as lib/components/QueryIndexGenerator.ts:61-67
+    const buffer = (typeof value === 'bigint') ? Buffer.from(value.toString(16), 'hex') : value;
+    return BigInt('0x' + crypto.createHash('sha256').update(buffer).digest().toString('hex'));
+}
+
+const registry = (typeof FinalizationRegistry !== 'undefined')
+    ? new FinalizationRegistry(({ ctx, ptr }) => { try { native().call('gs_free', ctx, ptr); } catch (e) { /* context gone */ } })
+    : null;
+
+class DeviceBuffer {
+    constructor(field, bytes) {
+        this.field = field;
+        this.ptr = native().alloc(field.ctx, bytes > 16 ? bytes : 16);
+        if (registry) registry.register(this, { ctx: field.ctx, ptr: this.ptr });
+    }
+}
+
+class Vector {
+    constructor(field, length, owner, offset = 0n, elementSize = ELEMENT_SIZE) {
+        this.field = field; this.length = length; this.elementSize = elementSize;
+        this.owner = owner || new DeviceBuffer(field, length * elementSize);
+        this.offset = offset;
+        this.seriesBase = undefined;
+    }
+    get ptr() { return this.owner.ptr + this.offset; }
+    get byteLength() { return this.length * this.elementSize; }
+    toBuffer(start = 0, count) {
+        count = (count === undefined) ? this.length - start : count;
+        const out = Buffer.alloc(count * this.elementSize);
+        if (count) native().call('gs_download', this.field.ctx, out, this.ptr + BigInt(start * this.elementSize), out.length);
+        return out;
+    }
+    getValue(index) { return fromLe(this.toBuffer(index, 1), 0, this.elementSize); }
+    toValues() {
+        const raw = this.toBuffer(); const out = new Array(this.length);
+        for (let i = 0; i < this.length; i++) out[i] = fromLe(raw, i * this.elementSize, this.elementSize);
+        return out;
+    }
+    copyValue(index, destination, offset) {  // lib/Stark.ts:290
+        this.toBuffer(index, 1).copy(destination, offset);
+        return this.elementSize;
+    }
+    valuesAt(indexes) {
+        const out = Buffer.alloc(indexes.length * this.elementSize);
+        if (indexes.length) native().call('gs_gather', this.field.ctx, this.ptr, this.elementSize, indexes, indexes.length, out);
+        return indexes.map((_, i) => out.slice(i * this.elementSize, (i + 1) * this.elementSize));
+    }
+}
+
+class Matrix {
+    constructor(field, rowCount, colCount, owner, offset = 0n) {
+        this.field = field; this.rowCount = rowCount; this.colCount = colCount; this.elementSize = ELEMENT_SIZE;
+        this.owner = owner || new DeviceBuffer(field, rowCount * colCount * ELEMENT_SIZE);
+        this.offset = offset;
+        this.quarticDomain = undefined;
+    }
+    get ptr() { return this.owner.ptr + this.offset; }
+    toBuffer() {
+        const out = Buffer.alloc(this.rowCount * this.colCount * ELEMENT_SIZE);
+        if (out.length) native().call('gs_download', this.field.ctx, out, this.ptr, out.length);
+        return out;
+    }
+    getValue(row, col) {
+        const out = Buffer.alloc(ELEMENT_SIZE);
+        native().call('gs_download', this.field.ctx, out, this.ptr + BigInt((row * this.colCount + col) * ELEMENT_SIZE), ELEMENT_SIZE);
+        return fromLe(out);
+    }
+    toValues() {
+        const raw = this.toBuffer(); const out = [];
+        for (let r = 0; r < this.rowCount; r++) {
+            const row = new Array(this.colCount);
+            for (let c = 0; c < this.colCount; c++) row[c] = fromLe(raw, (r * this.colCount + c) * ELEMENT_SIZE);
+            out.push(row);
+        }
+        return out;
+    }
+    rowsToBuffers(indexes) {  // lib/components/LowDegreeProver.ts:53,214,217
+        const rec = this.colCount * ELEMENT_SIZE;
+        const out = Buffer.alloc(indexes.length * rec);
+        if (indexes.length) native().call('gs_gather', this.field.ctx, this.ptr, rec, indexes, indexes.length, out);
+        return indexes.map((_, i) => out.slice(i * rec, (i + 1) * rec));
+    }
+    row(r) { return new Vector(this.field, this.colCount, this.owner, this.offset + BigInt(r * this.colCount * ELEMENT_SIZE)); }
+}
+
+class PrimeField {
+    constructor(modulus, options) {
+        if (BigInt(modulus) !== MODULUS) throw new TypeError('this build accelerates the 128-bit field 2^128 - 9*2^32 + 1 only');
+        this.modulus = MODULUS; this.elementSize = ELEMENT_SIZE; this.isOptimized = true;
+        this.zero = 0n; this.one = 1n;
+        this.ctx = (options && options.ctx) || native().ctxCreate((options && options.device) || 0);
+    }
+    // ---- scalars
+    mod(v) { return v >= 0n ? v % this.modulus : ((v % this.modulus) + this.modulus) % this.modulus; }
+    add(a, b) { return this.mod(a + b); }
+    sub(a, b) { return this.mod(a - b); }
+    mul(a, b) { return this.mod(a * b); }
+    neg(a) { return this.mod(-a); }
+    exp(b, e) {
+        if (e < 0n) { b = this.inv(b); e = -e; }
+        let r = 1n; b = this.mod(b);
+        while (e > 0n) { if (e & 1n) r = (r * b) % this.modulus; b = (b * b) % this.modulus; e >>= 1n; }
+        return r;
+    }
+    inv(a) { return this.mod(a) === 0n ? 0n : this.exp(a, this.modulus - 2n); }
+    div(a, b) { return this.mul(a, this.inv(b)); }
+    prng(seed, length) {  // UNVERIFIED restatement (SURVEY appendix A.1)
+        if (length === undefined) return this.mod(sha256(seed));
+        const out = new Array(length); let state = sha256(seed);
+        for (let i = 0; i < length; i++) { out[i] = this.mod(state); state = sha256(state); }
+        return this.newVectorFrom(out);
+    }
+    getRootOfUnity(order) {  // UNVERIFIED restatement (SURVEY appendix A.3)
+        const o = BigInt(order);
+        for (let i = 2n; i < 65536n; i++) {
+            const g = this.exp(i, (this.modulus - 1n) / o);
+            if (this.exp(g, o) === 1n && (o === 1n || this.exp(g, o / 2n) !== 1n)) return g;
+        }
+        throw new Error(`Root of unity for order ${order} was not found`);
+    }
+    // ---- construction
+    newVector(length) { return new Vector(this, length); }
+    newVectorFrom(values) {
+        const v = new Vector(this, values.length);
+        if (values.length) native().call('gs_upload', this.ctx, v.ptr, Buffer.concat(values.map(x => le(this.mod(BigInt(x))))), values.length * ELEMENT_SIZE);
+        return v;
+    }
+    newMatrix(rows, cols) { return new Matrix(this, rows, cols); }
+    newMatrixFrom(values) {
+        const rows = values.length, cols = rows ? values[0].length : 0;
+        const m = new Matrix(this, rows, cols);
+        if (rows * cols) native().call('gs_upload', this.ctx, m.ptr, Buffer.concat([].concat(...values).map(x => le(this.mod(BigInt(x))))), rows * cols * ELEMENT_SIZE);
+        return m;
+    }
+    newMatrixFromVectors(vectors) {
+        const cols = vectors[0].length; const m = new Matrix(this, vectors.length, cols);
+        vectors.forEach((v, r) => native().call('gs_copy', this.ctx, m.ptr + BigInt(r * cols * ELEMENT_SIZE), v.ptr, cols * ELEMENT_SIZE));
+        return m;
+    }
+    matrixRowsToVectors(m) { const out = []; for (let r = 0; r < m.rowCount; r++) out.push(m.row(r)); return out; }
+    // ---- vector ops
+    _binary(fnVec, fnScalar, a, b) {
+        const out = new Vector(this, a.length);
+        if (typeof b === 'bigint') native().call(fnScalar, this.ctx, a.ptr, le(this.mod(b)), a.length, out.ptr);
+        else {
+            if (a.length !== b.length) throw new Error('Cannot combine vector elements: vectors have different lengths');
+            native().call(fnVec, this.ctx, a.ptr, b.ptr, a.length, out.ptr);
+        }
+        return out;
+    }
+    addVectorElements(a, b) { return this._binary('gs_vec_add', 'gs_vec_add_scalar', a, b); }
+    subVectorElements(a, b) { return this._binary('gs_vec_sub', 'gs_vec_sub_scalar', a, b); }
+    mulVectorElements(a, b) { return this._binary('gs_vec_mul', 'gs_vec_mul_scalar', a, b); }
+    divVectorElements(a, b) {
+        if (typeof b === 'bigint') return this.mulVectorElements(a, this.inv(b));
+        const out = new Vector(this, a.length);
+        native().call('gs_vec_div', this.ctx, a.ptr, b.ptr, a.length, out.ptr);
+        return out;
+    }
+    invVectorElements(a) { const out = new Vector(this, a.length); native().call('gs_vec_inv', this.ctx, a.ptr, a.length, out.ptr); return out; }
+    expVectorElements(a, e) {
+        if (e < 0n) { a = this.invVectorElements(a); e = -e; }
+        const out = new Vector(this, a.length); native().call('gs_vec_exp', this.ctx, a.ptr, le(e), a.length, out.ptr); return out;
+    }
+    combineVectors(a, b) { const out = Buffer.alloc(16); native().call('gs_combine', this.ctx, a.ptr, b.ptr, a.length, out); return fromLe(out); }
+    combineManyVectors(vectors, coefficients) {
+        const ks = Array.isArray(coefficients) ? coefficients : coefficients.toValues();
+        const out = new Vector(this, vectors[0].length);
+        native().call('gs_combine_many', this.ctx, vectors.map(v => v.ptr), Buffer.concat(ks.map(le)), vectors.length, vectors[0].length, out.ptr);
+        return out;
+    }
+    getPowerSeries(base, length) {
+        const out = new Vector(this, length);
+        native().call('gs_power_series', this.ctx, le(this.mod(base)), length, out.ptr);
+        out.seriesBase = this.mod(base);
+        return out;
+    }
+    pluckVector(v, skip, times) { const out = new Vector(this, times); native().call('gs_pluck', this.ctx, v.ptr, v.length, skip, times, out.ptr); return out; }
+    transposeVector(v, columns, step = 1) {
+        const rows = v.length / (columns * step);
+        const m = new Matrix(this, rows, columns);
+        native().call('gs_transpose_vector', this.ctx, v.ptr, v.length, columns, step, m.ptr);
+        if (columns === 4 && v.seriesBase !== undefined) m.quarticDomain = { omega: v.seriesBase, n: v.length, step };
+        return m;
+    }
+    // ---- matrix ops
+    transposeMatrix(m) { const out = new Matrix(this, m.colCount, m.rowCount); native().call('gs_transpose_matrix', this.ctx, m.ptr, m.rowCount, m.colCount, out.ptr); return out; }
+    joinMatrixRows(m) { return new Vector(this, m.rowCount * m.colCount, m.owner, m.offset); }
+    subMatrixElementsFromVectors(vectors, m) {
+        const out = new Matrix(this, m.rowCount, m.colCount);
+        native().call('gs_sub_matrix_from_vectors', this.ctx, vectors.map(v => v.ptr), m.ptr, m.rowCount, m.colCount, out.ptr);
+        return out;
+    }
+    divMatrixElements(a, b) { const out = new Matrix(this, a.rowCount, a.colCount); native().call('gs_vec_div', this.ctx, a.ptr, b.ptr, a.rowCount * a.colCount, out.ptr); return out; }
+    // ---- polynomials
+    _omegaOf(roots) { return roots.seriesBase !== undefined ? roots.seriesBase : (roots.length > 1 ? roots.getValue(1) : 1n); }
+    evalPolyAtRoots(poly, roots) {
+        const out = new Vector(this, roots.length);
+        native().call('gs_eval_polys_at_roots', this.ctx, poly.ptr, 1, poly.length, le(this._omegaOf(roots)), roots.length, out.ptr);
+        return out;
+    }
+    evalPolysAtRoots(polys, roots) {
+        const out = new Matrix(this, polys.rowCount, roots.length);
+        native().call('gs_eval_polys_at_roots', this.ctx, polys.ptr, polys.rowCount, polys.colCount, le(this._omegaOf(roots)), roots.length, out.ptr);
+        return out;
+    }
+    interpolateRoots(roots, ys) {
+        const n = roots.length, isM = ys instanceof Matrix;
+        const out = isM ? new Matrix(this, ys.rowCount, n) : new Vector(this, n);
+        native().call('gs_interpolate_roots', this.ctx, ys.ptr, isM ? ys.rowCount : 1, le(this._omegaOf(roots)), n, out.ptr);
+        return out;
+    }
+    evalPolyAt(poly, x) { const out = Buffer.alloc(16); native().call('gs_eval_poly_at', this.ctx, poly.ptr, poly.length, le(this.mod(x)), out); return fromLe(out); }
+    mulPolys(a, b) {
+        const av = a.toValues(), bv = b.toValues(), out = new Array(av.length + bv.length - 1).fill(0n);
+        for (let i = 0; i < av.length; i++) for (let j = 0; j < bv.length; j++) out[i + j] = this.mod(out[i + j] + av[i] * bv[j]);
+        return this.newVectorFrom(out);
+    }
+    interpolate(xs, ys) {
+        const n = xs.length, out = Buffer.alloc(16 * n);
+        native().call('gs_small_interpolate', xs.toBuffer(), ys.toBuffer(), n, out);
+        const v = new Vector(this, n); native().call('gs_upload', this.ctx, v.ptr, out, out.length); return v;
+    }
+    interpolateQuarticBatch(xs, ys) {
+        const out = new Matrix(this, ys.rowCount, 4);
+        if (xs.quarticDomain) native().call('gs_interpolate_quartic_domain', this.ctx, le(xs.quarticDomain.omega), xs.quarticDomain.n, xs.quarticDomain.step, ys.ptr, ys.rowCount, out.ptr);
+        else native().call('gs_interpolate_quartic_batch', this.ctx, xs.ptr, ys.ptr, ys.rowCount, out.ptr);
+        return out;
+    }
+    evalQuarticBatch(polys, x) { const out = new Vector(this, polys.rowCount); native().call('gs_eval_quartic_batch', this.ctx, polys.ptr, polys.rowCount, le(this.mod(x)), out.ptr); return out; }
+}
+
+function createPrimeField(modulus, options) { return new PrimeField(modulus, options); }
+
+module.exports = { createPrimeField, PrimeField, Vector, Matrix, MODULUS, native, le, fromLe, sha256 };

@@ -1,0 +1,48 @@
+'use strict';
+// js/smoke.js — exercises the galois / merkle drop-in objects from node through the N-API shim on the GPU:
+// NTT round trip, LDE vs direct evaluation, hashing vs node crypto, Merkle batch proof, FRI fold consistency.
+const assert = require('assert');
+const crypto = require('crypto');
+const { createPrimeField, MODULUS } = require('./galois');
+const { createHash, MerkleTree } = require('./merkle');
+
+const field = createPrimeField(MODULUS);
+const P = MODULUS;
+const n = 1 << 14, T = n / 16;
+const w = field.getRootOfUnity(n);
+const domain = field.getPowerSeries(w, n);
+const coeffs = field.getPowerSeries(123456789123456789n, T);
+const ev = field.evalPolyAtRoots(coeffs, domain);
+// spot values by direct evaluation
+const cv = coeffs.toValues();
+for (const q of [0, 1, 77, n - 1]) {
+    const x = field.exp(w, BigInt(q));
+    let s = 0n;
+    for (let i = cv.length - 1; i >= 0; i--) s = (s * x + cv[i]) % P;
+    assert.strictEqual(ev.getValue(q), s);
+}
+const back = field.interpolateRoots(domain, ev).toValues();
+assert.deepStrictEqual(back.slice(0, T), cv);
+assert(back.slice(T).every(v => v === 0n));
+// pointwise + batch inverse
+const inv = field.invVectorElements(ev), one = field.mulVectorElements(ev, inv).toValues();
+assert(one.every((v, i) => v === 1n || ev.getValue(i) === 0n));
+// hashing vs node crypto
+for (const alg of ['sha256', 'blake2s256']) {
+    const h = createHash(alg, field);
+    const leaves = h.mergeVectorRows([ev]);
+    const raw = ev.toBuffer(), dg = leaves.toBuffer();
+    for (const i of [0, 5, n - 1]) assert(dg.slice(32 * i, 32 * i + 32).equals(crypto.createHash(alg).update(raw.slice(16 * i, 16 * i + 16)).digest()));
+    const tree = MerkleTree.create(leaves, h);
+    const idx = [3, 4, 900, n - 1, 17];
+    const proof = tree.proveBatch(idx);
+    assert(MerkleTree.verifyBatch(tree.root, idx, proof, h));
+    proof.values[0] = Buffer.alloc(32);
+    assert(!MerkleTree.verifyBatch(tree.root, idx, proof, h));
+}
+// FRI row polynomials: domain fast path == generic path
+const ys = field.transposeVector(ev, 4), xs = field.transposeVector(domain, 4);
+const fast = field.interpolateQuarticBatch(xs, ys).toBuffer();
+const generic = field.interpolateQuarticBatch(field.newMatrixFrom(xs.toValues()), ys).toBuffer();
+assert(fast.equals(generic));
+console.log(`js smoke OK: galois/merkle drop-in objects via N-API on backend ${process.env.GSTARK_ALLOW_TEST_DOUBLE === '1' ? '(test double allowed)' : 'hip-gfx950'}`);

@@ -1,0 +1,311 @@
+// napi/gstark_napi.cc — thin N-API shim over the C ABI of include/gstark.h.
+//
+// This is the binding a genSTARK maintainer adds in place of the wasm loaders of @guildofweavers/galois and
+// @guildofweavers/merkle: it dlopen()s libgstark_hip.so and forwards calls 1:1.  No arithmetic happens here.
+// JS-side conventions (used by js/galois.js and js/merkle.js, which rebuild the FiniteField / Hash / MerkleTree
+// objects lib/Stark.ts consumes):
+//   * a context is an External; a device pointer is a BigInt; sizes/counts are Numbers (or BigInts);
+//   * host byte arguments are Buffers (inputs are read, outputs are written in place);
+//   * arrays of device pointers / of 64-bit indexes are JS arrays of BigInt / Number.
+// Every gs_* function returns gs_status; a non-zero status is thrown as an Error carrying gs_last_error().
+//
+// build (no node-gyp needed):  g++ -O2 -shared -fPIC -I/usr/include/node napi/gstark_napi.cc -o napi/gstark_napi.node -ldl
+#include <dlfcn.h>
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../include/gstark.h"
+
+namespace {
+
+void *g_lib = nullptr;
+
+#define NAPI_OK(env, call)                                                \
+    do {                                                                  \
+        if ((call) != napi_ok) {                                          \
+            napi_throw_error((env), nullptr, "N-API call failed: " #call); \
+            return nullptr;                                               \
+        }                                                                 \
+    } while (0)
+
+// One descriptor per exported function: argument kinds after the optional leading ctx.
+//   c ctx | p device pointer | u uint64 | i int/uint32 | b host bytes in | o host bytes out |
+//   a array of device pointers | x array of uint64 | U out uint32 (returned in result object)
+struct FnDesc {
+    const char *name;
+    const char *sig;
+};
+const FnDesc kFns[] = {
+    {"gs_sync", "c"},
+    {"gs_free", "cp"},
+    {"gs_upload", "cpbu"},
+    {"gs_download", "copu"},
+    {"gs_copy", "cppu"},
+    {"gs_gather", "cpuxuo"},
+    {"gs_power_series", "cbup"},
+    {"gs_vec_add", "cppup"},
+    {"gs_vec_sub", "cppup"},
+    {"gs_vec_mul", "cppup"},
+    {"gs_vec_add_scalar", "cpbup"},
+    {"gs_vec_sub_scalar", "cpbup"},
+    {"gs_vec_mul_scalar", "cpbup"},
+    {"gs_vec_inv", "cpup"},
+    {"gs_vec_div", "cppup"},
+    {"gs_vec_exp", "cpbup"},
+    {"gs_combine_many", "cabiup"},
+    {"gs_combine", "cppuo"},
+    {"gs_pluck", "cpuuup"},
+    {"gs_transpose_vector", "cpuiup"},
+    {"gs_transpose_matrix", "cpuup"},
+    {"gs_sub_matrix_from_vectors", "capiup"},
+    {"gs_eval_polys_at_roots", "cpiubup"},
+    {"gs_interpolate_roots", "cpibup"},
+    {"gs_eval_poly_at", "cpubo"},
+    {"gs_interpolate_quartic_batch", "cppup"},
+    {"gs_interpolate_quartic_domain", "cbuupup"},
+    {"gs_eval_quartic_batch", "cpubp"},
+    {"gs_hash_digest", "cibuo"},
+    {"gs_hash_merge_rows", "ciaiup"},
+    {"gs_hash_digest_values", "cipuup"},
+    {"gs_merkle_build", "cipup"},
+    {"gs_mimc_trace", "cbbiup"},
+    {"gs_mimc_constraints", "cpuupup"},
+    {"gs_small_interpolate", "bbio"},
+    {"gs_small_eval_poly", "bibio"},
+};
+
+bool get_u64(napi_env env, napi_value v, uint64_t *out) {
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok) return false;
+    if (t == napi_bigint) {
+        bool lossless;
+        return napi_get_value_bigint_uint64(env, v, out, &lossless) == napi_ok;
+    }
+    if (t == napi_number) {
+        double d;
+        if (napi_get_value_double(env, v, &d) != napi_ok || d < 0) return false;
+        *out = (uint64_t)d;
+        return true;
+    }
+    return false;
+}
+
+typedef int (*fn12)(uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t,
+                    uintptr_t, uintptr_t);
+
+// call(name, ...args): generic forwarder.  All ABI parameters are integers or pointers, which the x86-64 SysV
+// calling convention passes in 8-byte slots; narrower parameters read the low bytes of their slot.
+napi_value Call(napi_env env, napi_callback_info info) {
+    size_t argc = 16;
+    napi_value argv[16];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    if (argc < 1) { napi_throw_type_error(env, nullptr, "call(name, ...args)"); return nullptr; }
+    char name[64];
+    size_t len;
+    NAPI_OK(env, napi_get_value_string_utf8(env, argv[0], name, sizeof name, &len));
+    const FnDesc *d = nullptr;
+    for (const FnDesc &f : kFns)
+        if (!strcmp(f.name, name)) d = &f;
+    if (!d) { napi_throw_error(env, nullptr, (std::string("unknown gstark function ") + name).c_str()); return nullptr; }
+    const size_t n = strlen(d->sig);
+    if (argc - 1 != n) { napi_throw_type_error(env, nullptr, (std::string(name) + ": wrong number of arguments").c_str()); return nullptr; }
+    void *sym = dlsym(g_lib, name);
+    if (!sym) { napi_throw_error(env, nullptr, (std::string("symbol not found: ") + name).c_str()); return nullptr; }
+    uintptr_t a[12] = {0};
+    std::vector<std::vector<uint64_t>> arrays;
+    arrays.reserve(4);
+    gs_ctx *ctx = nullptr;
+    for (size_t i = 0; i < n; i++) {
+        napi_value v = argv[i + 1];
+        switch (d->sig[i]) {
+            case 'c': {
+                void *p;
+                NAPI_OK(env, napi_get_value_external(env, v, &p));
+                ctx = (gs_ctx *)p;
+                a[i] = (uintptr_t)p;
+                break;
+            }
+            case 'p': case 'u': case 'i': {
+                uint64_t x;
+                if (!get_u64(env, v, &x)) { napi_throw_type_error(env, nullptr, (std::string(name) + ": expected a number/BigInt").c_str()); return nullptr; }
+                a[i] = (uintptr_t)x;
+                break;
+            }
+            case 'b': case 'o': {
+                void *data;
+                size_t blen;
+                if (napi_get_buffer_info(env, v, &data, &blen) != napi_ok) { napi_throw_type_error(env, nullptr, (std::string(name) + ": expected a Buffer").c_str()); return nullptr; }
+                a[i] = (uintptr_t)data;
+                break;
+            }
+            case 'a': case 'x': {
+                uint32_t alen;
+                NAPI_OK(env, napi_get_array_length(env, v, &alen));
+                arrays.emplace_back(alen);
+                for (uint32_t k = 0; k < alen; k++) {
+                    napi_value e;
+                    NAPI_OK(env, napi_get_element(env, v, k, &e));
+                    if (!get_u64(env, e, &arrays.back()[k])) { napi_throw_type_error(env, nullptr, (std::string(name) + ": bad array element").c_str()); return nullptr; }
+                }
+                a[i] = (uintptr_t)arrays.back().data();
+                break;
+            }
+            default:
+                napi_throw_error(env, nullptr, "bad descriptor");
+                return nullptr;
+        }
+    }
+    int rc = ((fn12)sym)(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11]);
+    if (rc != GS_OK) {
+        typedef const char *(*errfn)(const gs_ctx *);
+        errfn le = (errfn)dlsym(g_lib, "gs_last_error");
+        std::string msg = std::string(name) + " failed (" + std::to_string(rc) + ")";
+        if (ctx && le) msg += std::string(": ") + le(ctx);
+        napi_throw_error(env, nullptr, msg.c_str());
+        return nullptr;
+    }
+    napi_value undef;
+    napi_get_undefined(env, &undef);
+    return undef;
+}
+
+// load(path): dlopen libgstark_hip.so; returns the backend name
+napi_value Load(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    char path[1024];
+    size_t len;
+    NAPI_OK(env, napi_get_value_string_utf8(env, argv[0], path, sizeof path, &len));
+    void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { napi_throw_error(env, nullptr, (std::string("cannot load ") + path + ": " + dlerror() + " (there is no CPU fallback)").c_str()); return nullptr; }
+    typedef const char *(*namefn)(void);
+    namefn nf = (namefn)dlsym(lib, "gs_backend_name");
+    if (!nf) { napi_throw_error(env, nullptr, "not a gstark library"); return nullptr; }
+    g_lib = lib;
+    napi_value out;
+    NAPI_OK(env, napi_create_string_utf8(env, nf(), NAPI_AUTO_LENGTH, &out));
+    return out;
+}
+
+napi_value CtxCreate(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    int32_t device = 0;
+    if (argc >= 1) napi_get_value_int32(env, argv[0], &device);
+    if (!g_lib) { napi_throw_error(env, nullptr, "call load(path) first"); return nullptr; }
+    typedef int (*createfn)(int, void *, gs_ctx **);
+    createfn cf = (createfn)dlsym(g_lib, "gs_ctx_create");
+    gs_ctx *ctx = nullptr;
+    int rc = cf(device, nullptr, &ctx);
+    if (rc != GS_OK || !ctx) {
+        napi_throw_error(env, nullptr, ("gs_ctx_create failed (" + std::to_string(rc) + "): no gfx950 device; there is no CPU fallback").c_str());
+        return nullptr;
+    }
+    napi_value out;
+    NAPI_OK(env, napi_create_external(env, ctx, nullptr, nullptr, &out));
+    return out;
+}
+
+napi_value CtxDestroy(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    void *p;
+    NAPI_OK(env, napi_get_value_external(env, argv[0], &p));
+    typedef void (*dfn)(gs_ctx *);
+    ((dfn)dlsym(g_lib, "gs_ctx_destroy"))((gs_ctx *)p);
+    napi_value undef;
+    napi_get_undefined(env, &undef);
+    return undef;
+}
+
+// alloc(ctx, bytes) -> BigInt device pointer
+napi_value Alloc(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    void *p;
+    NAPI_OK(env, napi_get_value_external(env, argv[0], &p));
+    uint64_t bytes;
+    if (!get_u64(env, argv[1], &bytes)) { napi_throw_type_error(env, nullptr, "alloc(ctx, bytes)"); return nullptr; }
+    typedef int (*afn)(gs_ctx *, uint64_t, void **);
+    void *d = nullptr;
+    int rc = ((afn)dlsym(g_lib, "gs_alloc"))((gs_ctx *)p, bytes, &d);
+    if (rc != GS_OK) { napi_throw_error(env, nullptr, "gs_alloc failed"); return nullptr; }
+    napi_value out;
+    NAPI_OK(env, napi_create_bigint_uint64(env, (uint64_t)(uintptr_t)d, &out));
+    return out;
+}
+
+// merkleProveBatch(ctx, leavesPtr, nodesPtr, n, indexes[]) -> { values: Buffer, colLens: number[], nodes: Buffer }
+napi_value MerkleProveBatch(napi_env env, napi_callback_info info) {
+    size_t argc = 5;
+    napi_value argv[5];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    void *p;
+    NAPI_OK(env, napi_get_value_external(env, argv[0], &p));
+    uint64_t leaves, nodes, n;
+    if (!get_u64(env, argv[1], &leaves) || !get_u64(env, argv[2], &nodes) || !get_u64(env, argv[3], &n)) { napi_throw_type_error(env, nullptr, "merkleProveBatch: bad arguments"); return nullptr; }
+    uint32_t count;
+    NAPI_OK(env, napi_get_array_length(env, argv[4], &count));
+    std::vector<uint64_t> idx(count);
+    for (uint32_t k = 0; k < count; k++) {
+        napi_value e;
+        NAPI_OK(env, napi_get_element(env, argv[4], k, &e));
+        if (!get_u64(env, e, &idx[k])) { napi_throw_type_error(env, nullptr, "merkleProveBatch: bad index"); return nullptr; }
+    }
+    int depth = 0;
+    while ((1ull << depth) < n) depth++;
+    const uint64_t cap = (uint64_t)count * (depth ? depth : 1);
+    std::vector<uint8_t> values((size_t)count * 32), nd((size_t)cap * 32);
+    std::vector<uint32_t> lens(count ? count : 1);
+    uint32_t ncols = 0;
+    typedef int (*pfn)(gs_ctx *, const void *, const void *, uint64_t, const uint64_t *, uint32_t, uint8_t *, uint32_t *, uint32_t *, uint8_t *, uint64_t);
+    int rc = ((pfn)dlsym(g_lib, "gs_merkle_prove_batch"))((gs_ctx *)p, (const void *)(uintptr_t)leaves, (const void *)(uintptr_t)nodes, n, idx.data(),
+                                                          count, values.data(), &ncols, lens.data(), nd.data(), cap);
+    if (rc != GS_OK) {
+        typedef const char *(*errfn)(const gs_ctx *);
+        napi_throw_error(env, nullptr, ((errfn)dlsym(g_lib, "gs_last_error"))((gs_ctx *)p));
+        return nullptr;
+    }
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < ncols; i++) total += lens[i];
+    napi_value out, v, nb, arr;
+    NAPI_OK(env, napi_create_object(env, &out));
+    NAPI_OK(env, napi_create_buffer_copy(env, values.size(), values.data(), nullptr, &v));
+    NAPI_OK(env, napi_create_buffer_copy(env, (size_t)total * 32, nd.data(), nullptr, &nb));
+    NAPI_OK(env, napi_create_array_with_length(env, ncols, &arr));
+    for (uint32_t i = 0; i < ncols; i++) {
+        napi_value e;
+        NAPI_OK(env, napi_create_uint32(env, lens[i], &e));
+        NAPI_OK(env, napi_set_element(env, arr, i, e));
+    }
+    NAPI_OK(env, napi_set_named_property(env, out, "values", v));
+    NAPI_OK(env, napi_set_named_property(env, out, "nodes", nb));
+    NAPI_OK(env, napi_set_named_property(env, out, "colLens", arr));
+    return out;
+}
+
+napi_value Init(napi_env env, napi_value exports) {
+    const struct { const char *name; napi_callback cb; } fns[] = {
+        {"load", Load}, {"ctxCreate", CtxCreate}, {"ctxDestroy", CtxDestroy}, {"alloc", Alloc}, {"call", Call},
+        {"merkleProveBatch", MerkleProveBatch},
+    };
+    for (auto &f : fns) {
+        napi_value fn;
+        if (napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.cb, nullptr, &fn) != napi_ok) return nullptr;
+        if (napi_set_named_property(env, exports, f.name, fn) != napi_ok) return nullptr;
+    }
+    return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

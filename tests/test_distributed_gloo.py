@@ -1,0 +1,33 @@
+"""The N > 1 path of bench.py on CPU: world_size 2 over gloo, each rank proving its own trace (weak scaling, no
+data-path collective).  The device work goes to the oracle's implementation of the C ABI (test double) so that the
+distributed harness — rendezvous, barrier-bracketed timing, max-over-ranks reduction, per-rank seeds, rank-0 JSON —
+is exercised without a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ORACLE_LIB, ROOT
+
+
+def test_bench_two_ranks_gloo(oracle_backend):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29531', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--log-trace', '8',
+           '--fri-queries', '24', '--test-double-lib', ORACLE_LIB]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 2 and out['warmup'] == 1 and out['scaling'] == 'weak'
+    per_proof = out['config']['ntt_points_per_prove']
+    assert abs(out['value'] - 2 * per_proof / (out['ms_per_step'] * 1e-3)) < 1e-6 * out['value']
+
+
+def test_bench_single_rank_cpu_mode(oracle_backend):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--log-trace', '7',
+                        '--fri-queries', '24', '--test-double-lib', ORACLE_LIB], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert out['n_gpus'] == 1 and out['higher_is_better'] is True
