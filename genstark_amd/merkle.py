@@ -29,6 +29,17 @@ class Hash:
     def merge(self, a, b):
         return self.digest(bytes(a) + bytes(b))
 
+    def digestMany(self, messages):
+        """Digests of a list of equal-length host messages in one upload / kernel / download (verifier side:
+        rehashMerkleProofValues and the per-level merges of verifyBatch)."""
+        if not messages:
+            return []
+        size = len(messages[0])
+        if any(len(m) != size for m in messages):
+            return [self.digest(m) for m in messages]
+        raw = self.digestValues(b''.join(bytes(m) for m in messages), size).toBuffer()
+        return [raw[i * DIGEST_SIZE:(i + 1) * DIGEST_SIZE] for i in range(len(messages))]
+
     def mergeVectorRows(self, vectors):
         """lib/Stark.ts:115 — out[i] = H(v_0[i] || v_1[i] || ...), a Vector of 32-byte digests."""
         n = vectors[0].length
@@ -145,6 +156,8 @@ class MerkleTree:
             return False
         v, nxt, ptr = {}, [], [0] * len(norm)
         try:
+            # each level's merges are independent: hash them in one batch
+            pairs = []
             for i, ix in enumerate(norm):
                 i1, i2 = index_map.get(ix), index_map.get(ix + 1)
                 if i1 is not None and i2 is not None:
@@ -155,11 +168,13 @@ class MerkleTree:
                 else:
                     v1, v2 = proof['nodes'][i][0], proof['values'][i2]
                     ptr[i] = 1
-                parent = (offset + ix) >> 1
-                v[parent] = hash_.merge(v1, v2)
-                nxt.append(parent)
+                pairs.append(bytes(v1) + bytes(v2))
+                nxt.append((offset + ix) >> 1)
+            for parent, d in zip(nxt, hash_.digestMany(pairs)):
+                v[parent] = d
             for _ in range(proof['depth'] - 1, 0, -1):
                 cur, nxt, i = nxt, [], 0
+                pairs = []
                 while i < len(cur):
                     node_ix = cur[i]
                     sib_ix = node_ix ^ 1
@@ -170,9 +185,11 @@ class MerkleTree:
                         sib = proof['nodes'][i][ptr[i]]
                         ptr[i] += 1
                     node = v[node_ix]
-                    v[node_ix >> 1] = hash_.merge(sib, node) if node_ix & 1 else hash_.merge(node, sib)
+                    pairs.append(bytes(sib) + bytes(node) if node_ix & 1 else bytes(node) + bytes(sib))
                     nxt.append(node_ix >> 1)
                     i += 1
+                for parent, d in zip(nxt, hash_.digestMany(pairs)):
+                    v[parent] = d
         except (IndexError, KeyError, TypeError):
             return False
         return v.get(1) == bytes(root)

@@ -21,7 +21,7 @@ def powLog2(base, exponent):
 
 # ---- merkle proof (index.ts:34-45)
 def rehashMerkleProofValues(proof, hash_):
-    return {'nodes': proof['nodes'], 'values': [hash_.digest(v) for v in proof['values']], 'depth': proof['depth']}
+    return {'nodes': proof['nodes'], 'values': hash_.digestMany(proof['values']), 'depth': proof['depth']}
 
 
 # ---- big integers (serialization.ts:131-146): LE 32-bit limbs == little-endian bytes

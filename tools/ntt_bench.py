@@ -1,9 +1,10 @@
 """tools/ntt_bench.py — quick NTT / hashing / inversion timings on the GPU box through the C ABI (development aid)."""
 import ctypes as C
+import os
 import sys
 import time
 
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from genstark_amd._abi import Backend  # noqa: E402
 from genstark_amd.field import PrimeField  # noqa: E402
 from genstark_amd.merkle import MerkleTree, createHash  # noqa: E402

@@ -1,8 +1,9 @@
 """tools/ntt_only.py — a few 2^24-point NTTs and nothing else (target for rocprofv3 --pmc passes)."""
 import ctypes as C
+import os
 import sys
 
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from genstark_amd._abi import Backend  # noqa: E402
 from genstark_amd.field import PrimeField  # noqa: E402
 
