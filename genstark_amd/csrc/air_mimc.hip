@@ -34,7 +34,10 @@ int gs_mimc_trace(gs_ctx *c, const uint8_t seed[16], const uint8_t *rc_host, uin
     uint32_t ri = 0;
     for (uint64_t i = 0; i < steps; i++) {
         t[i] = x;
-        x = hf_add(hf_mul(hf_mul(x, x), x), rc[ri]);
+        hu128 y = hf_mul_weak(hf_mul_weak(x, x), x);   // any representative of x^3
+        hu128 sum = y + rc[ri];
+        if (sum < y) sum += HF_C;                        // wrapped past 2^128: +2^128 == +C (the wrapped value is small)
+        x = hf_canon(sum);
         if (++ri == nrc) ri = 0;
     }
     GS_HIP(c, hipMemcpyAsync(out, c->h_stage, steps * 16, hipMemcpyHostToDevice, c->stream));
