@@ -202,7 +202,7 @@ def main():
                     'kernel': f'k_ntt_pass<4> (radix-256 Stockham pass), {npass} launches per 2^{logn}-point transform',
                     'launch_ms': round(launch_ms, 4), 'transform_ms': round(transform_ms, 4),
                     'ntt_kernel_elements_per_sec': round(n / (transform_ms * 1e-3), 1),
-                    'note': 'kernel is bound by the 32x32-bit integer multiplier (v_mad_u64_u32 ~15 cycles/wave), not HBM: see DESIGN.md'}
+                    'note': 'VALU-issue-bound (about 90 carry/mad instructions of ~4.5 cycles per 128-bit modmul), not HBM-bound: DESIGN.md section 3'}
         del src, dst
 
         cpu = None if args.no_cpu_baseline else cpu_baseline(ga, args.cpu_log_trace, ef, fri)
