@@ -1,0 +1,5 @@
+'use strict';
+// one device context per process, shared by the galois / merkle / air-assembly replacements
+const { createPrimeField, MODULUS } = require('./galois');
+let field;
+module.exports = { defaultField() { return field || (field = createPrimeField(MODULUS)); } };

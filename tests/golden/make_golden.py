@@ -4,7 +4,11 @@
 
 1. oracle_proofs.json   — proofs, roots and positions produced by THIS repo's oracle (oracle/pyref.py) for
                           small MiMC instances: the byte-exact targets of the GPU path.
-2. reference_vectors.json — outputs of the reference's OWN compiled modules that can run here
+2. reference_driver_proofs.json — proofs produced by the reference's OWN compiled prover (bin/lib/Stark.js +
+                          bin/lib/components/*.js, unmodified, run under node from /root/reference) orchestrating THIS
+                          repository's drop-in modules for galois / merkle / air-assembly (js/shims via NODE_PATH) on the
+                          CPU oracle backend: every line of prove()/serialize()/verify() executed is the reference's.
+3. reference_vectors.json — outputs of the reference's OWN compiled modules that can run here
                           (QueryIndexGenerator, Serializer, sizeOf, powLog2, read/writeBigInt), produced by
                           gen_reference_vectors.js under node with /root/reference/bin/lib.  The reference's
                           arithmetic packages are absent, so nothing else of the reference can be executed.
@@ -81,6 +85,30 @@ def main():
     subprocess.check_call(['node', os.path.join(HERE, 'gen_reference_vectors.js'), os.path.join(ref, 'bin', 'lib'), tmp,
                            os.path.join(HERE, 'reference_vectors.json')])
     os.remove(tmp)
+    run_reference_driver(oracle_out, ref)
+
+
+def run_reference_driver(oracle_cases, ref):
+    """The reference's compiled Stark.js drives our drop-in JS modules (N-API -> C ABI -> oracle backend on CPU)."""
+    subprocess.check_call(['bash', os.path.join(ROOT, 'napi', 'build.sh')])
+    subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), '-s'])
+    cases = [{k: c[k] for k in ('name', 'steps', 'extension_factor', 'exe_query_count', 'fri_query_count', 'hash_algorithm', 'seed',
+                                'assertions')} for c in oracle_cases]
+    tmp_in, tmp_out = os.path.join(HERE, '_driver_cases.json'), os.path.join(HERE, '_driver_out.json')
+    with open(tmp_in, 'w') as f:
+        json.dump(cases, f)
+    env = dict(os.environ, NODE_PATH=os.path.join(ROOT, 'js', 'shims'), GSTARK_LIB=os.path.join(ROOT, 'oracle', 'liboracle.so'),
+               GSTARK_ALLOW_TEST_DOUBLE='1')
+    subprocess.check_call(['node', os.path.join(HERE, 'run_reference_stark.js'), os.path.join(ref, 'bin', 'lib'), tmp_in, tmp_out], env=env)
+    out = json.load(open(tmp_out))
+    for rec in out:   # keep the fixture small: the proof itself is identified by its hash and length
+        data = bytes.fromhex(rec.pop('proofHex'))
+        rec['proofSize'], rec['proofSha256'] = len(data), hashlib.sha256(data).hexdigest()
+    with open(os.path.join(HERE, 'reference_driver_proofs.json'), 'w') as f:
+        json.dump({'generator': 'genSTARK bin/lib/Stark.js (unmodified) under node, over js/shims + oracle backend', 'cases': cases,
+                   'results': out}, f)
+    os.remove(tmp_in)
+    os.remove(tmp_out)
 
 
 if __name__ == '__main__':

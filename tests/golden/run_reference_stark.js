@@ -1,0 +1,29 @@
+// tests/golden/run_reference_stark.js — drives the REFERENCE's own compiled prover/verifier (bin/lib/Stark.js and
+// bin/lib/components/*.js, unmodified, loaded from the genSTARK checkout) on top of this repository's drop-in modules
+// for @guildofweavers/{galois,merkle,air-assembly} (js/shims, found through NODE_PATH).
+//   usage: NODE_PATH=<repo>/js/shims node run_reference_stark.js /root/reference/bin/lib <cases.json> <out.json>
+// Every line of prove()/verify()/serialize() orchestration executed here is the reference's; only the arithmetic
+// objects it is handed are ours.
+const path = require('path');
+const fs = require('fs');
+const libDir = process.argv[2];
+const { Stark } = require(path.join(libDir, 'Stark.js'));
+const cases = JSON.parse(fs.readFileSync(process.argv[3], 'utf8'));
+const out = [];
+const noopLogger = { start() { return () => {}; }, sub() { return () => {}; }, done() {} };
+for (const c of cases) {
+    const options = { hashAlgorithm: c.hash_algorithm, extensionFactor: c.extension_factor, exeQueryCount: c.exe_query_count, friQueryCount: c.fri_query_count };
+    const stark = new Stark({ mimc: { steps: c.steps } }, 'mimc', options, noopLogger);
+    const assertions = c.assertions.map(a => ({ step: a.step, register: a.register, value: BigInt(a.value) }));
+    const proof = stark.prove(assertions, [], [BigInt(c.seed)]);
+    const bytes = stark.serialize(proof);
+    if (bytes.byteLength !== stark.sizeOf(proof)) throw new Error('size mismatch');
+    const ok = stark.verify(assertions, stark.parse(bytes));
+    let tamperRejected = false;
+    try { const bad = Buffer.from(bytes); bad[40] ^= 1; stark.verify(assertions, stark.parse(bad)); } catch (e) { tamperRejected = true; }
+    out.push({ name: c.name, proofHex: bytes.toString('hex'), evRoot: proof.evRoot.toString('hex'), lcRoot: proof.ldProof.lcRoot.toString('hex'),
+               friLayers: proof.ldProof.components.length, remainderLength: proof.ldProof.remainder.length, verified: ok === true,
+               tamperRejected, securityLevel: stark.securityLevel });
+    console.log(c.name, bytes.byteLength, 'verified', ok, 'security', stark.securityLevel);
+}
+fs.writeFileSync(process.argv[4], JSON.stringify(out));

@@ -1,0 +1,68 @@
+"""The strongest pin this container allows: the reference's OWN compiled prover and verifier (bin/lib/Stark.js,
+bin/lib/components/*.js — unmodified) run under node on top of this repository's drop-in modules for
+@guildofweavers/{galois,merkle,air-assembly} (js/shims via NODE_PATH -> N-API -> C ABI).  Its proofs are committed as
+tests/golden/reference_driver_proofs.json (hash + size + roots); they must equal, byte for byte, the proofs of
+  * the oracle's independent restatement (oracle/pyref.py -> oracle_proofs.json),
+  * the product's Python host mirror (on the oracle backend here, on the HIP backend under -m gpu).
+When the checkout and node are present (build container) the reference driver is also re-run live."""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ORACLE_LIB, ROOT
+from test_host_mirror import GOLDEN, golden_assertions, make_stark
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, 'golden', 'reference_driver_proofs.json')) as f:
+    DRIVER = json.load(f)
+REF_LIB = '/root/reference/bin/lib'
+
+
+def test_reference_driver_fixture_equals_oracle_golden():
+    gold = {c['name']: c for c in GOLDEN}
+    assert len(DRIVER['results']) == len(GOLDEN) >= 5
+    for rec in DRIVER['results']:
+        g = gold[rec['name']]
+        assert rec['verified'] is True and rec['tamperRejected'] is True
+        assert rec['proofSha256'] == g['proofSha256'] and rec['proofSize'] == g['proofSize']
+        assert rec['evRoot'] == g['evRoot'] and rec['lcRoot'] == g['lcRoot']
+        assert rec['friLayers'] == g['friLayers'] and rec['remainderLength'] == g['remainderLength']
+
+
+def _mirror_matches(backend):
+    by_name = {r['name']: r for r in DRIVER['results']}
+    for case in GOLDEN[:3]:
+        stark = make_stark(case, backend)
+        data = stark.serialize(stark.prove(golden_assertions(case), [], [case['seed']]))
+        assert hashlib.sha256(data).hexdigest() == by_name[case['name']]['proofSha256']
+        assert stark.securityLevel == by_name[case['name']]['securityLevel']
+
+
+def test_python_mirror_reproduces_reference_driver_proofs(oracle_backend):
+    _mirror_matches(oracle_backend)
+
+
+@pytest.mark.gpu
+def test_hip_backend_reproduces_reference_driver_proofs(hip_backend):
+    _mirror_matches(hip_backend)
+
+
+@pytest.mark.skipif(not (os.path.isdir(REF_LIB) and shutil.which('node') and os.path.exists('/usr/include/node/node_api.h')),
+                    reason='needs the genSTARK checkout and node (build container only)')
+def test_reference_stark_js_runs_live_on_the_drop_in_modules(oracle_backend, tmp_path):
+    subprocess.check_call(['bash', os.path.join(ROOT, 'napi', 'build.sh')])
+    cases = DRIVER['cases'][:2]
+    cin, cout = tmp_path / 'cases.json', tmp_path / 'out.json'
+    cin.write_text(json.dumps(cases))
+    env = dict(os.environ, NODE_PATH=os.path.join(ROOT, 'js', 'shims'), GSTARK_LIB=ORACLE_LIB, GSTARK_ALLOW_TEST_DOUBLE='1')
+    r = subprocess.run(['node', os.path.join(HERE, 'golden', 'run_reference_stark.js'), REF_LIB, str(cin), str(cout)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    gold = {c['name']: c for c in GOLDEN}
+    for rec in json.loads(cout.read_text()):
+        assert rec['verified'] and rec['tamperRejected']
+        assert rec['proofHex'] == gold[rec['name']]['proofHex']
