@@ -188,9 +188,14 @@ static void ntt_inplace(fe *a, uint64_t n, fe omega) {
         }
     }
 }
+static int check_root(gs_ctx *c, fe w, uint64_t n) { /* omega must generate the n-th roots of unity */
+    if (n == 1) return w == 1 ? GS_OK : fail(c, GS_ERR_ARG, "ntt: omega must be 1 for n = 1");
+    return fe_exp(w, n / 2) == fe_p() - 1 ? GS_OK : fail(c, GS_ERR_ARG, "ntt: omega is not a primitive n-th root of unity");
+}
 int gs_eval_polys_at_roots(gs_ctx *c, const void *polys, uint32_t rows, uint64_t plen, const uint8_t omega[16],
                            uint64_t n, void *out) {
     if (!is_pow2(n) || plen > n) return fail(c, GS_ERR_ARG, "eval_polys_at_roots: n must be a power of two >= poly_len");
+    if (check_root(c, fe_load(omega), n)) return GS_ERR_ARG;
     fe *t = (fe *)malloc(n * sizeof(fe));
     if (!t) return fail(c, GS_ERR_OOM, "malloc failed");
     fe w = fe_load(omega);
@@ -204,6 +209,7 @@ int gs_eval_polys_at_roots(gs_ctx *c, const void *polys, uint32_t rows, uint64_t
 }
 int gs_interpolate_roots(gs_ctx *c, const void *ys, uint32_t rows, const uint8_t omega[16], uint64_t n, void *out) {
     if (!is_pow2(n)) return fail(c, GS_ERR_ARG, "interpolate_roots: n must be a power of two");
+    if (check_root(c, fe_load(omega), n)) return GS_ERR_ARG;
     fe *t = (fe *)malloc(n * sizeof(fe));
     if (!t) return fail(c, GS_ERR_OOM, "malloc failed");
     fe winv = fe_inv(fe_load(omega)), ninv = fe_inv((fe)n);
