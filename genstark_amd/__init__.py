@@ -5,12 +5,15 @@ Layout (only what the hot path needs):
   _abi.py      ctypes binding of the C ABI (loads the HIP library; no CPU fallback)
   field.py     galois FiniteField / Vector / Matrix surface       (device-resident data)
   merkle.py    merkle Hash / MerkleTree surface
-  air.py       air-assembly AirModule / ProvingContext surface for the MiMC AIR
+  air.py       air-assembly AirModule / ProvingContext surface for the MiMC AIR (dedicated kernels)
+  air_generic.py  the same surface for AIRs given as expressions (register-machine programs); rescue.py: Rescue 4x128
+  sharded.py   register-sharded multi-GPU trace commitment
   components/  mirrors of lib/components/*.ts (the callers of the surface)
   stark.py     mirror of lib/Stark.ts (prove / verify / serialize / parse)
 """
 from ._abi import Backend, GstarkError, HIP_LIB_PATH
 from .air import MimcAir, runMimc, sha256_prng
+from .air_generic import GenericAir
 from .errors import StarkError
 from .field import MODULUS, Matrix, PrimeField, Vector, createPrimeField
 from .merkle import Hash, MerkleTree, createHash

@@ -1,0 +1,294 @@
+"""Generic AIR support: the AirModule / ProvingContext / VerificationContext surface of `@guildofweavers/air-assembly`
+ for AIRs whose transition function and constraint evaluator are given as
+arithmetic expressions over trace registers, next-row registers and cyclic static registers — the subset of AirAssembly
+(`add sub mul exp prod vector get load.trace load.static load.const`) the reference's Rescue and Poseidon examples use
+(examples/rescue/hash4x128.ts:83-108, assembly/lib128.aa:15-37).
+
+Expressions are compiled to straight-line programs for the register machine of include/gstark.h; the device evaluates the
+constraint program at every composition-domain point (`gs_air_constraints`), one host core runs the transition program
+step by step (`gs_air_trace`), and the verifier interprets the same program on Python integers.
+"""
+import ctypes as C
+
+from ._abi import GstarkError
+from .field import Matrix, PrimeField, Vector, _le
+
+OP_LOADC, OP_LOADR, OP_LOADN, OP_LOADS, OP_ADD, OP_SUB, OP_MUL, OP_POW, OP_POWC, OP_OUT = range(10)
+MAX_VM_REGS = 64
+
+
+class Expr:
+    """A node of an arithmetic expression DAG.  Build with reg(i), nxt(i), static(i), const(v) and + - * **."""
+    __slots__ = ('kind', 'args')
+
+    def __init__(self, kind, *args):
+        self.kind, self.args = kind, args
+
+    @staticmethod
+    def wrap(v):
+        return v if isinstance(v, Expr) else Expr('const', int(v))
+
+    def __add__(self, o): return Expr('add', self, Expr.wrap(o))
+    def __radd__(self, o): return Expr('add', Expr.wrap(o), self)
+    def __sub__(self, o): return Expr('sub', self, Expr.wrap(o))
+    def __rsub__(self, o): return Expr('sub', Expr.wrap(o), self)
+    def __mul__(self, o): return Expr('mul', self, Expr.wrap(o))
+    def __rmul__(self, o): return Expr('mul', Expr.wrap(o), self)
+
+    def __pow__(self, e):
+        e = int(e)
+        if e < 0:
+            raise GstarkError('negative exponents must be rewritten as e mod (p - 1)')
+        return Expr('pow', self, e)
+
+
+def reg(i): return Expr('reg', i)
+def nxt(i): return Expr('next', i)
+def static(i): return Expr('static', i)
+def const(v): return Expr('const', int(v))
+
+
+def mat_vec(m, v):
+    """`mds # vector` of AirScript (examples/rescue/hash4x128.ts:96-97)."""
+    out = []
+    for row in m:
+        acc = None
+        for a, b in zip(row, v):
+            t = Expr.wrap(a) * b
+            acc = t if acc is None else acc + t
+        out.append(acc)
+    return out
+
+
+class Program:
+    """Straight-line code {op, dst, a, b} + constant pool, with scratch registers reused after their last use."""
+
+    def __init__(self, outputs, modulus):
+        self.modulus = modulus
+        order, index = [], {}
+
+        def visit(e):
+            key = id(e)
+            if key in index:
+                return index[key]
+            ins = [visit(a) for a in e.args if isinstance(a, Expr)]
+            index[key] = len(order)
+            order.append((e, ins))
+            return index[key]
+
+        outs = [visit(Expr.wrap(o)) for o in outputs]
+        last_use = {}
+        for n, (_, ins) in enumerate(order):
+            for i in ins:
+                last_use[i] = n
+        for o in outs:
+            last_use[o] = len(order)
+        self.consts, const_ix = [], {}
+
+        def cidx(v):
+            v %= modulus
+            if v not in const_ix:
+                const_ix[v] = len(self.consts)
+                self.consts.append(v)
+            return const_ix[v]
+
+        free, where, nregs, code = [], {}, 0, []
+        for n, (e, ins) in enumerate(order):
+            srcs = [where[i] for i in ins]
+            for i in ins:                      # operands dying here free their register for the destination
+                if last_use[i] == n and where[i] not in free:
+                    free.append(where[i])
+            if free:
+                dst = free.pop()
+            else:
+                dst, nregs = nregs, nregs + 1
+            where[n] = dst
+            k = e.kind
+            if k == 'const':
+                code.append((OP_LOADC, dst, cidx(e.args[0] % modulus), 0))
+            elif k == 'reg':
+                code.append((OP_LOADR, dst, e.args[0], 0))
+            elif k == 'next':
+                code.append((OP_LOADN, dst, e.args[0], 0))
+            elif k == 'static':
+                code.append((OP_LOADS, dst, e.args[0], 0))
+            elif k in ('add', 'sub', 'mul'):
+                code.append(({'add': OP_ADD, 'sub': OP_SUB, 'mul': OP_MUL}[k], dst, srcs[0], srcs[1]))
+            elif k == 'pow':
+                ex = e.args[1]
+                if ex < (1 << 32):
+                    code.append((OP_POW, dst, srcs[0], ex))
+                else:
+                    code.append((OP_POWC, dst, srcs[0], cidx_raw(self, const_ix, ex)))
+            else:
+                raise GstarkError(f'unknown expression kind {k}')
+        for k, o in enumerate(outs):
+            code.append((OP_OUT, k, where[o], 0))
+        if nregs > MAX_VM_REGS:
+            raise GstarkError(f'program needs {nregs} scratch registers (max {MAX_VM_REGS})')
+        self.code, self.nregs, self.nout = code, max(nregs, 1), len(outs)
+
+    # ---- marshalling for the C ABI
+    def abi_args(self):
+        flat = (C.c_uint32 * (4 * len(self.code)))(*[w for ins in self.code for w in ins])
+        consts = b''.join(int(v).to_bytes(16, 'little') for v in self.consts) or bytes(16)
+        return flat, len(self.code), consts, len(self.consts), self.nregs
+
+    # ---- host interpreter (verifier side, Python integers)
+    def run(self, cur, nxt_row, statics):
+        p = self.modulus
+        vm, out = [0] * self.nregs, [0] * self.nout
+        for op, d, a, b in self.code:
+            if op == OP_LOADC: vm[d] = self.consts[a]
+            elif op == OP_LOADR: vm[d] = cur[a]
+            elif op == OP_LOADN: vm[d] = nxt_row[a]
+            elif op == OP_LOADS: vm[d] = statics[a]
+            elif op == OP_ADD: vm[d] = (vm[a] + vm[b]) % p
+            elif op == OP_SUB: vm[d] = (vm[a] - vm[b]) % p
+            elif op == OP_MUL: vm[d] = (vm[a] * vm[b]) % p
+            elif op == OP_POW: vm[d] = pow(vm[a], b, p)
+            elif op == OP_POWC: vm[d] = pow(vm[a], self.consts[b], p)
+            else: out[d] = vm[a]
+        return out
+
+
+def cidx_raw(prog, const_ix, v):
+    key = ('raw', v)
+    if key not in const_ix:
+        const_ix[key] = len(prog.consts)
+        prog.consts.append(v)
+    return const_ix[key]
+
+
+class _Context:
+    def __init__(self, air):
+        f = air.field
+        self.air, self.field = air, f
+        self.traceLength, self.extensionFactor = air.steps, air.extensionFactor
+        self.constraints = [{'degree': d} for d in air.constraintDegrees]
+        self.inputShapes = []
+        self.rootOfUnity = air.rootOfUnity
+        self.compositionFactor = air.compositionFactor
+
+    def _static_polys(self):
+        """Host coefficients of each cyclic register's polynomial K_s (degree < period): value at x is K_s(x^(T/period))."""
+        air, f = self.air, self.field
+        if air._staticPolys is None:
+            polys = []
+            for values in air.staticRegisters:
+                m = len(values)
+                g = f.exp(self.rootOfUnity, self.extensionFactor * (self.traceLength // m))   # order m
+                polys.append(f.interpolateRoots(f.getPowerSeries(g, m), f.newVectorFrom(values)).toValues())
+            air._staticPolys = polys
+        return air._staticPolys
+
+
+class GenericVerificationContext(_Context):
+    def evaluateConstraintsAt(self, x, rValues, nValues, hValues):   # CompositionPolynomial.ts:153
+        f = self.field
+        statics = []
+        for values, poly in zip(self.air.staticRegisters, self._static_polys()):
+            xc, k = f.exp(x, self.traceLength // len(values)), 0
+            for c in reversed(poly):
+                k = (k * xc + c) % f.modulus
+            statics.append(k)
+        return self.air.evaluationProgram.run(rValues, nValues, statics)
+
+
+class GenericProvingContext(_Context):
+    def __init__(self, air, first_row):
+        super().__init__(air)
+        f = self.field
+        n, nc = self.traceLength * self.extensionFactor, self.traceLength * self.compositionFactor
+        self.firstRow = [v % f.modulus for v in first_row]
+        self.evaluationDomain = f.getPowerSeries(self.rootOfUnity, n)
+        self.compositionDomain = f.getPowerSeries(f.exp(self.rootOfUnity, n // nc), nc)
+        self.executionDomain = f.getPowerSeries(f.exp(self.rootOfUnity, self.extensionFactor), self.traceLength)
+        self.secretRegisterTraces = []
+        # static registers over the composition domain: K_s at the (period * compositionFactor)-th roots of unity
+        lens = [len(v) * self.compositionFactor for v in air.staticRegisters]
+        self._staticLens = lens
+        self._staticTables = Vector(f.backend, max(sum(lens), 1))
+        off = 0
+        for values, poly, ln in zip(air.staticRegisters, self._static_polys(), lens):
+            wk = f.exp(self.compositionDomain.series_base, self.traceLength // len(values))
+            tab = f.evalPolyAtRoots(f.newVectorFrom(poly), f.getPowerSeries(wk, ln))
+            f.backend.call('gs_copy', C.c_void_p(self._staticTables.ptr + off * 16), C.c_void_p(tab.ptr), ln * 16)
+            off += ln
+
+    def generateExecutionTrace(self):   # lib/Stark.ts:97
+        air, f = self.air, self.field
+        code, ninstr, consts, nconsts, nregs = air.transitionProgram.abi_args()
+        m = Matrix(f.backend, air.traceRegisterCount, self.traceLength)
+        svals = b''.join(_le(v % f.modulus) for values in air.staticRegisters for v in values) or bytes(16)
+        periods = (C.c_uint32 * max(len(air.staticRegisters), 1))(*[len(v) for v in air.staticRegisters])
+        f.backend.call('gs_air_trace', code, ninstr, consts, nconsts, nregs, air.traceRegisterCount, svals, periods,
+                       len(air.staticRegisters), b''.join(_le(v) for v in self.firstRow), self.traceLength, C.c_void_p(m.ptr))
+        return m
+
+    def generateStaticTrace(self):
+        f = self.field
+        return f.newMatrixFrom([[v[i % len(v)] for i in range(self.traceLength)] for v in self.air.staticRegisters])
+
+    def evaluateTransitionConstraints(self, pPolys):   # CompositionPolynomial.ts:76
+        air, f = self.air, self.field
+        nc = self.compositionDomain.length
+        p_comp = f.evalPolysAtRoots(pPolys, self.compositionDomain)
+        code, ninstr, consts, nconsts, nregs = air.evaluationProgram.abi_args()
+        q = Matrix(f.backend, len(air.constraintDegrees), nc)
+        lens = (C.c_uint64 * max(len(self._staticLens), 1))(*self._staticLens)
+        f.backend.call('gs_air_constraints', code, ninstr, consts, nconsts, nregs, air.traceRegisterCount, len(air.constraintDegrees),
+                       C.c_void_p(p_comp.ptr), nc, nc // self.traceLength, C.c_void_p(self._staticTables.ptr), lens,
+                       len(self._staticLens), C.c_void_p(q.ptr))
+        return q
+
+
+class GenericAir:
+    """AirModule built from expression-level transition / evaluation functions.
+
+    transition(r, k)    -> list of `registers` Expr: next row from current row r[i] and static registers k[j]
+    evaluation(r, n, k) -> list of Expr, one per constraint: must vanish on every step but the last
+    init(seed)          -> first row (list of ints)"""
+
+    def __init__(self, steps, registers, constraintDegrees, staticRegisters, transition, evaluation, init, extensionFactor=None,
+                 field=None):
+        self.field = field or PrimeField()
+        f = self.field
+        if steps & (steps - 1) or steps < 2:
+            raise GstarkError('steps must be a power of 2')
+        for values in staticRegisters:
+            if len(values) & (len(values) - 1) or steps % len(values):
+                raise GstarkError('static register cycles must be powers of 2 dividing the trace length')
+        self.steps, self.traceRegisterCount, self.secretInputCount = steps, registers, 0
+        self.constraintDegrees = list(constraintDegrees)
+        self.maxConstraintDegree = max(self.constraintDegrees)
+        self.compositionFactor = 1 << (self.maxConstraintDegree - 1).bit_length()
+        self.extensionFactor = extensionFactor or 2 * self.compositionFactor
+        ef = self.extensionFactor
+        if ef & (ef - 1) or ef < 2 * self.compositionFactor or ef > 32:
+            raise GstarkError('Extension factor must be a power of 2 at least 2x the constraint degree and at most 32')
+        self.staticRegisters = [[v % f.modulus for v in values] for values in staticRegisters]
+        r = [reg(i) for i in range(registers)]
+        n = [nxt(i) for i in range(registers)]
+        k = [static(j) for j in range(len(staticRegisters))]
+        self.transitionProgram = Program(transition(r, k), f.modulus)
+        self.evaluationProgram = Program(evaluation(r, n, k), f.modulus)
+        if self.transitionProgram.nout != registers or self.evaluationProgram.nout != len(self.constraintDegrees):
+            raise GstarkError('transition must yield one value per register, evaluation one per constraint')
+        self.init = init
+        self.rootOfUnity = f.getRootOfUnity(steps * ef)
+        self._staticPolys = None
+
+    def initProvingContext(self, inputs=None, seed=None):
+        return GenericProvingContext(self, self.init(seed or []))
+
+    def initVerificationContext(self, inputShapes=None, publicInputs=None):
+        return GenericVerificationContext(self)
+
+    def hostTrace(self, seed, steps=None):
+        """Independent control computation on Python integers (the role of examples/rescue/utils.ts for the examples)."""
+        row, out = [v % self.field.modulus for v in self.init(seed)], []
+        for i in range(steps or self.steps):
+            out.append(row)
+            row = self.transitionProgram.run(row, None, [v[i % len(v)] for v in self.staticRegisters])
+        return out

@@ -1,0 +1,158 @@
+// air_vm.hip — generic AIR: transition functions and constraint evaluators as straight-line register-machine programs
+// (include/gstark.h, "AIR ... generic straight-line programs").  Replaces the code air-assembly generates for
+// ProvingContext.generateExecutionTrace / evaluateTransitionConstraints (lib/Stark.ts:97; CompositionPolynomial.ts:76).
+//
+// Constraint evaluation: one thread per composition-domain point interprets the program; the instruction stream and the
+// constant pool are wave-uniform (scalar loads), the scratch file lives in private memory.  Trace generation: steps are
+// sequentially dependent, one host core interprets the program on native 64-bit limbs.
+#include "common.h"
+#include "host_field.h"
+
+enum { OP_LOADC = 0, OP_LOADR = 1, OP_LOADN = 2, OP_LOADS = 3, OP_ADDV = 4, OP_SUBV = 5, OP_MULV = 6, OP_POW = 7, OP_POWC = 8, OP_OUT = 9 };
+
+struct StaticDesc {
+    uint64_t offset[GS_AIR_MAX_REGISTERS];  // element offset into the concatenated table
+    uint64_t len[GS_AIR_MAX_REGISTERS];
+};
+
+template <int NREG>
+__global__ void k_air_constraints(const uint4 *__restrict__ code, uint32_t ninstr, const fe *__restrict__ consts,
+                                  const fe *__restrict__ p, uint64_t nc, uint64_t shift, const fe *__restrict__ statics, StaticDesc sd,
+                                  fe *__restrict__ out) {
+    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < nc; j += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t jn = j + shift;
+        if (jn >= nc) jn -= nc;
+        fe vm[NREG];
+        for (uint32_t pc = 0; pc < ninstr; pc++) {
+            const uint4 ins = code[pc];
+            const uint32_t dst = ins.y, a = ins.z, b = ins.w;
+            switch (ins.x) {
+                case OP_LOADC: vm[dst] = consts[a]; break;
+                case OP_LOADR: vm[dst] = p[(uint64_t)a * nc + j]; break;
+                case OP_LOADN: vm[dst] = p[(uint64_t)a * nc + jn]; break;
+                case OP_LOADS: vm[dst] = statics[sd.offset[a] + j % sd.len[a]]; break;
+                case OP_ADDV: vm[dst] = fe_add(vm[a], vm[b]); break;
+                case OP_SUBV: vm[dst] = fe_sub(vm[a], vm[b]); break;
+                case OP_MULV: vm[dst] = fe_mul(vm[a], vm[b]); break;
+                case OP_POW: vm[dst] = fe_pow_u64(vm[a], b); break;
+                case OP_POWC: vm[dst] = fe_pow(vm[a], consts[b]); break;
+                default: out[(uint64_t)dst * nc + j] = vm[a]; break;  // OP_OUT
+            }
+        }
+    }
+}
+
+static int check_program(gs_ctx *c, const uint32_t *code, uint32_t ninstr, uint32_t nconsts, uint32_t vm_regs, uint32_t registers,
+                         uint32_t nstatic, uint32_t nout, bool allow_next) {
+    if (!code || !ninstr) return gs_fail(c, GS_ERR_ARG, "air program: empty");
+    if (vm_regs == 0 || vm_regs > GS_AIR_MAX_VM_REGS) return gs_fail(c, GS_ERR_ARG, "air program: vm_regs must be in 1..%d", GS_AIR_MAX_VM_REGS);
+    if (registers == 0 || registers > GS_AIR_MAX_REGISTERS || nstatic > GS_AIR_MAX_REGISTERS) return gs_fail(c, GS_ERR_ARG, "air program: too many registers");
+    for (uint32_t pc = 0; pc < ninstr; pc++) {
+        const uint32_t op = code[4 * pc], dst = code[4 * pc + 1], a = code[4 * pc + 2], b = code[4 * pc + 3];
+        bool ok = true;
+        switch (op) {
+            case OP_LOADC: ok = dst < vm_regs && a < nconsts; break;
+            case OP_LOADR: ok = dst < vm_regs && a < registers; break;
+            case OP_LOADN: ok = allow_next && dst < vm_regs && a < registers; break;
+            case OP_LOADS: ok = dst < vm_regs && a < nstatic; break;
+            case OP_ADDV: case OP_SUBV: case OP_MULV: ok = dst < vm_regs && a < vm_regs && b < vm_regs; break;
+            case OP_POW: ok = dst < vm_regs && a < vm_regs; break;
+            case OP_POWC: ok = dst < vm_regs && a < vm_regs && b < nconsts; break;
+            case OP_OUT: ok = dst < nout && a < vm_regs; break;
+            default: ok = false;
+        }
+        if (!ok) return gs_fail(c, GS_ERR_ARG, "air program: invalid instruction %u (op %u)", pc, op);
+    }
+    return GS_OK;
+}
+
+extern "C" {
+
+int gs_air_constraints(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs,
+                       uint32_t registers, uint32_t constraints, const void *p_comp, uint64_t nc, uint64_t shift, const void *static_tables,
+                       const uint64_t *static_lens_host, uint32_t nstatic, void *out) {
+    if (!c || !p_comp || !out || (!consts_host && nconsts) || (nstatic && (!static_tables || !static_lens_host))) return GS_ERR_ARG;
+    int rc = check_program(c, code_host, ninstr, nconsts, vm_regs, registers, nstatic, constraints, true);
+    if (rc) return rc;
+    if (!nc) return gs_fail(c, GS_ERR_ARG, "air_constraints: empty domain");
+    StaticDesc sd;
+    uint64_t off = 0;
+    for (uint32_t s = 0; s < GS_AIR_MAX_REGISTERS; s++) {
+        sd.offset[s] = off;
+        sd.len[s] = s < nstatic ? static_lens_host[s] : 1;
+        if (s < nstatic) {
+            if (!static_lens_host[s]) return gs_fail(c, GS_ERR_ARG, "air_constraints: empty static table");
+            off += static_lens_host[s];
+        }
+    }
+    // program + constants to device scratch (small; one sync so the staging buffer can be reused)
+    const uint64_t code_bytes = ((uint64_t)ninstr * 16 + 255) & ~(uint64_t)255, const_bytes = (uint64_t)(nconsts ? nconsts : 1) * 16;
+    void *dprog;
+    if ((rc = gs_tmp_alloc(c, code_bytes + const_bytes, &dprog))) return rc;
+    hipError_t e = hipMemcpyAsync(dprog, code_host, (size_t)ninstr * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && nconsts) e = hipMemcpyAsync((uint8_t *)dprog + code_bytes, consts_host, (size_t)nconsts * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // host buffers are pageable and owned by the caller
+    if (e != hipSuccess) { gs_tmp_free(c, dprog); return gs_fail(c, GS_ERR_DEVICE, "air_constraints upload: %s", hipGetErrorString(e)); }
+    const uint4 *dcode = (const uint4 *)dprog;
+    const fe *dconst = (const fe *)((uint8_t *)dprog + code_bytes);
+    dim3 grid(gs_grid(nc)), block(256);
+    if (vm_regs <= 16)
+        hipLaunchKernelGGL(k_air_constraints<16>, grid, block, 0, c->stream, dcode, ninstr, dconst, (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, sd, (fe *)out);
+    else if (vm_regs <= 32)
+        hipLaunchKernelGGL(k_air_constraints<32>, grid, block, 0, c->stream, dcode, ninstr, dconst, (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, sd, (fe *)out);
+    else
+        hipLaunchKernelGGL(k_air_constraints<64>, grid, block, 0, c->stream, dcode, ninstr, dconst, (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, sd, (fe *)out);
+    e = hipGetLastError();
+    gs_tmp_free(c, dprog);  // stream-ordered reuse: later users of the block are queued behind this kernel
+    if (e != hipSuccess) return gs_fail(c, GS_ERR_DEVICE, "air_constraints launch: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+int gs_air_trace(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs,
+                 uint32_t registers, const uint8_t *static_values_host, const uint32_t *static_periods_host, uint32_t nstatic,
+                 const uint8_t *first_row_host, uint64_t steps, void *out) {
+    if (!c || !first_row_host || !out || (!consts_host && nconsts) || (nstatic && (!static_values_host || !static_periods_host))) return GS_ERR_ARG;
+    int rc = check_program(c, code_host, ninstr, nconsts, vm_regs, registers, nstatic, registers, false);
+    if (rc) return rc;
+    if (!steps) return gs_fail(c, GS_ERR_ARG, "air_trace: empty");
+    std::vector<hu128> consts(nconsts ? nconsts : 1), vm(vm_regs), row(registers), next(registers);
+    for (uint32_t i = 0; i < nconsts; i++) consts[i] = hf_load(consts_host + 16 * i);
+    std::vector<std::vector<hu128>> statics(nstatic);
+    {
+        const uint8_t *p = static_values_host;
+        for (uint32_t s = 0; s < nstatic; s++) {
+            if (!static_periods_host[s]) return gs_fail(c, GS_ERR_ARG, "air_trace: empty static register");
+            statics[s].resize(static_periods_host[s]);
+            for (uint32_t i = 0; i < static_periods_host[s]; i++, p += 16) statics[s][i] = hf_load(p);
+        }
+    }
+    if ((rc = gs_stage_reserve(c, (uint64_t)registers * steps * 16))) return rc;
+    GS_HIP(c, hipStreamSynchronize(c->stream));
+    hu128 *t = (hu128 *)c->h_stage;  // registers x steps, row-major like the Matrix the caller gets
+    for (uint32_t r = 0; r < registers; r++) row[r] = hf_load(first_row_host + 16 * r);
+    for (uint64_t i = 0; i < steps; i++) {
+        for (uint32_t r = 0; r < registers; r++) t[(uint64_t)r * steps + i] = row[r];
+        if (i + 1 == steps) break;
+        next = row;
+        for (uint32_t pc = 0; pc < ninstr; pc++) {
+            const uint32_t op = code_host[4 * pc], dst = code_host[4 * pc + 1], a = code_host[4 * pc + 2], b = code_host[4 * pc + 3];
+            switch (op) {
+                case OP_LOADC: vm[dst] = consts[a]; break;
+                case OP_LOADR: vm[dst] = row[a]; break;
+                case OP_LOADS: vm[dst] = statics[a][i % statics[a].size()]; break;
+                case OP_ADDV: vm[dst] = hf_add(vm[a], vm[b]); break;
+                case OP_SUBV: vm[dst] = hf_sub(vm[a], vm[b]); break;
+                case OP_MULV: vm[dst] = hf_mul(vm[a], vm[b]); break;
+                case OP_POW: vm[dst] = hf_pow(vm[a], (hu128)b); break;
+                case OP_POWC: vm[dst] = hf_pow(vm[a], consts[b]); break;
+                default: next[dst] = vm[a]; break;
+            }
+        }
+        row = next;
+    }
+    GS_HIP(c, hipMemcpyAsync(out, c->h_stage, (size_t)registers * steps * 16, hipMemcpyHostToDevice, c->stream));
+    GS_HIP(c, hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+}  // extern "C"

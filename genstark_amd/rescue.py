@@ -1,0 +1,96 @@
+"""The Rescue 4x128 hash AIR of examples/rescue/hash4x128.ts (4 trace registers, 4 degree-3 constraints, 8 cyclic static
+registers of period 32) as a GenericAir, for BASELINE configs[2] ("Rescue hash-preimage STARK, 128-bit field").
+
+The cipher parameters (alpha, inv_alpha, MDS matrix and its inverse, the 24 seed constants) are DATA of the reference's
+example (hash4x128.ts:12-34,52-65); the key schedule and input injection are restated from examples/rescue/utils.ts:126-181
+and hash4x128.ts:130-160.  With steps > 32 the permutation simply keeps cycling through the 32-step round-constant
+schedule (the example's own trace is the first 32 steps; multi-input segmentation needs air-assembly's input registers and
+is out of scope)."""
+from .air_generic import GenericAir, mat_vec
+
+ALPHA = 3
+INV_ALPHA = 113427455640312821154458202464371168597     # 3 * INV_ALPHA == -1 (mod p - 1): (1/x)^INV_ALPHA is the cube root
+STEPS_PER_HASH = 32
+
+MDS = [
+    [340282366920938463463374607393113505064, 340282366920938463463374607393113476633, 340282366920938463463374607393112623703, 340282366920938463463374607393088807273],
+    [1080, 42471, 1277640, 35708310],
+    [340282366920938463463374607393113505403, 340282366920938463463374607393113491273, 340282366920938463463374607393113076364, 340282366920938463463374607393101570233],
+    [40, 1210, 33880, 925771],
+]
+INV_MDS = [
+    [236997924285633886309140921207528337986, 247254910923297358352547052529406562002, 311342028444809266296393502237594936029, 126030506267014245727175780515967965110],
+    [33069997328254894416993606273702832836, 59740111947936946229464514160137230831, 88480676416265968399408181712033476738, 124630167308491865219096049621346098829],
+    [336618017400133662891528246258390023400, 144341202744775798260123226512082052891, 154884404066691444097361840554534567820, 4667796528407935026932436315406220930],
+    [73878794827854483309086441046605817365, 229228508225866824084614421584601165863, 125857624914110248133585690282064031000, 84953896817024417490170340940393220925],
+]
+SEED_CONSTANTS = [
+    144517900019036866096022507193071809599, 271707809579969091656092579345468860225, 139424957805302989189422527487860690608, 126750251129487986697737866024960215983,
+    271118613762407276564214152179206069413, 39384648060424157691646880565718875760, 189037434251220539428539337560615209464, 218986062987136192416421725751708413726,
+    103808983578136303126641899945581033860, 198823153506012419365570940451368319246, 339599443104046223725845265111864465825, 169004341575174204803282453992954960786,
+    171596418631454858790177474513731208863, 157569361262795131998922854453557743690, 211837534394685913032370295607135890739, 328609939009439440841980058678511564944,
+    229628671790616575443886906286361261591, 95675137928612392156876334331168593412, 301613873771889848137714364785485714735, 278224571298089265666737094541710980794,
+    140049647417493050970983064725330334359, 159594320057012289760186736637936788141, 44954493393746175043012738454844468290, 223519669575552375517628855932195463175,
+]
+
+
+def key_schedule(f):
+    """examples/rescue/utils.ts:126-181 (unrollConstants + groupConstants) on host integers."""
+    n = 4
+    inv_exp = f.modulus - 1 - INV_ALPHA          # x^-INV_ALPHA
+    vadd = lambda a, b: [f.add(x, y) for x, y in zip(a, b)]
+
+    def mmul(m, v):
+        return [sum(a * b for a, b in zip(row, v)) % f.modulus for row in m]
+
+    c = list(SEED_CONSTANTS)
+    i_const, c_matrix, c_const = c[:n], [c[n + i * n:n + (i + 1) * n] for i in range(n)], c[n + n * n:n + n * n + n]
+    state, injection = list(i_const), i_const
+    states = [list(state)]
+    for _ in range(STEPS_PER_HASH + 1):
+        state = [f.exp(x, inv_exp) for x in state]
+        injection = vadd(mmul(c_matrix, injection), c_const)
+        state = vadd(mmul(MDS, state), injection)
+        states.append(list(state))
+        state = [f.exp(x, ALPHA) for x in state]
+        injection = vadd(mmul(c_matrix, injection), c_const)
+        state = vadd(mmul(MDS, state), injection)
+        states.append(list(state))
+    initial = states[0] + states[1]
+    rc = [[0] * STEPS_PER_HASH for _ in range(2 * n)]
+    k = 2
+    for i in range(STEPS_PER_HASH):
+        for j in range(n):
+            rc[j][i] = states[k][j]
+            rc[n + j][i] = states[k + 1][j]
+        k += 2
+    return initial, rc
+
+
+def build_inputs(f, values, initial):
+    """hash4x128.ts:130-160 — inject the two input elements and apply the first half round."""
+    inv_exp = f.modulus - 1 - INV_ALPHA
+    r = [f.add(values[0], initial[0]), f.add(values[1], initial[1]), initial[2], initial[3]]
+    a = [f.exp(x, inv_exp) for x in r]
+    r = [sum(m * x for m, x in zip(row, a)) % f.modulus for row in MDS]
+    return [f.add(r[j], initial[4 + j]) for j in range(4)]
+
+
+def rescue4x128_air(steps, extensionFactor=16, field=None):
+    """Returns the GenericAir; prove with `stark.prove(assertions, [], [v1, v2])` (the two hashed elements)."""
+    from .field import PrimeField
+    f = field or PrimeField()
+    initial, rc = key_schedule(f)
+    inv_exp = f.modulus - 1 - INV_ALPHA
+
+    def transition(r, k):      # hash4x128.ts:94-97
+        s = [a + b for a, b in zip(mat_vec(MDS, [x ** ALPHA for x in r]), k[0:4])]
+        return [a + b for a, b in zip(mat_vec(MDS, [x ** inv_exp for x in s]), k[4:8])]
+
+    def evaluation(r, n, k):   # hash4x128.ts:102-106
+        s = [a + b for a, b in zip(mat_vec(MDS, [x ** ALPHA for x in r]), k[0:4])]
+        nn = [x ** ALPHA for x in mat_vec(INV_MDS, [a - b for a, b in zip(n, k[4:8])])]
+        return [a - b for a, b in zip(s, nn)]
+
+    return GenericAir(steps, 4, [3, 3, 3, 3], rc, transition, evaluation, lambda seed: build_inputs(f, seed, initial),
+                      extensionFactor, f)

@@ -188,6 +188,29 @@ int gs_mimc_trace(gs_ctx *ctx, const uint8_t seed[16], const uint8_t *rc_host, u
 int gs_mimc_constraints(gs_ctx *ctx, const void *p_comp, uint64_t nc, uint64_t shift,
                         const void *k_table, uint64_t klen, void *out);
 
+/* ---- AIR (air-assembly ProvingContext), generic straight-line programs -------------------------------------
+ * air-assembly compiles an AIR's transition function and constraint evaluator into generated code over the field
+ * object (lib/Stark.ts:97, CompositionPolynomial.ts:76).  Here the same two functions are straight-line programs for a
+ * small register machine (no branches, no loops), run by one device thread per composition-domain point
+ * (constraints) or by one host core per step (trace: steps are sequentially dependent).  An instruction is four
+ * uint32 words {op, dst, a, b} over a scratch file of vm_regs field elements:
+ *     0 LOADC  vm[dst] = consts[a]            1 LOADR  vm[dst] = current row, register a
+ *     2 LOADN  vm[dst] = next row, register a 3 LOADS  vm[dst] = static register a at this step / point
+ *     4 ADD    5 SUB    6 MUL   vm[dst] = vm[a] op vm[b]
+ *     7 POW    vm[dst] = vm[a]^b  (b: literal exponent)      8 POWC  vm[dst] = vm[a]^consts[b] (128-bit exponent)
+ *     9 OUT    output[dst] = vm[a]   (next-row register for the trace, constraint index for the evaluator)
+ * Static registers are cyclic: in the trace, register s at step i is static_values[s][i mod period_s]; in the evaluator
+ * it is static_tables[s][j mod len_s], the register's polynomial evaluated over the composition domain. */
+#define GS_AIR_MAX_VM_REGS 64
+#define GS_AIR_MAX_REGISTERS 64
+int gs_air_trace(gs_ctx *ctx, const uint32_t *code_host, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts,
+                 uint32_t vm_regs, uint32_t registers, const uint8_t *static_values_host, const uint32_t *static_periods_host,
+                 uint32_t nstatic, const uint8_t *first_row_host, uint64_t steps, void *out /* registers x steps */);
+int gs_air_constraints(gs_ctx *ctx, const uint32_t *code_host, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts,
+                       uint32_t vm_regs, uint32_t registers, uint32_t constraints, const void *p_comp /* registers x nc */,
+                       uint64_t nc, uint64_t shift, const void *static_tables /* device, concatenated */,
+                       const uint64_t *static_lens_host, uint32_t nstatic, void *out /* constraints x nc */);
+
 #ifdef __cplusplus
 }
 #endif

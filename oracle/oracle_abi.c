@@ -428,3 +428,84 @@ int gs_small_eval_poly(const uint8_t *poly, uint32_t len, const uint8_t *xs, uin
     }
     return GS_OK;
 }
+
+/* ---- generic AIR programs (include/gstark.h): the simplest possible interpreter, both for the trace and per point ---- */
+static fe vm_pow_u32(fe b, uint32_t e) { return fe_exp(b, (u128)e); }
+static int air_check(gs_ctx *c, const uint32_t *code, uint32_t n, uint32_t nconsts, uint32_t vm, uint32_t regs, uint32_t nstatic, uint32_t nout, int allow_next) {
+    if (!code || !n || !vm || vm > GS_AIR_MAX_VM_REGS || !regs || regs > GS_AIR_MAX_REGISTERS || nstatic > GS_AIR_MAX_REGISTERS) return fail(c, GS_ERR_ARG, "air program: bad shape");
+    for (uint32_t pc = 0; pc < n; pc++) {
+        uint32_t op = code[4 * pc], d = code[4 * pc + 1], a = code[4 * pc + 2], b = code[4 * pc + 3];
+        int ok;
+        switch (op) {
+            case 0: ok = d < vm && a < nconsts; break;
+            case 1: ok = d < vm && a < regs; break;
+            case 2: ok = allow_next && d < vm && a < regs; break;
+            case 3: ok = d < vm && a < nstatic; break;
+            case 4: case 5: case 6: ok = d < vm && a < vm && b < vm; break;
+            case 7: ok = d < vm && a < vm; break;
+            case 8: ok = d < vm && a < vm && b < nconsts; break;
+            case 9: ok = d < nout && a < vm; break;
+            default: ok = 0;
+        }
+        if (!ok) return fail(c, GS_ERR_ARG, "air program: invalid instruction");
+    }
+    return GS_OK;
+}
+int gs_air_trace(gs_ctx *c, const uint32_t *code, uint32_t n, const uint8_t *consts, uint32_t nconsts, uint32_t vmn, uint32_t regs,
+                 const uint8_t *svals, const uint32_t *speriods, uint32_t nstatic, const uint8_t *row0, uint64_t steps, void *out) {
+    if (air_check(c, code, n, nconsts, vmn, regs, nstatic, regs, 0)) return GS_ERR_ARG;
+    if (!steps) return fail(c, GS_ERR_ARG, "air_trace: empty");
+    fe vm[GS_AIR_MAX_VM_REGS], row[GS_AIR_MAX_REGISTERS], next[GS_AIR_MAX_REGISTERS];
+    uint64_t soff[GS_AIR_MAX_REGISTERS];
+    uint64_t o = 0;
+    for (uint32_t s = 0; s < nstatic; s++) { if (!speriods[s]) return fail(c, GS_ERR_ARG, "air_trace: empty static register"); soff[s] = o; o += speriods[s]; }
+    for (uint32_t r = 0; r < regs; r++) row[r] = fe_load(row0 + 16 * r);
+    for (uint64_t i = 0; i < steps; i++) {
+        for (uint32_t r = 0; r < regs; r++) ST(out, (uint64_t)r * steps + i, row[r]);
+        if (i + 1 == steps) break;
+        for (uint32_t r = 0; r < regs; r++) next[r] = row[r];
+        for (uint32_t pc = 0; pc < n; pc++) {
+            uint32_t op = code[4 * pc], d = code[4 * pc + 1], a = code[4 * pc + 2], b = code[4 * pc + 3];
+            switch (op) {
+                case 0: vm[d] = fe_load(consts + 16 * a); break;
+                case 1: vm[d] = row[a]; break;
+                case 3: vm[d] = fe_load(svals + 16 * (soff[a] + i % speriods[a])); break;
+                case 4: vm[d] = fe_add(vm[a], vm[b]); break;
+                case 5: vm[d] = fe_sub(vm[a], vm[b]); break;
+                case 6: vm[d] = fe_mul(vm[a], vm[b]); break;
+                case 7: vm[d] = vm_pow_u32(vm[a], b); break;
+                case 8: vm[d] = fe_exp(vm[a], fe_load(consts + 16 * b)); break;
+                default: next[d] = vm[a]; break;
+            }
+        }
+        for (uint32_t r = 0; r < regs; r++) row[r] = next[r];
+    }
+    return GS_OK;
+}
+int gs_air_constraints(gs_ctx *c, const uint32_t *code, uint32_t n, const uint8_t *consts, uint32_t nconsts, uint32_t vmn, uint32_t regs,
+                       uint32_t ncons, const void *p, uint64_t nc, uint64_t shift, const void *stab, const uint64_t *slens, uint32_t nstatic, void *out) {
+    if (air_check(c, code, n, nconsts, vmn, regs, nstatic, ncons, 1)) return GS_ERR_ARG;
+    if (!nc) return fail(c, GS_ERR_ARG, "air_constraints: empty domain");
+    fe vm[GS_AIR_MAX_VM_REGS];
+    uint64_t soff[GS_AIR_MAX_REGISTERS], o = 0;
+    for (uint32_t s = 0; s < nstatic; s++) { if (!slens[s]) return fail(c, GS_ERR_ARG, "air_constraints: empty static table"); soff[s] = o; o += slens[s]; }
+    for (uint64_t j = 0; j < nc; j++) {
+        uint64_t jn = (j + shift) % nc;
+        for (uint32_t pc = 0; pc < n; pc++) {
+            uint32_t op = code[4 * pc], d = code[4 * pc + 1], a = code[4 * pc + 2], b = code[4 * pc + 3];
+            switch (op) {
+                case 0: vm[d] = fe_load(consts + 16 * a); break;
+                case 1: vm[d] = EL(p, (uint64_t)a * nc + j); break;
+                case 2: vm[d] = EL(p, (uint64_t)a * nc + jn); break;
+                case 3: vm[d] = EL(stab, soff[a] + j % slens[a]); break;
+                case 4: vm[d] = fe_add(vm[a], vm[b]); break;
+                case 5: vm[d] = fe_sub(vm[a], vm[b]); break;
+                case 6: vm[d] = fe_mul(vm[a], vm[b]); break;
+                case 7: vm[d] = vm_pow_u32(vm[a], b); break;
+                case 8: vm[d] = fe_exp(vm[a], fe_load(consts + 16 * b)); break;
+                default: ST(out, (uint64_t)d * nc + j, vm[a]); break;
+            }
+        }
+    }
+    return GS_OK;
+}

@@ -1,0 +1,118 @@
+"""Generic AIR path: transition / constraint expressions compiled to the register machine of include/gstark.h,
+exercised with the Rescue 4x128 hash AIR of examples/rescue/hash4x128.ts (4 registers, 4 degree-3 constraints, 8 cyclic
+static registers) and with MiMC re-expressed generically (must reproduce the dedicated MiMC kernels' proof bytes)."""
+import hashlib
+
+import pytest
+
+import genstark_amd as ga
+from genstark_amd.air_generic import GenericAir, Program, const, reg
+from genstark_amd.errors import StarkError
+from genstark_amd.field import PrimeField
+from genstark_amd.rescue import rescue4x128_air
+from genstark_amd.stark import Stark
+
+RESCUE_KAT = (302524937772545017647250309501879538110, 205025454306577433144586673939030012640)   # hash4x128.ts:115-118
+RESCUE_OPTS = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 68, 'friQueryCount': 24}   # hash4x128.ts:41-47
+
+
+def rescue_case(backend, steps):
+    f = PrimeField(backend=backend)
+    air = rescue4x128_air(steps, 16, f)
+    stark = Stark(air, RESCUE_OPTS)
+    full = air.hostTrace([42, 43])
+    assertions = [{'step': 31, 'register': 0, 'value': full[31][0]}, {'step': 31, 'register': 1, 'value': full[31][1]},
+                  {'step': steps - 1, 'register': 3, 'value': full[-1][3]}, {'step': 0, 'register': 2, 'value': full[0][2]}]
+    return air, stark, full, assertions
+
+
+def check_rescue(backend, steps):
+    air, stark, full, assertions = rescue_case(backend, steps)
+    assert (full[31][0], full[31][1]) == RESCUE_KAT
+    trace = air.initProvingContext([], [42, 43]).generateExecutionTrace().toValues()
+    assert trace == [list(r) for r in zip(*full)]
+    assert (trace[0][31], trace[1][31]) == RESCUE_KAT          # the reference example's known answer, through the VM
+    proof = stark.prove(assertions, [], [42, 43])
+    data = stark.serialize(proof)
+    assert len(data) == stark.sizeOf(proof)
+    assert stark.verify(assertions, stark.parse(data))
+    assert stark.securityLevel == 96
+    bad = bytearray(data)
+    bad[len(data) // 3] ^= 4
+    with pytest.raises((StarkError, IndexError, ValueError, AssertionError)):
+        stark.verify(assertions, stark.parse(bytes(bad)))
+    wrong = [dict(a) for a in assertions]
+    wrong[0]['value'] = (wrong[0]['value'] + 1) % ga.MODULUS
+    with pytest.raises(StarkError):
+        stark.verify(wrong, stark.parse(data))
+    return data
+
+
+def mimc_generic_air(field, steps, ef):
+    rc = ga.sha256_prng(bytes.fromhex('4d694d43'), 64, field)
+    return GenericAir(steps, 1, [3], [rc], lambda r, k: [r[0] ** 3 + k[0]], lambda r, n, k: [n[0] - (r[0] ** 3 + k[0])],
+                      lambda seed: [seed[0]], ef, field)
+
+
+def check_mimc_generic_equals_dedicated(backend, steps):
+    f = PrimeField(backend=backend)
+    opts = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 48, 'friQueryCount': 24}
+    dedicated = ga.instantiateMimc(steps, opts, backend=backend)
+    controls = ga.runMimc(f, steps, dedicated.air.roundConstants, 3)
+    assertions = [{'step': 0, 'register': 0, 'value': controls[0]}, {'step': steps - 1, 'register': 0, 'value': controls[-1]}]
+    want = dedicated.serialize(dedicated.prove(assertions, [], [3]))
+    generic = Stark(mimc_generic_air(f, steps, 16), opts)
+    got = generic.serialize(generic.prove(assertions, [], [3]))
+    assert got == want
+    assert generic.verify(assertions, generic.parse(got))
+
+
+def test_program_compiler_reuses_registers_and_matches_python():
+    x, y = reg(0), reg(1)
+    e = (x + y) * (x - y) + const(7) * x ** 5
+    prog = Program([e, x * x], ga.MODULUS)
+    assert prog.nregs <= 6
+    p = ga.MODULUS
+    assert prog.run([3, 10], None, []) == [((3 + 10) * (3 - 10) + 7 * 3 ** 5) % p, 9]
+
+
+@pytest.mark.parametrize('steps', [64, 256])
+def test_rescue_prove_verify_oracle(oracle_backend, steps):
+    check_rescue(oracle_backend, steps)
+
+
+def test_mimc_generic_equals_dedicated_oracle(oracle_backend):
+    check_mimc_generic_equals_dedicated(oracle_backend, 256)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('steps', [64, 1024, 1 << 13])
+def test_rescue_hip_equals_oracle(hip_backend, oracle_backend, steps):
+    got = check_rescue(hip_backend, steps)
+    air, stark, full, assertions = rescue_case(oracle_backend, steps)
+    want = stark.serialize(stark.prove(assertions, [], [42, 43]))
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want).hexdigest()
+
+
+@pytest.mark.gpu
+def test_mimc_generic_equals_dedicated_hip(hip_backend):
+    check_mimc_generic_equals_dedicated(hip_backend, 1 << 12)
+
+
+@pytest.mark.gpu
+def test_rescue_2p16_config_verifies(hip_backend):
+    """BASELINE configs[2]: Rescue hash STARK, 128-bit field, 2^16 steps, blake2s256 Merkle, E = 16 (N = 2^20, 6 FRI layers)."""
+    air, stark, full, assertions = None, None, None, None
+    f = PrimeField(backend=hip_backend)
+    steps = 1 << 16
+    air = rescue4x128_air(steps, 16, f)
+    stark = Stark(air, RESCUE_OPTS)
+    trace = air.initProvingContext([], [42, 43]).generateExecutionTrace()
+    assert (trace.getValue(0, 31), trace.getValue(1, 31)) == RESCUE_KAT
+    assertions = [{'step': 31, 'register': 0, 'value': RESCUE_KAT[0]}, {'step': 31, 'register': 1, 'value': RESCUE_KAT[1]},
+                  {'step': steps - 1, 'register': 2, 'value': trace.getValue(2, steps - 1)}]
+    proof = stark.prove(assertions, [], [42, 43])
+    assert len(proof['ldProof']['components']) == 6
+    data = stark.serialize(proof)
+    assert len(data) == stark.sizeOf(proof)
+    assert stark.verify(assertions, stark.parse(data))
