@@ -192,12 +192,14 @@ class PrimeField:
         return m
 
     def newMatrixFromVectors(self, vectors):
-        cols = vectors[0].length
+        # rows shorter than the longest one are zero-extended (polynomials of different degrees, e.g. boundary
+        # interpolants of registers with different numbers of assertions: BoundaryConstraints.ts:84-85)
+        cols = max(v.length for v in vectors)
         m = Matrix(self.backend, len(vectors), cols)
         for r, v in enumerate(vectors):
-            if v.length != cols:
-                raise GstarkError('Cannot create a matrix from vectors of different lengths')
-            self.backend.call('gs_copy', C.c_void_p(m.ptr + r * cols * 16), C.c_void_p(v.ptr), cols * 16)
+            self.backend.call('gs_copy', C.c_void_p(m.ptr + r * cols * 16), C.c_void_p(v.ptr), v.length * 16)
+            if v.length < cols:
+                self.backend.upload(m.ptr + (r * cols + v.length) * 16, bytes((cols - v.length) * 16))
         return m
 
     def matrixRowsToVectors(self, matrix):

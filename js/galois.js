@@ -168,8 +168,12 @@ class PrimeField {
         return m;
     }
     newMatrixFromVectors(vectors) {
-        const cols = vectors[0].length; const m = new Matrix(this, vectors.length, cols);
-        vectors.forEach((v, r) => native().call('gs_copy', this.ctx, m.ptr + BigInt(r * cols * ELEMENT_SIZE), v.ptr, cols * ELEMENT_SIZE));
+        // shorter rows are zero-extended (polynomials of different degrees: BoundaryConstraints.ts:84-85)
+        const cols = Math.max(...vectors.map(v => v.length)); const m = new Matrix(this, vectors.length, cols);
+        vectors.forEach((v, r) => {
+            native().call('gs_copy', this.ctx, m.ptr + BigInt(r * cols * ELEMENT_SIZE), v.ptr, v.length * ELEMENT_SIZE);
+            if (v.length < cols) native().call('gs_upload', this.ctx, m.ptr + BigInt((r * cols + v.length) * ELEMENT_SIZE), Buffer.alloc((cols - v.length) * ELEMENT_SIZE), (cols - v.length) * ELEMENT_SIZE);
+        });
         return m;
     }
     matrixRowsToVectors(m) { const out = []; for (let r = 0; r < m.rowCount; r++) out.push(m.row(r)); return out; }

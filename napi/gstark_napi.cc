@@ -35,7 +35,7 @@ void *g_lib = nullptr;
 
 // One descriptor per exported function: argument kinds after the optional leading ctx.
 //   c ctx | p device pointer | u uint64 | i int/uint32 | b host bytes in | o host bytes out |
-//   a array of device pointers | x array of uint64 | U out uint32 (returned in result object)
+//   a array of device pointers | x array of uint64 | w array of uint32
 struct FnDesc {
     const char *name;
     const char *sig;
@@ -75,6 +75,8 @@ const FnDesc kFns[] = {
     {"gs_merkle_build", "cipup"},
     {"gs_mimc_trace", "cbbiup"},
     {"gs_mimc_constraints", "cpuupup"},
+    {"gs_air_trace", "cwibiiibwibup"},
+    {"gs_air_constraints", "cwibiiiipuupxip"},
     {"gs_small_interpolate", "bbio"},
     {"gs_small_eval_poly", "bibio"},
 };
@@ -95,14 +97,14 @@ bool get_u64(napi_env env, napi_value v, uint64_t *out) {
     return false;
 }
 
-typedef int (*fn12)(uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t,
-                    uintptr_t, uintptr_t);
+typedef int (*fn16)(uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t,
+                    uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t, uintptr_t);
 
 // call(name, ...args): generic forwarder.  All ABI parameters are integers or pointers, which the x86-64 SysV
 // calling convention passes in 8-byte slots; narrower parameters read the low bytes of their slot.
 napi_value Call(napi_env env, napi_callback_info info) {
-    size_t argc = 16;
-    napi_value argv[16];
+    size_t argc = 20;
+    napi_value argv[20];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     if (argc < 1) { napi_throw_type_error(env, nullptr, "call(name, ...args)"); return nullptr; }
     char name[64];
@@ -116,9 +118,11 @@ napi_value Call(napi_env env, napi_callback_info info) {
     if (argc - 1 != n) { napi_throw_type_error(env, nullptr, (std::string(name) + ": wrong number of arguments").c_str()); return nullptr; }
     void *sym = dlsym(g_lib, name);
     if (!sym) { napi_throw_error(env, nullptr, (std::string("symbol not found: ") + name).c_str()); return nullptr; }
-    uintptr_t a[12] = {0};
+    uintptr_t a[16] = {0};
     std::vector<std::vector<uint64_t>> arrays;
+    std::vector<std::vector<uint32_t>> arrays32;
     arrays.reserve(4);
+    arrays32.reserve(4);
     gs_ctx *ctx = nullptr;
     for (size_t i = 0; i < n; i++) {
         napi_value v = argv[i + 1];
@@ -155,12 +159,26 @@ napi_value Call(napi_env env, napi_callback_info info) {
                 a[i] = (uintptr_t)arrays.back().data();
                 break;
             }
+            case 'w': {
+                uint32_t alen;
+                NAPI_OK(env, napi_get_array_length(env, v, &alen));
+                arrays32.emplace_back(alen);
+                for (uint32_t k = 0; k < alen; k++) {
+                    napi_value e;
+                    uint64_t x;
+                    NAPI_OK(env, napi_get_element(env, v, k, &e));
+                    if (!get_u64(env, e, &x)) { napi_throw_type_error(env, nullptr, (std::string(name) + ": bad array element").c_str()); return nullptr; }
+                    arrays32.back()[k] = (uint32_t)x;
+                }
+                a[i] = (uintptr_t)arrays32.back().data();
+                break;
+            }
             default:
                 napi_throw_error(env, nullptr, "bad descriptor");
                 return nullptr;
         }
     }
-    int rc = ((fn12)sym)(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11]);
+    int rc = ((fn16)sym)(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]);
     if (rc != GS_OK) {
         typedef const char *(*errfn)(const gs_ctx *);
         errfn le = (errfn)dlsym(g_lib, "gs_last_error");

@@ -116,3 +116,42 @@ def test_rescue_2p16_config_verifies(hip_backend):
     data = stark.serialize(proof)
     assert len(data) == stark.sizeOf(proof)
     assert stark.verify(assertions, stark.parse(data))
+
+
+def degree5_air(field, steps, ef=16):
+    """A synthetic Poseidon-SHAPED AIR (BASELINE configs[3] shape: 6 trace registers, degree-5 S-box => composition domain 8T,
+    composition degree 7T): r_i' = r_i^5 + 3*r_{i+1} + k_{i mod 2}, with two cyclic static registers of periods 16 and 4."""
+    ks = [[(7 * i + 1) % 1000003 for i in range(16)], [11, 22, 33, 44]]
+
+    def transition(r, k):
+        return [r[i] ** 5 + 3 * r[(i + 1) % 6] + k[i % 2] for i in range(6)]
+
+    def evaluation(r, n, k):
+        return [n[i] - (r[i] ** 5 + 3 * r[(i + 1) % 6] + k[i % 2]) for i in range(6)]
+
+    return GenericAir(steps, 6, [5] * 6, ks, transition, evaluation, lambda seed: [seed[0] + i for i in range(6)], ef, field)
+
+
+def check_degree5(backend, steps):
+    f = PrimeField(backend=backend)
+    air = degree5_air(f, steps)
+    assert air.compositionFactor == 8
+    stark = Stark(air, {'hashAlgorithm': 'sha256', 'extensionFactor': 16, 'exeQueryCount': 40, 'friQueryCount': 20})
+    full = air.hostTrace([5])
+    assertions = [{'step': 0, 'register': r, 'value': full[0][r]} for r in range(6)] + \
+                 [{'step': steps - 1, 'register': 4, 'value': full[-1][4]}, {'step': steps // 2, 'register': 4, 'value': full[steps // 2][4]}]
+    proof = stark.prove(assertions, [], [5])
+    data = stark.serialize(proof)
+    assert len(data) == stark.sizeOf(proof)
+    assert len(proof['evProof']['values'][0]) == 6 * 16          # six registers merged per leaf (lib/Stark.ts:284-296)
+    assert stark.verify(assertions, stark.parse(data))
+    return data
+
+
+def test_degree5_six_registers_oracle(oracle_backend):
+    check_degree5(oracle_backend, 64)
+
+
+@pytest.mark.gpu
+def test_degree5_six_registers_hip_equals_oracle(hip_backend, oracle_backend):
+    assert check_degree5(hip_backend, 1 << 10) == check_degree5(oracle_backend, 1 << 10)
