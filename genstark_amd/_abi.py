@@ -30,6 +30,7 @@ _SIGNATURES = {
     'gs_field_modulus': (_int, [_vp]),
     'gs_alloc': (_int, [_vp, _u64, _pvp]),
     'gs_free': (_int, [_vp, _vp]),
+    'gs_cache_trim': (_int, [_vp]),
     'gs_upload': (_int, [_vp, _vp, _bytes, _u64]),
     'gs_download': (_int, [_vp, _vp, _vp, _u64]),
     'gs_copy': (_int, [_vp, _vp, _vp, _u64]),
@@ -125,6 +126,10 @@ class Backend:
     def free(self, ptr):
         if self.ctx:
             self.lib.gs_free(self.ctx, C.c_void_p(ptr))
+
+    def trim(self):
+        """Give the cached device blocks back to the driver (long-running services with changing problem sizes)."""
+        self.call('gs_cache_trim')
 
     def upload(self, ptr, data):
         self.call('gs_upload', C.c_void_p(ptr), bytes(data), len(data))

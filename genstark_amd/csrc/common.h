@@ -27,7 +27,8 @@ struct gs_ctx {
     // twiddle tables per (omega, n)
     std::map<std::string, NttPlan *> plans;
     // pinned host staging + small device scratch for scalars / index lists / pointer tables
-    void *h_stage = nullptr;
+    void *h_stage = nullptr;      // pinned + mapped: kernels may read/write it directly (zero-copy for tiny results)
+    void *h_stage_dev = nullptr;  // the device-side address of h_stage
     void *d_stage = nullptr;
     uint64_t stage_bytes = 0;
 };

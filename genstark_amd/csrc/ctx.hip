@@ -110,6 +110,15 @@ int gs_free(gs_ctx *c, void *dptr) {
     return GS_OK;
 }
 
+int gs_cache_trim(gs_ctx *c) {
+    if (!c) return GS_ERR_ARG;
+    GS_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto &kv : c->free_blocks) hipFree(kv.second);
+    c->free_blocks.clear();
+    c->cached_bytes = 0;
+    return GS_OK;
+}
+
 int gs_upload(gs_ctx *c, void *dst, const void *host_src, uint64_t bytes) {
     if (!c || (!dst && bytes) || (!host_src && bytes)) return GS_ERR_ARG;
     if (!bytes) return GS_OK;
@@ -143,9 +152,10 @@ int gs_stage_reserve(gs_ctx *c, uint64_t bytes) {
     GS_HIP(c, hipStreamSynchronize(c->stream));
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->d_stage) hipFree(c->d_stage);
-    c->h_stage = c->d_stage = nullptr;
+    c->h_stage = c->d_stage = c->h_stage_dev = nullptr;
     c->stage_bytes = 0;
-    GS_HIP(c, hipHostMalloc(&c->h_stage, nb, hipHostMallocDefault));
+    GS_HIP(c, hipHostMalloc(&c->h_stage, nb, hipHostMallocMapped));
+    GS_HIP(c, hipHostGetDevicePointer(&c->h_stage_dev, c->h_stage, 0));
     GS_HIP(c, hipMalloc(&c->d_stage, nb));
     c->stage_bytes = nb;
     return GS_OK;
@@ -180,20 +190,21 @@ extern "C" int gs_gather(gs_ctx *c, const void *src, uint64_t rec_bytes, const u
     uint64_t idx_bytes = (count * 8 + 255) & ~(uint64_t)255, data_bytes = count * rec_bytes;
     int rc = gs_stage_reserve(c, idx_bytes + data_bytes);
     if (rc) return rc;
+    // zero-copy: the kernel reads the index list from, and writes the (tiny) result into, mapped pinned host memory:
+    // one launch + one stream synchronisation per call, no staging copies
     memcpy(c->h_stage, idx_host, count * 8);
-    GS_HIP(c, hipMemcpyAsync(c->d_stage, c->h_stage, count * 8, hipMemcpyHostToDevice, c->stream));
-    uint8_t *d_out = (uint8_t *)c->d_stage + idx_bytes;
+    const uint64_t *d_idx = (const uint64_t *)c->h_stage_dev;
+    uint8_t *d_out = (uint8_t *)c->h_stage_dev + idx_bytes;
     if (rec_bytes % 16 == 0 && ((uintptr_t)src % 16) == 0) {
         uint32_t rec16 = (uint32_t)(rec_bytes / 16);
-        hipLaunchKernelGGL(k_gather16, dim3(gs_grid(count * rec16)), dim3(256), 0, c->stream, (const uint4 *)src,
-                           (const uint64_t *)c->d_stage, count, rec16, (uint4 *)d_out);
+        hipLaunchKernelGGL(k_gather16, dim3(gs_grid(count * rec16)), dim3(256), 0, c->stream, (const uint4 *)src, d_idx, count, rec16,
+                           (uint4 *)d_out);
     } else {
-        hipLaunchKernelGGL(k_gather_bytes, dim3(gs_grid(data_bytes)), dim3(256), 0, c->stream, (const uint8_t *)src,
-                           (const uint64_t *)c->d_stage, count, rec_bytes, d_out);
+        hipLaunchKernelGGL(k_gather_bytes, dim3(gs_grid(data_bytes)), dim3(256), 0, c->stream, (const uint8_t *)src, d_idx, count,
+                           rec_bytes, d_out);
     }
     GS_LAUNCH_CHECK(c);
     uint8_t *h_out = (uint8_t *)c->h_stage + idx_bytes;
-    GS_HIP(c, hipMemcpyAsync(h_out, d_out, data_bytes, hipMemcpyDeviceToHost, c->stream));
     GS_HIP(c, hipStreamSynchronize(c->stream));
     memcpy(host_out, h_out, data_bytes);
     return GS_OK;

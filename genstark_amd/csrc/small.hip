@@ -107,14 +107,12 @@ extern "C" int gs_merkle_prove_batch(gs_ctx *c, const void *leaves, const void *
     const uint64_t idx_bytes = (nf * 8 + 255) & ~(uint64_t)255, data_bytes = nf * 32;
     int rc = gs_stage_reserve(c, idx_bytes + data_bytes);
     if (rc) return rc;
-    memcpy(c->h_stage, fetch.data(), nf * 8);
-    GS_HIP(c, hipMemcpyAsync(c->d_stage, c->h_stage, nf * 8, hipMemcpyHostToDevice, c->stream));
-    uint8_t *d_out = (uint8_t *)c->d_stage + idx_bytes;
+    memcpy(c->h_stage, fetch.data(), nf * 8);   // zero-copy through mapped pinned memory (see gs_gather)
+    uint8_t *d_out = (uint8_t *)c->h_stage_dev + idx_bytes;
     hipLaunchKernelGGL(k_gather_digests, dim3((unsigned)((nf * 2 + 255) / 256)), dim3(256), 0, c->stream, (const uint4 *)leaves,
-                       (const uint4 *)nodes, (const uint64_t *)c->d_stage, (uint32_t)nf, (uint4 *)d_out);
+                       (const uint4 *)nodes, (const uint64_t *)c->h_stage_dev, (uint32_t)nf, (uint4 *)d_out);
     GS_LAUNCH_CHECK(c);
     uint8_t *h_out = (uint8_t *)c->h_stage + idx_bytes;
-    GS_HIP(c, hipMemcpyAsync(h_out, d_out, data_bytes, hipMemcpyDeviceToHost, c->stream));
     GS_HIP(c, hipStreamSynchronize(c->stream));
     memcpy(values_out, h_out, (size_t)count * 32);
     memcpy(nodes_out, h_out + (size_t)count * 32, (size_t)total * 32);

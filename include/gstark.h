@@ -70,7 +70,8 @@ void *gs_stream(gs_ctx *ctx);                          /* the hipStream_t the ke
 int gs_field_modulus(uint8_t out_le[16]);              /* FiniteField.modulus */
 
 int gs_alloc(gs_ctx *ctx, uint64_t bytes, void **dptr);
-int gs_free(gs_ctx *ctx, void *dptr);
+int gs_free(gs_ctx *ctx, void *dptr);                 /* parks the block in the context's cache (no device sync) */
+int gs_cache_trim(gs_ctx *ctx);                        /* synchronises and returns every cached block to the driver */
 int gs_upload(gs_ctx *ctx, void *dst, const void *host_src, uint64_t bytes);   /* newVectorFrom: BoundaryConstraints.ts:24,40 */
 int gs_download(gs_ctx *ctx, void *host_dst, const void *src, uint64_t bytes); /* toValues / toBuffer: CompositionPolynomial.ts:58 */
 int gs_copy(gs_ctx *ctx, void *dst, const void *src, uint64_t bytes);

@@ -43,6 +43,7 @@ struct FnDesc {
 const FnDesc kFns[] = {
     {"gs_sync", "c"},
     {"gs_free", "cp"},
+    {"gs_cache_trim", "c"},
     {"gs_upload", "cpbu"},
     {"gs_download", "copu"},
     {"gs_copy", "cppu"},

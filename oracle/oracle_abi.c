@@ -50,6 +50,7 @@ int gs_alloc(gs_ctx *c, uint64_t bytes, void **p) {
     return *p ? GS_OK : fail(c, GS_ERR_OOM, "malloc failed");
 }
 int gs_free(gs_ctx *c, void *p) { (void)c; free(p); return GS_OK; }
+int gs_cache_trim(gs_ctx *c) { (void)c; return GS_OK; }
 int gs_upload(gs_ctx *c, void *d, const void *s, uint64_t n) { (void)c; memcpy(d, s, n); return GS_OK; }
 int gs_download(gs_ctx *c, void *d, const void *s, uint64_t n) { (void)c; memcpy(d, s, n); return GS_OK; }
 int gs_copy(gs_ctx *c, void *d, const void *s, uint64_t n) { (void)c; memmove(d, s, n); return GS_OK; }
