@@ -20,6 +20,8 @@
 //     into the first pass: out-of-range loads are predicated off, nothing is padded in memory.
 //   * The inverse transform is the same kernel on omega^-1 with the 1/n scale fused into the last
 //     pass's stores.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct NttPlan {
@@ -31,13 +33,14 @@ struct NttPlan {
     int npass = 0;
     int L[4] = {0, 0, 0, 0};
     fe *wR[4] = {nullptr, nullptr, nullptr, nullptr};  // (omega^(n/R))^i, i < R, per pass
+    fe *twp[4] = {nullptr, nullptr, nullptr, nullptr}; // inter-pass twiddles omega_{Ns*R}^(jq*k) as a [k][jq] table (passes >= 1, when small)
     fe w16[8];                                         // omega_16^i
 };
 
 struct PassArgs {
     uint64_t n, in_len, in_stride, out_stride;
     int logn, logNs, logWj, log_lo, scale;
-    const fe *tw_lo, *tw_hi, *wR;
+    const fe *tw_lo, *tw_hi, *wR, *twp;
     fe w16[8];
     fe ninv;
 };
@@ -102,7 +105,11 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const fe *__restrict__ in, fe 
     }
     const uint64_t Ns = 1ull << a.logNs;
     const uint64_t jq = j & (Ns - 1);
-    if (a.logNs > 0) {
+    if (a.logNs > 0 && a.twp != nullptr) {
+        // precomputed [k][jq] table (L2-resident): 16 coalesced loads replace the 15-step running product
+#pragma unroll
+        for (int m = 0; m < 16; m++) v[m] = fe_mul(v[m], a.twp[((uint64_t)(kk + RB * m) << a.logNs) + jq]);
+    } else if (a.logNs > 0) {
         // v[m] *= omega_{Ns*R}^(jq * (kk + RB*m)) : start value + running product
         const uint64_t eu = a.n >> (a.logNs + 4 + LB);
         fe cur = pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * kk * eu);
@@ -192,6 +199,22 @@ __global__ void k_eval_horner(const fe *__restrict__ in, fe *__restrict__ out, u
     }
 }
 
+// twp[k * Ns + jq] = omega^(jq * k * eu), eu = n / (Ns * R)
+__global__ void k_build_pass_twiddles(fe *__restrict__ out, uint64_t Ns, uint64_t R, uint64_t eu, const fe *__restrict__ tw_lo,
+                                      const fe *__restrict__ tw_hi, int log_lo, int logn) {
+    const uint64_t total = Ns * R;
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = t / Ns, jq = t % Ns;
+        out[t] = pow_lookup(tw_lo, tw_hi, log_lo, logn, jq * k * eu);
+    }
+}
+
+static uint64_t max_pass_twiddle_entries() {  // 16 MiB per table by default; larger passes keep the running product
+    static uint64_t v = 0;
+    if (!v) { const char *e = getenv("GSTARK_NTT_TWIDDLE_LOG"); v = 1ull << (e ? atoi(e) : 20); }
+    return v;
+}
+
 static std::string plan_key(const fe &omega, uint64_t n) {
     char buf[96];
     snprintf(buf, sizeof buf, "%08x%08x%08x%08x:%llu", omega.w3, omega.w2, omega.w1, omega.w0, (unsigned long long)n);
@@ -231,9 +254,17 @@ static int plan_get(gs_ctx *c, const fe &omega, uint64_t n, NttPlan **out) {
         p->npass = np;
         fe w16 = fe_pow_u64(omega, n / 16), cur = fe_one();
         for (int i = 0; i < 8; i++) { p->w16[i] = cur; cur = fe_mul(cur, w16); }
+        uint64_t Ns_acc = 1;
         for (int i = 0; i < np; i++) {
             p->L[i] = base + (i < extra ? 1 : 0);
             uint64_t R = 1ull << p->L[i];
+            if (i > 0 && Ns_acc * R <= max_pass_twiddle_entries()) {
+                if ((rc = gs_alloc(c, Ns_acc * R * 16, &q))) { delete p; return rc; }
+                p->twp[i] = (fe *)q;
+                hipLaunchKernelGGL(k_build_pass_twiddles, dim3(gs_grid(Ns_acc * R)), dim3(256), 0, c->stream, p->twp[i], Ns_acc, R,
+                                   n / (Ns_acc * R), p->tw_lo, p->tw_hi, p->log_lo, p->logn);
+            }
+            Ns_acc *= R;
             if (R > 16) {
                 // share tables between passes of equal radix
                 for (int k = 0; k < i; k++)
@@ -336,6 +367,7 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
         a.tw_lo = p->tw_lo;
         a.tw_hi = p->tw_hi;
         a.wR = p->wR[i];
+        a.twp = p->twp[i];
         for (int k = 0; k < 8; k++) a.w16[k] = p->w16[k];
         a.ninv = ninv;
         switch (LB) {
