@@ -113,3 +113,83 @@ def sharded_commit(field, hash_, local_traces, register_count, trace_length, ext
     while len(level) > 1:
         level = hash_.digestMany([level[2 * i] + level[2 * i + 1] for i in range(len(level) // 2)])
     return level[0], leaves, tree, {r: columns[r] for r in range(register_count)}
+
+
+def domain_sharded_commit(field, hash_, polys, extension_factor, group=None):
+    """Domain-sharded low-degree extension + commitment: works for ANY register count, including the single-register MiMC
+    proof (SURVEY.md section 8e "one register"), and keeps every GPU busy for G <= extensionFactor.
+
+    `polys` (Matrix R x T: the trace polynomials P_r, replicated on every rank — they are E times smaller than the
+    extension and come from one iNTT of the trace) is extended WITHOUT communication: rank g evaluates every P_r on the coset
+    {omega^(g + G*i)}: scale coefficient j by omega^(g*j), then one forward NTT of size N/G with root omega^G.  That leaves
+    the evaluations strided over the ranks (index i on rank i mod G); the Merkle tree is defined over natural order, so ONE
+    exchange (point-to-point, (N/G^2)*16 bytes per register per pair) plus a local G x N/G^2 transpose turns them into
+    contiguous blocks, after which leaf hashing, the subtree and the all-gather of sub-roots are as in sharded_commit().
+    Returns (root, local leaf digests, local subtree, {register -> Vector of this rank's N/G consecutive evaluations})."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    backend = field.backend
+    registers, t = polys.rowCount, polys.colCount
+    n = t * extension_factor
+    if world & (world - 1) or world > extension_factor or (n // world) % world:
+        raise ValueError('world size must be a power of two not larger than the extension factor')
+    m = n // world                       # evaluations per rank and register
+    chunk = m // world                   # what every pair of ranks exchanges per register
+    device = 'cpu' if backend.name != 'hip-gfx950' else torch.device('cuda', backend.device)
+    omega = field.getRootOfUnity(n)
+
+    # ---- 1. coset evaluations, no communication: P_r(omega^(g + G*i)), i < N/G
+    scale = field.getPowerSeries(field.exp(omega, rank), t)          # omega^(g*j)
+    sub_domain = field.getPowerSeries(field.exp(omega, world), m)    # powers of omega^G (order N/G)
+    send = torch.empty((registers, m * ELEMENT_SIZE), dtype=torch.uint8, device=device)
+    scaled = Matrix(backend, registers, t)
+    for r in range(registers):
+        backend.call('gs_vec_mul', C.c_void_p(polys.ptr + r * t * ELEMENT_SIZE), C.c_void_p(scale.ptr), t,
+                     C.c_void_p(scaled.ptr + r * t * ELEMENT_SIZE))
+    backend.call('gs_eval_polys_at_roots', C.c_void_p(scaled.ptr), registers, t, field.exp(omega, world).to_bytes(16, 'little'), m,
+                 C.c_void_p(send.data_ptr()))
+    backend.sync()
+
+    # ---- 2. strided -> blocked: rank h needs i in [h*m, (h+1)*m), i.e. my coset positions i' in [h*chunk, (h+1)*chunk)
+    recv = torch.empty((registers, world, chunk * ELEMENT_SIZE), dtype=torch.uint8, device=device)   # [r][source rank][i']
+    cb = chunk * ELEMENT_SIZE
+    if world == 1:
+        recv.view(registers, -1).copy_(send)
+    else:
+        ops = []
+        for h in range(world):
+            for r in range(registers):
+                piece = send[r, h * cb:(h + 1) * cb]
+                if h == rank:
+                    recv[r, rank].copy_(piece)
+                else:
+                    ops.append(dist.P2POp(dist.isend, piece, h, group, tag=r))
+        for h in range(world):
+            if h != rank:
+                for r in range(registers):
+                    ops.append(dist.P2POp(dist.irecv, recv[r, h], h, group, tag=r))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if device != 'cpu':
+        torch.cuda.synchronize()
+    # local transpose [source g][i'] -> natural order within my block: index (h*m + G*i' + g) - h*m = G*i' + g
+    columns = []
+    for r in range(registers):
+        src = _tensor_vector(backend, recv, m, byte_offset=r * m * ELEMENT_SIZE)
+        col = Vector(backend, m)
+        backend.call('gs_transpose_matrix', C.c_void_p(src.ptr), world, chunk, C.c_void_p(col.ptr))
+        columns.append(col)
+
+    # ---- 3./4. leaf hashing, subtree, all-gather of sub-roots
+    leaves = hash_.mergeVectorRows(columns)
+    tree = MerkleTree.create(leaves, hash_)
+    if world == 1:
+        level = [tree.root]
+    else:
+        mine_t = torch.frombuffer(bytearray(tree.root), dtype=torch.uint8).to(device)
+        gathered = [torch.empty(DIGEST_SIZE, dtype=torch.uint8, device=device) for _ in range(world)]
+        dist.all_gather(gathered, mine_t, group=group)
+        level = [bytes(x.cpu().numpy().tobytes()) for x in gathered]
+    while len(level) > 1:
+        level = hash_.digestMany([level[2 * i] + level[2 * i + 1] for i in range(len(level) // 2)])
+    return level[0], leaves, tree, {r: columns[r] for r in range(registers)}

@@ -11,7 +11,7 @@ import pytest
 from conftest import ORACLE_LIB, ROOT
 
 
-def launch(world, registers, log_t, ef, alg, port, env_extra=None):
+def launch(world, registers, log_t, ef, alg, port, env_extra=None, mode='registers'):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', **(env_extra or {}))
     worker = os.path.join(ROOT, 'tests', 'sharded_worker.py')
     if world == 1:
@@ -19,7 +19,7 @@ def launch(world, registers, log_t, ef, alg, port, env_extra=None):
     else:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
                '--master-port', str(port), worker]
-    return subprocess.run(cmd + [str(registers), str(log_t), str(ef), alg], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    return subprocess.run(cmd + [str(registers), str(log_t), str(ef), alg, mode], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
 
 
 @pytest.mark.parametrize('world,registers,log_t,ef,alg', [(1, 6, 6, 16, 'blake2s256'), (2, 6, 6, 16, 'blake2s256'),
@@ -28,6 +28,21 @@ def test_sharded_commit_gloo(oracle_backend, world, registers, log_t, ef, alg):
     r = launch(world, registers, log_t, ef, alg, 29540 + world + registers, {'GSTARK_TEST_LIB': ORACLE_LIB})
     assert r.returncode == 0, r.stderr[-3000:]
     assert 'sharded commit OK' in r.stdout
+
+
+@pytest.mark.parametrize('world,registers,log_t,ef', [(1, 1, 6, 16), (2, 1, 6, 16), (4, 1, 6, 16), (8, 1, 6, 16), (4, 6, 5, 16), (2, 3, 5, 8)])
+def test_domain_sharded_commit_gloo(oracle_backend, world, registers, log_t, ef):
+    """Single-register (MiMC) and multi-register traces, every rank busy: coset NTTs without communication, one exchange."""
+    r = launch(world, registers, log_t, ef, 'blake2s256', 29600 + world * 7 + registers, {'GSTARK_TEST_LIB': ORACLE_LIB}, mode='domain')
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'sharded commit OK: mode=domain' in r.stdout
+
+
+@pytest.mark.gpu
+def test_domain_sharded_commit_single_gpu():
+    r = launch(1, 1, 14, 16, 'blake2s256', 0, mode='domain')
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'sharded commit OK: mode=domain' in r.stdout
 
 
 @pytest.mark.gpu
