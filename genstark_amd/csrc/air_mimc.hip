@@ -32,15 +32,19 @@ int gs_mimc_trace(gs_ctx *c, const uint8_t seed[16], const uint8_t *rc_host, uin
     hu128 *t = (hu128 *)c->h_stage;
     hu128 x = hf_load(seed);
     uint32_t ri = 0;
-    for (uint64_t i = 0; i < steps; i++) {
-        t[i] = x;
-        hu128 y = hf_mul_weak(hf_mul_weak(x, x), x);   // any representative of x^3
-        hu128 sum = y + rc[ri];
-        if (sum < y) sum += HF_C;                        // wrapped past 2^128: +2^128 == +C (the wrapped value is small)
-        x = hf_canon(sum);
-        if (++ri == nrc) ri = 0;
+    const uint64_t CHUNK = 1ull << 16;            // copy finished chunks while the next one is being generated
+    for (uint64_t base = 0; base < steps; base += CHUNK) {
+        const uint64_t end = base + CHUNK < steps ? base + CHUNK : steps;
+        for (uint64_t i = base; i < end; i++) {
+            t[i] = x;
+            hu128 y = hf_mul_weak(hf_mul_weak(x, x), x);   // any representative of x^3
+            hu128 sum = y + rc[ri];
+            if (sum < y) sum += HF_C;                        // wrapped past 2^128: +2^128 == +C (the wrapped value is small)
+            x = hf_canon(sum);
+            if (++ri == nrc) ri = 0;
+        }
+        GS_HIP(c, hipMemcpyAsync((uint8_t *)out + base * 16, t + base, (end - base) * 16, hipMemcpyHostToDevice, c->stream));
     }
-    GS_HIP(c, hipMemcpyAsync(out, c->h_stage, steps * 16, hipMemcpyHostToDevice, c->stream));
     GS_HIP(c, hipStreamSynchronize(c->stream));
     return GS_OK;
 }

@@ -106,18 +106,22 @@ GF_HD fe fe_sub(const fe &a, const fe &b) {
 
 GF_HD fe fe_neg(const fe &a) { return fe_is_zero(a) ? a : fe_sub(fe_zero(), a); }
 
-// one row of the schoolbook product: o (5 limbs) = ai * b   (4 x v_mad_u64_u32 + 4 carry ops)
+// one row of the schoolbook product: o (5 limbs) = ai * b.  Each v_mad_u64_u32 (32x32+64) absorbs the high word of the
+// previous one as its addend (ai*bj + hi < 2^64 always), so a row is 4 dependent mads and NO carry-chain ops; the four
+// rows of a product are independent of each other and give the scheduler its parallelism.
 GF_HD void fe_row_mul(uint32_t ai, const uint32_t b[4], uint32_t o[5]) {
-    uint64_t p0 = (uint64_t)ai * b[0], p1 = (uint64_t)ai * b[1], p2 = (uint64_t)ai * b[2], p3 = (uint64_t)ai * b[3];
-    uint32_t c;
-    o[0] = (uint32_t)p0;
-    o[1] = gf_addc((uint32_t)p1, (uint32_t)(p0 >> 32), 0u, c);
-    o[2] = gf_addc((uint32_t)p2, (uint32_t)(p1 >> 32), c, c);
-    o[3] = gf_addc((uint32_t)p3, (uint32_t)(p2 >> 32), c, c);
-    o[4] = (uint32_t)(p3 >> 32) + c;
+    uint64_t t = (uint64_t)ai * b[0];
+    o[0] = (uint32_t)t;
+    t = (uint64_t)ai * b[1] + (t >> 32);
+    o[1] = (uint32_t)t;
+    t = (uint64_t)ai * b[2] + (t >> 32);
+    o[2] = (uint32_t)t;
+    t = (uint64_t)ai * b[3] + (t >> 32);
+    o[3] = (uint32_t)t;
+    o[4] = (uint32_t)(t >> 32);
 }
 
-// 128x128 -> 256-bit schoolbook product, 32-bit limbs: 16 x v_mad_u64_u32 + 31 carry-chain ops
+// 128x128 -> 256-bit schoolbook product, 32-bit limbs: 16 x v_mad_u64_u32 + 15 carry-chain ops (adding the rows up)
 GF_HD void fe_mul_wide(const fe &a, const fe &b, uint32_t r[8]) {
     const uint32_t bv[4] = {b.w0, b.w1, b.w2, b.w3};
     uint32_t r0[5], r1[5], r2[5], r3[5], c;
@@ -152,12 +156,15 @@ GF_HD uint32_t gf_fsh(uint32_t hi, uint32_t lo, int s) { return (hi << s) | (lo 
 //     =: w + k*2^128, k in {0,1}; k = 1 leaves w tiny, so a single "+C / conditional -p" finishes.
 GF_HD fe fe_reduce_wide(const uint32_t r[8]) {
     uint32_t c, b;
-    // A = 9*hi = (hi << 3) + hi, limbs a0..a4
-    uint32_t a0 = gf_addc(r[4] << 3, r[4], 0u, c);
-    uint32_t a1 = gf_addc(gf_fsh(r[5], r[4], 3), r[5], c, c);
-    uint32_t a2 = gf_addc(gf_fsh(r[6], r[5], 3), r[6], c, c);
-    uint32_t a3 = gf_addc(gf_fsh(r[7], r[6], 3), r[7], c, c);
-    uint32_t a4 = (r[7] >> 29) + c;
+    // A = 9*hi, limbs a0..a4 (a4 < 9): four chained mads instead of shift + carry-add pairs
+    uint64_t m = (uint64_t)r[4] * 9u;
+    uint32_t a0 = (uint32_t)m;
+    m = (uint64_t)r[5] * 9u + (m >> 32);
+    uint32_t a1 = (uint32_t)m;
+    m = (uint64_t)r[6] * 9u + (m >> 32);
+    uint32_t a2 = (uint32_t)m;
+    m = (uint64_t)r[7] * 9u + (m >> 32);
+    uint32_t a3 = (uint32_t)m, a4 = (uint32_t)(m >> 32);
     // U = lo + (A << 32), six limbs
     uint32_t u1 = gf_addc(r[1], a0, 0u, c);
     uint32_t u2 = gf_addc(r[2], a1, c, c);

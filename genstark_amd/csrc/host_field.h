@@ -31,38 +31,28 @@ static inline hu128 hf_mul(hu128 a, hu128 b) {
     return hf_reduce(hi, lo);
 }
 // Weakly reduced product for latency-bound serial chains (the MiMC recurrence): returns ANY 128-bit representative of
-// a*b mod p (inputs may be any 128-bit values).  The fold multiplies by 2^128 mod p = 2^35 + 2^32 - 1 with shifts and
-// skips the final compare-and-subtract, which shortens the dependency chain of x -> x^2 -> x^3.
+// a*b mod p (inputs may be any 128-bit values).  All-additive fold, no data-dependent branches (the sign fix-ups of a
+// shift/subtract fold mispredict every other product): with C = 2^128 mod p and hi = h1*2^64 + h0,
+//   a*b = lo + h0*C + ((h1*C mod 2^64) << 64) + ((h1*C >> 64) + carries) * C        (mod p)
+// and the final compare-and-subtract is skipped, which shortens the dependency chain of x -> x^2 -> x^3.
 static inline hu128 hf_mul_weak(hu128 a, hu128 b) {
     uint64_t a0 = (uint64_t)a, a1 = (uint64_t)(a >> 64), b0 = (uint64_t)b, b1 = (uint64_t)(b >> 64);
     hu128 p00 = (hu128)a0 * b0, p01 = (hu128)a0 * b1, p10 = (hu128)a1 * b0, p11 = (hu128)a1 * b1;
-    hu128 mid = p01 + p10, midc = mid < p01;
-    hu128 lo = p00 + (mid << 64), c1 = lo < p00;
-    hu128 hi = p11 + (mid >> 64) + (midc << 64) + c1;
-    // hi * C = ((9*hi) << 32) - hi
-    hu128 h8 = hi << 3;
-    uint64_t top = (uint64_t)(hi >> 125);
-    hu128 h9 = h8 + hi;
-    top += (h9 < h8);
-    hu128 sh = h9 << 32;
-    uint64_t T = (top << 32) | (uint64_t)(h9 >> 96);  // bits of (9*hi << 32) at or above 2^128, < 2^36
-    hu128 s = lo + sh;
-    int net = (int)(s < lo);
-    hu128 d = s - hi;
-    net -= (int)(s < hi);
-    hu128 tc = (((hu128)T * 9) << 32) - T;             // T * C < 2^73
-    hu128 e = d + tc;
-    net += (int)(e < d);                               // value = e + net * 2^128, net in {-1, 0, 1, 2}
-    if (net > 0) {
-        hu128 f = e + (hu128)(unsigned)net * HF_C;
-        if (f < e) f += HF_C;
-        e = f;
-    } else if (net < 0) {
-        hu128 f = e - HF_C;
-        if (f > e) f -= HF_C;
-        e = f;
-    }
-    return e;
+    hu128 mid = p01 + p10;
+    uint64_t midc = mid < p01;
+    hu128 lo = p00 + (mid << 64);
+    uint64_t c1 = lo < p00;
+    hu128 hi = p11 + (mid >> 64) + ((hu128)midc << 64) + c1;
+    const uint64_t cc = (uint64_t)HF_C;
+    hu128 m0 = (hu128)(uint64_t)hi * cc, m1 = (hu128)(uint64_t)(hi >> 64) * cc;   // each < 2^100
+    hu128 t = m0 + (m1 << 64);
+    uint64_t k = t < m0;
+    hu128 s = lo + t;
+    k += s < lo;
+    hu128 top = (hu128)((uint64_t)(m1 >> 64) + k) * cc;                              // (< 2^37) * C < 2^73
+    hu128 r = s + top;
+    if (__builtin_expect(r < s, 0)) r += HF_C;                                         // probability ~2^-55
+    return r;
 }
 static inline hu128 hf_canon(hu128 x) {
     while (x >= hf_p()) x -= hf_p();
