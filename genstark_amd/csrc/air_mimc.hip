@@ -37,7 +37,7 @@ int gs_mimc_trace(gs_ctx *c, const uint8_t seed[16], const uint8_t *rc_host, uin
         const uint64_t end = base + CHUNK < steps ? base + CHUNK : steps;
         for (uint64_t i = base; i < end; i++) {
             t[i] = x;
-            hu128 y = hf_mul_weak(hf_mul_weak(x, x), x);   // any representative of x^3
+            hu128 y = hf_cube_weak(x);                       // any representative of x^3
             hu128 sum = y + rc[ri];
             if (sum < y) sum += HF_C;                        // wrapped past 2^128: +2^128 == +C (the wrapped value is small)
             x = hf_canon(sum);
