@@ -344,13 +344,42 @@ class PrimeField:
         return int.from_bytes(buf.raw, 'little')
 
     def mulPolys(self, a, b):
-        """BoundaryConstraints.ts:30 — product of two tiny polynomials (degree <= #assertions)."""
-        av, bv = a.toValues(), b.toValues()
-        out = [0] * (len(av) + len(bv) - 1)
-        for i, x in enumerate(av):
-            for j, y in enumerate(bv):
-                out[i + j] = (out[i + j] + x * y) % self.modulus
-        return self.newVectorFrom(out)
+        """BoundaryConstraints.ts:30 — product of two polynomials.  The reference only multiplies tiny ones (degree <= number
+        of assertions): those stay on the host; larger operands go through the device NTT (evaluate both on a domain of
+        >= len(a)+len(b)-1 roots, multiply pointwise, interpolate)."""
+        la, lb = a.length, b.length
+        if la * lb <= 4096:
+            av, bv = a.toValues(), b.toValues()
+            out = [0] * (la + lb - 1)
+            for i, x in enumerate(av):
+                for j, y in enumerate(bv):
+                    out[i + j] = (out[i + j] + x * y) % self.modulus
+            return self.newVectorFrom(out)
+        n = 1 << (la + lb - 2).bit_length()
+        roots = self.getPowerSeries(self.getRootOfUnity(n), n)
+        prod = self.mulVectorElements(self.evalPolyAtRoots(a, roots), self.evalPolyAtRoots(b, roots))
+        full = self.interpolateRoots(roots, prod)
+        return Vector(self.backend, la + lb - 1, owner=full._owner, offset=full._offset)
+
+    def _pad_poly(self, v, length):
+        if v.length == length:
+            return v
+        out = Vector(self.backend, length)
+        self.backend.call('gs_copy', C.c_void_p(out.ptr), C.c_void_p(v.ptr), v.length * ELEMENT_SIZE)
+        self.backend.upload(out.ptr + v.length * ELEMENT_SIZE, bytes((length - v.length) * ELEMENT_SIZE))
+        return out
+
+    def addPolys(self, a, b):
+        """galois FiniteField.addPolys: coefficient-wise sum, the shorter operand zero-extended."""
+        n = max(a.length, b.length)
+        return self.addVectorElements(self._pad_poly(a, n), self._pad_poly(b, n))
+
+    def subPolys(self, a, b):
+        n = max(a.length, b.length)
+        return self.subVectorElements(self._pad_poly(a, n), self._pad_poly(b, n))
+
+    def mulPolyByConstant(self, a, c):
+        return self.mulVectorElements(a, c % self.modulus)
 
     def interpolate(self, xs, ys):
         """BoundaryConstraints.ts:42; LowDegreeProver.ts:243 — Lagrange through a handful of points: O(n^2) host

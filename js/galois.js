@@ -251,10 +251,29 @@ class PrimeField {
     }
     evalPolyAt(poly, x) { const out = Buffer.alloc(16); native().call('gs_eval_poly_at', this.ctx, poly.ptr, poly.length, le(this.mod(x)), out); return fromLe(out); }
     mulPolys(a, b) {
-        const av = a.toValues(), bv = b.toValues(), out = new Array(av.length + bv.length - 1).fill(0n);
-        for (let i = 0; i < av.length; i++) for (let j = 0; j < bv.length; j++) out[i + j] = this.mod(out[i + j] + av[i] * bv[j]);
-        return this.newVectorFrom(out);
+        // tiny operands (BoundaryConstraints.ts:30) on the host; larger ones through the device NTT
+        const la = a.length, lb = b.length;
+        if (la * lb <= 4096) {
+            const av = a.toValues(), bv = b.toValues(), out = new Array(la + lb - 1).fill(0n);
+            for (let i = 0; i < la; i++) for (let j = 0; j < lb; j++) out[i + j] = this.mod(out[i + j] + av[i] * bv[j]);
+            return this.newVectorFrom(out);
+        }
+        let n = 1; while (n < la + lb - 1) n <<= 1;
+        const roots = this.getPowerSeries(this.getRootOfUnity(n), n);
+        const full = this.interpolateRoots(roots, this.mulVectorElements(this.evalPolyAtRoots(a, roots), this.evalPolyAtRoots(b, roots)));
+        return new Vector(this, la + lb - 1, full.owner, full.offset);
     }
+    padPoly(v, length) {
+        if (v.length === length) return v;
+        const out = new Vector(this, length);
+        native().call('gs_copy', this.ctx, out.ptr, v.ptr, v.length * 16);
+        const zeros = Buffer.alloc((length - v.length) * 16);
+        native().call('gs_upload', this.ctx, out.ptr + BigInt(v.length * 16), zeros, zeros.length);
+        return out;
+    }
+    addPolys(a, b) { const n = Math.max(a.length, b.length); return this.addVectorElements(this.padPoly(a, n), this.padPoly(b, n)); }
+    subPolys(a, b) { const n = Math.max(a.length, b.length); return this.subVectorElements(this.padPoly(a, n), this.padPoly(b, n)); }
+    mulPolyByConstant(a, c) { return this.mulVectorElements(a, this.mod(c)); }
     interpolate(xs, ys) {
         const n = xs.length, out = Buffer.alloc(16 * n);
         native().call('gs_small_interpolate', xs.toBuffer(), ys.toBuffer(), n, out);

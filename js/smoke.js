@@ -45,4 +45,17 @@ const ys = field.transposeVector(ev, 4), xs = field.transposeVector(domain, 4);
 const fast = field.interpolateQuarticBatch(xs, ys).toBuffer();
 const generic = field.interpolateQuarticBatch(field.newMatrixFrom(xs.toValues()), ys).toBuffer();
 assert(fast.equals(generic));
+// polynomial members: NTT-based product vs schoolbook, zero-extending sum/difference
+{
+    const a = field.getPowerSeries(987654321987654321n, 150).toValues(), b = field.getPowerSeries(31337n, 90).toValues();
+    const want = new Array(a.length + b.length - 1).fill(0n);
+    for (let i = 0; i < a.length; i++) for (let j = 0; j < b.length; j++) want[i + j] = (want[i + j] + a[i] * b[j]) % P;
+    const got = field.mulPolys(field.newVectorFrom(a), field.newVectorFrom(b));
+    assert.strictEqual(got.length, want.length);
+    assert.deepStrictEqual(got.toValues(), want);
+    const pad = b.concat(new Array(a.length - b.length).fill(0n));
+    assert.deepStrictEqual(field.addPolys(field.newVectorFrom(a), field.newVectorFrom(b)).toValues(), a.map((x, i) => (x + pad[i]) % P));
+    assert.deepStrictEqual(field.subPolys(field.newVectorFrom(b), field.newVectorFrom(a)).toValues(), a.map((x, i) => (pad[i] - x + P) % P));
+    assert.deepStrictEqual(field.mulPolyByConstant(field.newVectorFrom(b), 5n).toValues(), b.map(x => x * 5n % P));
+}
 console.log(`js smoke OK: galois/merkle drop-in objects via N-API on backend ${process.env.GSTARK_ALLOW_TEST_DOUBLE === '1' ? '(test double allowed)' : 'hip-gfx950'}`);

@@ -128,6 +128,16 @@ def check_small_polys(backend, rng):
     big = rand_elements(rng, 300)
     x = rng.randrange(P)
     assert f.evalPolyAt(f.newVectorFrom(big), x) == PF.eval_poly_at(big, x)
+    # the rest of galois' polynomial members: large products go through the device NTT
+    for la, lb in ((300, 200), (65, 64), (1000, 7)):
+        a, b = rand_elements(rng, la), rand_elements(rng, lb)
+        got = f.mulPolys(f.newVectorFrom(a), f.newVectorFrom(b))
+        assert got.length == la + lb - 1 and got.toValues() == PF.mul_polys(a, b)
+    a, b = rand_elements(rng, 9), rand_elements(rng, 5)
+    pad = b + [0] * 4
+    assert f.addPolys(f.newVectorFrom(a), f.newVectorFrom(b)).toValues() == [(x + y) % P for x, y in zip(a, pad)]
+    assert f.subPolys(f.newVectorFrom(b), f.newVectorFrom(a)).toValues() == [(y - x) % P for x, y in zip(a, pad)]
+    assert f.mulPolyByConstant(f.newVectorFrom(a), P - 2).toValues() == [x * (P - 2) % P for x in a]
 
 
 def check_quartic(backend, rng, logn, depth):
