@@ -155,3 +155,70 @@ def test_degree5_six_registers_oracle(oracle_backend):
 @pytest.mark.gpu
 def test_degree5_six_registers_hip_equals_oracle(hip_backend, oracle_backend):
     assert check_degree5(hip_backend, 1 << 10) == check_degree5(oracle_backend, 1 << 10)
+
+
+# ---- Poseidon 6x128 (examples/poseidon/hash6x128.ts), BASELINE configs[3] ---------------------------------------------
+POSEIDON_OPTS = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 68, 'friQueryCount': 24}   # hash6x128.ts:33-39
+
+
+def poseidon_case(backend, steps):
+    from genstark_amd import poseidon
+    f = PrimeField(backend=backend)
+    air = poseidon.poseidon6x128_air(steps, 16, f)
+    digest = poseidon.poseidon_hash(f, [1, 2, 3, 4])          # the example's own control computation (hash6x128.ts:19)
+    assertions = [{'step': 63, 'register': 0, 'value': digest[0]}, {'step': 63, 'register': 1, 'value': digest[1]}]   # :93-96
+    return air, Stark(air, POSEIDON_OPTS), digest, assertions
+
+
+def check_poseidon(backend, steps, host_trace=True):
+    air, stark, digest, assertions = poseidon_case(backend, steps)
+    assert air.compositionFactor == 8 and air.traceRegisterCount == 6
+    trace = air.initProvingContext([], [1, 2, 3, 4]).generateExecutionTrace()
+    assert (trace.getValue(0, 63), trace.getValue(1, 63)) == tuple(digest)      # device-side VM trace == utils.ts createHash
+    if host_trace:
+        assert trace.toValues() == [list(r) for r in zip(*air.hostTrace([1, 2, 3, 4]))]
+    proof = stark.prove(assertions, [], [1, 2, 3, 4])
+    data = stark.serialize(proof)
+    assert len(data) == stark.sizeOf(proof)
+    assert stark.verify(assertions, stark.parse(data))
+    wrong = [dict(assertions[0], value=(digest[0] + 1) % ga.MODULUS), assertions[1]]
+    with pytest.raises(StarkError):
+        stark.prove(wrong, [], [1, 2, 3, 4])
+    with pytest.raises(StarkError):
+        stark.verify(wrong, stark.parse(data))
+    return data
+
+
+def test_poseidon_parameters_follow_the_example():
+    from genstark_amd import poseidon
+    f = PrimeField.__new__(PrimeField)
+    f.modulus = ga.MODULUS
+    f.inv = lambda a: pow(a, ga.MODULUS - 2, ga.MODULUS)
+    f.sub = lambda a, b: (a - b) % ga.MODULUS
+    rc = poseidon.round_constants(f)
+    assert len(rc) == 64 and all(len(r) == 6 for r in rc)
+    assert rc[1][2] == int(hashlib.sha256(b'Hades8').hexdigest(), 16) % ga.MODULUS            # c = round * width + column
+    mds = poseidon.mds_matrix(f)
+    x1 = int(hashlib.sha256(b'HadesMDSx1').hexdigest(), 16) % ga.MODULUS
+    y4 = int(hashlib.sha256(b'HadesMDSy4').hexdigest(), 16) % ga.MODULUS
+    assert mds[1][4] * (x1 - y4) % ga.MODULUS == 1
+    ctl = poseidon.round_controls()
+    assert len(ctl) == 64 and sum(ctl) == 8 and ctl[:5] == [1, 1, 1, 1, 0] and ctl[58:] == [0, 1, 1, 1, 1, 0]
+
+
+@pytest.mark.parametrize('steps', [64, 128])
+def test_poseidon_prove_verify_oracle(oracle_backend, steps):
+    check_poseidon(oracle_backend, steps)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('steps', [64, 1024])
+def test_poseidon_hip_equals_oracle(hip_backend, oracle_backend, steps):
+    assert check_poseidon(hip_backend, steps) == check_poseidon(oracle_backend, steps)
+
+
+@pytest.mark.gpu
+def test_poseidon_2p16_config_verifies(hip_backend):
+    """BASELINE configs[3] on one GPU: 6 state registers, 2^16 steps, E = 16 (N = 2^20, composition domain 2^19)."""
+    data = check_poseidon(hip_backend, 1 << 16, host_trace=False)
+    assert len(data) > 100000
