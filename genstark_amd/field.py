@@ -11,6 +11,7 @@ Call sites of every member: SURVEY.md section 8(b).
 """
 import ctypes as C
 import hashlib
+from hashlib import sha256 as _sha256
 
 from ._abi import Backend, GstarkError
 
@@ -26,9 +27,11 @@ def sha256_bigint(value):
     """galois utils.sha256 (same helper as lib/components/QueryIndexGenerator.ts:61-67): a bigint is
     hashed as Buffer.from(value.toString(16), 'hex') — no leading zeros, odd trailing nibble dropped."""
     if isinstance(value, int):
-        h = format(value, 'x')
-        value = bytes.fromhex(h[: len(h) // 2 * 2])
-    return int.from_bytes(hashlib.sha256(bytes(value)).digest(), 'big')
+        nhex = (value.bit_length() + 3) >> 2
+        if nhex & 1:
+            value >>= 4                  # odd number of hex digits: Buffer.from(..., 'hex') drops the last nibble
+        value = value.to_bytes(nhex >> 1, 'big')
+    return int.from_bytes(_sha256(value).digest(), 'big')
 
 
 class _DeviceBuffer:

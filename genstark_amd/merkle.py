@@ -135,12 +135,13 @@ class MerkleTree:
         self.hash.backend.call('gs_merkle_prove_batch', C.c_void_p(self.values.ptr), C.c_void_p(self.nodes.ptr), n, idx, count,
                                C.cast(values, C.c_void_p), C.byref(ncols), col_lens, C.cast(nodes, C.c_void_p), cap)
         vraw, nraw = values.raw, nodes.raw
+        lens = col_lens[:ncols.value]
+        flat = [nraw[o:o + DIGEST_SIZE] for o in range(0, sum(lens) * DIGEST_SIZE, DIGEST_SIZE)]
         out_nodes, o = [], 0
-        for i in range(ncols.value):
-            k = col_lens[i]
-            out_nodes.append([nraw[(o + t) * DIGEST_SIZE:(o + t + 1) * DIGEST_SIZE] for t in range(k)])
+        for k in lens:
+            out_nodes.append(flat[o:o + k])
             o += k
-        return {'values': [vraw[i * DIGEST_SIZE:(i + 1) * DIGEST_SIZE] for i in range(count)], 'nodes': out_nodes,
+        return {'values': [vraw[o:o + DIGEST_SIZE] for o in range(0, count * DIGEST_SIZE, DIGEST_SIZE)], 'nodes': out_nodes,
                 'depth': self.depth}
 
     @staticmethod
