@@ -40,12 +40,36 @@ class CompositionPolynomial:
         self.dCoefficients = coefficients[:dCoefficientCount]
         self.bCoefficients = coefficients[dCoefficientCount:]
 
+    @staticmethod
+    def prefetch(context):
+        """ISSUE ORDER ONLY (no counterpart in the reference, same values): enqueue the device work of evaluateAll that
+        depends on nothing but the context — Z(x) and its inverses, the degree-adjustment power series — before the caller
+        starts the host-side trace recurrence, so the GPU computes it while that one core is busy (lib/Stark.ts:97 blocks for
+        9 ms at 2^20 MiMC steps).  evaluateAll picks the vectors up from context.prefetched and logs the same phases."""
+        f = context.field
+        pre = {}
+        combinationDegree = getCombinationDegree(context.constraints, context.traceLength)
+        compositionDegree = max(combinationDegree - context.traceLength, context.traceLength)
+        z = ZeroPolynomial(context).evaluateAll(context.evaluationDomain)
+        pre['zInverses'] = f.divVectorElements(z['denominators'], z['numerators'])
+        compositionFactor = context.evaluationDomain.length // context.compositionDomain.length
+        compositionRou = f.exp(context.rootOfUnity, compositionFactor)
+        for g in groupTransitionConstraints(context.constraints, context.traceLength):
+            if g['degree'] != combinationDegree:
+                seed = f.exp(compositionRou, combinationDegree - g['degree'])
+                pre['qPowers', g['degree']] = f.getPowerSeries(seed, context.compositionDomain.length)
+        if compositionDegree > context.traceLength:
+            seed = f.exp(context.rootOfUnity, compositionDegree - context.traceLength)
+            pre['psbPowers'] = f.getPowerSeries(seed, context.evaluationDomain.length)
+        context.prefetched = pre
+
     @property
     def coefficientCount(self):
         return len(self.dCoefficients) + len(self.bCoefficients)
 
     def evaluateAll(self, pPolys, pEvaluations, context):  # :71-146
         f = self.field
+        pre = getattr(context, 'prefetched', None) or {}
         # 1 ----- transition constraints over the composition domain
         qEvaluations = context.evaluateTransitionConstraints(pPolys)
         self.log('Computed transition constraint polynomials Q(x)')
@@ -57,7 +81,9 @@ class CompositionPolynomial:
             if g['degree'] == self.combinationDegree:
                 continue
             powerSeed = f.exp(compositionRou, self.combinationDegree - g['degree'])
-            powers = f.getPowerSeries(powerSeed, context.compositionDomain.length)
+            powers = pre.get(('qPowers', g['degree']))
+            if powers is None:
+                powers = f.getPowerSeries(powerSeed, context.compositionDomain.length)
             for i in g['indexes']:
                 qaEvaluations.append(f.mulVectorElements(qaEvaluations[i], powers))
         self.log('Adjusted degrees of Q(x) polynomials')
@@ -68,9 +94,12 @@ class CompositionPolynomial:
         qeEvaluations = f.evalPolyAtRoots(qcPoly, context.evaluationDomain)
         self.log('Performed low degree extensions of Q(x) polynomial')
         # 4 ----- D(x) = Q(x) / Z(x)
-        zEvaluations = self.zPoly.evaluateAll(context.evaluationDomain)
+        zInverses = pre.get('zInverses')
+        if zInverses is None:
+            zEvaluations = self.zPoly.evaluateAll(context.evaluationDomain)
         self.log('Computed Z(x) polynomial')
-        zInverses = f.divVectorElements(zEvaluations['denominators'], zEvaluations['numerators'])  # 1/Z = den/num (:117)
+        if zInverses is None:
+            zInverses = f.divVectorElements(zEvaluations['denominators'], zEvaluations['numerators'])  # 1/Z = den/num (:117)
         self.log('Computed Z(x) inverses')
         dEvaluations = f.mulVectorElements(qeEvaluations, zInverses)
         self.log('Computed D(x) polynomial')
@@ -82,7 +111,9 @@ class CompositionPolynomial:
         bIncrementalDegree = self.compositionDegree - context.traceLength
         if bIncrementalDegree > 0:
             powerSeed = f.exp(context.rootOfUnity, bIncrementalDegree)
-            psbPowers = f.getPowerSeries(powerSeed, context.evaluationDomain.length)
+            psbPowers = pre.get('psbPowers')
+            if psbPowers is None:
+                psbPowers = f.getPowerSeries(powerSeed, context.evaluationDomain.length)
             for i in range(self.bPoly.count):
                 baEvaluations.append(f.mulVectorElements(baEvaluations[i], psbPowers))
         self.log('Adjusted degrees of B(x) polynomials')

@@ -26,10 +26,11 @@ int gs_mimc_trace(gs_ctx *c, const uint8_t seed[16], const uint8_t *rc_host, uin
     if (!nrc || !steps) return gs_fail(c, GS_ERR_ARG, "mimc_trace: empty");
     std::vector<hu128> rc(nrc);
     for (uint32_t i = 0; i < nrc; i++) rc[i] = hf_load(rc_host + 16 * i);
-    int rcode = gs_stage_reserve(c, steps * 16);  // pinned, grow-only: no per-call page pinning
+    // pinned, grow-only; waits only for the previous trace's upload, so device work the caller queued before this call
+    // (domains, Z(x) inverses, ...) runs while this core grinds through the recurrence
+    int rcode = gs_trace_begin(c, steps * 16);
     if (rcode) return rcode;
-    GS_HIP(c, hipStreamSynchronize(c->stream));   // earlier users of the staging buffer are done
-    hu128 *t = (hu128 *)c->h_stage;
+    hu128 *t = (hu128 *)c->h_trace;
     hu128 x = hf_load(seed);
     uint32_t ri = 0;
     const uint64_t CHUNK = 1ull << 16;            // copy finished chunks while the next one is being generated
@@ -45,8 +46,7 @@ int gs_mimc_trace(gs_ctx *c, const uint8_t seed[16], const uint8_t *rc_host, uin
         }
         GS_HIP(c, hipMemcpyAsync((uint8_t *)out + base * 16, t + base, (end - base) * 16, hipMemcpyHostToDevice, c->stream));
     }
-    GS_HIP(c, hipStreamSynchronize(c->stream));
-    return GS_OK;
+    return gs_trace_end(c);   // no synchronisation: consumers are ordered on the stream
 }
 
 int gs_mimc_constraints(gs_ctx *c, const void *p_comp, uint64_t nc, uint64_t shift, const void *k_table, uint64_t klen, void *out) {

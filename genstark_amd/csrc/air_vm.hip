@@ -126,9 +126,8 @@ int gs_air_trace(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, const ui
             for (uint32_t i = 0; i < static_periods_host[s]; i++, p += 16) statics[s][i] = hf_load(p);
         }
     }
-    if ((rc = gs_stage_reserve(c, (uint64_t)registers * steps * 16))) return rc;
-    GS_HIP(c, hipStreamSynchronize(c->stream));
-    hu128 *t = (hu128 *)c->h_stage;  // registers x steps, row-major like the Matrix the caller gets
+    if ((rc = gs_trace_begin(c, (uint64_t)registers * steps * 16))) return rc;
+    hu128 *t = (hu128 *)c->h_trace;  // registers x steps, row-major like the Matrix the caller gets
     for (uint32_t r = 0; r < registers; r++) row[r] = hf_load(first_row_host + 16 * r);
     for (uint64_t i = 0; i < steps; i++) {
         for (uint32_t r = 0; r < registers; r++) t[(uint64_t)r * steps + i] = row[r];
@@ -150,9 +149,8 @@ int gs_air_trace(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, const ui
         }
         row = next;
     }
-    GS_HIP(c, hipMemcpyAsync(out, c->h_stage, (size_t)registers * steps * 16, hipMemcpyHostToDevice, c->stream));
-    GS_HIP(c, hipStreamSynchronize(c->stream));
-    return GS_OK;
+    GS_HIP(c, hipMemcpyAsync(out, c->h_trace, (size_t)registers * steps * 16, hipMemcpyHostToDevice, c->stream));
+    return gs_trace_end(c);
 }
 
 }  // extern "C"

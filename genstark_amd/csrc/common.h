@@ -31,6 +31,12 @@ struct gs_ctx {
     void *h_stage_dev = nullptr;  // the device-side address of h_stage
     void *d_stage = nullptr;
     uint64_t stage_bytes = 0;
+    // pinned buffer the host-side trace generators write into; it is uploaded asynchronously, `trace_done` marks the end
+    // of the last upload so the next trace waits for THAT copy only, not for whatever else is queued on the stream
+    void *h_trace = nullptr;
+    uint64_t trace_bytes = 0;
+    hipEvent_t trace_done = nullptr;
+    bool trace_pending = false;
 };
 
 int gs_fail(gs_ctx *c, int code, const char *fmt, ...);
@@ -52,6 +58,8 @@ static inline fe fe_from_u64(uint64_t v) { return fe_make((uint32_t)v, (uint32_t
 
 // staging helpers (ctx.hip)
 int gs_stage_reserve(gs_ctx *c, uint64_t bytes);
+int gs_trace_begin(gs_ctx *c, uint64_t bytes);   // h_trace has >= bytes and no upload of it is in flight
+int gs_trace_end(gs_ctx *c);                     // call after the last hipMemcpyAsync out of h_trace
 // temp device block from the cache (same lifetime rules as gs_alloc/gs_free)
 int gs_tmp_alloc(gs_ctx *c, uint64_t bytes, void **p);
 void gs_tmp_free(gs_ctx *c, void *p);

@@ -54,6 +54,8 @@ void gs_ctx_destroy(gs_ctx *c) {
     for (auto &kv : c->live_blocks) hipFree(kv.first);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->d_stage) hipFree(c->d_stage);
+    if (c->h_trace) hipHostFree(c->h_trace);
+    if (c->trace_done) hipEventDestroy(c->trace_done);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -158,6 +160,29 @@ int gs_stage_reserve(gs_ctx *c, uint64_t bytes) {
     GS_HIP(c, hipHostGetDevicePointer(&c->h_stage_dev, c->h_stage, 0));
     GS_HIP(c, hipMalloc(&c->d_stage, nb));
     c->stage_bytes = nb;
+    return GS_OK;
+}
+
+int gs_trace_begin(gs_ctx *c, uint64_t bytes) {
+    if (c->trace_pending) {
+        GS_HIP(c, hipEventSynchronize(c->trace_done));
+        c->trace_pending = false;
+    }
+    if (!c->trace_done) GS_HIP(c, hipEventCreateWithFlags(&c->trace_done, hipEventDisableTiming));
+    if (bytes <= c->trace_bytes) return GS_OK;
+    uint64_t nb = 1 << 16;
+    while (nb < bytes) nb <<= 1;
+    if (c->h_trace) hipHostFree(c->h_trace);
+    c->h_trace = nullptr;
+    c->trace_bytes = 0;
+    GS_HIP(c, hipHostMalloc(&c->h_trace, nb, hipHostMallocDefault));
+    c->trace_bytes = nb;
+    return GS_OK;
+}
+
+int gs_trace_end(gs_ctx *c) {
+    GS_HIP(c, hipEventRecord(c->trace_done, c->stream));
+    c->trace_pending = true;
     return GS_OK;
 }
 

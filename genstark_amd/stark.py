@@ -53,6 +53,7 @@ class Stark:
         self.indexGenerator = QueryIndexGenerator(sOptions)
         self.serializer = Serializer(air, self.hash.digestSize)
         self.logger = logger or NoopLogger()
+        self.prefetch = True   # issue trace-independent device work before the host-side trace recurrence (same proof bytes)
 
     @property
     def securityLevel(self):  # :62-77
@@ -73,6 +74,8 @@ class Stark:
         context = self.air.initProvingContext(inputs, seed)
         field = context.field
         evaluationDomainSize = context.evaluationDomain.length
+        if self.prefetch:
+            CompositionPolynomial.prefetch(context)      # issue order only: device work that does not need the trace
         log('Set up evaluation context')
         # 2 ----- execution trace
         try:
