@@ -100,6 +100,8 @@ class MerkleTree:
 
     @staticmethod
     def create(leaves, hash_):
+        if getattr(leaves, 'dist', False):      # distributed digest vector (genstark_amd/distributed.py): sharded tree
+            return hash_.createTree(leaves)
         n = leaves.length
         if n < 2 or n & (n - 1):
             raise GstarkError('Number of leaves must be a power of 2')

@@ -49,7 +49,8 @@ class Stark:
     def __init__(self, air, options=None, logger=None):  # :35-58 (the AIR module arrives instantiated)
         self.air = air
         sOptions = buildSecurityOptions(options, air.extensionFactor)
-        self.hash = createHash(sOptions['hashAlgorithm'], air.field.backend)
+        make_hash = getattr(air.field, 'createHash', None)      # a distributed field brings its own Hash (distributed.py)
+        self.hash = make_hash(sOptions['hashAlgorithm']) if make_hash else createHash(sOptions['hashAlgorithm'], air.field.backend)
         self.indexGenerator = QueryIndexGenerator(sOptions)
         self.serializer = Serializer(air, self.hash.digestSize)
         self.logger = logger or NoopLogger()
