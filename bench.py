@@ -80,6 +80,8 @@ def main():
     ap.add_argument('--fri-queries', type=int, default=64)
     ap.add_argument('--cpu-log-trace', type=int, default=16, help='trace length of the bounded CPU-baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sharded-leg-timeout', type=float, default=150.0,
+                    help='N > 1 only: seconds allowed for the extra one-proof-across-all-ranks leg (0 = skip it)')
     ap.add_argument('--lanes', type=int, default=3, help='prover lanes of the extra throughput-mode leg (0 = skip it)')
     ap.add_argument('--lane-proofs', type=int, default=12, help='proofs pushed through the lanes in that leg')
     # test-only: drive the distributed harness on CPU (gloo) against the oracle's implementation of the C ABI
@@ -250,11 +252,57 @@ def main():
             'prove_ms': ms_per_step, 'per_step_ms': step_ms, 'phases_ms': phases, 'roofline': roofline, 'cpu_baseline': cpu,
             'pipelined': pipelined,
         }
+    # ---- extra leg for N > 1 (reported beside `value`, never as `value`): ONE proof of the same workload across all ranks
+    # (genstark_amd/distributed.py: strided distributed vectors, one digest exchange per Merkle tree).  It runs under a
+    # watchdog: whatever happens in it, every rank leaves within --sharded-leg-timeout seconds and rank 0 prints its line.
+    if dist is not None and args.sharded_leg_timeout > 0:
+        import hashlib
+        import threading
+        result = {}
+
+        def leg():
+            try:
+                from genstark_amd.air import MimcAir
+                from genstark_amd.distributed import DistField
+                from genstark_amd.stark import Stark
+                a0 = assertions_for(stark, steps, 3)                          # the same statement on every rank
+                opts = {'hashAlgorithm': 'blake2s256', 'extensionFactor': ef, 'exeQueryCount': 48, 'friQueryCount': fri}
+                dstark = Stark(MimcAir(steps, ef, DistField(backend, n)), opts)
+                pr = dstark.prove(a0, [], [3])                                  # warm-up: plans, block cache
+                barrier()
+                ts = time.perf_counter()
+                reps = max(1, min(args.steps, 3))
+                for _ in range(reps):
+                    pr = dstark.prove(a0, [], [3])
+                barrier()
+                ms = (time.perf_counter() - ts) / reps * 1e3
+                blob = dstark.serialize(pr)
+                digests = [None] * world
+                dist.all_gather_object(digests, hashlib.sha256(blob).hexdigest())
+                ok = len(set(digests)) == 1 and (rank != 0 or stark.verify(a0, stark.parse(blob)))
+                result.update({'ms_per_proof': round(ms, 3), 'ranks': world, 'scaling': 'strong', 'proofs_timed': reps,
+                               'proof_bytes': len(blob), 'same_bytes_on_every_rank_and_verified': bool(ok),
+                               'note': 'one proof across all ranks; the serial trace recurrence (one host core, replicated) '
+                                       'bounds it from below'})
+            except BaseException as e:                                          # never take the main line down
+                result['error'] = repr(e)[:300]
+
+        th = threading.Thread(target=leg, daemon=True)
+        th.start()
+        th.join(args.sharded_leg_timeout)
+        if th.is_alive():
+            result = {'error': f'timed out after {args.sharded_leg_timeout} s'}
+        if out is not None:
+            out['sharded'] = result
+            print(json.dumps(out), flush=True)
+        if th.is_alive() or 'error' in result:
+            os._exit(0)                                                         # a rank may be stuck in a collective
+    elif out is not None:
+        print(json.dumps(out), flush=True)
+        out = None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if out is not None:
-        print(json.dumps(out))
 
 
 if __name__ == '__main__':

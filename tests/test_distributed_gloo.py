@@ -23,6 +23,23 @@ def test_bench_two_ranks_gloo(oracle_backend):
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['warmup'] == 1 and out['scaling'] == 'weak'
     per_proof = out['config']['ntt_points_per_prove']
     assert abs(out['value'] - 2 * per_proof / (out['ms_per_step'] * 1e-3)) < 1e-6 * out['value']
+    # the extra leg: one proof across both ranks, same bytes everywhere, accepted by the verifier
+    sh = out['sharded']
+    assert 'error' not in sh, sh
+    assert sh['ranks'] == 2 and sh['scaling'] == 'strong' and sh['same_bytes_on_every_rank_and_verified'] is True
+
+
+def test_bench_sharded_leg_watchdog(oracle_backend):
+    """A leg that cannot finish in time must not take the main line down: rank 0 still prints exactly one JSON line."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--log-trace', '8',
+           '--fri-queries', '24', '--test-double-lib', ORACLE_LIB, '--sharded-leg-timeout', '0.001']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, (r.stdout, r.stderr[-2000:])
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and 'timed out' in out['sharded']['error']
 
 
 def test_bench_single_rank_cpu_mode(oracle_backend):
