@@ -117,7 +117,7 @@ class DistRowMatrix:
 
     def __init__(self, field, rows, cols, local):
         self.field, self.rowCount, self.colCount, self.local = field, int(rows), cols, local
-        self.quartic_domain = None
+        self.quartic_domain = self.quartic_coset = self.x_scale = None
         if local.rowCount * field.comm.world != self.rowCount:
             raise GstarkError('distributed matrix: local part has the wrong number of rows')
 
@@ -284,16 +284,31 @@ class DistField(PrimeField):
             raise GstarkError('distributed transposeVector: 4 columns, world must divide the row count')
         local = super().transposeVector(v.local, columns)
         local.quartic_domain = None
-        return DistRowMatrix(self, rows, columns, local)
+        out = DistRowMatrix(self, rows, columns, local)
+        if v.series_base is not None:
+            # my rows are x = s*u with s = base^rank and u running over the transposed power series of base^world: the
+            # cubic through (s*u_c, y_c) is Q(x/s) where Q interpolates (u_c, y_c) -- the 9-multiplication domain kernel
+            comm = self.comm
+            out.quartic_coset = ((self.exp(v.series_base, comm.world), v.length // comm.world, 1), self.exp(v.series_base, comm.rank))
+        return out
 
     def interpolateQuarticBatch(self, xs, ys):
         if not _is_dist(ys):
             return super().interpolateQuarticBatch(xs, ys)
-        return DistRowMatrix(self, ys.rowCount, 4, super().interpolateQuarticBatch(xs.local, ys.local))
+        coset = getattr(xs, 'quartic_coset', None)
+        if coset is None:
+            return DistRowMatrix(self, ys.rowCount, 4, super().interpolateQuarticBatch(xs.local, ys.local))
+        xs.local.quartic_domain = coset[0]
+        out = DistRowMatrix(self, ys.rowCount, 4, super().interpolateQuarticBatch(xs.local, ys.local))
+        out.x_scale = coset[1]            # coefficients are in the variable u = x / x_scale
+        return out
 
     def evalQuarticBatch(self, polys, x):
         if not _is_dist(polys):
             return super().evalQuarticBatch(polys, x)
+        scale = getattr(polys, 'x_scale', None)
+        if scale is not None:
+            x = self.div(x, scale)
         return DistVector(self, polys.rowCount, super().evalQuarticBatch(polys.local, x))
 
     def transposeMatrix(self, m):
