@@ -196,11 +196,12 @@ class GenericVerificationContext(_Context):
 
 
 class GenericProvingContext(_Context):
-    def __init__(self, air, first_row):
+    def __init__(self, air, first_rows):
         super().__init__(air)
         f = self.field
         n, nc = self.traceLength * self.extensionFactor, self.traceLength * self.compositionFactor
-        self.firstRow = [v % f.modulus for v in first_row]
+        self.firstRows = [[v % f.modulus for v in row] for row in first_rows]
+        self.firstRow = self.firstRows[0]
         self.evaluationDomain = f.getPowerSeries(self.rootOfUnity, n)
         self.compositionDomain = f.getPowerSeries(f.exp(self.rootOfUnity, n // nc), nc)
         self.executionDomain = f.getPowerSeries(f.exp(self.rootOfUnity, self.extensionFactor), self.traceLength)
@@ -222,8 +223,13 @@ class GenericProvingContext(_Context):
         m = Matrix(f.backend, air.traceRegisterCount, self.traceLength)
         svals = b''.join(_le(v % f.modulus) for values in air.staticRegisters for v in values) or bytes(16)
         periods = (C.c_uint32 * max(len(air.staticRegisters), 1))(*[len(v) for v in air.staticRegisters])
-        f.backend.call('gs_air_trace', code, ninstr, consts, nconsts, nregs, air.traceRegisterCount, svals, periods,
-                       len(air.staticRegisters), b''.join(_le(v) for v in self.firstRow), self.traceLength, C.c_void_p(m.ptr))
+        if air.segmentLength is None:
+            f.backend.call('gs_air_trace', code, ninstr, consts, nconsts, nregs, air.traceRegisterCount, svals, periods,
+                           len(air.staticRegisters), b''.join(_le(v) for v in self.firstRow), self.traceLength, C.c_void_p(m.ptr))
+        else:
+            f.backend.call('gs_air_trace_segments', code, ninstr, consts, nconsts, nregs, air.traceRegisterCount, svals, periods,
+                           len(air.staticRegisters), b''.join(_le(v) for row in self.firstRows for v in row), len(self.firstRows),
+                           air.segmentLength, C.c_void_p(m.ptr))
         return m
 
     def generateStaticTrace(self):
@@ -251,9 +257,27 @@ class GenericAir:
     init(seed)          -> first row (list of ints)"""
 
     def __init__(self, steps, registers, constraintDegrees, staticRegisters, transition, evaluation, init, extensionFactor=None,
-                 field=None):
+                 field=None, segmentLength=None):
+        """segmentLength = L splits the trace into steps/L independent runs (AirScript's `for each (input)` loop over several
+        inputs): `seed` is then a list of steps/L per-segment seeds, segment s starts from init(seed[s]) at step s*L, the
+        transition constraints are switched off on the last step of every segment by one more cyclic static register
+        (degree + 1), and the trace is generated on the device, one thread per segment (gs_air_trace_segments)."""
         self.field = field or PrimeField()
         f = self.field
+        self.segmentLength = segmentLength
+        if segmentLength is not None:
+            if segmentLength < 2 or segmentLength & (segmentLength - 1) or steps % segmentLength:
+                raise GstarkError('segment length must be a power of 2 dividing the trace length')
+            mask_index = len(staticRegisters)
+            staticRegisters = list(staticRegisters) + [[0] * (segmentLength - 1) + [1]]
+            constraintDegrees = [d + 1 for d in constraintDegrees]
+            inner = evaluation
+
+            def evaluation(r, n, k, inner=inner, mask_index=mask_index):
+                live = 1 - k[mask_index]
+                return [live * e for e in inner(r, n, k[:mask_index])]
+            inner_t = transition
+            transition = lambda r, k, inner_t=inner_t, mask_index=mask_index: inner_t(r, k[:mask_index])
         if steps & (steps - 1) or steps < 2:
             raise GstarkError('steps must be a power of 2')
         for values in staticRegisters:
@@ -279,16 +303,28 @@ class GenericAir:
         self.rootOfUnity = f.getRootOfUnity(steps * ef)
         self._staticPolys = None
 
+    def firstRows(self, seed):
+        if self.segmentLength is None:
+            return [self.init(seed or [])]
+        segments = self.steps // self.segmentLength
+        if seed is None or len(seed) != segments:
+            raise GstarkError(f'a segmented AIR needs one seed per segment ({segments})')
+        return [self.init(s) for s in seed]
+
     def initProvingContext(self, inputs=None, seed=None):
-        return GenericProvingContext(self, self.init(seed or []))
+        return GenericProvingContext(self, self.firstRows(seed))
 
     def initVerificationContext(self, inputShapes=None, publicInputs=None):
         return GenericVerificationContext(self)
 
     def hostTrace(self, seed, steps=None):
         """Independent control computation on Python integers (the role of examples/rescue/utils.ts for the examples)."""
-        row, out = [v % self.field.modulus for v in self.init(seed)], []
+        p, out = self.field.modulus, []
+        firsts = self.firstRows(seed)
+        seg = self.segmentLength or self.steps
         for i in range(steps or self.steps):
+            if i % seg == 0:
+                row = [v % p for v in firsts[i // seg]]
             out.append(row)
             row = self.transitionProgram.run(row, None, [v[i % len(v)] for v in self.staticRegisters])
         return out

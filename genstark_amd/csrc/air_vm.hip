@@ -42,6 +42,39 @@ __global__ void k_air_constraints(const uint4 *__restrict__ code, uint32_t ninst
     }
 }
 
+// one thread per independent trace segment: the same register machine, next-row outputs go to a private row buffer
+template <int NREG>
+__global__ void k_air_trace_segments(const uint4 *__restrict__ code, uint32_t ninstr, const fe *__restrict__ consts,
+                                     const fe *__restrict__ statics, StaticDesc sd, const fe *__restrict__ first_rows, uint32_t registers,
+                                     uint64_t segments, uint64_t seglen, fe *__restrict__ out) {
+    const uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (g >= segments) return;
+    const uint64_t steps = segments * seglen;
+    fe vm[NREG], row[GS_AIR_MAX_REGISTERS], next[GS_AIR_MAX_REGISTERS];
+    for (uint32_t r = 0; r < registers; r++) row[r] = first_rows[g * registers + r];
+    for (uint64_t k = 0; k < seglen; k++) {
+        const uint64_t i = g * seglen + k;
+        for (uint32_t r = 0; r < registers; r++) { out[(uint64_t)r * steps + i] = row[r]; next[r] = row[r]; }
+        if (k + 1 == seglen) break;
+        for (uint32_t pc = 0; pc < ninstr; pc++) {
+            const uint4 ins = code[pc];
+            const uint32_t dst = ins.y, a = ins.z, b = ins.w;
+            switch (ins.x) {
+                case OP_LOADC: vm[dst] = consts[a]; break;
+                case OP_LOADR: vm[dst] = row[a]; break;
+                case OP_LOADS: vm[dst] = statics[sd.offset[a] + i % sd.len[a]]; break;
+                case OP_ADDV: vm[dst] = fe_add(vm[a], vm[b]); break;
+                case OP_SUBV: vm[dst] = fe_sub(vm[a], vm[b]); break;
+                case OP_MULV: vm[dst] = fe_mul(vm[a], vm[b]); break;
+                case OP_POW: vm[dst] = fe_pow_u64(vm[a], b); break;
+                case OP_POWC: vm[dst] = fe_pow(vm[a], consts[b]); break;
+                default: next[dst] = vm[a]; break;  // OP_OUT
+            }
+        }
+        for (uint32_t r = 0; r < registers; r++) row[r] = next[r];
+    }
+}
+
 static int check_program(gs_ctx *c, const uint32_t *code, uint32_t ninstr, uint32_t nconsts, uint32_t vm_regs, uint32_t registers,
                          uint32_t nstatic, uint32_t nout, bool allow_next) {
     if (!code || !ninstr) return gs_fail(c, GS_ERR_ARG, "air program: empty");
@@ -105,6 +138,50 @@ int gs_air_constraints(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, co
     e = hipGetLastError();
     gs_tmp_free(c, dprog);  // stream-ordered reuse: later users of the block are queued behind this kernel
     if (e != hipSuccess) return gs_fail(c, GS_ERR_DEVICE, "air_constraints launch: %s", hipGetErrorString(e));
+    return GS_OK;
+}
+
+int gs_air_trace_segments(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs,
+                          uint32_t registers, const uint8_t *static_values_host, const uint32_t *static_periods_host, uint32_t nstatic,
+                          const uint8_t *first_rows_host, uint64_t segments, uint64_t segment_len, void *out) {
+    if (!c || !first_rows_host || !out || (!consts_host && nconsts) || (nstatic && (!static_values_host || !static_periods_host))) return GS_ERR_ARG;
+    int rc = check_program(c, code_host, ninstr, nconsts, vm_regs, registers, nstatic, registers, false);
+    if (rc) return rc;
+    if (!segments || !segment_len) return gs_fail(c, GS_ERR_ARG, "air_trace_segments: empty");
+    StaticDesc sd;
+    uint64_t nstat = 0;
+    for (uint32_t s = 0; s < GS_AIR_MAX_REGISTERS; s++) {
+        sd.offset[s] = nstat;
+        sd.len[s] = s < nstatic ? static_periods_host[s] : 1;
+        if (s < nstatic) {
+            if (!static_periods_host[s]) return gs_fail(c, GS_ERR_ARG, "air_trace_segments: empty static register");
+            nstat += static_periods_host[s];
+        }
+    }
+    // program, constants, static values and first rows -> one device block (pageable caller memory: one sync)
+    const uint64_t code_b = ((uint64_t)ninstr * 16 + 255) & ~(uint64_t)255, const_b = ((uint64_t)(nconsts ? nconsts : 1) * 16 + 255) & ~(uint64_t)255;
+    const uint64_t stat_b = ((nstat ? nstat : 1) * 16 + 255) & ~(uint64_t)255, rows_b = segments * registers * 16;
+    void *d;
+    if ((rc = gs_tmp_alloc(c, code_b + const_b + stat_b + rows_b, &d))) return rc;
+    uint8_t *p = (uint8_t *)d;
+    hipError_t e = hipMemcpyAsync(p, code_host, (size_t)ninstr * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && nconsts) e = hipMemcpyAsync(p + code_b, consts_host, (size_t)nconsts * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && nstat) e = hipMemcpyAsync(p + code_b + const_b, static_values_host, (size_t)nstat * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(p + code_b + const_b + stat_b, first_rows_host, (size_t)rows_b, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { gs_tmp_free(c, d); return gs_fail(c, GS_ERR_DEVICE, "air_trace_segments upload: %s", hipGetErrorString(e)); }
+    const uint4 *dcode = (const uint4 *)p;
+    const fe *dconst = (const fe *)(p + code_b), *dstat = (const fe *)(p + code_b + const_b), *drows = (const fe *)(p + code_b + const_b + stat_b);
+    dim3 block(64), grid((unsigned)((segments + 63) / 64));   // one wave per 64 segments: spread the few long-running threads over the CUs
+    if (vm_regs <= 16)
+        hipLaunchKernelGGL(k_air_trace_segments<16>, grid, block, 0, c->stream, dcode, ninstr, dconst, dstat, sd, drows, registers, segments, segment_len, (fe *)out);
+    else if (vm_regs <= 32)
+        hipLaunchKernelGGL(k_air_trace_segments<32>, grid, block, 0, c->stream, dcode, ninstr, dconst, dstat, sd, drows, registers, segments, segment_len, (fe *)out);
+    else
+        hipLaunchKernelGGL(k_air_trace_segments<64>, grid, block, 0, c->stream, dcode, ninstr, dconst, dstat, sd, drows, registers, segments, segment_len, (fe *)out);
+    e = hipGetLastError();
+    gs_tmp_free(c, d);
+    if (e != hipSuccess) return gs_fail(c, GS_ERR_DEVICE, "air_trace_segments launch: %s", hipGetErrorString(e));
     return GS_OK;
 }
 

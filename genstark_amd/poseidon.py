@@ -6,8 +6,10 @@ round constants sha256("Hades<c>") (:52-63), the Cauchy MDS matrix 1/(x_i - y_j)
 sha256("HadesMDSy<j>") (:65-81,119-126), the full/partial schedule of hash6x128.ts:21-29.  The AirScript `for steps [1..4,
 60..63]` / `[5..59]` segments (:70-79) become one more cyclic static register (1 = full round) that blends the two
 transition bodies, which makes every constraint degree 6 in x (S-box degree 5 times the degree-<T control polynomial).
-With steps > 64 the permutation keeps cycling through the 64-step schedule (step 63 -> 64 is one more partial round);
-re-initialising from further input pairs needs air-assembly's input registers and is out of scope."""
+With steps > 64 either the permutation keeps cycling through the 64-step schedule (step 63 -> 64 is one more partial round),
+or — segmented=True — every 64-step segment hashes its own inputs like the example's `for each (value1, value2)` loop over
+several inputs (GenericAir.segmentLength: the device generates the segments in parallel, the transition constraints are
+masked on the last step of each segment; the example's secret-input registers themselves are not modelled)."""
 import hashlib
 
 from .air_generic import GenericAir, mat_vec
@@ -53,7 +55,7 @@ def poseidon_hash(f, inputs):
     return state[:2]
 
 
-def poseidon6x128_air(steps, extensionFactor=16, field=None):
+def poseidon6x128_air(steps, extensionFactor=16, field=None, segmented=False):
     """Returns the GenericAir; prove with `stark.prove(assertions, [], [v1, v2, v3, v4])` (the hashed elements).  For
     steps == 64 the digest is registers 0 and 1 of step 63 (hash6x128.ts:93-96)."""
     from .field import PrimeField
@@ -77,4 +79,7 @@ def poseidon6x128_air(steps, extensionFactor=16, field=None):
             raise ValueError('Poseidon6x128 hashes two pairs of elements: seed must hold 4 values')
         return list(seed) + [0, 0]
 
-    return GenericAir(steps, m, [ALPHA + 1] * m, statics, next_state, evaluation, init, extensionFactor, f)
+    # segmented=True: steps/64 independent hashes (`for each (value1, value2)` over several inputs, hash6x128.ts:62-81),
+    # seed = [[a, b, c, d], ...], digest of input s in registers 0 and 1 of step 64*s + 63
+    return GenericAir(steps, m, [ALPHA + 1] * m, statics, next_state, evaluation, init, extensionFactor, f,
+                      segmentLength=STEPS_PER_HASH if segmented else None)

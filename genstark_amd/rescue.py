@@ -3,9 +3,10 @@ registers of period 32) as a GenericAir, for BASELINE configs[2] ("Rescue hash-p
 
 The cipher parameters (alpha, inv_alpha, MDS matrix and its inverse, the 24 seed constants) are DATA of the reference's
 example (hash4x128.ts:12-34,52-65); the key schedule and input injection are restated from examples/rescue/utils.ts:126-181
-and hash4x128.ts:130-160.  With steps > 32 the permutation simply keeps cycling through the 32-step round-constant
-schedule (the example's own trace is the first 32 steps; multi-input segmentation needs air-assembly's input registers and
-is out of scope)."""
+and hash4x128.ts:130-160.  With steps > 32 either the permutation keeps cycling through the 32-step round-constant
+schedule, or — segmented=True — every 32-step segment hashes its own input pair like the example's `for each (value1,
+value2)` loop over several inputs (GenericAir.segmentLength: segments generated in parallel on the device, transition
+constraints masked on the last step of each segment; the example's secret-input registers themselves are not modelled)."""
 from .air_generic import GenericAir, mat_vec
 
 ALPHA = 3
@@ -76,8 +77,10 @@ def build_inputs(f, values, initial):
     return [f.add(r[j], initial[4 + j]) for j in range(4)]
 
 
-def rescue4x128_air(steps, extensionFactor=16, field=None):
-    """Returns the GenericAir; prove with `stark.prove(assertions, [], [v1, v2])` (the two hashed elements)."""
+def rescue4x128_air(steps, extensionFactor=16, field=None, segmented=False):
+    """Returns the GenericAir; prove with `stark.prove(assertions, [], [v1, v2])` (the two hashed elements).  segmented=True:
+    steps/32 independent hashes (the example's `for each (value1, value2)` over several input pairs, hash4x128.ts:60-81):
+    seed = [[v1, v2], ...] one pair per 32-step segment, digest of pair s in registers 0 and 1 of step 32*s + 31."""
     from .field import PrimeField
     f = field or PrimeField()
     initial, rc = key_schedule(f)
@@ -93,4 +96,4 @@ def rescue4x128_air(steps, extensionFactor=16, field=None):
         return [a - b for a, b in zip(s, nn)]
 
     return GenericAir(steps, 4, [3, 3, 3, 3], rc, transition, evaluation, lambda seed: build_inputs(f, seed, initial),
-                      extensionFactor, f)
+                      extensionFactor, f, segmentLength=STEPS_PER_HASH if segmented else None)

@@ -222,3 +222,62 @@ def test_poseidon_2p16_config_verifies(hip_backend):
     """BASELINE configs[3] on one GPU: 6 state registers, 2^16 steps, E = 16 (N = 2^20, composition domain 2^19)."""
     data = check_poseidon(hip_backend, 1 << 16, host_trace=False)
     assert len(data) > 100000
+
+
+# ---- segmented traces: many independent hashes per proof, trace generated on the device (gs_air_trace_segments) --------
+def check_segmented(backend, kind, steps):
+    from genstark_amd import poseidon
+    f = PrimeField(backend=backend)
+    if kind == 'rescue':
+        air, per = rescue4x128_air(steps, 16, f, segmented=True), 32
+        seeds = [[42 + s, 43 + 2 * s] for s in range(steps // per)]
+        opts = RESCUE_OPTS
+    else:
+        air, per = poseidon.poseidon6x128_air(steps, 16, f, segmented=True), 64
+        seeds = [[1 + s, 2, 3 + s, 4] for s in range(steps // per)]
+        opts = POSEIDON_OPTS
+    stark = Stark(air, opts)
+    trace = air.initProvingContext([], seeds).generateExecutionTrace()
+    full = air.hostTrace(seeds)
+    assert trace.toValues() == [list(r) for r in zip(*full)]           # device VM, one thread per segment == host integers
+    if kind == 'rescue':
+        assert (full[31][0], full[31][1]) == RESCUE_KAT                # segment 0 hashes (42, 43): hash4x128.ts:115-118
+    else:
+        for s in (0, len(seeds) - 1):
+            assert full[64 * s + 63][:2] == poseidon.poseidon_hash(f, seeds[s])
+    last = len(seeds) - 1
+    assertions = [{'step': per - 1, 'register': 0, 'value': full[per - 1][0]}, {'step': per * last + per - 1, 'register': 1, 'value': full[per * last + per - 1][1]},
+                  {'step': per * last, 'register': 0, 'value': full[per * last][0]}]
+    proof = stark.prove(assertions, [], seeds)
+    data = stark.serialize(proof)
+    assert len(data) == stark.sizeOf(proof)
+    assert stark.verify(assertions, stark.parse(data))
+    # a trace that cheats INSIDE a segment must fail; the boundary rows are free by construction
+    wrong = [dict(assertions[0], value=(assertions[0]['value'] + 1) % ga.MODULUS)] + assertions[1:]
+    with pytest.raises(StarkError):
+        stark.verify(wrong, stark.parse(data))
+    return data
+
+
+@pytest.mark.parametrize('kind,steps', [('rescue', 128), ('poseidon', 128)])
+def test_segmented_hash_chains_oracle(oracle_backend, kind, steps):
+    check_segmented(oracle_backend, kind, steps)
+
+
+def test_segmented_air_rejects_wrong_seed_count(oracle_backend):
+    air = rescue4x128_air(64, 16, PrimeField(backend=oracle_backend), segmented=True)
+    with pytest.raises(Exception):
+        air.initProvingContext([], [[1, 2]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind,steps', [('rescue', 1024), ('poseidon', 1024)])
+def test_segmented_hash_chains_hip_equals_oracle(hip_backend, oracle_backend, kind, steps):
+    assert check_segmented(hip_backend, kind, steps) == check_segmented(oracle_backend, kind, steps)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind', ['rescue', 'poseidon'])
+def test_segmented_2p16_configs_verify(hip_backend, kind):
+    """BASELINE configs[2] / configs[3] in the reference's sense: 2^16 steps = 2048 Rescue hashes / 1024 Poseidon hashes."""
+    check_segmented(hip_backend, kind, 1 << 16)
