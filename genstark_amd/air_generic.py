@@ -63,7 +63,8 @@ def mat_vec(m, v):
 class Program:
     """Straight-line code {op, dst, a, b} + constant pool, with scratch registers reused after their last use."""
 
-    def __init__(self, outputs, modulus):
+    def __init__(self, outputs, modulus, share_consts_with=None):
+        """share_consts_with: another Program whose constant pool this one extends (indexes of the other stay valid)."""
         self.modulus = modulus
         order, index = [], {}
 
@@ -83,7 +84,11 @@ class Program:
                 last_use[i] = n
         for o in outs:
             last_use[o] = len(order)
-        self.consts, const_ix = [], {}
+        if share_consts_with is not None:
+            self.consts, const_ix = share_consts_with.consts, share_consts_with._const_ix
+        else:
+            self.consts, const_ix = [], {}
+        self._const_ix = const_ix
 
         def cidx(v):
             v %= modulus
@@ -227,7 +232,10 @@ class GenericProvingContext(_Context):
             f.backend.call('gs_air_trace', code, ninstr, consts, nconsts, nregs, air.traceRegisterCount, svals, periods,
                            len(air.staticRegisters), b''.join(_le(v) for v in self.firstRow), self.traceLength, C.c_void_p(m.ptr))
         else:
-            f.backend.call('gs_air_trace_segments', code, ninstr, consts, nconsts, nregs, air.traceRegisterCount, svals, periods,
+            icode, ininstr = None, 0
+            if air.initProgram is not None:
+                icode, ininstr = air.initProgram.abi_args()[:2]
+            f.backend.call('gs_air_trace_segments', code, ninstr, icode, ininstr, consts, nconsts, nregs, air.traceRegisterCount, svals, periods,
                            len(air.staticRegisters), b''.join(_le(v) for row in self.firstRows for v in row), len(self.firstRows),
                            air.segmentLength, C.c_void_p(m.ptr))
         return m
@@ -257,11 +265,13 @@ class GenericAir:
     init(seed)          -> first row (list of ints)"""
 
     def __init__(self, steps, registers, constraintDegrees, staticRegisters, transition, evaluation, init, extensionFactor=None,
-                 field=None, segmentLength=None):
+                 field=None, segmentLength=None, initExpr=None):
         """segmentLength = L splits the trace into steps/L independent runs (AirScript's `for each (input)` loop over several
         inputs): `seed` is then a list of steps/L per-segment seeds, segment s starts from init(seed[s]) at step s*L, the
         transition constraints are switched off on the last step of every segment by one more cyclic static register
-        (degree + 1), and the trace is generated on the device, one thread per segment (gs_air_trace_segments)."""
+        (degree + 1), and the trace is generated on the device, one thread per segment (gs_air_trace_segments).
+        initExpr(x) -> list of `registers` Expr over the raw inputs x[i] = reg(i): the `init { ... }` block as expressions, run
+        by the same device thread before the segment's first step (init(seed) then only returns the raw inputs, zero-padded)."""
         self.field = field or PrimeField()
         f = self.field
         self.segmentLength = segmentLength
@@ -300,6 +310,15 @@ class GenericAir:
         if self.transitionProgram.nout != registers or self.evaluationProgram.nout != len(self.constraintDegrees):
             raise GstarkError('transition must yield one value per register, evaluation one per constraint')
         self.init = init
+        self.initProgram = None
+        if initExpr is not None:
+            if segmentLength is None:
+                raise GstarkError('initExpr is for segmented AIRs')
+            self.initProgram = Program(initExpr(r), f.modulus, share_consts_with=self.transitionProgram)
+            if self.initProgram.nout != registers:
+                raise GstarkError('initExpr must yield one value per register')
+            if self.initProgram.nregs > self.transitionProgram.nregs:
+                self.transitionProgram.nregs = self.initProgram.nregs
         self.rootOfUnity = f.getRootOfUnity(steps * ef)
         self._staticPolys = None
 
@@ -311,6 +330,12 @@ class GenericAir:
             raise GstarkError(f'a segmented AIR needs one seed per segment ({segments})')
         return [self.init(s) for s in seed]
 
+    def _hostFirstRows(self, seed):
+        rows = [[v % self.field.modulus for v in row] for row in self.firstRows(seed)]
+        if self.initProgram is not None:
+            rows = [self.initProgram.run(row, None, []) for row in rows]
+        return rows
+
     def initProvingContext(self, inputs=None, seed=None):
         return GenericProvingContext(self, self.firstRows(seed))
 
@@ -320,7 +345,7 @@ class GenericAir:
     def hostTrace(self, seed, steps=None):
         """Independent control computation on Python integers (the role of examples/rescue/utils.ts for the examples)."""
         p, out = self.field.modulus, []
-        firsts = self.firstRows(seed)
+        firsts = self._hostFirstRows(seed)
         seg = self.segmentLength or self.steps
         for i in range(steps or self.steps):
             if i % seg == 0:

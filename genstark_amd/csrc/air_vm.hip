@@ -44,14 +44,32 @@ __global__ void k_air_constraints(const uint4 *__restrict__ code, uint32_t ninst
 
 // one thread per independent trace segment: the same register machine, next-row outputs go to a private row buffer
 template <int NREG>
-__global__ void k_air_trace_segments(const uint4 *__restrict__ code, uint32_t ninstr, const fe *__restrict__ consts,
+__global__ void k_air_trace_segments(const uint4 *__restrict__ code, uint32_t ninstr, const uint4 *__restrict__ icode, uint32_t init_ninstr,
+                                     const fe *__restrict__ consts,
                                      const fe *__restrict__ statics, StaticDesc sd, const fe *__restrict__ first_rows, uint32_t registers,
                                      uint64_t segments, uint64_t seglen, fe *__restrict__ out) {
     const uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (g >= segments) return;
     const uint64_t steps = segments * seglen;
     fe vm[NREG], row[GS_AIR_MAX_REGISTERS], next[GS_AIR_MAX_REGISTERS];
-    for (uint32_t r = 0; r < registers; r++) row[r] = first_rows[g * registers + r];
+    for (uint32_t r = 0; r < registers; r++) row[r] = next[r] = first_rows[g * registers + r];
+    if (init_ninstr) {   // the `init { ... }` block: inputs -> first row (no static registers, no next row)
+        for (uint32_t pc = 0; pc < init_ninstr; pc++) {
+            const uint4 ins = icode[pc];
+            const uint32_t dst = ins.y, a = ins.z, b = ins.w;
+            switch (ins.x) {
+                case OP_LOADC: vm[dst] = consts[a]; break;
+                case OP_LOADR: vm[dst] = row[a]; break;
+                case OP_ADDV: vm[dst] = fe_add(vm[a], vm[b]); break;
+                case OP_SUBV: vm[dst] = fe_sub(vm[a], vm[b]); break;
+                case OP_MULV: vm[dst] = fe_mul(vm[a], vm[b]); break;
+                case OP_POW: vm[dst] = fe_pow_u64(vm[a], b); break;
+                case OP_POWC: vm[dst] = fe_pow(vm[a], consts[b]); break;
+                default: next[dst] = vm[a]; break;
+            }
+        }
+        for (uint32_t r = 0; r < registers; r++) row[r] = next[r];
+    }
     for (uint64_t k = 0; k < seglen; k++) {
         const uint64_t i = g * seglen + k;
         for (uint32_t r = 0; r < registers; r++) { out[(uint64_t)r * steps + i] = row[r]; next[r] = row[r]; }
@@ -141,12 +159,14 @@ int gs_air_constraints(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, co
     return GS_OK;
 }
 
-int gs_air_trace_segments(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs,
-                          uint32_t registers, const uint8_t *static_values_host, const uint32_t *static_periods_host, uint32_t nstatic,
-                          const uint8_t *first_rows_host, uint64_t segments, uint64_t segment_len, void *out) {
+int gs_air_trace_segments(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, const uint32_t *init_code_host, uint32_t init_ninstr,
+                          const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs, uint32_t registers, const uint8_t *static_values_host,
+                          const uint32_t *static_periods_host, uint32_t nstatic, const uint8_t *first_rows_host, uint64_t segments,
+                          uint64_t segment_len, void *out) {
     if (!c || !first_rows_host || !out || (!consts_host && nconsts) || (nstatic && (!static_values_host || !static_periods_host))) return GS_ERR_ARG;
     int rc = check_program(c, code_host, ninstr, nconsts, vm_regs, registers, nstatic, registers, false);
     if (rc) return rc;
+    if (init_ninstr && (rc = check_program(c, init_code_host, init_ninstr, nconsts, vm_regs, registers, 0, registers, false))) return rc;
     if (!segments || !segment_len) return gs_fail(c, GS_ERR_ARG, "air_trace_segments: empty");
     StaticDesc sd;
     uint64_t nstat = 0;
@@ -159,26 +179,28 @@ int gs_air_trace_segments(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr,
         }
     }
     // program, constants, static values and first rows -> one device block (pageable caller memory: one sync)
-    const uint64_t code_b = ((uint64_t)ninstr * 16 + 255) & ~(uint64_t)255, const_b = ((uint64_t)(nconsts ? nconsts : 1) * 16 + 255) & ~(uint64_t)255;
+    const uint64_t main_b = ((uint64_t)ninstr * 16 + 255) & ~(uint64_t)255, code_b = main_b + (((uint64_t)init_ninstr * 16 + 255) & ~(uint64_t)255);
+    const uint64_t const_b = ((uint64_t)(nconsts ? nconsts : 1) * 16 + 255) & ~(uint64_t)255;
     const uint64_t stat_b = ((nstat ? nstat : 1) * 16 + 255) & ~(uint64_t)255, rows_b = segments * registers * 16;
     void *d;
     if ((rc = gs_tmp_alloc(c, code_b + const_b + stat_b + rows_b, &d))) return rc;
     uint8_t *p = (uint8_t *)d;
     hipError_t e = hipMemcpyAsync(p, code_host, (size_t)ninstr * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && init_ninstr) e = hipMemcpyAsync(p + main_b, init_code_host, (size_t)init_ninstr * 16, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && nconsts) e = hipMemcpyAsync(p + code_b, consts_host, (size_t)nconsts * 16, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && nstat) e = hipMemcpyAsync(p + code_b + const_b, static_values_host, (size_t)nstat * 16, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(p + code_b + const_b + stat_b, first_rows_host, (size_t)rows_b, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { gs_tmp_free(c, d); return gs_fail(c, GS_ERR_DEVICE, "air_trace_segments upload: %s", hipGetErrorString(e)); }
-    const uint4 *dcode = (const uint4 *)p;
+    const uint4 *dcode = (const uint4 *)p, *dinit = (const uint4 *)(p + main_b);
     const fe *dconst = (const fe *)(p + code_b), *dstat = (const fe *)(p + code_b + const_b), *drows = (const fe *)(p + code_b + const_b + stat_b);
     dim3 block(64), grid((unsigned)((segments + 63) / 64));   // one wave per 64 segments: spread the few long-running threads over the CUs
     if (vm_regs <= 16)
-        hipLaunchKernelGGL(k_air_trace_segments<16>, grid, block, 0, c->stream, dcode, ninstr, dconst, dstat, sd, drows, registers, segments, segment_len, (fe *)out);
+        hipLaunchKernelGGL(k_air_trace_segments<16>, grid, block, 0, c->stream, dcode, ninstr, dinit, init_ninstr, dconst, dstat, sd, drows, registers, segments, segment_len, (fe *)out);
     else if (vm_regs <= 32)
-        hipLaunchKernelGGL(k_air_trace_segments<32>, grid, block, 0, c->stream, dcode, ninstr, dconst, dstat, sd, drows, registers, segments, segment_len, (fe *)out);
+        hipLaunchKernelGGL(k_air_trace_segments<32>, grid, block, 0, c->stream, dcode, ninstr, dinit, init_ninstr, dconst, dstat, sd, drows, registers, segments, segment_len, (fe *)out);
     else
-        hipLaunchKernelGGL(k_air_trace_segments<64>, grid, block, 0, c->stream, dcode, ninstr, dconst, dstat, sd, drows, registers, segments, segment_len, (fe *)out);
+        hipLaunchKernelGGL(k_air_trace_segments<64>, grid, block, 0, c->stream, dcode, ninstr, dinit, init_ninstr, dconst, dstat, sd, drows, registers, segments, segment_len, (fe *)out);
     e = hipGetLastError();
     gs_tmp_free(c, d);
     if (e != hipSuccess) return gs_fail(c, GS_ERR_DEVICE, "air_trace_segments launch: %s", hipGetErrorString(e));

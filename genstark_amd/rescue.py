@@ -95,5 +95,13 @@ def rescue4x128_air(steps, extensionFactor=16, field=None, segmented=False):
         nn = [x ** ALPHA for x in mat_vec(INV_MDS, [a - b for a, b in zip(n, k[4:8])])]
         return [a - b for a, b in zip(s, nn)]
 
-    return GenericAir(steps, 4, [3, 3, 3, 3], rc, transition, evaluation, lambda seed: build_inputs(f, seed, initial),
-                      extensionFactor, f, segmentLength=STEPS_PER_HASH if segmented else None)
+    if not segmented:
+        return GenericAir(steps, 4, [3, 3, 3, 3], rc, transition, evaluation, lambda seed: build_inputs(f, seed, initial), extensionFactor, f)
+
+    def init_expr(x):          # build_inputs() as expressions: evaluated on the device for every segment
+        a = [(x[0] + initial[0]) ** inv_exp, (x[1] + initial[1]) ** inv_exp,
+             pow(initial[2], inv_exp, f.modulus), pow(initial[3], inv_exp, f.modulus)]     # registers 2, 3 start from constants
+        return [m + k for m, k in zip(mat_vec(MDS, a), initial[4:8])]
+
+    return GenericAir(steps, 4, [3, 3, 3, 3], rc, transition, evaluation, lambda seed: [seed[0], seed[1], 0, 0], extensionFactor, f,
+                      segmentLength=STEPS_PER_HASH, initExpr=init_expr)

@@ -210,11 +210,14 @@ int gs_air_trace(gs_ctx *ctx, const uint32_t *code_host, uint32_t ninstr, const 
 /* Trace made of `segments` INDEPENDENT runs of `segment_len` steps (AirScript `for each (input) { init {...} for steps [...] }`
  * with several inputs: examples/rescue/hash4x128.ts:60-81, examples/poseidon/hash6x128.ts:62-81): segment s starts from
  * first_rows[s] (registers elements) and fills steps [s*segment_len, (s+1)*segment_len); static registers are indexed by the
- * global step.  The segments do not depend on each other: one DEVICE thread interprets the program for each of them. */
-int gs_air_trace_segments(gs_ctx *ctx, const uint32_t *code_host, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts,
-                          uint32_t vm_regs, uint32_t registers, const uint8_t *static_values_host, const uint32_t *static_periods_host,
-                          uint32_t nstatic, const uint8_t *first_rows_host /* segments x registers */, uint64_t segments,
-                          uint64_t segment_len, void *out /* registers x (segments*segment_len) */);
+ * global step.  The segments do not depend on each other: one DEVICE thread interprets the program for each of them.
+ * init_code (optional, init_ninstr = 0 for none) is the `init { ... }` block: a program over the same constant pool that
+ * maps first_rows[s] (read with LOADR, e.g. the raw inputs padded with zeros) to the segment's actual first row. */
+int gs_air_trace_segments(gs_ctx *ctx, const uint32_t *code_host, uint32_t ninstr, const uint32_t *init_code_host, uint32_t init_ninstr,
+                          const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs, uint32_t registers,
+                          const uint8_t *static_values_host, const uint32_t *static_periods_host, uint32_t nstatic,
+                          const uint8_t *first_rows_host /* segments x registers */, uint64_t segments, uint64_t segment_len,
+                          void *out /* registers x (segments*segment_len) */);
 int gs_air_constraints(gs_ctx *ctx, const uint32_t *code_host, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts,
                        uint32_t vm_regs, uint32_t registers, uint32_t constraints, const void *p_comp /* registers x nc */,
                        uint64_t nc, uint64_t shift, const void *static_tables /* device, concatenated */,

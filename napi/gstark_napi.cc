@@ -77,7 +77,7 @@ const FnDesc kFns[] = {
     {"gs_mimc_trace", "cbbiup"},
     {"gs_mimc_constraints", "cpuupup"},
     {"gs_air_trace", "cwibiiibwibup"},
-    {"gs_air_trace_segments", "cwibiiibwibuup"},
+    {"gs_air_trace_segments", "cwiwibiiibwibuup"},
     {"gs_air_constraints", "cwibiiiipuupxip"},
     {"gs_small_interpolate", "bbio"},
     {"gs_small_eval_poly", "bibio"},

@@ -484,16 +484,34 @@ int gs_air_trace(gs_ctx *c, const uint32_t *code, uint32_t n, const uint8_t *con
     return GS_OK;
 }
 /* include/gstark.h gs_air_trace_segments: independent runs, each the serial loop above started from its own first row */
-int gs_air_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t n, const uint8_t *consts, uint32_t nconsts, uint32_t vmn, uint32_t regs,
-                          const uint8_t *svals, const uint32_t *speriods, uint32_t nstatic, const uint8_t *rows0, uint64_t segments,
-                          uint64_t seglen, void *out) {
+int gs_air_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t n, const uint32_t *icode, uint32_t in, const uint8_t *consts, uint32_t nconsts,
+                          uint32_t vmn, uint32_t regs, const uint8_t *svals, const uint32_t *speriods, uint32_t nstatic, const uint8_t *rows0,
+                          uint64_t segments, uint64_t seglen, void *out) {
     if (air_check(c, code, n, nconsts, vmn, regs, nstatic, regs, 0)) return GS_ERR_ARG;
+    if (in && air_check(c, icode, in, nconsts, vmn, regs, 0, regs, 0)) return GS_ERR_ARG;
     if (!segments || !seglen) return fail(c, GS_ERR_ARG, "air_trace_segments: empty");
     fe vm[GS_AIR_MAX_VM_REGS], row[GS_AIR_MAX_REGISTERS], next[GS_AIR_MAX_REGISTERS];
     uint64_t soff[GS_AIR_MAX_REGISTERS], o = 0, steps = segments * seglen;
     for (uint32_t s = 0; s < nstatic; s++) { if (!speriods[s]) return fail(c, GS_ERR_ARG, "air_trace_segments: empty static register"); soff[s] = o; o += speriods[s]; }
     for (uint64_t g = 0; g < segments; g++) {
         for (uint32_t r = 0; r < regs; r++) row[r] = fe_load(rows0 + 16 * (g * regs + r));
+        if (in) {   /* init block: inputs -> first row */
+            for (uint32_t r = 0; r < regs; r++) next[r] = row[r];
+            for (uint32_t pc = 0; pc < in; pc++) {
+                uint32_t op = icode[4 * pc], d = icode[4 * pc + 1], a = icode[4 * pc + 2], b = icode[4 * pc + 3];
+                switch (op) {
+                    case 0: vm[d] = fe_load(consts + 16 * a); break;
+                    case 1: vm[d] = row[a]; break;
+                    case 4: vm[d] = fe_add(vm[a], vm[b]); break;
+                    case 5: vm[d] = fe_sub(vm[a], vm[b]); break;
+                    case 6: vm[d] = fe_mul(vm[a], vm[b]); break;
+                    case 7: vm[d] = vm_pow_u32(vm[a], b); break;
+                    case 8: vm[d] = fe_exp(vm[a], fe_load(consts + 16 * b)); break;
+                    default: next[d] = vm[a]; break;
+                }
+            }
+            for (uint32_t r = 0; r < regs; r++) row[r] = next[r];
+        }
         for (uint64_t k = 0; k < seglen; k++) {
             const uint64_t i = g * seglen + k;
             for (uint32_t r = 0; r < regs; r++) ST(out, (uint64_t)r * steps + i, row[r]);
