@@ -262,6 +262,9 @@ def main():
 
         def leg():
             try:
+                if not cpu_mode:
+                    torch.cuda.set_device(local_rank)      # the HIP current device is per-thread state
+                    torch.cuda.set_stream(stream)
                 from genstark_amd.air import MimcAir
                 from genstark_amd.distributed import DistField
                 from genstark_amd.stark import Stark
