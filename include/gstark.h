@@ -22,7 +22,9 @@
  *    "host" are HOST pointers.
  *  - All calls are asynchronous on the context's HIP stream and ordered on it; gs_download,
  *    gs_gather and gs_sync block until the stream is drained.  Like the reference (synchronous,
- *    single-threaded JS) a context must not be used from two threads at once.
+ *    single-threaded JS) a context must not be used from two threads at once; a thread other than the
+ *    one that called gs_ctx_create must make the context's device its current HIP device first
+ *    (hipSetDevice is per-thread state; several contexts, one per thread, may share a GPU).
  *  - Every function returns GS_OK (0) or a negative gs_status; gs_last_error(ctx) describes it.
  *    There is NO CPU fallback: without a gfx950 device gs_ctx_create fails.
  */
