@@ -196,6 +196,31 @@ def test_ntt_full_size_properties(hip_backend, logn):
         assert ev.getValue(q) == want
 
 
+@pytest.mark.parametrize('logn', [25, 26])
+def test_ntt_four_pass_sizes_properties(hip_backend, logn):
+    """Beyond the BASELINE sizes: n = 2^25 / 2^26 take FOUR radix passes (1 GiB per vector at 2^26).  Round trip, linearity
+    (vectors compared on the device through their Merkle roots) and closed-form spot values of a zero-extended transform."""
+    f = PrimeField(backend=hip_backend)
+    h = createHash('blake2s256', hip_backend)
+    fingerprint = lambda v: MerkleTree.create(h.mergeVectorRows([v]), h).root
+    n = 1 << logn
+    w = f.getRootOfUnity(n)
+    roots = f.getPowerSeries(w, n)
+    a = f.getPowerSeries(0x1234567890abcdef1234567, n)
+    ea = f.evalPolyAtRoots(a, roots)
+    assert fingerprint(f.interpolateRoots(roots, ea)) == fingerprint(a)
+    b = f.getPowerSeries(0xfedcba9876543210fedcba987654321, n)
+    eb = f.evalPolyAtRoots(b, roots)
+    assert fingerprint(f.addVectorElements(ea, eb)) == fingerprint(f.evalPolyAtRoots(f.addVectorElements(a, b), roots))
+    del ea, eb, b
+    plen, c = n // 16, 987654321987654321
+    ev = f.evalPolyAtRoots(f.getPowerSeries(c, plen), roots)
+    rng = random.Random(logn)
+    for q in [0, 1, n - 1] + [rng.randrange(n) for _ in range(5)]:
+        cx = c * pow(w, q, P) % P
+        assert ev.getValue(q) == (pow(cx, plen, P) - 1) * pow(cx - 1, P - 2, P) % P
+
+
 def test_prove_2p20_full_config_verifies(hip_backend):
     """BASELINE configs[4]: MiMC-128, 2^20 steps, E=16, friQueryCount 64 — the proof verifies, sizeOf matches,
     8 FRI layers with a 256-value remainder."""
