@@ -11,6 +11,7 @@ Call sites of every member: SURVEY.md section 8(b).
 """
 import ctypes as C
 import hashlib
+import weakref
 from hashlib import sha256 as _sha256
 
 from ._abi import Backend, GstarkError
@@ -131,6 +132,7 @@ class PrimeField:
         if modulus != MODULUS:
             raise GstarkError('this build accelerates the 128-bit field 2^128 - 9*2^32 + 1 only')
         self.backend = backend or Backend()
+        self._lastEvaluation = None     # (polys, ptr, omega, n, result) of the latest evalPolysAtRoots, weakly held
         buf = C.create_string_buffer(16)
         self.backend.lib.gs_field_modulus(C.cast(buf, C.c_void_p))
         assert int.from_bytes(buf.raw, 'little') == modulus
@@ -318,12 +320,25 @@ class PrimeField:
         return out
 
     def evalPolysAtRoots(self, polys, roots):
-        """lib/Stark.ts:109; BoundaryConstraints.ts:87-88."""
+        """lib/Stark.ts:109; BoundaryConstraints.ts:87-88.  The evaluations of the SAME polynomials over a subgroup of the
+        domain they were last evaluated on (the composition domain after the evaluation domain: lib/Stark.ts:109 then
+        CompositionPolynomial.ts:76) are every k-th element of that result: a strided copy instead of another NTT."""
         if polys.colCount > roots.length:
             raise GstarkError('Number of roots of unity cannot be smaller than number of values')
-        out = Matrix(self.backend, polys.rowCount, roots.length)
-        self.backend.call('gs_eval_polys_at_roots', C.c_void_p(polys.ptr), polys.rowCount, polys.colCount,
-                          _le(self._omega_of(roots)), roots.length, C.c_void_p(out.ptr))
+        n, omega = roots.length, self._omega_of(roots)
+        out = Matrix(self.backend, polys.rowCount, n)
+        prev = self._lastEvaluation
+        if prev is not None:
+            ppolys, pptr, pomega, pn, pout = prev[0](), prev[1], prev[2], prev[3], prev[4]()
+            if ppolys is polys and pptr == polys.ptr and pout is not None and pn > n and pn % n == 0 and \
+                    pow(pomega, pn // n, self.modulus) == omega:
+                for r in range(polys.rowCount):
+                    self.backend.call('gs_pluck', C.c_void_p(pout.ptr + r * pn * ELEMENT_SIZE), pn, pn // n, n,
+                                      C.c_void_p(out.ptr + r * n * ELEMENT_SIZE))
+                return out
+        self.backend.call('gs_eval_polys_at_roots', C.c_void_p(polys.ptr), polys.rowCount, polys.colCount, _le(omega), n,
+                          C.c_void_p(out.ptr))
+        self._lastEvaluation = (weakref.ref(polys), polys.ptr, omega, n, weakref.ref(out))
         return out
 
     def interpolateRoots(self, roots, ys):
