@@ -82,8 +82,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sharded-leg-timeout', type=float, default=90.0,
                     help='N > 1 only: seconds allowed for the extra one-proof-across-all-ranks leg (0 = skip it)')
-    ap.add_argument('--lanes', type=int, default=3, help='prover lanes of the extra throughput-mode leg (0 = skip it)')
-    ap.add_argument('--lane-proofs', type=int, default=24, help='proofs pushed through the lanes in that leg')
+    ap.add_argument('--lanes', type=int, default=8, help='prover lanes of the extra throughput-mode leg (0 = skip it)')
+    ap.add_argument('--lane-proofs', type=int, default=48, help='proofs pushed through the lanes in that leg')
     # test-only: drive the distributed harness on CPU (gloo) against the oracle's implementation of the C ABI
     ap.add_argument('--test-double-lib', default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()

@@ -2,6 +2,7 @@
 FiniteField / Hash / MerkleTree calls as lib/Stark.ts:81-163; each of those calls lands in one HIP
 kernel launch (or a short chain) behind include/gstark.h.  verify() is lib/Stark.ts:167-248."""
 import math
+import os
 
 from .components import CompositionPolynomial, LinearCombination, LowDegreeProver, QueryIndexGenerator
 from .errors import StarkError
@@ -54,7 +55,8 @@ class Stark:
         self.indexGenerator = QueryIndexGenerator(sOptions)
         self.serializer = Serializer(air, self.hash.digestSize)
         self.logger = logger or NoopLogger()
-        self.prefetch = True   # issue trace-independent device work before the host-side trace recurrence (same proof bytes)
+        # issue trace-independent device work before the host-side trace recurrence (same proof bytes); GSTARK_PREFETCH=0 disables
+        self.prefetch = os.environ.get('GSTARK_PREFETCH', '1') != '0'
 
     @property
     def securityLevel(self):  # :62-77
