@@ -297,7 +297,9 @@ class GenericAir:
         self.constraintDegrees = list(constraintDegrees)
         self.maxConstraintDegree = max(self.constraintDegrees)
         self.compositionFactor = 1 << (self.maxConstraintDegree - 1).bit_length()
-        self.extensionFactor = extensionFactor or 2 * self.compositionFactor
+        # README.md:112 — a power of 2 at least 2x the constraint degree, at most 32; default: the smallest power of 2 GREATER
+        # than 2 * degree (degree 1 -> 4, degree 3 -> 8)
+        self.extensionFactor = extensionFactor or 1 << (2 * self.maxConstraintDegree).bit_length()
         ef = self.extensionFactor
         if ef & (ef - 1) or ef < 2 * self.compositionFactor or ef > 32:
             raise GstarkError('Extension factor must be a power of 2 at least 2x the constraint degree and at most 32')

@@ -281,3 +281,40 @@ def test_segmented_hash_chains_hip_equals_oracle(hip_backend, oracle_backend, ki
 def test_segmented_2p16_configs_verify(hip_backend, kind):
     """BASELINE configs[2] / configs[3] in the reference's sense: 2^16 steps = 2048 Rescue hashes / 1024 Poseidon hashes."""
     check_segmented(hip_backend, kind, 1 << 16)
+
+
+# ---- BASELINE configs[0]: "Foo" (README.md:17-60) — the smallest STARK the reference shows -----------------------------
+def foo_air(field, steps=64):
+    """x_{n+1} = x_n + 2: one register, one degree-1 constraint => extension factor 4, evaluation domain 256, which is not
+    larger than the FRI remainder bound: the low-degree proof has NO layers (LowDegreeProver.ts:179, getComponentCount = 0).
+    The README runs it over 2^32 - 3*2^25 + 1; the arithmetic here is the 128-bit field's (the only one this build accelerates),
+    the protocol path is the same."""
+    return GenericAir(steps, 1, [1], [], lambda r, k: [r[0] + 2], lambda r, n, k: [n[0] - (r[0] + 2)], lambda seed: [seed[0]], None, field)
+
+
+def check_foo(backend):
+    f = PrimeField(backend=backend)
+    air = foo_air(f)
+    assert air.extensionFactor == 4 and air.compositionFactor == 1
+    stark = Stark(air, None)                                   # default options: sha256, exe 80, fri 40 (lib/Stark.ts:17-23)
+    assert stark.hash.algorithm == 'sha256'
+    assertions = [{'step': 0, 'register': 0, 'value': 1}, {'step': 63, 'register': 0, 'value': 127}]     # README.md:42-45
+    proof = stark.prove(assertions, [], [1])
+    assert proof['ldProof']['components'] == [] and len(proof['ldProof']['remainder']) == 256
+    data = stark.serialize(proof)
+    assert len(data) == stark.sizeOf(proof)
+    assert stark.verify(assertions, stark.parse(data))
+    with pytest.raises(StarkError):
+        stark.verify([assertions[0], {'step': 63, 'register': 0, 'value': 126}], stark.parse(data))
+    with pytest.raises(StarkError):
+        stark.prove([{'step': 63, 'register': 0, 'value': 128}], [], [1])
+    return data
+
+
+def test_foo_readme_example_oracle(oracle_backend):
+    check_foo(oracle_backend)
+
+
+@pytest.mark.gpu
+def test_foo_readme_example_hip_equals_oracle(hip_backend, oracle_backend):
+    assert check_foo(hip_backend) == check_foo(oracle_backend)
