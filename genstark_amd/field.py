@@ -290,6 +290,13 @@ class PrimeField:
         self.backend.call('gs_transpose_matrix', C.c_void_p(m.ptr), m.rowCount, m.colCount, C.c_void_p(out.ptr))
         return out
 
+    def mulMatrixByVector(self, m, v):
+        """galois FiniteField.mulMatrixByVector (examples/poseidon/utils.ts:45: `mds x state`): out[r] = sum_c m[r][c] * v[c],
+        one device dot product per row."""
+        if m.colCount != v.length:
+            raise GstarkError('Matrix column count must be the same as vector length')
+        return self.newVectorFrom([self.combineVectors(m.row(r), v) for r in range(m.rowCount)])
+
     def joinMatrixRows(self, m):
         return Vector(self.backend, m.rowCount * m.colCount, owner=m._owner, offset=m._offset)
 

@@ -202,6 +202,11 @@ class PrimeField {
         const out = new Vector(this, a.length); native().call('gs_vec_exp', this.ctx, a.ptr, le(e), a.length, out.ptr); return out;
     }
     combineVectors(a, b) { const out = Buffer.alloc(16); native().call('gs_combine', this.ctx, a.ptr, b.ptr, a.length, out); return fromLe(out); }
+    mulMatrixByVector(m, v) {   // examples/poseidon/utils.ts:45
+        const out = [];
+        for (let r = 0; r < m.rowCount; r++) out.push(this.combineVectors(new Vector(this, m.colCount, m.owner, m.offset + BigInt(r * m.colCount * ELEMENT_SIZE)), v));
+        return this.newVectorFrom(out);
+    }
     combineManyVectors(vectors, coefficients) {
         const ks = Array.isArray(coefficients) ? coefficients : coefficients.toValues();
         const out = new Vector(this, vectors[0].length);

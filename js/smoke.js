@@ -57,5 +57,7 @@ assert(fast.equals(generic));
     assert.deepStrictEqual(field.addPolys(field.newVectorFrom(a), field.newVectorFrom(b)).toValues(), a.map((x, i) => (x + pad[i]) % P));
     assert.deepStrictEqual(field.subPolys(field.newVectorFrom(b), field.newVectorFrom(a)).toValues(), a.map((x, i) => (pad[i] - x + P) % P));
     assert.deepStrictEqual(field.mulPolyByConstant(field.newVectorFrom(b), 5n).toValues(), b.map(x => x * 5n % P));
+    const mat = [[1n, 2n, 3n], [P - 1n, 5n, 7n]], vec = [11n, P - 2n, 13n];
+    assert.deepStrictEqual(field.mulMatrixByVector(field.newMatrixFrom(mat), field.newVectorFrom(vec)).toValues(), mat.map(row => row.reduce((s, x, i) => (s + x * vec[i]) % P, 0n)));
 }
 console.log(`js smoke OK: galois/merkle drop-in objects via N-API on backend ${process.env.GSTARK_ALLOW_TEST_DOUBLE === '1' ? '(test double allowed)' : 'hip-gfx950'}`);

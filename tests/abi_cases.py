@@ -133,6 +133,10 @@ def check_small_polys(backend, rng):
         a, b = rand_elements(rng, la), rand_elements(rng, lb)
         got = f.mulPolys(f.newVectorFrom(a), f.newVectorFrom(b))
         assert got.length == la + lb - 1 and got.toValues() == PF.mul_polys(a, b)
+    # mulMatrixByVector: the way examples/poseidon/utils.ts applies its MDS matrix
+    mat = [rand_elements(rng, 6) for _ in range(6)]
+    vec = rand_elements(rng, 6)
+    assert f.mulMatrixByVector(f.newMatrixFrom(mat), f.newVectorFrom(vec)).toValues() == [sum(x * y for x, y in zip(row, vec)) % P for row in mat]
     a, b = rand_elements(rng, 9), rand_elements(rng, 5)
     pad = b + [0] * 4
     assert f.addPolys(f.newVectorFrom(a), f.newVectorFrom(b)).toValues() == [(x + y) % P for x, y in zip(a, pad)]
