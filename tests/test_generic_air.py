@@ -318,3 +318,35 @@ def test_foo_readme_example_oracle(oracle_backend):
 @pytest.mark.gpu
 def test_foo_readme_example_hip_equals_oracle(hip_backend, oracle_backend):
     assert check_foo(hip_backend) == check_foo(oracle_backend)
+
+
+def check_poseidon_hash_through_facade(backend):
+    """examples/poseidon/utils.ts:19-49 executed member by member on the galois-shaped field object (addVectorElements,
+    expVectorElements, mulMatrixByVector, exp, newVectorFrom/newMatrixFrom, toValues) must give the digest the host-integer
+    restatement gives."""
+    from genstark_amd import poseidon
+    f = PrimeField(backend=backend)
+    m, rf, rp = poseidon.STATE_WIDTH, poseidon.F_ROUNDS, poseidon.P_ROUNDS
+    mds = f.newMatrixFrom(poseidon.mds_matrix(f))
+    ark = [f.newVectorFrom(v) for v in poseidon.round_constants(f, m, rf + rp)]
+    for inputs in ([1, 2, 3, 4], [ga.MODULUS - 1, 0, 7]):
+        state = f.newVectorFrom(list(inputs) + [0] * (m - len(inputs)))
+        for i in range(rf + rp):
+            state = f.addVectorElements(state, ark[i])
+            if i < rf // 2 or i >= rf // 2 + rp:
+                state = f.expVectorElements(state, 5)
+            else:
+                values = state.toValues()
+                values[m - 1] = f.exp(values[m - 1], 5)
+                state = f.newVectorFrom(values)
+            state = f.mulMatrixByVector(mds, state)
+        assert state.toValues()[:2] == poseidon.poseidon_hash(f, inputs)
+
+
+def test_poseidon_hash_through_facade_oracle(oracle_backend):
+    check_poseidon_hash_through_facade(oracle_backend)
+
+
+@pytest.mark.gpu
+def test_poseidon_hash_through_facade_hip(hip_backend):
+    check_poseidon_hash_through_facade(hip_backend)
