@@ -3,21 +3,37 @@
 Fully specified in the reference tree, so this must be bit-exact, including the quirk that a bigint is
 hashed as Buffer.from(value.toString(16), 'hex') (odd trailing nibble dropped; :61-67).
 """
+import ctypes as C
+
 from ..field import sha256_bigint
 
 
 class QueryIndexGenerator:
-    def __init__(self, options):
+    def __init__(self, options, backend=None):
+        """backend: when given, the ~700 chained hashes per proof run in the library's host helper gs_pseudorandom_indexes
+        (same algorithm, pinned to the reference's own module by tests/test_reference_vectors.py) instead of a Python loop."""
         self.extensionFactor = options['extensionFactor']
         self.exeQueryCount = options['exeQueryCount']
         self.friQueryCount = options['friQueryCount']
+        self._native = getattr(backend.lib, 'gs_pseudorandom_indexes', None) if backend is not None else None
+
+    def _indexes(self, seed, count, max_):
+        if self._native is None or not isinstance(seed, (bytes, bytearray)) or max_ >= 1 << 63:
+            return getPseudorandomIndexes(seed, count, max_, self.extensionFactor)
+        maxCount = max_ - max_ // self.extensionFactor if self.extensionFactor else max_
+        if maxCount < count:
+            raise ValueError(f'Cannot select {count} unique pseudorandom indexes from {max_} values')
+        out = (C.c_uint64 * max(count, 1))()
+        if self._native(bytes(seed), len(seed), count, max_, self.extensionFactor, out):
+            raise ValueError(f'Could not generate {count} pseudorandom indexes')
+        return list(out[:count])
 
     def getExeIndexes(self, seed, domainSize):
         queryCount = min(self.exeQueryCount, domainSize - domainSize // self.extensionFactor)
-        return getPseudorandomIndexes(seed, queryCount, domainSize, self.extensionFactor)
+        return self._indexes(seed, queryCount, domainSize)
 
     def getFriIndexes(self, seed, columnLength):
-        return getPseudorandomIndexes(seed, self.friQueryCount, columnLength, self.extensionFactor)
+        return self._indexes(seed, self.friQueryCount, columnLength)
 
 
 def getPseudorandomIndexes(seed, count, max_, excludeMultiplesOf=0):

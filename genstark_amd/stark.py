@@ -52,7 +52,7 @@ class Stark:
         sOptions = buildSecurityOptions(options, air.extensionFactor)
         make_hash = getattr(air.field, 'createHash', None)      # a distributed field brings its own Hash (distributed.py)
         self.hash = make_hash(sOptions['hashAlgorithm']) if make_hash else createHash(sOptions['hashAlgorithm'], air.field.backend)
-        self.indexGenerator = QueryIndexGenerator(sOptions)
+        self.indexGenerator = QueryIndexGenerator(sOptions, air.field.backend)
         self.serializer = Serializer(air, self.hash.digestSize)
         self.logger = logger or NoopLogger()
         # issue trace-independent device work before the host-side trace recurrence (same proof bytes); GSTARK_PREFETCH=0 disables

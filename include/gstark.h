@@ -179,6 +179,15 @@ int gs_merkle_prove_batch(gs_ctx *ctx, const void *leaves, const void *nodes, ui
 int gs_small_interpolate(const uint8_t *xs_host, const uint8_t *ys_host, uint32_t n, uint8_t *coeffs_out);
 int gs_small_eval_poly(const uint8_t *poly_host, uint32_t len, const uint8_t *xs_host, uint32_t m, uint8_t *out_host);
 
+/* ---- host helper: Fiat-Shamir query positions -----------------------------------------------------------------------
+ * lib/components/QueryIndexGenerator.ts:39-67 (getPseudorandomIndexes + its sha256-of-a-bigint helper), host only, no
+ * context: state = sha256(seed); candidate i = sha256(Buffer.from((state + i).toString(16), 'hex')) mod max — the
+ * reference's quirk that an odd number of hex digits loses the last nibble included —, multiples of
+ * `exclude_multiples_of` (0 = none) and repeats skipped, until `count` distinct indexes exist or count*1000 candidates were
+ * tried (GS_ERR_ARG).  ~700 hashes per proof: a measurable slice of a 20 ms prove() when the host language is Python. */
+int gs_pseudorandom_indexes(const uint8_t *seed_host, uint32_t seed_len, uint32_t count, uint64_t max,
+                            uint32_t exclude_multiples_of, uint64_t *out_host);
+
 /* ---- AIR (air-assembly ProvingContext, MiMC instance) ------------------------------------------ */
 /* context.generateExecutionTrace() for the MiMC AIR of examples/mimc/mimc128Assembly.ts:28-51:
  * trace[0] = seed, trace[i+1] = trace[i]^3 + rc[i mod nrc] (examples/mimc/utils.ts:7-15).

@@ -563,3 +563,52 @@ int gs_air_constraints(gs_ctx *c, const uint32_t *code, uint32_t n, const uint8_
     }
     return GS_OK;
 }
+
+/* include/gstark.h gs_pseudorandom_indexes — QueryIndexGenerator.ts:39-67 on the host */
+#define SHA256(m, l, o) orc_sha256((m), (l), (o))
+int gs_pseudorandom_indexes(const uint8_t *seed, uint32_t seed_len, uint32_t count, uint64_t max_, uint32_t exclude, uint64_t *out) {
+    if (!seed || !out || !max_ || (count && !out)) return GS_ERR_ARG;
+    uint64_t max_count = exclude ? max_ - max_ / exclude : max_;
+    if (max_count < count) return GS_ERR_ARG;
+    uint8_t st[32], msg[33], dg[32];
+    SHA256(seed, seed_len, st);                       /* state: 256-bit big-endian integer */
+    uint32_t found = 0;
+    for (uint64_t i = 0; i < (uint64_t)count * 1000 && found < count; i++) {
+        /* v = state + i, 33 bytes big-endian */
+        uint64_t carry = i;
+        msg[0] = 0;
+        for (int k = 31; k >= 0; k--) { uint64_t t = (uint64_t)st[k] + (carry & 0xFF); msg[k + 1] = (uint8_t)t; carry = (carry >> 8) + (t >> 8); }
+        msg[0] = (uint8_t)carry;
+        /* hex digits without leading zeros; an odd count drops the last nibble: bytes = (v >> 4) then */
+        int lead = 0;
+        while (lead < 33 && msg[lead] == 0) lead++;
+        int nhex = lead == 33 ? 0 : (33 - lead) * 2 - ((msg[lead] >> 4) == 0 ? 1 : 0);
+        uint8_t buf[33];
+        int nbytes = nhex / 2;
+        if (nhex & 1) {                               /* shift right by one nibble */
+            for (int k = 0; k < nbytes; k++) {
+                /* byte k of the result = nibbles 2k, 2k+1 of the hex string */
+                int hi_n = 2 * k, lo_n = 2 * k + 1;   /* nibble index from the most significant nibble of the string */
+                int first = lead * 2 + 1;             /* string starts at the low nibble of msg[lead] */
+                int a = first + hi_n, b = first + lo_n;
+                uint8_t na = (a & 1) ? (msg[a >> 1] & 15) : (msg[a >> 1] >> 4);
+                uint8_t nb = (b & 1) ? (msg[b >> 1] & 15) : (msg[b >> 1] >> 4);
+                buf[k] = (uint8_t)((na << 4) | nb);
+            }
+        } else {
+            for (int k = 0; k < nbytes; k++) buf[k] = msg[lead + k];
+        }
+        SHA256(buf, (size_t)nbytes, dg);
+        /* index = dg (big-endian 256-bit) mod max */
+        unsigned __int128 r = 0;
+        for (int k = 0; k < 32; k++) r = ((r << 8) | dg[k]) % max_;
+        uint64_t index = (uint64_t)r;
+        if (exclude && index % exclude == 0) continue;
+        int dup = 0;
+        for (uint32_t k = 0; k < found; k++) if (out[k] == index) { dup = 1; break; }
+        if (dup) continue;
+        out[found++] = index;
+    }
+    return found == count ? GS_OK : GS_ERR_ARG;
+}
+#undef SHA256

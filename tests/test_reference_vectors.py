@@ -36,6 +36,42 @@ def test_query_index_generator_matches_reference():
                 assert pyref.pseudorandom_indexes(seed, rec['friQueryCount'], fri['columnLength'], rec['ef']) == fri['indexes']
 
 
+@pytest.mark.parametrize('which', ['oracle', 'hip'])
+def test_native_query_index_helper_matches_reference(which, oracle_backend):
+    """gs_pseudorandom_indexes (host code inside the libraries, used by the prover instead of the Python loop) against the
+    outputs of the reference's own QueryIndexGenerator module.  The HIP library's copy is host-only code: it is loaded with
+    plain ctypes here, no GPU needed."""
+    import ctypes as C
+    from genstark_amd._abi import HIP_LIB_PATH
+
+    class _B:
+        pass
+    if which == 'oracle':
+        backend = oracle_backend
+    else:
+        if not os.path.exists(HIP_LIB_PATH):
+            pytest.skip('libgstark_hip.so not built')
+        backend = _B()
+        backend.lib = C.CDLL(HIP_LIB_PATH)
+        backend.lib.gs_pseudorandom_indexes.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+        backend.lib.gs_pseudorandom_indexes.restype = C.c_int
+    checked = 0
+    for rec in REF['queryIndexes']:
+        seed = bytes.fromhex(rec['seed'])
+        g = QueryIndexGenerator({'extensionFactor': rec['ef'], 'exeQueryCount': rec['exeQueryCount'],
+                                 'friQueryCount': rec['friQueryCount']}, backend)
+        assert g._native is not None
+        assert g.getExeIndexes(seed, rec['domain']) == rec['exe']
+        for fri in rec['fri']:
+            if 'error' in fri:
+                with pytest.raises(ValueError):
+                    g.getFriIndexes(seed, fri['columnLength'])
+            else:
+                assert g.getFriIndexes(seed, fri['columnLength']) == fri['indexes']
+                checked += 1
+    assert checked >= 100
+
+
 def _revive_merkle(p):
     return {'values': [bytes.fromhex(v) for v in p['values']], 'nodes': [[bytes.fromhex(x) for x in c] for c in p['nodes']],
             'depth': p['depth']}
