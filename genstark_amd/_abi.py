@@ -66,8 +66,6 @@ _SIGNATURES = {
     'gs_small_eval_poly': (_int, [_bytes, _u32, _bytes, _u32, _vp]),
     'gs_mimc_trace': (_int, [_vp, _bytes, _bytes, _u32, _u64, _vp]),
     'gs_mimc_constraints': (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _vp]),
-    'gs_merkle_plan_batch': (_int, [_u64, C.POINTER(_u64), _u32, C.POINTER(_u64), _u64, C.POINTER(_u64), C.POINTER(_u32), C.POINTER(_u32)]),
-    'gs_gather_abs16': (_int, [_vp, C.POINTER(_u64), _u64, _vp]),
     'gs_pseudorandom_indexes': (_int, [_bytes, _u32, _u32, _u64, _u32, C.POINTER(_u64)]),
     'gs_air_trace_segments': (_int, [_vp, C.POINTER(_u32), _u32, C.POINTER(_u32), _u32, _bytes, _u32, _u32, _u32, _bytes, C.POINTER(_u32), _u32, _bytes, _u64, _u64, _vp]),
     'gs_air_trace': (_int, [_vp, C.POINTER(_u32), _u32, _bytes, _u32, _u32, _u32, _bytes, C.POINTER(_u32), _u32, _bytes, _u64, _vp]),
@@ -109,7 +107,6 @@ class Backend:
         if rc != GS_OK or not ctx.value:
             raise GstarkError(f'gs_ctx_create(device={device}) failed with {rc}: no gfx950 device? (no CPU fallback)')
         self.ctx = ctx
-        self._deferred = None       # list of pending (addresses, fill, keep-alive) while queries are being batched
         self.device = device
 
     def close(self):
@@ -156,32 +153,6 @@ class Backend:
 
     def sync(self):
         self.call('gs_sync')
-
-    # ---- batched queries: collect device addresses of 16-byte words now, fetch them all with one kernel + one sync later
-    def begin_deferred(self):
-        if self._deferred is None:
-            self._deferred = []
-
-    def defer16(self, addrs, fill, keep):
-        """addrs: numpy uint64 array of device addresses of 16-byte words; fill(raw bytes) stores the fetched words into the
-        caller's placeholders; keep: objects whose device memory must stay alive until the flush."""
-        self._deferred.append((addrs, fill, keep))
-
-    def flush_deferred(self):
-        pending, self._deferred = self._deferred, None
-        if not pending:
-            return
-        import numpy as np
-        addrs = np.ascontiguousarray(np.concatenate([p[0] for p in pending]), dtype=np.uint64)
-        out = C.create_string_buffer(16 * len(addrs))
-        self.call('gs_gather_abs16', addrs.ctypes.data_as(C.POINTER(C.c_uint64)), len(addrs), C.cast(out, C.c_void_p))
-        raw, o = out.raw, 0
-        for a, fill, _ in pending:
-            fill(raw[o:o + 16 * len(a)])
-            o += 16 * len(a)
-
-    def discard_deferred(self):
-        self._deferred = None
 
     @property
     def stream(self):

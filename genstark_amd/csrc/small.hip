@@ -62,20 +62,23 @@ __global__ void k_gather_digests(const uint4 *__restrict__ leaves, const uint4 *
     out[t] = src[((e & ~(1ull << 63)) << 1) + (t & 1)];
 }
 
-// the authentication-path plan: fetch = requested leaves (request order) then the node columns in order
-static int plan_batch(uint64_t n, const uint64_t *idx_host, uint32_t count, std::vector<uint64_t> &fetch, std::vector<std::vector<uint64_t>> &cols) {
-    if (!gs_is_pow2(n) || n < 2 || count == 0) return GS_ERR_ARG;
+extern "C" int gs_merkle_prove_batch(gs_ctx *c, const void *leaves, const void *nodes, uint64_t n, const uint64_t *idx_host,
+                                     uint32_t count, uint8_t *values_out, uint32_t *ncols_out, uint32_t *col_lens_out,
+                                     uint8_t *nodes_out, uint64_t nodes_cap) {
+    if (!c || !leaves || !nodes || !idx_host || !values_out || !ncols_out || !col_lens_out || !nodes_out) return GS_ERR_ARG;
+    if (!gs_is_pow2(n) || n < 2 || count == 0) return gs_fail(c, GS_ERR_ARG, "merkle_prove_batch: n must be a power of two >= 2, count > 0");
     const int depth = gs_log2(n);
     const uint64_t NODE = 1ull << 63;
     std::vector<uint64_t> sorted(idx_host, idx_host + count);
     for (uint32_t i = 0; i < count; i++)
-        if (idx_host[i] >= n) return GS_ERR_ARG;
+        if (idx_host[i] >= n) return gs_fail(c, GS_ERR_ARG, "merkle_prove_batch: index %llu out of range", (unsigned long long)idx_host[i]);
     std::sort(sorted.begin(), sorted.end());
     for (uint32_t i = 1; i < count; i++)
-        if (sorted[i] == sorted[i - 1]) return GS_ERR_ARG;
-    fetch.assign(idx_host, idx_host + count);
+        if (sorted[i] == sorted[i - 1]) return gs_fail(c, GS_ERR_ARG, "merkle_prove_batch: repeating indexes");
+    // fetch list: first the requested leaves (request order), then the column entries in column-major order
+    std::vector<uint64_t> fetch(idx_host, idx_host + count);
     std::vector<uint64_t> cur;
-    cols.clear();
+    std::vector<std::vector<uint64_t>> cols;
     for (uint32_t i = 0; i < count;) {
         uint64_t e = sorted[i] & ~1ull;
         bool has0 = false, has1 = false;
@@ -96,55 +99,6 @@ static int plan_batch(uint64_t n, const uint64_t *idx_host, uint32_t count, std:
         }
         cur.swap(nxt);
     }
-    return GS_OK;
-}
-
-extern "C" int gs_merkle_plan_batch(uint64_t n, const uint64_t *idx_host, uint32_t count, uint64_t *fetch_out, uint64_t fetch_cap,
-                                    uint64_t *nfetch_out, uint32_t *ncols_out, uint32_t *col_lens_out) {
-    if (!idx_host || !fetch_out || !nfetch_out || !ncols_out || !col_lens_out) return GS_ERR_ARG;
-    std::vector<uint64_t> fetch;
-    std::vector<std::vector<uint64_t>> cols;
-    int rc = plan_batch(n, idx_host, count, fetch, cols);
-    if (rc) return rc;
-    for (auto &col : cols) fetch.insert(fetch.end(), col.begin(), col.end());
-    if (fetch.size() > fetch_cap) return GS_ERR_ARG;
-    memcpy(fetch_out, fetch.data(), fetch.size() * 8);
-    *nfetch_out = fetch.size();
-    *ncols_out = (uint32_t)cols.size();
-    for (size_t i = 0; i < cols.size(); i++) col_lens_out[i] = (uint32_t)cols[i].size();
-    return GS_OK;
-}
-
-__global__ void k_gather_abs16(const uint64_t *__restrict__ addrs, uint64_t count, uint4 *__restrict__ out) {
-    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < count; t += (uint64_t)gridDim.x * blockDim.x)
-        out[t] = *reinterpret_cast<const uint4 *>(addrs[t]);
-}
-
-extern "C" int gs_gather_abs16(gs_ctx *c, const uint64_t *addrs_host, uint64_t count, uint8_t *out_host) {
-    if (!c || (count && (!addrs_host || !out_host))) return GS_ERR_ARG;
-    if (!count) return GS_OK;
-    for (uint64_t i = 0; i < count; i++)
-        if (addrs_host[i] & 15) return gs_fail(c, GS_ERR_ARG, "gather_abs16: address %llu is not 16-byte aligned", (unsigned long long)i);
-    const uint64_t idx_bytes = (count * 8 + 255) & ~(uint64_t)255;
-    int rc = gs_stage_reserve(c, idx_bytes + count * 16);
-    if (rc) return rc;
-    memcpy(c->h_stage, addrs_host, count * 8);
-    uint8_t *d_out = (uint8_t *)c->h_stage_dev + idx_bytes;
-    hipLaunchKernelGGL(k_gather_abs16, dim3(gs_grid(count)), dim3(256), 0, c->stream, (const uint64_t *)c->h_stage_dev, count, (uint4 *)d_out);
-    GS_LAUNCH_CHECK(c);
-    GS_HIP(c, hipStreamSynchronize(c->stream));
-    memcpy(out_host, (uint8_t *)c->h_stage + idx_bytes, count * 16);
-    return GS_OK;
-}
-
-extern "C" int gs_merkle_prove_batch(gs_ctx *c, const void *leaves, const void *nodes, uint64_t n, const uint64_t *idx_host,
-                                     uint32_t count, uint8_t *values_out, uint32_t *ncols_out, uint32_t *col_lens_out,
-                                     uint8_t *nodes_out, uint64_t nodes_cap) {
-    if (!c || !leaves || !nodes || !idx_host || !values_out || !ncols_out || !col_lens_out || !nodes_out) return GS_ERR_ARG;
-    if (!gs_is_pow2(n) || n < 2 || count == 0) return gs_fail(c, GS_ERR_ARG, "merkle_prove_batch: n must be a power of two >= 2, count > 0");
-    std::vector<uint64_t> fetch;
-    std::vector<std::vector<uint64_t>> cols;
-    if (plan_batch(n, idx_host, count, fetch, cols)) return gs_fail(c, GS_ERR_ARG, "merkle_prove_batch: index out of range or repeating indexes");
     uint64_t total = 0;
     for (auto &col : cols) total += col.size();
     if (total > nodes_cap) return gs_fail(c, GS_ERR_ARG, "merkle_prove_batch: nodes_out too small (%llu digests needed)", (unsigned long long)total);

@@ -118,23 +118,8 @@ class Matrix:
         return self.backend.download(self.ptr, self.rowCount * self.colCount * ELEMENT_SIZE)
 
     def rowsToBuffers(self, indexes):
-        """LowDegreeProver.ts:53,214,217 — one Buffer (colCount*16 bytes) per requested row.  While the backend is batching
-        queries (Backend.begin_deferred) the returned list is a placeholder filled at the flush."""
-        indexes = list(indexes)
-        if self.backend._deferred is None or not indexes:
-            return self.backend.gather(self.ptr, self.colCount * ELEMENT_SIZE, indexes)
-        import numpy as np
-        if min(indexes) < 0 or max(indexes) >= self.rowCount:
-            raise GstarkError('row index out of range')
-        rec, words = self.colCount * ELEMENT_SIZE, self.colCount
-        rows = np.asarray(indexes, dtype=np.uint64) * np.uint64(rec) + np.uint64(self.ptr)
-        addrs = (rows[:, None] + np.arange(words, dtype=np.uint64)[None, :] * np.uint64(16)).ravel()
-        out = [None] * len(indexes)
-
-        def fill(raw):
-            out[:] = [raw[o:o + rec] for o in range(0, len(indexes) * rec, rec)]
-        self.backend.defer16(addrs, fill, (self,))
-        return out
+        """LowDegreeProver.ts:53,214,217 — one Buffer (colCount*16 bytes) per requested row."""
+        return self.backend.gather(self.ptr, self.colCount * ELEMENT_SIZE, list(indexes))
 
     def row(self, r):
         return Vector(self.backend, self.colCount, owner=self._owner, offset=self._offset + r * self.colCount * ELEMENT_SIZE)

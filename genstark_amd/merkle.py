@@ -129,9 +129,6 @@ class MerkleTree:
         if count == 0:
             return {'values': [], 'nodes': [], 'depth': self.depth}
         idx = (C.c_uint64 * count)(*indexes)
-        backend = self.hash.backend
-        if backend._deferred is not None:
-            return self._proveBatchDeferred(backend, idx, count)
         values = C.create_string_buffer(count * DIGEST_SIZE)
         cap = count * max(self.depth, 1)
         nodes = C.create_string_buffer(cap * DIGEST_SIZE)
@@ -148,37 +145,6 @@ class MerkleTree:
             o += k
         return {'values': [vraw[o:o + DIGEST_SIZE] for o in range(0, count * DIGEST_SIZE, DIGEST_SIZE)], 'nodes': out_nodes,
                 'depth': self.depth}
-
-    def _proveBatchDeferred(self, backend, idx, count):
-        """Plan now (host), fetch with every other pending query in ONE kernel at Backend.flush_deferred(): the returned lists
-        are placeholders that the flush fills in place."""
-        import numpy as np
-        n = self.values.length
-        cap = count * (self.depth + 1)
-        fetch = (C.c_uint64 * cap)()
-        nfetch, ncols = C.c_uint64(), C.c_uint32()
-        col_lens = (C.c_uint32 * count)()
-        if backend.lib.gs_merkle_plan_batch(n, idx, count, fetch, cap, C.byref(nfetch), C.byref(ncols), col_lens):
-            raise GstarkError('gs_merkle_plan_batch failed: invalid or repeating indexes')
-        nf = nfetch.value
-        codes = np.frombuffer(fetch, dtype=np.uint64, count=nf)
-        index = codes & np.uint64((1 << 63) - 1)
-        base = np.where(codes >> np.uint64(63), np.uint64(self.nodes.ptr), np.uint64(self.values.ptr)) + index * np.uint64(DIGEST_SIZE)
-        addrs = np.empty(2 * nf, dtype=np.uint64)
-        addrs[0::2] = base
-        addrs[1::2] = base + np.uint64(16)
-        lens = col_lens[:ncols.value]
-        values, out_nodes = [None] * count, [[None] * k for k in lens]
-
-        def fill(raw):
-            digests = [raw[o:o + DIGEST_SIZE] for o in range(0, nf * DIGEST_SIZE, DIGEST_SIZE)]
-            values[:] = digests[:count]
-            o = count
-            for col, k in zip(out_nodes, lens):
-                col[:] = digests[o:o + k]
-                o += k
-        backend.defer16(addrs, fill, (self,))
-        return {'values': values, 'nodes': out_nodes, 'depth': self.depth}
 
     @staticmethod
     def verifyBatch(root, indexes, proof, hash_):

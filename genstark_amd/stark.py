@@ -57,8 +57,6 @@ class Stark:
         self.logger = logger or NoopLogger()
         # issue trace-independent device work before the host-side trace recurrence (same proof bytes); GSTARK_PREFETCH=0 disables
         self.prefetch = os.environ.get('GSTARK_PREFETCH', '1') != '0'
-        # answer all queries with one device gather at the end of prove() (same proof bytes); GSTARK_BATCH_QUERIES=0 disables
-        self.batchQueries = os.environ.get('GSTARK_BATCH_QUERIES', '1') != '0'
 
     @property
     def securityLevel(self):  # :62-77
@@ -111,18 +109,7 @@ class Stark:
         lCombination = LinearCombination(eTree.root, cPoly.compositionDegree, cPoly.coefficientCount, context)
         lEvaluations = lCombination.computeMany(cEvaluations, pEvaluations, sEvaluations)
         log('Combined P(x) and S(x) evaluations with C(x) evaluations')
-        # 7 ----- low-degree proof.  From here on the prover only answers queries (36 proveBatch / rowsToBuffers calls at 2^20
-        # steps): they are planned as they come and fetched from the device together, one kernel and one sync, at the end
-        batching = self.batchQueries and not hasattr(field, 'comm')
-        if batching:
-            field.backend.begin_deferred()
-        try:
-            return self._finishProof(context, field, cPoly, lEvaluations, eTree, eVectors, evaluationDomainSize, log, batching)
-        except BaseException:
-            field.backend.discard_deferred()
-            raise
-
-    def _finishProof(self, context, field, cPoly, lEvaluations, eTree, eVectors, evaluationDomainSize, log, batching):
+        # 7 ----- low-degree proof
         try:
             ldLogger = self.logger.sub('Computing low degree proof')
             ldProver = LowDegreeProver(self.indexGenerator, self.hash, context, ldLogger)
@@ -137,8 +124,6 @@ class Stark:
         eValues = self.mergeValues(eVectors, augmentedPositions)
         eProof = eTree.proveBatch(augmentedPositions)
         eProof['values'] = eValues
-        if batching:
-            field.backend.flush_deferred()
         log(f'Computed {len(positions)} evaluation spot checks')
         self.logger.done(log, 'STARK computed')
         return {'evRoot': eTree.root, 'evProof': eProof, 'ldProof': ldProof, 'iShapes': context.inputShapes}

@@ -179,18 +179,6 @@ int gs_merkle_prove_batch(gs_ctx *ctx, const void *leaves, const void *nodes, ui
 int gs_small_interpolate(const uint8_t *xs_host, const uint8_t *ys_host, uint32_t n, uint8_t *coeffs_out);
 int gs_small_eval_poly(const uint8_t *poly_host, uint32_t len, const uint8_t *xs_host, uint32_t m, uint8_t *out_host);
 
-/* ---- batched queries --------------------------------------------------------------------------------------------------
- * A prover answers its queries at the very end (LowDegreeProver.ts:209-217 runs after the recursion returns; lib/Stark.ts:
- * 146-152): 36 proveBatch / rowsToBuffers calls per 2^20-step proof, each a launch + a synchronisation when done one by
- * one.  The two functions below let a caller plan every batch proof on the host, collect the device addresses of all the
- * 16-byte words it needs (digests = 2 words, FRI rows = 4, elements = 1) and fetch them with ONE kernel and ONE sync.
- * gs_merkle_plan_batch (host only): the plan gs_merkle_prove_batch follows — fetch_out[0..count) are the requested leaves,
- * then the node columns in order; an entry is a leaf index, or a heap node index with bit 63 set. */
-int gs_merkle_plan_batch(uint64_t n, const uint64_t *idx_host, uint32_t count, uint64_t *fetch_out, uint64_t fetch_cap,
-                         uint64_t *nfetch_out, uint32_t *ncols_out, uint32_t *col_lens_out /* count entries */);
-/* out_host[16*i .. 16*i+16) = the 16 bytes at DEVICE address addrs_host[i] (16-byte aligned). */
-int gs_gather_abs16(gs_ctx *ctx, const uint64_t *addrs_host, uint64_t count, uint8_t *out_host);
-
 /* ---- host helper: Fiat-Shamir query positions -----------------------------------------------------------------------
  * lib/components/QueryIndexGenerator.ts:39-67 (getPseudorandomIndexes + its sha256-of-a-bigint helper), host only, no
  * context: state = sha256(seed); candidate i = sha256(Buffer.from((state + i).toString(16), 'hex')) mod max — the

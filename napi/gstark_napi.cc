@@ -81,8 +81,6 @@ const FnDesc kFns[] = {
     {"gs_air_constraints", "cwibiiiipuupxip"},
     {"gs_small_interpolate", "bbio"},
     {"gs_pseudorandom_indexes", "biiuio"},
-    {"gs_merkle_plan_batch", "uxiouooo"},
-    {"gs_gather_abs16", "cxuo"},
     {"gs_small_eval_poly", "bibio"},
 };
 

@@ -612,75 +612,3 @@ int gs_pseudorandom_indexes(const uint8_t *seed, uint32_t seed_len, uint32_t cou
     return found == count ? GS_OK : GS_ERR_ARG;
 }
 #undef SHA256
-
-/* include/gstark.h gs_merkle_plan_batch: the same walk as gs_merkle_prove_batch above, emitting WHICH digests it would copy
- * (leaf index, or heap node index with bit 63 set) instead of copying them */
-int gs_merkle_plan_batch(uint64_t n, const uint64_t *idx, uint32_t count, uint64_t *fetch_out, uint64_t fetch_cap, uint64_t *nfetch_out,
-                         uint32_t *ncols_out, uint32_t *col_lens) {
-    if (!idx || !fetch_out || !nfetch_out || !ncols_out || !col_lens || !is_pow2(n) || n < 2 || !count) return GS_ERR_ARG;
-    const uint64_t NODE = 1ull << 63;
-    int depth = 0;
-    while ((1ull << depth) < n) depth++;
-    uint64_t *sorted = (uint64_t *)malloc(count * sizeof(uint64_t) * 4);
-    if (!sorted) return GS_ERR_OOM;
-    uint64_t *norm = sorted + count, *cur = norm + count, *nxt = cur + count;
-    for (uint32_t i = 0; i < count; i++) {
-        if (idx[i] >= n) { free(sorted); return GS_ERR_ARG; }
-        sorted[i] = idx[i];
-    }
-    qsort(sorted, count, sizeof(uint64_t), cmp_u64);
-    uint32_t ncols = 0;
-    for (uint32_t i = 0; i < count; i++) {
-        if (i && sorted[i] == sorted[i - 1]) { free(sorted); return GS_ERR_ARG; }
-        uint64_t e = sorted[i] & ~1ull;
-        if (!ncols || norm[ncols - 1] != e) norm[ncols++] = e;
-    }
-    uint64_t *cols = (uint64_t *)malloc((size_t)ncols * depth * sizeof(uint64_t));
-    if (!cols) { free(sorted); return GS_ERR_OOM; }
-    for (uint32_t i = 0; i < ncols; i++) col_lens[i] = 0;
-#define PUSHC(col, code) do { cols[(size_t)(col) * depth + col_lens[col]] = (code); col_lens[col]++; } while (0)
-    uint32_t pos = 0;
-    for (uint32_t i = 0; i < ncols; i++) {
-        uint64_t e = norm[i];
-        int has0 = 0, has1 = 0;
-        while (pos < count && (sorted[pos] & ~1ull) == e) { if (sorted[pos] & 1) has1 = 1; else has0 = 1; pos++; }
-        if (has0 && !has1) PUSHC(i, e + 1);
-        else if (!has0 && has1) PUSHC(i, e);
-        cur[i] = (e + n) >> 1;
-    }
-    uint32_t len = ncols;
-    for (int d = depth - 1; d > 0; d--) {
-        uint32_t nl = 0;
-        for (uint32_t i = 0; i < len; i++) {
-            uint64_t sib = cur[i] ^ 1;
-            if (i + 1 < len && cur[i + 1] == sib) i++;
-            else PUSHC(i, sib | NODE);
-            nxt[nl++] = sib >> 1;
-        }
-        uint64_t *t = cur; cur = nxt; nxt = t;
-        len = nl;
-    }
-#undef PUSHC
-    uint64_t total = count;
-    for (uint32_t i = 0; i < ncols; i++) total += col_lens[i];
-    int rc = GS_OK;
-    if (total > fetch_cap) rc = GS_ERR_ARG;
-    else {
-        uint64_t o = 0;
-        for (uint32_t i = 0; i < count; i++) fetch_out[o++] = idx[i];
-        for (uint32_t i = 0; i < ncols; i++) for (uint32_t k = 0; k < col_lens[i]; k++) fetch_out[o++] = cols[(size_t)i * depth + k];
-        *nfetch_out = total;
-        *ncols_out = ncols;
-    }
-    free(cols);
-    free(sorted);
-    return rc;
-}
-int gs_gather_abs16(gs_ctx *c, const uint64_t *addrs, uint64_t count, uint8_t *out) {
-    if (count && (!addrs || !out)) return GS_ERR_ARG;
-    for (uint64_t i = 0; i < count; i++) {
-        if (addrs[i] & 15) return fail(c, GS_ERR_ARG, "gather_abs16: address is not 16-byte aligned");
-        memcpy(out + 16 * i, (const void *)(uintptr_t)addrs[i], 16);
-    }
-    return GS_OK;
-}
