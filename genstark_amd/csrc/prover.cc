@@ -1,0 +1,670 @@
+// prover.cc — the whole of Stark.prove() (lib/Stark.ts:81-163) as NATIVE host code above the C ABI.
+//
+// The Python package mirrors lib/Stark.ts and lib/components/*.ts call by call (genstark_amd/stark.py, components/); that
+// mirror is the readable reference for the sequence below and stays the thing the parity tests compare against.  This file
+// is the same sequence — context set-up, trace, P(x), low-degree extension, evaluation tree, CompositionPolynomial
+// (CompositionPolynomial.ts:29-146, BoundaryConstraints.ts:15-95, ZeroPolynomial.ts:36-44), LinearCombination (:36-64),
+// LowDegreeProver (:39-68, :176-252), QueryIndexGenerator, the spot checks and Serializer.serializeProof (:35-79) — without an
+// interpreter between two launches: ~250 ABI calls per proof issue back to back, the few host-side steps (Fiat-Shamir
+// hashing of roots, Lagrange interpolation of <= 256 points, the authentication-path plans) run on native limbs.
+//
+// It is written against include/gstark.h ONLY (plain C++, no HIP): gs_prover_bind() resolves the entry points from whatever
+// implementation of the ABI the caller loaded, so the product binds libgstark_hip.so and the CPU tests bind the oracle's
+// implementation, exactly like the Python mirror.  Output: the serialized proof (the bytes Serializer.serializeProof gives).
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gstark.h"
+#include "host_field.h"
+#include "host_sha256.h"
+
+namespace {
+
+// ---- the slice of the ABI this driver uses, resolved at bind time ------------------------------------------------------
+#define GS_API_LIST(X)                                                                                                        \
+    X(gs_alloc) X(gs_free) X(gs_upload) X(gs_download) X(gs_gather) X(gs_last_error) X(gs_power_series) X(gs_vec_add) X(gs_vec_mul) \
+    X(gs_vec_sub_scalar) X(gs_vec_div) X(gs_combine_many) X(gs_pluck) X(gs_transpose_vector) X(gs_sub_matrix_from_vectors)     \
+    X(gs_eval_polys_at_roots) X(gs_interpolate_roots) X(gs_interpolate_quartic_domain) X(gs_eval_quartic_batch)                \
+    X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
+    X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
+    X(gs_air_trace_segments) X(gs_air_constraints)
+struct Api {
+#define X(name) decltype(&::name) name = nullptr;
+    GS_API_LIST(X)
+#undef X
+} A;
+bool g_bound = false;
+
+struct Fail {
+    int code;
+    std::string msg;
+};
+[[noreturn]] void fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Fail{code, buf};
+}
+
+typedef hu128 F;
+const uint64_t DIGEST = 32, ELEM = 16, MAX_ARRAY = 256;
+typedef std::vector<uint8_t> Bytes;
+
+struct Ctx {
+    gs_ctx *c;
+    void check(int rc, const char *what) {
+        if (rc) fail(rc, "%s: %s", what, c ? A.gs_last_error(c) : "error");
+    }
+};
+
+// device block owned for the duration of a proof (gs_free parks it in the context's cache: no synchronisation)
+struct Buf {
+    Ctx *x = nullptr;
+    void *p = nullptr;
+    Buf() {}
+    Buf(Ctx &cx, uint64_t bytes) : x(&cx) { cx.check(A.gs_alloc(cx.c, bytes ? bytes : 16, &p), "gs_alloc"); }
+    Buf(const Buf &) = delete;
+    Buf &operator=(const Buf &) = delete;
+    Buf(Buf &&o) noexcept : x(o.x), p(o.p) { o.p = nullptr; }
+    Buf &operator=(Buf &&o) noexcept {
+        if (this != &o) { release(); x = o.x; p = o.p; o.p = nullptr; }
+        return *this;
+    }
+    void release() { if (p) { A.gs_free(x->c, p); p = nullptr; } }
+    ~Buf() { release(); }
+    uint8_t *at(uint64_t byte_offset) const { return (uint8_t *)p + byte_offset; }
+};
+
+void le16(F v, uint8_t out[16]) { memcpy(out, &v, 16); }
+F from16(const uint8_t *b) { F v; memcpy(&v, b, 16); return v; }
+
+// ---- galois prng (genstark_amd/field.py: prng — restated) and the index generator -----------------
+F digest_mod_p(const uint8_t d[32]) {          // 256-bit big-endian integer mod p
+    F hi = 0, lo = 0;
+    for (int i = 0; i < 16; i++) hi = (hi << 8) | d[i];
+    for (int i = 16; i < 32; i++) lo = (lo << 8) | d[i];
+    return hf_reduce(hi, lo);
+}
+std::vector<F> prng_many(const Bytes &seed, size_t count) {
+    std::vector<F> out(count);
+    uint8_t st[32], msg[32];
+    host_sha256(seed.data(), seed.size(), st);
+    for (size_t i = 0; i < count; i++) {
+        out[i] = digest_mod_p(st);
+        int n = host_bigint_bytes(st, 32, msg);
+        host_sha256(msg, (size_t)n, st);
+    }
+    return out;
+}
+F prng_one(const Bytes &seed) {
+    uint8_t st[32];
+    host_sha256(seed.data(), seed.size(), st);
+    return digest_mod_p(st);
+}
+std::vector<uint64_t> query_indexes(const Bytes &seed, uint32_t count, uint64_t max, uint32_t exclude) {
+    uint64_t max_count = exclude ? max - max / exclude : max;
+    if (max_count < count) fail(GS_ERR_ARG, "Cannot select %u unique pseudorandom indexes from %llu values", count, (unsigned long long)max);
+    std::vector<uint64_t> out(count ? count : 1);
+    if (A.gs_pseudorandom_indexes(seed.data(), (uint32_t)seed.size(), count, max, exclude, out.data()))
+        fail(GS_ERR_ARG, "Could not generate %u pseudorandom indexes", count);
+    out.resize(count);
+    return out;
+}
+
+// ---- Merkle batch proofs and the wire format (lib/Serializer.ts:35-79, lib/utils/serialization.ts) ------------------
+struct MerkleProof {
+    std::vector<Bytes> values;
+    std::vector<std::vector<Bytes>> nodes;
+    uint8_t depth = 0;
+};
+void write_array(Bytes &out, const std::vector<Bytes> &a) {
+    if (a.empty()) fail(GS_ERR_ARG, "Array cannot be zero-length");
+    if (a.size() > MAX_ARRAY) fail(GS_ERR_ARG, "Array length (%zu) cannot exceed 256", a.size());
+    out.push_back(a.size() == MAX_ARRAY ? 0 : (uint8_t)a.size());
+    for (auto &v : a) out.insert(out.end(), v.begin(), v.end());
+}
+void write_matrix(Bytes &out, const std::vector<std::vector<Bytes>> &m, uint64_t leaf_size) {
+    if (m.size() > MAX_ARRAY) fail(GS_ERR_ARG, "Matrix column count (%zu) cannot exceed 256", m.size());
+    out.push_back(m.size() == MAX_ARRAY ? 0 : (uint8_t)m.size());
+    for (auto &col : m) {
+        if (col.size() >= 128) fail(GS_ERR_ARG, "Matrix column length (%zu) cannot exceed 127", col.size());
+        uint8_t type = (!col.empty() && col[0].size() == leaf_size) ? 1 : 0;
+        out.push_back((uint8_t)((col.size() << 1) | type));
+    }
+    for (auto &col : m)
+        for (auto &v : col) out.insert(out.end(), v.begin(), v.end());
+}
+void write_merkle_proof(Bytes &out, const MerkleProof &p, uint64_t leaf_size) {
+    write_array(out, p.values);
+    write_matrix(out, p.nodes, leaf_size);
+    out.push_back(p.depth);
+}
+
+struct Tree {
+    Buf leaves, nodes;   // digests; nodes in heap order
+    uint64_t n = 0;
+    Bytes root;
+};
+Tree build_tree(Ctx &x, int alg, Buf &&leaves, uint64_t n) {
+    Tree t;
+    t.n = n;
+    t.leaves = std::move(leaves);
+    t.nodes = Buf(x, n * DIGEST);
+    x.check(A.gs_merkle_build(x.c, (gs_hash_alg)alg, t.leaves.p, n, t.nodes.p), "gs_merkle_build");
+    t.root.resize(DIGEST);
+    x.check(A.gs_download(x.c, t.root.data(), t.nodes.at(DIGEST), DIGEST), "gs_download(root)");
+    return t;
+}
+MerkleProof prove_batch(Ctx &x, const Tree &t, const std::vector<uint64_t> &idx) {
+    MerkleProof mp;
+    int depth = 0;
+    while ((1ull << depth) < t.n) depth++;
+    mp.depth = (uint8_t)depth;
+    const uint32_t count = (uint32_t)idx.size();
+    if (!count) return mp;
+    const uint64_t cap = (uint64_t)count * (depth ? depth : 1);
+    Bytes values(count * DIGEST), nodes(cap * DIGEST);
+    std::vector<uint32_t> lens(count);
+    uint32_t ncols = 0;
+    x.check(A.gs_merkle_prove_batch(x.c, t.leaves.p, t.nodes.p, t.n, idx.data(), count, values.data(), &ncols, lens.data(), nodes.data(), cap),
+            "gs_merkle_prove_batch");
+    for (uint32_t i = 0; i < count; i++) mp.values.emplace_back(values.begin() + i * DIGEST, values.begin() + (i + 1) * DIGEST);
+    uint64_t o = 0;
+    for (uint32_t cidx = 0; cidx < ncols; cidx++) {
+        mp.nodes.emplace_back();
+        for (uint32_t k = 0; k < lens[cidx]; k++, o++) mp.nodes.back().emplace_back(nodes.begin() + o * DIGEST, nodes.begin() + (o + 1) * DIGEST);
+    }
+    return mp;
+}
+std::vector<Bytes> gather(Ctx &x, const void *src, uint64_t rec, const std::vector<uint64_t> &idx) {
+    std::vector<Bytes> out;
+    if (idx.empty()) return out;
+    Bytes raw(idx.size() * rec);
+    x.check(A.gs_gather(x.c, src, rec, idx.data(), idx.size(), raw.data()), "gs_gather");
+    for (size_t i = 0; i < idx.size(); i++) out.emplace_back(raw.begin() + i * rec, raw.begin() + (i + 1) * rec);
+    return out;
+}
+std::vector<uint64_t> unique_in_order(const std::vector<uint64_t> &v) {
+    std::vector<uint64_t> out;
+    std::map<uint64_t, bool> seen;
+    for (uint64_t e : v)
+        if (!seen.count(e)) { seen[e] = true; out.push_back(e); }
+    return out;
+}
+
+}  // namespace
+
+extern "C" {
+
+struct gs_assertion {
+    uint64_t step;
+    uint32_t reg;
+    uint8_t value[16];
+};
+
+// What the AIR module contributes (lib/Stark.ts:35-58: `air`): counts, degrees and the two device routines.
+struct gs_prover_air {
+    uint32_t kind;               // 0 = MiMC (gs_mimc_trace / gs_mimc_constraints), 1 = register-machine programs (gs_air_*)
+    uint32_t registers;          // trace registers
+    uint32_t nconstraints;
+    const uint32_t *degrees;     // constraint degrees
+    // kind 0
+    uint8_t seed[16];
+    const uint8_t *round_constants;   // host, nrc * 16
+    uint32_t nrc;
+    const void *k_table;         // device: the cyclic register over the composition domain
+    uint64_t k_len;
+    // kind 1
+    const uint32_t *t_code; uint32_t t_ninstr;          // transition program
+    const uint32_t *i_code; uint32_t i_ninstr;          // init program (segments only, may be 0)
+    const uint32_t *e_code; uint32_t e_ninstr;          // constraint evaluator
+    const uint8_t *consts; uint32_t nconsts; uint32_t vm_regs;
+    const uint8_t *static_values; const uint32_t *static_periods; uint32_t nstatic;   // host, for the trace
+    const void *static_tables; const uint64_t *static_lens;                           // device + host lens, for the evaluator
+    const uint8_t *first_rows; uint64_t segments; uint64_t segment_len;               // segments = 0: one serial trace
+};
+
+struct gs_prover_job {
+    uint64_t steps;
+    uint32_t extension_factor, exe_query_count, fri_query_count;
+    int32_t hash_alg;
+    uint8_t root_of_unity[16];   // primitive (steps*extension_factor)-th root: galois getRootOfUnity, computed by the caller
+    const gs_assertion *assertions;
+    uint32_t nassertions;
+    struct gs_prover_air air;
+};
+
+int gs_prover_bind(void *dl_handle) {
+    if (!dl_handle) return GS_ERR_ARG;
+#define X(name)                                             \
+    A.name = (decltype(A.name))dlsym(dl_handle, #name);     \
+    if (!A.name) return GS_ERR_UNSUPPORTED;
+    GS_API_LIST(X)
+#undef X
+    g_bound = true;
+    return GS_OK;
+}
+
+static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out);
+
+// Serialized proof into out[0..cap); *len receives the size (also when cap is too small: GS_ERR_ARG then).
+int gs_prover_prove(gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, uint64_t cap, uint64_t *len, char *err, uint64_t errcap) {
+    if (!g_bound) return GS_ERR_UNSUPPORTED;
+    if (!ctx || !job || !len) return GS_ERR_ARG;
+    try {
+        Ctx x{ctx};
+        Bytes proof;
+        prove_impl(x, *job, proof);
+        *len = proof.size();
+        if (proof.size() > cap || !out) return GS_ERR_ARG;
+        memcpy(out, proof.data(), proof.size());
+        return GS_OK;
+    } catch (const Fail &f) {
+        if (err && errcap) snprintf(err, (size_t)errcap, "%s", f.msg.c_str());
+        return f.code ? f.code : GS_ERR_ARG;
+    } catch (const std::exception &e) {
+        if (err && errcap) snprintf(err, (size_t)errcap, "%s", e.what());
+        return GS_ERR_OOM;
+    }
+}
+
+}  // extern "C"
+
+namespace {
+
+struct Layer {           // one FRI layer: the tree / rows it queries and the child it produced
+    Tree *pTree;         // tree over polyValues rows
+    const Buf *polyValues;
+    uint64_t rows;       // rows of polyValues (4 columns)
+    Tree cTree;          // tree over the next layer's rows
+    Buf newPolyValues;
+    uint64_t column_length;
+};
+
+}  // namespace
+
+static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
+    const gs_prover_air &air = job.air;
+    const uint64_t T = job.steps, E = job.extension_factor, N = T * E;
+    const uint32_t R = air.registers;
+    const int alg = job.hash_alg;
+    if (!T || (T & (T - 1)) || !E || (E & (E - 1)) || !R || !air.nconstraints || !job.nassertions) fail(GS_ERR_ARG, "invalid job");
+    uint32_t max_degree = 1;
+    for (uint32_t i = 0; i < air.nconstraints; i++) max_degree = std::max(max_degree, air.degrees[i]);
+    uint64_t cf = 1;
+    while (cf < max_degree) cf <<= 1;                              // compositionFactor = 2^ceil(log2(max degree))
+    const uint64_t Nc = T * cf;
+    if (E < 2 * cf) fail(GS_ERR_ARG, "extension factor must be at least 2x the composition factor");
+    const F omega = from16(job.root_of_unity);
+    const F comp_rou = hf_pow(omega, (hu128)(N / Nc)), exec_rou = hf_pow(omega, (hu128)E);
+    uint8_t s16[16], s16b[16];
+
+    // 1 ----- evaluation context (lib/Stark.ts:92-94): the domains
+    Buf evalDomain(x, N * ELEM);
+    le16(omega, s16);
+    x.check(A.gs_power_series(x.c, s16, N, evalDomain.p), "gs_power_series(evaluation domain)");
+
+    // work of CompositionPolynomial.evaluateAll that does not depend on the trace goes first: the device computes it while
+    // the host core below runs the trace recurrence (same values, issue order only)
+    const uint64_t combination_degree = cf * T;                                        // CompositionPolynomial.ts:196-204
+    const uint64_t composition_degree = std::max(combination_degree - T, T);
+    Buf zInverses(x, N * ELEM);
+    {
+        Buf xToTheSteps(x, N * ELEM), num(x, N * ELEM), den(x, N * ELEM);
+        x.check(A.gs_pluck(x.c, evalDomain.p, N, T, N, xToTheSteps.p), "gs_pluck");                    // ZeroPolynomial.ts:40
+        le16(1, s16);
+        x.check(A.gs_vec_sub_scalar(x.c, xToTheSteps.p, s16, N, num.p), "gs_vec_sub_scalar");
+        le16(hf_pow(omega, (hu128)((T - 1) * E)), s16);                                                // :21-23
+        x.check(A.gs_vec_sub_scalar(x.c, evalDomain.p, s16, N, den.p), "gs_vec_sub_scalar");
+        x.check(A.gs_vec_div(x.c, den.p, num.p, N, zInverses.p), "gs_vec_div(1/Z)");                   // CompositionPolynomial.ts:117
+    }
+    Buf psbPowers;                                                 // x^(compositionDegree - T) over the evaluation domain
+    const uint64_t b_inc = composition_degree - T;
+    if (b_inc > 0) {
+        psbPowers = Buf(x, N * ELEM);
+        le16(hf_pow(omega, (hu128)b_inc), s16);
+        x.check(A.gs_power_series(x.c, s16, N, psbPowers.p), "gs_power_series(psb)");
+    }
+
+    // 2 ----- execution trace (:97) and the assertions it must satisfy (:356-375)
+    Buf trace(x, (uint64_t)R * T * ELEM);
+    if (air.kind == 0)
+        x.check(A.gs_mimc_trace(x.c, air.seed, air.round_constants, air.nrc, T, trace.p), "gs_mimc_trace");
+    else if (air.segments)
+        x.check(A.gs_air_trace_segments(x.c, air.t_code, air.t_ninstr, air.i_code, air.i_ninstr, air.consts, air.nconsts, air.vm_regs, R,
+                                        air.static_values, air.static_periods, air.nstatic, air.first_rows, air.segments, air.segment_len, trace.p),
+                "gs_air_trace_segments");
+    else
+        x.check(A.gs_air_trace(x.c, air.t_code, air.t_ninstr, air.consts, air.nconsts, air.vm_regs, R, air.static_values, air.static_periods,
+                               air.nstatic, air.first_rows, T, trace.p), "gs_air_trace");
+    {
+        std::vector<uint64_t> pos;
+        for (uint32_t i = 0; i < job.nassertions; i++) {
+            const gs_assertion &a = job.assertions[i];
+            if (a.reg >= R) fail(GS_ERR_ARG, "Invalid assertion: register %u is outside of register bank", a.reg);
+            if (a.step >= T) fail(GS_ERR_ARG, "Invalid assertion: step %llu is outside of execution trace", (unsigned long long)a.step);
+            pos.push_back((uint64_t)a.reg * T + a.step);
+        }
+        auto got = gather(x, trace.p, ELEM, pos);
+        for (uint32_t i = 0; i < job.nassertions; i++)
+            if (memcmp(got[i].data(), job.assertions[i].value, 16))
+                fail(GS_ERR_ARG, "Assertion at step %llu, register %u conflicts with execution trace", (unsigned long long)job.assertions[i].step,
+                     job.assertions[i].reg);
+    }
+
+    // 3 ----- P(x) and its low-degree extension (:106-109)
+    Buf pPolys(x, (uint64_t)R * T * ELEM), pEval(x, (uint64_t)R * N * ELEM);
+    le16(exec_rou, s16);
+    x.check(A.gs_interpolate_roots(x.c, trace.p, R, s16, T, pPolys.p), "gs_interpolate_roots(trace)");
+    trace.release();
+    le16(omega, s16);
+    x.check(A.gs_eval_polys_at_roots(x.c, pPolys.p, R, T, s16, N, pEval.p), "gs_eval_polys_at_roots(P)");
+    std::vector<const void *> pRows(R);
+    for (uint32_t r = 0; r < R; r++) pRows[r] = pEval.at((uint64_t)r * N * ELEM);
+
+    // 4 ----- evaluation Merkle tree (:113-118)
+    Tree eTree;
+    {
+        Buf hashed(x, N * DIGEST);
+        x.check(A.gs_hash_merge_rows(x.c, (gs_hash_alg)alg, pRows.data(), R, N, hashed.p), "gs_hash_merge_rows");
+        eTree = build_tree(x, alg, std::move(hashed), N);
+    }
+
+    // 5 ----- composition polynomial (CompositionPolynomial.ts:29-146)
+    // boundary constraints per asserted register, in order of first appearance (BoundaryConstraints.ts:15-45)
+    struct RegData { uint32_t reg; std::vector<F> xs, ys; };
+    std::vector<RegData> rdata;
+    for (uint32_t i = 0; i < job.nassertions; i++) {
+        const gs_assertion &a = job.assertions[i];
+        RegData *d = nullptr;
+        for (auto &e : rdata) if (e.reg == a.reg) d = &e;
+        if (!d) { rdata.push_back(RegData{a.reg, {}, {}}); d = &rdata.back(); }
+        d->xs.push_back(hf_pow(omega, (hu128)(a.step * E)));
+        d->ys.push_back(from16(a.value));
+    }
+    const uint32_t bcount = (uint32_t)rdata.size();
+    // constraint groups by degree, in order of first appearance (:206-225)
+    std::vector<std::pair<uint64_t, std::vector<uint32_t>>> groups;
+    for (uint32_t i = 0; i < air.nconstraints; i++) {
+        uint64_t d = (uint64_t)air.degrees[i] * T;
+        bool found = false;
+        for (auto &g : groups) if (g.first == d) { g.second.push_back(i); found = true; }
+        if (!found) groups.push_back({d, {i}});
+    }
+    uint32_t dcount = air.nconstraints;
+    for (auto &g : groups) if (g.first < combination_degree) dcount += (uint32_t)g.second.size();
+    uint32_t bcoef = bcount * (composition_degree > T ? 2 : 1);
+    std::vector<F> coefficients = prng_many(eTree.root, dcount + bcoef);
+    auto coeff_bytes = [&](size_t from, size_t count) {
+        Bytes b(count * 16);
+        for (size_t i = 0; i < count; i++) le16(coefficients[from + i], b.data() + 16 * i);
+        return b;
+    };
+
+    Buf cEval(x, N * ELEM);
+    {
+        // 5.1 transition constraints over the composition domain (:76).  P over that domain is every (N/Nc)-th element of the
+        // extension just computed
+        Buf pComp(x, (uint64_t)R * Nc * ELEM), q(x, (uint64_t)air.nconstraints * Nc * ELEM);
+        for (uint32_t r = 0; r < R; r++)
+            x.check(A.gs_pluck(x.c, pRows[r], N, N / Nc, Nc, pComp.at((uint64_t)r * Nc * ELEM)), "gs_pluck(P over the composition domain)");
+        if (air.kind == 0)
+            x.check(A.gs_mimc_constraints(x.c, pComp.p, Nc, Nc / T, air.k_table, air.k_len, q.p), "gs_mimc_constraints");
+        else
+            x.check(A.gs_air_constraints(x.c, air.e_code, air.e_ninstr, air.consts, air.nconsts, air.vm_regs, R, air.nconstraints, pComp.p, Nc,
+                                         Nc / T, air.static_tables, air.static_lens, air.nstatic, q.p), "gs_air_constraints");
+        pComp.release();
+        // 5.2 degree adjustment (:83-101) and 5.3 merge + extension (:103-111)
+        std::vector<const void *> qa;
+        for (uint32_t i = 0; i < air.nconstraints; i++) qa.push_back(q.at((uint64_t)i * Nc * ELEM));
+        std::vector<Buf> adjusted;
+        for (auto &g : groups) {
+            if (g.first == combination_degree) continue;
+            Buf powers(x, Nc * ELEM);
+            le16(hf_pow(comp_rou, (hu128)(combination_degree - g.first)), s16);
+            x.check(A.gs_power_series(x.c, s16, Nc, powers.p), "gs_power_series(q powers)");
+            for (uint32_t i : g.second) {
+                adjusted.emplace_back(x, Nc * ELEM);
+                x.check(A.gs_vec_mul(x.c, qa[i], powers.p, Nc, adjusted.back().p), "gs_vec_mul");
+                qa.push_back(adjusted.back().p);
+            }
+        }
+        Buf qc(x, Nc * ELEM), qcPoly(x, Nc * ELEM), qe(x, N * ELEM);
+        Bytes dco = coeff_bytes(0, dcount);
+        x.check(A.gs_combine_many(x.c, qa.data(), dco.data(), dcount, Nc, qc.p), "gs_combine_many(Q)");
+        le16(comp_rou, s16);
+        x.check(A.gs_interpolate_roots(x.c, qc.p, 1, s16, Nc, qcPoly.p), "gs_interpolate_roots(Q)");
+        le16(omega, s16);
+        x.check(A.gs_eval_polys_at_roots(x.c, qcPoly.p, 1, Nc, s16, N, qe.p), "gs_eval_polys_at_roots(Q)");
+        // 5.4 D(x) = Q(x) / Z(x) (:113-121)
+        Buf dEval(x, N * ELEM);
+        x.check(A.gs_vec_mul(x.c, qe.p, zInverses.p, N, dEval.p), "gs_vec_mul(D)");
+        // 5.5 boundary constraints (BoundaryConstraints.ts:71-95)
+        size_t ilen = 0, zlen = 0;
+        std::vector<std::vector<F>> ipolys, zpolys;
+        for (auto &d : rdata) {
+            const uint32_t m = (uint32_t)d.xs.size();
+            Bytes xs(m * 16), ys(m * 16), co(m * 16);
+            for (uint32_t i = 0; i < m; i++) { le16(d.xs[i], xs.data() + 16 * i); le16(d.ys[i], ys.data() + 16 * i); }
+            if (A.gs_small_interpolate(xs.data(), ys.data(), m, co.data())) fail(GS_ERR_ARG, "gs_small_interpolate failed");
+            std::vector<F> ip(m), zp{1};
+            for (uint32_t i = 0; i < m; i++) ip[i] = from16(co.data() + 16 * i);
+            for (uint32_t i = 0; i < m; i++) {          // zPoly *= (x - xs[i]), BoundaryConstraints.ts:24-30
+                std::vector<F> nz(zp.size() + 1, 0);
+                const F nx = hf_sub(0, d.xs[i]);
+                for (size_t k = 0; k < zp.size(); k++) {
+                    nz[k] = hf_add(nz[k], hf_mul(zp[k], nx));
+                    nz[k + 1] = hf_add(nz[k + 1], zp[k]);
+                }
+                zp.swap(nz);
+            }
+            ilen = std::max(ilen, ip.size());
+            zlen = std::max(zlen, zp.size());
+            ipolys.push_back(ip);
+            zpolys.push_back(zp);
+        }
+        auto upload_rows = [&](const std::vector<std::vector<F>> &rows, size_t len) {
+            Bytes host(rows.size() * len * 16, 0);                    // shorter rows are zero-extended (newMatrixFromVectors)
+            for (size_t r = 0; r < rows.size(); r++)
+                for (size_t k = 0; k < rows[r].size(); k++) le16(rows[r][k], host.data() + (r * len + k) * 16);
+            Buf b(x, host.size());
+            x.check(A.gs_upload(x.c, b.p, host.data(), host.size()), "gs_upload(boundary polynomials)");
+            return b;
+        };
+        Buf iPolys = upload_rows(ipolys, ilen), zPolys = upload_rows(zpolys, zlen);
+        Buf iValues(x, (uint64_t)bcount * N * ELEM), zValues(x, (uint64_t)bcount * N * ELEM), pi(x, (uint64_t)bcount * N * ELEM),
+            bEval(x, (uint64_t)bcount * N * ELEM);
+        le16(omega, s16);
+        x.check(A.gs_eval_polys_at_roots(x.c, iPolys.p, bcount, ilen, s16, N, iValues.p), "gs_eval_polys_at_roots(I)");
+        x.check(A.gs_eval_polys_at_roots(x.c, zPolys.p, bcount, zlen, s16, N, zValues.p), "gs_eval_polys_at_roots(Zb)");
+        std::vector<const void *> pv;
+        for (auto &d : rdata) pv.push_back(pRows[d.reg]);
+        x.check(A.gs_sub_matrix_from_vectors(x.c, pv.data(), iValues.p, bcount, N, pi.p), "gs_sub_matrix_from_vectors");
+        x.check(A.gs_vec_div(x.c, pi.p, zValues.p, (uint64_t)bcount * N, bEval.p), "gs_vec_div(B)");
+        iValues.release(); zValues.release(); pi.release();
+        // 5.6 degree adjustment of B (:124-138) and 5.7 merge (:140-146)
+        std::vector<const void *> ba;
+        for (uint32_t i = 0; i < bcount; i++) ba.push_back(bEval.at((uint64_t)i * N * ELEM));
+        std::vector<Buf> badj;
+        if (b_inc > 0)
+            for (uint32_t i = 0; i < bcount; i++) {
+                badj.emplace_back(x, N * ELEM);
+                x.check(A.gs_vec_mul(x.c, ba[i], psbPowers.p, N, badj.back().p), "gs_vec_mul(B powers)");
+                ba.push_back(badj.back().p);
+            }
+        Buf bc(x, N * ELEM);
+        Bytes bco = coeff_bytes(dcount, bcoef);
+        x.check(A.gs_combine_many(x.c, ba.data(), bco.data(), bcoef, N, bc.p), "gs_combine_many(B)");
+        x.check(A.gs_vec_add(x.c, dEval.p, bc.p, N, cEval.p), "gs_vec_add(C)");
+    }
+    zInverses.release();
+
+    // 6 ----- random linear combination (LinearCombination.ts:36-64)
+    Buf lEval(x, N * ELEM);
+    {
+        std::vector<const void *> all(pRows.begin(), pRows.end());
+        std::vector<Buf> ps2;
+        if (b_inc > 0)                                             // psIncrementalDegree = compositionDegree - T, same powers
+            for (uint32_t r = 0; r < R; r++) {
+                ps2.emplace_back(x, N * ELEM);
+                x.check(A.gs_vec_mul(x.c, pRows[r], psbPowers.p, N, ps2.back().p), "gs_vec_mul(P powers)");
+                all.push_back(ps2.back().p);
+            }
+        const uint32_t offset = dcount + bcoef, cnt = (uint32_t)all.size();
+        std::vector<F> co = prng_many(eTree.root, offset + cnt);
+        Bytes cb(cnt * 16);
+        for (uint32_t i = 0; i < cnt; i++) le16(co[offset + i], cb.data() + 16 * i);
+        Buf comb(x, N * ELEM);
+        x.check(A.gs_combine_many(x.c, all.data(), cb.data(), cnt, N, comb.p), "gs_combine_many(P)");
+        x.check(A.gs_vec_add(x.c, cEval.p, comb.p, N, lEval.p), "gs_vec_add(L)");
+    }
+    cEval.release();
+    psbPowers.release();
+
+    // 7 ----- low-degree proof (LowDegreeProver.ts:39-68, 176-221)
+    if (N < 128) fail(GS_ERR_ARG, "Invalid array length");
+    Buf polyValues0(x, N * ELEM);
+    x.check(A.gs_transpose_vector(x.c, lEval.p, N, 4, 1, polyValues0.p), "gs_transpose_vector");
+    Tree pTree0;
+    {
+        Buf h(x, N / 4 * DIGEST);
+        x.check(A.gs_hash_digest_values(x.c, (gs_hash_alg)alg, polyValues0.p, 4 * ELEM, N / 4, h.p), "gs_hash_digest_values");
+        pTree0 = build_tree(x, alg, std::move(h), N / 4);
+    }
+    const uint32_t exe_count = (uint32_t)std::min<uint64_t>(job.exe_query_count, N - N / E);
+    std::vector<uint64_t> exe_positions = query_indexes(pTree0.root, exe_count, N, (uint32_t)E);   // QueryIndexGenerator.ts:28-32
+    std::vector<uint64_t> lc_positions;
+    for (uint64_t p : exe_positions) lc_positions.push_back(p % (N / 4));
+    lc_positions = unique_in_order(lc_positions);                                                 // LowDegreeProver.ts:302-309
+    MerkleProof lcProof = prove_batch(x, pTree0, lc_positions);
+    lcProof.values = gather(x, polyValues0.p, 4 * ELEM, lc_positions);
+
+    // layers (:176-221): the loop below is the recursion unrolled; queries are answered afterwards
+    std::vector<Layer> layers;
+    Tree *pTree = &pTree0;
+    const Buf *polyValues = &polyValues0;
+    const Buf *column_src = &lEval;     // the vector the current polyValues was transposed from (the remainder at the end)
+    Buf column_store;
+    uint64_t len = N;                   // elements in polyValues
+    uint64_t max_degree_plus1 = composition_degree;
+    uint32_t depth = 0;
+    layers.reserve(32);
+    while (len > 256) {
+        const uint64_t rows = len / 4;
+        Buf polys(x, len * ELEM), column(x, rows * ELEM);
+        le16(omega, s16);
+        uint64_t step = 1;
+        for (uint32_t d = 0; d < depth; d++) step *= 4;
+        x.check(A.gs_interpolate_quartic_domain(x.c, s16, N, step, polyValues->p, rows, polys.p), "gs_interpolate_quartic_domain");
+        le16(prng_one(pTree->root), s16b);                                                        // :194
+        x.check(A.gs_eval_quartic_batch(x.c, polys.p, rows, s16b, column.p), "gs_eval_quartic_batch");
+        layers.emplace_back();
+        Layer &L = layers.back();
+        L.pTree = pTree;
+        L.polyValues = polyValues;
+        L.rows = rows;
+        L.column_length = rows;
+        L.newPolyValues = Buf(x, rows * ELEM);
+        x.check(A.gs_transpose_vector(x.c, column.p, rows, 4, 1, L.newPolyValues.p), "gs_transpose_vector");
+        Buf h(x, rows / 4 * DIGEST);
+        x.check(A.gs_hash_digest_values(x.c, (gs_hash_alg)alg, L.newPolyValues.p, 4 * ELEM, rows / 4, h.p), "gs_hash_digest_values");
+        L.cTree = build_tree(x, alg, std::move(h), rows / 4);
+        column_store = std::move(column);
+        column_src = &column_store;
+        pTree = &L.cTree;
+        polyValues = &L.newPolyValues;
+        len = rows;
+        max_degree_plus1 /= 4;
+        depth++;
+    }
+    // remainder (:179-187): the natural-order vector the last polyValues came from
+    std::vector<F> remainder(len);
+    {
+        Bytes raw(len * ELEM);
+        x.check(A.gs_download(x.c, raw.data(), column_src->p, len * ELEM), "gs_download(remainder)");
+        for (uint64_t i = 0; i < len; i++) remainder[i] = from16(raw.data() + 16 * i);
+        // verifyRemainder (:223-252)
+        F rou = omega;
+        for (uint32_t d = 0; d < depth; d++) { rou = hf_mul(rou, rou); rou = hf_mul(rou, rou); }      // omega^(4^depth)
+        std::vector<uint64_t> positions;
+        for (uint64_t i = 0; i < len; i++) if (i % E) positions.push_back(i);
+        std::vector<F> domain(len);
+        F cur = 1;
+        for (uint64_t i = 0; i < len; i++) { domain[i] = cur; cur = hf_mul(cur, rou); }
+        if (max_degree_plus1 > positions.size()) fail(GS_ERR_ARG, "Remainder degree is greater than number of remainder values");
+        const uint32_t m = (uint32_t)max_degree_plus1;
+        if (m) {
+            Bytes xs(m * 16), ys(m * 16), poly(m * 16);
+            for (uint32_t i = 0; i < m; i++) { le16(domain[positions[i]], xs.data() + 16 * i); le16(remainder[positions[i]], ys.data() + 16 * i); }
+            if (A.gs_small_interpolate(xs.data(), ys.data(), m, poly.data())) fail(GS_ERR_ARG, "gs_small_interpolate failed");
+            const uint32_t rest = (uint32_t)positions.size() - m;
+            if (rest) {
+                Bytes rx(rest * 16), rv(rest * 16);
+                for (uint32_t i = 0; i < rest; i++) le16(domain[positions[m + i]], rx.data() + 16 * i);
+                if (A.gs_small_eval_poly(poly.data(), m, rx.data(), rest, rv.data())) fail(GS_ERR_ARG, "gs_small_eval_poly failed");
+                for (uint32_t i = 0; i < rest; i++)
+                    if (from16(rv.data() + 16 * i) != remainder[positions[m + i]])
+                        fail(GS_ERR_ARG, "Low degree proof failed: Remainder is not a valid degree %u polynomial", m - 1);
+            }
+        }
+    }
+    // queries of every layer (:209-219)
+    struct Component { Bytes columnRoot; MerkleProof columnProof, polyProof; };
+    std::vector<Component> components(layers.size());
+    for (size_t d = 0; d < layers.size(); d++) {
+        Layer &L = layers[d];
+        std::vector<uint64_t> positions = query_indexes(L.cTree.root, job.fri_query_count, L.column_length, (uint32_t)E);
+        std::vector<uint64_t> aug;
+        for (uint64_t p : positions) aug.push_back(p % (L.column_length / 4));
+        aug = unique_in_order(aug);
+        Component &c = components[d];
+        c.columnRoot = L.cTree.root;
+        c.columnProof = prove_batch(x, L.cTree, aug);
+        c.columnProof.values = gather(x, L.newPolyValues.p, 4 * ELEM, aug);
+        c.polyProof = prove_batch(x, *L.pTree, positions);
+        c.polyProof.values = gather(x, L.polyValues->p, 4 * ELEM, positions);
+    }
+
+    // 8 ----- spot checks of the evaluation tree (lib/Stark.ts:146-152, 274-296)
+    std::vector<uint64_t> positions = query_indexes(pTree0.root, exe_count, N, (uint32_t)E);
+    std::vector<uint64_t> aug;
+    for (uint64_t p : positions) { aug.push_back(p); aug.push_back((p + E) % N); }
+    aug = unique_in_order(aug);
+    MerkleProof evProof = prove_batch(x, eTree, aug);
+    {
+        std::vector<std::vector<Bytes>> cols;
+        for (uint32_t r = 0; r < R; r++) cols.push_back(gather(x, pRows[r], ELEM, aug));
+        evProof.values.clear();
+        for (size_t i = 0; i < aug.size(); i++) {
+            Bytes v;
+            for (uint32_t r = 0; r < R; r++) v.insert(v.end(), cols[r][i].begin(), cols[r][i].end());
+            evProof.values.push_back(v);
+        }
+    }
+
+    // ----- Serializer.serializeProof (:35-79)
+    out.clear();
+    out.insert(out.end(), eTree.root.begin(), eTree.root.end());
+    write_merkle_proof(out, evProof, (uint64_t)R * ELEM);
+    out.insert(out.end(), pTree0.root.begin(), pTree0.root.end());
+    write_merkle_proof(out, lcProof, 4 * ELEM);
+    if (components.size() > 255) fail(GS_ERR_ARG, "too many FRI components");
+    out.push_back((uint8_t)components.size());
+    for (auto &c : components) {
+        out.insert(out.end(), c.columnRoot.begin(), c.columnRoot.end());
+        write_merkle_proof(out, c.columnProof, 4 * ELEM);
+        write_merkle_proof(out, c.polyProof, 4 * ELEM);
+    }
+    if (remainder.size() > MAX_ARRAY) fail(GS_ERR_ARG, "remainder too long");
+    out.push_back(remainder.size() == MAX_ARRAY ? 0 : (uint8_t)remainder.size());
+    for (F v : remainder) { uint8_t b[16]; le16(v, b); out.insert(out.end(), b, b + 16); }
+    out.push_back(0);    // no input shapes (iShapes = [])
+}

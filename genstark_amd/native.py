@@ -1,0 +1,175 @@
+"""Binding of the native prove() driver (genstark_amd/csrc/prover.cc -> libgstark_prover.so).
+
+`NativeProver(stark)` proves the same statements as `stark.prove()` — same AIR, same options, same bytes
+(tests/test_native_prover.py) — with the whole call sequence of lib/Stark.ts:81-163 issued by native host code instead of
+the Python mirror: no interpreter between two launches.  The driver is bound to the ABI library the Stark's backend loaded
+(the HIP library in the product; the oracle's implementation only when a test injected it), it never falls back to anything.
+"""
+import ctypes as C
+import os
+
+from ._abi import GstarkError
+from .air import MimcAir
+from .air_generic import GenericAir
+from .errors import StarkError
+from .field import _le
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PROVER_LIB_PATH = os.path.join(_HERE, 'csrc', 'libgstark_prover.so')
+
+
+class _Assertion(C.Structure):
+    _fields_ = [('step', C.c_uint64), ('reg', C.c_uint32), ('value', C.c_uint8 * 16)]
+
+
+class _Air(C.Structure):
+    _fields_ = [('kind', C.c_uint32), ('registers', C.c_uint32), ('nconstraints', C.c_uint32), ('degrees', C.POINTER(C.c_uint32)),
+                ('seed', C.c_uint8 * 16), ('round_constants', C.c_char_p), ('nrc', C.c_uint32), ('k_table', C.c_void_p), ('k_len', C.c_uint64),
+                ('t_code', C.POINTER(C.c_uint32)), ('t_ninstr', C.c_uint32), ('i_code', C.POINTER(C.c_uint32)), ('i_ninstr', C.c_uint32),
+                ('e_code', C.POINTER(C.c_uint32)), ('e_ninstr', C.c_uint32), ('consts', C.c_char_p), ('nconsts', C.c_uint32),
+                ('vm_regs', C.c_uint32), ('static_values', C.c_char_p), ('static_periods', C.POINTER(C.c_uint32)), ('nstatic', C.c_uint32),
+                ('static_tables', C.c_void_p), ('static_lens', C.POINTER(C.c_uint64)), ('first_rows', C.c_char_p), ('segments', C.c_uint64),
+                ('segment_len', C.c_uint64)]
+
+
+class _Job(C.Structure):
+    _fields_ = [('steps', C.c_uint64), ('extension_factor', C.c_uint32), ('exe_query_count', C.c_uint32), ('fri_query_count', C.c_uint32),
+                ('hash_alg', C.c_int32), ('root_of_unity', C.c_uint8 * 16), ('assertions', C.POINTER(_Assertion)), ('nassertions', C.c_uint32),
+                ('air', _Air)]
+
+
+_bound = {}
+
+
+def _driver(backend):
+    """libgstark_prover.so bound to the ABI library of `backend` (one private copy of the driver per ABI library)."""
+    key = backend.lib._name
+    if key not in _bound:
+        if not os.path.exists(PROVER_LIB_PATH):
+            raise GstarkError(f'{PROVER_LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"`')
+        mode = getattr(os, 'RTLD_LOCAL', 0) | getattr(os, 'RTLD_NOW', 2)
+        if len(_bound):
+            # a second ABI library in the same process (tests: oracle double + HIP): the driver keeps its binding in static
+            # storage, so give it its own image
+            import shutil
+            import tempfile
+            tmp = os.path.join(tempfile.mkdtemp(prefix='gstark_prover_'), f'libgstark_prover_{len(_bound)}.so')
+            shutil.copy(PROVER_LIB_PATH, tmp)
+            lib = C.CDLL(tmp, mode=mode)
+        else:
+            lib = C.CDLL(PROVER_LIB_PATH, mode=mode)
+        lib.gs_prover_bind.argtypes = [C.c_void_p]
+        lib.gs_prover_bind.restype = C.c_int
+        lib.gs_prover_prove.argtypes = [C.c_void_p, C.POINTER(_Job), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
+        lib.gs_prover_prove.restype = C.c_int
+        rc = lib.gs_prover_bind(C.c_void_p(backend.lib._handle))
+        if rc:
+            raise GstarkError(f'gs_prover_bind failed ({rc}): the ABI library lacks an entry point the driver needs')
+        _bound[key] = lib
+    return _bound[key]
+
+
+class NativeProver:
+    def __init__(self, stark):
+        self.stark = stark
+        air = stark.air
+        self.field = air.field
+        self.backend = self.field.backend
+        if hasattr(self.field, 'comm'):
+            raise GstarkError('the native driver proves on one device; use the distributed field with Stark.prove()')
+        self.lib = _driver(self.backend)
+        self._keep = []
+        # AIR-instance constants the device routines need, computed once (they depend on the AIR only, like the static register
+        # polynomials an air-assembly module holds)
+        if isinstance(air, MimcAir):
+            ctx = air.initProvingContext([], [0])
+            self.kind, self.degrees = 0, [3]
+            self._kTable = ctx._kTable
+            self._rc = b''.join(_le(k) for k in air.roundConstants)
+            self.rootOfUnity = ctx.rootOfUnity
+        elif isinstance(air, GenericAir):
+            rows = [[0] * air.traceRegisterCount]
+            from .air_generic import GenericProvingContext
+            ctx = GenericProvingContext(air, rows * (air.steps // air.segmentLength if air.segmentLength else 1))
+            self.kind, self.degrees = 1, list(air.constraintDegrees)
+            self._tables, self._lens = ctx._staticTables, ctx._staticLens
+            self.rootOfUnity = air.rootOfUnity
+        else:
+            raise GstarkError('the native driver knows the MiMC AIR and GenericAir')
+
+    def prove_bytes(self, assertions, inputs=None, seed=None):
+        """The serialized proof of Stark.prove(assertions, inputs, seed): stark.serialize(stark.prove(...)) byte for byte."""
+        stark, air, f = self.stark, self.stark.air, self.field
+        if not isinstance(assertions, list):
+            raise TypeError('Assertions parameter must be an array')
+        if len(assertions) == 0:
+            raise TypeError('At least one assertion must be provided')
+        job = _Job()
+        job.steps, job.extension_factor = air.steps, air.extensionFactor
+        job.exe_query_count, job.fri_query_count = stark.indexGenerator.exeQueryCount, stark.indexGenerator.friQueryCount
+        job.hash_alg = stark.hash.alg
+        job.root_of_unity[:] = _le(self.rootOfUnity)
+        arr = (_Assertion * len(assertions))()
+        for i, a in enumerate(assertions):
+            if a['register'] < 0 or a['step'] < 0:
+                raise ValueError('Invalid assertion')
+            arr[i].step, arr[i].reg = a['step'], a['register']
+            arr[i].value[:] = _le(a['value'] % f.modulus)
+        job.assertions, job.nassertions = arr, len(assertions)
+        ja = job.air
+        ja.kind, ja.registers, ja.nconstraints = self.kind, air.traceRegisterCount, len(self.degrees)
+        degrees = (C.c_uint32 * len(self.degrees))(*self.degrees)
+        ja.degrees = degrees
+        keep = [arr, degrees]
+        if self.kind == 0:
+            ja.seed[:] = _le((seed or [0])[0] % f.modulus)
+            ja.round_constants, ja.nrc = self._rc, len(air.roundConstants)
+            ja.k_table, ja.k_len = self._kTable.ptr, self._kTable.length
+        else:
+            t_code, t_n, consts, nconsts, nregs = air.transitionProgram.abi_args()
+            e_code, e_n, consts, nconsts, _ = air.evaluationProgram.abi_args() if air.evaluationProgram.consts is air.transitionProgram.consts \
+                else (None, 0, None, 0, 0)
+            if e_code is None:
+                # transition and evaluator have separate constant pools: concatenate and rebase the evaluator's constant indexes
+                e_prog, t_prog = air.evaluationProgram, air.transitionProgram
+                base = len(t_prog.consts)
+                from .air_generic import OP_LOADC, OP_POWC
+                code = []
+                for op, d, a, b in e_prog.code:
+                    if op == OP_LOADC:
+                        a += base
+                    elif op == OP_POWC:
+                        b += base
+                    code.extend((op, d, a, b))
+                e_code, e_n = (C.c_uint32 * len(code))(*code), len(e_prog.code)
+                pool = list(t_prog.consts) + list(e_prog.consts)
+                consts, nconsts = b''.join(int(v).to_bytes(16, 'little') for v in pool), len(pool)
+                nregs = max(t_prog.nregs, e_prog.nregs)
+            ja.t_code, ja.t_ninstr, ja.e_code, ja.e_ninstr = t_code, t_n, e_code, e_n
+            ja.consts, ja.nconsts, ja.vm_regs = consts, nconsts, nregs
+            if air.initProgram is not None:
+                i_code, i_n = air.initProgram.abi_args()[:2]
+                ja.i_code, ja.i_ninstr = i_code, i_n
+                keep.append(i_code)
+                ja.vm_regs = max(ja.vm_regs, air.initProgram.nregs)
+            svals = b''.join(_le(v % f.modulus) for values in air.staticRegisters for v in values) or bytes(16)
+            periods = (C.c_uint32 * max(len(air.staticRegisters), 1))(*[len(v) for v in air.staticRegisters])
+            lens = (C.c_uint64 * max(len(self._lens), 1))(*self._lens)
+            ja.static_values, ja.static_periods, ja.nstatic = svals, periods, len(air.staticRegisters)
+            ja.static_tables, ja.static_lens = self._tables.ptr, lens
+            rows = air.firstRows(seed)
+            first = b''.join(_le(v % f.modulus) for row in rows for v in row)
+            ja.first_rows = first
+            ja.segments, ja.segment_len = (len(rows), air.segmentLength) if air.segmentLength else (0, 0)
+            keep += [t_code, e_code, consts, svals, periods, lens, first]
+        cap = 1 << 22
+        out = C.create_string_buffer(cap)
+        n = C.c_uint64()
+        err = C.create_string_buffer(512)
+        rc = self.lib.gs_prover_prove(self.backend.ctx, C.byref(job), C.cast(out, C.c_void_p), cap, C.byref(n), err, 512)
+        if rc:
+            raise StarkError(f'native prove() failed ({rc}): {err.value.decode(errors="replace")}')
+        return out.raw[:n.value]
+
+    def prove(self, assertions, inputs=None, seed=None):
+        return self.stark.parse(self.prove_bytes(assertions, inputs, seed))

@@ -1,0 +1,110 @@
+"""The native prove() driver (genstark_amd/csrc/prover.cc: the call sequence of lib/Stark.ts:81-163 issued by C++ above the C
+ABI) must produce exactly the bytes the Python mirror's prove() + serialize() produce: golden MiMC proofs, the generic AIR path
+(Rescue, Poseidon, many-hash segmented variants, Foo with zero FRI layers), error behaviour.  CPU: bound to the oracle's
+implementation of the ABI; GPU: bound to the HIP library."""
+import hashlib
+import json
+import os
+
+import pytest
+
+import genstark_amd as ga
+from genstark_amd.errors import StarkError
+from genstark_amd.field import PrimeField
+from genstark_amd.native import NativeProver
+from genstark_amd.stark import Stark
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, 'golden', 'oracle_proofs.json')) as f:
+    GOLDEN = json.load(f)
+
+
+def check_golden(case, backend):
+    options = {'hashAlgorithm': case['hash_algorithm'], 'extensionFactor': case['extension_factor'],
+               'exeQueryCount': case['exe_query_count'], 'friQueryCount': case['fri_query_count']}
+    stark = ga.instantiateMimc(case['steps'], options, None, backend=backend)
+    assertions = [{'step': a['step'], 'register': a['register'], 'value': int(a['value'])} for a in case['assertions']]
+    native = NativeProver(stark)
+    data = native.prove_bytes(assertions, [], [case['seed']])
+    assert len(data) == case['proofSize'] and hashlib.sha256(data).hexdigest() == case['proofSha256']
+    assert data == stark.serialize(stark.prove(assertions, [], [case['seed']]))
+    proof = native.prove(assertions, [], [case['seed']])
+    assert proof['evRoot'].hex() == case['evRoot'] and stark.verify(assertions, proof)
+    return native, assertions
+
+
+@pytest.mark.parametrize('case', GOLDEN, ids=[c['name'] for c in GOLDEN])
+def test_native_prover_matches_golden_bytes_oracle(case, oracle_backend):
+    check_golden(case, oracle_backend)
+
+
+def test_native_prover_errors(oracle_backend):
+    native, assertions = check_golden(GOLDEN[0], oracle_backend)
+    with pytest.raises(StarkError, match='conflicts with execution trace'):
+        native.prove_bytes([dict(assertions[0], value=assertions[0]['value'] + 1)], [], [GOLDEN[0]['seed']])
+    with pytest.raises(StarkError, match='outside of execution trace'):
+        native.prove_bytes([dict(assertions[0], step=GOLDEN[0]['steps'])], [], [GOLDEN[0]['seed']])
+    with pytest.raises(StarkError, match='outside of register bank'):
+        native.prove_bytes([dict(assertions[0], register=1)], [], [GOLDEN[0]['seed']])
+    with pytest.raises(TypeError):
+        native.prove_bytes([], [], [3])
+
+
+def generic_cases(backend):
+    from genstark_amd import poseidon
+    from genstark_amd.rescue import rescue4x128_air
+    from test_generic_air import POSEIDON_OPTS, RESCUE_OPTS, degree5_air, foo_air
+    f = PrimeField(backend=backend)
+    out = []
+    air = rescue4x128_air(64, 16, f)
+    out.append(('rescue', Stark(air, RESCUE_OPTS), [42, 43], air.hostTrace([42, 43]), [(31, 0), (31, 1), (63, 3), (0, 2), (5, 1), (9, 1)]))
+    air = poseidon.poseidon6x128_air(128, 16, f)
+    out.append(('poseidon', Stark(air, POSEIDON_OPTS), [1, 2, 3, 4], air.hostTrace([1, 2, 3, 4]), [(63, 0), (63, 1), (127, 5)]))
+    air = rescue4x128_air(128, 16, f, segmented=True)
+    seeds = [[42 + s, 43 + 2 * s] for s in range(4)]
+    out.append(('rescue-segmented', Stark(air, RESCUE_OPTS), seeds, air.hostTrace(seeds), [(31, 0), (127, 1), (96, 0)]))
+    air = poseidon.poseidon6x128_air(128, 16, f, segmented=True)
+    seeds = [[1, 2, 3, 4], [5, 6, 7, 8]]
+    out.append(('poseidon-segmented', Stark(air, POSEIDON_OPTS), seeds, air.hostTrace(seeds), [(63, 0), (127, 1)]))
+    air = degree5_air(f, 64)
+    out.append(('degree5', Stark(air, {'hashAlgorithm': 'sha256', 'extensionFactor': 16, 'exeQueryCount': 40, 'friQueryCount': 20}), [5],
+                air.hostTrace([5]), [(0, r) for r in range(6)] + [(63, 4), (32, 4)]))
+    air = foo_air(f)
+    out.append(('foo', Stark(air, None), [1], air.hostTrace([1]), [(0, 0), (63, 0)]))
+    return out
+
+
+def check_generic(backend):
+    digests = {}
+    for name, stark, seed, trace, points in generic_cases(backend):
+        assertions = [{'step': s, 'register': r, 'value': trace[s][r]} for s, r in points]
+        want = stark.serialize(stark.prove(assertions, [], seed))
+        got = NativeProver(stark).prove_bytes(assertions, [], seed)
+        assert got == want, name
+        assert stark.verify(assertions, stark.parse(got)), name
+        digests[name] = hashlib.sha256(got).hexdigest()
+    return digests
+
+
+def test_native_prover_generic_airs_oracle(oracle_backend):
+    check_generic(oracle_backend)
+
+
+@pytest.mark.gpu
+def test_native_prover_hip(hip_backend, oracle_backend):
+    for case in GOLDEN:
+        check_golden(case, hip_backend)
+    assert check_generic(hip_backend) == check_generic(oracle_backend)
+
+
+@pytest.mark.gpu
+def test_native_prover_2p20_config(hip_backend):
+    """BASELINE configs[4] through the native driver: same bytes as the Python mirror on the same device."""
+    opts = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 48, 'friQueryCount': 64}
+    steps = 1 << 20
+    stark = ga.instantiateMimc(steps, opts, None, backend=hip_backend)
+    trace = stark.air.initProvingContext([], [3]).generateExecutionTrace()
+    assertions = [{'step': 0, 'register': 0, 'value': trace.getValue(0, 0)}, {'step': steps - 1, 'register': 0, 'value': trace.getValue(0, steps - 1)}]
+    data = NativeProver(stark).prove_bytes(assertions, [], [3])
+    assert data == stark.serialize(stark.prove(assertions, [], [3]))
+    assert stark.verify(assertions, stark.parse(data))
