@@ -16,12 +16,13 @@ from ._abi import Backend
 
 
 class ProverPool:
-    def __init__(self, stark_factory, lanes=2, backend_factory=None):
+    def __init__(self, stark_factory, lanes=2, backend_factory=None, native=False):
         """stark_factory(backend) -> Stark; backend_factory() -> Backend, called once inside every lane's thread (the HIP
         current device is per-thread state, gs_ctx_create sets it for the calling thread)."""
         if lanes < 1:
             raise ValueError('lanes must be >= 1')
         self.lanes = lanes
+        self.native = native        # lanes prove through the native driver (genstark_amd/native.py): the GIL is released for a whole proof
         self._jobs = queue.Queue()
         self._errors = []
         self._ready = threading.Barrier(lanes + 1)
@@ -37,6 +38,9 @@ class ProverPool:
     def _lane(self, index, stark_factory, backend_factory):
         try:
             stark = stark_factory(backend_factory())
+            if self.native:
+                from .native import NativeProver
+                stark = NativeProver(stark)
             self.starks[index] = stark
         except BaseException as e:      # surface construction failures (e.g. no HIP library) in the caller
             self._errors.append(e)
@@ -68,6 +72,10 @@ class ProverPool:
     def prove_many(self, jobs):
         """jobs: iterable of (assertions, inputs, seed) as for Stark.prove; returns the proofs in job order."""
         return self._run([(lambda s, j=j: s.prove(*j)) for j in jobs])
+
+    def prove_many_bytes(self, jobs):
+        """Serialized proofs in job order (native lanes: NativeProver.prove_bytes)."""
+        return self._run([(lambda s, j=j: s.prove_bytes(*j)) for j in jobs])
 
     def on_every_lane(self, fn):
         """Run fn(stark) once on EVERY lane (warm-up of plans and block caches, synchronisation before timing)."""

@@ -55,6 +55,26 @@ def check_pool(make_backend, lanes):
         assert seq.serialize(pool.prove_many(jobs[:1])[0]) == expected[0]      # the pool survives a failed job
 
 
+def check_native_pool(make_backend, lanes):
+    case = CASE
+    seq = factory(case)(make_backend())
+    jobs = jobs_for(seq, case['steps'], [case['seed'], 5, 7, 11, 13])
+    expected = [seq.serialize(seq.prove(*j)) for j in jobs]
+    with ProverPool(factory(case), lanes=lanes, backend_factory=make_backend, native=True) as pool:
+        pool.on_every_lane(lambda s: s.prove_bytes(*jobs[0]))
+        assert pool.prove_many_bytes(jobs) == expected
+        assert [seq.serialize(p) for p in pool.prove_many(jobs)] == expected      # NativeProver.prove parses its own bytes
+
+
+def test_native_pool_matches_sequential_proofs_oracle_backend(oracle_backend):
+    check_native_pool(lambda: Backend(lib_path=ORACLE_LIB, allow_test_double=True), 3)
+
+
+@pytest.mark.gpu
+def test_native_pool_matches_sequential_proofs_hip():
+    check_native_pool(lambda: Backend(device=0), 4)
+
+
 @pytest.mark.parametrize('lanes', [1, 3])
 def test_pool_matches_sequential_proofs_oracle_backend(oracle_backend, lanes):
     check_pool(lambda: Backend(lib_path=ORACLE_LIB, allow_test_double=True), lanes)
