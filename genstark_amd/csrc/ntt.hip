@@ -120,7 +120,14 @@ __global__ __launch_bounds__(256) void k_ntt_pass(const fe *__restrict__ in, fe 
             if (m < 15) cur = fe_mul(cur, step);
         }
     }
-    ntt_dif_reg<4>(v, a.w16);  // A[qa] = v[brev(qa,4)]
+    // Low-degree extension by >= 16x (in_len <= n/16, e.g. trace polynomials onto the evaluation domain): only m = 0 was in
+    // range above, and the 16-point transform of (v0, 0, ..., 0) is v0 everywhere — skip the butterfly network (wave-uniform)
+    if (a.in_len <= nR * RB) {
+#pragma unroll
+        for (int m = 1; m < 16; m++) v[m] = v[0];
+    } else {
+        ntt_dif_reg<4>(v, a.w16);  // A[qa] = v[brev(qa,4)]
+    }
 
     const uint64_t jbase = (j - jq) * R + jq;
     const bool first = (a.logNs == 0);  // first pass: the tile's output is one contiguous block of R*Wj elements
