@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import genstark_amd as ga
 from genstark_amd._abi import Backend
 from genstark_amd.field import PrimeField
+from genstark_amd.native import NativeProver
 from genstark_amd.poseidon import poseidon6x128_air, poseidon_hash
 from genstark_amd.rescue import rescue4x128_air
 from genstark_amd.stark import Stark
@@ -31,6 +32,14 @@ def run(name, stark, assertions, seed, reps=5):
         be.sync()
         t.append((time.perf_counter() - t0) * 1e3)
     data = stark.serialize(proof)
+    nat = NativeProver(stark)
+    tn = []
+    for i in range(reps + 2):
+        t0 = time.perf_counter()
+        nd = nat.prove_bytes(assertions, [], seed)
+        if i >= 2:
+            tn.append((time.perf_counter() - t0) * 1e3)
+    assert nd == data
     t0 = time.perf_counter()
     assert stark.verify(assertions, stark.parse(data))
     tv = (time.perf_counter() - t0) * 1e3
@@ -38,7 +47,7 @@ def run(name, stark, assertions, seed, reps=5):
     s2.prove(assertions, [], seed)
     phases = {k.strip(): v for k, v in log.phases}
     trace_ms = phases.get('Generated execution trace', 0.0)
-    rows.append(f'| {name} | {min(t):.2f} | {sum(t) / len(t):.2f} | {trace_ms:.2f} | {tv:.1f} | {len(data)} | {stark.securityLevel} |')
+    rows.append(f'| {name} | {min(tn):.2f} | {sum(tn) / len(tn):.2f} | {min(t):.2f} | {trace_ms:.2f} | {tv:.1f} | {len(data)} | {stark.securityLevel} |')
 
 
 stark_opts = {}
@@ -88,7 +97,7 @@ a = [{'step': 0, 'register': 0, 'value': tr.getValue(0, 0)}, {'step': (1 << 20) 
 run(name, st, a, [3])
 
 print('# prove() wall-clock of the BASELINE configurations, 1 x MI355X (HIP backend), host-side trace generation included\n')
-print('command: `python tools/time_configs.py` (2 warm-up proofs, 5 timed, each followed by a stream sync; verify() timed once on the host)\n')
-print('| configuration | prove() best ms | mean ms | of which trace generation (host core) ms | verify() ms | proof bytes | security level |')
-print('|---|---:|---:|---:|---:|---:|---:|')
+print('command: `python tools/time_configs.py` (2 warm-up proofs, 5 timed; native driver = csrc/prover.cc, Python mirror = stark.prove(), same bytes asserted; verify() timed once on the host)\n')
+print('| configuration | prove() native driver best ms | mean ms | Python mirror best ms | of which trace generation ms | verify() ms (host) | proof bytes | security level |')
+print('|---|---:|---:|---:|---:|---:|---:|---:|')
 print('\n'.join(rows))
