@@ -236,3 +236,82 @@ def test_prove_2p20_full_config_verifies(hip_backend):
     data = stark.serialize(proof)
     assert len(data) == stark.sizeOf(proof)
     assert stark.verify(assertions, stark.parse(data))
+
+
+# ---- (e) randomized differential runs: the same call on both backends, every shape drawn at random -----------------------
+@pytest.mark.parametrize('seed', range(12))
+def test_randomized_differential_hip_vs_oracle(hip_backend, oracle_backend, seed):
+    """40 randomly shaped calls per seed (lengths that are not powers of two, ragged NTT inputs, random register counts,
+    random query sets, zeros sprinkled into inversions): byte equality of every result on the HIP library and on the oracle."""
+    rng = random.Random(1000 + seed)
+    fh, fo = PrimeField(backend=hip_backend), PrimeField(backend=oracle_backend)
+    hh, ho = createHash('blake2s256' if seed % 2 else 'sha256', hip_backend), createHash('blake2s256' if seed % 2 else 'sha256', oracle_backend)
+
+    def both(fn):
+        a, b = fn(fh, hh), fn(fo, ho)
+        for x, y in zip(a, b):
+            assert x == y
+    for _ in range(40):
+        kind = rng.randrange(8)
+        if kind == 0:       # pointwise family on an arbitrary length
+            n = rng.choice([1, 2, 3, 63, 64, 65, 255, 1000, 4097, rng.randrange(1, 150000)])
+            xs, ys, k, e = rand_elements(rng, n), rand_elements(rng, n, edge=0.3), rng.randrange(P), rng.choice([0, 1, 5, P - 2])
+            both(lambda f, h: [f.addVectorElements(f.newVectorFrom(xs), f.newVectorFrom(ys)).toBuffer(),
+                               f.subVectorElements(f.newVectorFrom(xs), k).toBuffer(),
+                               f.mulVectorElements(f.newVectorFrom(xs), f.newVectorFrom(ys)).toBuffer(),
+                               f.divVectorElements(f.newVectorFrom(xs), f.newVectorFrom(ys)).toBuffer(),     # zeros in ys: 0^-1 := 0
+                               f.invVectorElements(f.newVectorFrom(ys)).toBuffer(),
+                               f.expVectorElements(f.newVectorFrom(xs[:64]), e).toBuffer()])
+        elif kind == 1:     # linear combinations / dot products
+            n, k = rng.randrange(1, 30000), rng.randrange(1, 20)
+            vs, cs = [rand_elements(rng, n) for _ in range(k)], rand_elements(rng, k)
+            both(lambda f, h: [f.combineManyVectors([f.newVectorFrom(v) for v in vs], cs).toBuffer(),
+                               f.combineVectors(f.newVectorFrom(vs[0]), f.newVectorFrom(vs[-1])).to_bytes(16, 'little')])
+        elif kind == 2:     # NTT: ragged polynomial lengths, several rows, forward and inverse
+            logn = rng.randrange(0, 17)
+            n, rows = 1 << logn, rng.randrange(1, 4)
+            plen = rng.choice([1, n, max(1, n // 16), rng.randrange(1, n + 1)])
+            polys = [rand_elements(rng, plen) for _ in range(rows)]
+            both(lambda f, h: [f.evalPolysAtRoots(f.newMatrixFrom(polys), f.getPowerSeries(f.getRootOfUnity(n), n)).toBuffer(),
+                               f.interpolateRoots(f.getPowerSeries(f.getRootOfUnity(n), n),
+                                                  f.evalPolysAtRoots(f.newMatrixFrom(polys), f.getPowerSeries(f.getRootOfUnity(n), n))).toBuffer()])
+        elif kind == 3:     # power series, pluck, transposes
+            n = 1 << rng.randrange(2, 15)
+            base, skip = rng.randrange(2, P), rng.randrange(1, 50)
+            step = rng.choice([1, 1, 4]) if n >= 64 else 1
+            times = n * 2
+            both(lambda f, h: [f.getPowerSeries(base, n).toBuffer(), f.pluckVector(f.getPowerSeries(base, n), skip, times).toBuffer(),
+                               f.transposeVector(f.getPowerSeries(base, n), 4, step).toBuffer()])
+        elif kind == 4:     # leaf / row hashing with a random number of registers
+            n, regs = rng.randrange(1, 5000), rng.randrange(1, 9)
+            cols = [rand_elements(rng, n) for _ in range(regs)]
+            both(lambda f, h: [h.mergeVectorRows([f.newVectorFrom(c) for c in cols]).toBuffer()])
+        elif kind == 5:     # Merkle tree + batch proofs over random query sets
+            logn = rng.randrange(1, 13)
+            n = 1 << logn
+            leaves = rand_elements(rng, n)
+            idx = rng.sample(range(n), rng.randrange(1, min(n, 70) + 1))
+
+            def run(f, h):
+                tree = MerkleTree.create(h.mergeVectorRows([f.newVectorFrom(leaves)]), h)
+                proof = tree.proveBatch(idx)
+                assert MerkleTree.verifyBatch(tree.root, idx, proof, h)
+                return [tree.root, b''.join(proof['values']), b''.join(b''.join(c) for c in proof['nodes']), bytes([len(c) for c in proof['nodes']])]
+            both(run)
+        elif kind == 6:     # FRI rows: domain fast path, generic path, evaluation
+            n = 1 << rng.randrange(4, 14)
+            vals, x = rand_elements(rng, n), rng.randrange(P)
+
+            def run(f, h):
+                dom = f.getPowerSeries(f.getRootOfUnity(n), n)
+                ys = f.transposeVector(f.newVectorFrom(vals), 4)
+                polys = f.interpolateQuarticBatch(f.transposeVector(dom, 4), ys)
+                return [polys.toBuffer(), f.evalQuarticBatch(polys, x).toBuffer(), h.digestValues(ys, 64).toBuffer()]
+            both(run)
+        else:               # small host-side polynomials and gathers
+            m = rng.randrange(1, 40)
+            xs, ys = rng.sample(range(1, 10 ** 9), m), rand_elements(rng, m)
+            n = rng.randrange(m, 3000)
+            vec, idx = rand_elements(rng, n), [rng.randrange(n) for _ in range(rng.randrange(1, 200))]
+            both(lambda f, h: [f.interpolate(f.newVectorFrom(xs), f.newVectorFrom(ys)).toBuffer(), b''.join(f.newVectorFrom(vec).valuesAt(idx)),
+                               f.mulPolys(f.newVectorFrom(vec[:90]), f.newVectorFrom(vec[-80:] if n >= 80 else vec)).toBuffer()])
