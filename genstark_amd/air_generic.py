@@ -197,26 +197,48 @@ class GenericVerificationContext(_Context):
             for c in reversed(poly):
                 k = (k * xc + c) % f.modulus
             statics.append(k)
-        return self.air.evaluationProgram.run(rValues, nValues, statics)
+        if len(hValues) != self.air.secretInputCount:
+            raise GstarkError('wrong number of secret register values')
+        return self.air.evaluationProgram.run(rValues, nValues, statics + [v % f.modulus for v in hValues])
 
 
 class GenericProvingContext(_Context):
-    def __init__(self, air, first_rows):
+    def __init__(self, air, first_rows, secret_values=None):
         super().__init__(air)
         f = self.field
+        secret_values = [list(v) for v in (secret_values or [])]
+        if len(secret_values) != air.secretInputCount:
+            raise GstarkError(f'the AIR has {air.secretInputCount} secret registers: `inputs` must hold one list of values for each')
+        for values in secret_values:
+            if not values or len(values) & (len(values) - 1) or self.traceLength % len(values):
+                raise GstarkError('a secret register holds a power-of-2 number of values dividing the trace length (it repeats cyclically)')
+        self.secretValues = [[v % f.modulus for v in values] for values in secret_values]
         n, nc = self.traceLength * self.extensionFactor, self.traceLength * self.compositionFactor
         self.firstRows = [[v % f.modulus for v in row] for row in first_rows]
         self.firstRow = self.firstRows[0]
         self.evaluationDomain = f.getPowerSeries(self.rootOfUnity, n)
         self.compositionDomain = f.getPowerSeries(f.exp(self.rootOfUnity, n // nc), nc)
         self.executionDomain = f.getPowerSeries(f.exp(self.rootOfUnity, self.extensionFactor), self.traceLength)
+        # secret registers (lib/Stark.ts:113): cyclic like the static ones, but known to the prover only — their low-degree
+        # extension is committed next to P(x) and their values reach the verifier inside the proof's leaves
+        secret_polys = []
+        for values in self.secretValues:
+            m = len(values)
+            g = f.exp(self.rootOfUnity, self.extensionFactor * (self.traceLength // m))
+            secret_polys.append(f.interpolateRoots(f.getPowerSeries(g, m), f.newVectorFrom(values)).toValues())
         self.secretRegisterTraces = []
+        for values, poly in zip(self.secretValues, secret_polys):
+            stride = self.traceLength // len(values)             # S(x) = K(x^stride): K's coefficients at multiples of stride
+            coeffs = [0] * self.traceLength
+            coeffs[::stride] = poly
+            self.secretRegisterTraces.append(f.evalPolyAtRoots(f.newVectorFrom(coeffs), self.evaluationDomain))
         # static registers over the composition domain: K_s at the (period * compositionFactor)-th roots of unity
-        lens = [len(v) * self.compositionFactor for v in air.staticRegisters]
+        all_values = list(air.staticRegisters) + self.secretValues
+        lens = [len(v) * self.compositionFactor for v in all_values]
         self._staticLens = lens
         self._staticTables = Vector(f.backend, max(sum(lens), 1))
         off = 0
-        for values, poly, ln in zip(air.staticRegisters, self._static_polys(), lens):
+        for values, poly, ln in zip(all_values, list(self._static_polys()) + secret_polys, lens):
             wk = f.exp(self.compositionDomain.series_base, self.traceLength // len(values))
             tab = f.evalPolyAtRoots(f.newVectorFrom(poly), f.getPowerSeries(wk, ln))
             f.backend.call('gs_copy', C.c_void_p(self._staticTables.ptr + off * 16), C.c_void_p(tab.ptr), ln * 16)
@@ -226,23 +248,24 @@ class GenericProvingContext(_Context):
         air, f = self.air, self.field
         code, ninstr, consts, nconsts, nregs = air.transitionProgram.abi_args()
         m = Matrix(f.backend, air.traceRegisterCount, self.traceLength)
-        svals = b''.join(_le(v % f.modulus) for values in air.staticRegisters for v in values) or bytes(16)
-        periods = (C.c_uint32 * max(len(air.staticRegisters), 1))(*[len(v) for v in air.staticRegisters])
+        statics = list(air.staticRegisters) + self.secretValues
+        svals = b''.join(_le(v % f.modulus) for values in statics for v in values) or bytes(16)
+        periods = (C.c_uint32 * max(len(statics), 1))(*[len(v) for v in statics])
         if air.segmentLength is None:
             f.backend.call('gs_air_trace', code, ninstr, consts, nconsts, nregs, air.traceRegisterCount, svals, periods,
-                           len(air.staticRegisters), b''.join(_le(v) for v in self.firstRow), self.traceLength, C.c_void_p(m.ptr))
+                           len(statics), b''.join(_le(v) for v in self.firstRow), self.traceLength, C.c_void_p(m.ptr))
         else:
             icode, ininstr = None, 0
             if air.initProgram is not None:
                 icode, ininstr = air.initProgram.abi_args()[:2]
             f.backend.call('gs_air_trace_segments', code, ninstr, icode, ininstr, consts, nconsts, nregs, air.traceRegisterCount, svals, periods,
-                           len(air.staticRegisters), b''.join(_le(v) for row in self.firstRows for v in row), len(self.firstRows),
+                           len(statics), b''.join(_le(v) for row in self.firstRows for v in row), len(self.firstRows),
                            air.segmentLength, C.c_void_p(m.ptr))
         return m
 
     def generateStaticTrace(self):
         f = self.field
-        return f.newMatrixFrom([[v[i % len(v)] for i in range(self.traceLength)] for v in self.air.staticRegisters])
+        return f.newMatrixFrom([[v[i % len(v)] for i in range(self.traceLength)] for v in list(self.air.staticRegisters) + self.secretValues])
 
     def evaluateTransitionConstraints(self, pPolys):   # CompositionPolynomial.ts:76
         air, f = self.air, self.field
@@ -265,17 +288,23 @@ class GenericAir:
     init(seed)          -> first row (list of ints)"""
 
     def __init__(self, steps, registers, constraintDegrees, staticRegisters, transition, evaluation, init, extensionFactor=None,
-                 field=None, segmentLength=None, initExpr=None):
+                 field=None, segmentLength=None, initExpr=None, secretRegisters=0):
         """segmentLength = L splits the trace into steps/L independent runs (AirScript's `for each (input)` loop over several
         inputs): `seed` is then a list of steps/L per-segment seeds, segment s starts from init(seed[s]) at step s*L, the
         transition constraints are switched off on the last step of every segment by one more cyclic static register
         (degree + 1), and the trace is generated on the device, one thread per segment (gs_air_trace_segments).
         initExpr(x) -> list of `registers` Expr over the raw inputs x[i] = reg(i): the `init { ... }` block as expressions, run
-        by the same device thread before the segment's first step (init(seed) then only returns the raw inputs, zero-padded)."""
+        by the same device thread before the segment's first step (init(seed) then only returns the raw inputs, zero-padded).
+        secretRegisters = S: the last S entries of the static-register list `k` seen by transition / evaluation are SECRET
+        registers (AirScript `secret input`, examples/mimc/mimc128.ts:38): cyclic columns supplied per proof through
+        `prove(assertions, inputs, seed)` (inputs = S lists of values), committed with the trace and read back by the verifier
+        from the proof (lib/Stark.ts:113-114, 284-313)."""
         self.field = field or PrimeField()
         f = self.field
         self.segmentLength = segmentLength
         if segmentLength is not None:
+            if secretRegisters:
+                raise GstarkError('secret registers and trace segments cannot be combined yet')
             if segmentLength < 2 or segmentLength & (segmentLength - 1) or steps % segmentLength:
                 raise GstarkError('segment length must be a power of 2 dividing the trace length')
             mask_index = len(staticRegisters)
@@ -293,7 +322,7 @@ class GenericAir:
         for values in staticRegisters:
             if len(values) & (len(values) - 1) or steps % len(values):
                 raise GstarkError('static register cycles must be powers of 2 dividing the trace length')
-        self.steps, self.traceRegisterCount, self.secretInputCount = steps, registers, 0
+        self.steps, self.traceRegisterCount, self.secretInputCount = steps, registers, int(secretRegisters)
         self.constraintDegrees = list(constraintDegrees)
         self.maxConstraintDegree = max(self.constraintDegrees)
         self.compositionFactor = 1 << (self.maxConstraintDegree - 1).bit_length()
@@ -306,7 +335,7 @@ class GenericAir:
         self.staticRegisters = [[v % f.modulus for v in values] for values in staticRegisters]
         r = [reg(i) for i in range(registers)]
         n = [nxt(i) for i in range(registers)]
-        k = [static(j) for j in range(len(staticRegisters))]
+        k = [static(j) for j in range(len(staticRegisters) + self.secretInputCount)]
         self.transitionProgram = Program(transition(r, k), f.modulus)
         self.evaluationProgram = Program(evaluation(r, n, k), f.modulus)
         if self.transitionProgram.nout != registers or self.evaluationProgram.nout != len(self.constraintDegrees):
@@ -339,19 +368,20 @@ class GenericAir:
         return rows
 
     def initProvingContext(self, inputs=None, seed=None):
-        return GenericProvingContext(self, self.firstRows(seed))
+        return GenericProvingContext(self, self.firstRows(seed), inputs)
 
     def initVerificationContext(self, inputShapes=None, publicInputs=None):
         return GenericVerificationContext(self)
 
-    def hostTrace(self, seed, steps=None):
+    def hostTrace(self, seed, steps=None, inputs=None):
         """Independent control computation on Python integers (the role of examples/rescue/utils.ts for the examples)."""
         p, out = self.field.modulus, []
+        statics = list(self.staticRegisters) + [[v % p for v in values] for values in (inputs or [])]
         firsts = self._hostFirstRows(seed)
         seg = self.segmentLength or self.steps
         for i in range(steps or self.steps):
             if i % seg == 0:
                 row = [v % p for v in firsts[i // seg]]
             out.append(row)
-            row = self.transitionProgram.run(row, None, [v[i % len(v)] for v in self.staticRegisters])
+            row = self.transitionProgram.run(row, None, [v[i % len(v)] for v in statics])
         return out

@@ -88,6 +88,8 @@ class NativeProver:
             self._rc = b''.join(_le(k) for k in air.roundConstants)
             self.rootOfUnity = ctx.rootOfUnity
         elif isinstance(air, GenericAir):
+            if air.secretInputCount:
+                raise GstarkError('the native driver does not commit secret registers yet: use Stark.prove()')
             rows = [[0] * air.traceRegisterCount]
             from .air_generic import GenericProvingContext
             ctx = GenericProvingContext(air, rows * (air.steps // air.segmentLength if air.segmentLength else 1))

@@ -350,3 +350,59 @@ def test_poseidon_hash_through_facade_oracle(oracle_backend):
 @pytest.mark.gpu
 def test_poseidon_hash_through_facade_hip(hip_backend):
     check_poseidon_hash_through_facade(hip_backend)
+
+
+# ---- secret registers (AirScript `secret input`, examples/mimc/mimc128.ts:38; lib/Stark.ts:113-114, 284-313) -------------
+def secret_air(field, steps=64, ef=16):
+    """MiMC-like chain keyed by a SECRET cyclic register: x' = x^3 + k_public + s_secret, y' = y + s_secret * x.  Two trace
+    registers, one public static register (period 8), two secret registers (periods 4 and steps): the leaves of the evaluation
+    tree hold P_0 | P_1 | S_0 | S_1 and the verifier takes S(x) from the proof."""
+    pub = [[(5 * i + 3) % 1009 for i in range(8)]]
+
+    def transition(r, k):
+        return [r[0] ** 3 + k[0] + k[1], r[1] + k[1] * r[0] + k[2]]
+
+    def evaluation(r, n, k):
+        t = transition(r, k)
+        return [n[0] - t[0], n[1] - t[1]]
+
+    return GenericAir(steps, 2, [3, 2], pub, transition, evaluation, lambda seed: [seed[0], seed[1]], ef, field, secretRegisters=2)
+
+
+def check_secret_registers(backend, steps=64):
+    f = PrimeField(backend=backend)
+    air = secret_air(f, steps)
+    assert air.secretInputCount == 2
+    stark = Stark(air, {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 30, 'friQueryCount': 20})
+    secrets = [[11, 22, 33, 44], [(7 * i * i + 1) % 100003 for i in range(steps)]]
+    full = air.hostTrace([3, 4], inputs=secrets)
+    trace = air.initProvingContext(secrets, [3, 4]).generateExecutionTrace().toValues()
+    assert trace == [list(r) for r in zip(*full)]
+    assertions = [{'step': 0, 'register': 0, 'value': 3}, {'step': steps - 1, 'register': 0, 'value': full[-1][0]},
+                  {'step': steps - 1, 'register': 1, 'value': full[-1][1]}]
+    proof = stark.prove(assertions, secrets, [3, 4])
+    assert len(proof['evProof']['values'][0]) == 4 * 16            # P_0 | P_1 | S_0 | S_1 per leaf (lib/Stark.ts:284-296)
+    data = stark.serialize(proof)
+    assert len(data) == stark.sizeOf(proof)
+    parsed = stark.parse(data)
+    assert stark.verify(assertions, parsed)
+    # the secret columns are bound: another secret gives another trace, and a proof with a doctored secret value is rejected
+    other = stark.prove([assertions[0]], [[11, 22, 33, 45], secrets[1]], [3, 4])
+    assert other['evRoot'] != proof['evRoot']
+    leaf = bytearray(parsed['evProof']['values'][0])
+    leaf[2 * 16] ^= 1                                               # first byte of S_0 at the first queried position
+    parsed['evProof']['values'][0] = bytes(leaf)
+    with pytest.raises(StarkError):
+        stark.verify(assertions, parsed)
+    with pytest.raises(Exception):
+        stark.prove(assertions, [secrets[0]], [3, 4])               # one secret register missing
+    return data
+
+
+def test_secret_registers_oracle(oracle_backend):
+    check_secret_registers(oracle_backend)
+
+
+@pytest.mark.gpu
+def test_secret_registers_hip_equals_oracle(hip_backend, oracle_backend):
+    assert check_secret_registers(hip_backend, 256) == check_secret_registers(oracle_backend, 256)
