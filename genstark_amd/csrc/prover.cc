@@ -230,6 +230,9 @@ struct gs_prover_air {
     const uint8_t *static_values; const uint32_t *static_periods; uint32_t nstatic;   // host, for the trace
     const void *static_tables; const uint64_t *static_lens;                           // device + host lens, for the evaluator
     const uint8_t *first_rows; uint64_t segments; uint64_t segment_len;               // segments = 0: one serial trace
+    // secret registers (lib/Stark.ts:113): their low-degree extensions over the evaluation domain, prepared by the caller;
+    // static_values / static_tables then hold the public registers followed by the secret ones
+    const void *const *secret_traces; uint32_t nsecret;
 };
 
 struct gs_prover_job {
@@ -369,12 +372,15 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     x.check(A.gs_eval_polys_at_roots(x.c, pPolys.p, R, T, s16, N, pEval.p), "gs_eval_polys_at_roots(P)");
     std::vector<const void *> pRows(R);
     for (uint32_t r = 0; r < R; r++) pRows[r] = pEval.at((uint64_t)r * N * ELEM);
+    std::vector<const void *> eVectors(pRows);                    // [P_0.., S_0..] (lib/Stark.ts:113-114)
+    for (uint32_t i = 0; i < air.nsecret; i++) eVectors.push_back(air.secret_traces[i]);
+    const uint32_t V = (uint32_t)eVectors.size();
 
     // 4 ----- evaluation Merkle tree (:113-118)
     Tree eTree;
     {
         Buf hashed(x, N * DIGEST);
-        x.check(A.gs_hash_merge_rows(x.c, (gs_hash_alg)alg, pRows.data(), R, N, hashed.p), "gs_hash_merge_rows");
+        x.check(A.gs_hash_merge_rows(x.c, (gs_hash_alg)alg, eVectors.data(), V, N, hashed.p), "gs_hash_merge_rows");
         eTree = build_tree(x, alg, std::move(hashed), N);
     }
 
@@ -510,12 +516,12 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     // 6 ----- random linear combination (LinearCombination.ts:36-64)
     Buf lEval(x, N * ELEM);
     {
-        std::vector<const void *> all(pRows.begin(), pRows.end());
+        std::vector<const void *> all(eVectors.begin(), eVectors.end());
         std::vector<Buf> ps2;
         if (b_inc > 0)                                             // psIncrementalDegree = compositionDegree - T, same powers
-            for (uint32_t r = 0; r < R; r++) {
+            for (uint32_t r = 0; r < V; r++) {
                 ps2.emplace_back(x, N * ELEM);
-                x.check(A.gs_vec_mul(x.c, pRows[r], psbPowers.p, N, ps2.back().p), "gs_vec_mul(P powers)");
+                x.check(A.gs_vec_mul(x.c, eVectors[r], psbPowers.p, N, ps2.back().p), "gs_vec_mul(P powers)");
                 all.push_back(ps2.back().p);
             }
         const uint32_t offset = dcount + bcoef, cnt = (uint32_t)all.size();
@@ -641,11 +647,11 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     MerkleProof evProof = prove_batch(x, eTree, aug);
     {
         std::vector<std::vector<Bytes>> cols;
-        for (uint32_t r = 0; r < R; r++) cols.push_back(gather(x, pRows[r], ELEM, aug));
+        for (uint32_t r = 0; r < V; r++) cols.push_back(gather(x, eVectors[r], ELEM, aug));
         evProof.values.clear();
         for (size_t i = 0; i < aug.size(); i++) {
             Bytes v;
-            for (uint32_t r = 0; r < R; r++) v.insert(v.end(), cols[r][i].begin(), cols[r][i].end());
+            for (uint32_t r = 0; r < V; r++) v.insert(v.end(), cols[r][i].begin(), cols[r][i].end());
             evProof.values.push_back(v);
         }
     }
@@ -653,7 +659,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     // ----- Serializer.serializeProof (:35-79)
     out.clear();
     out.insert(out.end(), eTree.root.begin(), eTree.root.end());
-    write_merkle_proof(out, evProof, (uint64_t)R * ELEM);
+    write_merkle_proof(out, evProof, (uint64_t)V * ELEM);
     out.insert(out.end(), pTree0.root.begin(), pTree0.root.end());
     write_merkle_proof(out, lcProof, 4 * ELEM);
     if (components.size() > 255) fail(GS_ERR_ARG, "too many FRI components");

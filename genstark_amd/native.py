@@ -29,7 +29,7 @@ class _Air(C.Structure):
                 ('e_code', C.POINTER(C.c_uint32)), ('e_ninstr', C.c_uint32), ('consts', C.c_char_p), ('nconsts', C.c_uint32),
                 ('vm_regs', C.c_uint32), ('static_values', C.c_char_p), ('static_periods', C.POINTER(C.c_uint32)), ('nstatic', C.c_uint32),
                 ('static_tables', C.c_void_p), ('static_lens', C.POINTER(C.c_uint64)), ('first_rows', C.c_char_p), ('segments', C.c_uint64),
-                ('segment_len', C.c_uint64)]
+                ('segment_len', C.c_uint64), ('secret_traces', C.POINTER(C.c_void_p)), ('nsecret', C.c_uint32)]
 
 
 class _Job(C.Structure):
@@ -88,13 +88,12 @@ class NativeProver:
             self._rc = b''.join(_le(k) for k in air.roundConstants)
             self.rootOfUnity = ctx.rootOfUnity
         elif isinstance(air, GenericAir):
-            if air.secretInputCount:
-                raise GstarkError('the native driver does not commit secret registers yet: use Stark.prove()')
             rows = [[0] * air.traceRegisterCount]
             from .air_generic import GenericProvingContext
-            ctx = GenericProvingContext(air, rows * (air.steps // air.segmentLength if air.segmentLength else 1))
             self.kind, self.degrees = 1, list(air.constraintDegrees)
-            self._tables, self._lens = ctx._staticTables, ctx._staticLens
+            if not air.secretInputCount:      # public static registers only: the tables are constants of the AIR
+                ctx = GenericProvingContext(air, rows * (air.steps // air.segmentLength if air.segmentLength else 1))
+                self._tables, self._lens = ctx._staticTables, ctx._staticLens
             self.rootOfUnity = air.rootOfUnity
         else:
             raise GstarkError('the native driver knows the MiMC AIR and GenericAir')
@@ -154,12 +153,24 @@ class NativeProver:
                 ja.i_code, ja.i_ninstr = i_code, i_n
                 keep.append(i_code)
                 ja.vm_regs = max(ja.vm_regs, air.initProgram.nregs)
-            svals = b''.join(_le(v % f.modulus) for values in air.staticRegisters for v in values) or bytes(16)
-            periods = (C.c_uint32 * max(len(air.staticRegisters), 1))(*[len(v) for v in air.staticRegisters])
-            lens = (C.c_uint64 * max(len(self._lens), 1))(*self._lens)
-            ja.static_values, ja.static_periods, ja.nstatic = svals, periods, len(air.staticRegisters)
-            ja.static_tables, ja.static_lens = self._tables.ptr, lens
             rows = air.firstRows(seed)
+            statics, tables, table_lens = list(air.staticRegisters), None, None
+            if air.secretInputCount:
+                # secret registers come with the proof's inputs: their tables and low-degree extensions are per-proof device data
+                from .air_generic import GenericProvingContext
+                ctx = GenericProvingContext(air, rows, inputs)
+                statics += ctx.secretValues
+                tables, table_lens = ctx._staticTables, ctx._staticLens
+                straces = (C.c_void_p * air.secretInputCount)(*[v.ptr for v in ctx.secretRegisterTraces])
+                ja.secret_traces, ja.nsecret = straces, air.secretInputCount
+                keep += [ctx, straces]
+            else:
+                tables, table_lens = self._tables, self._lens
+            svals = b''.join(_le(v % f.modulus) for values in statics for v in values) or bytes(16)
+            periods = (C.c_uint32 * max(len(statics), 1))(*[len(v) for v in statics])
+            lens = (C.c_uint64 * max(len(table_lens), 1))(*table_lens)
+            ja.static_values, ja.static_periods, ja.nstatic = svals, periods, len(statics)
+            ja.static_tables, ja.static_lens = tables.ptr, lens
             first = b''.join(_le(v % f.modulus) for row in rows for v in row)
             ja.first_rows = first
             ja.segments, ja.segment_len = (len(rows), air.segmentLength) if air.segmentLength else (0, 0)

@@ -71,15 +71,21 @@ def generic_cases(backend):
                 air.hostTrace([5]), [(0, r) for r in range(6)] + [(63, 4), (32, 4)]))
     air = foo_air(f)
     out.append(('foo', Stark(air, None), [1], air.hostTrace([1]), [(0, 0), (63, 0)]))
+    from test_generic_air import secret_air
+    air = secret_air(f, 64)
+    secrets = [[11, 22, 33, 44], [(7 * i * i + 1) % 100003 for i in range(64)]]
+    out.append(('secret-registers', Stark(air, {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 30, 'friQueryCount': 20}),
+                [3, 4], air.hostTrace([3, 4], inputs=secrets), [(0, 0), (63, 0), (63, 1)], secrets))
     return out
 
 
 def check_generic(backend):
     digests = {}
-    for name, stark, seed, trace, points in generic_cases(backend):
+    for name, stark, seed, trace, points, *rest in generic_cases(backend):
+        inputs = rest[0] if rest else []
         assertions = [{'step': s, 'register': r, 'value': trace[s][r]} for s, r in points]
-        want = stark.serialize(stark.prove(assertions, [], seed))
-        got = NativeProver(stark).prove_bytes(assertions, [], seed)
+        want = stark.serialize(stark.prove(assertions, inputs, seed))
+        got = NativeProver(stark).prove_bytes(assertions, inputs, seed)
         assert got == want, name
         assert stark.verify(assertions, stark.parse(got)), name
         digests[name] = hashlib.sha256(got).hexdigest()
