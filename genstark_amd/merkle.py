@@ -5,6 +5,7 @@ the few hundred digests a batch proof needs are gathered back to the host.
 Call sites: lib/Stark.ts:50,115,118,150,206; lib/components/LowDegreeProver.ts:45-53,163-164,201-217.
 """
 import ctypes as C
+import hashlib
 
 from ._abi import HASH_ALGS, Backend, GstarkError
 from .field import Vector
@@ -19,9 +20,15 @@ class Hash:
         self.algorithm, self.alg, self.backend = algorithm, HASH_ALGS[algorithm], backend
         self.digestSize = DIGEST_SIZE
         self.isOptimized = True  # lib/Stark.ts:51
+        self._host = hashlib.sha256 if algorithm == 'sha256' else (lambda data: hashlib.blake2s(data, digest_size=32))
 
     def digest(self, value):
-        """Hash.digest(Buffer) -> Buffer (lib/utils/index.ts:37)."""
+        """Hash.digest(Buffer) -> Buffer (lib/utils/index.ts:37).  Host buffers are hashed on the host by the language
+        runtime, like the reference's verifier does (a few hundred leaves and nodes of a proof; lib/Stark.ts:167-248 never
+        needs the device); `digestOnDevice` keeps the library's gs_hash_digest reachable for the parity tests."""
+        return self._host(bytes(value)).digest()
+
+    def digestOnDevice(self, value):
         out = C.create_string_buffer(32)
         self.backend.call('gs_hash_digest', self.alg, bytes(value), len(value), C.cast(out, C.c_void_p))
         return out.raw
@@ -30,15 +37,9 @@ class Hash:
         return self.digest(bytes(a) + bytes(b))
 
     def digestMany(self, messages):
-        """Digests of a list of equal-length host messages in one upload / kernel / download (verifier side:
-        rehashMerkleProofValues and the per-level merges of verifyBatch)."""
-        if not messages:
-            return []
-        size = len(messages[0])
-        if any(len(m) != size for m in messages):
-            return [self.digest(m) for m in messages]
-        raw = self.digestValues(b''.join(bytes(m) for m in messages), size).toBuffer()
-        return [raw[i * DIGEST_SIZE:(i + 1) * DIGEST_SIZE] for i in range(len(messages))]
+        """Digests of a list of host messages (verifier side: rehashMerkleProofValues, the per-level merges of verifyBatch)."""
+        host = self._host
+        return [host(bytes(m)).digest() for m in messages]
 
     def mergeVectorRows(self, vectors):
         """lib/Stark.ts:115 — out[i] = H(v_0[i] || v_1[i] || ...), a Vector of 32-byte digests."""
