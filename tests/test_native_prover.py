@@ -71,6 +71,17 @@ def generic_cases(backend):
                 air.hostTrace([5]), [(0, r) for r in range(6)] + [(63, 4), (32, 4)]))
     air = foo_air(f)
     out.append(('foo', Stark(air, None), [1], air.hostTrace([1]), [(0, 0), (63, 0)]))
+    # assembly/lib128.aa: ComputePoseidonHash (two hashes) and ComputeMerkleRoot (depth 4) with their input registers
+    from genstark_amd import lib128
+    from test_lib128 import OPTS as LIB_OPTS, merkle_case
+    air = lib128.compute_poseidon_hash_air(f, 2)
+    raw = [[42, 52], [43, 44], [44, 44], [45, 46]]
+    cols = air.expandInputs(raw)
+    out.append(('lib128-hash', Stark(air, LIB_OPTS), [c[0] for c in raw], air.hostTrace([c[0] for c in raw], inputs=cols), [(63, 0), (127, 1)], cols))
+    tree, leaf, nodes, bits = merkle_case(f, 4, 5)
+    air = lib128.compute_merkle_root_air(f, bits)
+    cols, first = lib128.merkle_inputs(f, leaf, nodes)
+    out.append(('lib128-merkle', Stark(air, LIB_OPTS), first, air.hostTrace(first, inputs=cols), [(255, 0), (255, 1)], cols))
     from test_generic_air import secret_air
     air = secret_air(f, 64)
     secrets = [[11, 22, 33, 44], [(7 * i * i + 1) % 100003 for i in range(64)]]
