@@ -288,7 +288,7 @@ class GenericAir:
     init(seed)          -> first row (list of ints)"""
 
     def __init__(self, steps, registers, constraintDegrees, staticRegisters, transition, evaluation, init, extensionFactor=None,
-                 field=None, segmentLength=None, initExpr=None, secretRegisters=0):
+                 field=None, segmentLength=None, initExpr=None, secretRegisters=0, maskSegments=True):
         """segmentLength = L splits the trace into steps/L independent runs (AirScript's `for each (input)` loop over several
         inputs): `seed` is then a list of steps/L per-segment seeds, segment s starts from init(seed[s]) at step s*L, the
         transition constraints are switched off on the last step of every segment by one more cyclic static register
@@ -302,11 +302,14 @@ class GenericAir:
         self.field = field or PrimeField()
         f = self.field
         self.segmentLength = segmentLength
-        if segmentLength is not None:
+        if segmentLength is not None and (segmentLength < 2 or segmentLength & (segmentLength - 1) or steps % segmentLength):
+            raise GstarkError('segment length must be a power of 2 dividing the trace length')
+        # maskSegments=False: the AIR's own transition restarts every segment from init(segment seed) (AirAssembly's mask /
+        # input registers, e.g. assembly/lib128.aa:99-108), segmentLength then only tells the trace generator that the
+        # segments can be computed independently, one device thread each
+        if segmentLength is not None and maskSegments:
             if secretRegisters:
-                raise GstarkError('secret registers and trace segments cannot be combined yet')
-            if segmentLength < 2 or segmentLength & (segmentLength - 1) or steps % segmentLength:
-                raise GstarkError('segment length must be a power of 2 dividing the trace length')
+                raise GstarkError('secret registers and masked trace segments cannot be combined')
             mask_index = len(staticRegisters)
             staticRegisters = list(staticRegisters) + [[0] * (segmentLength - 1) + [1]]
             constraintDegrees = [d + 1 for d in constraintDegrees]

@@ -72,9 +72,10 @@ def segment_mask(steps):
 
 
 def compute_poseidon_hash_air(field, hashes=1, extensionFactor=32):
-    """lib128.aa:81-123.  prove(assertions, inputs, seed): inputs = the four secret input registers, each a list of `hashes`
-    values (lib128.ts:61: [[42n], [43n], [44n], [45n]]); seed = the first row's inputs is taken from them.  The digest of
-    hash number s is in registers 0, 1 at step 64*s + 63."""
+    """lib128.aa:81-123.  prove(assertions, air.expandInputs(raw), air.segmentSeeds(raw)) with raw = the four secret input
+    registers, each a list of `hashes` values (lib128.ts:61: [[42n], [43n], [44n], [45n]]).  The digest of hash number s is in
+    registers 0, 1 at step 64*s + 63.  The transition itself restarts every 64-step segment from the next inputs (mask
+    register), so the segments are independent and the device generates them in parallel."""
     total = ROUND_STEPS * hashes
     rc = round_constant_columns(field)
     public = [segment_mask(ROUND_STEPS), round_controls()] + rc          # k[0] mask, k[1] round kind, k[2..7] round constants
@@ -90,8 +91,9 @@ def compute_poseidon_hash_air(field, hashes=1, extensionFactor=32):
         return [a - b for a, b in zip(n, transition(r, k))]
 
     air = GenericAir(total, STATE_WIDTH, [7] * STATE_WIDTH, public, transition, evaluation, lambda seed: list(seed) + [0, 0],
-                     extensionFactor, field, secretRegisters=4)
+                     extensionFactor, field, secretRegisters=4, segmentLength=ROUND_STEPS, maskSegments=False)
     air.expandInputs = lambda inputs: [held([v % field.modulus for v in col], ROUND_STEPS, total) for col in inputs]
+    air.segmentSeeds = lambda inputs: [[col[s] for col in inputs] for s in range(hashes)]
     return air
 
 

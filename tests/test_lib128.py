@@ -17,7 +17,7 @@ def check_hash(backend, hashes):
     f = PrimeField(backend=backend)
     air = lib128.compute_poseidon_hash_air(f, hashes)
     raw = [[42 + 10 * s for s in range(hashes)], [43 + s for s in range(hashes)], [44] * hashes, [45 + s * s for s in range(hashes)]]   # lib128.ts:61
-    inputs, seed = air.expandInputs(raw), [col[0] for col in raw]
+    inputs, seed = air.expandInputs(raw), air.segmentSeeds(raw)
     stark = Stark(air, OPTS)
     trace = air.hostTrace(seed, inputs=inputs)
     assertions = []

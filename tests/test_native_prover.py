@@ -77,7 +77,7 @@ def generic_cases(backend):
     air = lib128.compute_poseidon_hash_air(f, 2)
     raw = [[42, 52], [43, 44], [44, 44], [45, 46]]
     cols = air.expandInputs(raw)
-    out.append(('lib128-hash', Stark(air, LIB_OPTS), [c[0] for c in raw], air.hostTrace([c[0] for c in raw], inputs=cols), [(63, 0), (127, 1)], cols))
+    out.append(('lib128-hash', Stark(air, LIB_OPTS), air.segmentSeeds(raw), air.hostTrace(air.segmentSeeds(raw), inputs=cols), [(63, 0), (127, 1)], cols))
     tree, leaf, nodes, bits = merkle_case(f, 4, 5)
     air = lib128.compute_merkle_root_air(f, bits)
     cols, first = lib128.merkle_inputs(f, leaf, nodes)
