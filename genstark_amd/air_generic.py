@@ -202,17 +202,37 @@ class GenericVerificationContext(_Context):
         return self.air.evaluationProgram.run(rValues, nValues, statics + [v % f.modulus for v in hValues])
 
 
+class PackedColumn:
+    """A column of field elements as packed 16-byte little-endian words: what a secret register of 2^16 values should travel as
+    (packing 262 144 Python integers per proof costs more than the proof)."""
+
+    def __init__(self, data):
+        if len(data) % 16:
+            raise GstarkError('packed column: length must be a multiple of 16 bytes')
+        self.data = bytes(data)
+
+    def __len__(self):
+        return len(self.data) // 16
+
+    def ints(self):
+        return [int.from_bytes(self.data[i:i + 16], 'little') for i in range(0, len(self.data), 16)]
+
+    @staticmethod
+    def of(values, modulus):
+        return values if isinstance(values, PackedColumn) else PackedColumn(b''.join(_le(v % modulus) for v in values))
+
+
 class GenericProvingContext(_Context):
     def __init__(self, air, first_rows, secret_values=None):
         super().__init__(air)
         f = self.field
-        secret_values = [list(v) for v in (secret_values or [])]
+        secret_values = list(secret_values or [])
         if len(secret_values) != air.secretInputCount:
             raise GstarkError(f'the AIR has {air.secretInputCount} secret registers: `inputs` must hold one list of values for each')
         for values in secret_values:
-            if not values or len(values) & (len(values) - 1) or self.traceLength % len(values):
+            if not len(values) or len(values) & (len(values) - 1) or self.traceLength % len(values):
                 raise GstarkError('a secret register holds a power-of-2 number of values dividing the trace length (it repeats cyclically)')
-        self.secretValues = [[v % f.modulus for v in values] for values in secret_values]
+        self.secretValues = [PackedColumn.of(values, f.modulus) for values in secret_values]
         n, nc = self.traceLength * self.extensionFactor, self.traceLength * self.compositionFactor
         self.firstRows = [[v % f.modulus for v in row] for row in first_rows]
         self.firstRow = self.firstRows[0]
@@ -221,36 +241,48 @@ class GenericProvingContext(_Context):
         self.executionDomain = f.getPowerSeries(f.exp(self.rootOfUnity, self.extensionFactor), self.traceLength)
         # secret registers (lib/Stark.ts:113): cyclic like the static ones, but known to the prover only — their low-degree
         # extension is committed next to P(x) and their values reach the verifier inside the proof's leaves
-        secret_polys = []
-        for values in self.secretValues:
-            m = len(values)
+        secret_polys = []                                        # device vectors of K_s' coefficients
+        for col in self.secretValues:
+            m = len(col)
             g = f.exp(self.rootOfUnity, self.extensionFactor * (self.traceLength // m))
-            secret_polys.append(f.interpolateRoots(f.getPowerSeries(g, m), f.newVectorFrom(values)).toValues())
+            values = Vector(f.backend, m)
+            f.backend.upload(values.ptr, col.data)
+            secret_polys.append(f.interpolateRoots(f.getPowerSeries(g, m), values))
         self.secretRegisterTraces = []
-        for values, poly in zip(self.secretValues, secret_polys):
-            stride = self.traceLength // len(values)             # S(x) = K(x^stride): K's coefficients at multiples of stride
-            coeffs = [0] * self.traceLength
-            coeffs[::stride] = poly
-            self.secretRegisterTraces.append(f.evalPolyAtRoots(f.newVectorFrom(coeffs), self.evaluationDomain))
+        for col, poly in zip(self.secretValues, secret_polys):
+            stride = self.traceLength // len(col)                # S(x) = K(x^stride): K's coefficients at multiples of stride
+            if stride > 1:
+                coeffs = [0] * self.traceLength
+                coeffs[::stride] = poly.toValues()
+                poly = f.newVectorFrom(coeffs)
+            self.secretRegisterTraces.append(f.evalPolyAtRoots(poly, self.evaluationDomain))
         # static registers over the composition domain: K_s at the (period * compositionFactor)-th roots of unity
-        all_values = list(air.staticRegisters) + self.secretValues
-        lens = [len(v) * self.compositionFactor for v in all_values]
+        all_polys = [(len(v), f.newVectorFrom(p)) for v, p in zip(air.staticRegisters, self._static_polys())] + \
+                    [(len(c), p) for c, p in zip(self.secretValues, secret_polys)]
+        lens = [m * self.compositionFactor for m, _ in all_polys]
         self._staticLens = lens
         self._staticTables = Vector(f.backend, max(sum(lens), 1))
         off = 0
-        for values, poly, ln in zip(all_values, list(self._static_polys()) + secret_polys, lens):
-            wk = f.exp(self.compositionDomain.series_base, self.traceLength // len(values))
-            tab = f.evalPolyAtRoots(f.newVectorFrom(poly), f.getPowerSeries(wk, ln))
+        for (m, poly), ln in zip(all_polys, lens):
+            wk = f.exp(self.compositionDomain.series_base, self.traceLength // m)
+            tab = f.evalPolyAtRoots(poly, f.getPowerSeries(wk, ln))
             f.backend.call('gs_copy', C.c_void_p(self._staticTables.ptr + off * 16), C.c_void_p(tab.ptr), ln * 16)
             off += ln
+
+    def staticValuesPacked(self):
+        """(bytes, periods) of every static register's values for the trace generators: public ones, then the secret columns."""
+        air, f = self.air, self.field
+        packed = b''.join(_le(v % f.modulus) for values in air.staticRegisters for v in values) + b''.join(c.data for c in self.secretValues)
+        periods = [len(v) for v in air.staticRegisters] + [len(c) for c in self.secretValues]
+        return packed or bytes(16), periods
 
     def generateExecutionTrace(self):   # lib/Stark.ts:97
         air, f = self.air, self.field
         code, ninstr, consts, nconsts, nregs = air.transitionProgram.abi_args()
         m = Matrix(f.backend, air.traceRegisterCount, self.traceLength)
-        statics = list(air.staticRegisters) + self.secretValues
-        svals = b''.join(_le(v % f.modulus) for values in statics for v in values) or bytes(16)
-        periods = (C.c_uint32 * max(len(statics), 1))(*[len(v) for v in statics])
+        svals, plist = self.staticValuesPacked()
+        statics = plist
+        periods = (C.c_uint32 * max(len(plist), 1))(*plist)
         if air.segmentLength is None:
             f.backend.call('gs_air_trace', code, ninstr, consts, nconsts, nregs, air.traceRegisterCount, svals, periods,
                            len(statics), b''.join(_le(v) for v in self.firstRow), self.traceLength, C.c_void_p(m.ptr))
@@ -265,7 +297,8 @@ class GenericProvingContext(_Context):
 
     def generateStaticTrace(self):
         f = self.field
-        return f.newMatrixFrom([[v[i % len(v)] for i in range(self.traceLength)] for v in list(self.air.staticRegisters) + self.secretValues])
+        cols = list(self.air.staticRegisters) + [c.ints() for c in self.secretValues]
+        return f.newMatrixFrom([[v[i % len(v)] for i in range(self.traceLength)] for v in cols])
 
     def evaluateTransitionConstraints(self, pPolys):   # CompositionPolynomial.ts:76
         air, f = self.air, self.field
@@ -379,7 +412,8 @@ class GenericAir:
     def hostTrace(self, seed, steps=None, inputs=None):
         """Independent control computation on Python integers (the role of examples/rescue/utils.ts for the examples)."""
         p, out = self.field.modulus, []
-        statics = list(self.staticRegisters) + [[v % p for v in values] for values in (inputs or [])]
+        statics = list(self.staticRegisters) + [values.ints() if isinstance(values, PackedColumn) else [v % p for v in values]
+                                                for values in (inputs or [])]
         firsts = self._hostFirstRows(seed)
         seg = self.segmentLength or self.steps
         for i in range(steps or self.steps):

@@ -17,7 +17,7 @@ restatement as the MiMC constants, genstark_amd/air.py: sha256_prng; the example
 generator, examples/assembly/lib128.ts:21-28, so the known answers below do not depend on it).
 """
 from .air import sha256_prng
-from .air_generic import GenericAir, mat_vec
+from .air_generic import GenericAir, PackedColumn, mat_vec
 from .poseidon import F_ROUNDS, P_ROUNDS, STATE_WIDTH, round_controls
 
 ROUND_STEPS = F_ROUNDS + P_ROUNDS + 1      # 64
@@ -66,6 +66,14 @@ def held(values, steps, total, shift=-1):
     return [values[((i - shift) // steps) % len(values)] for i in range(total)]
 
 
+def held_packed(values, steps, modulus):
+    """held(values, steps, len(values) * steps) as a PackedColumn, built on bytes (one input per 64-step hash: 2^16 steps = 1 024
+    values to pack instead of 65 536)."""
+    words = [int(v % modulus).to_bytes(16, 'little') for v in values]
+    flat = b''.join(w * steps for w in words)
+    return PackedColumn(flat[16:] + flat[:16])               # the rotation by one step of `(shift -1)`
+
+
 def segment_mask(steps):
     """`(mask (input i))` for an input held `steps` steps and rotated by -1: 1 on the last step of every segment."""
     return [0] * (steps - 1) + [1]
@@ -92,7 +100,7 @@ def compute_poseidon_hash_air(field, hashes=1, extensionFactor=32):
 
     air = GenericAir(total, STATE_WIDTH, [7] * STATE_WIDTH, public, transition, evaluation, lambda seed: list(seed) + [0, 0],
                      extensionFactor, field, secretRegisters=4, segmentLength=ROUND_STEPS, maskSegments=False)
-    air.expandInputs = lambda inputs: [held([v % field.modulus for v in col], ROUND_STEPS, total) for col in inputs]
+    air.expandInputs = lambda inputs: [held_packed(col, ROUND_STEPS, field.modulus) for col in inputs]
     air.segmentSeeds = lambda inputs: [[col[s] for col in inputs] for s in range(hashes)]
     return air
 

@@ -154,22 +154,22 @@ class NativeProver:
                 keep.append(i_code)
                 ja.vm_regs = max(ja.vm_regs, air.initProgram.nregs)
             rows = air.firstRows(seed)
-            statics, tables, table_lens = list(air.staticRegisters), None, None
             if air.secretInputCount:
                 # secret registers come with the proof's inputs: their tables and low-degree extensions are per-proof device data
                 from .air_generic import GenericProvingContext
                 ctx = GenericProvingContext(air, rows, inputs)
-                statics += ctx.secretValues
+                svals, plist = ctx.staticValuesPacked()
                 tables, table_lens = ctx._staticTables, ctx._staticLens
                 straces = (C.c_void_p * air.secretInputCount)(*[v.ptr for v in ctx.secretRegisterTraces])
                 ja.secret_traces, ja.nsecret = straces, air.secretInputCount
                 keep += [ctx, straces]
             else:
                 tables, table_lens = self._tables, self._lens
-            svals = b''.join(_le(v % f.modulus) for values in statics for v in values) or bytes(16)
-            periods = (C.c_uint32 * max(len(statics), 1))(*[len(v) for v in statics])
+                svals = b''.join(_le(v % f.modulus) for values in air.staticRegisters for v in values) or bytes(16)
+                plist = [len(v) for v in air.staticRegisters]
+            periods = (C.c_uint32 * max(len(plist), 1))(*plist)
             lens = (C.c_uint64 * max(len(table_lens), 1))(*table_lens)
-            ja.static_values, ja.static_periods, ja.nstatic = svals, periods, len(statics)
+            ja.static_values, ja.static_periods, ja.nstatic = svals, periods, len(plist)
             ja.static_tables, ja.static_lens = tables.ptr, lens
             first = b''.join(_le(v % f.modulus) for row in rows for v in row)
             ja.first_rows = first
