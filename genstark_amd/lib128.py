@@ -122,17 +122,53 @@ def compute_merkle_root_air(field, index_bits, extensionFactor=32):
         s = k[npub:npub + 4]
         return [s[0], s[1], s[2], s[3], k[0], k[1], k[2], k[3]] + list(k[4:10])
 
-    def merkle_transition(r, k):                                           # lib128.aa:48-77 ($merkleTransition)
-        h1 = poseidon_round(r[0:6], k[8:14], k[7])
-        h2 = poseidon_round(r[6:12], k[8:14], k[7])
-        h = [r[6] * k[4] + r[0] * (1 - k[4]), r[7] * k[4] + r[1] * (1 - k[4])]
-        a = init_merkle_hash(k[0:2], k[1:3])                               # as written in lib128.aa:66 (slices 0..1 and 1..2)
-        b = init_merkle_hash(h, k[2:4])
-        return [x * k[5] + (y * ((1 - k[5]) * k[6]) + z * ((1 - k[5]) * (1 - k[6]))) for x, y, z in zip(a, b, h1 + h2)]
-
-    transition = lambda r, k: merkle_transition(r, lib_order(k))
+    transition = lambda r, k: _merkle_transition(r, lib_order(k))
     evaluation = lambda r, n, k: [a - b for a, b in zip(n, transition(r, k))]
     return GenericAir(total, 12, [8] * 12, public, transition, evaluation, lambda seed: list(seed), extensionFactor, field, secretRegisters=4)
+
+
+def _merkle_transition(r, k):                 # lib128.aa:48-77 ($merkleTransition), k in the library's order (14 values)
+    h1 = poseidon_round(r[0:6], k[8:14], k[7])
+    h2 = poseidon_round(r[6:12], k[8:14], k[7])
+    h = [r[6] * k[4] + r[0] * (1 - k[4]), r[7] * k[4] + r[1] * (1 - k[4])]
+    a = init_merkle_hash(k[0:2], k[1:3])      # as written in lib128.aa:66 (slices 0..1 and 1..2)
+    b = init_merkle_hash(h, k[2:4])
+    return [x * k[5] + (y * ((1 - k[5]) * k[6]) + z * ((1 - k[5]) * (1 - k[6]))) for x, y, z in zip(a, b, h1 + h2)]
+
+
+def compute_merkle_update_air(field, depth, extensionFactor=32):
+    """lib128.aa:152-203 (ComputeMerkleUpdate): the authentication paths of an old and a new leaf at the same (SECRET) index run
+    side by side — 24 registers, 24 transition constraints + `bit^2 = bit`.  Secret columns from merkle_update_inputs(); the old
+    root is in registers 0, 1 and the new root in registers 12, 13 at step 64*depth - 1 (lib128.ts:150-155)."""
+    total = ROUND_STEPS * depth
+    public = [segment_mask(total), segment_mask(ROUND_STEPS), round_controls()] + round_constant_columns(field)   # masks, round kind, constants
+    npub = len(public)
+
+    def halves(k):
+        s = k[npub:npub + 7]                  # oldLeaf 1,2  newLeaf 1,2  nodes 1,2  index bit
+        shared = [s[4], s[5], s[6]] + list(k[0:npub])
+        return [s[0], s[1]] + shared, [s[2], s[3]] + shared
+
+    def transition(r, k):                     # :179-187
+        old, new = halves(k)
+        return _merkle_transition(r[0:12], old) + _merkle_transition(r[12:24], new)
+
+    def evaluation(r, n, k):                  # :188-203
+        bit = k[npub + 6]
+        return [a - b for a, b in zip(n, transition(r, k))] + [bit ** 2 - bit]
+
+    return GenericAir(total, 24, [8] * 24 + [2], public, transition, evaluation, lambda seed: list(seed), extensionFactor, field, secretRegisters=7)
+
+
+def merkle_update_inputs(field, old_leaf, new_leaf, nodes, index_bits):
+    """Secret columns and first row (lib128.aa:175-178) of ComputeMerkleUpdate."""
+    depth = len(nodes)
+    total = ROUND_STEPS * depth
+    one = lambda v: held([v], total, total)
+    cols = [one(old_leaf[0]), one(old_leaf[1]), one(new_leaf[0]), one(new_leaf[1]), held([n[0] for n in nodes], ROUND_STEPS, total),
+            held([n[1] for n in nodes], ROUND_STEPS, total), held(list(index_bits), ROUND_STEPS, total)]
+    first = init_merkle_hash(old_leaf, nodes[0]) + init_merkle_hash(new_leaf, nodes[0])
+    return [[v % field.modulus for v in c] for c in cols], [v % field.modulus for v in first]
 
 
 def merkle_inputs(field, leaf, nodes):

@@ -88,3 +88,45 @@ def test_lib128_hip_equals_oracle(hip_backend, oracle_backend):
 def test_compute_merkle_root_depth8_hip(hip_backend):
     """lib128.ts:77-117 as it stands: tree depth 8, index 42 -> 512 steps, 12 registers, extension factor 32."""
     check_merkle(hip_backend, 8, 42)
+
+
+def check_merkle_update(backend, depth, index):
+    """lib128.ts:119-167: the same leaf position before and after an update; both roots come out of one 24-register trace."""
+    f = PrimeField(backend=backend)
+    old_value, new_value = (9, 10), (11, 12)                                    # lib128.ts:125
+    tree1, _, nodes, bits = merkle_case(f, depth, index)
+    leaves = [tree1.nodes[(1 << depth) + i] for i in range(1 << depth)]
+    leaves[index] = old_value
+    tree1 = lib128.PoseidonMerkleTree(f, leaves)
+    leaves2 = list(leaves)
+    leaves2[index] = new_value
+    tree2 = lib128.PoseidonMerkleTree(f, leaves2)
+    path1, path2 = tree1.prove(index), tree2.prove(index)
+    assert path1[1:] == path2[1:] and path1[0] == old_value and path2[0] == new_value
+    air = lib128.compute_merkle_update_air(f, depth)
+    inputs, first = lib128.merkle_update_inputs(f, old_value, new_value, path1[1:], bits)
+    trace = air.hostTrace(first, inputs=inputs)
+    last = 64 * depth - 1
+    assert tuple(trace[last][0:2]) == tree1.root and tuple(trace[last][12:14]) == tree2.root
+    stark = Stark(air, OPTS)
+    assertions = [{'step': last, 'register': 0, 'value': tree1.root[0]}, {'step': last, 'register': 1, 'value': tree1.root[1]},
+                  {'step': last, 'register': 12, 'value': tree2.root[0]}, {'step': last, 'register': 13, 'value': tree2.root[1]}]   # lib128.ts:150-155
+    proof = stark.prove(assertions, inputs, first)
+    data = stark.serialize(proof)
+    assert len(data) == stark.sizeOf(proof) and stark.verify(assertions, stark.parse(data))
+    assert len(proof['evProof']['values'][0]) == (24 + 7) * 16
+    # an index "bit" that is not binary breaks the 25th constraint: the prover's own remainder check refuses the proof
+    bad = [list(c) for c in inputs]
+    bad[6] = [2 if v else 0 for v in bad[6]]
+    with pytest.raises(StarkError, match='Low degree proof failed'):
+        stark.prove([{'step': 0, 'register': 0, 'value': first[0]}], bad, first)      # the trace itself is consistent with `bad`
+    return data
+
+
+def test_compute_merkle_update_oracle(oracle_backend):
+    check_merkle_update(oracle_backend, 4, 5)
+
+
+@pytest.mark.gpu
+def test_compute_merkle_update_hip_equals_oracle(hip_backend, oracle_backend):
+    assert check_merkle_update(hip_backend, 4, 6) == check_merkle_update(oracle_backend, 4, 6)
