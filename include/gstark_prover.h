@@ -1,0 +1,70 @@
+/* gstark_prover.h — C interface of the native prove() driver (genstark_amd/csrc/prover.cc -> libgstark_prover.so).
+ *
+ * One call = one Stark.prove() of the reference (lib/Stark.ts:81-163) + Serializer.serializeProof (lib/Serializer.ts:35-79):
+ * the driver issues the entry points of gstark.h in the reference's order from native host code and returns the serialized
+ * proof.  It contains no device code and no arithmetic kernels of its own: gs_prover_bind() takes the dlopen() handle of the
+ * implementation of gstark.h the caller loaded (libgstark_hip.so) and resolves every gs_* symbol it needs from it.  A node
+ * addon would expose gs_prover_prove as one N-API function next to the member-by-member surface of INTEGRATION.md. */
+#ifndef GSTARK_PROVER_H
+#define GSTARK_PROVER_H
+
+#include "gstark.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gs_assertion gs_assertion;
+struct gs_assertion {          /* lib/Stark.ts:356-375: register `reg` holds `value` at `step` */
+    uint64_t step;
+    uint32_t reg;
+    uint8_t value[16];
+};
+
+/* What the AIR module contributes (lib/Stark.ts:35-58: `air`): counts, degrees and the two device routines. */
+struct gs_prover_air {
+    uint32_t kind;               /* 0 = MiMC (gs_mimc_trace / gs_mimc_constraints), 1 = register-machine programs (gs_air_*) */
+    uint32_t registers;          /* trace registers */
+    uint32_t nconstraints;
+    const uint32_t *degrees;     /* constraint degrees */
+    /* kind 0 */
+    uint8_t seed[16];
+    const uint8_t *round_constants;   /* host, nrc * 16 */
+    uint32_t nrc;
+    const void *k_table;         /* device: the cyclic register over the composition domain */
+    uint64_t k_len;
+    /* kind 1 */
+    const uint32_t *t_code; uint32_t t_ninstr;          /* transition program */
+    const uint32_t *i_code; uint32_t i_ninstr;          /* init program (segments only, may be 0) */
+    const uint32_t *e_code; uint32_t e_ninstr;          /* constraint evaluator */
+    const uint8_t *consts; uint32_t nconsts; uint32_t vm_regs;
+    const uint8_t *static_values; const uint32_t *static_periods; uint32_t nstatic;   /* host, for the trace */
+    const void *static_tables; const uint64_t *static_lens;                           /* device + host lens, for the evaluator */
+    const uint8_t *first_rows; uint64_t segments; uint64_t segment_len;               /* segments = 0: one serial trace */
+    /* secret registers (lib/Stark.ts:113): their low-degree extensions over the evaluation domain, prepared by the caller; */
+    /* static_values / static_tables then hold the public registers followed by the secret ones */
+    const void *const *secret_traces; uint32_t nsecret;
+};
+
+struct gs_prover_job {
+    uint64_t steps;
+    uint32_t extension_factor, exe_query_count, fri_query_count;
+    int32_t hash_alg;
+    uint8_t root_of_unity[16];   /* primitive (steps*extension_factor)-th root: galois getRootOfUnity, computed by the caller */
+    const gs_assertion *assertions;
+    uint32_t nassertions;
+    struct gs_prover_air air;
+};
+
+
+/* Resolves the gs_* entry points from `dl_handle` (the handle dlopen() returned for the ABI library).  GS_ERR_UNSUPPORTED if one
+ * is missing. */
+int gs_prover_bind(void *dl_handle);
+/* The serialized proof into out[0..cap); *len receives its size (GS_ERR_ARG with *len set when cap is too small).  On failure
+ * err[0..errcap) holds the reference's message where there is one ("Assertion at step ... conflicts with execution trace"). */
+int gs_prover_prove(gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, uint64_t cap, uint64_t *len, char *err, uint64_t errcap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

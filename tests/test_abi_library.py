@@ -69,3 +69,29 @@ def test_device_field_header_on_host(tmp_path, compiler, rng):
     m = 300
     assert run('h_inv', m, A[:16 * m]) == [pow(x, P - 2, P) for x in a[:m]]
     assert run('h_pow', m, A[:16 * m], B[:16 * m]) == [pow(x, y, P) for x, y in zip(a[:m], b[:m])]
+
+
+def test_prover_library_exports_its_header():
+    """include/gstark_prover.h <-> libgstark_prover.so: the two entry points exist, the header is valid C, and the driver refuses
+    to run unbound."""
+    import ctypes as C
+    import re
+    import subprocess
+    from genstark_amd.native import PROVER_LIB_PATH
+    header = os.path.join(ROOT, 'include', 'gstark_prover.h')
+    subprocess.check_call(['gcc', '-fsyntax-only', '-x', 'c', '-std=c11', header])
+    names = set(re.findall(r'^int\s+(gs_prover_\w+)\s*\(', open(header).read(), flags=re.M))
+    assert names == {'gs_prover_bind', 'gs_prover_prove'}
+    if not os.path.exists(PROVER_LIB_PATH):
+        pytest.skip('libgstark_prover.so not built')
+    import shutil
+    import tempfile
+    private = os.path.join(tempfile.mkdtemp(), 'libgstark_prover_unbound.so')       # a fresh image: never bound
+    shutil.copy(PROVER_LIB_PATH, private)
+    lib = C.CDLL(private)
+    for name in names:
+        assert hasattr(lib, name)
+    lib.gs_prover_prove.restype = C.c_int
+    n = C.c_uint64()
+    assert lib.gs_prover_prove(None, None, None, C.c_uint64(0), C.byref(n), None, C.c_uint64(0)) != 0
+    assert lib.gs_prover_bind(None) != 0
