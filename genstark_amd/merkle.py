@@ -101,7 +101,7 @@ class MerkleTree:
 
     @staticmethod
     def create(leaves, hash_):
-        if getattr(leaves, 'dist', False):      # distributed digest vector (genstark_amd/distributed.py): sharded tree
+        if getattr(leaves, 'dist', False) or getattr(leaves, 'host', False):      # distributed (distributed.py) / host (hostfield.py) digests
             return hash_.createTree(leaves)
         n = leaves.length
         if n < 2 or n & (n - 1):
