@@ -147,7 +147,7 @@ class PrimeField:
     def sub(self, a, b): return (a - b) % self.modulus
     def mul(self, a, b): return (a * b) % self.modulus
     def neg(self, a): return (-a) % self.modulus
-    def inv(self, a): return pow(a, self.modulus - 2, self.modulus) if a % self.modulus else 0
+    def inv(self, a): return pow(a, -1, self.modulus) if a % self.modulus else 0
     def div(self, a, b): return a * self.inv(b) % self.modulus
 
     def exp(self, base, exponent):

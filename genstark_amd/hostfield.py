@@ -57,7 +57,7 @@ class HostField:
     def sub(self, a, b): return (a - b) % self.modulus
     def mul(self, a, b): return a * b % self.modulus
     def neg(self, a): return -a % self.modulus
-    def inv(self, a): return pow(a, self.modulus - 2, self.modulus) if a % self.modulus else 0
+    def inv(self, a): return pow(a, -1, self.modulus) if a % self.modulus else 0      # extended Euclid: ~10x cheaper than Fermat
     def div(self, a, b): return a * self.inv(b) % self.modulus
 
     def exp(self, base, exponent):
@@ -116,7 +116,7 @@ class HostField:
             den = 0
             for d in range(n - 1, -1, -1):
                 den = (den * xs[j] + q[d]) % p
-            s = ys[j] * pow(den, p - 2, p) % p
+            s = ys[j] * pow(den, -1, p) % p
             for d in range(n):
                 out[d] = (out[d] + q[d] * s) % p
         return out
@@ -154,8 +154,28 @@ class HostField:
         rows = len(vals) // (columns * step)
         return HostMatrix([[vals[(r + c * rows) * step] for c in range(columns)] for r in range(rows)])
 
+    def _interpolate4(self, x, y):
+        """The cubic through four points: Lagrange basis written out, ONE modular inversion (of the product of the four
+        denominators) instead of four."""
+        p = self.modulus
+        x0, x1, x2, x3 = x
+        d = [(x0 - x1) * (x0 - x2) * (x0 - x3) % p, (x1 - x0) * (x1 - x2) * (x1 - x3) % p,
+             (x2 - x0) * (x2 - x1) * (x2 - x3) % p, (x3 - x0) * (x3 - x1) * (x3 - x2) % p]
+        p01, p23 = d[0] * d[1] % p, d[2] * d[3] % p
+        inv_all = pow(p01 * p23 % p, -1, p)
+        i01, i23 = inv_all * p23 % p, inv_all * p01 % p
+        w = [y[0] * (i01 * d[1] % p) % p, y[1] * (i01 * d[0] % p) % p, y[2] * (i23 * d[3] % p) % p, y[3] * (i23 * d[2] % p) % p]
+        c = [0, 0, 0, 0]
+        for j, (a, b, e) in enumerate(((x1, x2, x3), (x0, x2, x3), (x0, x1, x3), (x0, x1, x2))):
+            ab = a * b % p
+            c[0] -= w[j] * (ab * e % p)
+            c[1] += w[j] * ((ab + (a + b) * e) % p)
+            c[2] -= w[j] * ((a + b + e) % p)
+            c[3] += w[j]
+        return [v % p for v in c]
+
     def interpolateQuarticBatch(self, xs, ys):
-        return HostMatrix([self.interpolateValues(x, y) for x, y in zip(xs.toValues(), ys.toValues())])
+        return HostMatrix([self._interpolate4(x, y) for x, y in zip(xs.toValues(), ys.toValues())])
 
     def evalQuarticBatch(self, polys, x):
         return HostVector([self.evalPolyAt(HostVector(row), x) for row in polys.toValues()])

@@ -43,11 +43,21 @@ def run(name, stark, assertions, seed, reps=5):
     t0 = time.perf_counter()
     assert stark.verify(assertions, stark.parse(data))
     tv = (time.perf_counter() - t0) * 1e3
+    th = None
+    if name.startswith('MiMC'):          # the same proof through the GPU-free verifier (genstark_amd/hostfield.py)
+        from genstark_amd.air import MimcAir
+        from genstark_amd.hostfield import HostField
+        hv = Stark(MimcAir(stark.air.steps, stark.air.extensionFactor, HostField()), stark_opts[name])
+        hv.verify(assertions, hv.parse(data))
+        t0 = time.perf_counter()
+        assert hv.verify(assertions, hv.parse(data))
+        th = (time.perf_counter() - t0) * 1e3
     s2 = Stark(stark.air, stark_opts[name], log)
     s2.prove(assertions, [], seed)
     phases = {k.strip(): v for k, v in log.phases}
     trace_ms = phases.get('Generated execution trace', 0.0)
-    rows.append(f'| {name} | {min(tn):.2f} | {sum(tn) / len(tn):.2f} | {min(t):.2f} | {trace_ms:.2f} | {tv:.1f} | {len(data)} | {stark.securityLevel} |')
+    ths = f'{th:.1f}' if th else '-'
+    rows.append(f'| {name} | {min(tn):.2f} | {sum(tn) / len(tn):.2f} | {min(t):.2f} | {trace_ms:.2f} | {tv:.1f} | {ths} | {len(data)} | {stark.securityLevel} |')
 
 
 stark_opts = {}
@@ -98,6 +108,6 @@ run(name, st, a, [3])
 
 print('# prove() wall-clock of the BASELINE configurations, 1 x MI355X (HIP backend), host-side trace generation included\n')
 print('command: `python tools/time_configs.py` (2 warm-up proofs, 5 timed; native driver = csrc/prover.cc, Python mirror = stark.prove(), same bytes asserted; verify() timed once on the host)\n')
-print('| configuration | prove() native driver best ms | mean ms | Python mirror best ms | of which trace generation ms | verify() ms (host) | proof bytes | security level |')
-print('|---|---:|---:|---:|---:|---:|---:|---:|')
+print('| configuration | prove() native driver best ms | mean ms | Python mirror best ms | of which trace generation ms | verify() ms (device-side field) | verify() ms (HostField, no GPU) | proof bytes | security level |')
+print('|---|---:|---:|---:|---:|---:|---:|---:|---:|')
 print('\n'.join(rows))
