@@ -60,4 +60,20 @@ assert(fast.equals(generic));
     const mat = [[1n, 2n, 3n], [P - 1n, 5n, 7n]], vec = [11n, P - 2n, 13n];
     assert.deepStrictEqual(field.mulMatrixByVector(field.newMatrixFrom(mat), field.newVectorFrom(vec)).toValues(), mat.map(row => row.reduce((s, x, i) => (s + x * vec[i]) % P, 0n)));
 }
+// one native call for a whole proof (js/prover.js -> N-API -> csrc/prover.cc): the golden MiMC proofs, byte for byte
+{
+    const fs = require('fs'), path = require('path');
+    const { MimcAir } = require('./air_mimc');
+    const { proveMimcSerialized } = require('./prover');
+    const golden = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'tests', 'golden', 'oracle_proofs.json'), 'utf8'));
+    for (const c of golden.slice(0, 3)) {
+        const options = { hashAlgorithm: c.hash_algorithm, extensionFactor: c.extension_factor, exeQueryCount: c.exe_query_count, friQueryCount: c.fri_query_count };
+        const assertions = c.assertions.map(a => ({ step: a.step, register: a.register, value: BigInt(a.value) }));
+        const bytes = proveMimcSerialized(new MimcAir(c.steps, c.extension_factor, field), options, assertions, BigInt(c.seed));
+        assert.strictEqual(bytes.length, c.proofSize);
+        assert.strictEqual(crypto.createHash('sha256').update(bytes).digest('hex'), c.proofSha256);
+    }
+    assert.throws(() => proveMimcSerialized(new MimcAir(64, 16, field), { hashAlgorithm: 'blake2s256', extensionFactor: 16, exeQueryCount: 48, friQueryCount: 24 },
+                                          [{ step: 0, register: 0, value: 4n }], 3n), /conflicts with execution trace/);
+}
 console.log(`js smoke OK: galois/merkle drop-in objects via N-API on backend ${process.env.GSTARK_ALLOW_TEST_DOUBLE === '1' ? '(test double allowed)' : 'hip-gfx950'}`);

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../include/gstark.h"
+#include "../include/gstark_prover.h"
 
 namespace {
 
@@ -314,10 +315,84 @@ napi_value MerkleProveBatch(napi_env env, napi_callback_info info) {
     return out;
 }
 
+// proveMimcSerialized(ctx, proverLibPath, job) -> Buffer: ONE call = Stark.prove() + Serializer.serializeProof() of the MiMC AIR through
+// the native driver (include/gstark_prover.h; the driver is bound to the ABI library load() opened).
+//   job = { steps, extensionFactor, exeQueryCount, friQueryCount, hashAlg, rootOfUnity: Buffer(16), seed: Buffer(16),
+//           roundConstants: Buffer(16*n), kTable: BigInt (device pointer), kLen, assertions: [{step, register, value: Buffer(16)}] }
+void *g_prover = nullptr;
+napi_value ProveMimcSerialized(napi_env env, napi_callback_info info) {
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    void *ctx;
+    NAPI_OK(env, napi_get_value_external(env, argv[0], &ctx));
+    if (!g_lib) { napi_throw_error(env, nullptr, "call load(path) first"); return nullptr; }
+    typedef int (*bindfn)(void *);
+    typedef int (*provefn)(gs_ctx *, const gs_prover_job *, uint8_t *, uint64_t, uint64_t *, char *, uint64_t);
+    if (!g_prover) {
+        char path[1024];
+        size_t len;
+        NAPI_OK(env, napi_get_value_string_utf8(env, argv[1], path, sizeof path, &len));
+        void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { napi_throw_error(env, nullptr, (std::string("cannot load ") + path + ": " + dlerror()).c_str()); return nullptr; }
+        bindfn bf = (bindfn)dlsym(lib, "gs_prover_bind");
+        if (!bf || bf(g_lib) != GS_OK) { napi_throw_error(env, nullptr, "gs_prover_bind failed"); return nullptr; }
+        g_prover = lib;
+    }
+    auto prop = [&](const char *name) { napi_value v; napi_get_named_property(env, argv[2], name, &v); return v; };
+    auto u64 = [&](const char *name, uint64_t *out) { return get_u64(env, prop(name), out); };
+    auto bytes = [&](napi_value v, const uint8_t **data, size_t *len) { void *d; bool ok = napi_get_buffer_info(env, v, &d, len) == napi_ok; *data = (const uint8_t *)d; return ok; };
+    gs_prover_job job;
+    memset(&job, 0, sizeof job);
+    uint64_t t, ef, exe, fri, alg, klen, ktab;
+    const uint8_t *rou, *seed, *rc;
+    size_t nrou, nseed, nrc;
+    if (!u64("steps", &t) || !u64("extensionFactor", &ef) || !u64("exeQueryCount", &exe) || !u64("friQueryCount", &fri) || !u64("hashAlg", &alg) ||
+        !u64("kLen", &klen) || !u64("kTable", &ktab) || !bytes(prop("rootOfUnity"), &rou, &nrou) || nrou != 16 || !bytes(prop("seed"), &seed, &nseed) ||
+        nseed != 16 || !bytes(prop("roundConstants"), &rc, &nrc) || nrc % 16) {
+        napi_throw_type_error(env, nullptr, "proveMimcSerialized: malformed job");
+        return nullptr;
+    }
+    job.steps = t; job.extension_factor = (uint32_t)ef; job.exe_query_count = (uint32_t)exe; job.fri_query_count = (uint32_t)fri; job.hash_alg = (int32_t)alg;
+    memcpy(job.root_of_unity, rou, 16);
+    const uint32_t degree = 3;
+    job.air.kind = 0; job.air.registers = 1; job.air.nconstraints = 1; job.air.degrees = &degree;
+    memcpy(job.air.seed, seed, 16);
+    job.air.round_constants = rc; job.air.nrc = (uint32_t)(nrc / 16);
+    job.air.k_table = (const void *)(uintptr_t)ktab; job.air.k_len = klen;
+    napi_value arr = prop("assertions");
+    uint32_t na = 0;
+    NAPI_OK(env, napi_get_array_length(env, arr, &na));
+    std::vector<gs_assertion> as(na);
+    for (uint32_t i = 0; i < na; i++) {
+        napi_value e, v;
+        NAPI_OK(env, napi_get_element(env, arr, i, &e));
+        uint64_t step, reg;
+        const uint8_t *val; size_t nval;
+        napi_get_named_property(env, e, "step", &v);
+        bool ok = get_u64(env, v, &step);
+        napi_get_named_property(env, e, "register", &v);
+        ok = ok && get_u64(env, v, &reg);
+        napi_get_named_property(env, e, "value", &v);
+        ok = ok && bytes(v, &val, &nval) && nval == 16;
+        if (!ok) { napi_throw_type_error(env, nullptr, "proveMimcSerialized: malformed assertion"); return nullptr; }
+        as[i].step = step; as[i].reg = (uint32_t)reg; memcpy(as[i].value, val, 16);
+    }
+    job.assertions = as.data(); job.nassertions = na;
+    std::vector<uint8_t> out(1 << 22);
+    uint64_t n = 0;
+    char err[512] = {0};
+    int rcode = ((provefn)dlsym(g_prover, "gs_prover_prove"))((gs_ctx *)ctx, &job, out.data(), out.size(), &n, err, sizeof err);
+    if (rcode != GS_OK) { napi_throw_error(env, nullptr, (std::string("native prove() failed: ") + err).c_str()); return nullptr; }
+    napi_value buf;
+    NAPI_OK(env, napi_create_buffer_copy(env, (size_t)n, out.data(), nullptr, &buf));
+    return buf;
+}
+
 napi_value Init(napi_env env, napi_value exports) {
     const struct { const char *name; napi_callback cb; } fns[] = {
         {"load", Load}, {"ctxCreate", CtxCreate}, {"ctxDestroy", CtxDestroy}, {"alloc", Alloc}, {"call", Call},
-        {"merkleProveBatch", MerkleProveBatch},
+        {"merkleProveBatch", MerkleProveBatch}, {"proveMimcSerialized", ProveMimcSerialized},
     };
     for (auto &f : fns) {
         napi_value fn;

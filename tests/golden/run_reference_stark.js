@@ -9,6 +9,10 @@ const fs = require('fs');
 const libDir = process.argv[2];
 const { Stark } = require(path.join(libDir, 'Stark.js'));
 const cases = JSON.parse(fs.readFileSync(process.argv[3], 'utf8'));
+// the native driver (C++ above the C ABI) behind the same addon: its bytes must equal what the reference's Stark.js produces
+const repoJs = path.join(__dirname, '..', '..', 'js');
+const { MimcAir } = require(path.join(repoJs, 'air_mimc.js'));
+const { proveMimcSerialized } = require(path.join(repoJs, 'prover.js'));
 const out = [];
 const noopLogger = { start() { return () => {}; }, sub() { return () => {}; }, done() {} };
 for (const c of cases) {
@@ -21,7 +25,8 @@ for (const c of cases) {
     const ok = stark.verify(assertions, stark.parse(bytes));
     let tamperRejected = false;
     try { const bad = Buffer.from(bytes); bad[40] ^= 1; stark.verify(assertions, stark.parse(bad)); } catch (e) { tamperRejected = true; }
-    out.push({ name: c.name, proofHex: bytes.toString('hex'), evRoot: proof.evRoot.toString('hex'), lcRoot: proof.ldProof.lcRoot.toString('hex'),
+    const nativeBytes = proveMimcSerialized(new MimcAir(c.steps, c.extension_factor), options, assertions, BigInt(c.seed));
+    out.push({ name: c.name, nativeDriverEqualsReference: Buffer.from(bytes).equals(nativeBytes), proofHex: bytes.toString('hex'), evRoot: proof.evRoot.toString('hex'), lcRoot: proof.ldProof.lcRoot.toString('hex'),
                friLayers: proof.ldProof.components.length, remainderLength: proof.ldProof.remainder.length, verified: ok === true,
                tamperRejected, securityLevel: stark.securityLevel });
     console.log(c.name, bytes.byteLength, 'verified', ok, 'security', stark.securityLevel);

@@ -66,3 +66,6 @@ def test_reference_stark_js_runs_live_on_the_drop_in_modules(oracle_backend, tmp
     for rec in json.loads(cout.read_text()):
         assert rec['verified'] and rec['tamperRejected']
         assert rec['proofHex'] == gold[rec['name']]['proofHex']
+        # the native driver (csrc/prover.cc), called through the same N-API addon in the same process, gives the bytes the
+        # reference's own Stark.js produced
+        assert rec['nativeDriverEqualsReference'] is True
