@@ -78,6 +78,43 @@ class Program:
             return index[key]
 
         outs = [visit(Expr.wrap(o)) for o in outputs]
+        # list scheduling: exponentiations are held back until nothing else is ready, so independent ones (the S-box applied to
+        # every register of a round) end up next to each other, grouped by exponent — the device trace generator runs such a group
+        # as interleaved square-and-multiply chains (k_air_trace_segments: one thread per segment is latency-bound, four
+        # independent chains issue in the time of two)
+        level = [0] * len(order)             # exponentiations on the longest dependency path ending at (and including) a node
+        for n, (e, ins) in enumerate(order):
+            level[n] = max([level[i] for i in ins], default=0) + (1 if e.kind == 'pow' else 0)
+        groups = {}
+        for n, (e, ins) in enumerate(order):
+            if e.kind == 'pow':
+                groups.setdefault((level[n], e.args[1]), []).append(n)
+        schedule, done = [], set()
+
+        def emit(n):                         # n with everything it needs, in the original relative order
+            if n in done:
+                return
+            for i in sorted(set(order[n][1])):
+                emit(i)
+            done.add(n)
+            schedule.append(n)
+        for n, (e, ins) in enumerate(order):
+            if n in done:
+                continue
+            if e.kind != 'pow':
+                emit(n)
+                continue
+            members = [m for m in groups[(level[n], e.args[1])] if m not in done][:8]    # at most 8 at a time: register pressure
+            for mbr in members:              # first everything the whole group needs ...
+                for i in sorted(set(order[mbr][1])):
+                    emit(i)
+            for mbr in members:              # ... then its members back to back
+                done.add(mbr)
+                schedule.append(mbr)
+        assert len(schedule) == len(order)
+        position = {old: new for new, old in enumerate(schedule)}
+        order = [(order[old][0], [position[i] for i in order[old][1]]) for old in schedule]
+        outs = [position[o] for o in outs]
         last_use = {}
         for n, (_, ins) in enumerate(order):
             for i in ins:

@@ -42,6 +42,33 @@ __global__ void k_air_constraints(const uint4 *__restrict__ code, uint32_t ninst
     }
 }
 
+// g (<= 4) independent square-and-multiply chains with the SAME exponent, interleaved: one thread per trace segment is bound by
+// the latency of a dependent fe_mul chain (~780 cycles per product against ~360 of issue), four chains fill the gaps
+template <int G>
+__device__ __forceinline__ void pow_group(fe (&x)[4], const fe &e) {
+    fe r[4];
+#pragma unroll
+    for (int i = 0; i < G; i++) r[i] = fe_one();
+    const uint32_t ev[4] = {e.w0, e.w1, e.w2, e.w3};
+    int top = 3;
+    while (top > 0 && ev[top] == 0) top--;
+    for (int w = 0; w <= top; w++) {
+        uint32_t bits = ev[w];
+        const int nb = (w == top) ? 32 - __clz(bits | 1u) : 32;
+        for (int k = 0; k < nb; k++) {
+            if (bits & 1u) {
+#pragma unroll
+                for (int i = 0; i < G; i++) r[i] = fe_mul(r[i], x[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < G; i++) x[i] = fe_sqr(x[i]);
+            bits >>= 1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < G; i++) x[i] = r[i];
+}
+
 // one thread per independent trace segment: the same register machine, next-row outputs go to a private row buffer
 template <int NREG>
 __global__ void k_air_trace_segments(const uint4 *__restrict__ code, uint32_t ninstr, const uint4 *__restrict__ icode, uint32_t init_ninstr,
@@ -84,8 +111,29 @@ __global__ void k_air_trace_segments(const uint4 *__restrict__ code, uint32_t ni
                 case OP_ADDV: vm[dst] = fe_add(vm[a], vm[b]); break;
                 case OP_SUBV: vm[dst] = fe_sub(vm[a], vm[b]); break;
                 case OP_MULV: vm[dst] = fe_mul(vm[a], vm[b]); break;
-                case OP_POW: vm[dst] = fe_pow_u64(vm[a], b); break;
-                case OP_POWC: vm[dst] = fe_pow(vm[a], consts[b]); break;
+                case OP_POW:
+                case OP_POWC: {
+                    // adjacent exponentiations with the same exponent whose results do not feed each other (the compiler puts
+                    // the S-boxes of a round next to each other): up to four at a time as interleaved chains
+                    uint32_t g = 1;
+                    while (g < 4 && pc + g < ninstr) {
+                        const uint4 nx = code[pc + g];
+                        bool ok = nx.x == ins.x && nx.w == b;
+                        for (uint32_t i = 0; ok && i < g; i++) ok = nx.z != code[pc + i].y;      // a source must not be an earlier result
+                        if (!ok) break;
+                        g++;
+                    }
+                    fe x[4];
+                    for (uint32_t i = 0; i < g; i++) x[i] = vm[code[pc + i].z];
+                    const fe e = ins.x == OP_POWC ? consts[b] : fe_make(b, 0, 0, 0);
+                    if (g == 4) pow_group<4>(x, e);
+                    else if (g == 3) pow_group<3>(x, e);
+                    else if (g == 2) pow_group<2>(x, e);
+                    else pow_group<1>(x, e);
+                    for (uint32_t i = 0; i < g; i++) vm[code[pc + i].y] = x[i];
+                    pc += g - 1;
+                    break;
+                }
                 default: next[dst] = vm[a]; break;  // OP_OUT
             }
         }
