@@ -70,47 +70,55 @@ __device__ __forceinline__ void pow_group(fe (&x)[4], const fe &e) {
 }
 
 // one thread per independent trace segment: the same register machine, next-row outputs go to a private row buffer
-template <int NREG>
+template <int NREG, bool LDS>
 __global__ void k_air_trace_segments(const uint4 *__restrict__ code, uint32_t ninstr, const uint4 *__restrict__ icode, uint32_t init_ninstr,
                                      const fe *__restrict__ consts,
                                      const fe *__restrict__ statics, StaticDesc sd, const fe *__restrict__ first_rows, uint32_t registers,
-                                     uint64_t segments, uint64_t seglen, fe *__restrict__ out) {
+                                     uint64_t segments, uint64_t seglen, uint32_t nvm, fe *__restrict__ out) {
+    // The interpreter's register file (vm), the current row and the row being produced are indexed by the instruction stream:
+    // as private arrays they live in scratch memory, and with one wave per SIMD nothing hides a scratch round trip (~670 cycles
+    // per VM instruction measured).  LDS variant: slot s of lane l at lds[s * 64 + l] (16-byte words, conflict-free).
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
+    fe *const lds = reinterpret_cast<fe *>(vm_smem) + threadIdx.x;
+    fe p_vm[LDS ? 1 : NREG], p_row[LDS ? 1 : GS_AIR_MAX_REGISTERS], p_next[LDS ? 1 : GS_AIR_MAX_REGISTERS];
     const uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     if (g >= segments) return;
     const uint64_t steps = segments * seglen;
-    fe vm[NREG], row[GS_AIR_MAX_REGISTERS], next[GS_AIR_MAX_REGISTERS];
-    for (uint32_t r = 0; r < registers; r++) row[r] = next[r] = first_rows[g * registers + r];
+#define vm(i) (*(LDS ? &lds[(uint32_t)(i) * 64] : &p_vm[LDS ? 0 : (i)]))
+#define row(i) (*(LDS ? &lds[(nvm + (uint32_t)(i)) * 64] : &p_row[LDS ? 0 : (i)]))
+#define next(i) (*(LDS ? &lds[(nvm + registers + (uint32_t)(i)) * 64] : &p_next[LDS ? 0 : (i)]))
+    for (uint32_t r = 0; r < registers; r++) row(r) = next(r) = first_rows[g * registers + r];
     if (init_ninstr) {   // the `init { ... }` block: inputs -> first row (no static registers, no next row)
         for (uint32_t pc = 0; pc < init_ninstr; pc++) {
             const uint4 ins = icode[pc];
             const uint32_t dst = ins.y, a = ins.z, b = ins.w;
             switch (ins.x) {
-                case OP_LOADC: vm[dst] = consts[a]; break;
-                case OP_LOADR: vm[dst] = row[a]; break;
-                case OP_ADDV: vm[dst] = fe_add(vm[a], vm[b]); break;
-                case OP_SUBV: vm[dst] = fe_sub(vm[a], vm[b]); break;
-                case OP_MULV: vm[dst] = fe_mul(vm[a], vm[b]); break;
-                case OP_POW: vm[dst] = fe_pow_u64(vm[a], b); break;
-                case OP_POWC: vm[dst] = fe_pow(vm[a], consts[b]); break;
-                default: next[dst] = vm[a]; break;
+                case OP_LOADC: vm(dst) = consts[a]; break;
+                case OP_LOADR: vm(dst) = row(a); break;
+                case OP_ADDV: vm(dst) = fe_add(vm(a), vm(b)); break;
+                case OP_SUBV: vm(dst) = fe_sub(vm(a), vm(b)); break;
+                case OP_MULV: vm(dst) = fe_mul(vm(a), vm(b)); break;
+                case OP_POW: vm(dst) = fe_pow_u64(vm(a), b); break;
+                case OP_POWC: vm(dst) = fe_pow(vm(a), consts[b]); break;
+                default: next(dst) = vm(a); break;
             }
         }
-        for (uint32_t r = 0; r < registers; r++) row[r] = next[r];
+        for (uint32_t r = 0; r < registers; r++) row(r) = next(r);
     }
     for (uint64_t k = 0; k < seglen; k++) {
         const uint64_t i = g * seglen + k;
-        for (uint32_t r = 0; r < registers; r++) { out[(uint64_t)r * steps + i] = row[r]; next[r] = row[r]; }
+        for (uint32_t r = 0; r < registers; r++) { out[(uint64_t)r * steps + i] = row(r); next(r) = row(r); }
         if (k + 1 == seglen) break;
         for (uint32_t pc = 0; pc < ninstr; pc++) {
             const uint4 ins = code[pc];
             const uint32_t dst = ins.y, a = ins.z, b = ins.w;
             switch (ins.x) {
-                case OP_LOADC: vm[dst] = consts[a]; break;
-                case OP_LOADR: vm[dst] = row[a]; break;
-                case OP_LOADS: vm[dst] = statics[sd.offset[a] + i % sd.len[a]]; break;
-                case OP_ADDV: vm[dst] = fe_add(vm[a], vm[b]); break;
-                case OP_SUBV: vm[dst] = fe_sub(vm[a], vm[b]); break;
-                case OP_MULV: vm[dst] = fe_mul(vm[a], vm[b]); break;
+                case OP_LOADC: vm(dst) = consts[a]; break;
+                case OP_LOADR: vm(dst) = row(a); break;
+                case OP_LOADS: vm(dst) = statics[sd.offset[a] + i % sd.len[a]]; break;
+                case OP_ADDV: vm(dst) = fe_add(vm(a), vm(b)); break;
+                case OP_SUBV: vm(dst) = fe_sub(vm(a), vm(b)); break;
+                case OP_MULV: vm(dst) = fe_mul(vm(a), vm(b)); break;
                 case OP_POW:
                 case OP_POWC: {
                     // adjacent exponentiations with the same exponent whose results do not feed each other (the compiler puts
@@ -124,22 +132,25 @@ __global__ void k_air_trace_segments(const uint4 *__restrict__ code, uint32_t ni
                         g++;
                     }
                     fe x[4];
-                    for (uint32_t i = 0; i < g; i++) x[i] = vm[code[pc + i].z];
+                    for (uint32_t i = 0; i < g; i++) x[i] = vm(code[pc + i].z);
                     const fe e = ins.x == OP_POWC ? consts[b] : fe_make(b, 0, 0, 0);
                     if (g == 4) pow_group<4>(x, e);
                     else if (g == 3) pow_group<3>(x, e);
                     else if (g == 2) pow_group<2>(x, e);
                     else pow_group<1>(x, e);
-                    for (uint32_t i = 0; i < g; i++) vm[code[pc + i].y] = x[i];
+                    for (uint32_t i = 0; i < g; i++) vm(code[pc + i].y) = x[i];
                     pc += g - 1;
                     break;
                 }
-                default: next[dst] = vm[a]; break;  // OP_OUT
+                default: next(dst) = vm(a); break;  // OP_OUT
             }
         }
-        for (uint32_t r = 0; r < registers; r++) row[r] = next[r];
+        for (uint32_t r = 0; r < registers; r++) row(r) = next(r);
     }
 }
+#undef vm
+#undef row
+#undef next
 
 static int check_program(gs_ctx *c, const uint32_t *code, uint32_t ninstr, uint32_t nconsts, uint32_t vm_regs, uint32_t registers,
                          uint32_t nstatic, uint32_t nout, bool allow_next) {
@@ -243,12 +254,15 @@ int gs_air_trace_segments(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr,
     const uint4 *dcode = (const uint4 *)p, *dinit = (const uint4 *)(p + main_b);
     const fe *dconst = (const fe *)(p + code_b), *dstat = (const fe *)(p + code_b + const_b), *drows = (const fe *)(p + code_b + const_b + stat_b);
     dim3 block(64), grid((unsigned)((segments + 63) / 64));   // one wave per 64 segments: spread the few long-running threads over the CUs
-    if (vm_regs <= 16)
-        hipLaunchKernelGGL(k_air_trace_segments<16>, grid, block, 0, c->stream, dcode, ninstr, dinit, init_ninstr, dconst, dstat, sd, drows, registers, segments, segment_len, (fe *)out);
-    else if (vm_regs <= 32)
-        hipLaunchKernelGGL(k_air_trace_segments<32>, grid, block, 0, c->stream, dcode, ninstr, dinit, init_ninstr, dconst, dstat, sd, drows, registers, segments, segment_len, (fe *)out);
-    else
-        hipLaunchKernelGGL(k_air_trace_segments<64>, grid, block, 0, c->stream, dcode, ninstr, dinit, init_ninstr, dconst, dstat, sd, drows, registers, segments, segment_len, (fe *)out);
+    const uint64_t lds_bytes = ((uint64_t)vm_regs + 2ull * registers) * 64 * 16;
+#define GS_LAUNCH_TRACE(N, L, SH)                                                                                                        \
+    hipLaunchKernelGGL((k_air_trace_segments<N, L>), grid, block, SH, c->stream, dcode, ninstr, dinit, init_ninstr, dconst, dstat, sd, drows, \
+                       registers, segments, segment_len, vm_regs, (fe *)out)
+    if (lds_bytes <= 64 * 1024) GS_LAUNCH_TRACE(1, true, (size_t)lds_bytes);
+    else if (vm_regs <= 16) GS_LAUNCH_TRACE(16, false, 0);
+    else if (vm_regs <= 32) GS_LAUNCH_TRACE(32, false, 0);
+    else GS_LAUNCH_TRACE(64, false, 0);
+#undef GS_LAUNCH_TRACE
     e = hipGetLastError();
     gs_tmp_free(c, d);
     if (e != hipSuccess) return gs_fail(c, GS_ERR_DEVICE, "air_trace_segments launch: %s", hipGetErrorString(e));
