@@ -11,6 +11,13 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, 'csrc', 'libgstark_hip.so')
+# one build flavour of the library per field (csrc/build.sh): the 128-bit field of the hot path and the small prime fields of the
+# reference's examples (csrc/gf_small.cuh: same kernels, same 16-byte element layout, plain arithmetic)
+MODULUS_128 = 2**128 - 9 * 2**32 + 1
+MODULUS_64 = 2**64 - 21 * 2**30 + 1        # examples/rescue/hash2x64.ts:10
+MODULUS_32 = 2**32 - 3 * 2**25 + 1         # examples/demo/fibonacci.ts:14, README.md:23 (Foo)
+HIP_LIB_PATHS = {MODULUS_128: HIP_LIB_PATH, MODULUS_64: os.path.join(_HERE, 'csrc', 'libgstark_hip_q64.so'),
+                 MODULUS_32: os.path.join(_HERE, 'csrc', 'libgstark_hip_q32.so')}
 
 GS_OK = 0
 HASH_ALGS = {'sha256': 0, 'blake2s256': 1}  # gs_hash_alg; lib/Stark.ts:19
@@ -95,8 +102,18 @@ def load_library(path):
 class Backend:
     """One gs_ctx (one device, one HIP stream).  All device work of the package goes through it."""
 
-    def __init__(self, device=0, stream=None, lib_path=None, allow_test_double=False):
-        self.lib = load_library(lib_path or HIP_LIB_PATH)
+    def __init__(self, device=0, stream=None, lib_path=None, allow_test_double=False, modulus=None):
+        """modulus: picks the library flavour built for that field (default: the 128-bit field); lib_path overrides."""
+        if lib_path is None:
+            if modulus is not None and modulus not in HIP_LIB_PATHS:
+                raise GstarkError(f'no build of the library for the field of {modulus} elements (built: {sorted(HIP_LIB_PATHS)})')
+            lib_path = HIP_LIB_PATHS[modulus] if modulus is not None else HIP_LIB_PATH
+        self.lib = load_library(lib_path)
+        buf = C.create_string_buffer(16)
+        self.lib.gs_field_modulus(C.cast(buf, C.c_void_p))
+        self.modulus = int.from_bytes(buf.raw, 'little')
+        if modulus is not None and self.modulus != modulus:
+            raise GstarkError(f'{lib_path} is built for the field of {self.modulus} elements, not {modulus}')
         self.name = self.lib.gs_backend_name().decode()
         if self.name != 'hip-gfx950' and not allow_test_double:
             raise GstarkError(f'refusing backend {self.name!r}: the product path runs on hip-gfx950 only')

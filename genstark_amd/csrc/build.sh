@@ -4,17 +4,29 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
-mkdir -p build
-pids=()
-for f in ctx ntt pointwise hash air_mimc air_vm small; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ gf128.cuh -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ host_field.h -nt build/$f.o ] || [ host_sha256.h -nt build/$f.o ] || [ hash_core.cuh -nt build/$f.o ] || [ ../../include/gstark.h -nt build/$f.o ]; then
-    $HIPCC $FLAGS -c $f.hip -o build/$f.o &
-    pids+=($!)
+UNITS="ctx ntt pointwise hash air_mimc air_vm small"
+HDRS="gf128.cuh gf_small.cuh common.h host_field.h host_field_small.h host_sha256.h hash_core.cuh ../../include/gstark.h"
+# one library per field: the 128-bit field of the hot path, and two "plumbing" flavours of the same sources for the small prime
+# fields of the reference's examples (gf_small.cuh): 2^64 - 21*2^30 + 1 (rescue/hash2x64.ts) and 2^32 - 3*2^25 + 1 (demo/fibonacci.ts)
+build_flavour() {   # <object dir> <output> <extra flags>
+  local dir=$1 out=$2 extra=$3 pids=() stale=0
+  mkdir -p $dir
+  for f in $UNITS; do
+    local need=0
+    [ -f $dir/$f.o ] || need=1
+    for h in $f.hip $HDRS; do [ $h -nt $dir/$f.o ] && need=1; done
+    if [ $need = 1 ]; then $HIPCC $FLAGS $extra -c $f.hip -o $dir/$f.o & pids+=($!); stale=1; fi
+  done
+  for p in "${pids[@]}"; do wait $p; done
+  if [ $stale = 1 ] || [ ! -f $out ]; then
+    $HIPCC --offload-arch=gfx950 -shared -fPIC -o $out $(for f in $UNITS; do echo $dir/$f.o; done)
   fi
-done
-for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libgstark_hip.so build/ctx.o build/ntt.o build/pointwise.o build/hash.o build/air_mimc.o build/air_vm.o build/small.o
-echo built $(pwd)/libgstark_hip.so
+  echo built $(pwd)/$out
+}
+build_flavour build libgstark_hip.so "" &
+build_flavour build_q64 libgstark_hip_q64.so "-DGS_SMALL_Q=18446744051160973313ull" &
+build_flavour build_q32 libgstark_hip_q32.so "-DGS_SMALL_Q=4194304001ull" &
+wait
 # the native prove() driver: plain C++ above the C ABI (binds to whichever implementation of it the caller loaded)
 g++ -O2 -std=c++17 -shared -fPIC -Wall -Wno-unused-function prover.cc -ldl -o libgstark_prover.so
 echo built $(pwd)/libgstark_prover.so

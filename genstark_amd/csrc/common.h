@@ -10,7 +10,11 @@
 #include <vector>
 
 #include "../../include/gstark.h"
+#ifdef GS_SMALL_Q
+#include "gf_small.cuh"   // build flavour for a prime below 2^64 (same names, same 16-byte elements)
+#else
 #include "gf128.cuh"
+#endif
 
 struct NttPlan;  // ntt.hip
 

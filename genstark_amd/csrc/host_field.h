@@ -2,6 +2,9 @@
 // the serial MiMC recurrence (air_mimc.hip) and O(n^2) Lagrange interpolation of <= a few hundred points
 // (small.hip).  Same modulus and canonical representation as gf128.cuh.
 #pragma once
+#ifdef GS_SMALL_Q
+#include "host_field_small.h"
+#else
 #include <stdint.h>
 #include <string.h>
 
@@ -112,3 +115,4 @@ static inline hu128 hf_pow(hu128 b, hu128 e) {
 static inline hu128 hf_inv(hu128 a) { return a ? hf_pow(a, hf_p() - 2) : 0; }
 static inline hu128 hf_load(const uint8_t *b) { hu128 v; memcpy(&v, b, 16); return v; }
 static inline void hf_store(uint8_t *b, hu128 v) { memcpy(b, &v, 16); }
+#endif  // GS_SMALL_Q

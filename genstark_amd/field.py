@@ -128,17 +128,17 @@ class Matrix:
 class PrimeField:
     """createPrimeField(modulus[, wasmOptions]) — index.ts:14; lib/Stark.ts:40."""
 
-    def __init__(self, modulus=MODULUS, backend=None):
-        if modulus != MODULUS:
-            raise GstarkError('this build accelerates the 128-bit field 2^128 - 9*2^32 + 1 only')
-        self.backend = backend or Backend()
+    def __init__(self, modulus=None, backend=None):
+        """modulus None: the field the backend's library is built for (default library: the 128-bit field)."""
+        self.backend = backend or Backend(modulus=modulus)
+        if modulus is None:
+            modulus = self.backend.modulus
+        if modulus != self.backend.modulus:
+            raise GstarkError(f'the backend computes in the field of {self.backend.modulus} elements, not {modulus}: '
+                              'construct Backend(modulus=...) for one of the built fields')
         self._lastEvaluation = None     # (polys, ptr, omega, n, result) of the latest evalPolysAtRoots, weakly held
-        buf = C.create_string_buffer(16)
-        self.backend.lib.gs_field_modulus(C.cast(buf, C.c_void_p))
-        assert int.from_bytes(buf.raw, 'little') == modulus
         self.modulus = modulus
-        self.elementSize = ELEMENT_SIZE
-        self.isOptimized = True       # lib/Stark.ts:41,49
+        self.elementSize = ELEMENT_SIZE  # every build flavour stores an element in 16 bytes
         self.zero, self.one = 0, 1
 
     # ---- scalar arithmetic (bigint in, bigint out)

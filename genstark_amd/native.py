@@ -75,6 +75,9 @@ class NativeProver:
         air = stark.air
         self.field = air.field
         self.backend = self.field.backend
+        from .field import MODULUS
+        if self.field.modulus != MODULUS:
+            raise GstarkError('the native driver is built for the 128-bit field; use Stark.prove() on the small-field builds')
         if hasattr(self.field, 'comm'):
             raise GstarkError('the native driver proves on one device; use the distributed field with Stark.prove()')
         self.lib = _driver(self.backend)

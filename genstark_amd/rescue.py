@@ -105,3 +105,71 @@ def rescue4x128_air(steps, extensionFactor=16, field=None, segmented=False):
 
     return GenericAir(steps, 4, [3, 3, 3, 3], rc, transition, evaluation, lambda seed: [seed[0], seed[1], 0, 0], extensionFactor, f,
                       segmentLength=STEPS_PER_HASH, initExpr=init_expr)
+
+
+# ---- Rescue 2x64 (examples/rescue/hash2x64.ts): the same construction over the 64-bit field 2^64 - 21*2^30 + 1 -------------
+MODULUS_2X64 = 2**64 - 21 * 2**30 + 1
+INV_ALPHA_2X64 = 6148914683720324437                     # hash2x64.ts:14 (invAlpha = -6148914683720324437)
+MDS_2X64 = [[18446744051160973310, 18446744051160973301], [4, 13]]                                       # :17-20
+INV_MDS_2X64 = [[2049638227906774814, 6148914683720324439], [16397105823254198500, 12297829367440648875]]   # :57-60
+SEED_CONSTANTS_2X64 = [1908230773479027697, 11775995824954138427, 18345613653544031596, 8765075832563166921,
+                       10398013025088720944, 5494050611496560306, 17002767073604012844, 4907993559994152336]  # :23-28
+
+
+def key_schedule_2x64(f):
+    """examples/rescue/utils.ts:126-181 for state width 2 (same procedure as key_schedule above)."""
+    n = 2
+    inv_exp = f.modulus - 1 - INV_ALPHA_2X64
+    vadd = lambda a, b: [f.add(x, y) for x, y in zip(a, b)]
+    mmul = lambda m, v: [sum(a * b for a, b in zip(row, v)) % f.modulus for row in m]
+    c = list(SEED_CONSTANTS_2X64)
+    i_const, c_matrix, c_const = c[:n], [c[n + i * n:n + (i + 1) * n] for i in range(n)], c[n + n * n:n + n * n + n]
+    state, injection = list(i_const), i_const
+    states = [list(state)]
+    for _ in range(STEPS_PER_HASH + 1):
+        state = [f.exp(x, inv_exp) for x in state]
+        injection = vadd(mmul(c_matrix, injection), c_const)
+        state = vadd(mmul(MDS_2X64, state), injection)
+        states.append(list(state))
+        state = [f.exp(x, ALPHA) for x in state]
+        injection = vadd(mmul(c_matrix, injection), c_const)
+        state = vadd(mmul(MDS_2X64, state), injection)
+        states.append(list(state))
+    initial = states[0] + states[1]
+    rc = [[0] * STEPS_PER_HASH for _ in range(2 * n)]
+    k = 2
+    for i in range(STEPS_PER_HASH):
+        for j in range(n):
+            rc[j][i] = states[k][j]
+            rc[n + j][i] = states[k + 1][j]
+        k += 2
+    return initial, rc
+
+
+def rescue2x64_air(steps, extensionFactor=16, field=None):
+    """examples/rescue/hash2x64.ts:50-98 — 2 registers, 2 degree-3 constraints, 4 cyclic static registers of period 32, over the
+    64-bit field (a PrimeField on the q64 build of the library).  prove(assertions, [], [value]); the digest is register 0 at
+    step 31 (hash2x64.ts:101-107: 42 -> 14354339131598895532)."""
+    from ._abi import Backend
+    from .field import PrimeField
+    f = field or PrimeField(backend=Backend(modulus=MODULUS_2X64))
+    if f.modulus != MODULUS_2X64:
+        raise ValueError('Rescue 2x64 is defined over 2^64 - 21*2^30 + 1')
+    initial, rc = key_schedule_2x64(f)
+    inv_exp = f.modulus - 1 - INV_ALPHA_2X64
+
+    def transition(r, k):      # hash2x64.ts:76-79
+        s = [a + b for a, b in zip(mat_vec(MDS_2X64, [x ** ALPHA for x in r]), k[0:2])]
+        return [a + b for a, b in zip(mat_vec(MDS_2X64, [x ** inv_exp for x in s]), k[2:4])]
+
+    def evaluation(r, n, k):   # :90-94
+        s = [a + b for a, b in zip(mat_vec(MDS_2X64, [x ** ALPHA for x in r]), k[0:2])]
+        nn = [x ** ALPHA for x in mat_vec(INV_MDS_2X64, [a - b for a, b in zip(n, k[2:4])])]
+        return [a - b for a, b in zip(s, nn)]
+
+    def init(seed):            # buildInputs, hash2x64.ts:121-135
+        r = [f.add(seed[0], initial[0]), f.add(0, initial[1])]
+        a = [f.exp(x, inv_exp) for x in r]
+        return [f.add(sum(m * x for m, x in zip(MDS_2X64[j], a)) % f.modulus, initial[2 + j]) for j in range(2)]
+
+    return GenericAir(steps, 2, [3, 3], rc, transition, evaluation, init, extensionFactor, f)

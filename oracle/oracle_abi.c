@@ -15,7 +15,11 @@
  * parity unpinned (see gf128.h).
  */
 #include "../include/gstark.h"
+#ifdef GS_SMALL_Q
+#include "gf_small.h"   /* checker flavour for a prime below 2^64 */
+#else
 #include "gf128.h"
+#endif
 #include "hashes.h"
 #include <stdio.h>
 #include <stdlib.h>
