@@ -25,6 +25,9 @@
  *    single-threaded JS) a context must not be used from two threads at once; a thread other than the
  *    one that called gs_ctx_create must make the context's device its current HIP device first
  *    (hipSetDevice is per-thread state; several contexts, one per thread, may share a GPU).
+ *  - The library is built once per field: libgstark_hip.so computes in GF(2^128 - 9*2^32 + 1), the flavours
+ *    libgstark_hip_q64.so / _q32.so in GF(2^64 - 21*2^30 + 1) / GF(2^32 - 3*2^25 + 1) (gs_field_modulus says which);
+ *    elements are 16 bytes little-endian in every flavour.
  *  - Every function returns GS_OK (0) or a negative gs_status; gs_last_error(ctx) describes it.
  *    There is NO CPU fallback: without a gfx950 device gs_ctx_create fails.
  */

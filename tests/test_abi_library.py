@@ -34,6 +34,44 @@ def test_hip_library_exports_every_symbol():
     assert int.from_bytes(buf.raw, 'little') == P
 
 
+def test_small_field_flavours_export_every_symbol():
+    """The q64 / q32 builds of the same sources (csrc/gf_small.cuh): same ABI, their own modulus."""
+    for modulus, path in _abi.HIP_LIB_PATHS.items():
+        assert os.path.exists(path), f'{path}: run __graft_entry__.build() first'
+        lib = ctypes.CDLL(path)
+        for name in header_symbols():
+            assert hasattr(lib, name), (path, name)
+        lib.gs_backend_name.restype = ctypes.c_char_p
+        assert lib.gs_backend_name() == b'hip-gfx950'
+        buf = ctypes.create_string_buffer(16)
+        lib.gs_field_modulus(buf)
+        assert int.from_bytes(buf.raw, 'little') == modulus
+
+
+def test_small_field_device_header_on_host(tmp_path, rng):
+    """gf_small.cuh compiled for the host (the same GF_HD functions the kernels inline) against Python integers, both moduli."""
+    src = tmp_path / 'h.cpp'
+    src.write_text('#include <stdint.h>\n#include "%s"\n'
+                   'extern "C" void ops(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *add, uint64_t *sub, uint64_t *mul, uint64_t *inv) {\n'
+                   '  for (uint64_t i = 0; i < n; i++) { fe x = fe_from(a[i]), y = fe_from(b[i]);\n'
+                   '    add[i] = fe_u64(fe_add(x, y)); sub[i] = fe_u64(fe_sub(x, y)); mul[i] = fe_u64(fe_mul(x, y)); inv[i] = fe_u64(fe_inv(x)); } }\n'
+                   % os.path.join(ROOT, 'genstark_amd', 'csrc', 'gf_small.cuh'))
+    for q in (_abi.MODULUS_64, _abi.MODULUS_32):
+        so = str(tmp_path / f'h_{q}.so')
+        subprocess.check_call(['g++', '-O2', '-shared', '-fPIC', f'-DGS_SMALL_Q={q}ull', '-o', so, str(src)])
+        lib = ctypes.CDLL(so)
+        n = 5000
+        a = [0, 1, q - 1, q - 2] + [rng.randrange(q) for _ in range(n - 4)]
+        b = [q - 1, q - 1, q - 1, 2] + [rng.randrange(q) for _ in range(n - 4)]
+        arr = lambda v: (ctypes.c_uint64 * n)(*v)
+        A, B, o = arr(a), arr(b), [(ctypes.c_uint64 * n)() for _ in range(4)]
+        lib.ops(A, B, ctypes.c_uint64(n), *o)
+        assert list(o[0]) == [(x + y) % q for x, y in zip(a, b)]
+        assert list(o[1]) == [(x - y) % q for x, y in zip(a, b)]
+        assert list(o[2]) == [x * y % q for x, y in zip(a, b)]
+        assert list(o[3]) == [pow(x, -1, q) if x else 0 for x in a]
+
+
 def test_product_refuses_the_oracle_backend(oracle_backend):
     from conftest import ORACLE_LIB
     with pytest.raises(_abi.GstarkError, match='refusing backend'):
