@@ -12,12 +12,17 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, 'csrc', 'libgstark_hip.so')
 # one build flavour of the library per field (csrc/build.sh): the 128-bit field of the hot path and the small prime fields of the
-# reference's examples (csrc/gf_small.cuh: same kernels, same 16-byte element layout, plain arithmetic)
+# reference's examples (csrc/gf_small.cuh: same kernels, same 16-byte element layout, plain arithmetic), and the two multi-limb
+# primes of its examples (csrc/gf_wide.cuh: same kernels, 32-byte elements)
 MODULUS_128 = 2**128 - 9 * 2**32 + 1
 MODULUS_64 = 2**64 - 21 * 2**30 + 1        # examples/rescue/hash2x64.ts:10
 MODULUS_32 = 2**32 - 3 * 2**25 + 1         # examples/demo/fibonacci.ts:14, README.md:23 (Foo)
+MODULUS_256 = 2**256 - 351 * 2**32 + 1      # examples/mimc/mimc256.ts:13
+MODULUS_224 = 2**224 - 2**96 + 1            # assembly/lib224.aa:3
 HIP_LIB_PATHS = {MODULUS_128: HIP_LIB_PATH, MODULUS_64: os.path.join(_HERE, 'csrc', 'libgstark_hip_q64.so'),
-                 MODULUS_32: os.path.join(_HERE, 'csrc', 'libgstark_hip_q32.so')}
+                 MODULUS_32: os.path.join(_HERE, 'csrc', 'libgstark_hip_q32.so'),
+                 MODULUS_256: os.path.join(_HERE, 'csrc', 'libgstark_hip_p256.so'),
+                 MODULUS_224: os.path.join(_HERE, 'csrc', 'libgstark_hip_p224.so')}
 
 GS_OK = 0
 HASH_ALGS = {'sha256': 0, 'blake2s256': 1}  # gs_hash_alg; lib/Stark.ts:19
@@ -34,6 +39,7 @@ _SIGNATURES = {
     'gs_last_error': (C.c_char_p, [_vp]),
     'gs_sync': (_int, [_vp]),
     'gs_stream': (_vp, [_vp]),
+    'gs_element_size': (_int, []),
     'gs_field_modulus': (_int, [_vp]),
     'gs_alloc': (_int, [_vp, _u64, _pvp]),
     'gs_free': (_int, [_vp, _vp]),
@@ -109,7 +115,8 @@ class Backend:
                 raise GstarkError(f'no build of the library for the field of {modulus} elements (built: {sorted(HIP_LIB_PATHS)})')
             lib_path = HIP_LIB_PATHS[modulus] if modulus is not None else HIP_LIB_PATH
         self.lib = load_library(lib_path)
-        buf = C.create_string_buffer(16)
+        self.element_size = self.lib.gs_element_size()          # 16, or 32 in the 256- / 224-bit flavours
+        buf = C.create_string_buffer(self.element_size)
         self.lib.gs_field_modulus(C.cast(buf, C.c_void_p))
         self.modulus = int.from_bytes(buf.raw, 'little')
         if modulus is not None and self.modulus != modulus:

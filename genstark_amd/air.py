@@ -14,7 +14,7 @@ import ctypes as C
 import hashlib
 
 from ._abi import GstarkError
-from .field import Matrix, PrimeField, Vector, _le
+from .field import Matrix, PrimeField, Vector
 
 MIMC_SEED = bytes.fromhex('4d694d43')
 
@@ -90,8 +90,8 @@ class ProvingContext(_Context):
         """lib/Stark.ts:97 — 1 x T matrix; sequential on the host CPU inside the library."""
         f = self.field
         m = Matrix(f.backend, 1, self.traceLength)
-        rc = b''.join(_le(k) for k in self.roundConstants)
-        f.backend.call('gs_mimc_trace', _le(self.seed), rc, len(self.roundConstants), self.traceLength, C.c_void_p(m.ptr))
+        rc = b''.join(f.le(k) for k in self.roundConstants)
+        f.backend.call('gs_mimc_trace', f.le(self.seed), rc, len(self.roundConstants), self.traceLength, C.c_void_p(m.ptr))
         return m
 
     def generateStaticTrace(self):

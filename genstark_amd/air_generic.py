@@ -11,7 +11,7 @@ step by step (`gs_air_trace`), and the verifier interprets the same program on P
 import ctypes as C
 
 from ._abi import GstarkError
-from .field import Matrix, PrimeField, Vector, _le
+from .field import Matrix, PrimeField, Vector
 
 OP_LOADC, OP_LOADR, OP_LOADN, OP_LOADS, OP_ADD, OP_SUB, OP_MUL, OP_POW, OP_POWC, OP_OUT = range(10)
 MAX_VM_REGS = 64
@@ -171,9 +171,9 @@ class Program:
         self.code, self.nregs, self.nout = code, max(nregs, 1), len(outs)
 
     # ---- marshalling for the C ABI
-    def abi_args(self):
+    def abi_args(self, element_size=16):
         flat = (C.c_uint32 * (4 * len(self.code)))(*[w for ins in self.code for w in ins])
-        consts = b''.join(int(v).to_bytes(16, 'little') for v in self.consts) or bytes(16)
+        consts = b''.join(int(v).to_bytes(element_size, 'little') for v in self.consts) or bytes(element_size)
         return flat, len(self.code), consts, len(self.consts), self.nregs
 
     # ---- host interpreter (verifier side, Python integers)
@@ -240,23 +240,28 @@ class GenericVerificationContext(_Context):
 
 
 class PackedColumn:
-    """A column of field elements as packed 16-byte little-endian words: what a secret register of 2^16 values should travel as
-    (packing 262 144 Python integers per proof costs more than the proof)."""
+    """A column of field elements as packed little-endian words of the field's elementSize (16 bytes unless said otherwise): what
+    a secret register of 2^16 values should travel as (packing 262 144 Python integers per proof costs more than the proof)."""
 
-    def __init__(self, data):
-        if len(data) % 16:
-            raise GstarkError('packed column: length must be a multiple of 16 bytes')
-        self.data = bytes(data)
+    def __init__(self, data, element_size=16):
+        if len(data) % element_size:
+            raise GstarkError(f'packed column: length must be a multiple of {element_size} bytes')
+        self.data, self.elementSize = bytes(data), element_size
 
     def __len__(self):
-        return len(self.data) // 16
+        return len(self.data) // self.elementSize
 
     def ints(self):
-        return [int.from_bytes(self.data[i:i + 16], 'little') for i in range(0, len(self.data), 16)]
+        es = self.elementSize
+        return [int.from_bytes(self.data[i:i + es], 'little') for i in range(0, len(self.data), es)]
 
     @staticmethod
-    def of(values, modulus):
-        return values if isinstance(values, PackedColumn) else PackedColumn(b''.join(_le(v % modulus) for v in values))
+    def of(values, modulus, element_size=16):
+        if isinstance(values, PackedColumn):
+            if values.elementSize != element_size:
+                raise GstarkError(f'packed column of {values.elementSize}-byte elements in a field of {element_size}-byte elements')
+            return values
+        return PackedColumn(b''.join(int(v % modulus).to_bytes(element_size, 'little') for v in values), element_size)
 
 
 class GenericProvingContext(_Context):
@@ -269,7 +274,7 @@ class GenericProvingContext(_Context):
         for values in secret_values:
             if not len(values) or len(values) & (len(values) - 1) or self.traceLength % len(values):
                 raise GstarkError('a secret register holds a power-of-2 number of values dividing the trace length (it repeats cyclically)')
-        self.secretValues = [PackedColumn.of(values, f.modulus) for values in secret_values]
+        self.secretValues = [PackedColumn.of(values, f.modulus, f.elementSize) for values in secret_values]
         n, nc = self.traceLength * self.extensionFactor, self.traceLength * self.compositionFactor
         self.firstRows = [[v % f.modulus for v in row] for row in first_rows]
         self.firstRow = self.firstRows[0]
@@ -303,32 +308,32 @@ class GenericProvingContext(_Context):
         for (m, poly), ln in zip(all_polys, lens):
             wk = f.exp(self.compositionDomain.series_base, self.traceLength // m)
             tab = f.evalPolyAtRoots(poly, f.getPowerSeries(wk, ln))
-            f.backend.call('gs_copy', C.c_void_p(self._staticTables.ptr + off * 16), C.c_void_p(tab.ptr), ln * 16)
+            f.backend.call('gs_copy', C.c_void_p(self._staticTables.ptr + off * f.elementSize), C.c_void_p(tab.ptr), ln * f.elementSize)
             off += ln
 
     def staticValuesPacked(self):
         """(bytes, periods) of every static register's values for the trace generators: public ones, then the secret columns."""
         air, f = self.air, self.field
-        packed = b''.join(_le(v % f.modulus) for values in air.staticRegisters for v in values) + b''.join(c.data for c in self.secretValues)
+        packed = b''.join(f.le(v % f.modulus) for values in air.staticRegisters for v in values) + b''.join(c.data for c in self.secretValues)
         periods = [len(v) for v in air.staticRegisters] + [len(c) for c in self.secretValues]
-        return packed or bytes(16), periods
+        return packed or bytes(f.elementSize), periods
 
     def generateExecutionTrace(self):   # lib/Stark.ts:97
         air, f = self.air, self.field
-        code, ninstr, consts, nconsts, nregs = air.transitionProgram.abi_args()
+        code, ninstr, consts, nconsts, nregs = air.transitionProgram.abi_args(f.elementSize)
         m = Matrix(f.backend, air.traceRegisterCount, self.traceLength)
         svals, plist = self.staticValuesPacked()
         statics = plist
         periods = (C.c_uint32 * max(len(plist), 1))(*plist)
         if air.segmentLength is None:
             f.backend.call('gs_air_trace', code, ninstr, consts, nconsts, nregs, air.traceRegisterCount, svals, periods,
-                           len(statics), b''.join(_le(v) for v in self.firstRow), self.traceLength, C.c_void_p(m.ptr))
+                           len(statics), b''.join(f.le(v) for v in self.firstRow), self.traceLength, C.c_void_p(m.ptr))
         else:
             icode, ininstr = None, 0
             if air.initProgram is not None:
-                icode, ininstr = air.initProgram.abi_args()[:2]
+                icode, ininstr = air.initProgram.abi_args(f.elementSize)[:2]
             f.backend.call('gs_air_trace_segments', code, ninstr, icode, ininstr, consts, nconsts, nregs, air.traceRegisterCount, svals, periods,
-                           len(statics), b''.join(_le(v) for row in self.firstRows for v in row), len(self.firstRows),
+                           len(statics), b''.join(f.le(v) for row in self.firstRows for v in row), len(self.firstRows),
                            air.segmentLength, C.c_void_p(m.ptr))
         return m
 
@@ -341,7 +346,7 @@ class GenericProvingContext(_Context):
         air, f = self.air, self.field
         nc = self.compositionDomain.length
         p_comp = f.evalPolysAtRoots(pPolys, self.compositionDomain)
-        code, ninstr, consts, nconsts, nregs = air.evaluationProgram.abi_args()
+        code, ninstr, consts, nconsts, nregs = air.evaluationProgram.abi_args(f.elementSize)
         q = Matrix(f.backend, len(air.constraintDegrees), nc)
         lens = (C.c_uint64 * max(len(self._staticLens), 1))(*self._staticLens)
         f.backend.call('gs_air_constraints', code, ninstr, consts, nconsts, nregs, air.traceRegisterCount, len(air.constraintDegrees),

@@ -21,30 +21,27 @@ __global__ void k_mimc_constraints(const fe *__restrict__ p, uint64_t nc, uint64
 // (host_field.h), written straight into a pinned staging buffer that is then copied to the device.
 extern "C" {
 
-int gs_mimc_trace(gs_ctx *c, const uint8_t seed[16], const uint8_t *rc_host, uint32_t nrc, uint64_t steps, void *out) {
+int gs_mimc_trace(gs_ctx *c, const gs_elt *seed, const uint8_t *rc_host, uint32_t nrc, uint64_t steps, void *out) {
     if (!c || !seed || !rc_host || !out) return GS_ERR_ARG;
     if (!nrc || !steps) return gs_fail(c, GS_ERR_ARG, "mimc_trace: empty");
-    std::vector<hu128> rc(nrc);
-    for (uint32_t i = 0; i < nrc; i++) rc[i] = hf_load(rc_host + 16 * i);
+    std::vector<hfe> rc(nrc);
+    for (uint32_t i = 0; i < nrc; i++) rc[i] = hf_load(rc_host + GS_ELT * i);
     // pinned, grow-only; waits only for the previous trace's upload, so device work the caller queued before this call
     // (domains, Z(x) inverses, ...) runs while this core grinds through the recurrence
-    int rcode = gs_trace_begin(c, steps * 16);
+    int rcode = gs_trace_begin(c, steps * GS_ELT);
     if (rcode) return rcode;
-    hu128 *t = (hu128 *)c->h_trace;
-    hu128 x = hf_load(seed);
+    hfe *t = (hfe *)c->h_trace;
+    hfe x = hf_load(seed);
     uint32_t ri = 0;
     const uint64_t CHUNK = 1ull << 16;            // copy finished chunks while the next one is being generated
     for (uint64_t base = 0; base < steps; base += CHUNK) {
         const uint64_t end = base + CHUNK < steps ? base + CHUNK : steps;
         for (uint64_t i = base; i < end; i++) {
             t[i] = x;
-            hu128 y = hf_cube_weak(x);                       // any representative of x^3
-            hu128 sum = y + rc[ri];
-            if (sum < y) sum += HF_C;                        // wrapped past 2^128: +2^128 == +C (the wrapped value is small)
-            x = hf_canon(sum);
+            x = hf_mimc_step(x, rc[ri]);
             if (++ri == nrc) ri = 0;
         }
-        GS_HIP(c, hipMemcpyAsync((uint8_t *)out + base * 16, t + base, (end - base) * 16, hipMemcpyHostToDevice, c->stream));
+        GS_HIP(c, hipMemcpyAsync((uint8_t *)out + base * GS_ELT, t + base, (end - base) * GS_ELT, hipMemcpyHostToDevice, c->stream));
     }
     return gs_trace_end(c);   // no synchronisation: consumers are ordered on the stream
 }

@@ -49,8 +49,10 @@ __device__ __forceinline__ void pow_group(fe (&x)[4], const fe &e) {
     fe r[4];
 #pragma unroll
     for (int i = 0; i < G; i++) r[i] = fe_one();
-    const uint32_t ev[4] = {e.w0, e.w1, e.w2, e.w3};
-    int top = 3;
+    uint32_t ev[GF_LIMBS];
+#pragma unroll
+    for (int l = 0; l < GF_LIMBS; l++) ev[l] = fe_limb(e, l);
+    int top = GF_LIMBS - 1;
     while (top > 0 && ev[top] == 0) top--;
     for (int w = 0; w <= top; w++) {
         uint32_t bits = ev[w];
@@ -196,11 +198,11 @@ int gs_air_constraints(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, co
         }
     }
     // program + constants to device scratch (small; one sync so the staging buffer can be reused)
-    const uint64_t code_bytes = ((uint64_t)ninstr * 16 + 255) & ~(uint64_t)255, const_bytes = (uint64_t)(nconsts ? nconsts : 1) * 16;
+    const uint64_t code_bytes = ((uint64_t)ninstr * 16 + 255) & ~(uint64_t)255, const_bytes = (uint64_t)(nconsts ? nconsts : 1) * GS_ELT;
     void *dprog;
     if ((rc = gs_tmp_alloc(c, code_bytes + const_bytes, &dprog))) return rc;
     hipError_t e = hipMemcpyAsync(dprog, code_host, (size_t)ninstr * 16, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && nconsts) e = hipMemcpyAsync((uint8_t *)dprog + code_bytes, consts_host, (size_t)nconsts * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && nconsts) e = hipMemcpyAsync((uint8_t *)dprog + code_bytes, consts_host, (size_t)nconsts * GS_ELT, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // host buffers are pageable and owned by the caller
     if (e != hipSuccess) { gs_tmp_free(c, dprog); return gs_fail(c, GS_ERR_DEVICE, "air_constraints upload: %s", hipGetErrorString(e)); }
     const uint4 *dcode = (const uint4 *)dprog;
@@ -239,22 +241,22 @@ int gs_air_trace_segments(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr,
     }
     // program, constants, static values and first rows -> one device block (pageable caller memory: one sync)
     const uint64_t main_b = ((uint64_t)ninstr * 16 + 255) & ~(uint64_t)255, code_b = main_b + (((uint64_t)init_ninstr * 16 + 255) & ~(uint64_t)255);
-    const uint64_t const_b = ((uint64_t)(nconsts ? nconsts : 1) * 16 + 255) & ~(uint64_t)255;
-    const uint64_t stat_b = ((nstat ? nstat : 1) * 16 + 255) & ~(uint64_t)255, rows_b = segments * registers * 16;
+    const uint64_t const_b = ((uint64_t)(nconsts ? nconsts : 1) * GS_ELT + 255) & ~(uint64_t)255;
+    const uint64_t stat_b = ((nstat ? nstat : 1) * GS_ELT + 255) & ~(uint64_t)255, rows_b = segments * registers * GS_ELT;
     void *d;
     if ((rc = gs_tmp_alloc(c, code_b + const_b + stat_b + rows_b, &d))) return rc;
     uint8_t *p = (uint8_t *)d;
     hipError_t e = hipMemcpyAsync(p, code_host, (size_t)ninstr * 16, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && init_ninstr) e = hipMemcpyAsync(p + main_b, init_code_host, (size_t)init_ninstr * 16, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && nconsts) e = hipMemcpyAsync(p + code_b, consts_host, (size_t)nconsts * 16, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && nstat) e = hipMemcpyAsync(p + code_b + const_b, static_values_host, (size_t)nstat * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && nconsts) e = hipMemcpyAsync(p + code_b, consts_host, (size_t)nconsts * GS_ELT, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && nstat) e = hipMemcpyAsync(p + code_b + const_b, static_values_host, (size_t)nstat * GS_ELT, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(p + code_b + const_b + stat_b, first_rows_host, (size_t)rows_b, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { gs_tmp_free(c, d); return gs_fail(c, GS_ERR_DEVICE, "air_trace_segments upload: %s", hipGetErrorString(e)); }
     const uint4 *dcode = (const uint4 *)p, *dinit = (const uint4 *)(p + main_b);
     const fe *dconst = (const fe *)(p + code_b), *dstat = (const fe *)(p + code_b + const_b), *drows = (const fe *)(p + code_b + const_b + stat_b);
     dim3 block(64), grid((unsigned)((segments + 63) / 64));   // one wave per 64 segments: spread the few long-running threads over the CUs
-    const uint64_t lds_bytes = ((uint64_t)vm_regs + 2ull * registers) * 64 * 16;
+    const uint64_t lds_bytes = ((uint64_t)vm_regs + 2ull * registers) * 64 * GS_ELT;
 #define GS_LAUNCH_TRACE(N, L, SH)                                                                                                        \
     hipLaunchKernelGGL((k_air_trace_segments<N, L>), grid, block, SH, c->stream, dcode, ninstr, dinit, init_ninstr, dconst, dstat, sd, drows, \
                        registers, segments, segment_len, vm_regs, (fe *)out)
@@ -276,20 +278,20 @@ int gs_air_trace(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, const ui
     int rc = check_program(c, code_host, ninstr, nconsts, vm_regs, registers, nstatic, registers, false);
     if (rc) return rc;
     if (!steps) return gs_fail(c, GS_ERR_ARG, "air_trace: empty");
-    std::vector<hu128> consts(nconsts ? nconsts : 1), vm(vm_regs), row(registers), next(registers);
-    for (uint32_t i = 0; i < nconsts; i++) consts[i] = hf_load(consts_host + 16 * i);
-    std::vector<std::vector<hu128>> statics(nstatic);
+    std::vector<hfe> consts(nconsts ? nconsts : 1), vm(vm_regs), row(registers), next(registers);
+    for (uint32_t i = 0; i < nconsts; i++) consts[i] = hf_load(consts_host + GS_ELT * i);
+    std::vector<std::vector<hfe>> statics(nstatic);
     {
         const uint8_t *p = static_values_host;
         for (uint32_t s = 0; s < nstatic; s++) {
             if (!static_periods_host[s]) return gs_fail(c, GS_ERR_ARG, "air_trace: empty static register");
             statics[s].resize(static_periods_host[s]);
-            for (uint32_t i = 0; i < static_periods_host[s]; i++, p += 16) statics[s][i] = hf_load(p);
+            for (uint32_t i = 0; i < static_periods_host[s]; i++, p += GS_ELT) statics[s][i] = hf_load(p);
         }
     }
-    if ((rc = gs_trace_begin(c, (uint64_t)registers * steps * 16))) return rc;
-    hu128 *t = (hu128 *)c->h_trace;  // registers x steps, row-major like the Matrix the caller gets
-    for (uint32_t r = 0; r < registers; r++) row[r] = hf_load(first_row_host + 16 * r);
+    if ((rc = gs_trace_begin(c, (uint64_t)registers * steps * GS_ELT))) return rc;
+    hfe *t = (hfe *)c->h_trace;  // registers x steps, row-major like the Matrix the caller gets
+    for (uint32_t r = 0; r < registers; r++) row[r] = hf_load(first_row_host + GS_ELT * r);
     for (uint64_t i = 0; i < steps; i++) {
         for (uint32_t r = 0; r < registers; r++) t[(uint64_t)r * steps + i] = row[r];
         if (i + 1 == steps) break;
@@ -303,14 +305,14 @@ int gs_air_trace(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, const ui
                 case OP_ADDV: vm[dst] = hf_add(vm[a], vm[b]); break;
                 case OP_SUBV: vm[dst] = hf_sub(vm[a], vm[b]); break;
                 case OP_MULV: vm[dst] = hf_mul(vm[a], vm[b]); break;
-                case OP_POW: vm[dst] = hf_pow(vm[a], (hu128)b); break;
+                case OP_POW: vm[dst] = hf_pow(vm[a], (hfe)b); break;
                 case OP_POWC: vm[dst] = hf_pow(vm[a], consts[b]); break;
                 default: next[dst] = vm[a]; break;
             }
         }
         row = next;
     }
-    GS_HIP(c, hipMemcpyAsync(out, c->h_trace, (size_t)registers * steps * 16, hipMemcpyHostToDevice, c->stream));
+    GS_HIP(c, hipMemcpyAsync(out, c->h_trace, (size_t)registers * steps * GS_ELT, hipMemcpyHostToDevice, c->stream));
     return gs_trace_end(c);
 }
 

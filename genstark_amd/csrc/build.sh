@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
 UNITS="ctx ntt pointwise hash air_mimc air_vm small"
-HDRS="gf128.cuh gf_small.cuh common.h host_field.h host_field_small.h host_sha256.h hash_core.cuh ../../include/gstark.h"
+HDRS="gf128.cuh gf_small.cuh gf_wide.cuh common.h host_field.h host_field_small.h host_field_wide.h host_sha256.h hash_core.cuh ../../include/gstark.h"
 # one library per field: the 128-bit field of the hot path, and two "plumbing" flavours of the same sources for the small prime
 # fields of the reference's examples (gf_small.cuh): 2^64 - 21*2^30 + 1 (rescue/hash2x64.ts) and 2^32 - 3*2^25 + 1 (demo/fibonacci.ts)
 build_flavour() {   # <object dir> <output> <extra flags>
@@ -26,6 +26,9 @@ build_flavour() {   # <object dir> <output> <extra flags>
 build_flavour build libgstark_hip.so "" &
 build_flavour build_q64 libgstark_hip_q64.so "-DGS_SMALL_Q=18446744051160973313ull" &
 build_flavour build_q32 libgstark_hip_q32.so "-DGS_SMALL_Q=4194304001ull" &
+# ... and the two multi-limb fields (gf_wide.cuh, 32-byte elements): 2^256 - 351*2^32 + 1 (mimc/mimc256.ts), 2^224 - 2^96 + 1 (lib224.aa)
+build_flavour build_p256 libgstark_hip_p256.so "-DGS_WIDE_BITS=256" &
+build_flavour build_p224 libgstark_hip_p224.so "-DGS_WIDE_BITS=224" &
 wait
 # the native prove() driver: plain C++ above the C ABI (binds to whichever implementation of it the caller loaded)
 g++ -O2 -std=c++17 -shared -fPIC -Wall -Wno-unused-function prover.cc -ldl -o libgstark_prover.so

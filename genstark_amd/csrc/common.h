@@ -10,10 +10,24 @@
 #include <vector>
 
 #include "../../include/gstark.h"
-#ifdef GS_SMALL_Q
+#if defined(GS_SMALL_Q)
 #include "gf_small.cuh"   // build flavour for a prime below 2^64 (same names, same 16-byte elements)
+#elif defined(GS_WIDE_BITS)
+#include "gf_wide.cuh"    // build flavour for the 256- / 224-bit primes (same names, 32-byte elements)
 #else
 #include "gf128.cuh"
+#endif
+
+// bytes of one element in memory and on the ABI (gs_element_size()), and the same in 16-byte words
+#define GS_ELT ((uint64_t)sizeof(fe))
+#define GS_EW ((uint32_t)(sizeof(fe) / 16))
+#ifndef GF_LIMBS
+#define GF_LIMBS 4
+GF_HD uint32_t fe_limb(const fe &a, int i) { return i == 0 ? a.w0 : (i == 1 ? a.w1 : (i == 2 ? a.w2 : a.w3)); }
+GF_HD void fe_set_limb(fe &a, int i, uint32_t v) { if (i == 0) a.w0 = v; else if (i == 1) a.w1 = v; else if (i == 2) a.w2 = v; else a.w3 = v; }
+#else
+GF_HD uint32_t fe_limb(const fe &a, int i) { return a.w[i]; }
+GF_HD void fe_set_limb(fe &a, int i, uint32_t v) { a.w[i] = v; }
 #endif
 
 struct NttPlan;  // ntt.hip
@@ -56,8 +70,8 @@ int gs_fail(gs_ctx *c, int code, const char *fmt, ...);
 static inline bool gs_is_pow2(uint64_t x) { return x && !(x & (x - 1)); }
 static inline int gs_log2(uint64_t x) { int l = 0; while ((1ull << l) < x) l++; return l; }
 
-static inline fe fe_from_bytes(const uint8_t *b) { fe r; memcpy(&r, b, 16); return r; }
-static inline void fe_to_bytes(uint8_t *b, const fe &v) { memcpy(b, &v, 16); }
+static inline fe fe_from_bytes(const uint8_t *b) { fe r; memcpy(&r, b, sizeof(fe)); return r; }
+static inline void fe_to_bytes(uint8_t *b, const fe &v) { memcpy(b, &v, sizeof(fe)); }
 static inline fe fe_from_u64(uint64_t v) { return fe_make((uint32_t)v, (uint32_t)(v >> 32), 0, 0); }
 
 // staging helpers (ctx.hip)

@@ -18,9 +18,16 @@ extern "C" {
 int gs_abi_version(void) { return GS_ABI_VERSION; }
 const char *gs_backend_name(void) { return "hip-gfx950"; }
 
-int gs_field_modulus(uint8_t out_le[16]) {
+int gs_element_size(void) { return (int)sizeof(fe); }
+
+int gs_field_modulus(uint8_t *out_le) {
+#ifdef GS_WIDE_BITS
+    fe p;
+    for (int i = 0; i < GF_LIMBS; i++) p.w[i] = gf_p_limb(i);
+#else
     fe p = fe_make(GF_P0, GF_P1, GF_P2, GF_P3);
-    memcpy(out_le, &p, 16);
+#endif
+    memcpy(out_le, &p, sizeof(fe));
     return GS_OK;
 }
 

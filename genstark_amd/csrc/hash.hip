@@ -68,7 +68,7 @@ template <int ALG>
 __global__ void k_hash_merge_rows(HashPtrArgs va, uint32_t count, uint64_t n, uint4 *__restrict__ out) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t d[8];
-        digest_words16<ALG>([&](uint32_t w) { return va.v[w][i]; }, count, d);
+        digest_words16<ALG>([&](uint32_t w) { return va.v[w / GS_EW][i * GS_EW + w % GS_EW]; }, count * GS_EW, d);
         store_digest(out, i, d);
     }
 }
@@ -77,7 +77,7 @@ template <int ALG>
 __global__ void k_hash_merge_rows1(const uint4 *__restrict__ v, uint64_t n, uint4 *__restrict__ out) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         uint32_t d[8];
-        digest_words16<ALG>([&](uint32_t) { return v[i]; }, 1, d);
+        digest_words16<ALG>([&](uint32_t w) { return v[i * GS_EW + w]; }, GS_EW, d);
         store_digest(out, i, d);
     }
 }

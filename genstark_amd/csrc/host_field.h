@@ -2,35 +2,37 @@
 // the serial MiMC recurrence (air_mimc.hip) and O(n^2) Lagrange interpolation of <= a few hundred points
 // (small.hip).  Same modulus and canonical representation as gf128.cuh.
 #pragma once
-#ifdef GS_SMALL_Q
+#if defined(GS_SMALL_Q)
 #include "host_field_small.h"
+#elif defined(GS_WIDE_BITS)
+#include "host_field_wide.h"
 #else
 #include <stdint.h>
 #include <string.h>
 
-typedef unsigned __int128 hu128;
+typedef unsigned __int128 hfe;
 
-static inline hu128 hf_p() { return ((hu128)0xFFFFFFFFFFFFFFFFull << 64) | 0xFFFFFFF700000001ull; }
-static const hu128 HF_C = (hu128)0x8FFFFFFFFull;  // 2^128 mod p
+static inline hfe hf_p() { return ((hfe)0xFFFFFFFFFFFFFFFFull << 64) | 0xFFFFFFF700000001ull; }
+static const hfe HF_C = (hfe)0x8FFFFFFFFull;  // 2^128 mod p
 
-static inline hu128 hf_reduce(hu128 hi, hu128 lo) {
-    hu128 m0 = (hu128)(uint64_t)hi * HF_C, m1 = (hu128)(uint64_t)(hi >> 64) * HF_C;
-    hu128 tl = m0 + (m1 << 64);
-    hu128 th = (m1 >> 64) + (tl < m0);
-    hu128 s = tl + lo;
+static inline hfe hf_reduce(hfe hi, hfe lo) {
+    hfe m0 = (hfe)(uint64_t)hi * HF_C, m1 = (hfe)(uint64_t)(hi >> 64) * HF_C;
+    hfe tl = m0 + (m1 << 64);
+    hfe th = (m1 >> 64) + (tl < m0);
+    hfe s = tl + lo;
     unsigned k = s < tl;
-    hu128 s2 = s + th * HF_C;
+    hfe s2 = s + th * HF_C;
     k += s2 < s;
-    while (k) { hu128 s3 = s2 + HF_C; k -= 1; k += s3 < s2; s2 = s3; }
+    while (k) { hfe s3 = s2 + HF_C; k -= 1; k += s3 < s2; s2 = s3; }
     while (s2 >= hf_p()) s2 -= hf_p();
     return s2;
 }
-static inline hu128 hf_mul(hu128 a, hu128 b) {
+static inline hfe hf_mul(hfe a, hfe b) {
     uint64_t a0 = (uint64_t)a, a1 = (uint64_t)(a >> 64), b0 = (uint64_t)b, b1 = (uint64_t)(b >> 64);
-    hu128 p00 = (hu128)a0 * b0, p01 = (hu128)a0 * b1, p10 = (hu128)a1 * b0, p11 = (hu128)a1 * b1;
-    hu128 mid = p01 + p10, midc = mid < p01;
-    hu128 lo = p00 + (mid << 64), c1 = lo < p00;
-    hu128 hi = p11 + (mid >> 64) + (midc << 64) + c1;
+    hfe p00 = (hfe)a0 * b0, p01 = (hfe)a0 * b1, p10 = (hfe)a1 * b0, p11 = (hfe)a1 * b1;
+    hfe mid = p01 + p10, midc = mid < p01;
+    hfe lo = p00 + (mid << 64), c1 = lo < p00;
+    hfe hi = p11 + (mid >> 64) + (midc << 64) + c1;
     return hf_reduce(hi, lo);
 }
 // Weakly reduced product for latency-bound serial chains (the MiMC recurrence): returns ANY 128-bit representative of
@@ -38,73 +40,73 @@ static inline hu128 hf_mul(hu128 a, hu128 b) {
 // shift/subtract fold mispredict every other product): with C = 2^128 mod p and hi = h1*2^64 + h0,
 //   a*b = lo + h0*C + ((h1*C mod 2^64) << 64) + ((h1*C >> 64) + carries) * C        (mod p)
 // and the final compare-and-subtract is skipped, which shortens the dependency chain of x -> x^2 -> x^3.
-static inline hu128 hf_mul_weak(hu128 a, hu128 b) {
+static inline hfe hf_mul_weak(hfe a, hfe b) {
     uint64_t a0 = (uint64_t)a, a1 = (uint64_t)(a >> 64), b0 = (uint64_t)b, b1 = (uint64_t)(b >> 64);
-    hu128 p00 = (hu128)a0 * b0, p01 = (hu128)a0 * b1, p10 = (hu128)a1 * b0, p11 = (hu128)a1 * b1;
-    hu128 mid = p01 + p10;
+    hfe p00 = (hfe)a0 * b0, p01 = (hfe)a0 * b1, p10 = (hfe)a1 * b0, p11 = (hfe)a1 * b1;
+    hfe mid = p01 + p10;
     uint64_t midc = mid < p01;
-    hu128 lo = p00 + (mid << 64);
+    hfe lo = p00 + (mid << 64);
     uint64_t c1 = lo < p00;
-    hu128 hi = p11 + (mid >> 64) + ((hu128)midc << 64) + c1;
+    hfe hi = p11 + (mid >> 64) + ((hfe)midc << 64) + c1;
     const uint64_t cc = (uint64_t)HF_C;
-    hu128 m0 = (hu128)(uint64_t)hi * cc, m1 = (hu128)(uint64_t)(hi >> 64) * cc;   // each < 2^100
-    hu128 t = m0 + (m1 << 64);
+    hfe m0 = (hfe)(uint64_t)hi * cc, m1 = (hfe)(uint64_t)(hi >> 64) * cc;   // each < 2^100
+    hfe t = m0 + (m1 << 64);
     uint64_t k = t < m0;
-    hu128 s = lo + t;
+    hfe s = lo + t;
     k += s < lo;
-    hu128 top = (hu128)((uint64_t)(m1 >> 64) + k) * cc;                              // (< 2^37) * C < 2^73
-    hu128 r = s + top;
+    hfe top = (hfe)((uint64_t)(m1 >> 64) + k) * cc;                              // (< 2^37) * C < 2^73
+    hfe r = s + top;
     if (__builtin_expect(r < s, 0)) r += HF_C;                                         // probability ~2^-55
     return r;
 }
 // Weak x^3 for the MiMC recurrence in one go: 256-bit square, 384-bit product, ONE fold of the upper 256 bits
 // (2^128 == C, 2^256 == C^2 mod p).  10% shorter dependency chain than two hf_mul_weak on Zen 5 (tools/trace_bench.cpp).
-static inline hu128 hf_cube_weak(hu128 x) {
+static inline hfe hf_cube_weak(hfe x) {
     typedef uint64_t u64;
     const u64 C = (u64)HF_C, C20 = 0xFFFFFFEE00000001ull, C21 = 80;   // C^2 = 81*2^64 - 18*2^32 + 1 = C21*2^64 + C20
     u64 x0 = (u64)x, x1 = (u64)(x >> 64);
-    hu128 p00 = (hu128)x0 * x0, p01 = (hu128)x0 * x1, p11 = (hu128)x1 * x1;
+    hfe p00 = (hfe)x0 * x0, p01 = (hfe)x0 * x1, p11 = (hfe)x1 * x1;
     u64 s0 = (u64)p00;
-    hu128 mid = (p00 >> 64) + ((hu128)(u64)p01 << 1);
+    hfe mid = (p00 >> 64) + ((hfe)(u64)p01 << 1);
     u64 s1 = (u64)mid;
-    hu128 up = (mid >> 64) + ((p01 >> 64) << 1) + (u64)p11;
+    hfe up = (mid >> 64) + ((p01 >> 64) << 1) + (u64)p11;
     u64 s2 = (u64)up;
     u64 s3 = (u64)(up >> 64) + (u64)(p11 >> 64);
-    hu128 q00 = (hu128)s0 * x0, q10 = (hu128)s1 * x0, q20 = (hu128)s2 * x0, q30 = (hu128)s3 * x0;
-    hu128 q01 = (hu128)s0 * x1, q11 = (hu128)s1 * x1, q21 = (hu128)s2 * x1, q31 = (hu128)s3 * x1;
+    hfe q00 = (hfe)s0 * x0, q10 = (hfe)s1 * x0, q20 = (hfe)s2 * x0, q30 = (hfe)s3 * x0;
+    hfe q01 = (hfe)s0 * x1, q11 = (hfe)s1 * x1, q21 = (hfe)s2 * x1, q31 = (hfe)s3 * x1;
     u64 y0 = (u64)q00;
-    hu128 c1 = (q00 >> 64) + (u64)q10 + (u64)q01;
+    hfe c1 = (q00 >> 64) + (u64)q10 + (u64)q01;
     u64 y1 = (u64)c1;
-    hu128 c2 = (c1 >> 64) + (q10 >> 64) + (q01 >> 64) + (u64)q20 + (u64)q11;
+    hfe c2 = (c1 >> 64) + (q10 >> 64) + (q01 >> 64) + (u64)q20 + (u64)q11;
     u64 y2 = (u64)c2;
-    hu128 c3 = (c2 >> 64) + (q20 >> 64) + (q11 >> 64) + (u64)q30 + (u64)q21;
+    hfe c3 = (c2 >> 64) + (q20 >> 64) + (q11 >> 64) + (u64)q30 + (u64)q21;
     u64 y3 = (u64)c3;
-    hu128 c4 = (c3 >> 64) + (q30 >> 64) + (q21 >> 64) + (u64)q31;
+    hfe c4 = (c3 >> 64) + (q30 >> 64) + (q21 >> 64) + (u64)q31;
     u64 y4 = (u64)c4;
     u64 y5 = (u64)(c4 >> 64) + (u64)(q31 >> 64);
-    hu128 A = (hu128)y2 * C, B = (hu128)y3 * C, D = (hu128)y4 * C20, E = (hu128)y4 * C21, G = (hu128)y5 * C20, H = (hu128)y5 * C21;
-    hu128 a0 = (hu128)y0 + (u64)A + (u64)D;
-    hu128 a1 = (hu128)y1 + (u64)(A >> 64) + (u64)(D >> 64) + (u64)B + (u64)E + (u64)G + (u64)(a0 >> 64);
-    hu128 T = (B >> 64) + (E >> 64) + (G >> 64) + H + (a1 >> 64);          // < 2^73
-    hu128 R = ((hu128)(u64)a1 << 64) | (u64)a0;
-    hu128 TC = (hu128)(u64)T * C + (((hu128)(u64)(T >> 64) * C) << 64);
-    hu128 r = R + TC;
+    hfe A = (hfe)y2 * C, B = (hfe)y3 * C, D = (hfe)y4 * C20, E = (hfe)y4 * C21, G = (hfe)y5 * C20, H = (hfe)y5 * C21;
+    hfe a0 = (hfe)y0 + (u64)A + (u64)D;
+    hfe a1 = (hfe)y1 + (u64)(A >> 64) + (u64)(D >> 64) + (u64)B + (u64)E + (u64)G + (u64)(a0 >> 64);
+    hfe T = (B >> 64) + (E >> 64) + (G >> 64) + H + (a1 >> 64);          // < 2^73
+    hfe R = ((hfe)(u64)a1 << 64) | (u64)a0;
+    hfe TC = (hfe)(u64)T * C + (((hfe)(u64)(T >> 64) * C) << 64);
+    hfe r = R + TC;
     if (__builtin_expect(r < R, 0)) r += HF_C;
     return r;
 }
 
-static inline hu128 hf_canon(hu128 x) {
+static inline hfe hf_canon(hfe x) {
     while (x >= hf_p()) x -= hf_p();
     return x;
 }
-static inline hu128 hf_add(hu128 a, hu128 b) {
-    hu128 s = a + b;
+static inline hfe hf_add(hfe a, hfe b) {
+    hfe s = a + b;
     if (s < a || s >= hf_p()) s -= hf_p();
     return s;
 }
-static inline hu128 hf_sub(hu128 a, hu128 b) { return a >= b ? a - b : a - b + hf_p(); }
-static inline hu128 hf_pow(hu128 b, hu128 e) {
-    hu128 r = 1;
+static inline hfe hf_sub(hfe a, hfe b) { return a >= b ? a - b : a - b + hf_p(); }
+static inline hfe hf_pow(hfe b, hfe e) {
+    hfe r = 1;
     while (e) {
         if (e & 1) r = hf_mul(r, b);
         b = hf_mul(b, b);
@@ -112,7 +114,14 @@ static inline hu128 hf_pow(hu128 b, hu128 e) {
     }
     return r;
 }
-static inline hu128 hf_inv(hu128 a) { return a ? hf_pow(a, hf_p() - 2) : 0; }
-static inline hu128 hf_load(const uint8_t *b) { hu128 v; memcpy(&v, b, 16); return v; }
-static inline void hf_store(uint8_t *b, hu128 v) { memcpy(b, &v, 16); }
+static inline hfe hf_inv(hfe a) { return a ? hf_pow(a, hf_p() - 2) : 0; }
+static inline hfe hf_load(const uint8_t *b) { hfe v; memcpy(&v, b, 16); return v; }
+static inline void hf_store(uint8_t *b, hfe v) { memcpy(b, &v, 16); }
+// one step of the MiMC recurrence x <- x^3 + k (examples/mimc/utils.ts:7-15) on the weak cube
+static inline hfe hf_mimc_step(hfe x, hfe k) {
+    hfe y = hf_cube_weak(x);                           // any representative of x^3
+    hfe sum = y + k;
+    if (sum < y) sum += HF_C;                          // wrapped past 2^128: +2^128 == +C (the wrapped value is small)
+    return hf_canon(sum);
+}
 #endif  // GS_SMALL_Q

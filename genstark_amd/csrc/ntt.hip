@@ -223,8 +223,10 @@ static uint64_t max_pass_twiddle_entries() {  // 16 MiB per table by default; la
 }
 
 static std::string plan_key(const fe &omega, uint64_t n) {
-    char buf[96];
-    snprintf(buf, sizeof buf, "%08x%08x%08x%08x:%llu", omega.w3, omega.w2, omega.w1, omega.w0, (unsigned long long)n);
+    char buf[16 + 8 * GF_LIMBS + 24];
+    int at = 0;
+    for (int l = GF_LIMBS - 1; l >= 0; l--) at += snprintf(buf + at, sizeof buf - at, "%08x", fe_limb(omega, l));
+    snprintf(buf + at, sizeof buf - at, ":%llu", (unsigned long long)n);
     return buf;
 }
 
@@ -245,12 +247,12 @@ static int plan_get(gs_ctx *c, const fe &omega, uint64_t n, NttPlan **out) {
     p->log_lo = p->logn < 12 ? p->logn : 12;
     int rc;
     void *q = nullptr;
-    if ((rc = gs_alloc(c, (1ull << p->log_lo) * 16, &q))) { delete p; return rc; }
+    if ((rc = gs_alloc(c, (1ull << p->log_lo) * GS_ELT, &q))) { delete p; return rc; }
     p->tw_lo = (fe *)q;
     if ((rc = gs_power_series_dev(c, omega, 1ull << p->log_lo, p->tw_lo))) { delete p; return rc; }
     if (p->logn > p->log_lo) {
         uint64_t nhi = n >> p->log_lo;
-        if ((rc = gs_alloc(c, nhi * 16, &q))) { delete p; return rc; }
+        if ((rc = gs_alloc(c, nhi * GS_ELT, &q))) { delete p; return rc; }
         p->tw_hi = (fe *)q;
         if ((rc = gs_power_series_dev(c, fe_pow_u64(omega, 1ull << p->log_lo), nhi, p->tw_hi))) { delete p; return rc; }
     } else {
@@ -266,7 +268,7 @@ static int plan_get(gs_ctx *c, const fe &omega, uint64_t n, NttPlan **out) {
             p->L[i] = base + (i < extra ? 1 : 0);
             uint64_t R = 1ull << p->L[i];
             if (i > 0 && Ns_acc * R <= max_pass_twiddle_entries()) {
-                if ((rc = gs_alloc(c, Ns_acc * R * 16, &q))) { delete p; return rc; }
+                if ((rc = gs_alloc(c, Ns_acc * R * GS_ELT, &q))) { delete p; return rc; }
                 p->twp[i] = (fe *)q;
                 hipLaunchKernelGGL(k_build_pass_twiddles, dim3(gs_grid(Ns_acc * R)), dim3(256), 0, c->stream, p->twp[i], Ns_acc, R,
                                    n / (Ns_acc * R), p->tw_lo, p->tw_hi, p->log_lo, p->logn);
@@ -277,7 +279,7 @@ static int plan_get(gs_ctx *c, const fe &omega, uint64_t n, NttPlan **out) {
                 for (int k = 0; k < i; k++)
                     if (p->L[k] == p->L[i]) p->wR[i] = p->wR[k];
                 if (!p->wR[i]) {
-                    if ((rc = gs_alloc(c, R * 16, &q))) { delete p; return rc; }
+                    if ((rc = gs_alloc(c, R * GS_ELT, &q))) { delete p; return rc; }
                     p->wR[i] = (fe *)q;
                     if ((rc = gs_power_series_dev(c, fe_pow_u64(omega, n / R), R, p->wR[i]))) { delete p; return rc; }
                 }
@@ -310,10 +312,10 @@ static void launch_pass(gs_ctx *c, const fe *in, fe *out, const PassArgs &a, uin
     const int Wj = 1 << a.logWj;
     const uint64_t tiles = (a.n / R) / Wj;
     const bool need_lds = (RB > 1) || (a.logNs == 0);
-    const size_t lds = need_lds ? (size_t)Wj * (R + 1) * 16 : 0;
+    const size_t lds = need_lds ? (size_t)Wj * (R + 1) * GS_ELT : 0;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass<LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass<LB>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_EW == 1 ? 96 * 1024 : 160 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL(k_ntt_pass<LB>, dim3((unsigned)tiles, rows), dim3(RB * Wj), lds, c->stream, in, out, a);
@@ -327,8 +329,8 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
     if (rows > 65535) return gs_fail(c, GS_ERR_ARG, "ntt: at most 65535 rows per call");
     const uint64_t total = (uint64_t)rows * n;
     {   // output must not overlap the input (the passes are out of place)
-        const uint8_t *i0 = (const uint8_t *)in, *i1 = i0 + ((uint64_t)(rows - 1) * in_stride + in_len) * 16;
-        const uint8_t *o0 = (const uint8_t *)out, *o1 = o0 + total * 16;
+        const uint8_t *i0 = (const uint8_t *)in, *i1 = i0 + ((uint64_t)(rows - 1) * in_stride + in_len) * GS_ELT;
+        const uint8_t *o0 = (const uint8_t *)out, *o1 = o0 + total * GS_ELT;
         if (i0 < o1 && o0 < i1) return gs_fail(c, GS_ERR_ARG, "ntt: output overlaps input");
     }
     fe w = inverse ? fe_inv(omega) : omega;
@@ -348,7 +350,7 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
     fe *tmp = nullptr;
     if (p->npass >= 2) {
         void *q;
-        if ((rc = gs_tmp_alloc(c, total * 16, &q))) return rc;
+        if ((rc = gs_tmp_alloc(c, total * GS_ELT, &q))) return rc;
         tmp = (fe *)q;
     }
     // ping-pong so that the last pass lands in `out`:  1: in->out   2: in->tmp->out   3: in->out->tmp->out   4: in->tmp->out->tmp->out
@@ -398,13 +400,13 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
 
 extern "C" {
 
-int gs_eval_polys_at_roots(gs_ctx *c, const void *polys, uint32_t rows, uint64_t poly_len, const uint8_t omega[16], uint64_t n,
+int gs_eval_polys_at_roots(gs_ctx *c, const void *polys, uint32_t rows, uint64_t poly_len, const gs_elt *omega, uint64_t n,
                            void *out) {
     if (!c || !polys || !omega || !out) return GS_ERR_ARG;
     return ntt_run(c, (const fe *)polys, rows, poly_len, poly_len, fe_from_bytes(omega), n, false, (fe *)out);
 }
 
-int gs_interpolate_roots(gs_ctx *c, const void *ys, uint32_t rows, const uint8_t omega[16], uint64_t n, void *out) {
+int gs_interpolate_roots(gs_ctx *c, const void *ys, uint32_t rows, const gs_elt *omega, uint64_t n, void *out) {
     if (!c || !ys || !omega || !out) return GS_ERR_ARG;
     return ntt_run(c, (const fe *)ys, rows, n, n, fe_from_bytes(omega), n, true, (fe *)out);
 }

@@ -116,10 +116,8 @@ __device__ __forceinline__ fe block_reduce_add(fe s, fe *sh) {
     // wave reduce via shuffles, then one LDS step across the (<= 4) waves of the block
     for (int off = 32; off >= 1; off >>= 1) {
         fe o;
-        o.w0 = __shfl_down(s.w0, off);
-        o.w1 = __shfl_down(s.w1, off);
-        o.w2 = __shfl_down(s.w2, off);
-        o.w3 = __shfl_down(s.w3, off);
+#pragma unroll
+        for (int l = 0; l < GF_LIMBS; l++) fe_set_limb(o, l, __shfl_down(fe_limb(s, l), off));
         s = fe_add(s, o);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -272,23 +270,23 @@ __global__ void k_quartic_eval(const fe *__restrict__ polys, uint64_t rows, fe x
 #define CHECK3(c, a, b, o) \
     if (!(c) || !(a) || !(b) || !(o)) return GS_ERR_ARG
 
-static int dot_to_host(gs_ctx *c, const fe *a, const fe *b, uint64_t n, uint8_t out_host[16]) {
+static int dot_to_host(gs_ctx *c, const fe *a, const fe *b, uint64_t n, gs_elt *out_host) {
     unsigned blocks = gs_grid(n, 256, 1024);
-    int rc = gs_stage_reserve(c, (uint64_t)(blocks + 1) * 16);
+    int rc = gs_stage_reserve(c, (uint64_t)(blocks + 1) * GS_ELT);
     if (rc) return rc;
     fe *partial = (fe *)c->d_stage;
     hipLaunchKernelGGL(k_dot_partial, dim3(blocks), dim3(256), 0, c->stream, a, b, n, partial + 1);
     hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, c->stream, partial + 1, blocks, partial);
     GS_LAUNCH_CHECK(c);
-    GS_HIP(c, hipMemcpyAsync(c->h_stage, partial, 16, hipMemcpyDeviceToHost, c->stream));
+    GS_HIP(c, hipMemcpyAsync(c->h_stage, partial, GS_ELT, hipMemcpyDeviceToHost, c->stream));
     GS_HIP(c, hipStreamSynchronize(c->stream));
-    memcpy(out_host, c->h_stage, 16);
+    memcpy(out_host, c->h_stage, GS_ELT);
     return GS_OK;
 }
 
 extern "C" {
 
-int gs_power_series(gs_ctx *c, const uint8_t base[16], uint64_t n, void *out) {
+int gs_power_series(gs_ctx *c, const gs_elt *base, uint64_t n, void *out) {
     if (!c || !base || (!out && n)) return GS_ERR_ARG;
     return gs_power_series_dev(c, fe_from_bytes(base), n, (fe *)out);
 }
@@ -302,7 +300,7 @@ int gs_power_series(gs_ctx *c, const uint8_t base[16], uint64_t n, void *out) {
         return GS_OK;                                                                                      \
     }
 #define VEC_SCALAR(NAME, OP)                                                                               \
-    int NAME(gs_ctx *c, const void *a, const uint8_t s[16], uint64_t n, void *out) {                       \
+    int NAME(gs_ctx *c, const void *a, const gs_elt *s, uint64_t n, void *out) {                       \
         CHECK3(c, a, s, out);                                                                              \
         if (!n) return GS_OK;                                                                              \
         hipLaunchKernelGGL(k_vec_scalar<OP>, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const fe *)a, fe_from_bytes(s), n, (fe *)out); \
@@ -324,7 +322,7 @@ int gs_vec_div(gs_ctx *c, const void *a, const void *b, uint64_t n, void *out) {
     CHECK3(c, a, b, out);
     return launch_batch_inv(c, (const fe *)b, (const fe *)a, n, (fe *)out);
 }
-int gs_vec_exp(gs_ctx *c, const void *a, const uint8_t e[16], uint64_t n, void *out) {
+int gs_vec_exp(gs_ctx *c, const void *a, const gs_elt *e, uint64_t n, void *out) {
     CHECK3(c, a, e, out);
     if (!n) return GS_OK;
     hipLaunchKernelGGL(k_vec_exp, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const fe *)a, fe_from_bytes(e), n, (fe *)out);
@@ -339,16 +337,16 @@ int gs_combine_many(gs_ctx *c, const void *const *vecs_host, const uint8_t *coef
     CombineArgs va;
     for (uint32_t j = 0; j < GS_MAX_COMBINE; j++) {
         va.v[j] = (const fe *)vecs_host[j < count ? j : 0];
-        va.k[j] = j < count ? fe_from_bytes(coeffs_host + 16 * j) : fe_zero();
+        va.k[j] = j < count ? fe_from_bytes(coeffs_host + GS_ELT * j) : fe_zero();
     }
     hipLaunchKernelGGL(k_combine_many, dim3(gs_grid(n)), dim3(256), 0, c->stream, va, count, n, (fe *)out);
     GS_LAUNCH_CHECK(c);
     return GS_OK;
 }
 
-int gs_combine(gs_ctx *c, const void *a, const void *b, uint64_t n, uint8_t out_host[16]) {
+int gs_combine(gs_ctx *c, const void *a, const void *b, uint64_t n, gs_elt *out_host) {
     CHECK3(c, a, b, out_host);
-    if (!n) { memset(out_host, 0, 16); return GS_OK; }
+    if (!n) { memset(out_host, 0, GS_ELT); return GS_OK; }
     return dot_to_host(c, (const fe *)a, (const fe *)b, n, out_host);
 }
 
@@ -394,12 +392,12 @@ int gs_sub_matrix_from_vectors(gs_ctx *c, const void *const *vecs_host, const vo
     return GS_OK;
 }
 
-int gs_eval_poly_at(gs_ctx *c, const void *poly, uint64_t len, const uint8_t x[16], uint8_t out_host[16]) {
+int gs_eval_poly_at(gs_ctx *c, const void *poly, uint64_t len, const gs_elt *x, gs_elt *out_host) {
     if (!c || !x || !out_host || (!poly && len)) return GS_ERR_ARG;
-    if (!len) { memset(out_host, 0, 16); return GS_OK; }
+    if (!len) { memset(out_host, 0, GS_ELT); return GS_OK; }
     // sum_i poly[i] * x^i as a dot product with the power series of x
     void *pw;
-    int rc = gs_tmp_alloc(c, len * 16, &pw);
+    int rc = gs_tmp_alloc(c, len * GS_ELT, &pw);
     if (rc) return rc;
     rc = gs_power_series_dev(c, fe_from_bytes(x), len, (fe *)pw);
     if (!rc) rc = dot_to_host(c, (const fe *)poly, (const fe *)pw, len, out_host);
@@ -416,7 +414,7 @@ int gs_interpolate_quartic_batch(gs_ctx *c, const void *xs, const void *ys, uint
     return GS_OK;
 }
 
-int gs_interpolate_quartic_domain(gs_ctx *c, const uint8_t omega[16], uint64_t n, uint64_t step, const void *ys, uint64_t rows,
+int gs_interpolate_quartic_domain(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *ys, uint64_t rows,
                                   void *out) {
     CHECK3(c, omega, ys, out);
     if (!gs_is_pow2(n) || n < 4 || rows * 4 * step != n) return gs_fail(c, GS_ERR_ARG, "interpolate_quartic_domain: rows*4*step != n");
@@ -434,7 +432,7 @@ int gs_interpolate_quartic_domain(gs_ctx *c, const uint8_t omega[16], uint64_t n
     return GS_OK;
 }
 
-int gs_eval_quartic_batch(gs_ctx *c, const void *polys, uint64_t rows, const uint8_t x[16], void *out) {
+int gs_eval_quartic_batch(gs_ctx *c, const void *polys, uint64_t rows, const gs_elt *x, void *out) {
     CHECK3(c, polys, x, out);
     if (!rows) return GS_OK;
     hipLaunchKernelGGL(k_quartic_eval, dim3(gs_grid(rows)), dim3(256), 0, c->stream, (const fe *)polys, rows, fe_from_bytes(x), (fe *)out);

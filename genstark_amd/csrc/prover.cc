@@ -55,7 +55,7 @@ struct Fail {
     throw Fail{code, buf};
 }
 
-typedef hu128 F;
+typedef hfe F;
 const uint64_t DIGEST = 32, ELEM = 16, MAX_ARRAY = 256;
 typedef std::vector<uint8_t> Bytes;
 
@@ -267,7 +267,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     const uint64_t Nc = T * cf;
     if (E < 2 * cf) fail(GS_ERR_ARG, "extension factor must be at least 2x the composition factor");
     const F omega = from16(job.root_of_unity);
-    const F comp_rou = hf_pow(omega, (hu128)(N / Nc)), exec_rou = hf_pow(omega, (hu128)E);
+    const F comp_rou = hf_pow(omega, (hfe)(N / Nc)), exec_rou = hf_pow(omega, (hfe)E);
     uint8_t s16[16], s16b[16];
 
     // 1 ----- evaluation context (lib/Stark.ts:92-94): the domains
@@ -285,7 +285,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         x.check(A.gs_pluck(x.c, evalDomain.p, N, T, N, xToTheSteps.p), "gs_pluck");                    // ZeroPolynomial.ts:40
         le16(1, s16);
         x.check(A.gs_vec_sub_scalar(x.c, xToTheSteps.p, s16, N, num.p), "gs_vec_sub_scalar");
-        le16(hf_pow(omega, (hu128)((T - 1) * E)), s16);                                                // :21-23
+        le16(hf_pow(omega, (hfe)((T - 1) * E)), s16);                                                // :21-23
         x.check(A.gs_vec_sub_scalar(x.c, evalDomain.p, s16, N, den.p), "gs_vec_sub_scalar");
         x.check(A.gs_vec_div(x.c, den.p, num.p, N, zInverses.p), "gs_vec_div(1/Z)");                   // CompositionPolynomial.ts:117
     }
@@ -293,7 +293,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     const uint64_t b_inc = composition_degree - T;
     if (b_inc > 0) {
         psbPowers = Buf(x, N * ELEM);
-        le16(hf_pow(omega, (hu128)b_inc), s16);
+        le16(hf_pow(omega, (hfe)b_inc), s16);
         x.check(A.gs_power_series(x.c, s16, N, psbPowers.p), "gs_power_series(psb)");
     }
 
@@ -353,7 +353,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         RegData *d = nullptr;
         for (auto &e : rdata) if (e.reg == a.reg) d = &e;
         if (!d) { rdata.push_back(RegData{a.reg, {}, {}}); d = &rdata.back(); }
-        d->xs.push_back(hf_pow(omega, (hu128)(a.step * E)));
+        d->xs.push_back(hf_pow(omega, (hfe)(a.step * E)));
         d->ys.push_back(from16(a.value));
     }
     const uint32_t bcount = (uint32_t)rdata.size();
@@ -395,7 +395,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         for (auto &g : groups) {
             if (g.first == combination_degree) continue;
             Buf powers(x, Nc * ELEM);
-            le16(hf_pow(comp_rou, (hu128)(combination_degree - g.first)), s16);
+            le16(hf_pow(comp_rou, (hfe)(combination_degree - g.first)), s16);
             x.check(A.gs_power_series(x.c, s16, Nc, powers.p), "gs_power_series(q powers)");
             for (uint32_t i : g.second) {
                 adjusted.emplace_back(x, Nc * ELEM);

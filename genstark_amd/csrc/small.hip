@@ -14,39 +14,39 @@ extern "C" {
 
 int gs_small_interpolate(const uint8_t *xs_host, const uint8_t *ys_host, uint32_t n, uint8_t *coeffs_out) {
     if (!xs_host || !ys_host || !coeffs_out || n == 0 || n > 4096) return GS_ERR_ARG;
-    std::vector<hu128> x(n), y(n), master(n + 1, 0), q(n), out(n, 0);
-    for (uint32_t i = 0; i < n; i++) { x[i] = hf_load(xs_host + 16 * i); y[i] = hf_load(ys_host + 16 * i); }
+    std::vector<hfe> x(n), y(n), master(n + 1, 0), q(n), out(n, 0);
+    for (uint32_t i = 0; i < n; i++) { x[i] = hf_load(xs_host + GS_ELT * i); y[i] = hf_load(ys_host + GS_ELT * i); }
     // master polynomial M(X) = prod (X - x_i)
     master[0] = 1;
     for (uint32_t i = 0; i < n; i++) {
-        hu128 nx = hf_sub(0, x[i]);
+        hfe nx = hf_sub(0, x[i]);
         for (uint32_t d = i + 1; d >= 1; d--) master[d] = hf_add(master[d - 1], hf_mul(master[d], nx));
         master[0] = hf_mul(master[0], nx);
     }
     for (uint32_t j = 0; j < n; j++) {
         // q = M / (X - x_j) by synthetic division; the Lagrange denominator is q(x_j)
-        hu128 carry = 0;
+        hfe carry = 0;
         for (uint32_t d = n; d >= 1; d--) {
             carry = hf_add(master[d], hf_mul(carry, x[j]));
             q[d - 1] = carry;
         }
-        hu128 den = 0;
+        hfe den = 0;
         for (uint32_t d = n; d-- > 0;) den = hf_add(hf_mul(den, x[j]), q[d]);
-        hu128 s = hf_mul(y[j], hf_inv(den));
+        hfe s = hf_mul(y[j], hf_inv(den));
         for (uint32_t d = 0; d < n; d++) out[d] = hf_add(out[d], hf_mul(q[d], s));
     }
-    for (uint32_t d = 0; d < n; d++) hf_store(coeffs_out + 16 * d, out[d]);
+    for (uint32_t d = 0; d < n; d++) hf_store(coeffs_out + GS_ELT * d, out[d]);
     return GS_OK;
 }
 
 int gs_small_eval_poly(const uint8_t *poly_host, uint32_t len, const uint8_t *xs_host, uint32_t m, uint8_t *out_host) {
     if ((!poly_host && len) || (!xs_host && m) || (!out_host && m)) return GS_ERR_ARG;
-    std::vector<hu128> p(len);
-    for (uint32_t i = 0; i < len; i++) p[i] = hf_load(poly_host + 16 * i);
+    std::vector<hfe> p(len);
+    for (uint32_t i = 0; i < len; i++) p[i] = hf_load(poly_host + GS_ELT * i);
     for (uint32_t i = 0; i < m; i++) {
-        hu128 x = hf_load(xs_host + 16 * i), s = 0;
+        hfe x = hf_load(xs_host + GS_ELT * i), s = 0;
         for (uint32_t k = len; k-- > 0;) s = hf_add(hf_mul(s, x), p[k]);
-        hf_store(out_host + 16 * i, s);
+        hf_store(out_host + GS_ELT * i, s);
     }
     return GS_OK;
 }

@@ -54,7 +54,8 @@ class _DeviceBuffer:
 class Vector:
     """galois Vector: `length` elements of `elementSize` bytes, little-endian."""
 
-    def __init__(self, backend, length, owner=None, offset=0, element_size=ELEMENT_SIZE):
+    def __init__(self, backend, length, owner=None, offset=0, element_size=None):
+        element_size = element_size or backend.element_size          # 16; 32 in the 256- / 224-bit library flavours
         self.backend, self.length, self.elementSize = backend, int(length), element_size
         self._owner = owner or _DeviceBuffer(backend, self.length * element_size)
         self._offset = offset
@@ -95,8 +96,8 @@ class Matrix:
     """galois Matrix: rowCount x colCount elements, row-major contiguous (LowDegreeProver.ts:45)."""
 
     def __init__(self, backend, rows, cols, owner=None, offset=0):
-        self.backend, self.rowCount, self.colCount, self.elementSize = backend, int(rows), int(cols), ELEMENT_SIZE
-        self._owner = owner or _DeviceBuffer(backend, self.rowCount * self.colCount * ELEMENT_SIZE)
+        self.backend, self.rowCount, self.colCount, self.elementSize = backend, int(rows), int(cols), backend.element_size
+        self._owner = owner or _DeviceBuffer(backend, self.rowCount * self.colCount * self.elementSize)
         self._offset = offset
         self.quartic_domain = None  # (omega, n, step) when built by transposeVector(power series, 4, step)
 
@@ -105,24 +106,24 @@ class Matrix:
         return self._owner.ptr + self._offset
 
     def getValue(self, row, col):
-        off = (row * self.colCount + col) * ELEMENT_SIZE
-        return int.from_bytes(self.backend.download(self.ptr, ELEMENT_SIZE, off), 'little')
+        off = (row * self.colCount + col) * self.elementSize
+        return int.from_bytes(self.backend.download(self.ptr, self.elementSize, off), 'little')
 
     def toValues(self):
         raw = self.toBuffer()
-        c = self.colCount
-        return [[int.from_bytes(raw[(r * c + k) * 16:(r * c + k + 1) * 16], 'little') for k in range(c)]
+        c, es = self.colCount, self.elementSize
+        return [[int.from_bytes(raw[(r * c + k) * es:(r * c + k + 1) * es], 'little') for k in range(c)]
                 for r in range(self.rowCount)]
 
     def toBuffer(self):
-        return self.backend.download(self.ptr, self.rowCount * self.colCount * ELEMENT_SIZE)
+        return self.backend.download(self.ptr, self.rowCount * self.colCount * self.elementSize)
 
     def rowsToBuffers(self, indexes):
-        """LowDegreeProver.ts:53,214,217 — one Buffer (colCount*16 bytes) per requested row."""
-        return self.backend.gather(self.ptr, self.colCount * ELEMENT_SIZE, list(indexes))
+        """LowDegreeProver.ts:53,214,217 — one Buffer (colCount*elementSize bytes) per requested row."""
+        return self.backend.gather(self.ptr, self.colCount * self.elementSize, list(indexes))
 
     def row(self, r):
-        return Vector(self.backend, self.colCount, owner=self._owner, offset=self._offset + r * self.colCount * ELEMENT_SIZE)
+        return Vector(self.backend, self.colCount, owner=self._owner, offset=self._offset + r * self.colCount * self.elementSize)
 
 
 class PrimeField:
@@ -138,8 +139,11 @@ class PrimeField:
                               'construct Backend(modulus=...) for one of the built fields')
         self._lastEvaluation = None     # (polys, ptr, omega, n, result) of the latest evalPolysAtRoots, weakly held
         self.modulus = modulus
-        self.elementSize = ELEMENT_SIZE  # every build flavour stores an element in 16 bytes
+        self.elementSize = self.backend.element_size   # 16 bytes; 32 in the 256- / 224-bit library flavours
         self.zero, self.one = 0, 1
+
+    def le(self, v):
+        return int(v).to_bytes(self.elementSize, 'little')
 
     # ---- scalar arithmetic (bigint in, bigint out)
     def mod(self, v): return v % self.modulus
@@ -183,7 +187,7 @@ class PrimeField:
     def newVectorFrom(self, values):
         v = Vector(self.backend, len(values))
         if values:
-            self.backend.upload(v.ptr, b''.join(_le(x % self.modulus) for x in values))
+            self.backend.upload(v.ptr, b''.join(self.le(x % self.modulus) for x in values))
         return v
 
     def newMatrix(self, rows, cols):
@@ -193,7 +197,7 @@ class PrimeField:
         rows, cols = len(values), len(values[0]) if values else 0
         m = Matrix(self.backend, rows, cols)
         if rows * cols:
-            self.backend.upload(m.ptr, b''.join(_le(x % self.modulus) for r in values for x in r))
+            self.backend.upload(m.ptr, b''.join(self.le(x % self.modulus) for r in values for x in r))
         return m
 
     def newMatrixFromVectors(self, vectors):
@@ -202,9 +206,9 @@ class PrimeField:
         cols = max(v.length for v in vectors)
         m = Matrix(self.backend, len(vectors), cols)
         for r, v in enumerate(vectors):
-            self.backend.call('gs_copy', C.c_void_p(m.ptr + r * cols * 16), C.c_void_p(v.ptr), v.length * 16)
+            self.backend.call('gs_copy', C.c_void_p(m.ptr + r * cols * self.elementSize), C.c_void_p(v.ptr), v.length * self.elementSize)
             if v.length < cols:
-                self.backend.upload(m.ptr + (r * cols + v.length) * 16, bytes((cols - v.length) * 16))
+                self.backend.upload(m.ptr + (r * cols + v.length) * self.elementSize, bytes((cols - v.length) * self.elementSize))
         return m
 
     def matrixRowsToVectors(self, matrix):
@@ -214,7 +218,7 @@ class PrimeField:
     def _binary(self, fn_vec, fn_scalar, a, b):
         out = Vector(self.backend, a.length)
         if isinstance(b, int):
-            self.backend.call(fn_scalar, C.c_void_p(a.ptr), _le(b % self.modulus), a.length, C.c_void_p(out.ptr))
+            self.backend.call(fn_scalar, C.c_void_p(a.ptr), self.le(b % self.modulus), a.length, C.c_void_p(out.ptr))
         else:
             if a.length != b.length:
                 raise GstarkError('Cannot combine vector elements: vectors have different lengths')
@@ -243,13 +247,13 @@ class PrimeField:
         out = Vector(self.backend, a.length)
         if e < 0:
             a, e = self.invVectorElements(a), -e
-        self.backend.call('gs_vec_exp', C.c_void_p(a.ptr), _le(e), a.length, C.c_void_p(out.ptr))
+        self.backend.call('gs_vec_exp', C.c_void_p(a.ptr), self.le(e), a.length, C.c_void_p(out.ptr))
         return out
 
     def combineVectors(self, a, b):
         if a.length != b.length:
             raise GstarkError('Cannot combine vectors: vectors have different lengths')
-        buf = C.create_string_buffer(16)
+        buf = C.create_string_buffer(self.elementSize)
         self.backend.call('gs_combine', C.c_void_p(a.ptr), C.c_void_p(b.ptr), a.length, C.cast(buf, C.c_void_p))
         return int.from_bytes(buf.raw, 'little')
 
@@ -260,12 +264,12 @@ class PrimeField:
         n = vectors[0].length
         out = Vector(self.backend, n)
         self.backend.call('gs_combine_many', Backend.ptr_array([v.ptr for v in vectors]),
-                          b''.join(_le(k) for k in ks), len(vectors), n, C.c_void_p(out.ptr))
+                          b''.join(self.le(k) for k in ks), len(vectors), n, C.c_void_p(out.ptr))
         return out
 
     def getPowerSeries(self, base, length):
         out = Vector(self.backend, length)
-        self.backend.call('gs_power_series', _le(base), length, C.c_void_p(out.ptr))
+        self.backend.call('gs_power_series', self.le(base), length, C.c_void_p(out.ptr))
         out.series_base = base % self.modulus
         return out
 
@@ -322,7 +326,7 @@ class PrimeField:
         if poly.length > roots.length:
             raise GstarkError('Number of roots of unity cannot be smaller than number of values')
         out = Vector(self.backend, roots.length)
-        self.backend.call('gs_eval_polys_at_roots', C.c_void_p(poly.ptr), 1, poly.length, _le(self._omega_of(roots)),
+        self.backend.call('gs_eval_polys_at_roots', C.c_void_p(poly.ptr), 1, poly.length, self.le(self._omega_of(roots)),
                           roots.length, C.c_void_p(out.ptr))
         return out
 
@@ -340,10 +344,10 @@ class PrimeField:
             if ppolys is polys and pptr == polys.ptr and pout is not None and pn > n and pn % n == 0 and \
                     pow(pomega, pn // n, self.modulus) == omega:
                 for r in range(polys.rowCount):
-                    self.backend.call('gs_pluck', C.c_void_p(pout.ptr + r * pn * ELEMENT_SIZE), pn, pn // n, n,
-                                      C.c_void_p(out.ptr + r * n * ELEMENT_SIZE))
+                    self.backend.call('gs_pluck', C.c_void_p(pout.ptr + r * pn * self.elementSize), pn, pn // n, n,
+                                      C.c_void_p(out.ptr + r * n * self.elementSize))
                 return out
-        self.backend.call('gs_eval_polys_at_roots', C.c_void_p(polys.ptr), polys.rowCount, polys.colCount, _le(omega), n,
+        self.backend.call('gs_eval_polys_at_roots', C.c_void_p(polys.ptr), polys.rowCount, polys.colCount, self.le(omega), n,
                           C.c_void_p(out.ptr))
         self._lastEvaluation = (weakref.ref(polys), polys.ptr, omega, n, weakref.ref(out))
         return out
@@ -360,12 +364,12 @@ class PrimeField:
             if ys.length != n:
                 raise GstarkError('Number of roots of unity must be the same as the number of y coordinates')
             out, rows = Vector(self.backend, n), 1
-        self.backend.call('gs_interpolate_roots', C.c_void_p(ys.ptr), rows, _le(self._omega_of(roots)), n, C.c_void_p(out.ptr))
+        self.backend.call('gs_interpolate_roots', C.c_void_p(ys.ptr), rows, self.le(self._omega_of(roots)), n, C.c_void_p(out.ptr))
         return out
 
     def evalPolyAt(self, poly, x):
-        buf = C.create_string_buffer(16)
-        self.backend.call('gs_eval_poly_at', C.c_void_p(poly.ptr), poly.length, _le(x), C.cast(buf, C.c_void_p))
+        buf = C.create_string_buffer(self.elementSize)
+        self.backend.call('gs_eval_poly_at', C.c_void_p(poly.ptr), poly.length, self.le(x), C.cast(buf, C.c_void_p))
         return int.from_bytes(buf.raw, 'little')
 
     def mulPolys(self, a, b):
@@ -390,8 +394,8 @@ class PrimeField:
         if v.length == length:
             return v
         out = Vector(self.backend, length)
-        self.backend.call('gs_copy', C.c_void_p(out.ptr), C.c_void_p(v.ptr), v.length * ELEMENT_SIZE)
-        self.backend.upload(out.ptr + v.length * ELEMENT_SIZE, bytes((length - v.length) * ELEMENT_SIZE))
+        self.backend.call('gs_copy', C.c_void_p(out.ptr), C.c_void_p(v.ptr), v.length * self.elementSize)
+        self.backend.upload(out.ptr + v.length * self.elementSize, bytes((length - v.length) * self.elementSize))
         return out
 
     def addPolys(self, a, b):
@@ -417,24 +421,26 @@ class PrimeField:
 
     def interpolateValues(self, xv, yv):
         n = len(xv)
-        out = C.create_string_buffer(16 * n)
-        rc = self.backend.lib.gs_small_interpolate(b''.join(_le(x % self.modulus) for x in xv),
-                                                   b''.join(_le(y % self.modulus) for y in yv), n, C.cast(out, C.c_void_p))
+        es = self.elementSize
+        out = C.create_string_buffer(es * n)
+        rc = self.backend.lib.gs_small_interpolate(b''.join(self.le(x % self.modulus) for x in xv),
+                                                   b''.join(self.le(y % self.modulus) for y in yv), n, C.cast(out, C.c_void_p))
         if rc:
             raise GstarkError(f'gs_small_interpolate failed ({rc})')
         raw = out.raw
-        return [int.from_bytes(raw[16 * i:16 * i + 16], 'little') for i in range(n)]
+        return [int.from_bytes(raw[es * i:es * i + es], 'little') for i in range(n)]
 
     def evalPolyAtMany(self, poly_values, xs):
         """evalPolyAt over a list of points (LowDegreeProver.ts:246-251), host arithmetic inside the library."""
         m = len(xs)
-        out = C.create_string_buffer(16 * max(m, 1))
-        rc = self.backend.lib.gs_small_eval_poly(b''.join(_le(c) for c in poly_values), len(poly_values),
-                                                 b''.join(_le(x) for x in xs), m, C.cast(out, C.c_void_p))
+        es = self.elementSize
+        out = C.create_string_buffer(es * max(m, 1))
+        rc = self.backend.lib.gs_small_eval_poly(b''.join(self.le(c) for c in poly_values), len(poly_values),
+                                                 b''.join(self.le(x) for x in xs), m, C.cast(out, C.c_void_p))
         if rc:
             raise GstarkError(f'gs_small_eval_poly failed ({rc})')
         raw = out.raw
-        return [int.from_bytes(raw[16 * i:16 * i + 16], 'little') for i in range(m)]
+        return [int.from_bytes(raw[es * i:es * i + es], 'little') for i in range(m)]
 
     def interpolateQuarticBatch(self, xs, ys):
         """LowDegreeProver.ts:137,191 — one cubic per row.  When xs is the transposed power-series domain
@@ -444,7 +450,7 @@ class PrimeField:
         out = Matrix(self.backend, ys.rowCount, 4)
         if xs.quartic_domain is not None:
             omega, n, step = xs.quartic_domain
-            self.backend.call('gs_interpolate_quartic_domain', _le(omega), n, step, C.c_void_p(ys.ptr), ys.rowCount,
+            self.backend.call('gs_interpolate_quartic_domain', self.le(omega), n, step, C.c_void_p(ys.ptr), ys.rowCount,
                               C.c_void_p(out.ptr))
         else:
             self.backend.call('gs_interpolate_quartic_batch', C.c_void_p(xs.ptr), C.c_void_p(ys.ptr), ys.rowCount,
@@ -453,7 +459,7 @@ class PrimeField:
 
     def evalQuarticBatch(self, polys, x):
         out = Vector(self.backend, polys.rowCount)
-        self.backend.call('gs_eval_quartic_batch', C.c_void_p(polys.ptr), polys.rowCount, _le(x), C.c_void_p(out.ptr))
+        self.backend.call('gs_eval_quartic_batch', C.c_void_p(polys.ptr), polys.rowCount, self.le(x), C.c_void_p(out.ptr))
         return out
 
 

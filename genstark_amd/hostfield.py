@@ -44,13 +44,14 @@ class HostMatrix:
 
 
 class HostField:
-    def __init__(self, modulus=MODULUS):
-        self.modulus, self.elementSize = modulus, ELEMENT_SIZE
+    def __init__(self, modulus=MODULUS, elementSize=None):
+        # the prover's libraries store an element in 16 bytes, or in 32 for the 256- / 224-bit fields
+        self.modulus, self.elementSize = modulus, elementSize or (ELEMENT_SIZE if modulus < (1 << 128) else 32)
         self.zero, self.one, self.isOptimized = 0, 1, False
         self.backend = None
 
     def createHash(self, algorithm):
-        return HostHash(algorithm)
+        return HostHash(algorithm, self.elementSize)
 
     # ---- scalars
     def add(self, a, b): return (a + b) % self.modulus
@@ -85,7 +86,7 @@ class HostField:
 
     # ---- the small vector / polynomial members of the verification path
     def newVectorFrom(self, values):
-        return HostVector([v % self.modulus for v in values])
+        return HostVector([v % self.modulus for v in values], self.elementSize)
 
     def newMatrixFrom(self, values):
         return HostMatrix([[v % self.modulus for v in row] for row in values])
@@ -95,7 +96,7 @@ class HostField:
         for _ in range(length):
             out.append(x)
             x = x * base % self.modulus
-        v = HostVector(out)
+        v = HostVector(out, self.elementSize)
         v.series_base = base % self.modulus
         return v
 
@@ -185,7 +186,8 @@ class HostField:
 
 
 class HostHash:
-    def __init__(self, algorithm):
+    def __init__(self, algorithm, element_size=ELEMENT_SIZE):
+        self.elementSize = element_size
         if algorithm not in ('sha256', 'blake2s256'):
             raise TypeError(f'Hash algorithm {algorithm} is not supported')
         self.algorithm, self.digestSize, self.isOptimized = algorithm, DIGEST_SIZE, False
@@ -205,7 +207,7 @@ class HostHash:
         if isinstance(values, (bytes, bytearray)):
             raw = bytes(values)
         else:
-            raw = b''.join(int(v).to_bytes(ELEMENT_SIZE, 'little') for row in values.toValues() for v in row)
+            raw = b''.join(int(v).to_bytes(self.elementSize, 'little') for row in values.toValues() for v in row)
         if len(raw) % valueSize:
             raise GstarkError('Values buffer cannot contain partial number of elements')
         out = HostVector([self._host(raw[i:i + valueSize]).digest() for i in range(0, len(raw), valueSize)], DIGEST_SIZE)

@@ -62,7 +62,7 @@ class Hash:
             src = tmp
         else:
             src = values
-            nbytes = (values.rowCount * values.colCount * 16) if hasattr(values, 'rowCount') else values.byteLength
+            nbytes = (values.rowCount * values.colCount * values.elementSize) if hasattr(values, 'rowCount') else values.byteLength
             if nbytes % valueSize:
                 raise GstarkError('Values buffer cannot contain partial number of elements')
             count = nbytes // valueSize

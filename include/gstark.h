@@ -10,15 +10,16 @@
  * (genstark_amd/) bind exactly these symbols; nothing else is exported.
  *
  * Conventions
- *  - A field element is 16 bytes, little-endian, canonical (value < p),
- *    p = 2^128 - 9*2^32 + 1 (the 128-bit field galois accelerates; examples/mimc/mimc128.ts:13).
+ *  - A field element is gs_element_size() bytes (16; 32 in the 256- / 224-bit flavours below), little-endian,
+ *    canonical (value < p); p = 2^128 - 9*2^32 + 1 in the main library (the 128-bit field galois accelerates;
+ *    examples/mimc/mimc128.ts:13).  `gs_elt *` arguments point at ONE such element in host memory.
  *    This is the byte layout `Vector.copyValue` / `Matrix.rowsToBuffers` hand to the proof
  *    (lib/Stark.ts:284-296, lib/utils/serialization.ts:131-146).
  *  - A Vector is n contiguous elements.  A Matrix is rows*cols elements, row-major, contiguous
  *    (`Matrix.toBuffer()` must be row-contiguous: lib/components/LowDegreeProver.ts:45).
  *  - A digest is 32 bytes.  A digest Vector is n contiguous digests.
  *  - `void *` buffer arguments are DEVICE pointers obtained from gs_alloc (or any hipMalloc'd /
- *    torch-owned device memory); `const uint8_t x[16]`-style arguments and everything documented
+ *    torch-owned device memory); `const gs_elt *x`-style arguments and everything documented
  *    "host" are HOST pointers.
  *  - All calls are asynchronous on the context's HIP stream and ordered on it; gs_download,
  *    gs_gather and gs_sync block until the stream is drained.  Like the reference (synchronous,
@@ -26,8 +27,9 @@
  *    one that called gs_ctx_create must make the context's device its current HIP device first
  *    (hipSetDevice is per-thread state; several contexts, one per thread, may share a GPU).
  *  - The library is built once per field: libgstark_hip.so computes in GF(2^128 - 9*2^32 + 1), the flavours
- *    libgstark_hip_q64.so / _q32.so in GF(2^64 - 21*2^30 + 1) / GF(2^32 - 3*2^25 + 1) (gs_field_modulus says which);
- *    elements are 16 bytes little-endian in every flavour.
+ *    libgstark_hip_q64.so / _q32.so in GF(2^64 - 21*2^30 + 1) / GF(2^32 - 3*2^25 + 1) with 16-byte elements, the flavours
+ *    libgstark_hip_p256.so / _p224.so in GF(2^256 - 351*2^32 + 1) / GF(2^224 - 2^96 + 1) with 32-byte elements
+ *    (gs_field_modulus / gs_element_size say which).
  *  - Every function returns GS_OK (0) or a negative gs_status; gs_last_error(ctx) describes it.
  *    There is NO CPU fallback: without a gfx950 device gs_ctx_create fails.
  */
@@ -57,8 +59,9 @@ typedef enum gs_hash_alg {    /* createHash(algorithm, useWasm): lib/Stark.ts:19
 } gs_hash_alg;
 
 typedef struct gs_ctx gs_ctx;
+typedef uint8_t gs_elt;       /* first byte of one field element in HOST memory: gs_element_size() bytes, little-endian */
 
-#define GS_ELEMENT_BYTES 16
+#define GS_ELEMENT_BYTES 16   /* of the main (128-bit) library; gs_element_size() is authoritative */
 #define GS_DIGEST_BYTES 32
 #define GS_MAX_COMBINE 64     /* max vectors in gs_combine_many / gs_hash_merge_rows */
 
@@ -72,7 +75,8 @@ void gs_ctx_destroy(gs_ctx *ctx);
 const char *gs_last_error(const gs_ctx *ctx);
 int gs_sync(gs_ctx *ctx);
 void *gs_stream(gs_ctx *ctx);                          /* the hipStream_t the kernels run on */
-int gs_field_modulus(uint8_t out_le[16]);              /* FiniteField.modulus */
+int gs_element_size(void);                             /* FiniteField.elementSize: lib/Stark.ts:260,285,299 */
+int gs_field_modulus(gs_elt *out_le);                  /* FiniteField.modulus */
 
 int gs_alloc(gs_ctx *ctx, uint64_t bytes, void **dptr);
 int gs_free(gs_ctx *ctx, void *dptr);                 /* parks the block in the context's cache (no device sync) */
@@ -88,7 +92,7 @@ int gs_gather(gs_ctx *ctx, const void *src, uint64_t rec_bytes, const uint64_t *
 /* ---- vector arithmetic (FiniteField vector ops) ------------------------------------------------ */
 /* getPowerSeries(base, n): out[i] = base^i.  CompositionPolynomial.ts:94,132; LinearCombination.ts:46;
  * also how air-assembly builds execution/evaluation/composition domains (lib/Stark.ts:90-91). */
-int gs_power_series(gs_ctx *ctx, const uint8_t base[16], uint64_t n, void *out);
+int gs_power_series(gs_ctx *ctx, const gs_elt *base, uint64_t n, void *out);
 /* addVectorElements(a, b): CompositionPolynomial.ts:145; LinearCombination.ts:63 */
 int gs_vec_add(gs_ctx *ctx, const void *a, const void *b, uint64_t n, void *out);
 /* subVectorElements(a, b: Vector): ZeroPolynomial.ts:41-42 (Vector form) */
@@ -96,22 +100,22 @@ int gs_vec_sub(gs_ctx *ctx, const void *a, const void *b, uint64_t n, void *out)
 /* mulVectorElements(a, b: Vector): CompositionPolynomial.ts:98,120,136; LinearCombination.ts:50 */
 int gs_vec_mul(gs_ctx *ctx, const void *a, const void *b, uint64_t n, void *out);
 /* scalar forms — (a, b: bigint): ZeroPolynomial.ts:41-42; LinearCombination.ts:75 */
-int gs_vec_add_scalar(gs_ctx *ctx, const void *a, const uint8_t s[16], uint64_t n, void *out);
-int gs_vec_sub_scalar(gs_ctx *ctx, const void *a, const uint8_t s[16], uint64_t n, void *out);
-int gs_vec_mul_scalar(gs_ctx *ctx, const void *a, const uint8_t s[16], uint64_t n, void *out);
+int gs_vec_add_scalar(gs_ctx *ctx, const void *a, const gs_elt *s, uint64_t n, void *out);
+int gs_vec_sub_scalar(gs_ctx *ctx, const void *a, const gs_elt *s, uint64_t n, void *out);
+int gs_vec_mul_scalar(gs_ctx *ctx, const void *a, const gs_elt *s, uint64_t n, void *out);
 /* invVectorElements: out[i] = a[i]^-1, with 0^-1 := 0 (batch inversion) */
 int gs_vec_inv(gs_ctx *ctx, const void *a, uint64_t n, void *out);
 /* divVectorElements(a, b): out[i] = a[i] * b[i]^-1.  CompositionPolynomial.ts:117;
  * divMatrixElements (BoundaryConstraints.ts:92) is the same call over rows*cols elements. */
 int gs_vec_div(gs_ctx *ctx, const void *a, const void *b, uint64_t n, void *out);
 /* expVectorElements(a, e): out[i] = a[i]^e (examples/poseidon/utils.ts:34) */
-int gs_vec_exp(gs_ctx *ctx, const void *a, const uint8_t e[16], uint64_t n, void *out);
+int gs_vec_exp(gs_ctx *ctx, const void *a, const gs_elt *e, uint64_t n, void *out);
 /* combineManyVectors(v[], k): out[i] = sum_j v_j[i] * k_j.  vecs_host: host array of `count`
  * device pointers; coeffs_host: count*16 bytes.  CompositionPolynomial.ts:105,142; LinearCombination.ts:60 */
 int gs_combine_many(gs_ctx *ctx, const void *const *vecs_host, const uint8_t *coeffs_host,
                     uint32_t count, uint64_t n, void *out);
 /* combineVectors(a, b) -> scalar sum_i a[i]*b[i] (host out).  CompositionPolynomial.ts:168,188 */
-int gs_combine(gs_ctx *ctx, const void *a, const void *b, uint64_t n, uint8_t out_host[16]);
+int gs_combine(gs_ctx *ctx, const void *a, const void *b, uint64_t n, gs_elt *out_host);
 /* pluckVector(v, skip, times): out[i] = v[(i*skip) mod vlen], i < times.  ZeroPolynomial.ts:40 */
 int gs_pluck(gs_ctx *ctx, const void *v, uint64_t vlen, uint64_t skip, uint64_t times, void *out);
 /* transposeVector(v, cols, step): rows = n/(cols*step); out[r*cols+c] = v[(r + c*rows)*step].
@@ -129,23 +133,23 @@ int gs_sub_matrix_from_vectors(gs_ctx *ctx, const void *const *vecs_host, const 
  * {omega^i}; out is rows*n, natural order (out[r][i] = p_r(omega^i)).
  * lib/Stark.ts:109; CompositionPolynomial.ts:110; BoundaryConstraints.ts:87-88 */
 int gs_eval_polys_at_roots(gs_ctx *ctx, const void *polys, uint32_t rows, uint64_t poly_len,
-                           const uint8_t omega[16], uint64_t n, void *out);
+                           const gs_elt *omega, uint64_t n, void *out);
 /* interpolateRoots(roots, ys: Vector|Matrix): inverse NTT of each row; out[r] = coefficients of the
  * unique deg<n polynomial with p(omega^i) = ys[r][i].  lib/Stark.ts:106; CompositionPolynomial.ts:109 */
-int gs_interpolate_roots(gs_ctx *ctx, const void *ys, uint32_t rows, const uint8_t omega[16],
+int gs_interpolate_roots(gs_ctx *ctx, const void *ys, uint32_t rows, const gs_elt *omega,
                          uint64_t n, void *out);
 /* evalPolyAt(poly, x) -> scalar.  BoundaryConstraints.ts:59-60; LowDegreeProver.ts:248 */
-int gs_eval_poly_at(gs_ctx *ctx, const void *poly, uint64_t len, const uint8_t x[16], uint8_t out_host[16]);
+int gs_eval_poly_at(gs_ctx *ctx, const void *poly, uint64_t len, const gs_elt *x, gs_elt *out_host);
 /* interpolateQuarticBatch(xs, ys): per row, the cubic through (xs[r][c], ys[r][c]), c<4; out rows*4
  * coefficients (ascending).  LowDegreeProver.ts:137,191 */
 int gs_interpolate_quartic_batch(gs_ctx *ctx, const void *xs, const void *ys, uint64_t rows, void *out);
 /* Same result as gs_interpolate_quartic_batch when xs = transposeVector(powerSeries(omega, n), 4, step)
  * (the only shape the prover builds: LowDegreeProver.ts:190-191): xs[r][c] = omega^((r + c*rows)*step),
  * rows*4*step == n.  xs is never materialised. */
-int gs_interpolate_quartic_domain(gs_ctx *ctx, const uint8_t omega[16], uint64_t n, uint64_t step,
+int gs_interpolate_quartic_domain(gs_ctx *ctx, const gs_elt *omega, uint64_t n, uint64_t step,
                                   const void *ys, uint64_t rows, void *out);
 /* evalQuarticBatch(polys, x) -> Vector of rows values.  LowDegreeProver.ts:140,195 */
-int gs_eval_quartic_batch(gs_ctx *ctx, const void *polys, uint64_t rows, const uint8_t x[16], void *out);
+int gs_eval_quartic_batch(gs_ctx *ctx, const void *polys, uint64_t rows, const gs_elt *x, void *out);
 
 /* ---- hashing / Merkle (merkle package) --------------------------------------------------------- */
 /* Hash.digest(Buffer) on host bytes (verifier side; lib/utils/index.ts:37) — runs on the device
@@ -195,7 +199,7 @@ int gs_pseudorandom_indexes(const uint8_t *seed_host, uint32_t seed_len, uint32_
 /* context.generateExecutionTrace() for the MiMC AIR of examples/mimc/mimc128Assembly.ts:28-51:
  * trace[0] = seed, trace[i+1] = trace[i]^3 + rc[i mod nrc] (examples/mimc/utils.ts:7-15).
  * Inherently sequential: computed on the host CPU, then copied to `out` (steps elements). */
-int gs_mimc_trace(gs_ctx *ctx, const uint8_t seed[16], const uint8_t *rc_host, uint32_t nrc,
+int gs_mimc_trace(gs_ctx *ctx, const gs_elt *seed, const uint8_t *rc_host, uint32_t nrc,
                   uint64_t steps, void *out);
 /* context.evaluateTransitionConstraints(pPolys) body for that AIR over the composition domain
  * (CompositionPolynomial.ts:76): q[j] = p[(j + shift) mod nc] - (p[j]^3 + k[j mod klen]),

@@ -15,10 +15,16 @@
  * parity unpinned (see gf128.h).
  */
 #include "../include/gstark.h"
-#ifdef GS_SMALL_Q
+#if defined(GS_SMALL_Q)
 #include "gf_small.h"   /* checker flavour for a prime below 2^64 */
+#elif defined(GS_WIDE_BITS)
+#include "gf_wide.h"    /* checker flavour for the 256- / 224-bit primes (32-byte elements; needs a C23 _BitInt compiler) */
 #else
 #include "gf128.h"
+#endif
+#ifndef FE_BYTES
+#define FE_BYTES 16     /* bytes of one element in memory */
+typedef u128 fexp;      /* an exponent as wide as an element */
 #endif
 #include "hashes.h"
 #include <stdio.h>
@@ -47,7 +53,8 @@ void gs_ctx_destroy(gs_ctx *c) { free(c); }
 const char *gs_last_error(const gs_ctx *c) { return c ? c->err : "null context"; }
 int gs_sync(gs_ctx *c) { (void)c; return GS_OK; }
 void *gs_stream(gs_ctx *c) { (void)c; return NULL; }
-int gs_field_modulus(uint8_t out[16]) { fe_store(out, fe_p()); return GS_OK; }
+int gs_element_size(void) { return FE_BYTES; }
+int gs_field_modulus(gs_elt *out) { fe_store(out, fe_p()); return GS_OK; }
 
 int gs_alloc(gs_ctx *c, uint64_t bytes, void **p) {
     *p = malloc(bytes ? bytes : 1);
@@ -64,10 +71,10 @@ int gs_gather(gs_ctx *c, const void *src, uint64_t rec, const uint64_t *idx, uin
     return GS_OK;
 }
 
-#define EL(p, i) fe_load((const uint8_t *)(p) + 16 * (uint64_t)(i))
-#define ST(p, i, v) fe_store((uint8_t *)(p) + 16 * (uint64_t)(i), (v))
+#define EL(p, i) fe_load((const uint8_t *)(p) + FE_BYTES * (uint64_t)(i))
+#define ST(p, i, v) fe_store((uint8_t *)(p) + FE_BYTES * (uint64_t)(i), (v))
 
-int gs_power_series(gs_ctx *c, const uint8_t base[16], uint64_t n, void *out) {
+int gs_power_series(gs_ctx *c, const gs_elt *base, uint64_t n, void *out) {
     (void)c;
     fe b = fe_load(base), x = 1;
     for (uint64_t i = 0; i < n; i++) { ST(out, i, x); x = fe_mul(x, b); }
@@ -82,13 +89,13 @@ int gs_vec_sub(gs_ctx *c, const void *a, const void *b, uint64_t n, void *o) {
 int gs_vec_mul(gs_ctx *c, const void *a, const void *b, uint64_t n, void *o) {
     (void)c; for (uint64_t i = 0; i < n; i++) ST(o, i, fe_mul(EL(a, i), EL(b, i))); return GS_OK;
 }
-int gs_vec_add_scalar(gs_ctx *c, const void *a, const uint8_t s[16], uint64_t n, void *o) {
+int gs_vec_add_scalar(gs_ctx *c, const void *a, const gs_elt *s, uint64_t n, void *o) {
     (void)c; fe k = fe_load(s); for (uint64_t i = 0; i < n; i++) ST(o, i, fe_add(EL(a, i), k)); return GS_OK;
 }
-int gs_vec_sub_scalar(gs_ctx *c, const void *a, const uint8_t s[16], uint64_t n, void *o) {
+int gs_vec_sub_scalar(gs_ctx *c, const void *a, const gs_elt *s, uint64_t n, void *o) {
     (void)c; fe k = fe_load(s); for (uint64_t i = 0; i < n; i++) ST(o, i, fe_sub(EL(a, i), k)); return GS_OK;
 }
-int gs_vec_mul_scalar(gs_ctx *c, const void *a, const uint8_t s[16], uint64_t n, void *o) {
+int gs_vec_mul_scalar(gs_ctx *c, const void *a, const gs_elt *s, uint64_t n, void *o) {
     (void)c; fe k = fe_load(s); for (uint64_t i = 0; i < n; i++) ST(o, i, fe_mul(EL(a, i), k)); return GS_OK;
 }
 
@@ -127,8 +134,8 @@ int gs_vec_div(gs_ctx *c, const void *a, const void *b, uint64_t n, void *o) {
     free(t);
     return GS_OK;
 }
-int gs_vec_exp(gs_ctx *c, const void *a, const uint8_t e[16], uint64_t n, void *o) {
-    (void)c; u128 ee = fe_load(e);
+int gs_vec_exp(gs_ctx *c, const void *a, const gs_elt *e, uint64_t n, void *o) {
+    (void)c; fexp ee = fe_load(e);
     for (uint64_t i = 0; i < n; i++) ST(o, i, fe_exp(EL(a, i), ee));
     return GS_OK;
 }
@@ -136,12 +143,12 @@ int gs_combine_many(gs_ctx *c, const void *const *vecs, const uint8_t *coeffs, u
     if (count == 0 || count > GS_MAX_COMBINE) return fail(c, GS_ERR_ARG, "combine_many: bad count");
     for (uint64_t i = 0; i < n; i++) {
         fe s = 0;
-        for (uint32_t j = 0; j < count; j++) s = fe_add(s, fe_mul(EL(vecs[j], i), fe_load(coeffs + 16 * j)));
+        for (uint32_t j = 0; j < count; j++) s = fe_add(s, fe_mul(EL(vecs[j], i), fe_load(coeffs + FE_BYTES * j)));
         ST(o, i, s);
     }
     return GS_OK;
 }
-int gs_combine(gs_ctx *c, const void *a, const void *b, uint64_t n, uint8_t out[16]) {
+int gs_combine(gs_ctx *c, const void *a, const void *b, uint64_t n, gs_elt *out) {
     (void)c; fe s = 0;
     for (uint64_t i = 0; i < n; i++) s = fe_add(s, fe_mul(EL(a, i), EL(b, i)));
     fe_store(out, s);
@@ -197,7 +204,7 @@ static int check_root(gs_ctx *c, fe w, uint64_t n) { /* omega must generate the 
     if (n == 1) return w == 1 ? GS_OK : fail(c, GS_ERR_ARG, "ntt: omega must be 1 for n = 1");
     return fe_exp(w, n / 2) == fe_p() - 1 ? GS_OK : fail(c, GS_ERR_ARG, "ntt: omega is not a primitive n-th root of unity");
 }
-int gs_eval_polys_at_roots(gs_ctx *c, const void *polys, uint32_t rows, uint64_t plen, const uint8_t omega[16],
+int gs_eval_polys_at_roots(gs_ctx *c, const void *polys, uint32_t rows, uint64_t plen, const gs_elt *omega,
                            uint64_t n, void *out) {
     if (!is_pow2(n) || plen > n) return fail(c, GS_ERR_ARG, "eval_polys_at_roots: n must be a power of two >= poly_len");
     if (check_root(c, fe_load(omega), n)) return GS_ERR_ARG;
@@ -212,7 +219,7 @@ int gs_eval_polys_at_roots(gs_ctx *c, const void *polys, uint32_t rows, uint64_t
     free(t);
     return GS_OK;
 }
-int gs_interpolate_roots(gs_ctx *c, const void *ys, uint32_t rows, const uint8_t omega[16], uint64_t n, void *out) {
+int gs_interpolate_roots(gs_ctx *c, const void *ys, uint32_t rows, const gs_elt *omega, uint64_t n, void *out) {
     if (!is_pow2(n)) return fail(c, GS_ERR_ARG, "interpolate_roots: n must be a power of two");
     if (check_root(c, fe_load(omega), n)) return GS_ERR_ARG;
     fe *t = (fe *)malloc(n * sizeof(fe));
@@ -226,7 +233,7 @@ int gs_interpolate_roots(gs_ctx *c, const void *ys, uint32_t rows, const uint8_t
     free(t);
     return GS_OK;
 }
-int gs_eval_poly_at(gs_ctx *c, const void *poly, uint64_t len, const uint8_t x[16], uint8_t out[16]) {
+int gs_eval_poly_at(gs_ctx *c, const void *poly, uint64_t len, const gs_elt *x, gs_elt *out) {
     (void)c; fe xx = fe_load(x), s = 0;
     for (uint64_t i = len; i-- > 0;) s = fe_add(fe_mul(s, xx), EL(poly, i));
     fe_store(out, s);
@@ -265,19 +272,19 @@ int gs_interpolate_quartic_batch(gs_ctx *c, const void *xs, const void *ys, uint
     }
     return GS_OK;
 }
-int gs_interpolate_quartic_domain(gs_ctx *c, const uint8_t omega[16], uint64_t n, uint64_t step, const void *ys,
+int gs_interpolate_quartic_domain(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *ys,
                                   uint64_t rows, void *out) {
     if (rows * 4 * step != n) return fail(c, GS_ERR_ARG, "interpolate_quartic_domain: rows*4*step != n");
     fe w = fe_load(omega);
     for (uint64_t r = 0; r < rows; r++) {
         fe x[4], y[4], k[4];
-        for (int j = 0; j < 4; j++) { x[j] = fe_exp(w, (u128)((r + (uint64_t)j * rows) * step)); y[j] = EL(ys, r * 4 + j); }
+        for (int j = 0; j < 4; j++) { x[j] = fe_exp(w, (fexp)((r + (uint64_t)j * rows) * step)); y[j] = EL(ys, r * 4 + j); }
         lagrange4(x, y, k);
         for (int j = 0; j < 4; j++) ST(out, r * 4 + j, k[j]);
     }
     return GS_OK;
 }
-int gs_eval_quartic_batch(gs_ctx *c, const void *polys, uint64_t rows, const uint8_t x[16], void *out) {
+int gs_eval_quartic_batch(gs_ctx *c, const void *polys, uint64_t rows, const gs_elt *x, void *out) {
     (void)c; fe xx = fe_load(x);
     for (uint64_t r = 0; r < rows; r++) {
         fe s = EL(polys, r * 4 + 3);
@@ -292,10 +299,10 @@ int gs_hash_digest(gs_ctx *c, gs_hash_alg alg, const uint8_t *msg, uint64_t len,
 }
 int gs_hash_merge_rows(gs_ctx *c, gs_hash_alg alg, const void *const *vecs, uint32_t count, uint64_t n, void *out) {
     if (count == 0 || count > GS_MAX_COMBINE) return fail(c, GS_ERR_ARG, "hash_merge_rows: bad count");
-    uint8_t buf[16 * GS_MAX_COMBINE];
+    uint8_t buf[FE_BYTES * GS_MAX_COMBINE];
     for (uint64_t i = 0; i < n; i++) {
-        for (uint32_t j = 0; j < count; j++) memcpy(buf + 16 * j, (const uint8_t *)vecs[j] + 16 * i, 16);
-        orc_hash((int)alg, buf, 16 * (size_t)count, (uint8_t *)out + 32 * i);
+        for (uint32_t j = 0; j < count; j++) memcpy(buf + FE_BYTES * j, (const uint8_t *)vecs[j] + FE_BYTES * i, FE_BYTES);
+        orc_hash((int)alg, buf, FE_BYTES * (size_t)count, (uint8_t *)out + 32 * i);
     }
     return GS_OK;
 }
@@ -313,12 +320,12 @@ int gs_merkle_build(gs_ctx *c, gs_hash_alg alg, const void *leaves, uint64_t n, 
     return GS_OK;
 }
 
-int gs_mimc_trace(gs_ctx *c, const uint8_t seed[16], const uint8_t *rc, uint32_t nrc, uint64_t steps, void *out) {
+int gs_mimc_trace(gs_ctx *c, const gs_elt *seed, const uint8_t *rc, uint32_t nrc, uint64_t steps, void *out) {
     if (!nrc || !steps) return fail(c, GS_ERR_ARG, "mimc_trace: empty");
     fe x = fe_load(seed);
     for (uint64_t i = 0; i < steps; i++) {
         ST(out, i, x);
-        x = fe_add(fe_mul(fe_mul(x, x), x), fe_load(rc + 16 * (i % nrc)));
+        x = fe_add(fe_mul(fe_mul(x, x), x), fe_load(rc + FE_BYTES * (i % nrc)));
     }
     return GS_OK;
 }
@@ -404,7 +411,7 @@ int gs_small_interpolate(const uint8_t *xs, const uint8_t *ys, uint32_t n, uint8
     fe *x = (fe *)malloc(sizeof(fe) * n * 4);
     if (!x) return GS_ERR_OOM;
     fe *y = x + n, *num = y + n, *acc = num + n;
-    for (uint32_t i = 0; i < n; i++) { x[i] = fe_load(xs + 16 * i); y[i] = fe_load(ys + 16 * i); acc[i] = 0; }
+    for (uint32_t i = 0; i < n; i++) { x[i] = fe_load(xs + FE_BYTES * i); y[i] = fe_load(ys + FE_BYTES * i); acc[i] = 0; }
     for (uint32_t j = 0; j < n; j++) { /* plain O(n^2)-per-basis Lagrange: rebuild each numerator from scratch */
         uint32_t deg = 0;
         fe den = 1;
@@ -421,21 +428,21 @@ int gs_small_interpolate(const uint8_t *xs, const uint8_t *ys, uint32_t n, uint8
         fe s = fe_mul(y[j], fe_inv(den));
         for (uint32_t d = 0; d < n; d++) acc[d] = fe_add(acc[d], fe_mul(num[d], s));
     }
-    for (uint32_t d = 0; d < n; d++) fe_store(out + 16 * d, acc[d]);
+    for (uint32_t d = 0; d < n; d++) fe_store(out + FE_BYTES * d, acc[d]);
     free(x);
     return GS_OK;
 }
 int gs_small_eval_poly(const uint8_t *poly, uint32_t len, const uint8_t *xs, uint32_t m, uint8_t *out) {
     for (uint32_t i = 0; i < m; i++) {
-        fe x = fe_load(xs + 16 * i), s = 0;
-        for (uint32_t k = len; k-- > 0;) s = fe_add(fe_mul(s, x), fe_load(poly + 16 * k));
-        fe_store(out + 16 * i, s);
+        fe x = fe_load(xs + FE_BYTES * i), s = 0;
+        for (uint32_t k = len; k-- > 0;) s = fe_add(fe_mul(s, x), fe_load(poly + FE_BYTES * k));
+        fe_store(out + FE_BYTES * i, s);
     }
     return GS_OK;
 }
 
 /* ---- generic AIR programs (include/gstark.h): the simplest possible interpreter, both for the trace and per point ---- */
-static fe vm_pow_u32(fe b, uint32_t e) { return fe_exp(b, (u128)e); }
+static fe vm_pow_u32(fe b, uint32_t e) { return fe_exp(b, (fexp)e); }
 static int air_check(gs_ctx *c, const uint32_t *code, uint32_t n, uint32_t nconsts, uint32_t vm, uint32_t regs, uint32_t nstatic, uint32_t nout, int allow_next) {
     if (!code || !n || !vm || vm > GS_AIR_MAX_VM_REGS || !regs || regs > GS_AIR_MAX_REGISTERS || nstatic > GS_AIR_MAX_REGISTERS) return fail(c, GS_ERR_ARG, "air program: bad shape");
     for (uint32_t pc = 0; pc < n; pc++) {
@@ -464,7 +471,7 @@ int gs_air_trace(gs_ctx *c, const uint32_t *code, uint32_t n, const uint8_t *con
     uint64_t soff[GS_AIR_MAX_REGISTERS];
     uint64_t o = 0;
     for (uint32_t s = 0; s < nstatic; s++) { if (!speriods[s]) return fail(c, GS_ERR_ARG, "air_trace: empty static register"); soff[s] = o; o += speriods[s]; }
-    for (uint32_t r = 0; r < regs; r++) row[r] = fe_load(row0 + 16 * r);
+    for (uint32_t r = 0; r < regs; r++) row[r] = fe_load(row0 + FE_BYTES * r);
     for (uint64_t i = 0; i < steps; i++) {
         for (uint32_t r = 0; r < regs; r++) ST(out, (uint64_t)r * steps + i, row[r]);
         if (i + 1 == steps) break;
@@ -472,14 +479,14 @@ int gs_air_trace(gs_ctx *c, const uint32_t *code, uint32_t n, const uint8_t *con
         for (uint32_t pc = 0; pc < n; pc++) {
             uint32_t op = code[4 * pc], d = code[4 * pc + 1], a = code[4 * pc + 2], b = code[4 * pc + 3];
             switch (op) {
-                case 0: vm[d] = fe_load(consts + 16 * a); break;
+                case 0: vm[d] = fe_load(consts + FE_BYTES * a); break;
                 case 1: vm[d] = row[a]; break;
-                case 3: vm[d] = fe_load(svals + 16 * (soff[a] + i % speriods[a])); break;
+                case 3: vm[d] = fe_load(svals + FE_BYTES * (soff[a] + i % speriods[a])); break;
                 case 4: vm[d] = fe_add(vm[a], vm[b]); break;
                 case 5: vm[d] = fe_sub(vm[a], vm[b]); break;
                 case 6: vm[d] = fe_mul(vm[a], vm[b]); break;
                 case 7: vm[d] = vm_pow_u32(vm[a], b); break;
-                case 8: vm[d] = fe_exp(vm[a], fe_load(consts + 16 * b)); break;
+                case 8: vm[d] = fe_exp(vm[a], fe_load(consts + FE_BYTES * b)); break;
                 default: next[d] = vm[a]; break;
             }
         }
@@ -498,19 +505,19 @@ int gs_air_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t n, const uin
     uint64_t soff[GS_AIR_MAX_REGISTERS], o = 0, steps = segments * seglen;
     for (uint32_t s = 0; s < nstatic; s++) { if (!speriods[s]) return fail(c, GS_ERR_ARG, "air_trace_segments: empty static register"); soff[s] = o; o += speriods[s]; }
     for (uint64_t g = 0; g < segments; g++) {
-        for (uint32_t r = 0; r < regs; r++) row[r] = fe_load(rows0 + 16 * (g * regs + r));
+        for (uint32_t r = 0; r < regs; r++) row[r] = fe_load(rows0 + FE_BYTES * (g * regs + r));
         if (in) {   /* init block: inputs -> first row */
             for (uint32_t r = 0; r < regs; r++) next[r] = row[r];
             for (uint32_t pc = 0; pc < in; pc++) {
                 uint32_t op = icode[4 * pc], d = icode[4 * pc + 1], a = icode[4 * pc + 2], b = icode[4 * pc + 3];
                 switch (op) {
-                    case 0: vm[d] = fe_load(consts + 16 * a); break;
+                    case 0: vm[d] = fe_load(consts + FE_BYTES * a); break;
                     case 1: vm[d] = row[a]; break;
                     case 4: vm[d] = fe_add(vm[a], vm[b]); break;
                     case 5: vm[d] = fe_sub(vm[a], vm[b]); break;
                     case 6: vm[d] = fe_mul(vm[a], vm[b]); break;
                     case 7: vm[d] = vm_pow_u32(vm[a], b); break;
-                    case 8: vm[d] = fe_exp(vm[a], fe_load(consts + 16 * b)); break;
+                    case 8: vm[d] = fe_exp(vm[a], fe_load(consts + FE_BYTES * b)); break;
                     default: next[d] = vm[a]; break;
                 }
             }
@@ -524,14 +531,14 @@ int gs_air_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t n, const uin
             for (uint32_t pc = 0; pc < n; pc++) {
                 uint32_t op = code[4 * pc], d = code[4 * pc + 1], a = code[4 * pc + 2], b = code[4 * pc + 3];
                 switch (op) {
-                    case 0: vm[d] = fe_load(consts + 16 * a); break;
+                    case 0: vm[d] = fe_load(consts + FE_BYTES * a); break;
                     case 1: vm[d] = row[a]; break;
-                    case 3: vm[d] = fe_load(svals + 16 * (soff[a] + i % speriods[a])); break;
+                    case 3: vm[d] = fe_load(svals + FE_BYTES * (soff[a] + i % speriods[a])); break;
                     case 4: vm[d] = fe_add(vm[a], vm[b]); break;
                     case 5: vm[d] = fe_sub(vm[a], vm[b]); break;
                     case 6: vm[d] = fe_mul(vm[a], vm[b]); break;
                     case 7: vm[d] = vm_pow_u32(vm[a], b); break;
-                    case 8: vm[d] = fe_exp(vm[a], fe_load(consts + 16 * b)); break;
+                    case 8: vm[d] = fe_exp(vm[a], fe_load(consts + FE_BYTES * b)); break;
                     default: next[d] = vm[a]; break;
                 }
             }
@@ -552,7 +559,7 @@ int gs_air_constraints(gs_ctx *c, const uint32_t *code, uint32_t n, const uint8_
         for (uint32_t pc = 0; pc < n; pc++) {
             uint32_t op = code[4 * pc], d = code[4 * pc + 1], a = code[4 * pc + 2], b = code[4 * pc + 3];
             switch (op) {
-                case 0: vm[d] = fe_load(consts + 16 * a); break;
+                case 0: vm[d] = fe_load(consts + FE_BYTES * a); break;
                 case 1: vm[d] = EL(p, (uint64_t)a * nc + j); break;
                 case 2: vm[d] = EL(p, (uint64_t)a * nc + jn); break;
                 case 3: vm[d] = EL(stab, soff[a] + j % slens[a]); break;
@@ -560,7 +567,7 @@ int gs_air_constraints(gs_ctx *c, const uint32_t *code, uint32_t n, const uint8_
                 case 5: vm[d] = fe_sub(vm[a], vm[b]); break;
                 case 6: vm[d] = fe_mul(vm[a], vm[b]); break;
                 case 7: vm[d] = vm_pow_u32(vm[a], b); break;
-                case 8: vm[d] = fe_exp(vm[a], fe_load(consts + 16 * b)); break;
+                case 8: vm[d] = fe_exp(vm[a], fe_load(consts + FE_BYTES * b)); break;
                 default: ST(out, (uint64_t)d * nc + j, vm[a]); break;
             }
         }

@@ -34,8 +34,9 @@ def test_hip_library_exports_every_symbol():
     assert int.from_bytes(buf.raw, 'little') == P
 
 
-def test_small_field_flavours_export_every_symbol():
-    """The q64 / q32 builds of the same sources (csrc/gf_small.cuh): same ABI, their own modulus."""
+def test_field_flavours_export_every_symbol():
+    """The q64 / q32 builds (csrc/gf_small.cuh) and the p256 / p224 builds (csrc/gf_wide.cuh) of the same sources: same ABI, their
+    own modulus and element size."""
     for modulus, path in _abi.HIP_LIB_PATHS.items():
         assert os.path.exists(path), f'{path}: run __graft_entry__.build() first'
         lib = ctypes.CDLL(path)
@@ -43,7 +44,8 @@ def test_small_field_flavours_export_every_symbol():
             assert hasattr(lib, name), (path, name)
         lib.gs_backend_name.restype = ctypes.c_char_p
         assert lib.gs_backend_name() == b'hip-gfx950'
-        buf = ctypes.create_string_buffer(16)
+        assert lib.gs_element_size() == (16 if modulus < 2**128 else 32)
+        buf = ctypes.create_string_buffer(lib.gs_element_size())
         lib.gs_field_modulus(buf)
         assert int.from_bytes(buf.raw, 'little') == modulus
 
@@ -70,6 +72,33 @@ def test_small_field_device_header_on_host(tmp_path, rng):
         assert list(o[1]) == [(x - y) % q for x, y in zip(a, b)]
         assert list(o[2]) == [x * y % q for x, y in zip(a, b)]
         assert list(o[3]) == [pow(x, -1, q) if x else 0 for x in a]
+
+
+def test_wide_field_device_header_on_host(tmp_path, rng):
+    """gf_wide.cuh compiled for the host (the same GF_HD functions the kernels inline) against Python integers, both moduli."""
+    src = tmp_path / 'w.cpp'
+    src.write_text('#include <stdint.h>\n#include <string.h>\n#include "%s"\n'
+                   'extern "C" void ops(const uint8_t *a, const uint8_t *b, uint64_t n, uint8_t *add, uint8_t *sub, uint8_t *mul, uint8_t *inv) {\n'
+                   '  for (uint64_t i = 0; i < n; i++) { fe x, y, r; memcpy(&x, a + 32 * i, 32); memcpy(&y, b + 32 * i, 32);\n'
+                   '    r = fe_add(x, y); memcpy(add + 32 * i, &r, 32); r = fe_sub(x, y); memcpy(sub + 32 * i, &r, 32);\n'
+                   '    r = fe_mul(x, y); memcpy(mul + 32 * i, &r, 32); if (i < 200) { r = fe_inv(x); memcpy(inv + 32 * i, &r, 32); } } }\n'
+                   % os.path.join(ROOT, 'genstark_amd', 'csrc', 'gf_wide.cuh'))
+    for bits, p in ((256, _abi.MODULUS_256), (224, _abi.MODULUS_224)):
+        so = str(tmp_path / f'w_{bits}.so')
+        subprocess.check_call(['g++', '-O2', '-shared', '-fPIC', '-Wno-unknown-pragmas', f'-DGS_WIDE_BITS={bits}', '-o', so, str(src)])
+        lib = ctypes.CDLL(so)
+        n = 20000
+        edge = [0, 1, 2, p - 1, p - 2, 2**128 - 1, 2**128, 1 << (bits - 1), p >> 1, 2**32 - 1, p - 2**32, p - 2**96]
+        a = [rng.choice(edge) if rng.random() < 0.3 else rng.randrange(p) for _ in range(n)]
+        b = [rng.choice(edge) if rng.random() < 0.3 else rng.randrange(p) for _ in range(n)]
+        pack = lambda v: b''.join(x.to_bytes(32, 'little') for x in v)
+        outs = [ctypes.create_string_buffer(32 * n) for _ in range(4)]
+        lib.ops(pack(a), pack(b), ctypes.c_uint64(n), *outs)
+        dec = lambda o, m=n: [int.from_bytes(o.raw[32 * i:32 * i + 32], 'little') for i in range(m)]
+        assert dec(outs[0]) == [(x + y) % p for x, y in zip(a, b)]
+        assert dec(outs[1]) == [(x - y) % p for x, y in zip(a, b)]
+        assert dec(outs[2]) == [x * y % p for x, y in zip(a, b)]
+        assert dec(outs[3], 200) == [pow(x, p - 2, p) for x in a[:200]]
 
 
 def test_product_refuses_the_oracle_backend(oracle_backend):

@@ -1,0 +1,107 @@
+"""The two multi-limb prime fields of the reference's examples on the build flavours of the library (genstark_amd/csrc/gf_wide.cuh;
+SURVEY 8f-3): 2^256 - 351*2^32 + 1 (examples/mimc/mimc256.ts:13) and 2^224 - 2^96 + 1 (assembly/lib224.aa:3).  Same kernels,
+32-byte elements.  The reference pins nothing for these fields beyond prove -> verify round trips (mimc256.ts:70-85), so the
+checks are: every vector member against Python integers, NTT against direct evaluation, MiMC-256 with the example's options
+proved, serialized, parsed, verified (also by the GPU-free verifier), tampering rejected.  CPU: the oracle flavours (C23 _BitInt
+arithmetic, nothing shared with the device code); GPU: the HIP flavours, byte-identical proofs."""
+import os
+
+import pytest
+
+from conftest import ROOT, _build_oracle
+from genstark_amd._abi import MODULUS_224, MODULUS_256, Backend
+from genstark_amd.air import MimcAir, runMimc
+from genstark_amd.air_generic import GenericAir
+from genstark_amd.errors import StarkError
+from genstark_amd.field import PrimeField
+from genstark_amd.hostfield import HostField
+from genstark_amd.stark import Stark
+from test_small_fields import check_arithmetic
+
+FLAVOURS = {'p256': MODULUS_256, 'p224': MODULUS_224}
+MIMC256_OPTIONS = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 40, 'friQueryCount': 24}    # mimc256.ts:22-28
+
+
+def oracle_for(name):
+    _build_oracle()
+    return Backend(lib_path=os.path.join(ROOT, 'oracle', f'liboracle_{name}.so'), allow_test_double=True)
+
+
+def hip_for(name):
+    return Backend(device=0, modulus=FLAVOURS[name])
+
+
+def quintic_air(field, steps):
+    """A two-register degree-5 chain with a cyclic constant (the S-box of lib224.aa's Poseidon, x^5): exercises the generic
+    trace / constraint VM, exponentiation by a constant and static registers over the wide field."""
+    ks = [[(7 * i + 3) % field.modulus for i in range(8)]]
+    return GenericAir(steps, 2, [5, 5], ks, lambda r, k: [(r[0] + k[0]) ** 5 + r[1], r[0] + 2 * r[1]],
+                      lambda r, n, k: [n[0] - ((r[0] + k[0]) ** 5 + r[1]), n[1] - (r[0] + 2 * r[1])], lambda seed: [seed[0], seed[1]], None, field)
+
+
+def check_starks(backend, name, steps=2**7):
+    q = FLAVOURS[name]
+    f = PrimeField(backend=backend)
+    assert f.elementSize == 32 and f.modulus == q
+    out = []
+    # MiMC over the wide field (mimc256.ts:30-56: x <- x^3 + k, 64 cyclic round constants)
+    air = MimcAir(steps, 16, f)
+    control = runMimc(f, steps, air.roundConstants, 3)
+    trace = air.initProvingContext([], [3]).generateExecutionTrace()
+    assert trace.toValues()[0] == control
+    stark = Stark(air, MIMC256_OPTIONS)
+    assertions = [{'step': 0, 'register': 0, 'value': 3}, {'step': steps - 1, 'register': 0, 'value': control[-1]}]    # mimc256.ts:60-63
+    proof = stark.prove(assertions, [], [3])
+    data = stark.serialize(proof)
+    assert len(data) == stark.sizeOf(proof)                                   # mimc256.ts:76
+    assert stark.verify(assertions, stark.parse(data))
+    hv = Stark(MimcAir(steps, 16, HostField(q)), MIMC256_OPTIONS)
+    assert hv.verify(assertions, hv.parse(data))
+    with pytest.raises(StarkError):
+        stark.verify([assertions[0], dict(assertions[1], value=(control[-1] + 1) % q)], stark.parse(data))
+    with pytest.raises(StarkError):
+        stark.prove([assertions[0], dict(assertions[1], value=(control[-1] + 1) % q)], [], [3])
+    out.append(data)
+    # generic AIR (register machine) over the wide field, sha256 leaves
+    air = quintic_air(f, 64)
+    full = air.hostTrace([5, 9])
+    assert [list(r) for r in zip(*full)] == air.initProvingContext([], [5, 9]).generateExecutionTrace().toValues()
+    stark = Stark(air, {'hashAlgorithm': 'sha256', 'extensionFactor': 16, 'exeQueryCount': 30, 'friQueryCount': 16})
+    assertions = [{'step': 0, 'register': 0, 'value': 5}, {'step': 63, 'register': 0, 'value': full[63][0]},
+                  {'step': 63, 'register': 1, 'value': full[63][1]}]
+    data = stark.serialize(stark.prove(assertions, [], [5, 9]))
+    assert stark.verify(assertions, stark.parse(data))
+    hv = Stark(quintic_air(HostField(q), 64), {'hashAlgorithm': 'sha256', 'extensionFactor': 16, 'exeQueryCount': 30, 'friQueryCount': 16})
+    assert hv.verify(assertions, hv.parse(data))
+    out.append(data)
+    return out
+
+
+@pytest.mark.parametrize('name', ['p256', 'p224'])
+def test_wide_field_arithmetic_oracle(name):
+    b = oracle_for(name)
+    assert b.element_size == 32
+    check_arithmetic(b, FLAVOURS[name], 7)
+
+
+@pytest.mark.parametrize('name', ['p256', 'p224'])
+def test_wide_field_starks_oracle(name):
+    check_starks(oracle_for(name), name)
+
+
+def test_wide_field_moduli_are_the_examples():
+    from sympy import isprime
+    assert isprime(MODULUS_256) and isprime(MODULUS_224)
+    assert (MODULUS_256 - 1) % 2**32 == 0 and (MODULUS_224 - 1) % 2**96 == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['p256', 'p224'])
+def test_wide_field_hip(name):
+    hip = hip_for(name)
+    assert hip.name == 'hip-gfx950' and hip.modulus == FLAVOURS[name] and hip.element_size == 32
+    check_arithmetic(hip, FLAVOURS[name], 11)
+    assert check_starks(hip, name) == check_starks(oracle_for(name), name)
+    # a size where the NTT runs its multi-pass radix-256 path and the Merkle tree its streaming levels
+    big = check_starks(hip, name, steps=2**12)
+    assert len(big) == 2
