@@ -15,6 +15,7 @@ from genstark_amd.air_generic import GenericAir
 from genstark_amd.errors import StarkError
 from genstark_amd.field import PrimeField
 from genstark_amd.hostfield import HostField
+from genstark_amd.pointmul import ec_multiply, point_mul_air, to_bits
 from genstark_amd.stark import Stark
 from test_small_fields import check_arithmetic
 
@@ -29,6 +30,46 @@ def oracle_for(name):
 
 def hip_for(name):
     return Backend(device=0, modulus=FLAVOURS[name])
+
+
+# examples/elliptic/pointMul.ts:22-31: the point, the scalar, the expected product (the reference's own known answer)
+EC_POINT = (19277929113566293071110308034699488026831934219452440156649784352033, 19926808758034470970197974370888749184205991990603949537637343198772)
+EC_SCALAR = 21628546220445634706341881427918508772248629391536891476641575405363
+EC_PRODUCT = (5326626235735428056996404471396244610891648579045949976641038973984, 6753729428472267765045584530315486521937702623726344079323769311058)
+EC_OPTIONS = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 48, 'friQueryCount': 24}             # pointMul.ts:11-17
+
+
+def check_point_mul(backend):
+    """examples/elliptic/pointmul.aa over the 224-bit field: the trace the register machine generates holds the product the
+    reference expects; the proof round-trips like pointMul.ts:39-56 and the GPU-free verifier accepts it."""
+    f = PrimeField(backend=backend)
+    air = point_mul_air(f)
+    raw = [[EC_POINT[0]], [EC_POINT[1]], [to_bits(EC_SCALAR)]]
+    inputs, seeds = air.expandInputs(raw), air.segmentSeeds(raw)
+    trace = air.initProvingContext(inputs, seeds).generateExecutionTrace().toValues()
+    assert (trace[2][255], trace[3][255]) == EC_PRODUCT                      # pointMul.ts:28-37
+    assert trace[7][255] == EC_SCALAR and trace[6][0] == 1 and trace[6][255] == 0
+    assert [list(r) for r in zip(*air.hostTrace(seeds, inputs=inputs))] == trace
+    stark = Stark(air, EC_OPTIONS)
+    assertions = [{'step': 255, 'register': 2, 'value': EC_PRODUCT[0]}, {'step': 255, 'register': 3, 'value': EC_PRODUCT[1]}]
+    proof = stark.prove(assertions, inputs, seeds)
+    data = stark.serialize(proof)
+    assert len(data) == stark.sizeOf(proof) and stark.verify(assertions, stark.parse(data))
+    hv = Stark(point_mul_air(HostField(MODULUS_224)), EC_OPTIONS)
+    assert hv.verify(assertions, hv.parse(data))
+    with pytest.raises(StarkError):
+        stark.verify([assertions[0], dict(assertions[1], value=EC_PRODUCT[1] ^ 1)], stark.parse(data))
+    # two multiplications in one trace (two device threads), the second by another scalar
+    k2 = 0x1234567890abcdef1234567890abcdef1234567890abcdef12345678
+    air2 = point_mul_air(f, 2)
+    raw2 = [[EC_POINT[0], EC_PRODUCT[0]], [EC_POINT[1], EC_PRODUCT[1]], [to_bits(EC_SCALAR), to_bits(k2)]]
+    inputs2, seeds2 = air2.expandInputs(raw2), air2.segmentSeeds(raw2)
+    want2 = ec_multiply(MODULUS_224, EC_PRODUCT, k2)
+    stark2 = Stark(air2, EC_OPTIONS)
+    assertions2 = assertions + [{'step': 511, 'register': 2, 'value': want2[0]}, {'step': 511, 'register': 3, 'value': want2[1]}]
+    data2 = stark2.serialize(stark2.prove(assertions2, inputs2, seeds2))
+    assert stark2.verify(assertions2, stark2.parse(data2))
+    return [data, data2]
 
 
 def quintic_air(field, steps):
@@ -89,6 +130,11 @@ def test_wide_field_starks_oracle(name):
     check_starks(oracle_for(name), name)
 
 
+def test_point_multiplication_oracle():
+    assert ec_multiply(MODULUS_224, EC_POINT, EC_SCALAR) == EC_PRODUCT       # the plain control computation agrees with the reference
+    check_point_mul(oracle_for('p224'))
+
+
 def test_wide_field_moduli_are_the_examples():
     from sympy import isprime
     assert isprime(MODULUS_256) and isprime(MODULUS_224)
@@ -105,3 +151,8 @@ def test_wide_field_hip(name):
     # a size where the NTT runs its multi-pass radix-256 path and the Merkle tree its streaming levels
     big = check_starks(hip, name, steps=2**12)
     assert len(big) == 2
+
+
+@pytest.mark.gpu
+def test_point_multiplication_hip():
+    assert check_point_mul(hip_for('p224')) == check_point_mul(oracle_for('p224'))
