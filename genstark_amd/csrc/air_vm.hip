@@ -10,6 +10,8 @@
 
 enum { OP_LOADC = 0, OP_LOADR = 1, OP_LOADN = 2, OP_LOADS = 3, OP_ADDV = 4, OP_SUBV = 5, OP_MULV = 6, OP_POW = 7, OP_POWC = 8, OP_OUT = 9 };
 
+#define GS_HOST_TRACE_MAX_SEGMENTS 8   // fewer segments than this: one host core beats one device thread per segment
+
 struct StaticDesc {
     uint64_t offset[GS_AIR_MAX_REGISTERS];  // element offset into the concatenated table
     uint64_t len[GS_AIR_MAX_REGISTERS];
@@ -178,6 +180,66 @@ static int check_program(gs_ctx *c, const uint32_t *code, uint32_t ninstr, uint3
     return GS_OK;
 }
 
+// One host core interprets the program on native limbs (host_field.h): the whole trace of an unsegmented AIR (steps are
+// sequentially dependent), and segmented AIRs with only a few segments — one device thread per segment is an order of magnitude
+// slower than a host core per step, which only pays off when many segments run side by side.
+static void host_run(const uint32_t *code, uint32_t ninstr, const std::vector<hfe> &consts, std::vector<hfe> &vm, const std::vector<hfe> &row,
+                     std::vector<hfe> &next, const std::vector<std::vector<hfe>> *statics, uint64_t i) {
+    for (uint32_t pc = 0; pc < ninstr; pc++) {
+        const uint32_t op = code[4 * pc], dst = code[4 * pc + 1], a = code[4 * pc + 2], b = code[4 * pc + 3];
+        switch (op) {
+            case OP_LOADC: vm[dst] = consts[a]; break;
+            case OP_LOADR: vm[dst] = row[a]; break;
+            case OP_LOADS: vm[dst] = (*statics)[a][i % (*statics)[a].size()]; break;
+            case OP_ADDV: vm[dst] = hf_add(vm[a], vm[b]); break;
+            case OP_SUBV: vm[dst] = hf_sub(vm[a], vm[b]); break;
+            case OP_MULV: vm[dst] = hf_mul(vm[a], vm[b]); break;
+            case OP_POW: vm[dst] = hf_pow(vm[a], (hfe)b); break;
+            case OP_POWC: vm[dst] = hf_pow(vm[a], consts[b]); break;
+            default: next[dst] = vm[a]; break;
+        }
+    }
+}
+
+static int host_trace(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, const uint32_t *init_code_host, uint32_t init_ninstr,
+                      const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs, uint32_t registers, const uint8_t *static_values_host,
+                      const uint32_t *static_periods_host, uint32_t nstatic, const uint8_t *first_rows_host, uint64_t segments,
+                      uint64_t segment_len, void *out) {
+    std::vector<hfe> consts(nconsts ? nconsts : 1), vm(vm_regs), row(registers), next(registers);
+    for (uint32_t i = 0; i < nconsts; i++) consts[i] = hf_load(consts_host + GS_ELT * i);
+    std::vector<std::vector<hfe>> statics(nstatic);
+    {
+        const uint8_t *p = static_values_host;
+        for (uint32_t s = 0; s < nstatic; s++) {
+            if (!static_periods_host[s]) return gs_fail(c, GS_ERR_ARG, "air_trace: empty static register");
+            statics[s].resize(static_periods_host[s]);
+            for (uint32_t i = 0; i < static_periods_host[s]; i++, p += GS_ELT) statics[s][i] = hf_load(p);
+        }
+    }
+    const uint64_t steps = segments * segment_len;
+    int rc;
+    if ((rc = gs_trace_begin(c, (uint64_t)registers * steps * GS_ELT))) return rc;
+    hfe *t = (hfe *)c->h_trace;  // registers x steps, row-major like the Matrix the caller gets
+    for (uint64_t g = 0; g < segments; g++) {
+        for (uint32_t r = 0; r < registers; r++) row[r] = hf_load(first_rows_host + GS_ELT * (g * registers + r));
+        if (init_ninstr) {   // the `init { ... }` block: inputs -> first row
+            next = row;
+            host_run(init_code_host, init_ninstr, consts, vm, row, next, nullptr, 0);
+            row = next;
+        }
+        for (uint64_t k = 0; k < segment_len; k++) {
+            const uint64_t i = g * segment_len + k;
+            for (uint32_t r = 0; r < registers; r++) t[(uint64_t)r * steps + i] = row[r];
+            if (k + 1 == segment_len) break;
+            next = row;
+            host_run(code_host, ninstr, consts, vm, row, next, &statics, i);
+            row = next;
+        }
+    }
+    GS_HIP(c, hipMemcpyAsync(out, c->h_trace, (size_t)registers * steps * GS_ELT, hipMemcpyHostToDevice, c->stream));
+    return gs_trace_end(c);
+}
+
 extern "C" {
 
 int gs_air_constraints(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs,
@@ -239,6 +301,9 @@ int gs_air_trace_segments(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr,
             nstat += static_periods_host[s];
         }
     }
+    if (segments <= GS_HOST_TRACE_MAX_SEGMENTS)
+        return host_trace(c, code_host, ninstr, init_code_host, init_ninstr, consts_host, nconsts, vm_regs, registers, static_values_host,
+                          static_periods_host, nstatic, first_rows_host, segments, segment_len, out);
     // program, constants, static values and first rows -> one device block (pageable caller memory: one sync)
     const uint64_t main_b = ((uint64_t)ninstr * 16 + 255) & ~(uint64_t)255, code_b = main_b + (((uint64_t)init_ninstr * 16 + 255) & ~(uint64_t)255);
     const uint64_t const_b = ((uint64_t)(nconsts ? nconsts : 1) * GS_ELT + 255) & ~(uint64_t)255;
@@ -260,7 +325,14 @@ int gs_air_trace_segments(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr,
 #define GS_LAUNCH_TRACE(N, L, SH)                                                                                                        \
     hipLaunchKernelGGL((k_air_trace_segments<N, L>), grid, block, SH, c->stream, dcode, ninstr, dinit, init_ninstr, dconst, dstat, sd, drows, \
                        registers, segments, segment_len, vm_regs, (fe *)out)
-    if (lds_bytes <= 64 * 1024) GS_LAUNCH_TRACE(1, true, (size_t)lds_bytes);
+    if (lds_bytes <= 160 * 1024) {   // gfx950: 160 KB of LDS per workgroup
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute(reinterpret_cast<const void *>(k_air_trace_segments<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        GS_LAUNCH_TRACE(1, true, (size_t)lds_bytes);
+    }
     else if (vm_regs <= 16) GS_LAUNCH_TRACE(16, false, 0);
     else if (vm_regs <= 32) GS_LAUNCH_TRACE(32, false, 0);
     else GS_LAUNCH_TRACE(64, false, 0);
@@ -278,42 +350,8 @@ int gs_air_trace(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, const ui
     int rc = check_program(c, code_host, ninstr, nconsts, vm_regs, registers, nstatic, registers, false);
     if (rc) return rc;
     if (!steps) return gs_fail(c, GS_ERR_ARG, "air_trace: empty");
-    std::vector<hfe> consts(nconsts ? nconsts : 1), vm(vm_regs), row(registers), next(registers);
-    for (uint32_t i = 0; i < nconsts; i++) consts[i] = hf_load(consts_host + GS_ELT * i);
-    std::vector<std::vector<hfe>> statics(nstatic);
-    {
-        const uint8_t *p = static_values_host;
-        for (uint32_t s = 0; s < nstatic; s++) {
-            if (!static_periods_host[s]) return gs_fail(c, GS_ERR_ARG, "air_trace: empty static register");
-            statics[s].resize(static_periods_host[s]);
-            for (uint32_t i = 0; i < static_periods_host[s]; i++, p += GS_ELT) statics[s][i] = hf_load(p);
-        }
-    }
-    if ((rc = gs_trace_begin(c, (uint64_t)registers * steps * GS_ELT))) return rc;
-    hfe *t = (hfe *)c->h_trace;  // registers x steps, row-major like the Matrix the caller gets
-    for (uint32_t r = 0; r < registers; r++) row[r] = hf_load(first_row_host + GS_ELT * r);
-    for (uint64_t i = 0; i < steps; i++) {
-        for (uint32_t r = 0; r < registers; r++) t[(uint64_t)r * steps + i] = row[r];
-        if (i + 1 == steps) break;
-        next = row;
-        for (uint32_t pc = 0; pc < ninstr; pc++) {
-            const uint32_t op = code_host[4 * pc], dst = code_host[4 * pc + 1], a = code_host[4 * pc + 2], b = code_host[4 * pc + 3];
-            switch (op) {
-                case OP_LOADC: vm[dst] = consts[a]; break;
-                case OP_LOADR: vm[dst] = row[a]; break;
-                case OP_LOADS: vm[dst] = statics[a][i % statics[a].size()]; break;
-                case OP_ADDV: vm[dst] = hf_add(vm[a], vm[b]); break;
-                case OP_SUBV: vm[dst] = hf_sub(vm[a], vm[b]); break;
-                case OP_MULV: vm[dst] = hf_mul(vm[a], vm[b]); break;
-                case OP_POW: vm[dst] = hf_pow(vm[a], (hfe)b); break;
-                case OP_POWC: vm[dst] = hf_pow(vm[a], consts[b]); break;
-                default: next[dst] = vm[a]; break;
-            }
-        }
-        row = next;
-    }
-    GS_HIP(c, hipMemcpyAsync(out, c->h_trace, (size_t)registers * steps * GS_ELT, hipMemcpyHostToDevice, c->stream));
-    return gs_trace_end(c);
+    return host_trace(c, code_host, ninstr, nullptr, 0, consts_host, nconsts, vm_regs, registers, static_values_host, static_periods_host, nstatic,
+                      first_row_host, 1, steps, out);
 }
 
 }  // extern "C"

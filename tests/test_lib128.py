@@ -80,7 +80,7 @@ def test_compute_merkle_root_oracle(oracle_backend):
 
 @pytest.mark.gpu
 def test_lib128_hip_equals_oracle(hip_backend, oracle_backend):
-    assert check_hash(hip_backend, 4) == check_hash(oracle_backend, 4)
+    assert check_hash(hip_backend, 16) == check_hash(oracle_backend, 16)      # 16 segments: the device trace generator (8 or fewer run on the host)
     assert check_merkle(hip_backend, 4, 5) == check_merkle(oracle_backend, 4, 5)
 
 

@@ -69,6 +69,15 @@ def check_point_mul(backend):
     assertions2 = assertions + [{'step': 511, 'register': 2, 'value': want2[0]}, {'step': 511, 'register': 3, 'value': want2[1]}]
     data2 = stark2.serialize(stark2.prove(assertions2, inputs2, seeds2))
     assert stark2.verify(assertions2, stark2.parse(data2))
+    if backend.name == 'hip-gfx950':
+        # 16 multiplications: past the host-side threshold, one device thread per multiplication; same rows as the host interpreter
+        air16 = point_mul_air(f, 16)
+        ks = [EC_SCALAR + 7 * i for i in range(16)]
+        raw16 = [[EC_POINT[0]] * 16, [EC_POINT[1]] * 16, [to_bits(k) for k in ks]]
+        inputs16, seeds16 = air16.expandInputs(raw16), air16.segmentSeeds(raw16)
+        t16 = air16.initProvingContext(inputs16, seeds16).generateExecutionTrace().toValues()
+        for i in (0, 5, 15):
+            assert (t16[2][256 * i + 255], t16[3][256 * i + 255]) == ec_multiply(MODULUS_224, EC_POINT, ks[i])
     return [data, data2]
 
 
