@@ -1,14 +1,15 @@
 """genstark_amd — MI355X-native prime-field polynomial + Merkle backend behind genSTARK's prove().
 
 Layout (only what the hot path needs):
-  csrc/        hand-written HIP kernels for gfx950 + the C ABI (include/gstark.h) -> libgstark_hip.so;
+  csrc/        hand-written HIP kernels for gfx950 + the C ABI (include/gstark.h) -> libgstark_hip.so (+ one flavour per other field);
                prover.cc: the native prove() driver above the ABI -> libgstark_prover.so
   _abi.py      ctypes binding of the C ABI (loads the HIP library; no CPU fallback)
   field.py     galois FiniteField / Vector / Matrix surface       (device-resident data)
   merkle.py    merkle Hash / MerkleTree surface
   air.py       air-assembly AirModule / ProvingContext surface for the MiMC AIR (dedicated kernels)
   air_generic.py  the same surface for AIRs given as expressions (register-machine programs, secret registers, segments);
-               rescue.py, poseidon.py: the example hash AIRs; lib128.py: the exports of assembly/lib128.aa
+               rescue.py, poseidon.py: the example hash AIRs; lib128.py, lib224.py: the exports of assembly/lib128.aa / lib224.aa;
+               pointmul.py: examples/elliptic/pointmul.aa
   native.py    binding of the native prove() driver (same bytes as stark.py's prove + serialize)
   pipeline.py  several proofs in flight on one GPU (throughput mode)
   distributed.py  ONE proof across the GPUs of a node (distributed vectors under the unchanged prover); sharded.py: commitments
