@@ -17,10 +17,12 @@ HIP_LIB_PATH = os.path.join(_HERE, 'csrc', 'libgstark_hip.so')
 MODULUS_128 = 2**128 - 9 * 2**32 + 1
 MODULUS_64 = 2**64 - 21 * 2**30 + 1        # examples/rescue/hash2x64.ts:10
 MODULUS_32 = 2**32 - 3 * 2**25 + 1         # examples/demo/fibonacci.ts:14, README.md:23 (Foo)
+MODULUS_17 = 96769                          # examples/demo/staticVariables.ts:11
 MODULUS_256 = 2**256 - 351 * 2**32 + 1      # examples/mimc/mimc256.ts:13
 MODULUS_224 = 2**224 - 2**96 + 1            # assembly/lib224.aa:3
 HIP_LIB_PATHS = {MODULUS_128: HIP_LIB_PATH, MODULUS_64: os.path.join(_HERE, 'csrc', 'libgstark_hip_q64.so'),
                  MODULUS_32: os.path.join(_HERE, 'csrc', 'libgstark_hip_q32.so'),
+                 MODULUS_17: os.path.join(_HERE, 'csrc', 'libgstark_hip_q17.so'),
                  MODULUS_256: os.path.join(_HERE, 'csrc', 'libgstark_hip_p256.so'),
                  MODULUS_224: os.path.join(_HERE, 'csrc', 'libgstark_hip_p224.so')}
 

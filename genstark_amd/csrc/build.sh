@@ -26,6 +26,7 @@ build_flavour() {   # <object dir> <output> <extra flags>
 build_flavour build libgstark_hip.so "" &
 build_flavour build_q64 libgstark_hip_q64.so "-DGS_SMALL_Q=18446744051160973313ull" &
 build_flavour build_q32 libgstark_hip_q32.so "-DGS_SMALL_Q=4194304001ull" &
+build_flavour build_q17 libgstark_hip_q17.so "-DGS_SMALL_Q=96769ull" &        # examples/demo/staticVariables.ts:11
 # ... and the two multi-limb fields (gf_wide.cuh, 32-byte elements): 2^256 - 351*2^32 + 1 (mimc/mimc256.ts), 2^224 - 2^96 + 1 (lib224.aa)
 build_flavour build_p256 libgstark_hip_p256.so "-DGS_WIDE_BITS=256" &
 build_flavour build_p224 libgstark_hip_p224.so "-DGS_WIDE_BITS=224" &

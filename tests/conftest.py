@@ -18,7 +18,7 @@ def pytest_configure(config):
 
 def _build_oracle():
     src = [os.path.join(ROOT, 'oracle', f) for f in ('oracle_abi.c', 'hashes.c', 'gf128.h', 'gf_small.h', 'gf_wide.h', 'hashes.h')]
-    libs = [ORACLE_LIB] + [os.path.join(ROOT, 'oracle', f'liboracle_{n}.so') for n in ('q64', 'q32', 'p256', 'p224')]
+    libs = [ORACLE_LIB] + [os.path.join(ROOT, 'oracle', f'liboracle_{n}.so') for n in ('q64', 'q32', 'q17', 'p256', 'p224')]
     if any(not os.path.exists(l) or any(os.path.getmtime(s) > os.path.getmtime(l) for s in src) for l in libs):
         subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), '-s'])
     return ORACLE_LIB

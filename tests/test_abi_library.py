@@ -58,7 +58,7 @@ def test_small_field_device_header_on_host(tmp_path, rng):
                    '  for (uint64_t i = 0; i < n; i++) { fe x = fe_from(a[i]), y = fe_from(b[i]);\n'
                    '    add[i] = fe_u64(fe_add(x, y)); sub[i] = fe_u64(fe_sub(x, y)); mul[i] = fe_u64(fe_mul(x, y)); inv[i] = fe_u64(fe_inv(x)); } }\n'
                    % os.path.join(ROOT, 'genstark_amd', 'csrc', 'gf_small.cuh'))
-    for q in (_abi.MODULUS_64, _abi.MODULUS_32):
+    for q in (_abi.MODULUS_64, _abi.MODULUS_32, _abi.MODULUS_17):
         so = str(tmp_path / f'h_{q}.so')
         subprocess.check_call(['g++', '-O2', '-shared', '-fPIC', f'-DGS_SMALL_Q={q}ull', '-o', so, str(src)])
         lib = ctypes.CDLL(so)
