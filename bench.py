@@ -307,8 +307,9 @@ def main():
         if out is not None:
             out['sharded'] = result
             print(json.dumps(out), flush=True)
-        if th.is_alive() or 'error' in result:
-            os._exit(0)                                                         # a rank may be stuck in a collective
+        sys.stdout.flush()
+        os._exit(0)      # the line is out; a rank may be stuck in (or may have bailed out of) a collective of the extra leg, so no
+                         # rank waits for the others in a final barrier
     elif out is not None:
         print(json.dumps(out), flush=True)
         out = None
