@@ -2,4 +2,4 @@
 // one device context per process, shared by the galois / merkle / air-assembly replacements
 const { createPrimeField, MODULUS } = require('./galois');
 let field;
-module.exports = { defaultField() { return field || (field = createPrimeField(MODULUS)); } };
+module.exports = { defaultField(modulus) { return field || (field = createPrimeField(modulus === undefined ? MODULUS : modulus)); } };

@@ -7,28 +7,43 @@ const crypto = require('crypto');
 const path = require('path');
 
 const MODULUS = 2n ** 128n - 9n * 2n ** 32n + 1n;
-const ELEMENT_SIZE = 16;
+// one build flavour of the library per field (genstark_amd/csrc/build.sh); a process works in ONE field, like the reference's
+// example scripts: the first createPrimeField(modulus) picks the library, ELEMENT_SIZE / LOADED_MODULUS follow from it
+const LIBRARIES = new Map([
+    [MODULUS, 'libgstark_hip.so'],
+    [2n ** 64n - 21n * 2n ** 30n + 1n, 'libgstark_hip_q64.so'], [2n ** 32n - 3n * 2n ** 25n + 1n, 'libgstark_hip_q32.so'], [96769n, 'libgstark_hip_q17.so'],
+    [2n ** 256n - 351n * 2n ** 32n + 1n, 'libgstark_hip_p256.so'], [2n ** 224n - 2n ** 96n + 1n, 'libgstark_hip_p224.so'],
+]);
+let ELEMENT_SIZE = 16;
+let LOADED_MODULUS = null;
 
 let addon = null;
-function native() {
+function native(modulus) {
     if (!addon) {
-        addon = require(path.join(__dirname, '..', 'napi', 'gstark_napi.node'));
-        const lib = process.env.GSTARK_LIB || path.join(__dirname, '..', 'genstark_amd', 'csrc', 'libgstark_hip.so');
-        const name = addon.load(lib);
+        const wanted = modulus === undefined ? MODULUS : BigInt(modulus);
+        if (!process.env.GSTARK_LIB && !LIBRARIES.has(wanted)) throw new TypeError(`no build of the library for the field of ${wanted} elements`);
+        const lib = process.env.GSTARK_LIB || path.join(__dirname, '..', 'genstark_amd', 'csrc', LIBRARIES.get(wanted));
+        const a = require(path.join(__dirname, '..', 'napi', 'gstark_napi.node'));
+        const name = a.load(lib);
         if (name !== 'hip-gfx950' && process.env.GSTARK_ALLOW_TEST_DOUBLE !== '1') {
             throw new Error(`refusing backend ${name}: the product path runs on hip-gfx950 only (no CPU fallback)`);
         }
+        const info = a.fieldInfo();
+        ELEMENT_SIZE = info.elementSize;
+        LOADED_MODULUS = fromLe(info.modulus, 0, info.elementSize);
+        addon = a;
     }
     return addon;
 }
 
-function le(v) {  // bigint -> 16-byte little-endian Buffer (lib/utils/serialization.ts:140-146 layout)
+function le(v) {  // bigint -> elementSize-byte little-endian Buffer (lib/utils/serialization.ts:140-146 layout)
     const b = Buffer.alloc(ELEMENT_SIZE);
     let x = BigInt(v);
     for (let i = 0; i < ELEMENT_SIZE; i++) { b[i] = Number(x & 0xFFn); x >>= 8n; }
     return b;
 }
-function fromLe(buf, off = 0, size = ELEMENT_SIZE) {
+function fromLe(buf, off = 0, size) {
+    if (size === undefined) size = ELEMENT_SIZE;
     let v = 0n;
     for (let i = size - 1; i >= 0; i--) v = (v << 8n) | BigInt(buf[off + i]);
     return v;
@@ -51,7 +66,8 @@ class DeviceBuffer {
 }
 
 class Vector {
-    constructor(field, length, owner, offset = 0n, elementSize = ELEMENT_SIZE) {
+    constructor(field, length, owner, offset = 0n, elementSize) {
+        if (elementSize === undefined) elementSize = ELEMENT_SIZE;
         this.field = field; this.length = length; this.elementSize = elementSize;
         this.owner = owner || new DeviceBuffer(field, length * elementSize);
         this.offset = offset;
@@ -120,8 +136,9 @@ class Matrix {
 
 class PrimeField {
     constructor(modulus, options) {
-        if (BigInt(modulus) !== MODULUS) throw new TypeError('this build accelerates the 128-bit field 2^128 - 9*2^32 + 1 only');
-        this.modulus = MODULUS; this.elementSize = ELEMENT_SIZE; this.isOptimized = true;
+        native(modulus);
+        if (BigInt(modulus) !== LOADED_MODULUS) throw new TypeError(`the loaded library computes in the field of ${LOADED_MODULUS} elements, not ${modulus} (one field per process)`);
+        this.modulus = LOADED_MODULUS; this.elementSize = ELEMENT_SIZE; this.isOptimized = true;
         this.zero = 0n; this.one = 1n;
         this.ctx = (options && options.ctx) || native().ctxCreate((options && options.device) || 0);
     }
@@ -201,7 +218,7 @@ class PrimeField {
         if (e < 0n) { a = this.invVectorElements(a); e = -e; }
         const out = new Vector(this, a.length); native().call('gs_vec_exp', this.ctx, a.ptr, le(e), a.length, out.ptr); return out;
     }
-    combineVectors(a, b) { const out = Buffer.alloc(16); native().call('gs_combine', this.ctx, a.ptr, b.ptr, a.length, out); return fromLe(out); }
+    combineVectors(a, b) { const out = Buffer.alloc(ELEMENT_SIZE); native().call('gs_combine', this.ctx, a.ptr, b.ptr, a.length, out); return fromLe(out); }
     mulMatrixByVector(m, v) {   // examples/poseidon/utils.ts:45
         const out = [];
         for (let r = 0; r < m.rowCount; r++) out.push(this.combineVectors(new Vector(this, m.colCount, m.owner, m.offset + BigInt(r * m.colCount * ELEMENT_SIZE)), v));
@@ -254,7 +271,7 @@ class PrimeField {
         native().call('gs_interpolate_roots', this.ctx, ys.ptr, isM ? ys.rowCount : 1, le(this._omegaOf(roots)), n, out.ptr);
         return out;
     }
-    evalPolyAt(poly, x) { const out = Buffer.alloc(16); native().call('gs_eval_poly_at', this.ctx, poly.ptr, poly.length, le(this.mod(x)), out); return fromLe(out); }
+    evalPolyAt(poly, x) { const out = Buffer.alloc(ELEMENT_SIZE); native().call('gs_eval_poly_at', this.ctx, poly.ptr, poly.length, le(this.mod(x)), out); return fromLe(out); }
     mulPolys(a, b) {
         // tiny operands (BoundaryConstraints.ts:30) on the host; larger ones through the device NTT
         const la = a.length, lb = b.length;
@@ -271,16 +288,16 @@ class PrimeField {
     padPoly(v, length) {
         if (v.length === length) return v;
         const out = new Vector(this, length);
-        native().call('gs_copy', this.ctx, out.ptr, v.ptr, v.length * 16);
-        const zeros = Buffer.alloc((length - v.length) * 16);
-        native().call('gs_upload', this.ctx, out.ptr + BigInt(v.length * 16), zeros, zeros.length);
+        native().call('gs_copy', this.ctx, out.ptr, v.ptr, v.length * ELEMENT_SIZE);
+        const zeros = Buffer.alloc((length - v.length) * ELEMENT_SIZE);
+        native().call('gs_upload', this.ctx, out.ptr + BigInt(v.length * ELEMENT_SIZE), zeros, zeros.length);
         return out;
     }
     addPolys(a, b) { const n = Math.max(a.length, b.length); return this.addVectorElements(this.padPoly(a, n), this.padPoly(b, n)); }
     subPolys(a, b) { const n = Math.max(a.length, b.length); return this.subVectorElements(this.padPoly(a, n), this.padPoly(b, n)); }
     mulPolyByConstant(a, c) { return this.mulVectorElements(a, this.mod(c)); }
     interpolate(xs, ys) {
-        const n = xs.length, out = Buffer.alloc(16 * n);
+        const n = xs.length, out = Buffer.alloc(ELEMENT_SIZE * n);
         native().call('gs_small_interpolate', xs.toBuffer(), ys.toBuffer(), n, out);
         const v = new Vector(this, n); native().call('gs_upload', this.ctx, v.ptr, out, out.length); return v;
     }
@@ -295,4 +312,4 @@ class PrimeField {
 
 function createPrimeField(modulus, options) { return new PrimeField(modulus, options); }
 
-module.exports = { createPrimeField, PrimeField, Vector, Matrix, MODULUS, native, le, fromLe, sha256 };
+module.exports = { createPrimeField, PrimeField, Vector, Matrix, MODULUS, LIBRARIES, native, le, fromLe, sha256 };

@@ -26,7 +26,7 @@ class Hash {
             src = new Vector(this.field, values.length, undefined, 0n, 1);
             native().call('gs_upload', this.field.ctx, src.ptr, values, values.length);
             bytes = values.length;
-        } else bytes = values.rowCount !== undefined ? values.rowCount * values.colCount * 16 : values.byteLength;
+        } else bytes = values.rowCount !== undefined ? values.rowCount * values.colCount * values.elementSize : values.byteLength;
         const count = bytes / valueSize, out = new Vector(this.field, count, undefined, 0n, DIGEST);
         native().call('gs_hash_digest_values', this.field.ctx, this.alg, src.ptr, valueSize, count, out.ptr);
         return out;

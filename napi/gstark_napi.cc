@@ -215,6 +215,27 @@ napi_value Load(napi_env env, napi_callback_info info) {
     return out;
 }
 
+// fieldInfo(): { elementSize, modulus: Buffer } of the loaded library (gs_element_size / gs_field_modulus)
+napi_value FieldInfo(napi_env env, napi_callback_info info) {
+    if (!g_lib) { napi_throw_error(env, nullptr, "no library loaded"); return nullptr; }
+    typedef int (*sizefn)(void);
+    typedef int (*modfn)(uint8_t *);
+    sizefn sf = (sizefn)dlsym(g_lib, "gs_element_size");
+    modfn mf = (modfn)dlsym(g_lib, "gs_field_modulus");
+    if (!sf || !mf) { napi_throw_error(env, nullptr, "not a gstark library"); return nullptr; }
+    const int es = sf();
+    uint8_t mod[64] = {0};
+    if (es <= 0 || es > 64 || mf(mod) != GS_OK) { napi_throw_error(env, nullptr, "gs_field_modulus failed"); return nullptr; }
+    napi_value out, v;
+    NAPI_OK(env, napi_create_object(env, &out));
+    NAPI_OK(env, napi_create_uint32(env, (uint32_t)es, &v));
+    NAPI_OK(env, napi_set_named_property(env, out, "elementSize", v));
+    void *copy;
+    NAPI_OK(env, napi_create_buffer_copy(env, (size_t)es, mod, &copy, &v));
+    NAPI_OK(env, napi_set_named_property(env, out, "modulus", v));
+    return out;
+}
+
 napi_value CtxCreate(napi_env env, napi_callback_info info) {
     size_t argc = 1;
     napi_value argv[1];
@@ -391,7 +412,7 @@ napi_value ProveMimcSerialized(napi_env env, napi_callback_info info) {
 
 napi_value Init(napi_env env, napi_value exports) {
     const struct { const char *name; napi_callback cb; } fns[] = {
-        {"load", Load}, {"ctxCreate", CtxCreate}, {"ctxDestroy", CtxDestroy}, {"alloc", Alloc}, {"call", Call},
+        {"load", Load}, {"fieldInfo", FieldInfo}, {"ctxCreate", CtxCreate}, {"ctxDestroy", CtxDestroy}, {"alloc", Alloc}, {"call", Call},
         {"merkleProveBatch", MerkleProveBatch}, {"proveMimcSerialized", ProveMimcSerialized},
     };
     for (auto &f : fns) {

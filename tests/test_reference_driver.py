@@ -69,3 +69,39 @@ def test_reference_stark_js_runs_live_on_the_drop_in_modules(oracle_backend, tmp
         # the native driver (csrc/prover.cc), called through the same N-API addon in the same process, gives the bytes the
         # reference's own Stark.js produced
         assert rec['nativeDriverEqualsReference'] is True
+
+
+@pytest.mark.skipif(not (os.path.isdir(REF_LIB) and shutil.which('node') and os.path.exists('/usr/include/node/node_api.h')),
+                    reason='needs the genSTARK checkout and node (build container only)')
+@pytest.mark.parametrize('name', ['p256', 'q64'])
+def test_reference_stark_js_runs_live_over_another_field(name, tmp_path):
+    """The reference's own Stark.js / components / Serializer over the 32-byte elements of the 256-bit flavour (and the 16-byte
+    ones of the 64-bit flavour): MiMC over that field through the drop-in modules gives the bytes the Python mirror produces on
+    the same library (`elementSize` is what lib/Stark.ts:260,285,299 and lib/Serializer.ts read from the field object)."""
+    from genstark_amd._abi import MODULUS_64, MODULUS_256, Backend
+    from genstark_amd.air import MimcAir, runMimc
+    from genstark_amd.field import PrimeField
+    from genstark_amd.stark import Stark
+    from conftest import _build_oracle
+    _build_oracle()
+    subprocess.check_call(['bash', os.path.join(ROOT, 'napi', 'build.sh')])
+    modulus = {'p256': MODULUS_256, 'q64': MODULUS_64}[name]
+    lib = os.path.join(ROOT, 'oracle', f'liboracle_{name}.so')
+    f = PrimeField(backend=Backend(lib_path=lib, allow_test_double=True))
+    steps, opts = 128, {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 40, 'friQueryCount': 24}
+    air = MimcAir(steps, 16, f)
+    control = runMimc(f, steps, air.roundConstants, 3)
+    assertions = [{'step': 0, 'register': 0, 'value': 3}, {'step': steps - 1, 'register': 0, 'value': control[-1]}]
+    stark = Stark(air, opts)
+    want = stark.serialize(stark.prove(assertions, [], [3]))
+    case = {'name': f'mimc_{name}', 'steps': steps, 'extension_factor': 16, 'exe_query_count': 40, 'fri_query_count': 24, 'hash_algorithm': 'blake2s256',
+            'seed': 3, 'modulus': str(modulus), 'assertions': [dict(a, value=str(a['value'])) for a in assertions]}
+    cin, cout = tmp_path / 'cases.json', tmp_path / 'out.json'
+    cin.write_text(json.dumps([case]))
+    env = dict(os.environ, NODE_PATH=os.path.join(ROOT, 'js', 'shims'), GSTARK_LIB=lib, GSTARK_ALLOW_TEST_DOUBLE='1')
+    r = subprocess.run(['node', os.path.join(HERE, 'golden', 'run_reference_stark.js'), REF_LIB, str(cin), str(cout)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = json.loads(cout.read_text())[0]
+    assert rec['verified'] and rec['tamperRejected']
+    assert rec['proofHex'] == want.hex()
