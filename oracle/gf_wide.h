@@ -4,7 +4,9 @@
  * -DGS_WIDE_BITS=224: 2^224 - 2^96 + 1, assembly/lib224.aa:3): the checker of the wide build flavours of the HIP library
  * (genstark_amd/csrc/gf_wide.cuh).  Elements are 32 bytes little-endian.
  *
- * The mathematical definition on C23 bit-precise integers — (a * b) % p in 512 bits — nothing shared with the device code.
+ * The mathematical definition on C23 bit-precise integers — the 512-bit product a * b reduced with 2^BITS == 2^BITS - p until it
+ * fits, then by subtraction (a generic 512-bit `%` gives the same values ten times slower: -DGS_ORACLE_PLAIN_MOD selects it) —
+ * nothing shared with the device code.
  * gcc 11 has no _BitInt: this flavour is compiled with the ROCm clang (oracle/Makefile).
  * parity unpinned (see gf128.h).
  */
@@ -37,13 +39,23 @@ static inline fe fe_load(const uint8_t *b) {
 static inline void fe_store(uint8_t *b, fe a) {
     for (int i = 0; i < 32; i++) { b[i] = (uint8_t)(a & 0xFF); a >>= 8; }
 }
-static inline fe fe_add(fe a, fe b) { return (fe)(((fe2)a + (fe2)b) % (fe2)fe_p()); }
-static inline fe fe_sub(fe a, fe b) { return (fe)(((fe2)a + (fe2)fe_p() - (fe2)(b % fe_p())) % (fe2)fe_p()); }
-static inline fe fe_neg(fe a) { return a % fe_p() ? fe_p() - a % fe_p() : 0; }
-static inline fe fe_mul(fe a, fe b) { return (fe)(((fe2)a * (fe2)b) % (fe2)fe_p()); }
+static inline fe fe_mod(fe2 t) {
+#ifdef GS_ORACLE_PLAIN_MOD
+    return (fe)(t % (fe2)fe_p());
+#else
+    const fe2 one = 1, c = (one << GS_WIDE_BITS) - (fe2)fe_p(), mask = (one << GS_WIDE_BITS) - 1;
+    while (t >> GS_WIDE_BITS) t = (t >> GS_WIDE_BITS) * c + (t & mask);      /* 2^BITS == c (mod p) */
+    while (t >= (fe2)fe_p()) t -= (fe2)fe_p();
+    return (fe)t;
+#endif
+}
+static inline fe fe_add(fe a, fe b) { return fe_mod((fe2)a + (fe2)b); }
+static inline fe fe_sub(fe a, fe b) { return fe_mod((fe2)a + (fe2)fe_p() - (fe2)fe_mod(b)); }
+static inline fe fe_neg(fe a) { return fe_mod(a) ? fe_p() - fe_mod(a) : 0; }
+static inline fe fe_mul(fe a, fe b) { return fe_mod((fe2)a * (fe2)b); }
 static inline fe fe_exp(fe b, fexp e) {
     fe r = 1;
-    b %= fe_p();
+    b = fe_mod(b);
     while (e) {
         if (e & 1) r = fe_mul(r, b);
         b = fe_mul(b, b);
@@ -51,7 +63,7 @@ static inline fe fe_exp(fe b, fexp e) {
     }
     return r;
 }
-static inline fe fe_inv(fe a) { return a % fe_p() ? fe_exp(a, fe_p() - 2) : 0; }
+static inline fe fe_inv(fe a) { return fe_mod(a) ? fe_exp(a, fe_p() - 2) : 0; }
 static inline fe fe_div(fe a, fe b) { return fe_mul(a, fe_inv(b)); }
 
 #endif

@@ -1,0 +1,220 @@
+"""AirAssembly source -> STARK (`instantiate(source, component, options)`, index.ts:18-33; genstark_amd/airassembly.py).
+* Own fixtures (tests/golden/aa/*.aa, written for these tests): a cube chain whose proofs must equal the dedicated MiMC path byte
+  for byte, and a module using every input-register feature (secret / public, peerof / childof, steps, shift, mask, cycles,
+  matrix product, division) checked against a plain Python model of the same recurrence.
+* In the build container the loader is also run on the REFERENCE's own sources (assembly/lib128.aa, assembly/lib224.aa,
+  examples/elliptic/pointmul.aa, the inline module of examples/mimc/mimc128Assembly.ts) and must give, byte for byte, the proofs
+  of this repository's hand transcriptions of those files (lib128.py, lib224.py, pointmul.py) — which in turn reproduce the
+  reference examples' known answers."""
+import os
+import re
+
+import pytest
+
+import genstark_amd as ga
+from conftest import ROOT
+from genstark_amd import airassembly, lib128, lib224
+from genstark_amd._abi import GstarkError
+from genstark_amd.errors import StarkError
+from genstark_amd.field import PrimeField
+from genstark_amd.hostfield import HostField
+from genstark_amd.pointmul import point_mul_air, to_bits
+from genstark_amd.stark import Stark
+
+AA = os.path.join(ROOT, 'tests', 'golden', 'aa')
+REF = '/root/reference'
+needs_reference = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'assembly')), reason='needs the genSTARK checkout (build container only)')
+MIMC_OPTS = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 48, 'friQueryCount': 24}
+
+
+def without_shapes(stark, proof):
+    """The hand transcriptions are fixed-shape GenericAirs (no input shapes in the proof); everything else must match."""
+    return stark.serialize(dict(proof, iShapes=[]))
+
+
+# ---- own fixtures ---------------------------------------------------------------------------------------------------------------------
+def check_cube_chain(backend):
+    f = PrimeField(backend=backend)
+    stark = airassembly.instantiate(os.path.join(AA, 'cube_chain.aa'), 'chain', MIMC_OPTS, field=f)
+    assert stark.air.constraintDegrees == [3] and stark.air.secretInputCount == 0
+    dedicated = ga.instantiateMimc(64, MIMC_OPTS, backend=backend)
+    control = ga.runMimc(f, 64, dedicated.air.roundConstants, 3)
+    assertions = [{'step': 0, 'register': 0, 'value': 3}, {'step': 63, 'register': 0, 'value': control[-1]}]
+    data = stark.serialize(stark.prove(assertions, [], [3]))
+    assert data == dedicated.serialize(dedicated.prove(assertions, [], [3]))          # the same statement, the same bytes
+    assert stark.verify(assertions, stark.parse(data))
+    return data
+
+
+def ledger_model(p, balances, factors, deposits):
+    rows = []
+    for b, fac, deps in zip(balances, factors, deposits):
+        r = [b % p, fac % p, 0]
+        for t in range(2 * len(deps)):
+            rows.append(r)
+            step = len(rows) - 1
+            dep = deps[min((t + 1) // 2, len(deps) - 1)]          # (shift -1): a step sees the value of the step after it
+            n0 = (r[0] + dep * (1, 2, 3, 4)[step % 4]) % p
+            n1 = (r[1] * fac + pow(2, step % 8, p)) % p
+            s = (n0 + 2 * n1) % p
+            r = [n0, n1, s * s * pow(3, p - 2, p) % p]
+    return rows
+
+
+def check_ledger(backend, runs):
+    f = PrimeField(backend=backend)
+    p = f.modulus
+    stark = airassembly.instantiate(os.path.join(AA, 'ledger.aa'), 'default', {'hashAlgorithm': 'sha256', 'exeQueryCount': 24, 'friQueryCount': 12}, field=f)
+    air = stark.air
+    assert air.constraintDegrees == [3, 3, 5] and air.extensionFactor == 16 and air.secretInputCount == 2
+    balances = [100 + 7 * i for i in range(runs)]
+    factors = [3 + i for i in range(runs)]
+    deposits = [[5 + i + 2 * j for j in range(4)] for i in range(runs)]
+    inputs = [balances, factors, deposits]
+    model = ledger_model(p, balances, factors, deposits)
+    trace = air.initProvingContext(inputs).generateExecutionTrace().toValues()
+    assert [list(r) for r in zip(*trace)] == model
+    last = 8 * runs - 1
+    assertions = [{'step': 0, 'register': 0, 'value': balances[0]}, {'step': last, 'register': 2, 'value': model[last][2]},
+                  {'step': last, 'register': 0, 'value': model[last][0]}]
+    proof = stark.prove(assertions, inputs)
+    assert proof['iShapes'] == [[runs], [runs], [runs, 4]]
+    data = stark.serialize(proof)
+    assert len(data) == stark.sizeOf(proof)
+    assert stark.verify(assertions, stark.parse(data), [deposits])                       # the verifier supplies the PUBLIC register
+    hv = airassembly.instantiate(os.path.join(AA, 'ledger.aa'), 'default', {'hashAlgorithm': 'sha256', 'exeQueryCount': 24, 'friQueryCount': 12},
+                                 field=HostField(p))
+    assert hv.verify(assertions, hv.parse(data), [deposits])                             # ... also without a GPU
+    other = [list(d) for d in deposits]
+    other[0][1] += 1
+    with pytest.raises(StarkError):
+        stark.verify(assertions, stark.parse(data), [other])
+    with pytest.raises(StarkError):
+        stark.verify([dict(assertions[1], value=model[last][2] ^ 1)], stark.parse(data), [deposits])
+    return data
+
+
+def test_cube_chain_equals_dedicated_mimc_oracle(oracle_backend):
+    check_cube_chain(oracle_backend)
+
+
+@pytest.mark.parametrize('runs', [2, 4])
+def test_ledger_oracle(oracle_backend, runs):
+    check_ledger(oracle_backend, runs)
+
+
+def test_source_errors(oracle_backend):
+    f = PrimeField(backend=oracle_backend)
+    src = open(os.path.join(AA, 'ledger.aa')).read()
+    with pytest.raises(GstarkError, match='not exported'):
+        airassembly.AssemblyAir(src, 'nope', None, f)
+    with pytest.raises(GstarkError, match='unknown operation'):
+        airassembly.AssemblyAir(src.replace('(exp (load.local $sum) (scalar 2))', '(frobnicate (load.local $sum))'), 'default', None, f)
+    with pytest.raises(GstarkError, match='constraints declared'):
+        airassembly.AssemblyAir(src.replace('(constraints 3)', '(constraints 4)'), 'default', None, f)
+    air = airassembly.AssemblyAir(src, 'default', None, f)
+    with pytest.raises(GstarkError, match='one entry'):
+        air.initProvingContext([[1], [2]])
+    with pytest.raises(GstarkError, match='ragged'):
+        air.initProvingContext([[1, 2], [3, 4], [[1, 2, 3, 4], [1, 2]]])
+    with pytest.raises(GstarkError, match='peer'):
+        air.initProvingContext([[1, 2], [3], [[1, 2, 3, 4], [1, 2, 3, 4]]])
+    with pytest.raises(GstarkError, match='power of 2'):
+        air.initProvingContext([[1, 2, 3], [3, 4, 5], [[1, 2, 3, 4]] * 3])
+    with pytest.raises(GstarkError, match='field'):
+        airassembly.AssemblyAir(src.replace('340282366920938463463374607393113505793', '96769'), 'default', None, f)
+    assert airassembly.parse('(a (b 1) # comment\n c)') == [['a', ['b', '1'], 'c']]
+
+
+@pytest.mark.gpu
+def test_airassembly_hip_equals_oracle(hip_backend, oracle_backend):
+    assert check_cube_chain(hip_backend) == check_cube_chain(oracle_backend)
+    assert check_ledger(hip_backend, 4) == check_ledger(oracle_backend, 4)
+    assert check_ledger(hip_backend, 16) == check_ledger(oracle_backend, 16)             # 16 runs: device-side trace segments
+
+
+# ---- the reference's own sources (build container) ---------------------------------------------------------------------------------------
+LIB_OPTS = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 32, 'exeQueryCount': 44, 'friQueryCount': 20}
+
+
+@needs_reference
+def test_reference_lib128_source_equals_hand_transcription(oracle_backend):
+    from test_lib128 import merkle_case
+    f = PrimeField(backend=oracle_backend)
+    src = open(os.path.join(REF, 'assembly', 'lib128.aa')).read()
+    hashes = 2
+    raw = [[42 + 10 * s for s in range(hashes)], [43 + s for s in range(hashes)], [44] * hashes, [45 + s * s for s in range(hashes)]]
+    air = lib128.compute_poseidon_hash_air(f, hashes)
+    hand = Stark(air, LIB_OPTS)
+    assertions = []
+    for s in range(hashes):
+        d = lib128.poseidon_hash(f, [c[s] for c in raw])
+        assertions += [{'step': 64 * s + 63, 'register': 0, 'value': d[0]}, {'step': 64 * s + 63, 'register': 1, 'value': d[1]}]
+    want = without_shapes(hand, hand.prove(assertions, air.expandInputs(raw), air.segmentSeeds(raw)))
+    stark = airassembly.instantiate(src, 'ComputePoseidonHash', LIB_OPTS, field=f)
+    assert stark.air.constraintDegrees == [7] * 6
+    proof = stark.prove(assertions, raw)                                                  # lib128.ts:61-64: prove(assertions, inputs)
+    assert without_shapes(stark, proof) == want and proof['iShapes'] == [[2]] * 4
+    assert stark.verify(assertions, stark.parse(stark.serialize(proof)))
+    # ComputeMerkleRoot with its public index-bit register (lib128.ts:97-112)
+    tree, leaf, nodes, bits = merkle_case(f, 4, 5)
+    air = lib128.compute_merkle_root_air(f, bits)
+    inputs, first = lib128.merkle_inputs(f, leaf, nodes)
+    hand = Stark(air, LIB_OPTS)
+    assertions = [{'step': 255, 'register': 0, 'value': tree.root[0]}, {'step': 255, 'register': 1, 'value': tree.root[1]}]
+    want = without_shapes(hand, hand.prove(assertions, inputs, first))
+    stark = airassembly.instantiate(src, 'ComputeMerkleRoot', LIB_OPTS, field=f)
+    raw = [[leaf[0]], [leaf[1]], [[n[0] for n in nodes]], [[n[1] for n in nodes]], [bits]]
+    proof = stark.prove(assertions, raw)
+    assert without_shapes(stark, proof) == want
+    data = stark.serialize(proof)
+    assert stark.verify(assertions, stark.parse(data), [[bits]])                         # lib128.ts:112: verify(assertions, proof, [[indexBits]])
+    with pytest.raises(StarkError):
+        stark.verify(assertions, stark.parse(data), [[[bits[0], 1 - bits[1]] + bits[2:]]])
+    assert airassembly.AssemblyAir(src, 'ComputeMerkleUpdate', 32, f).constraintDegrees == [8] * 24 + [2]
+
+
+@needs_reference
+def test_reference_mimc_assembly_source_equals_dedicated_path(oracle_backend):
+    f = PrimeField(backend=oracle_backend)
+    ts = open(os.path.join(REF, 'examples', 'mimc', 'mimc128Assembly.ts')).read()
+    src = re.search(r'Buffer\.from\(`(.*?)`', ts, re.S).group(1).replace('${steps}', '64').replace('${constantCount}', '64')
+    stark = airassembly.instantiate(src, 'mimc', MIMC_OPTS, field=f)
+    dedicated = ga.instantiateMimc(64, MIMC_OPTS, backend=oracle_backend)
+    control = ga.runMimc(f, 64, dedicated.air.roundConstants, 3)
+    assertions = [{'step': 0, 'register': 0, 'value': 3}, {'step': 63, 'register': 0, 'value': control[-1]}]
+    assert stark.serialize(stark.prove(assertions, [], [3])) == dedicated.serialize(dedicated.prove(assertions, [], [3]))
+
+
+@needs_reference
+def test_reference_224_bit_sources_equal_hand_transcriptions():
+    from test_lib224 import SIG_G, SIG_H, SIG_P, SIG_R, SIG_S
+    from test_wide_fields import EC_OPTIONS, EC_POINT, EC_PRODUCT, EC_SCALAR, oracle_for
+    f = PrimeField(backend=oracle_for('p224'))
+    air = point_mul_air(f)
+    raw = [[EC_POINT[0]], [EC_POINT[1]], [to_bits(EC_SCALAR)]]
+    assertions = [{'step': 255, 'register': 2, 'value': EC_PRODUCT[0]}, {'step': 255, 'register': 3, 'value': EC_PRODUCT[1]}]     # pointMul.ts:33-36
+    hand = Stark(air, EC_OPTIONS)
+    want = without_shapes(hand, hand.prove(assertions, air.expandInputs(raw), air.segmentSeeds(raw)))
+    stark = airassembly.instantiate(os.path.join(REF, 'examples', 'elliptic', 'pointmul.aa'), 'default', EC_OPTIONS, field=f)
+    proof = stark.prove(assertions, raw)                                                  # pointMul.ts:39
+    assert without_shapes(stark, proof) == want and proof['iShapes'] == [[1], [1], [1, 256]]
+    src = open(os.path.join(REF, 'assembly', 'lib224.aa')).read()
+    degrees = {c: airassembly.AssemblyAir(src, c, 32, f).constraintDegrees for c in ('ComputePoseidonHash', 'ComputeMerkleRoot', 'ComputeMerkleUpdate', 'VerifySchnorrSignature')}
+    assert degrees == {'ComputePoseidonHash': [7] * 3, 'ComputeMerkleRoot': [8] * 6, 'ComputeMerkleUpdate': [8] * 12 + [2], 'VerifySchnorrSignature': lib224.SCHNORR_DEGREES}
+    # VerifySchnorrSignature: the same trace and the same constraint values as the hand transcription (a full proof over the
+    # _BitInt oracle takes half a minute; the GPU suite proves it: test_lib224.py)
+    import random
+    rng = random.Random(9)
+    hand = lib224.verify_schnorr_signature_air(f)
+    raw = [[SIG_G[0]], [SIG_G[1]], [to_bits(SIG_S)], [SIG_P[0]], [SIG_P[1]], [to_bits(SIG_H)], [SIG_R[0]], [SIG_R[1]]]
+    loaded = airassembly.AssemblyAir(src, 'VerifySchnorrSignature', 16, f)
+    context = loaded.initProvingContext(raw)
+    trace = context.generateExecutionTrace().toValues()
+    assert trace == hand.initProvingContext(hand.expandInputs(raw), hand.segmentSeeds(raw)).generateExecutionTrace().toValues()
+    assert (trace[2][255], trace[3][255]) == (trace[9][255], trace[10][255]) and trace[13][255] == SIG_H      # lib224.ts:184-208
+    inner = context.air
+    p = f.modulus
+    for _ in range(5):
+        r, n, k = ([rng.randrange(p) for _ in range(count)] for count in (14, 14, 10))
+        assert inner.evaluationProgram.run(r, n, k) == hand.evaluationProgram.run(r, n, k)
