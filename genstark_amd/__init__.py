@@ -9,7 +9,7 @@ Layout (only what the hot path needs):
   air.py       air-assembly AirModule / ProvingContext surface for the MiMC AIR (dedicated kernels)
   air_generic.py  the same surface for AIRs given as expressions (register-machine programs, secret registers, segments);
                rescue.py, poseidon.py: the example hash AIRs; lib128.py, lib224.py: the exports of assembly/lib128.aa / lib224.aa;
-               pointmul.py: examples/elliptic/pointmul.aa
+               pointmul.py: examples/elliptic/pointmul.aa; airassembly.py: AirAssembly source -> AirModule (index.ts:18-33 instantiate)
   native.py    binding of the native prove() driver (same bytes as stark.py's prove + serialize)
   pipeline.py  several proofs in flight on one GPU (throughput mode)
   distributed.py  ONE proof across the GPUs of a node (distributed vectors under the unchanged prover); sharded.py: commitments
