@@ -5,7 +5,10 @@ class BoundaryConstraints:
     def __init__(self, assertions, context):  # :15-45
         f = self.field = context.field
         rData = {}
+        self.rootOfUnity = context.rootOfUnity
+        self.rootIndexes = {}             # register -> positions of its divisor's roots in the evaluation domain
         for c in assertions:
+            self.rootIndexes.setdefault(c['register'], []).append(c['step'] * context.extensionFactor)
             x = f.exp(context.rootOfUnity, c['step'] * context.extensionFactor)
             zPoly = f.newVectorFrom([f.neg(x), f.one])
             data = rData.get(c['register'])
@@ -42,6 +45,11 @@ class BoundaryConstraints:
             iPolys.append(c['iPoly'])
             zPolys.append(c['zPoly'])
         iValues = f.evalPolysAtRoots(f.newMatrixFromVectors(iPolys), domain)
-        zValues = f.evalPolysAtRoots(f.newMatrixFromVectors(zPolys), domain)
         piValues = f.subMatrixElementsFromVectors(pValues, iValues)
+        roots = [self.rootIndexes[register] for register in self.polys]
+        if getattr(f, 'fusedDomainDivisions', False) and max(len(r) for r in roots) <= f.MAX_DOMAIN_ROOTS and getattr(domain, 'series_base', None) == self.rootOfUnity:
+            # the divisors' roots are domain points: their inverses are look-ups in the domain's table 1/(omega^j - 1) — the same
+            # values as the two lines below, without the batch inversion
+            return f.divByDomainRoots(piValues, self.rootOfUnity, roots)
+        zValues = f.evalPolysAtRoots(f.newMatrixFromVectors(zPolys), domain)
         return f.divMatrixElements(piValues, zValues)

@@ -50,8 +50,7 @@ class CompositionPolynomial:
         pre = {}
         combinationDegree = getCombinationDegree(context.constraints, context.traceLength)
         compositionDegree = max(combinationDegree - context.traceLength, context.traceLength)
-        z = ZeroPolynomial(context).evaluateAll(context.evaluationDomain)
-        pre['zInverses'] = f.divVectorElements(z['denominators'], z['numerators'])
+        pre['zInverses'] = ZeroPolynomial(context).inverseOverDomain(context)
         compositionFactor = context.evaluationDomain.length // context.compositionDomain.length
         compositionRou = f.exp(context.rootOfUnity, compositionFactor)
         for g in groupTransitionConstraints(context.constraints, context.traceLength):
@@ -95,11 +94,9 @@ class CompositionPolynomial:
         self.log('Performed low degree extensions of Q(x) polynomial')
         # 4 ----- D(x) = Q(x) / Z(x)
         zInverses = pre.get('zInverses')
-        if zInverses is None:
-            zEvaluations = self.zPoly.evaluateAll(context.evaluationDomain)
         self.log('Computed Z(x) polynomial')
         if zInverses is None:
-            zInverses = f.divVectorElements(zEvaluations['denominators'], zEvaluations['numerators'])  # 1/Z = den/num (:117)
+            zInverses = self.zPoly.inverseOverDomain(context)                                       # 1/Z = den/num (:111-117)
         self.log('Computed Z(x) inverses')
         dEvaluations = f.mulVectorElements(qeEvaluations, zInverses)
         self.log('Computed D(x) polynomial')

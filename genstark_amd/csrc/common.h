@@ -93,3 +93,4 @@ static inline unsigned gs_grid(uint64_t work_items, unsigned block = 256, unsign
 // NTT entry points implemented in ntt.hip and used by other units
 void gs_plans_destroy(gs_ctx *c);
 int gs_plan_pow_tables(gs_ctx *c, const fe &omega, uint64_t n, const fe **tw_lo, const fe **tw_hi, int *log_lo);
+int gs_plan_inverse_table(gs_ctx *c, const fe &omega, uint64_t n, const fe **u);   // 1 / (omega^j - 1), cached with the plan

@@ -35,6 +35,7 @@ struct NttPlan {
     fe *wR[4] = {nullptr, nullptr, nullptr, nullptr};  // (omega^(n/R))^i, i < R, per pass
     fe *twp[4] = {nullptr, nullptr, nullptr, nullptr}; // inter-pass twiddles omega_{Ns*R}^(jq*k) as a [k][jq] table (passes >= 1, when small)
     fe w16[8];                                         // omega_16^i
+    fe *inv_table = nullptr;                           // 1 / (omega^j - 1), j < n, [0] = 0 (built on first use: gs_plan_inverse_table)
 };
 
 struct PassArgs {
@@ -303,6 +304,35 @@ int gs_plan_pow_tables(gs_ctx *c, const fe &omega, uint64_t n, const fe **tw_lo,
     *tw_lo = p->tw_lo;
     *tw_hi = p->tw_hi;
     *log_lo = p->log_lo;
+    return GS_OK;
+}
+
+__global__ void k_omega_minus_one(const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn, uint64_t n,
+                                  fe *__restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = fe_sub(pow_lookup(tw_lo, tw_hi, log_lo, logn, i), fe_one());
+}
+
+int gs_vec_inv_dev(gs_ctx *c, const fe *a, uint64_t n, fe *out);   // pointwise.hip
+
+// u[j] = 1 / (omega^j - 1) over the whole domain, u[0] = 0: a constant of (omega, n) like the twiddle tables, cached with the plan.
+// 1 / (omega^i - omega^k) = omega^-k * u[(i - k) mod n]: every division by a polynomial whose roots lie in the domain
+// (boundary-constraint denominators) becomes table look-ups instead of a batch inversion per proof.
+int gs_plan_inverse_table(gs_ctx *c, const fe &omega, uint64_t n, const fe **u) {
+    NttPlan *p;
+    int rc = plan_get(c, omega, n, &p);
+    if (rc) return rc;
+    if (!p->inv_table) {
+        void *q = nullptr, *t = nullptr;
+        if ((rc = gs_alloc(c, n * GS_ELT, &q))) return rc;
+        if ((rc = gs_tmp_alloc(c, n * GS_ELT, &t))) { gs_free(c, q); return rc; }
+        hipLaunchKernelGGL(k_omega_minus_one, dim3(gs_grid(n)), dim3(256), 0, c->stream, p->tw_lo, p->tw_hi, p->log_lo, p->logn, n, (fe *)t);
+        rc = gs_vec_inv_dev(c, (const fe *)t, n, (fe *)q);
+        gs_tmp_free(c, t);
+        if (rc) { gs_free(c, q); return rc; }
+        p->inv_table = (fe *)q;
+    }
+    *u = p->inv_table;
     return GS_OK;
 }
 

@@ -155,6 +155,38 @@ static int launch_batch_inv(gs_ctx *c, const fe *a, const fe *num, uint64_t n, f
     return GS_OK;
 }
 
+int gs_vec_inv_dev(gs_ctx *c, const fe *a, uint64_t n, fe *out) { return launch_batch_inv(c, a, nullptr, n, out); }
+
+// ---- divisions whose denominators are known in closed form over the domain {omega^i} ---------------------------------
+// 1/Z(x) of the transition constraints (ZeroPolynomial.ts:36-44 + CompositionPolynomial.ts:117): the denominator x^T - 1 takes only
+// n/T distinct values over the domain -> a table of n/T inverses (host), one product per point, no vector is read
+#define GS_ZPOLY_MAX_PERIOD 32
+struct ZTable { fe c[GS_ZPOLY_MAX_PERIOD]; };
+__global__ void k_zero_poly_inverses(const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn, uint64_t n, ZTable tab,
+                                     uint32_t period, fe x_last, fe *__restrict__ out) {
+    __shared__ fe c[GS_ZPOLY_MAX_PERIOD];
+    if (threadIdx.x < period) c[threadIdx.x] = tab.c[threadIdx.x];
+    __syncthreads();
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        fe x = tw_lo[i & ((1ull << log_lo) - 1)];
+        if (logn > log_lo) x = fe_mul(x, tw_hi[i >> log_lo]);
+        out[i] = fe_mul(fe_sub(x, x_last), c[i & (period - 1)]);
+    }
+}
+
+// num[i] / prod_a (omega^i - omega^k_a): the roots are domain points, so each factor's inverse is omega^-k_a * u[(i - k_a) mod n]
+// with u = 1/(omega^j - 1) (cached table): nroots table reads and products per point instead of a batch inversion
+#define GS_DOMAIN_ROOTS_MAX 4
+struct RootArgs { uint64_t k[GS_DOMAIN_ROOTS_MAX]; };
+__global__ void k_div_by_domain_roots(const fe *__restrict__ num, const fe *__restrict__ u, uint64_t n, RootArgs roots, uint32_t nroots, fe scale,
+                                      fe *__restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        fe r = fe_mul(num[i], scale);
+        for (uint32_t a = 0; a < nroots; a++) r = fe_mul(r, u[(i + n - roots.k[a]) & (n - 1)]);
+        out[i] = r;
+    }
+}
+
 // ---- linear combination of many vectors --------------------------------------------------------------
 struct PtrArgs {
     const fe *v[GS_MAX_COMBINE];
@@ -408,6 +440,56 @@ int gs_combine(gs_ctx *c, const void *a, const void *b, uint64_t n, gs_elt *out_
     CHECK3(c, a, b, out_host);
     if (!n) { memset(out_host, 0, GS_ELT); return GS_OK; }
     return dot_to_host(c, (const fe *)a, (const fe *)b, n, out_host);
+}
+
+int gs_zero_poly_inverses(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t steps, const gs_elt *x_last, void *out) {
+    if (!c || !omega || !x_last || !out) return GS_ERR_ARG;
+    if (!gs_is_pow2(n) || !gs_is_pow2(steps) || steps > n) return gs_fail(c, GS_ERR_ARG, "zero_poly_inverses: n and steps must be powers of two, steps <= n");
+    const uint64_t period = n / steps;
+    if (period > GS_ZPOLY_MAX_PERIOD) return gs_fail(c, GS_ERR_UNSUPPORTED, "zero_poly_inverses: n / steps above %d", GS_ZPOLY_MAX_PERIOD);
+    const fe w = fe_from_bytes(omega);
+    const fe *lo, *hi;
+    int log_lo;
+    int rc = gs_plan_pow_tables(c, w, n, &lo, &hi, &log_lo);      // also checks that omega is a primitive n-th root of unity
+    if (rc) return rc;
+    ZTable tab;
+    const fe g = fe_pow_u64(w, steps);                            // omega^(i*steps) = g^(i mod period)
+    fe cur = fe_one();
+    for (uint64_t j = 0; j < GS_ZPOLY_MAX_PERIOD; j++) {
+        tab.c[j] = j < period ? fe_inv(fe_sub(cur, fe_one())) : fe_zero();     // j = 0: 0^-1 = 0
+        cur = fe_mul(cur, g);
+    }
+    hipLaunchKernelGGL(k_zero_poly_inverses, dim3(gs_grid(n)), dim3(256), 0, c->stream, lo, hi, log_lo, gs_log2(n), n, tab, (uint32_t)period,
+                       fe_from_bytes(x_last), (fe *)out);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
+int gs_div_by_domain_roots(gs_ctx *c, const void *num, uint32_t rows, uint64_t n, const gs_elt *omega, const uint64_t *root_index_host,
+                           const uint32_t *roots_per_row_host, uint32_t max_roots, void *out) {
+    if (!c || !num || !omega || !out || !roots_per_row_host || (max_roots && !root_index_host)) return GS_ERR_ARG;
+    if (!gs_is_pow2(n)) return gs_fail(c, GS_ERR_ARG, "div_by_domain_roots: n must be a power of two");
+    if (!rows) return GS_OK;
+    for (uint32_t r = 0; r < rows; r++)
+        if (roots_per_row_host[r] > max_roots || roots_per_row_host[r] > GS_DOMAIN_ROOTS_MAX)
+            return gs_fail(c, GS_ERR_UNSUPPORTED, "div_by_domain_roots: at most %d roots per row", GS_DOMAIN_ROOTS_MAX);
+    const fe w = fe_from_bytes(omega);
+    const fe *u;
+    int rc = gs_plan_inverse_table(c, w, n, &u);
+    if (rc) return rc;
+    for (uint32_t r = 0; r < rows; r++) {
+        RootArgs ra;
+        uint64_t ksum = 0;
+        for (uint32_t a = 0; a < GS_DOMAIN_ROOTS_MAX; a++) {
+            ra.k[a] = a < roots_per_row_host[r] ? root_index_host[(uint64_t)r * max_roots + a] & (n - 1) : 0;
+            if (a < roots_per_row_host[r]) ksum = (ksum + ra.k[a]) & (n - 1);
+        }
+        const fe scale = fe_pow_u64(w, (n - ksum) & (n - 1));     // prod omega^-k_a
+        hipLaunchKernelGGL(k_div_by_domain_roots, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const fe *)num + (uint64_t)r * n, u, n, ra,
+                           roots_per_row_host[r], scale, (fe *)out + (uint64_t)r * n);
+    }
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
 }
 
 int gs_pluck(gs_ctx *c, const void *v, uint64_t vlen, uint64_t skip, uint64_t times, void *out) {

@@ -34,7 +34,7 @@ namespace {
     X(gs_eval_polys_at_roots) X(gs_interpolate_roots) X(gs_interpolate_quartic_domain) X(gs_eval_quartic_batch)                \
     X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
     X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
-    X(gs_air_trace_segments) X(gs_air_constraints)
+    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots)
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
     GS_API_LIST(X)
@@ -281,13 +281,19 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     const uint64_t composition_degree = std::max(combination_degree - T, T);
     Buf zInverses(x, N * ELEM);
     {
-        Buf xToTheSteps(x, N * ELEM), num(x, N * ELEM), den(x, N * ELEM);
-        x.check(A.gs_pluck(x.c, evalDomain.p, N, T, N, xToTheSteps.p), "gs_pluck");                    // ZeroPolynomial.ts:40
-        le16(1, s16);
-        x.check(A.gs_vec_sub_scalar(x.c, xToTheSteps.p, s16, N, num.p), "gs_vec_sub_scalar");
-        le16(hf_pow(omega, (hfe)((T - 1) * E)), s16);                                                // :21-23
-        x.check(A.gs_vec_sub_scalar(x.c, evalDomain.p, s16, N, den.p), "gs_vec_sub_scalar");
-        x.check(A.gs_vec_div(x.c, den.p, num.p, N, zInverses.p), "gs_vec_div(1/Z)");                   // CompositionPolynomial.ts:117
+        // ZeroPolynomial.ts:36-44 and the division of CompositionPolynomial.ts:117 in one kernel: x^T - 1 takes only E distinct values
+        le16(omega, s16);
+        le16(hf_pow(omega, (hfe)((T - 1) * E)), s16b);                                               // :21-23
+        if (E <= 32) {
+            x.check(A.gs_zero_poly_inverses(x.c, s16, N, T, s16b, zInverses.p), "gs_zero_poly_inverses");
+        } else {
+            Buf xToTheSteps(x, N * ELEM), num(x, N * ELEM), den(x, N * ELEM);
+            x.check(A.gs_pluck(x.c, evalDomain.p, N, T, N, xToTheSteps.p), "gs_pluck");                // ZeroPolynomial.ts:40
+            le16(1, s16);
+            x.check(A.gs_vec_sub_scalar(x.c, xToTheSteps.p, s16, N, num.p), "gs_vec_sub_scalar");
+            x.check(A.gs_vec_sub_scalar(x.c, evalDomain.p, s16b, N, den.p), "gs_vec_sub_scalar");
+            x.check(A.gs_vec_div(x.c, den.p, num.p, N, zInverses.p), "gs_vec_div(1/Z)");               // CompositionPolynomial.ts:117
+        }
     }
     Buf psbPowers;                                                 // x^(compositionDegree - T) over the evaluation domain
     const uint64_t b_inc = composition_degree - T;
@@ -346,13 +352,14 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
 
     // 5 ----- composition polynomial (CompositionPolynomial.ts:29-146)
     // boundary constraints per asserted register, in order of first appearance (BoundaryConstraints.ts:15-45)
-    struct RegData { uint32_t reg; std::vector<F> xs, ys; };
+    struct RegData { uint32_t reg; std::vector<F> xs, ys; std::vector<uint64_t> at; };   // at: positions of the xs in the evaluation domain
     std::vector<RegData> rdata;
     for (uint32_t i = 0; i < job.nassertions; i++) {
         const gs_assertion &a = job.assertions[i];
         RegData *d = nullptr;
         for (auto &e : rdata) if (e.reg == a.reg) d = &e;
-        if (!d) { rdata.push_back(RegData{a.reg, {}, {}}); d = &rdata.back(); }
+        if (!d) { rdata.push_back(RegData{a.reg, {}, {}, {}}); d = &rdata.back(); }
+        d->at.push_back(a.step * E);
         d->xs.push_back(hf_pow(omega, (hfe)(a.step * E)));
         d->ys.push_back(from16(a.value));
     }
@@ -445,17 +452,31 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
             x.check(A.gs_upload(x.c, b.p, host.data(), host.size()), "gs_upload(boundary polynomials)");
             return b;
         };
-        Buf iPolys = upload_rows(ipolys, ilen), zPolys = upload_rows(zpolys, zlen);
-        Buf iValues(x, (uint64_t)bcount * N * ELEM), zValues(x, (uint64_t)bcount * N * ELEM), pi(x, (uint64_t)bcount * N * ELEM),
-            bEval(x, (uint64_t)bcount * N * ELEM);
+        Buf iPolys = upload_rows(ipolys, ilen);
+        Buf iValues(x, (uint64_t)bcount * N * ELEM), pi(x, (uint64_t)bcount * N * ELEM), bEval(x, (uint64_t)bcount * N * ELEM);
         le16(omega, s16);
         x.check(A.gs_eval_polys_at_roots(x.c, iPolys.p, bcount, ilen, s16, N, iValues.p), "gs_eval_polys_at_roots(I)");
-        x.check(A.gs_eval_polys_at_roots(x.c, zPolys.p, bcount, zlen, s16, N, zValues.p), "gs_eval_polys_at_roots(Zb)");
         std::vector<const void *> pv;
         for (auto &d : rdata) pv.push_back(pRows[d.reg]);
         x.check(A.gs_sub_matrix_from_vectors(x.c, pv.data(), iValues.p, bcount, N, pi.p), "gs_sub_matrix_from_vectors");
-        x.check(A.gs_vec_div(x.c, pi.p, zValues.p, (uint64_t)bcount * N, bEval.p), "gs_vec_div(B)");
-        iValues.release(); zValues.release(); pi.release();
+        size_t max_roots = 0;
+        for (auto &d : rdata) max_roots = std::max(max_roots, d.at.size());
+        if (max_roots <= 4) {
+            // the divisors' roots are domain points: look-ups in the domain's table 1/(omega^j - 1) instead of evaluating Z_r(x)
+            // and inverting it (same values: BoundaryConstraints.ts:88,92)
+            std::vector<uint64_t> at(bcount * max_roots, 0);
+            std::vector<uint32_t> per_row(bcount);
+            for (uint32_t r = 0; r < bcount; r++) {
+                per_row[r] = (uint32_t)rdata[r].at.size();
+                for (size_t k = 0; k < rdata[r].at.size(); k++) at[r * max_roots + k] = rdata[r].at[k];
+            }
+            x.check(A.gs_div_by_domain_roots(x.c, pi.p, bcount, N, s16, at.data(), per_row.data(), (uint32_t)max_roots, bEval.p), "gs_div_by_domain_roots");
+        } else {
+            Buf zPolys = upload_rows(zpolys, zlen), zValues(x, (uint64_t)bcount * N * ELEM);
+            x.check(A.gs_eval_polys_at_roots(x.c, zPolys.p, bcount, zlen, s16, N, zValues.p), "gs_eval_polys_at_roots(Zb)");
+            x.check(A.gs_vec_div(x.c, pi.p, zValues.p, (uint64_t)bcount * N, bEval.p), "gs_vec_div(B)");
+        }
+        iValues.release(); pi.release();
         // 5.6 degree adjustment of B (:124-138) and 5.7 merge (:140-146)
         std::vector<const void *> ba;
         for (uint32_t i = 0; i < bcount; i++) ba.push_back(bEval.at((uint64_t)i * N * ELEM));

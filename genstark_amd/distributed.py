@@ -152,6 +152,7 @@ def _is_dist(x):
 
 class DistField(PrimeField):
     """PrimeField whose vectors of `dist_length` elements (the evaluation domain size N) are distributed."""
+    fusedDomainDivisions = False         # the general member sequences are index-local here; the fused kernels enumerate a whole domain
 
     def __init__(self, backend, dist_length, group=None):
         super().__init__(backend=backend)

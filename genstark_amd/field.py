@@ -250,6 +250,29 @@ class PrimeField:
         self.backend.call('gs_vec_exp', C.c_void_p(a.ptr), self.le(e), a.length, C.c_void_p(out.ptr))
         return out
 
+    # ---- fused forms of divisions whose denominators are known in closed form over the domain (no counterpart in galois: same
+    # values as the member sequences named in include/gstark.h, one kernel each)
+    fusedDomainDivisions = True          # the components ask before using the two members below (a distributed field says no)
+
+    def zeroPolyInverses(self, rootOfUnity, domainSize, steps, xAtLastStep):
+        """1/Z(x) over the evaluation domain: ZeroPolynomial.evaluateAll + CompositionPolynomial.ts:117 (den / num)."""
+        out = Vector(self.backend, domainSize)
+        self.backend.call('gs_zero_poly_inverses', self.le(rootOfUnity), domainSize, steps, self.le(xAtLastStep), C.c_void_p(out.ptr))
+        return out
+
+    MAX_DOMAIN_ROOTS = 4
+
+    def divByDomainRoots(self, numerators, rootOfUnity, rootIndexes):
+        """numerators[r][i] / prod_k (omega^i - omega^k), k in rootIndexes[r]: BoundaryConstraints.ts:87-92 when every divisor's
+        roots are domain points (at most MAX_DOMAIN_ROOTS per row)."""
+        rows, n = numerators.rowCount, numerators.colCount
+        width = max(len(r) for r in rootIndexes)
+        flat = (C.c_uint64 * (rows * width))(*[(r[a] if a < len(r) else 0) for r in rootIndexes for a in range(width)])
+        counts = (C.c_uint32 * rows)(*[len(r) for r in rootIndexes])
+        out = Matrix(self.backend, rows, n)
+        self.backend.call('gs_div_by_domain_roots', C.c_void_p(numerators.ptr), rows, n, self.le(rootOfUnity), flat, counts, width, C.c_void_p(out.ptr))
+        return out
+
     def combineVectors(self, a, b):
         if a.length != b.length:
             raise GstarkError('Cannot combine vectors: vectors have different lengths')

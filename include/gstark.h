@@ -118,6 +118,19 @@ int gs_combine_many(gs_ctx *ctx, const void *const *vecs_host, const uint8_t *co
 int gs_combine(gs_ctx *ctx, const void *a, const void *b, uint64_t n, gs_elt *out_host);
 /* pluckVector(v, skip, times): out[i] = v[(i*skip) mod vlen], i < times.  ZeroPolynomial.ts:40 */
 int gs_pluck(gs_ctx *ctx, const void *v, uint64_t vlen, uint64_t skip, uint64_t times, void *out);
+/* Fused ZeroPolynomial.evaluateAll (ZeroPolynomial.ts:36-44) + the division of CompositionPolynomial.ts:117 (SURVEY 8a row A8,
+ * "zpoly_numden"): over the evaluation domain {omega^i}, i < n, of a trace of `steps` steps
+ *     out[i] = (omega^i - x_last) / (omega^(i*steps) - 1),   0 where the denominator vanishes
+ * — the values pluckVector / subVectorElements / divVectorElements produce, without materialising them (the denominator takes
+ * only n/steps distinct values).  n / steps <= 32. */
+int gs_zero_poly_inverses(gs_ctx *ctx, const gs_elt *omega, uint64_t n, uint64_t steps, const gs_elt *x_last, void *out);
+/* The division of BoundaryConstraints.ts:87-92 when the divisor's roots are domain points (they are: assertions sit on
+ * execution-domain steps): num is rows x n, row-major;
+ *     out[r][i] = num[r][i] / prod_{a < roots_per_row[r]} (omega^i - omega^(root_index[r*max_roots + a])),   0 where a factor vanishes
+ * — the values evalPolysAtRoots(Z polynomials) + divMatrixElements produce.  At most 4 roots per row (GS_ERR_UNSUPPORTED above:
+ * use the general members).  The library keeps the table 1/(omega^j - 1) of the domain with its transform plan. */
+int gs_div_by_domain_roots(gs_ctx *ctx, const void *num, uint32_t rows, uint64_t n, const gs_elt *omega,
+                           const uint64_t *root_index_host, const uint32_t *roots_per_row_host, uint32_t max_roots, void *out);
 /* transposeVector(v, cols, step): rows = n/(cols*step); out[r*cols+c] = v[(r + c*rows)*step].
  * LowDegreeProver.ts:42,162,190,198 */
 int gs_transpose_vector(gs_ctx *ctx, const void *v, uint64_t n, uint32_t cols, uint64_t step, void *out);

@@ -62,6 +62,8 @@ const FnDesc kFns[] = {
     {"gs_combine_many", "cabiup"},
     {"gs_combine", "cppuo"},
     {"gs_pluck", "cpuuup"},
+    {"gs_zero_poly_inverses", "cbuubp"},
+    {"gs_div_by_domain_roots", "cpiubxwip"},
     {"gs_transpose_vector", "cpuiup"},
     {"gs_transpose_matrix", "cpuup"},
     {"gs_sub_matrix_from_vectors", "capiup"},

@@ -159,6 +159,45 @@ int gs_pluck(gs_ctx *c, const void *v, uint64_t vlen, uint64_t skip, uint64_t ti
     for (uint64_t i = 0; i < times; i++) ST(o, i, EL(v, (i * skip) % vlen));
     return GS_OK;
 }
+/* the definitions, term by term: denominators materialised, inverted with the serial Montgomery trick, multiplied */
+int gs_zero_poly_inverses(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t steps, const gs_elt *x_last, void *o) {
+    if (!is_pow2(n) || !is_pow2(steps) || steps > n) return fail(c, GS_ERR_ARG, "zero_poly_inverses: bad sizes");
+    if (n / steps > 32) return fail(c, GS_ERR_UNSUPPORTED, "zero_poly_inverses: n / steps above 32");
+    fe w = fe_load(omega), xl = fe_load(x_last), ws = fe_exp(w, (fexp)steps);
+    uint8_t *den = (uint8_t *)malloc((n ? n : 1) * FE_BYTES);
+    fe *inv = (fe *)malloc((n ? n : 1) * sizeof(fe));
+    if (!den || !inv) { free(den); free(inv); return fail(c, GS_ERR_OOM, "malloc failed"); }
+    fe d = 1;
+    for (uint64_t i = 0; i < n; i++) { ST(den, i, fe_sub(d, 1)); d = fe_mul(d, ws); }      /* omega^(i*steps) - 1 */
+    batch_inv(den, n, inv);
+    fe x = 1;
+    for (uint64_t i = 0; i < n; i++) { ST(o, i, fe_mul(fe_sub(x, xl), inv[i])); x = fe_mul(x, w); }
+    free(den); free(inv);
+    return GS_OK;
+}
+int gs_div_by_domain_roots(gs_ctx *c, const void *num, uint32_t rows, uint64_t n, const gs_elt *omega, const uint64_t *root_index,
+                           const uint32_t *roots_per_row, uint32_t max_roots, void *o) {
+    if (!is_pow2(n)) return fail(c, GS_ERR_ARG, "div_by_domain_roots: n must be a power of two");
+    fe w = fe_load(omega);
+    uint8_t *den = (uint8_t *)malloc((n ? n : 1) * FE_BYTES);
+    fe *inv = (fe *)malloc((n ? n : 1) * sizeof(fe));
+    if (!den || !inv) { free(den); free(inv); return fail(c, GS_ERR_OOM, "malloc failed"); }
+    for (uint32_t r = 0; r < rows; r++) {
+        if (roots_per_row[r] > max_roots || roots_per_row[r] > 4) { free(den); free(inv); return fail(c, GS_ERR_UNSUPPORTED, "div_by_domain_roots: at most 4 roots per row"); }
+        fe x = 1, root[4];
+        for (uint32_t a = 0; a < roots_per_row[r]; a++) root[a] = fe_exp(w, (fexp)(root_index[(uint64_t)r * max_roots + a] % n));
+        for (uint64_t i = 0; i < n; i++) {
+            fe z = 1;
+            for (uint32_t a = 0; a < roots_per_row[r]; a++) z = fe_mul(z, fe_sub(x, root[a]));
+            ST(den, i, z);
+            x = fe_mul(x, w);
+        }
+        batch_inv(den, n, inv);
+        for (uint64_t i = 0; i < n; i++) ST(o, (uint64_t)r * n + i, fe_mul(EL(num, (uint64_t)r * n + i), inv[i]));
+    }
+    free(den); free(inv);
+    return GS_OK;
+}
 int gs_transpose_vector(gs_ctx *c, const void *v, uint64_t n, uint32_t cols, uint64_t step, void *o) {
     if (!cols || !step || n % ((uint64_t)cols * step)) return fail(c, GS_ERR_ARG, "transpose_vector: n %% (cols*step) != 0");
     uint64_t rows = n / ((uint64_t)cols * step);

@@ -44,6 +44,46 @@ def check_inverse_with_zeros(backend, rng, n):
     assert zeros == [0] * n
 
 
+def check_domain_divisions(backend, rng, logn, logsteps):
+    """gs_zero_poly_inverses / gs_div_by_domain_roots against their definitions on Python integers (0^-1 = 0), and against the
+    member sequences they stand for (pluck / sub / div; evalPolysAtRoots / divMatrixElements)."""
+    f = field_for(backend)
+    n, steps = 1 << logn, 1 << logsteps
+    w = f.getRootOfUnity(n)
+    inv = lambda x: pow(x, P - 2, P) if x % P else 0
+    xs = [pow(w, i, P) for i in range(n)]
+    x_last = pow(w, (steps - 1) * (n // steps), P)
+    want = [(x - x_last) * inv(pow(x, steps, P) - 1) % P for x in xs]
+    got = f.zeroPolyInverses(w, n, steps, x_last)
+    assert got.toValues() == want
+    domain = f.getPowerSeries(w, n)
+    num = f.subVectorElements(f.pluckVector(domain, steps, n), 1)
+    den = f.subVectorElements(domain, x_last)
+    assert f.divVectorElements(den, num).toBuffer() == got.toBuffer()
+    # rows with 1..4 roots (first and last execution steps among them, as assertions have)
+    e = n // steps
+    roots = [[0], [0, (steps - 1) * e], [e * rng.randrange(steps) for _ in range(3)], [rng.randrange(n) for _ in range(4)]]
+    rows = [rand_elements(rng, n) for _ in roots]
+    numerators = f.newMatrixFrom(rows)
+    got = f.divByDomainRoots(numerators, w, roots)
+    want = []
+    for r, ks in zip(rows, roots):
+        zs = [1] * n
+        for k in ks:
+            zs = [z * (x - pow(w, k, P)) % P for z, x in zip(zs, xs)]
+        want.append([v * inv(z) % P for v, z in zip(r, zs)])
+    assert got.toValues() == want
+    zpolys = []
+    for ks in roots:
+        poly = [1]
+        for k in ks:
+            poly = [(a - b * pow(w, k, P)) % P for a, b in zip([0] + poly, poly + [0])]
+        zpolys.append(f.newVectorFrom(poly))
+    z_values = f.evalPolysAtRoots(f.newMatrixFromVectors(zpolys), domain)
+    assert f.divMatrixElements(numerators, z_values).toBuffer() == got.toBuffer()
+    return got.toBuffer()
+
+
 def check_power_series_and_shuffles(backend, rng, n):
     f = field_for(backend)
     base = rng.randrange(2, P)

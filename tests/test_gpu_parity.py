@@ -33,6 +33,11 @@ def test_pointwise(hip_backend, rng, n):
     cases.check_pointwise(hip_backend, rng, n)
 
 
+@pytest.mark.parametrize('logn,logsteps', [(4, 2), (8, 4), (12, 7), (17, 13)])
+def test_domain_divisions(hip_backend, rng, logn, logsteps):
+    cases.check_domain_divisions(hip_backend, rng, logn, logsteps)
+
+
 @pytest.mark.parametrize('n', [5, 257, 40000])
 def test_inverse_with_zeros(hip_backend, rng, n):
     cases.check_inverse_with_zeros(hip_backend, rng, n)

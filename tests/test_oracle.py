@@ -12,6 +12,11 @@ def test_pointwise(oracle_backend, rng, n):
     cases.check_pointwise(oracle_backend, rng, n)
 
 
+@pytest.mark.parametrize('logn,logsteps', [(4, 2), (8, 4), (10, 5)])
+def test_domain_divisions(oracle_backend, rng, logn, logsteps):
+    cases.check_domain_divisions(oracle_backend, rng, logn, logsteps)
+
+
 def test_inverse_with_zeros(oracle_backend, rng):
     cases.check_inverse_with_zeros(oracle_backend, rng, 257)
 
