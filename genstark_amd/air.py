@@ -85,6 +85,23 @@ class ProvingContext(_Context):
         wk = f.exp(self.compositionDomain.series_base, self.cycleCount)
         kp = f.newVectorFrom(self.kPoly)
         self._kTable = f.evalPolyAtRoots(kp, f.getPowerSeries(wk, klen))
+        self._kTableN = None
+
+    def evaluateTransitionConstraintsOverEvaluationDomain(self, pEvaluations):
+        """Q over the EVALUATION domain straight from the extension of P that prove() already holds (lib/Stark.ts:109): the
+        reference evaluates Q on the smaller composition domain, interpolates the combination and extends it
+        (CompositionPolynomial.ts:76-111) — the combined, degree-adjusted polynomial has degree < |composition domain|, so its
+        extension IS what the constraint expression gives on every evaluation-domain point.  Same values, no iNTT + NTT."""
+        f = self.field
+        n = self.evaluationDomain.length
+        if self._kTableN is None:
+            klen = len(self.roundConstants) * self.extensionFactor
+            wk = f.exp(self.rootOfUnity, self.cycleCount)                       # order 64 * extensionFactor
+            self._kTableN = f.evalPolyAtRoots(f.newVectorFrom(self.kPoly), f.getPowerSeries(wk, klen))
+        q = Matrix(f.backend, 1, n)
+        f.backend.call('gs_mimc_constraints', C.c_void_p(pEvaluations.ptr), n, n // self.traceLength,
+                       C.c_void_p(self._kTableN.ptr), self._kTableN.length, C.c_void_p(q.ptr))
+        return q
 
     def generateExecutionTrace(self):
         """lib/Stark.ts:97 — 1 x T matrix; sequential on the host CPU inside the library."""

@@ -53,14 +53,21 @@ class CompositionPolynomial:
         pre['zInverses'] = ZeroPolynomial(context).inverseOverDomain(context)
         compositionFactor = context.evaluationDomain.length // context.compositionDomain.length
         compositionRou = f.exp(context.rootOfUnity, compositionFactor)
+        direct = CompositionPolynomial.directRoute(context)
         for g in groupTransitionConstraints(context.constraints, context.traceLength):
             if g['degree'] != combinationDegree:
-                seed = f.exp(compositionRou, combinationDegree - g['degree'])
-                pre['qPowers', g['degree']] = f.getPowerSeries(seed, context.compositionDomain.length)
+                seed = f.exp(context.rootOfUnity if direct else compositionRou, combinationDegree - g['degree'])
+                pre['qPowers', g['degree']] = f.getPowerSeries(seed, (context.evaluationDomain if direct else context.compositionDomain).length)
         if compositionDegree > context.traceLength:
             seed = f.exp(context.rootOfUnity, compositionDegree - context.traceLength)
             pre['psbPowers'] = f.getPowerSeries(seed, context.evaluationDomain.length)
         context.prefetched = pre
+
+    @staticmethod
+    def directRoute(context):
+        """True when Q can be evaluated on the evaluation domain directly (the context offers it, the field is not distributed):
+        evaluateAll then skips the interpolation + extension of CompositionPolynomial.ts:109-110 — same values."""
+        return hasattr(context, 'evaluateTransitionConstraintsOverEvaluationDomain') and getattr(context.field, 'fusedDomainDivisions', False)
 
     @property
     def coefficientCount(self):
@@ -69,12 +76,14 @@ class CompositionPolynomial:
     def evaluateAll(self, pPolys, pEvaluations, context):  # :71-146
         f = self.field
         pre = getattr(context, 'prefetched', None) or {}
-        # 1 ----- transition constraints over the composition domain
-        qEvaluations = context.evaluateTransitionConstraints(pPolys)
+        # 1 ----- transition constraints over the composition domain (or, directRoute, over the evaluation domain)
+        direct = self.directRoute(context)
+        qEvaluations = context.evaluateTransitionConstraintsOverEvaluationDomain(pEvaluations) if direct else context.evaluateTransitionConstraints(pPolys)
         self.log('Computed transition constraint polynomials Q(x)')
         # 2 ----- adjust degrees
-        compositionFactor = context.evaluationDomain.length // context.compositionDomain.length
+        compositionFactor = 1 if direct else context.evaluationDomain.length // context.compositionDomain.length
         compositionRou = f.exp(context.rootOfUnity, compositionFactor)
+        qDomainLength = (context.evaluationDomain if direct else context.compositionDomain).length
         qaEvaluations = f.matrixRowsToVectors(qEvaluations)
         for g in self.constraintGroups:
             if g['degree'] == self.combinationDegree:
@@ -82,15 +91,18 @@ class CompositionPolynomial:
             powerSeed = f.exp(compositionRou, self.combinationDegree - g['degree'])
             powers = pre.get(('qPowers', g['degree']))
             if powers is None:
-                powers = f.getPowerSeries(powerSeed, context.compositionDomain.length)
+                powers = f.getPowerSeries(powerSeed, qDomainLength)
             for i in g['indexes']:
                 qaEvaluations.append(f.mulVectorElements(qaEvaluations[i], powers))
         self.log('Adjusted degrees of Q(x) polynomials')
         # 3 ----- merge into one polynomial and extend to the evaluation domain
         qcEvaluations = f.combineManyVectors(qaEvaluations, self.dCoefficients)
         self.log('Computed linear combination of Q(x) polynomials')
-        qcPoly = f.interpolateRoots(context.compositionDomain, qcEvaluations)
-        qeEvaluations = f.evalPolyAtRoots(qcPoly, context.evaluationDomain)
+        if direct:
+            qeEvaluations = qcEvaluations
+        else:
+            qcPoly = f.interpolateRoots(context.compositionDomain, qcEvaluations)
+            qeEvaluations = f.evalPolyAtRoots(qcPoly, context.evaluationDomain)
         self.log('Performed low degree extensions of Q(x) polynomial')
         # 4 ----- D(x) = Q(x) / Z(x)
         zInverses = pre.get('zInverses')

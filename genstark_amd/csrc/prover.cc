@@ -384,39 +384,58 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
 
     Buf cEval(x, N * ELEM);
     {
-        // 5.1 transition constraints over the composition domain (:76).  P over that domain is every (N/Nc)-th element of the
-        // extension just computed
-        Buf pComp(x, (uint64_t)R * Nc * ELEM), q(x, (uint64_t)air.nconstraints * Nc * ELEM);
-        for (uint32_t r = 0; r < R; r++)
-            x.check(A.gs_pluck(x.c, pRows[r], N, N / Nc, Nc, pComp.at((uint64_t)r * Nc * ELEM)), "gs_pluck(P over the composition domain)");
-        if (air.kind == 0)
-            x.check(A.gs_mimc_constraints(x.c, pComp.p, Nc, Nc / T, air.k_table, air.k_len, q.p), "gs_mimc_constraints");
-        else
+        // 5.1-5.3: the combined, degree-adjusted Q has degree < Nc, so its extension to the evaluation domain (:109-110) is what
+        // the constraint expression gives there.  MiMC (one cheap constraint): evaluate it on all N points from the extension of P
+        // already at hand — no interpolation + extension; AIR programs: on the composition domain as the reference does.
+        const bool direct = air.kind == 0;
+        const uint64_t Nq = direct ? N : Nc;
+        const F q_rou = direct ? omega : comp_rou;
+        Buf q(x, (uint64_t)air.nconstraints * Nq * ELEM);
+        if (direct) {
+            // the cyclic register over the evaluation domain: K's 64 coefficients from its composition-domain table, then its values
+            // at the (k_len * N/Nc)-th roots of unity
+            const uint64_t klen_n = air.k_len * (N / Nc);
+            Buf kPoly(x, air.k_len * ELEM), kN(x, klen_n * ELEM);
+            le16(hf_pow(omega, (hfe)(N / air.k_len)), s16);
+            x.check(A.gs_interpolate_roots(x.c, air.k_table, 1, s16, air.k_len, kPoly.p), "gs_interpolate_roots(K)");
+            le16(hf_pow(omega, (hfe)(N / klen_n)), s16);
+            x.check(A.gs_eval_polys_at_roots(x.c, kPoly.p, 1, air.k_len, s16, klen_n, kN.p), "gs_eval_polys_at_roots(K)");
+            x.check(A.gs_mimc_constraints(x.c, pRows[0], N, N / T, kN.p, klen_n, q.p), "gs_mimc_constraints");
+        } else {
+            // P over the composition domain is every (N/Nc)-th element of the extension just computed (:76)
+            Buf pComp(x, (uint64_t)R * Nc * ELEM);
+            for (uint32_t r = 0; r < R; r++)
+                x.check(A.gs_pluck(x.c, pRows[r], N, N / Nc, Nc, pComp.at((uint64_t)r * Nc * ELEM)), "gs_pluck(P over the composition domain)");
             x.check(A.gs_air_constraints(x.c, air.e_code, air.e_ninstr, air.consts, air.nconsts, air.vm_regs, R, air.nconstraints, pComp.p, Nc,
                                          Nc / T, air.static_tables, air.static_lens, air.nstatic, q.p), "gs_air_constraints");
-        pComp.release();
+        }
         // 5.2 degree adjustment (:83-101) and 5.3 merge + extension (:103-111)
         std::vector<const void *> qa;
-        for (uint32_t i = 0; i < air.nconstraints; i++) qa.push_back(q.at((uint64_t)i * Nc * ELEM));
+        for (uint32_t i = 0; i < air.nconstraints; i++) qa.push_back(q.at((uint64_t)i * Nq * ELEM));
         std::vector<Buf> adjusted;
         for (auto &g : groups) {
             if (g.first == combination_degree) continue;
-            Buf powers(x, Nc * ELEM);
-            le16(hf_pow(comp_rou, (hfe)(combination_degree - g.first)), s16);
-            x.check(A.gs_power_series(x.c, s16, Nc, powers.p), "gs_power_series(q powers)");
+            Buf powers(x, Nq * ELEM);
+            le16(hf_pow(q_rou, (hfe)(combination_degree - g.first)), s16);
+            x.check(A.gs_power_series(x.c, s16, Nq, powers.p), "gs_power_series(q powers)");
             for (uint32_t i : g.second) {
-                adjusted.emplace_back(x, Nc * ELEM);
-                x.check(A.gs_vec_mul(x.c, qa[i], powers.p, Nc, adjusted.back().p), "gs_vec_mul");
+                adjusted.emplace_back(x, Nq * ELEM);
+                x.check(A.gs_vec_mul(x.c, qa[i], powers.p, Nq, adjusted.back().p), "gs_vec_mul");
                 qa.push_back(adjusted.back().p);
             }
         }
-        Buf qc(x, Nc * ELEM), qcPoly(x, Nc * ELEM), qe(x, N * ELEM);
+        Buf qe(x, N * ELEM);
         Bytes dco = coeff_bytes(0, dcount);
-        x.check(A.gs_combine_many(x.c, qa.data(), dco.data(), dcount, Nc, qc.p), "gs_combine_many(Q)");
-        le16(comp_rou, s16);
-        x.check(A.gs_interpolate_roots(x.c, qc.p, 1, s16, Nc, qcPoly.p), "gs_interpolate_roots(Q)");
-        le16(omega, s16);
-        x.check(A.gs_eval_polys_at_roots(x.c, qcPoly.p, 1, Nc, s16, N, qe.p), "gs_eval_polys_at_roots(Q)");
+        if (direct) {
+            x.check(A.gs_combine_many(x.c, qa.data(), dco.data(), dcount, N, qe.p), "gs_combine_many(Q)");
+        } else {
+            Buf qc(x, Nc * ELEM), qcPoly(x, Nc * ELEM);
+            x.check(A.gs_combine_many(x.c, qa.data(), dco.data(), dcount, Nc, qc.p), "gs_combine_many(Q)");
+            le16(comp_rou, s16);
+            x.check(A.gs_interpolate_roots(x.c, qc.p, 1, s16, Nc, qcPoly.p), "gs_interpolate_roots(Q)");
+            le16(omega, s16);
+            x.check(A.gs_eval_polys_at_roots(x.c, qcPoly.p, 1, Nc, s16, N, qe.p), "gs_eval_polys_at_roots(Q)");
+        }
         // 5.4 D(x) = Q(x) / Z(x) (:113-121)
         Buf dEval(x, N * ELEM);
         x.check(A.gs_vec_mul(x.c, qe.p, zInverses.p, N, dEval.p), "gs_vec_mul(D)");
