@@ -16,6 +16,38 @@ __global__ void k_mimc_constraints(const fe *__restrict__ p, uint64_t nc, uint64
     }
 }
 
+// CompositionPolynomial.evaluateAll for this AIR in ONE pass over the evaluation domain (see include/gstark.h): per point nine field
+// products, reads p[i], p[i + E], k, two entries of the domain's table u = 1/(omega^j - 1); everything that depends on x^T only
+// (the degree-adjustment factors and 1/(x^T - 1): E distinct values) comes from two E-entry tables built on the host.
+#define GS_MIMC_COMP_MAX_PERIOD 32
+#define GS_MIMC_COMP_MAX_ROOTS 4
+struct MimcCompArgs {
+    fe qz[GS_MIMC_COMP_MAX_PERIOD];   // (d0 + d1 * g^(j*qm)) / (g^j - 1),  g = omega^steps
+    fe bt[GS_MIMC_COMP_MAX_PERIOD];   // (b0 + b1 * g^(j*bm)) * prod_a omega^-k_a
+    fe ipoly[GS_MIMC_COMP_MAX_ROOTS];
+    uint64_t root[GS_MIMC_COMP_MAX_ROOTS];
+    fe x_last;
+};
+__global__ void k_mimc_composition(const fe *__restrict__ p, uint64_t n, uint64_t shift, const fe *__restrict__ k, uint64_t klen,
+                                   const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn, const fe *__restrict__ u,
+                                   MimcCompArgs a, uint32_t period, uint32_t nroots, fe *__restrict__ out) {
+    __shared__ fe qz[GS_MIMC_COMP_MAX_PERIOD], bt[GS_MIMC_COMP_MAX_PERIOD];
+    if (threadIdx.x < period) { qz[threadIdx.x] = a.qz[threadIdx.x]; bt[threadIdx.x] = a.bt[threadIdx.x]; }
+    __syncthreads();
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        fe x = tw_lo[i & ((1ull << log_lo) - 1)];
+        if (logn > log_lo) x = fe_mul(x, tw_hi[i >> log_lo]);
+        const fe pi = p[i], pn = p[(i + shift) & (n - 1)];
+        const fe q = fe_sub(pn, fe_add(fe_mul(fe_mul(pi, pi), pi), k[i % klen]));                    // transition constraint
+        const fe d = fe_mul(fe_mul(q, fe_sub(x, a.x_last)), qz[i & (period - 1)]);                     // Q * adjustment / Z
+        fe iv = a.ipoly[nroots - 1];                                                                   // I(x), Horner
+        for (int c = (int)nroots - 2; c >= 0; c--) iv = fe_add(fe_mul(iv, x), a.ipoly[c]);
+        fe b = fe_mul(fe_sub(pi, iv), bt[i & (period - 1)]);
+        for (uint32_t r = 0; r < nroots; r++) b = fe_mul(b, u[(i + n - a.root[r]) & (n - 1)]);         // / prod (x - x_a)
+        out[i] = fe_add(d, b);
+    }
+}
+
 // The MiMC recurrence x <- x^3 + k is a serial dependency chain (examples/mimc/utils.ts:7-15): like
 // the reference (generated JS over one input) it runs on one host core, here on native 64-bit limbs
 // (host_field.h), written straight into a pinned staging buffer that is then copied to the device.
@@ -51,6 +83,50 @@ int gs_mimc_constraints(gs_ctx *c, const void *p_comp, uint64_t nc, uint64_t shi
     if (!nc || !klen) return gs_fail(c, GS_ERR_ARG, "mimc_constraints: empty");
     hipLaunchKernelGGL(k_mimc_constraints, dim3(gs_grid(nc)), dim3(256), 0, c->stream, (const fe *)p_comp, nc, shift % nc,
                        (const fe *)k_table, klen, (fe *)out);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
+int gs_mimc_composition(gs_ctx *c, const void *p_eval, uint64_t n, uint64_t steps, const gs_elt *omega, const void *k_table, uint64_t klen,
+                        const uint8_t *coeffs_host, uint64_t q_inc, uint64_t b_inc, const uint8_t *ipoly_host, const uint64_t *root_index_host,
+                        uint32_t nroots, void *out) {
+    if (!c || !p_eval || !omega || !k_table || !coeffs_host || !ipoly_host || !root_index_host || !out) return GS_ERR_ARG;
+    if (!gs_is_pow2(n) || !gs_is_pow2(steps) || steps > n || !klen) return gs_fail(c, GS_ERR_ARG, "mimc_composition: bad sizes");
+    const uint64_t period = n / steps;
+    if (period > GS_MIMC_COMP_MAX_PERIOD || nroots == 0 || nroots > GS_MIMC_COMP_MAX_ROOTS)
+        return gs_fail(c, GS_ERR_UNSUPPORTED, "mimc_composition: n / steps <= %d and 1..%d assertions", GS_MIMC_COMP_MAX_PERIOD, GS_MIMC_COMP_MAX_ROOTS);
+    if (q_inc % steps || b_inc % steps) return gs_fail(c, GS_ERR_ARG, "mimc_composition: degree increments must be multiples of the trace length");
+    const fe w = fe_from_bytes(omega);
+    const fe *lo, *hi, *u;
+    int log_lo;
+    int rc = gs_plan_pow_tables(c, w, n, &lo, &hi, &log_lo);
+    if (!rc) rc = gs_plan_inverse_table(c, w, n, &u);
+    if (rc) return rc;
+    const fe d0 = fe_from_bytes(coeffs_host), d1 = fe_from_bytes(coeffs_host + GS_ELT), b0 = fe_from_bytes(coeffs_host + 2 * GS_ELT),
+             b1 = fe_from_bytes(coeffs_host + 3 * GS_ELT);
+    MimcCompArgs a;
+    uint64_t ksum = 0;
+    for (uint32_t r = 0; r < GS_MIMC_COMP_MAX_ROOTS; r++) {
+        a.root[r] = r < nroots ? root_index_host[r] & (n - 1) : 0;
+        a.ipoly[r] = r < nroots ? fe_from_bytes(ipoly_host + GS_ELT * r) : fe_zero();
+        if (r < nroots) ksum = (ksum + a.root[r]) & (n - 1);
+    }
+    const fe scale = fe_pow_u64(w, (n - ksum) & (n - 1));                    // prod omega^-k_a
+    const fe g = fe_pow_u64(w, steps);                                       // x^steps = g^(i mod period)
+    const fe gq = fe_pow_u64(g, (q_inc / steps) % period), gb = fe_pow_u64(g, (b_inc / steps) % period);
+    fe gj = fe_one(), gqj = fe_one(), gbj = fe_one();
+    for (uint64_t j = 0; j < GS_MIMC_COMP_MAX_PERIOD; j++) {
+        if (j < period) {
+            a.qz[j] = fe_mul(fe_add(d0, fe_mul(d1, gqj)), fe_inv(fe_sub(gj, fe_one())));      // j = 0: 0^-1 = 0
+            a.bt[j] = fe_mul(fe_add(b0, fe_mul(b1, gbj)), scale);
+        } else {
+            a.qz[j] = a.bt[j] = fe_zero();
+        }
+        gj = fe_mul(gj, g); gqj = fe_mul(gqj, gq); gbj = fe_mul(gbj, gb);
+    }
+    a.x_last = fe_pow_u64(w, (steps - 1) * period);
+    hipLaunchKernelGGL(k_mimc_composition, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const fe *)p_eval, n, period, (const fe *)k_table, klen, lo, hi,
+                       log_lo, gs_log2(n), u, a, (uint32_t)period, nroots, (fe *)out);
     GS_LAUNCH_CHECK(c);
     return GS_OK;
 }

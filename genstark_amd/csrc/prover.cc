@@ -34,7 +34,7 @@ namespace {
     X(gs_eval_polys_at_roots) X(gs_interpolate_roots) X(gs_interpolate_quartic_domain) X(gs_eval_quartic_batch)                \
     X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
     X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
-    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots)
+    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition)
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
     GS_API_LIST(X)
@@ -279,8 +279,14 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     // the host core below runs the trace recurrence (same values, issue order only)
     const uint64_t combination_degree = cf * T;                                        // CompositionPolynomial.ts:196-204
     const uint64_t composition_degree = std::max(combination_degree - T, T);
-    Buf zInverses(x, N * ELEM);
-    {
+    // MiMC with up to four assertions: the whole of CompositionPolynomial.evaluateAll is one kernel over the evaluation domain
+    // (gs_mimc_composition, below); otherwise the member-by-member sequence, whose trace-independent part is issued here
+    uint32_t assertions_on_r0 = 0;
+    for (uint32_t i = 0; i < job.nassertions; i++) assertions_on_r0 += job.assertions[i].reg == 0;
+    const bool fused = air.kind == 0 && E <= 32 && air.nconstraints == 1 && assertions_on_r0 == job.nassertions && job.nassertions <= 4;
+    Buf zInverses;
+    if (!fused) {
+        zInverses = Buf(x, N * ELEM);
         // ZeroPolynomial.ts:36-44 and the division of CompositionPolynomial.ts:117 in one kernel: x^T - 1 takes only E distinct values
         le16(omega, s16);
         le16(hf_pow(omega, (hfe)((T - 1) * E)), s16b);                                               // :21-23
@@ -297,7 +303,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     }
     Buf psbPowers;                                                 // x^(compositionDegree - T) over the evaluation domain
     const uint64_t b_inc = composition_degree - T;
-    if (b_inc > 0) {
+    if (b_inc > 0) {                                               // also what LinearCombination.ts:44-52 multiplies by
         psbPowers = Buf(x, N * ELEM);
         le16(hf_pow(omega, (hfe)b_inc), s16);
         x.check(A.gs_power_series(x.c, s16, N, psbPowers.p), "gs_power_series(psb)");
@@ -383,7 +389,29 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     };
 
     Buf cEval(x, N * ELEM);
-    {
+    if (fused) {
+        // K over the evaluation domain (see below), the interpolant through the assertions, then one kernel for :71-146
+        const uint64_t klen_n = air.k_len * (N / Nc);
+        Buf kPoly(x, air.k_len * ELEM), kN(x, klen_n * ELEM);
+        le16(hf_pow(omega, (hfe)(N / air.k_len)), s16);
+        x.check(A.gs_interpolate_roots(x.c, air.k_table, 1, s16, air.k_len, kPoly.p), "gs_interpolate_roots(K)");
+        le16(hf_pow(omega, (hfe)(N / klen_n)), s16);
+        x.check(A.gs_eval_polys_at_roots(x.c, kPoly.p, 1, air.k_len, s16, klen_n, kN.p), "gs_eval_polys_at_roots(K)");
+        const RegData &d = rdata[0];
+        const uint32_t m = (uint32_t)d.xs.size();
+        Bytes xs(m * 16), ys(m * 16), ipoly(m * 16);
+        for (uint32_t i = 0; i < m; i++) { le16(d.xs[i], xs.data() + 16 * i); le16(d.ys[i], ys.data() + 16 * i); }
+        if (A.gs_small_interpolate(xs.data(), ys.data(), m, ipoly.data())) fail(GS_ERR_ARG, "gs_small_interpolate failed");    // BoundaryConstraints.ts:42
+        const bool q_adjusted = groups[0].first < combination_degree;
+        Bytes co(4 * 16, 0);
+        le16(coefficients[0], co.data());
+        if (q_adjusted) le16(coefficients[1], co.data() + 16);
+        le16(coefficients[dcount], co.data() + 32);
+        if (b_inc > 0) le16(coefficients[dcount + 1], co.data() + 48);
+        le16(omega, s16);
+        x.check(A.gs_mimc_composition(x.c, pRows[0], N, T, s16, kN.p, klen_n, co.data(), q_adjusted ? combination_degree - groups[0].first : 0, b_inc,
+                                      ipoly.data(), d.at.data(), m, cEval.p), "gs_mimc_composition");
+    } else {
         // 5.1-5.3: the combined, degree-adjusted Q has degree < Nc, so its extension to the evaluation domain (:109-110) is what
         // the constraint expression gives there.  MiMC (one cheap constraint): evaluate it on all N points from the extension of P
         // already at hand — no interpolation + extension; AIR programs: on the composition domain as the reference does.
@@ -511,7 +539,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         x.check(A.gs_combine_many(x.c, ba.data(), bco.data(), bcoef, N, bc.p), "gs_combine_many(B)");
         x.check(A.gs_vec_add(x.c, dEval.p, bc.p, N, cEval.p), "gs_vec_add(C)");
     }
-    zInverses.release();
+    if (!fused) zInverses.release();
 
     // 6 ----- random linear combination (LinearCombination.ts:36-64)
     Buf lEval(x, N * ELEM);

@@ -377,6 +377,45 @@ int gs_mimc_constraints(gs_ctx *c, const void *p, uint64_t nc, uint64_t shift, c
     }
     return GS_OK;
 }
+/* the definition, line by line of the header comment: Q, the two divisors inverted with the serial Montgomery trick, the sum */
+int gs_mimc_composition(gs_ctx *c, const void *p, uint64_t n, uint64_t steps, const gs_elt *omega, const void *k, uint64_t klen,
+                        const uint8_t *coeffs, uint64_t q_inc, uint64_t b_inc, const uint8_t *ipoly, const uint64_t *root_index, uint32_t nroots,
+                        void *out) {
+    if (!is_pow2(n) || !is_pow2(steps) || steps > n || !klen) return fail(c, GS_ERR_ARG, "mimc_composition: bad sizes");
+    if (n / steps > 32 || !nroots || nroots > 4) return fail(c, GS_ERR_UNSUPPORTED, "mimc_composition: n / steps <= 32 and 1..4 assertions");
+    if (q_inc % steps || b_inc % steps) return fail(c, GS_ERR_ARG, "mimc_composition: degree increments must be multiples of the trace length");
+    fe w = fe_load(omega), d0 = fe_load(coeffs), d1 = fe_load(coeffs + FE_BYTES), b0 = fe_load(coeffs + 2 * FE_BYTES), b1 = fe_load(coeffs + 3 * FE_BYTES);
+    fe x_last = fe_exp(w, (fexp)((steps - 1) * (n / steps))), root[4];
+    for (uint32_t a = 0; a < nroots; a++) root[a] = fe_exp(w, (fexp)(root_index[a] % n));
+    uint8_t *den = (uint8_t *)malloc(2 * n * FE_BYTES);
+    fe *inv = (fe *)malloc(2 * n * sizeof(fe));
+    if (!den || !inv) { free(den); free(inv); return fail(c, GS_ERR_OOM, "malloc failed"); }
+    /* x^steps, x^q_inc, x^b_inc along the domain: running products of omega^steps, omega^q_inc, omega^b_inc */
+    const fe ws = fe_exp(w, (fexp)steps), wq = fe_exp(w, (fexp)q_inc), wb = fe_exp(w, (fexp)b_inc);
+    fe x = 1, xs = 1, xq = 1, xb = 1;
+    for (uint64_t i = 0; i < n; i++) {
+        fe zb = 1;
+        for (uint32_t a = 0; a < nroots; a++) zb = fe_mul(zb, fe_sub(x, root[a]));
+        ST(den, i, fe_sub(xs, 1));
+        ST(den, n + i, zb);
+        x = fe_mul(x, w);
+        xs = fe_mul(xs, ws);
+    }
+    batch_inv(den, 2 * n, inv);
+    x = 1;
+    for (uint64_t i = 0; i < n; i++, xq = fe_mul(xq, wq), xb = fe_mul(xb, wb)) {
+        fe pi = EL(p, i), pn = EL(p, (i + n / steps) % n);
+        fe q = fe_sub(pn, fe_add(fe_mul(fe_mul(pi, pi), pi), EL(k, i % klen)));
+        fe d = fe_mul(fe_mul(fe_mul(q, fe_add(d0, fe_mul(d1, xq))), fe_sub(x, x_last)), inv[i]);
+        fe iv = 0;
+        for (uint32_t cidx = nroots; cidx-- > 0;) iv = fe_add(fe_mul(iv, x), fe_load(ipoly + FE_BYTES * cidx));
+        fe bq = fe_mul(fe_sub(pi, iv), inv[n + i]);
+        ST(out, i, fe_add(d, fe_mul(bq, fe_add(b0, fe_mul(b1, xb)))));
+        x = fe_mul(x, w);
+    }
+    free(den); free(inv);
+    return GS_OK;
+}
 
 /* ---- MerkleTree.proveBatch restated (same layout as oracle/pyref.py MerkleTree.prove_batch) ---- */
 static int cmp_u64(const void *a, const void *b) {

@@ -84,6 +84,40 @@ def check_domain_divisions(backend, rng, logn, logsteps):
     return got.toBuffer()
 
 
+def check_mimc_composition(backend, rng, logn, logsteps, nroots):
+    """gs_mimc_composition against its definition on Python integers."""
+    import ctypes as C
+    f = field_for(backend)
+    n, steps = 1 << logn, 1 << logsteps
+    e = n // steps
+    w = f.getRootOfUnity(n)
+    inv = lambda v: pow(v, P - 2, P) if v % P else 0
+    xs = [pow(w, i, P) for i in range(n)]
+    p_eval = rand_elements(rng, n)
+    klen = 64 if n >= 64 else n
+    k = rand_elements(rng, klen)
+    d0, d1, b0, b1 = (rng.randrange(P) for _ in range(4))
+    q_inc, b_inc = steps, 2 * steps
+    roots = [0, (steps - 1) * e, 3 * e, 5 * e][:nroots]
+    ipoly = [rng.randrange(P) for _ in range(nroots)]
+    x_last = pow(w, (steps - 1) * e, P)
+    want = []
+    for i, x in enumerate(xs):
+        q = (p_eval[(i + e) % n] - (pow(p_eval[i], 3, P) + k[i % klen])) % P
+        d = q * (d0 + d1 * pow(x, q_inc, P)) * (x - x_last) * inv(pow(x, steps, P) - 1) % P
+        iv = sum(c * pow(x, j, P) for j, c in enumerate(ipoly)) % P
+        z = 1
+        for r in roots:
+            z = z * (x - pow(w, r, P)) % P
+        want.append((d + (p_eval[i] - iv) * inv(z) * (b0 + b1 * pow(x, b_inc, P))) % P)
+    vp, vk, out = f.newVectorFrom(p_eval), f.newVectorFrom(k), f.newVector(n)
+    f.backend.call('gs_mimc_composition', C.c_void_p(vp.ptr), n, steps, f.le(w), C.c_void_p(vk.ptr), klen,
+                   b''.join(f.le(v) for v in (d0, d1, b0, b1)), q_inc, b_inc, b''.join(f.le(v) for v in ipoly),
+                   (C.c_uint64 * nroots)(*roots), nroots, C.c_void_p(out.ptr))
+    assert out.toValues() == want
+    return out.toBuffer()
+
+
 def check_power_series_and_shuffles(backend, rng, n):
     f = field_for(backend)
     base = rng.randrange(2, P)

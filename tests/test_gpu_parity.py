@@ -38,6 +38,14 @@ def test_domain_divisions(hip_backend, rng, logn, logsteps):
     cases.check_domain_divisions(hip_backend, rng, logn, logsteps)
 
 
+@pytest.mark.parametrize('logn,logsteps,nroots', [(5, 2, 1), (8, 4, 2), (12, 8, 4), (16, 12, 2)])
+def test_mimc_composition(hip_backend, oracle_backend, rng, logn, logsteps, nroots):
+    import random
+    seed = rng.randrange(1 << 30)
+    assert cases.check_mimc_composition(hip_backend, random.Random(seed), logn, logsteps, nroots) == \
+        cases.check_mimc_composition(oracle_backend, random.Random(seed), logn, logsteps, nroots)
+
+
 @pytest.mark.parametrize('n', [5, 257, 40000])
 def test_inverse_with_zeros(hip_backend, rng, n):
     cases.check_inverse_with_zeros(hip_backend, rng, n)

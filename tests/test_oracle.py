@@ -17,6 +17,11 @@ def test_domain_divisions(oracle_backend, rng, logn, logsteps):
     cases.check_domain_divisions(oracle_backend, rng, logn, logsteps)
 
 
+@pytest.mark.parametrize('logn,logsteps,nroots', [(5, 2, 1), (8, 4, 2), (10, 6, 4)])
+def test_mimc_composition(oracle_backend, rng, logn, logsteps, nroots):
+    cases.check_mimc_composition(oracle_backend, rng, logn, logsteps, nroots)
+
+
 def test_inverse_with_zeros(oracle_backend, rng):
     cases.check_inverse_with_zeros(oracle_backend, rng, 257)
 
