@@ -83,7 +83,7 @@ _SIGNATURES = {
     'gs_small_eval_poly': (_int, [_bytes, _u32, _bytes, _u32, _vp]),
     'gs_mimc_trace': (_int, [_vp, _bytes, _bytes, _u32, _u64, _vp]),
     'gs_mimc_constraints': (_int, [_vp, _vp, _u64, _u64, _vp, _u64, _vp]),
-    'gs_mimc_composition': (_int, [_vp, _vp, _u64, _u64, _bytes, _vp, _u64, _bytes, _u64, _u64, _bytes, C.POINTER(_u64), _u32, _vp]),
+    'gs_mimc_composition': (_int, [_vp, _vp, _u64, _u64, _bytes, _vp, _u64, _bytes, _u64, _u64, _bytes, C.POINTER(_u64), _u32, _bytes, _vp]),
     'gs_pseudorandom_indexes': (_int, [_bytes, _u32, _u32, _u64, _u32, C.POINTER(_u64)]),
     'gs_air_trace_segments': (_int, [_vp, C.POINTER(_u32), _u32, C.POINTER(_u32), _u32, _bytes, _u32, _u32, _u32, _bytes, C.POINTER(_u32), _u32, _bytes, _u64, _u64, _vp]),
     'gs_air_trace': (_int, [_vp, C.POINTER(_u32), _u32, _bytes, _u32, _u32, _u32, _bytes, C.POINTER(_u32), _u32, _bytes, _u64, _vp]),

@@ -24,15 +24,16 @@ __global__ void k_mimc_constraints(const fe *__restrict__ p, uint64_t nc, uint64
 struct MimcCompArgs {
     fe qz[GS_MIMC_COMP_MAX_PERIOD];   // (d0 + d1 * g^(j*qm)) / (g^j - 1),  g = omega^steps
     fe bt[GS_MIMC_COMP_MAX_PERIOD];   // (b0 + b1 * g^(j*bm)) * prod_a omega^-k_a
+    fe lt[GS_MIMC_COMP_MAX_PERIOD];   // l0 + l1 * g^(j*bm)   (linear combination with P; zeros when not asked for)
     fe ipoly[GS_MIMC_COMP_MAX_ROOTS];
     uint64_t root[GS_MIMC_COMP_MAX_ROOTS];
     fe x_last;
 };
 __global__ void k_mimc_composition(const fe *__restrict__ p, uint64_t n, uint64_t shift, const fe *__restrict__ k, uint64_t klen,
                                    const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn, const fe *__restrict__ u,
-                                   MimcCompArgs a, uint32_t period, uint32_t nroots, fe *__restrict__ out) {
-    __shared__ fe qz[GS_MIMC_COMP_MAX_PERIOD], bt[GS_MIMC_COMP_MAX_PERIOD];
-    if (threadIdx.x < period) { qz[threadIdx.x] = a.qz[threadIdx.x]; bt[threadIdx.x] = a.bt[threadIdx.x]; }
+                                   MimcCompArgs a, uint32_t period, uint32_t nroots, int with_lc, fe *__restrict__ out) {
+    __shared__ fe qz[GS_MIMC_COMP_MAX_PERIOD], bt[GS_MIMC_COMP_MAX_PERIOD], lt[GS_MIMC_COMP_MAX_PERIOD];
+    if (threadIdx.x < period) { qz[threadIdx.x] = a.qz[threadIdx.x]; bt[threadIdx.x] = a.bt[threadIdx.x]; lt[threadIdx.x] = a.lt[threadIdx.x]; }
     __syncthreads();
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         fe x = tw_lo[i & ((1ull << log_lo) - 1)];
@@ -44,7 +45,9 @@ __global__ void k_mimc_composition(const fe *__restrict__ p, uint64_t n, uint64_
         for (int c = (int)nroots - 2; c >= 0; c--) iv = fe_add(fe_mul(iv, x), a.ipoly[c]);
         fe b = fe_mul(fe_sub(pi, iv), bt[i & (period - 1)]);
         for (uint32_t r = 0; r < nroots; r++) b = fe_mul(b, u[(i + n - a.root[r]) & (n - 1)]);         // / prod (x - x_a)
-        out[i] = fe_add(d, b);
+        fe r = fe_add(d, b);
+        if (with_lc) r = fe_add(r, fe_mul(pi, lt[i & (period - 1)]));                                 // wave-uniform
+        out[i] = r;
     }
 }
 
@@ -89,7 +92,7 @@ int gs_mimc_constraints(gs_ctx *c, const void *p_comp, uint64_t nc, uint64_t shi
 
 int gs_mimc_composition(gs_ctx *c, const void *p_eval, uint64_t n, uint64_t steps, const gs_elt *omega, const void *k_table, uint64_t klen,
                         const uint8_t *coeffs_host, uint64_t q_inc, uint64_t b_inc, const uint8_t *ipoly_host, const uint64_t *root_index_host,
-                        uint32_t nroots, void *out) {
+                        uint32_t nroots, const uint8_t *lc_coeffs_host, void *out) {
     if (!c || !p_eval || !omega || !k_table || !coeffs_host || !ipoly_host || !root_index_host || !out) return GS_ERR_ARG;
     if (!gs_is_pow2(n) || !gs_is_pow2(steps) || steps > n || !klen) return gs_fail(c, GS_ERR_ARG, "mimc_composition: bad sizes");
     const uint64_t period = n / steps;
@@ -104,6 +107,7 @@ int gs_mimc_composition(gs_ctx *c, const void *p_eval, uint64_t n, uint64_t step
     if (rc) return rc;
     const fe d0 = fe_from_bytes(coeffs_host), d1 = fe_from_bytes(coeffs_host + GS_ELT), b0 = fe_from_bytes(coeffs_host + 2 * GS_ELT),
              b1 = fe_from_bytes(coeffs_host + 3 * GS_ELT);
+    const fe l0 = lc_coeffs_host ? fe_from_bytes(lc_coeffs_host) : fe_zero(), l1 = lc_coeffs_host ? fe_from_bytes(lc_coeffs_host + GS_ELT) : fe_zero();
     MimcCompArgs a;
     uint64_t ksum = 0;
     for (uint32_t r = 0; r < GS_MIMC_COMP_MAX_ROOTS; r++) {
@@ -119,14 +123,15 @@ int gs_mimc_composition(gs_ctx *c, const void *p_eval, uint64_t n, uint64_t step
         if (j < period) {
             a.qz[j] = fe_mul(fe_add(d0, fe_mul(d1, gqj)), fe_inv(fe_sub(gj, fe_one())));      // j = 0: 0^-1 = 0
             a.bt[j] = fe_mul(fe_add(b0, fe_mul(b1, gbj)), scale);
+            a.lt[j] = fe_add(l0, fe_mul(l1, gbj));
         } else {
-            a.qz[j] = a.bt[j] = fe_zero();
+            a.qz[j] = a.bt[j] = a.lt[j] = fe_zero();
         }
         gj = fe_mul(gj, g); gqj = fe_mul(gqj, gq); gbj = fe_mul(gbj, gb);
     }
     a.x_last = fe_pow_u64(w, (steps - 1) * period);
     hipLaunchKernelGGL(k_mimc_composition, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const fe *)p_eval, n, period, (const fe *)k_table, klen, lo, hi,
-                       log_lo, gs_log2(n), u, a, (uint32_t)period, nroots, (fe *)out);
+                       log_lo, gs_log2(n), u, a, (uint32_t)period, nroots, lc_coeffs_host ? 1 : 0, (fe *)out);
     GS_LAUNCH_CHECK(c);
     return GS_OK;
 }

@@ -389,6 +389,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     };
 
     Buf cEval(x, N * ELEM);
+    bool lc_fused = false;                     // cEval already holds L (LinearCombination folded into the composition kernel)
     if (fused) {
         // K over the evaluation domain (see below), the interpolant through the assertions, then one kernel for :71-146
         const uint64_t klen_n = air.k_len * (N / Nc);
@@ -408,9 +409,18 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         if (q_adjusted) le16(coefficients[1], co.data() + 16);
         le16(coefficients[dcount], co.data() + 32);
         if (b_inc > 0) le16(coefficients[dcount + 1], co.data() + 48);
+        // ... and, with one committed vector, LinearCombination.computeMany (:36-64) on top: the same prng stream continues
+        const bool with_lc = V == 1;
+        Bytes lc(2 * 16, 0);
+        if (with_lc) {
+            std::vector<F> all = prng_many(eTree.root, dcount + bcoef + (b_inc > 0 ? 2 : 1));
+            le16(all[dcount + bcoef], lc.data());
+            if (b_inc > 0) le16(all[dcount + bcoef + 1], lc.data() + 16);
+        }
+        lc_fused = with_lc;
         le16(omega, s16);
         x.check(A.gs_mimc_composition(x.c, pRows[0], N, T, s16, kN.p, klen_n, co.data(), q_adjusted ? combination_degree - groups[0].first : 0, b_inc,
-                                      ipoly.data(), d.at.data(), m, cEval.p), "gs_mimc_composition");
+                                      ipoly.data(), d.at.data(), m, with_lc ? lc.data() : nullptr, cEval.p), "gs_mimc_composition");
     } else {
         // 5.1-5.3: the combined, degree-adjusted Q has degree < Nc, so its extension to the evaluation domain (:109-110) is what
         // the constraint expression gives there.  MiMC (one cheap constraint): evaluate it on all N points from the extension of P
@@ -542,8 +552,11 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     if (!fused) zInverses.release();
 
     // 6 ----- random linear combination (LinearCombination.ts:36-64)
-    Buf lEval(x, N * ELEM);
-    {
+    Buf lEval;
+    if (lc_fused) {
+        lEval = std::move(cEval);
+    } else {
+        lEval = Buf(x, N * ELEM);
         std::vector<const void *> all(eVectors.begin(), eVectors.end());
         std::vector<Buf> ps2;
         if (b_inc > 0)                                             // psIncrementalDegree = compositionDegree - T, same powers

@@ -225,12 +225,15 @@ int gs_mimc_constraints(gs_ctx *ctx, const void *p_comp, uint64_t nc, uint64_t s
  *     Q      = p[(i + n/steps) mod n] - (p[i]^3 + k[i mod klen])                      k: the cyclic register over this domain
  *     D      = Q * (d0 + d1 * x^q_inc) * (x - x_last) / (x^steps - 1)                 x_last = omega^((steps - 1) * n/steps)
  *     B      = (p[i] - I(x)) / prod_{a < nroots} (x - omega^root_index[a])            I = sum_c ipoly[c] x^c, nroots coefficients
- *     out[i] = D + B * (b0 + b1 * x^b_inc)                                            0^-1 = 0 in both divisions
- * coeffs_host = d0, d1, b0, b1; q_inc, b_inc multiples of steps; n/steps <= 32; 1 <= nroots <= 4 (GS_ERR_UNSUPPORTED otherwise:
+ *     C      = D + B * (b0 + b1 * x^b_inc)                                            0^-1 = 0 in both divisions
+ *     out[i] = C                                  when lc_coeffs_host is NULL,
+ *            = C + p[i] * (l0 + l1 * x^b_inc)     otherwise: LinearCombination.computeMany for one register, no secret registers
+ *                                                 (LinearCombination.ts:36-64; same degree increment, same prng stream)
+ * coeffs_host = d0, d1, b0, b1; lc_coeffs_host = l0, l1; q_inc, b_inc multiples of steps; n/steps <= 32; 1 <= nroots <= 4 (GS_ERR_UNSUPPORTED otherwise:
  * the member-by-member sequence gives the same values). */
 int gs_mimc_composition(gs_ctx *ctx, const void *p_eval, uint64_t n, uint64_t steps, const gs_elt *omega, const void *k_table,
                         uint64_t klen, const uint8_t *coeffs_host, uint64_t q_inc, uint64_t b_inc, const uint8_t *ipoly_host,
-                        const uint64_t *root_index_host, uint32_t nroots, void *out);
+                        const uint64_t *root_index_host, uint32_t nroots, const uint8_t *lc_coeffs_host, void *out);
 
 /* ---- AIR (air-assembly ProvingContext), generic straight-line programs -------------------------------------
  * air-assembly compiles an AIR's transition function and constraint evaluator into generated code over the field

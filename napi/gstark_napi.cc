@@ -79,7 +79,7 @@ const FnDesc kFns[] = {
     {"gs_merkle_build", "cipup"},
     {"gs_mimc_trace", "cbbiup"},
     {"gs_mimc_constraints", "cpuupup"},
-    {"gs_mimc_composition", "cpuubpubuubxip"},
+    {"gs_mimc_composition", "cpuubpubuubxibp"},
     {"gs_air_trace", "cwibiiibwibup"},
     {"gs_air_trace_segments", "cwiwibiiibwibuup"},
     {"gs_air_constraints", "cwibiiiipuupxip"},

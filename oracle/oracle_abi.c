@@ -380,7 +380,7 @@ int gs_mimc_constraints(gs_ctx *c, const void *p, uint64_t nc, uint64_t shift, c
 /* the definition, line by line of the header comment: Q, the two divisors inverted with the serial Montgomery trick, the sum */
 int gs_mimc_composition(gs_ctx *c, const void *p, uint64_t n, uint64_t steps, const gs_elt *omega, const void *k, uint64_t klen,
                         const uint8_t *coeffs, uint64_t q_inc, uint64_t b_inc, const uint8_t *ipoly, const uint64_t *root_index, uint32_t nroots,
-                        void *out) {
+                        const uint8_t *lc_coeffs, void *out) {
     if (!is_pow2(n) || !is_pow2(steps) || steps > n || !klen) return fail(c, GS_ERR_ARG, "mimc_composition: bad sizes");
     if (n / steps > 32 || !nroots || nroots > 4) return fail(c, GS_ERR_UNSUPPORTED, "mimc_composition: n / steps <= 32 and 1..4 assertions");
     if (q_inc % steps || b_inc % steps) return fail(c, GS_ERR_ARG, "mimc_composition: degree increments must be multiples of the trace length");
@@ -410,7 +410,9 @@ int gs_mimc_composition(gs_ctx *c, const void *p, uint64_t n, uint64_t steps, co
         fe iv = 0;
         for (uint32_t cidx = nroots; cidx-- > 0;) iv = fe_add(fe_mul(iv, x), fe_load(ipoly + FE_BYTES * cidx));
         fe bq = fe_mul(fe_sub(pi, iv), inv[n + i]);
-        ST(out, i, fe_add(d, fe_mul(bq, fe_add(b0, fe_mul(b1, xb)))));
+        fe r = fe_add(d, fe_mul(bq, fe_add(b0, fe_mul(b1, xb))));
+        if (lc_coeffs) r = fe_add(r, fe_mul(pi, fe_add(fe_load(lc_coeffs), fe_mul(fe_load(lc_coeffs + FE_BYTES), xb))));
+        ST(out, i, r);
         x = fe_mul(x, w);
     }
     free(den); free(inv);

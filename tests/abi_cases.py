@@ -110,12 +110,15 @@ def check_mimc_composition(backend, rng, logn, logsteps, nroots):
         for r in roots:
             z = z * (x - pow(w, r, P)) % P
         want.append((d + (p_eval[i] - iv) * inv(z) * (b0 + b1 * pow(x, b_inc, P))) % P)
-    vp, vk, out = f.newVectorFrom(p_eval), f.newVectorFrom(k), f.newVector(n)
-    f.backend.call('gs_mimc_composition', C.c_void_p(vp.ptr), n, steps, f.le(w), C.c_void_p(vk.ptr), klen,
-                   b''.join(f.le(v) for v in (d0, d1, b0, b1)), q_inc, b_inc, b''.join(f.le(v) for v in ipoly),
-                   (C.c_uint64 * nroots)(*roots), nroots, C.c_void_p(out.ptr))
-    assert out.toValues() == want
-    return out.toBuffer()
+    l0, l1 = rng.randrange(P), rng.randrange(P)
+    want_l = [(c + v * (l0 + l1 * pow(x, b_inc, P))) % P for c, v, x in zip(want, p_eval, xs)]
+    vp, vk, out, out_l = f.newVectorFrom(p_eval), f.newVectorFrom(k), f.newVector(n), f.newVector(n)
+    args = (C.c_void_p(vp.ptr), n, steps, f.le(w), C.c_void_p(vk.ptr), klen, b''.join(f.le(v) for v in (d0, d1, b0, b1)), q_inc, b_inc,
+            b''.join(f.le(v) for v in ipoly), (C.c_uint64 * nroots)(*roots), nroots)
+    f.backend.call('gs_mimc_composition', *args, None, C.c_void_p(out.ptr))
+    f.backend.call('gs_mimc_composition', *args, f.le(l0) + f.le(l1), C.c_void_p(out_l.ptr))
+    assert out.toValues() == want and out_l.toValues() == want_l
+    return out.toBuffer() + out_l.toBuffer()
 
 
 def check_power_series_and_shuffles(backend, rng, n):
