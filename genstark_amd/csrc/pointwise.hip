@@ -358,6 +358,31 @@ __global__ void k_quartic_eval(const fe *__restrict__ polys, uint64_t rows, fe x
     }
 }
 
+// One FRI folding step straight from a column (the transposed matrix is never written): row r of transposeVector(column, 4) is
+// (column[r], column[r + rows], column[r + 2 rows], column[r + 3 rows]) at x_r zeta^c; the cubic through them evaluated at X is
+// (u0 + u1 t + u2 t^2 + u3 t^3) / 4 with u = the inverse 4-point DFT above and t = X / x_r.
+__global__ void k_fri_fold(const fe *__restrict__ column, uint64_t rows, uint64_t step, uint64_t n, const fe *__restrict__ tw_lo,
+                           const fe *__restrict__ tw_hi, int log_lo, int logn, fe zeta_inv, fe inv4, fe X, fe *__restrict__ out) {
+    for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * blockDim.x) {
+        fe y0 = column[r], y1 = column[r + rows], y2 = column[r + 2 * rows], y3 = column[r + 3 * rows];
+        fe s0 = fe_add(y0, y2), s1 = fe_sub(y0, y2), s2 = fe_add(y1, y3);
+        fe s3 = fe_mul(fe_sub(y1, y3), zeta_inv);
+        fe u0 = fe_add(s0, s2), u2 = fe_sub(s0, s2), u1 = fe_add(s1, s3), u3 = fe_sub(s1, s3);
+        uint64_t e = (r * step) & (n - 1);
+        e = e ? n - e : 0;
+        fe t = X;                                      // X * x_r^-1
+        if (e) {
+            fe xi = tw_lo[e & ((1ull << log_lo) - 1)];
+            if (logn > log_lo) xi = fe_mul(xi, tw_hi[e >> log_lo]);
+            t = fe_mul(X, xi);
+        }
+        fe v = fe_add(fe_mul(u3, t), u2);
+        v = fe_add(fe_mul(v, t), u1);
+        v = fe_add(fe_mul(v, t), u0);
+        out[r] = fe_mul(v, inv4);
+    }
+}
+
 // ---- C ABI ----------------------------------------------------------------------------------------------
 #define CHECK3(c, a, b, o) \
     if (!(c) || !(a) || !(b) || !(o)) return GS_ERR_ARG
@@ -570,6 +595,24 @@ int gs_interpolate_quartic_domain(gs_ctx *c, const gs_elt *omega, uint64_t n, ui
     fe inv4 = fe_inv(fe_from_u64(4));
     hipLaunchKernelGGL(k_quartic_interp_domain, dim3(gs_grid(rows)), dim3(256), 0, c->stream, (const fe *)ys, rows, step, n, lo, hi,
                        log_lo, gs_log2(n), zeta_inv, inv4, (fe *)out);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
+int gs_fri_fold(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const gs_elt *x, void *out) {
+    if (!c || !omega || !column || !x || !out) return GS_ERR_ARG;
+    if (!gs_is_pow2(n) || n < 4 || m < 4 || m * step != n) return gs_fail(c, GS_ERR_ARG, "fri_fold: column length * step != n");
+    if (column == out) return gs_fail(c, GS_ERR_ARG, "fri_fold: output must not alias the column");
+    fe w = fe_from_bytes(omega);
+    const fe *lo, *hi;
+    int log_lo;
+    int rc = gs_plan_pow_tables(c, w, n, &lo, &hi, &log_lo);
+    if (rc) return rc;
+    fe zeta = fe_pow_u64(w, n / 4);
+    fe zeta_inv = fe_mul(fe_mul(zeta, zeta), zeta);  // zeta^3 = zeta^-1
+    fe inv4 = fe_inv(fe_from_u64(4));
+    hipLaunchKernelGGL(k_fri_fold, dim3(gs_grid(m / 4)), dim3(256), 0, c->stream, (const fe *)column, m / 4, step, n, lo, hi, log_lo, gs_log2(n),
+                       zeta_inv, inv4, fe_from_bytes(x), (fe *)out);
     GS_LAUNCH_CHECK(c);
     return GS_OK;
 }

@@ -34,7 +34,7 @@ namespace {
     X(gs_eval_polys_at_roots) X(gs_interpolate_roots) X(gs_interpolate_quartic_domain) X(gs_eval_quartic_batch)                \
     X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
     X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
-    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition)
+    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold)
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
     GS_API_LIST(X)
@@ -193,6 +193,24 @@ std::vector<Bytes> gather(Ctx &x, const void *src, uint64_t rec, const std::vect
     for (size_t i = 0; i < idx.size(); i++) out.emplace_back(raw.begin() + i * rec, raw.begin() + (i + 1) * rec);
     return out;
 }
+// rows of transposeVector(column, 4) without the transposed copy: row r = column[r], column[r + rows], column[r + 2 rows], column[r + 3 rows]
+std::vector<Bytes> gather_rows4(Ctx &x, const void *column, uint64_t rows, const std::vector<uint64_t> &positions) {
+    std::vector<uint64_t> idx;
+    for (uint64_t r : positions)
+        for (uint64_t c = 0; c < 4; c++) idx.push_back(r + c * rows);
+    std::vector<Bytes> out;
+    if (idx.empty()) return out;
+    Bytes raw(idx.size() * ELEM);
+    x.check(A.gs_gather(x.c, column, ELEM, idx.data(), idx.size(), raw.data()), "gs_gather");
+    for (size_t i = 0; i < positions.size(); i++) out.emplace_back(raw.begin() + i * 4 * ELEM, raw.begin() + (i + 1) * 4 * ELEM);
+    return out;
+}
+// digests of those rows (Hash.digestValues of the transposed matrix, LowDegreeProver.ts:45,201) = mergeVectorRows of the four quarters
+void hash_rows4(Ctx &x, int alg, const void *column, uint64_t rows, void *digests) {
+    const void *quarters[4];
+    for (uint64_t c = 0; c < 4; c++) quarters[c] = (const uint8_t *)column + c * rows * ELEM;
+    x.check(A.gs_hash_merge_rows(x.c, (gs_hash_alg)alg, quarters, 4, rows, digests), "gs_hash_merge_rows(rows of 4)");
+}
 std::vector<uint64_t> unique_in_order(const std::vector<uint64_t> &v) {
     std::vector<uint64_t> out;
     std::map<uint64_t, bool> seen;
@@ -244,11 +262,11 @@ int gs_prover_prove(gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, 
 namespace {
 
 struct Layer {           // one FRI layer: the tree / rows it queries and the child it produced
-    Tree *pTree;         // tree over polyValues rows
-    const Buf *polyValues;
-    uint64_t rows;       // rows of polyValues (4 columns)
+    Tree *pTree;         // tree over the rows of transposeVector(column, 4)
+    const void *column;  // the layer's values in natural order (4 * rows of them); rows are read strided, never transposed
+    uint64_t rows;
     Tree cTree;          // tree over the next layer's rows
-    Buf newPolyValues;
+    Buf next;            // the folded column: `rows` values
     uint64_t column_length;
 };
 
@@ -270,10 +288,8 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     const F comp_rou = hf_pow(omega, (hfe)(N / Nc)), exec_rou = hf_pow(omega, (hfe)E);
     uint8_t s16[16], s16b[16];
 
-    // 1 ----- evaluation context (lib/Stark.ts:92-94): the domains
-    Buf evalDomain(x, N * ELEM);
-    le16(omega, s16);
-    x.check(A.gs_power_series(x.c, s16, N, evalDomain.p), "gs_power_series(evaluation domain)");
+    // 1 ----- evaluation context (lib/Stark.ts:92-94): the kernels below derive domain points from omega; the evaluation domain is
+    // materialised only by the general Z(x) sequence
 
     // work of CompositionPolynomial.evaluateAll that does not depend on the trace goes first: the device computes it while
     // the host core below runs the trace recurrence (same values, issue order only)
@@ -293,7 +309,9 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         if (E <= 32) {
             x.check(A.gs_zero_poly_inverses(x.c, s16, N, T, s16b, zInverses.p), "gs_zero_poly_inverses");
         } else {
-            Buf xToTheSteps(x, N * ELEM), num(x, N * ELEM), den(x, N * ELEM);
+            Buf evalDomain(x, N * ELEM), xToTheSteps(x, N * ELEM), num(x, N * ELEM), den(x, N * ELEM);
+            le16(omega, s16);
+            x.check(A.gs_power_series(x.c, s16, N, evalDomain.p), "gs_power_series(evaluation domain)");
             x.check(A.gs_pluck(x.c, evalDomain.p, N, T, N, xToTheSteps.p), "gs_pluck");                // ZeroPolynomial.ts:40
             le16(1, s16);
             x.check(A.gs_vec_sub_scalar(x.c, xToTheSteps.p, s16, N, num.p), "gs_vec_sub_scalar");
@@ -303,7 +321,8 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     }
     Buf psbPowers;                                                 // x^(compositionDegree - T) over the evaluation domain
     const uint64_t b_inc = composition_degree - T;
-    if (b_inc > 0) {                                               // also what LinearCombination.ts:44-52 multiplies by
+    const bool lc_folds = fused && R + air.nsecret == 1;           // LinearCombination folded into the composition kernel too
+    if (b_inc > 0 && !lc_folds) {                                  // also what LinearCombination.ts:44-52 multiplies by
         psbPowers = Buf(x, N * ELEM);
         le16(hf_pow(omega, (hfe)b_inc), s16);
         x.check(A.gs_power_series(x.c, s16, N, psbPowers.p), "gs_power_series(psb)");
@@ -410,7 +429,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         le16(coefficients[dcount], co.data() + 32);
         if (b_inc > 0) le16(coefficients[dcount + 1], co.data() + 48);
         // ... and, with one committed vector, LinearCombination.computeMany (:36-64) on top: the same prng stream continues
-        const bool with_lc = V == 1;
+        const bool with_lc = lc_folds;
         Bytes lc(2 * 16, 0);
         if (with_lc) {
             std::vector<F> all = prng_many(eTree.root, dcount + bcoef + (b_inc > 0 ? 2 : 1));
@@ -578,12 +597,12 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
 
     // 7 ----- low-degree proof (LowDegreeProver.ts:39-68, 176-221)
     if (N < 128) fail(GS_ERR_ARG, "Invalid array length");
-    Buf polyValues0(x, N * ELEM);
-    x.check(A.gs_transpose_vector(x.c, lEval.p, N, 4, 1, polyValues0.p), "gs_transpose_vector");
+    // transposeVector(v, 4) is never materialised: row r of it is v[r], v[r + rows], v[r + 2 rows], v[r + 3 rows], which the hashing,
+    // folding and gathering below read in place
     Tree pTree0;
     {
         Buf h(x, N / 4 * DIGEST);
-        x.check(A.gs_hash_digest_values(x.c, (gs_hash_alg)alg, polyValues0.p, 4 * ELEM, N / 4, h.p), "gs_hash_digest_values");
+        hash_rows4(x, alg, lEval.p, N / 4, h.p);                                                      // :45
         pTree0 = build_tree(x, alg, std::move(h), N / 4);
     }
     const uint32_t exe_count = (uint32_t)std::min<uint64_t>(job.exe_query_count, N - N / E);
@@ -592,42 +611,35 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     for (uint64_t p : exe_positions) lc_positions.push_back(p % (N / 4));
     lc_positions = unique_in_order(lc_positions);                                                 // LowDegreeProver.ts:302-309
     MerkleProof lcProof = prove_batch(x, pTree0, lc_positions);
-    lcProof.values = gather(x, polyValues0.p, 4 * ELEM, lc_positions);
+    lcProof.values = gather_rows4(x, lEval.p, N / 4, lc_positions);
 
     // layers (:176-221): the loop below is the recursion unrolled; queries are answered afterwards
     std::vector<Layer> layers;
     Tree *pTree = &pTree0;
-    const Buf *polyValues = &polyValues0;
-    const Buf *column_src = &lEval;     // the vector the current polyValues was transposed from (the remainder at the end)
-    Buf column_store;
-    uint64_t len = N;                   // elements in polyValues
+    const void *column_src = lEval.p;   // the current layer's values in natural order (the remainder at the end)
+    uint64_t len = N;
     uint64_t max_degree_plus1 = composition_degree;
     uint32_t depth = 0;
     layers.reserve(32);
     while (len > 256) {
         const uint64_t rows = len / 4;
-        Buf polys(x, len * ELEM), column(x, rows * ELEM);
-        le16(omega, s16);
         uint64_t step = 1;
         for (uint32_t d = 0; d < depth; d++) step *= 4;
-        x.check(A.gs_interpolate_quartic_domain(x.c, s16, N, step, polyValues->p, rows, polys.p), "gs_interpolate_quartic_domain");
-        le16(prng_one(pTree->root), s16b);                                                        // :194
-        x.check(A.gs_eval_quartic_batch(x.c, polys.p, rows, s16b, column.p), "gs_eval_quartic_batch");
         layers.emplace_back();
         Layer &L = layers.back();
         L.pTree = pTree;
-        L.polyValues = polyValues;
+        L.column = column_src;
         L.rows = rows;
         L.column_length = rows;
-        L.newPolyValues = Buf(x, rows * ELEM);
-        x.check(A.gs_transpose_vector(x.c, column.p, rows, 4, 1, L.newPolyValues.p), "gs_transpose_vector");
+        L.next = Buf(x, rows * ELEM);
+        le16(omega, s16);
+        le16(prng_one(pTree->root), s16b);                                                        // :194
+        x.check(A.gs_fri_fold(x.c, s16, N, step, column_src, len, s16b, L.next.p), "gs_fri_fold");     // :189-198
         Buf h(x, rows / 4 * DIGEST);
-        x.check(A.gs_hash_digest_values(x.c, (gs_hash_alg)alg, L.newPolyValues.p, 4 * ELEM, rows / 4, h.p), "gs_hash_digest_values");
+        hash_rows4(x, alg, L.next.p, rows / 4, h.p);                                                  // :201
         L.cTree = build_tree(x, alg, std::move(h), rows / 4);
-        column_store = std::move(column);
-        column_src = &column_store;
+        column_src = L.next.p;
         pTree = &L.cTree;
-        polyValues = &L.newPolyValues;
         len = rows;
         max_degree_plus1 /= 4;
         depth++;
@@ -636,7 +648,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     std::vector<F> remainder(len);
     {
         Bytes raw(len * ELEM);
-        x.check(A.gs_download(x.c, raw.data(), column_src->p, len * ELEM), "gs_download(remainder)");
+        x.check(A.gs_download(x.c, raw.data(), column_src, len * ELEM), "gs_download(remainder)");
         for (uint64_t i = 0; i < len; i++) remainder[i] = from16(raw.data() + 16 * i);
         // verifyRemainder (:223-252)
         F rou = omega;
@@ -675,9 +687,9 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         Component &c = components[d];
         c.columnRoot = L.cTree.root;
         c.columnProof = prove_batch(x, L.cTree, aug);
-        c.columnProof.values = gather(x, L.newPolyValues.p, 4 * ELEM, aug);
+        c.columnProof.values = gather_rows4(x, L.next.p, L.column_length / 4, aug);
         c.polyProof = prove_batch(x, *L.pTree, positions);
-        c.polyProof.values = gather(x, L.polyValues->p, 4 * ELEM, positions);
+        c.polyProof.values = gather_rows4(x, L.column, L.rows, positions);
     }
 
     // 8 ----- spot checks of the evaluation tree (lib/Stark.ts:146-152, 274-296)

@@ -163,6 +163,10 @@ int gs_interpolate_quartic_domain(gs_ctx *ctx, const gs_elt *omega, uint64_t n, 
                                   const void *ys, uint64_t rows, void *out);
 /* evalQuarticBatch(polys, x) -> Vector of rows values.  LowDegreeProver.ts:140,195 */
 int gs_eval_quartic_batch(gs_ctx *ctx, const void *polys, uint64_t rows, const gs_elt *x, void *out);
+/* One FRI folding step on a column of m values (LowDegreeProver.ts:189-198: transposeVector(column, 4) + interpolateQuarticBatch +
+ * evalQuarticBatch fused — the transposed matrix and the cubics are never written): rows = m/4, m * step = n,
+ *     out[r] = P_r(x),  P_r the cubic through (omega^((r + c*rows) * step), column[r + c*rows]), c < 4. */
+int gs_fri_fold(gs_ctx *ctx, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const gs_elt *x, void *out);
 
 /* ---- hashing / Merkle (merkle package) --------------------------------------------------------- */
 /* Hash.digest(Buffer) on host bytes (verifier side; lib/utils/index.ts:37) — runs on the device

@@ -73,6 +73,7 @@ const FnDesc kFns[] = {
     {"gs_interpolate_quartic_batch", "cppup"},
     {"gs_interpolate_quartic_domain", "cbuupup"},
     {"gs_eval_quartic_batch", "cpubp"},
+    {"gs_fri_fold", "cbuupubp"},
     {"gs_hash_digest", "cibuo"},
     {"gs_hash_merge_rows", "ciaiup"},
     {"gs_hash_digest_values", "cipuup"},

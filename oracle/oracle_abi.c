@@ -323,6 +323,19 @@ int gs_interpolate_quartic_domain(gs_ctx *c, const gs_elt *omega, uint64_t n, ui
     }
     return GS_OK;
 }
+int gs_fri_fold(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const gs_elt *xp, void *out) {
+    if (m < 4 || m * step != n) return fail(c, GS_ERR_ARG, "fri_fold: column length * step != n");
+    fe w = fe_load(omega), X = fe_load(xp);
+    uint64_t rows = m / 4;
+    for (uint64_t r = 0; r < rows; r++) {
+        fe x[4], y[4], k[4], s = 0;
+        for (int j = 0; j < 4; j++) { x[j] = fe_exp(w, (fexp)((r + (uint64_t)j * rows) * step)); y[j] = EL(column, r + (uint64_t)j * rows); }
+        lagrange4(x, y, k);
+        for (int j = 3; j >= 0; j--) s = fe_add(fe_mul(s, X), k[j]);
+        ST(out, r, s);
+    }
+    return GS_OK;
+}
 int gs_eval_quartic_batch(gs_ctx *c, const void *polys, uint64_t rows, const gs_elt *x, void *out) {
     (void)c; fe xx = fe_load(x);
     for (uint64_t r = 0; r < rows; r++) {

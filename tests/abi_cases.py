@@ -84,6 +84,30 @@ def check_domain_divisions(backend, rng, logn, logsteps):
     return got.toBuffer()
 
 
+def check_fri_fold(backend, rng, logn, depth):
+    """gs_fri_fold == transposeVector + interpolateQuarticBatch + evalQuarticBatch (the members it fuses), on layer `depth`."""
+    import ctypes as C
+    f = field_for(backend)
+    n = 1 << logn
+    step = 4 ** depth
+    m = n // step
+    w = f.getRootOfUnity(n)
+    column = f.newVectorFrom(rand_elements(rng, m))
+    x = rng.randrange(P)
+    out = f.newVector(m // 4)
+    f.backend.call('gs_fri_fold', f.le(w), n, step, C.c_void_p(column.ptr), m, f.le(x), C.c_void_p(out.ptr))
+    domain = f.getPowerSeries(w, n)
+    xs = f.transposeVector(domain, 4, step)
+    ys = f.transposeVector(column, 4)
+    want = f.evalQuarticBatch(f.interpolateQuarticBatch(xs, ys), x)
+    assert out.toBuffer() == want.toBuffer()
+    vals, rows = column.toValues(), m // 4
+    for r in (0, 1, rows - 1):
+        pts = [(pow(w, (r + c * rows) * step, P), vals[r + c * rows]) for c in range(4)]
+        assert out.getValue(r) == PF.lagrange_eval(pts, x) if hasattr(PF, 'lagrange_eval') else True
+    return out.toBuffer()
+
+
 def check_mimc_composition(backend, rng, logn, logsteps, nroots):
     """gs_mimc_composition against its definition on Python integers."""
     import ctypes as C

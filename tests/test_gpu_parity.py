@@ -46,6 +46,15 @@ def test_mimc_composition(hip_backend, oracle_backend, rng, logn, logsteps, nroo
         cases.check_mimc_composition(oracle_backend, random.Random(seed), logn, logsteps, nroots)
 
 
+@pytest.mark.parametrize('logn,depth', [(4, 0), (8, 1), (14, 0), (14, 3), (20, 1)])
+def test_fri_fold(hip_backend, oracle_backend, rng, logn, depth):
+    import random
+    seed = rng.randrange(1 << 30)
+    got = cases.check_fri_fold(hip_backend, random.Random(seed), logn, depth)
+    if logn <= 14:
+        assert got == cases.check_fri_fold(oracle_backend, random.Random(seed), logn, depth)
+
+
 @pytest.mark.parametrize('n', [5, 257, 40000])
 def test_inverse_with_zeros(hip_backend, rng, n):
     cases.check_inverse_with_zeros(hip_backend, rng, n)

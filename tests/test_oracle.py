@@ -22,6 +22,11 @@ def test_mimc_composition(oracle_backend, rng, logn, logsteps, nroots):
     cases.check_mimc_composition(oracle_backend, rng, logn, logsteps, nroots)
 
 
+@pytest.mark.parametrize('logn,depth', [(4, 0), (8, 0), (8, 1), (10, 2)])
+def test_fri_fold(oracle_backend, rng, logn, depth):
+    cases.check_fri_fold(oracle_backend, rng, logn, depth)
+
+
 def test_inverse_with_zeros(oracle_backend, rng):
     cases.check_inverse_with_zeros(oracle_backend, rng, 257)
 
