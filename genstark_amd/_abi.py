@@ -49,6 +49,8 @@ _SIGNATURES = {
     'gs_upload': (_int, [_vp, _vp, _bytes, _u64]),
     'gs_download': (_int, [_vp, _vp, _vp, _u64]),
     'gs_copy': (_int, [_vp, _vp, _vp, _u64]),
+    'gs_defer_begin': (_int, [_vp]),
+    'gs_defer_end': (_int, [_vp]),
     'gs_gather': (_int, [_vp, _vp, _u64, C.POINTER(_u64), _u64, _vp]),
     'gs_power_series': (_int, [_vp, _bytes, _u64, _vp]),
     'gs_vec_add': (_int, [_vp, _vp, _vp, _u64, _vp]),

@@ -49,6 +49,12 @@ struct gs_ctx {
     void *h_stage_dev = nullptr;  // the device-side address of h_stage
     void *d_stage = nullptr;
     uint64_t stage_bytes = 0;
+    // deferred read-backs (gs_defer_begin / gs_defer_end): gathers only record the device addresses of the 16-byte words they want;
+    // gs_defer_end fetches all of them with ONE kernel and one synchronisation
+    struct DeferredCopy { void *dst; uint64_t first_word, bytes; };
+    bool defer = false;
+    std::vector<uint64_t> defer_addrs;
+    std::vector<DeferredCopy> defer_copies;
     // pinned buffer the host-side trace generators write into; it is uploaded asynchronously, `trace_done` marks the end
     // of the last upload so the next trace waits for THAT copy only, not for whatever else is queued on the stream
     void *h_trace = nullptr;
@@ -76,6 +82,7 @@ static inline fe fe_from_u64(uint64_t v) { return fe_make((uint32_t)v, (uint32_t
 
 // staging helpers (ctx.hip)
 int gs_stage_reserve(gs_ctx *c, uint64_t bytes);
+int gs_defer_flush(gs_ctx *c);                                    // fetch and deliver every queued read-back
 int gs_trace_begin(gs_ctx *c, uint64_t bytes);   // h_trace has >= bytes and no upload of it is in flight
 int gs_trace_end(gs_ctx *c);                     // call after the last hipMemcpyAsync out of h_trace
 // temp device block from the cache (same lifetime rules as gs_alloc/gs_free)

@@ -154,7 +154,38 @@ int gs_copy(gs_ctx *c, void *dst, const void *src, uint64_t bytes) {
 
 }  // extern "C"
 
+// out[t] = the 16-byte word at device address addr[t] (addresses and results in mapped pinned host memory)
+__global__ void k_gather_words(const uint64_t *__restrict__ addr, uint64_t total, uint4 *__restrict__ out) {
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x)
+        out[t] = *reinterpret_cast<const uint4 *>(addr[t]);
+}
+
+int gs_defer_flush(gs_ctx *c) {
+    const uint64_t total = c->defer_addrs.size();
+    if (!total) { c->defer_copies.clear(); return GS_OK; }
+    const bool was = c->defer;
+    c->defer = false;                                     // the staging buffer is ours now
+    const uint64_t addr_bytes = (total * 8 + 255) & ~(uint64_t)255;
+    int rc = gs_stage_reserve(c, addr_bytes + total * 16);
+    c->defer = was;
+    if (rc) return rc;
+    memcpy(c->h_stage, c->defer_addrs.data(), total * 8);
+    hipLaunchKernelGGL(k_gather_words, dim3(gs_grid(total)), dim3(256), 0, c->stream, (const uint64_t *)c->h_stage_dev, total,
+                       (uint4 *)((uint8_t *)c->h_stage_dev + addr_bytes));
+    GS_LAUNCH_CHECK(c);
+    GS_HIP(c, hipStreamSynchronize(c->stream));
+    const uint8_t *words = (const uint8_t *)c->h_stage + addr_bytes;
+    for (auto &d : c->defer_copies) memcpy(d.dst, words + d.first_word * 16, d.bytes);
+    c->defer_addrs.clear();
+    c->defer_copies.clear();
+    return GS_OK;
+}
+
 int gs_stage_reserve(gs_ctx *c, uint64_t bytes) {
+    if (c->defer && !c->defer_addrs.empty()) {            // another user of the staging buffer inside a deferral window
+        int rc = gs_defer_flush(c);
+        if (rc) return rc;
+    }
     if (bytes <= c->stage_bytes) return GS_OK;
     uint64_t nb = 1 << 16;
     while (nb < bytes) nb <<= 1;
@@ -220,6 +251,13 @@ extern "C" int gs_gather(gs_ctx *c, const void *src, uint64_t rec_bytes, const u
     if (!c || !src || !rec_bytes || (!idx_host && count) || (!host_out && count)) return GS_ERR_ARG;
     if (!count) return GS_OK;
     uint64_t idx_bytes = (count * 8 + 255) & ~(uint64_t)255, data_bytes = count * rec_bytes;
+    if (c->defer && rec_bytes % 16 == 0 && ((uintptr_t)src % 16) == 0) {
+        // inside a deferral window: only note which words are wanted; gs_defer_end fetches them all at once
+        c->defer_copies.push_back({host_out, (uint64_t)c->defer_addrs.size(), data_bytes});
+        for (uint64_t i = 0; i < count; i++)
+            for (uint64_t w = 0; w < rec_bytes; w += 16) c->defer_addrs.push_back((uint64_t)(uintptr_t)src + idx_host[i] * rec_bytes + w);
+        return GS_OK;
+    }
     int rc = gs_stage_reserve(c, idx_bytes + data_bytes);
     if (rc) return rc;
     // zero-copy: the kernel reads the index list from, and writes the (tiny) result into, mapped pinned host memory:
@@ -240,4 +278,21 @@ extern "C" int gs_gather(gs_ctx *c, const void *src, uint64_t rec_bytes, const u
     GS_HIP(c, hipStreamSynchronize(c->stream));
     memcpy(host_out, h_out, data_bytes);
     return GS_OK;
+}
+
+extern "C" int gs_defer_begin(gs_ctx *c) {
+    if (!c) return GS_ERR_ARG;
+    if (c->defer) return gs_fail(c, GS_ERR_ARG, "defer_begin: already deferring");
+    c->defer = true;
+    c->defer_addrs.clear();
+    c->defer_copies.clear();
+    return GS_OK;
+}
+
+extern "C" int gs_defer_end(gs_ctx *c) {
+    if (!c) return GS_ERR_ARG;
+    if (!c->defer) return gs_fail(c, GS_ERR_ARG, "defer_end: not deferring");
+    int rc = gs_defer_flush(c);
+    c->defer = false;
+    return rc;
 }

@@ -17,6 +17,8 @@
 
 #include <algorithm>
 #include <map>
+#include <chrono>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -34,7 +36,7 @@ namespace {
     X(gs_eval_polys_at_roots) X(gs_interpolate_roots) X(gs_interpolate_quartic_domain) X(gs_eval_quartic_batch)                \
     X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
     X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
-    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold)
+    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_defer_begin) X(gs_defer_end)
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
     GS_API_LIST(X)
@@ -121,31 +123,31 @@ std::vector<uint64_t> query_indexes(const Bytes &seed, uint32_t count, uint64_t 
 }
 
 // ---- Merkle batch proofs and the wire format (lib/Serializer.ts:35-79, lib/utils/serialization.ts) ------------------
-struct MerkleProof {
-    std::vector<Bytes> values;
-    std::vector<std::vector<Bytes>> nodes;
+struct MerkleProof {          // flat: one allocation per part instead of one per digest (a proof holds ~10^4 of them)
+    Bytes values;              // nvalues records of value_size bytes (the queried rows)
+    uint64_t value_size = 0;
+    uint32_t nvalues = 0;
+    Bytes nodes;               // digests, column after column
+    std::vector<uint32_t> lens;
     uint8_t depth = 0;
 };
-void write_array(Bytes &out, const std::vector<Bytes> &a) {
-    if (a.empty()) fail(GS_ERR_ARG, "Array cannot be zero-length");
-    if (a.size() > MAX_ARRAY) fail(GS_ERR_ARG, "Array length (%zu) cannot exceed 256", a.size());
-    out.push_back(a.size() == MAX_ARRAY ? 0 : (uint8_t)a.size());
-    for (auto &v : a) out.insert(out.end(), v.begin(), v.end());
-}
-void write_matrix(Bytes &out, const std::vector<std::vector<Bytes>> &m, uint64_t leaf_size) {
-    if (m.size() > MAX_ARRAY) fail(GS_ERR_ARG, "Matrix column count (%zu) cannot exceed 256", m.size());
-    out.push_back(m.size() == MAX_ARRAY ? 0 : (uint8_t)m.size());
-    for (auto &col : m) {
-        if (col.size() >= 128) fail(GS_ERR_ARG, "Matrix column length (%zu) cannot exceed 127", col.size());
-        uint8_t type = (!col.empty() && col[0].size() == leaf_size) ? 1 : 0;
-        out.push_back((uint8_t)((col.size() << 1) | type));
-    }
-    for (auto &col : m)
-        for (auto &v : col) out.insert(out.end(), v.begin(), v.end());
-}
 void write_merkle_proof(Bytes &out, const MerkleProof &p, uint64_t leaf_size) {
-    write_array(out, p.values);
-    write_matrix(out, p.nodes, leaf_size);
+    // values: lib/utils/serialization.ts writeArray
+    if (!p.nvalues) fail(GS_ERR_ARG, "Array cannot be zero-length");
+    if (p.nvalues > MAX_ARRAY) fail(GS_ERR_ARG, "Array length (%u) cannot exceed 256", p.nvalues);
+    out.push_back(p.nvalues == MAX_ARRAY ? 0 : (uint8_t)p.nvalues);
+    out.insert(out.end(), p.values.begin(), p.values.begin() + (uint64_t)p.nvalues * p.value_size);
+    // nodes: writeMatrix
+    if (p.lens.size() > MAX_ARRAY) fail(GS_ERR_ARG, "Matrix column count (%zu) cannot exceed 256", p.lens.size());
+    out.push_back(p.lens.size() == MAX_ARRAY ? 0 : (uint8_t)p.lens.size());
+    uint64_t total = 0;
+    for (uint32_t len : p.lens) {
+        if (len >= 128) fail(GS_ERR_ARG, "Matrix column length (%u) cannot exceed 127", len);
+        const uint8_t type = (len && DIGEST == leaf_size) ? 1 : 0;
+        out.push_back((uint8_t)((len << 1) | type));
+        total += len;
+    }
+    out.insert(out.end(), p.nodes.begin(), p.nodes.begin() + total * DIGEST);
     out.push_back(p.depth);
 }
 
@@ -164,46 +166,57 @@ Tree build_tree(Ctx &x, int alg, Buf &&leaves, uint64_t n) {
     x.check(A.gs_download(x.c, t.root.data(), t.nodes.at(DIGEST), DIGEST), "gs_download(root)");
     return t;
 }
+// The query answers of a proof are issued inside one deferral window (gs_defer_begin / gs_defer_end): the calls below queue the
+// device work into buffers that stay put (std::deque) and `unpack` builds the proof objects after the single synchronisation.
+struct Readbacks {
+    struct Batch { MerkleProof *mp; Bytes digests; uint32_t ncols = 0; };
+    struct Rows { MerkleProof *mp; Bytes raw; uint64_t rec = 0; uint32_t n = 0; };
+    std::deque<Batch> batches;
+    std::deque<Rows> rows;
+    void prove_batch(Ctx &x, const Tree &t, const std::vector<uint64_t> &idx, MerkleProof *mp) {
+        int depth = 0;
+        while ((1ull << depth) < t.n) depth++;
+        mp->depth = (uint8_t)depth;
+        const uint32_t count = (uint32_t)idx.size();
+        if (!count) return;
+        batches.emplace_back();
+        Batch &b = batches.back();
+        b.mp = mp;
+        const uint64_t cap = (uint64_t)count * (depth ? depth : 1);
+        b.digests.resize(count * DIGEST);         // the leaf digests: the proof carries the rows themselves instead (gather below)
+        mp->nodes.resize(cap * DIGEST);
+        mp->lens.assign(count, 0);
+        x.check(A.gs_merkle_prove_batch(x.c, t.leaves.p, t.nodes.p, t.n, idx.data(), count, b.digests.data(), &b.ncols, mp->lens.data(), mp->nodes.data(), cap),
+                "gs_merkle_prove_batch");
+        mp->lens.resize(b.ncols);                 // the shape is known at once; the digests arrive with gs_defer_end
+    }
+    void gather(Ctx &x, const void *src, uint64_t rec, const std::vector<uint64_t> &idx, uint64_t per_row, MerkleProof *mp) {
+        if (idx.empty()) return;
+        mp->values.resize(idx.size() * rec);
+        mp->value_size = rec * per_row;
+        mp->nvalues = (uint32_t)(idx.size() / per_row);
+        x.check(A.gs_gather(x.c, src, rec, idx.data(), idx.size(), mp->values.data()), "gs_gather");
+    }
+    // rows of transposeVector(column, 4), read strided (see gather_rows4)
+    void gather_rows4(Ctx &x, const void *column, uint64_t nrows, const std::vector<uint64_t> &positions, MerkleProof *mp) {
+        std::vector<uint64_t> idx;
+        idx.reserve(positions.size() * 4);
+        for (uint64_t r : positions)
+            for (uint64_t c = 0; c < 4; c++) idx.push_back(r + c * nrows);
+        gather(x, column, ELEM, idx, 4, mp);
+    }
+};
+
 MerkleProof prove_batch(Ctx &x, const Tree &t, const std::vector<uint64_t> &idx) {
     MerkleProof mp;
-    int depth = 0;
-    while ((1ull << depth) < t.n) depth++;
-    mp.depth = (uint8_t)depth;
-    const uint32_t count = (uint32_t)idx.size();
-    if (!count) return mp;
-    const uint64_t cap = (uint64_t)count * (depth ? depth : 1);
-    Bytes values(count * DIGEST), nodes(cap * DIGEST);
-    std::vector<uint32_t> lens(count);
-    uint32_t ncols = 0;
-    x.check(A.gs_merkle_prove_batch(x.c, t.leaves.p, t.nodes.p, t.n, idx.data(), count, values.data(), &ncols, lens.data(), nodes.data(), cap),
-            "gs_merkle_prove_batch");
-    for (uint32_t i = 0; i < count; i++) mp.values.emplace_back(values.begin() + i * DIGEST, values.begin() + (i + 1) * DIGEST);
-    uint64_t o = 0;
-    for (uint32_t cidx = 0; cidx < ncols; cidx++) {
-        mp.nodes.emplace_back();
-        for (uint32_t k = 0; k < lens[cidx]; k++, o++) mp.nodes.back().emplace_back(nodes.begin() + o * DIGEST, nodes.begin() + (o + 1) * DIGEST);
-    }
+    Readbacks rb;
+    rb.prove_batch(x, t, idx, &mp);               // outside a deferral window the call returns with the digests in place
     return mp;
 }
-std::vector<Bytes> gather(Ctx &x, const void *src, uint64_t rec, const std::vector<uint64_t> &idx) {
-    std::vector<Bytes> out;
-    if (idx.empty()) return out;
-    Bytes raw(idx.size() * rec);
-    x.check(A.gs_gather(x.c, src, rec, idx.data(), idx.size(), raw.data()), "gs_gather");
-    for (size_t i = 0; i < idx.size(); i++) out.emplace_back(raw.begin() + i * rec, raw.begin() + (i + 1) * rec);
-    return out;
-}
 // rows of transposeVector(column, 4) without the transposed copy: row r = column[r], column[r + rows], column[r + 2 rows], column[r + 3 rows]
-std::vector<Bytes> gather_rows4(Ctx &x, const void *column, uint64_t rows, const std::vector<uint64_t> &positions) {
-    std::vector<uint64_t> idx;
-    for (uint64_t r : positions)
-        for (uint64_t c = 0; c < 4; c++) idx.push_back(r + c * rows);
-    std::vector<Bytes> out;
-    if (idx.empty()) return out;
-    Bytes raw(idx.size() * ELEM);
-    x.check(A.gs_gather(x.c, column, ELEM, idx.data(), idx.size(), raw.data()), "gs_gather");
-    for (size_t i = 0; i < positions.size(); i++) out.emplace_back(raw.begin() + i * 4 * ELEM, raw.begin() + (i + 1) * 4 * ELEM);
-    return out;
+void gather_rows4(Ctx &x, const void *column, uint64_t rows, const std::vector<uint64_t> &positions, MerkleProof *mp) {
+    Readbacks rb;
+    rb.gather_rows4(x, column, rows, positions, mp);
 }
 // digests of those rows (Hash.digestValues of the transposed matrix, LowDegreeProver.ts:45,201) = mergeVectorRows of the four quarters
 void hash_rows4(Ctx &x, int alg, const void *column, uint64_t rows, void *digests) {
@@ -272,7 +285,22 @@ struct Layer {           // one FRI layer: the tree / rows it queries and the ch
 
 }  // namespace
 
+// GSTARK_PROVER_TIMING=1: host wall-clock at the phase boundaries on stderr (no device synchronisation is added, so a phase
+// shows the time until its last BLOCKING call returned)
+struct PhaseClock {
+    bool on = getenv("GSTARK_PROVER_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    void mark(const char *what) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[prover] %-44s %8.3f ms  (+%.3f)\n", what, std::chrono::duration<double, std::milli>(now - t0).count(),
+                std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+
 static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
+    PhaseClock clock;
     const gs_prover_air &air = job.air;
     const uint64_t T = job.steps, E = job.extension_factor, N = T * E;
     const uint32_t R = air.registers;
@@ -328,6 +356,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         x.check(A.gs_power_series(x.c, s16, N, psbPowers.p), "gs_power_series(psb)");
     }
 
+    clock.mark("context + trace-independent work issued");
     // 2 ----- execution trace (:97) and the assertions it must satisfy (:356-375)
     Buf trace(x, (uint64_t)R * T * ELEM);
     if (air.kind == 0)
@@ -347,13 +376,15 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
             if (a.step >= T) fail(GS_ERR_ARG, "Invalid assertion: step %llu is outside of execution trace", (unsigned long long)a.step);
             pos.push_back((uint64_t)a.reg * T + a.step);
         }
-        auto got = gather(x, trace.p, ELEM, pos);
+        Bytes got(pos.size() * ELEM);
+        x.check(A.gs_gather(x.c, trace.p, ELEM, pos.data(), pos.size(), got.data()), "gs_gather(asserted cells)");
         for (uint32_t i = 0; i < job.nassertions; i++)
-            if (memcmp(got[i].data(), job.assertions[i].value, 16))
+            if (memcmp(got.data() + i * ELEM, job.assertions[i].value, 16))
                 fail(GS_ERR_ARG, "Assertion at step %llu, register %u conflicts with execution trace", (unsigned long long)job.assertions[i].step,
                      job.assertions[i].reg);
     }
 
+    clock.mark("execution trace (host recurrence)");
     // 3 ----- P(x) and its low-degree extension (:106-109)
     Buf pPolys(x, (uint64_t)R * T * ELEM), pEval(x, (uint64_t)R * N * ELEM);
     le16(exec_rou, s16);
@@ -375,6 +406,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         eTree = build_tree(x, alg, std::move(hashed), N);
     }
 
+    clock.mark("P(x), extension, evaluation tree root");
     // 5 ----- composition polynomial (CompositionPolynomial.ts:29-146)
     // boundary constraints per asserted register, in order of first appearance (BoundaryConstraints.ts:15-45)
     struct RegData { uint32_t reg; std::vector<F> xs, ys; std::vector<uint64_t> at; };   // at: positions of the xs in the evaluation domain
@@ -595,6 +627,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     cEval.release();
     psbPowers.release();
 
+    clock.mark("composition + linear combination issued");
     // 7 ----- low-degree proof (LowDegreeProver.ts:39-68, 176-221)
     if (N < 128) fail(GS_ERR_ARG, "Invalid array length");
     // transposeVector(v, 4) is never materialised: row r of it is v[r], v[r + rows], v[r + 2 rows], v[r + 3 rows], which the hashing,
@@ -611,7 +644,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     for (uint64_t p : exe_positions) lc_positions.push_back(p % (N / 4));
     lc_positions = unique_in_order(lc_positions);                                                 // LowDegreeProver.ts:302-309
     MerkleProof lcProof = prove_batch(x, pTree0, lc_positions);
-    lcProof.values = gather_rows4(x, lEval.p, N / 4, lc_positions);
+    gather_rows4(x, lEval.p, N / 4, lc_positions, &lcProof);
 
     // layers (:176-221): the loop below is the recursion unrolled; queries are answered afterwards
     std::vector<Layer> layers;
@@ -644,6 +677,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         max_degree_plus1 /= 4;
         depth++;
     }
+    clock.mark("FRI layers (roots read back one by one)");
     // remainder (:179-187): the natural-order vector the last polyValues came from
     std::vector<F> remainder(len);
     {
@@ -675,9 +709,13 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
             }
         }
     }
-    // queries of every layer (:209-219)
+    clock.mark("remainder read back + checked");
+    // queries of every layer (:209-219) and the spot checks of the evaluation tree (lib/Stark.ts:146-152, 274-296): every position
+    // follows from roots the host already holds, so all the answers are requested in one deferral window — one round trip
     struct Component { Bytes columnRoot; MerkleProof columnProof, polyProof; };
     std::vector<Component> components(layers.size());
+    Readbacks rb;
+    x.check(A.gs_defer_begin(x.c), "gs_defer_begin");
     for (size_t d = 0; d < layers.size(); d++) {
         Layer &L = layers[d];
         std::vector<uint64_t> positions = query_indexes(L.cTree.root, job.fri_query_count, L.column_length, (uint32_t)E);
@@ -686,29 +724,33 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         aug = unique_in_order(aug);
         Component &c = components[d];
         c.columnRoot = L.cTree.root;
-        c.columnProof = prove_batch(x, L.cTree, aug);
-        c.columnProof.values = gather_rows4(x, L.next.p, L.column_length / 4, aug);
-        c.polyProof = prove_batch(x, *L.pTree, positions);
-        c.polyProof.values = gather_rows4(x, L.column, L.rows, positions);
+        rb.prove_batch(x, L.cTree, aug, &c.columnProof);
+        rb.gather_rows4(x, L.next.p, L.column_length / 4, aug, &c.columnProof);
+        rb.prove_batch(x, *L.pTree, positions, &c.polyProof);
+        rb.gather_rows4(x, L.column, L.rows, positions, &c.polyProof);
     }
-
-    // 8 ----- spot checks of the evaluation tree (lib/Stark.ts:146-152, 274-296)
+    // 8 ----- spot checks of the evaluation tree
     std::vector<uint64_t> positions = query_indexes(pTree0.root, exe_count, N, (uint32_t)E);
     std::vector<uint64_t> aug;
     for (uint64_t p : positions) { aug.push_back(p); aug.push_back((p + E) % N); }
     aug = unique_in_order(aug);
-    MerkleProof evProof = prove_batch(x, eTree, aug);
-    {
-        std::vector<std::vector<Bytes>> cols;
-        for (uint32_t r = 0; r < V; r++) cols.push_back(gather(x, eVectors[r], ELEM, aug));
-        evProof.values.clear();
-        for (size_t i = 0; i < aug.size(); i++) {
-            Bytes v;
-            for (uint32_t r = 0; r < V; r++) v.insert(v.end(), cols[r][i].begin(), cols[r][i].end());
-            evProof.values.push_back(v);
-        }
+    MerkleProof evProof;
+    rb.prove_batch(x, eTree, aug, &evProof);
+    // the leaves of the evaluation tree are the committed vectors' elements side by side (lib/Stark.ts:284-296)
+    std::vector<MerkleProof> cols(V);
+    for (uint32_t r = 0; r < V; r++) rb.gather(x, eVectors[r], ELEM, aug, 1, V == 1 ? &evProof : &cols[r]);
+    clock.mark("query positions + batch-proof plans");
+    x.check(A.gs_defer_end(x.c), "gs_defer_end");
+    clock.mark("query answers fetched (one round trip)");
+    if (V > 1) {
+        evProof.value_size = (uint64_t)V * ELEM;
+        evProof.nvalues = (uint32_t)aug.size();
+        evProof.values.resize(aug.size() * V * ELEM);
+        for (size_t i = 0; i < aug.size(); i++)
+            for (uint32_t r = 0; r < V; r++) memcpy(evProof.values.data() + (i * V + r) * ELEM, cols[r].values.data() + i * ELEM, ELEM);
     }
 
+    clock.mark("query answers unpacked");
     // ----- Serializer.serializeProof (:35-79)
     out.clear();
     out.insert(out.end(), eTree.root.begin(), eTree.root.end());
@@ -726,4 +768,5 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     out.push_back(remainder.size() == MAX_ARRAY ? 0 : (uint8_t)remainder.size());
     for (F v : remainder) { uint8_t b[16]; le16(v, b); out.insert(out.end(), b, b + 16); }
     out.push_back(0);    // no input shapes (iShapes = [])
+    clock.mark("serialized");
 }

@@ -85,6 +85,7 @@ extern "C" int gs_merkle_prove_batch(gs_ctx *c, const void *leaves, const void *
         bool has0 = false, has1 = false;
         while (i < count && (sorted[i] & ~1ull) == e) { (sorted[i] & 1 ? has1 : has0) = true; i++; }
         cols.emplace_back();
+        cols.back().reserve(depth);
         if (has0 && !has1) cols.back().push_back(e + 1);
         else if (!has0 && has1) cols.back().push_back(e);
         cur.push_back((e + n) >> 1);
@@ -106,6 +107,19 @@ extern "C" int gs_merkle_prove_batch(gs_ctx *c, const void *leaves, const void *
     for (auto &col : cols) fetch.insert(fetch.end(), col.begin(), col.end());
     const uint64_t nf = fetch.size();
     const uint64_t idx_bytes = (nf * 8 + 255) & ~(uint64_t)255, data_bytes = nf * 32;
+    *ncols_out = (uint32_t)cols.size();                           // the shape is host knowledge; only the digests come from the device
+    for (size_t i = 0; i < cols.size(); i++) col_lens_out[i] = (uint32_t)cols[i].size();
+    if (c->defer) {
+        // inside a deferral window: note the two 16-byte words of every digest; gs_defer_end fetches them all at once
+        c->defer_copies.push_back({values_out, (uint64_t)c->defer_addrs.size(), (uint64_t)count * 32});
+        if (total) c->defer_copies.push_back({nodes_out, (uint64_t)c->defer_addrs.size() + 2ull * count, total * 32});
+        for (uint64_t e : fetch) {
+            const uint64_t at = (uint64_t)(uintptr_t)((e >> 63) ? nodes : leaves) + (e & ~NODE) * 32;
+            c->defer_addrs.push_back(at);
+            c->defer_addrs.push_back(at + 16);
+        }
+        return GS_OK;
+    }
     int rc = gs_stage_reserve(c, idx_bytes + data_bytes);
     if (rc) return rc;
     memcpy(c->h_stage, fetch.data(), nf * 8);   // zero-copy through mapped pinned memory (see gs_gather)
@@ -117,8 +131,6 @@ extern "C" int gs_merkle_prove_batch(gs_ctx *c, const void *leaves, const void *
     GS_HIP(c, hipStreamSynchronize(c->stream));
     memcpy(values_out, h_out, (size_t)count * 32);
     memcpy(nodes_out, h_out + (size_t)count * 32, (size_t)total * 32);
-    *ncols_out = (uint32_t)cols.size();
-    for (size_t i = 0; i < cols.size(); i++) col_lens_out[i] = (uint32_t)cols[i].size();
     return GS_OK;
 }
 

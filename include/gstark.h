@@ -88,6 +88,13 @@ int gs_copy(gs_ctx *ctx, void *dst, const void *src, uint64_t bytes);
  * Copies `count` records of `rec_bytes` at record indices idx[] (host) from src to host_out. */
 int gs_gather(gs_ctx *ctx, const void *src, uint64_t rec_bytes, const uint64_t *idx_host,
               uint64_t count, void *host_out);
+/* Deferred read-backs: between gs_defer_begin and gs_defer_end, gs_gather and gs_merkle_prove_batch queue their device work and
+ * return at once (shapes — ncols_out, col_lens_out — are filled immediately, they are host knowledge); the host output buffers,
+ * which must stay valid, are filled by gs_defer_end after ONE synchronisation for the whole window.  The ~40 query answers of a
+ * proof (lib/Stark.ts:146-152; LowDegreeProver.ts:209-219) become one round trip.  Any other staging user inside the window
+ * delivers what is queued first. */
+int gs_defer_begin(gs_ctx *ctx);
+int gs_defer_end(gs_ctx *ctx);
 
 /* ---- vector arithmetic (FiniteField vector ops) ------------------------------------------------ */
 /* getPowerSeries(base, n): out[i] = base^i.  CompositionPolynomial.ts:94,132; LinearCombination.ts:46;

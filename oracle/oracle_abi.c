@@ -71,6 +71,9 @@ int gs_gather(gs_ctx *c, const void *src, uint64_t rec, const uint64_t *idx, uin
     return GS_OK;
 }
 
+int gs_defer_begin(gs_ctx *c) { (void)c; return GS_OK; }   /* host memory: every read-back is immediate */
+int gs_defer_end(gs_ctx *c) { (void)c; return GS_OK; }
+
 #define EL(p, i) fe_load((const uint8_t *)(p) + FE_BYTES * (uint64_t)(i))
 #define ST(p, i, v) fe_store((uint8_t *)(p) + FE_BYTES * (uint64_t)(i), (v))
 

@@ -84,6 +84,49 @@ def check_domain_divisions(backend, rng, logn, logsteps):
     return got.toBuffer()
 
 
+def check_deferred_readbacks(backend, rng, n):
+    """gs_defer_begin / gs_defer_end: gathers and Merkle batch proofs queued in one window deliver what the immediate calls deliver,
+    also when another staging user (a dot product) runs inside the window and when the window outgrows the staging buffer."""
+    import ctypes as C
+    f = field_for(backend)
+    h = createHash('blake2s256', backend)
+    vals = rand_elements(rng, n)
+    v = f.newVectorFrom(vals)
+    leaves = h.mergeVectorRows([v])
+    tree = MerkleTree.create(leaves, h)
+    be = f.backend
+    picks = [sorted(rng.sample(range(n), min(n, 40))) for _ in range(12)]
+    want_rows = [be.gather(v.ptr, 16, p) for p in picks]
+    want_proofs = [tree.proveBatch(p) for p in picks]
+    bufs = []
+    be.call('gs_defer_begin')
+    for p in picks:
+        idx = (C.c_uint64 * len(p))(*p)
+        out = C.create_string_buffer(16 * len(p))
+        be.call('gs_gather', C.c_void_p(v.ptr), 16, idx, len(p), C.cast(out, C.c_void_p))
+        depth = n.bit_length() - 1
+        values, nodes = C.create_string_buffer(32 * len(p)), C.create_string_buffer(32 * len(p) * max(depth, 1))
+        ncols, lens = C.c_uint32(), (C.c_uint32 * len(p))()
+        be.call('gs_merkle_prove_batch', C.c_void_p(tree.values.ptr), C.c_void_p(tree.nodes.ptr), n, idx, len(p), C.cast(values, C.c_void_p),
+                C.byref(ncols), lens, C.cast(nodes, C.c_void_p), len(p) * max(depth, 1))
+        bufs.append((idx, out, values, nodes, ncols, lens))
+        if len(bufs) == 5:
+            assert f.combineVectors(v, v) == sum(x * x for x in vals) % P        # a staging user inside the window
+    be.call('gs_defer_end')
+    for (idx, out, values, nodes, ncols, lens), rows, proof, p in zip(bufs, want_rows, want_proofs, picks):
+        assert [out.raw[16 * i:16 * i + 16] for i in range(len(p))] == rows
+        assert [values.raw[32 * i:32 * i + 32] for i in range(len(p))] == proof['values']
+        flat, o = [], 0
+        for cidx in range(ncols.value):
+            flat.append([nodes.raw[32 * (o + k):32 * (o + k + 1)] for k in range(lens[cidx])])
+            o += lens[cidx]
+        assert flat == proof['nodes']
+    if be.name == 'hip-gfx950':                                                   # (the oracle reads back at once: its window is a no-op)
+        import pytest
+        with pytest.raises(Exception):
+            be.call('gs_defer_end')                                               # not deferring any more
+
+
 def check_fri_fold(backend, rng, logn, depth):
     """gs_fri_fold == transposeVector + interpolateQuarticBatch + evalQuarticBatch (the members it fuses), on layer `depth`."""
     import ctypes as C

@@ -55,6 +55,11 @@ def test_fri_fold(hip_backend, oracle_backend, rng, logn, depth):
         assert got == cases.check_fri_fold(oracle_backend, random.Random(seed), logn, depth)
 
 
+@pytest.mark.parametrize('n', [64, 1 << 16])
+def test_deferred_readbacks(hip_backend, rng, n):
+    cases.check_deferred_readbacks(hip_backend, rng, n)
+
+
 @pytest.mark.parametrize('n', [5, 257, 40000])
 def test_inverse_with_zeros(hip_backend, rng, n):
     cases.check_inverse_with_zeros(hip_backend, rng, n)

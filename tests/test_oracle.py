@@ -27,6 +27,10 @@ def test_fri_fold(oracle_backend, rng, logn, depth):
     cases.check_fri_fold(oracle_backend, rng, logn, depth)
 
 
+def test_deferred_readbacks(oracle_backend, rng):
+    cases.check_deferred_readbacks(oracle_backend, rng, 256)
+
+
 def test_inverse_with_zeros(oracle_backend, rng):
     cases.check_inverse_with_zeros(oracle_backend, rng, 257)
 
