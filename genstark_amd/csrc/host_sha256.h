@@ -5,6 +5,49 @@
 #include <stdint.h>
 #include <string.h>
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+// one block with the SHA extensions (x86 SHA-NI: two rounds per sha256rnds2, the message schedule by sha256msg1 / sha256msg2):
+//   W[i] = msg2(msg1(W[i-4], W[i-3]) + alignr(W[i-1], W[i-2], 4), W[i-1])   for the 4-word groups i >= 4
+__attribute__((target("sha,sse4.1,ssse3"))) static inline void host_sha256_block_ni(uint32_t h[8], const uint8_t blk[64], const uint32_t K[64]) {
+    const __m128i bswap = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL);
+    __m128i tmp = _mm_loadu_si128((const __m128i *)&h[0]), s1 = _mm_loadu_si128((const __m128i *)&h[4]);
+    tmp = _mm_shuffle_epi32(tmp, 0xB1);                    // CDAB
+    s1 = _mm_shuffle_epi32(s1, 0x1B);                      // EFGH
+    __m128i s0 = _mm_alignr_epi8(tmp, s1, 8);              // ABEF
+    s1 = _mm_blend_epi16(s1, tmp, 0xF0);                   // CDGH
+    const __m128i save0 = s0, save1 = s1;
+    __m128i w[16];
+    for (int i = 0; i < 16; i++) {
+        if (i < 4) {
+            w[i] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(blk + 16 * i)), bswap);
+        } else {
+            __m128i x = _mm_sha256msg1_epu32(w[i - 4], w[i - 3]);
+            x = _mm_add_epi32(x, _mm_alignr_epi8(w[i - 1], w[i - 2], 4));
+            w[i] = _mm_sha256msg2_epu32(x, w[i - 1]);
+        }
+        __m128i m = _mm_add_epi32(w[i], _mm_loadu_si128((const __m128i *)&K[4 * i]));
+        s1 = _mm_sha256rnds2_epu32(s1, s0, m);
+        m = _mm_shuffle_epi32(m, 0x0E);
+        s0 = _mm_sha256rnds2_epu32(s0, s1, m);
+    }
+    s0 = _mm_add_epi32(s0, save0);
+    s1 = _mm_add_epi32(s1, save1);
+    tmp = _mm_shuffle_epi32(s0, 0x1B);                     // FEBA
+    s1 = _mm_shuffle_epi32(s1, 0xB1);                      // DCHG
+    s0 = _mm_blend_epi16(tmp, s1, 0xF0);                   // DCBA
+    s1 = _mm_alignr_epi8(s1, tmp, 8);                      // HGFE
+    _mm_storeu_si128((__m128i *)&h[0], s0);
+    _mm_storeu_si128((__m128i *)&h[4], s1);
+}
+static inline bool host_sha256_has_ni() {
+    static const bool ok = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3");
+    return ok;
+}
+#else
+static inline bool host_sha256_has_ni() { return false; }
+#endif
+
 static inline void host_sha256(const uint8_t *msg, size_t len, uint8_t out[32]) {
     static const uint32_t K[64] = {
         0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
@@ -26,6 +69,9 @@ static inline void host_sha256(const uint8_t *msg, size_t len, uint8_t out[32]) 
             uint64_t bits = (uint64_t)len * 8;
             for (int k = 0; k < 8; k++) blk[63 - k] = (uint8_t)(bits >> (8 * k));
         }
+#if defined(__x86_64__)
+        if (host_sha256_has_ni()) { host_sha256_block_ni(h, blk, K); continue; }
+#endif
         uint32_t w[64];
         for (int i = 0; i < 16; i++) w[i] = (uint32_t)blk[4 * i] << 24 | (uint32_t)blk[4 * i + 1] << 16 | (uint32_t)blk[4 * i + 2] << 8 | blk[4 * i + 3];
         for (int i = 16; i < 64; i++) {

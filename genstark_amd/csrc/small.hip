@@ -170,9 +170,16 @@ extern "C" int gs_pseudorandom_indexes(const uint8_t *seed, uint32_t seed_len, u
         }
         SHA256(buf, (size_t)nbytes, dg);
         /* index = dg (big-endian 256-bit) mod max */
-        unsigned __int128 r = 0;
-        for (int k = 0; k < 32; k++) r = ((r << 8) | dg[k]) % max_;
-        uint64_t index = (uint64_t)r;
+        uint64_t index;
+        if ((max_ & (max_ - 1)) == 0) {               /* domain sizes are powers of two: the low bits of the digest */
+            uint64_t low = 0;
+            for (int k = 24; k < 32; k++) low = (low << 8) | dg[k];
+            index = low & (max_ - 1);
+        } else {
+            unsigned __int128 r = 0;
+            for (int k = 0; k < 32; k++) r = ((r << 8) | dg[k]) % max_;
+            index = (uint64_t)r;
+        }
         if (exclude && index % exclude == 0) continue;
         int dup = 0;
         for (uint32_t k = 0; k < found; k++) if (out[k] == index) { dup = 1; break; }
