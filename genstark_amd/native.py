@@ -82,6 +82,7 @@ class NativeProver:
             raise GstarkError('the native driver proves on one device; use the distributed field with Stark.prove()')
         self.lib = _driver(self.backend)
         self._keep = []
+        self._out = C.create_string_buffer(1 << 22)
         # AIR-instance constants the device routines need, computed once (they depend on the AIR only, like the static register
         # polynomials an air-assembly module holds)
         if isinstance(air, MimcAir):
@@ -179,13 +180,13 @@ class NativeProver:
             ja.segments, ja.segment_len = (len(rows), air.segmentLength) if air.segmentLength else (0, 0)
             keep += [t_code, e_code, consts, svals, periods, lens, first]
         cap = 1 << 22
-        out = C.create_string_buffer(cap)
+        out = self._out        # one output buffer per prover (a lane of a pool has its own prover): no 4 MB allocation + copy per proof
         n = C.c_uint64()
         err = C.create_string_buffer(512)
         rc = self.lib.gs_prover_prove(self.backend.ctx, C.byref(job), C.cast(out, C.c_void_p), cap, C.byref(n), err, 512)
         if rc:
             raise StarkError(f'native prove() failed ({rc}): {err.value.decode(errors="replace")}')
-        return out.raw[:n.value]
+        return C.string_at(out, n.value)
 
     def prove(self, assertions, inputs=None, seed=None):
         return self.stark.parse(self.prove_bytes(assertions, inputs, seed))
