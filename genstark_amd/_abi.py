@@ -49,6 +49,8 @@ _SIGNATURES = {
     'gs_upload': (_int, [_vp, _vp, _bytes, _u64]),
     'gs_download': (_int, [_vp, _vp, _vp, _u64]),
     'gs_copy': (_int, [_vp, _vp, _vp, _u64]),
+    'gs_air_jit': (_int, [_vp, _int]),
+    'gs_air_jit_launches': (_u64, [_vp]),
     'gs_defer_begin': (_int, [_vp]),
     'gs_defer_end': (_int, [_vp]),
     'gs_gather': (_int, [_vp, _vp, _u64, C.POINTER(_u64), _u64, _vp]),
@@ -140,6 +142,15 @@ class Backend:
             raise GstarkError(f'gs_ctx_create(device={device}) failed with {rc}: no gfx950 device? (no CPU fallback)')
         self.ctx = ctx
         self.device = device
+
+    def jit(self, enable=True):
+        """Compile AIR programs (gs_air_jit) instead of interpreting them: for a prover that serves many proofs of one AIR."""
+        self.call('gs_air_jit', 1 if enable else 0)
+        return self
+
+    @property
+    def jit_launches(self):
+        return self.lib.gs_air_jit_launches(self.ctx)
 
     def close(self):
         if getattr(self, 'ctx', None):

@@ -267,6 +267,11 @@ int gs_air_constraints(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, co
     if (e == hipSuccess && nconsts) e = hipMemcpyAsync((uint8_t *)dprog + code_bytes, consts_host, (size_t)nconsts * GS_ELT, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // host buffers are pageable and owned by the caller
     if (e != hipSuccess) { gs_tmp_free(c, dprog); return gs_fail(c, GS_ERR_DEVICE, "air_constraints upload: %s", hipGetErrorString(e)); }
+    if (c->air_jit) {   // compiled form of the program (air_jit.hip); the interpreter below is the fallback
+        int jrc = gs_jit_constraints(c, code_host, ninstr, vm_regs, registers, sd.offset, sd.len, (const fe *)((uint8_t *)dprog + code_bytes),
+                                     (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, (fe *)out);
+        if (jrc == GS_OK) { gs_tmp_free(c, dprog); return GS_OK; }
+    }
     const uint4 *dcode = (const uint4 *)dprog;
     const fe *dconst = (const fe *)((uint8_t *)dprog + code_bytes);
     dim3 grid(gs_grid(nc)), block(256);
@@ -320,6 +325,11 @@ int gs_air_trace_segments(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr,
     if (e != hipSuccess) { gs_tmp_free(c, d); return gs_fail(c, GS_ERR_DEVICE, "air_trace_segments upload: %s", hipGetErrorString(e)); }
     const uint4 *dcode = (const uint4 *)p, *dinit = (const uint4 *)(p + main_b);
     const fe *dconst = (const fe *)(p + code_b), *dstat = (const fe *)(p + code_b + const_b), *drows = (const fe *)(p + code_b + const_b + stat_b);
+    if (c->air_jit) {   // compiled form of the program (air_jit.hip); the interpreter below is the fallback
+        int jrc = gs_jit_trace_segments(c, code_host, ninstr, init_code_host, init_ninstr, vm_regs, registers, sd.offset, sd.len, dconst, dstat, drows,
+                                        segments, segment_len, (fe *)out);
+        if (jrc == GS_OK) { gs_tmp_free(c, d); return GS_OK; }
+    }
     dim3 block(64), grid((unsigned)((segments + 63) / 64));   // one wave per 64 segments: spread the few long-running threads over the CUs
     const uint64_t lds_bytes = ((uint64_t)vm_regs + 2ull * registers) * 64 * GS_ELT;
 #define GS_LAUNCH_TRACE(N, L, SH)                                                                                                        \

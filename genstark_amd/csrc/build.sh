@@ -4,10 +4,15 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
-UNITS="ctx ntt pointwise hash air_mimc air_vm small"
+UNITS="ctx ntt pointwise hash air_mimc air_vm air_jit small"
 HDRS="gf128.cuh gf_small.cuh gf_wide.cuh common.h host_field.h host_field_small.h host_field_wide.h host_sha256.h hash_core.cuh ../../include/gstark.h"
 # one library per field: the 128-bit field of the hot path, and two "plumbing" flavours of the same sources for the small prime
 # fields of the reference's examples (gf_small.cuh): 2^64 - 21*2^30 + 1 (rescue/hash2x64.ts) and 2^32 - 3*2^25 + 1 (demo/fibonacci.ts)
+# the field headers as string literals: the source text hiprtc compiles AIR programs against (air_jit.hip)
+for pair in gf128.cuh:jit_gf128.inc gf_small.cuh:jit_gf_small.inc gf_wide.cuh:jit_gf_wide.inc; do
+  src=${pair%%:*}; dst=${pair##*:}
+  if [ ! -f $dst ] || [ $src -nt $dst ]; then { printf 'R"GSJIT('; cat $src; printf ')GSJIT"\n'; } > $dst; fi
+done
 build_flavour() {   # <object dir> <output> <extra flags>
   local dir=$1 out=$2 extra=$3 pids=() stale=0
   mkdir -p $dir
@@ -19,7 +24,7 @@ build_flavour() {   # <object dir> <output> <extra flags>
   done
   for p in "${pids[@]}"; do wait $p; done
   if [ $stale = 1 ] || [ ! -f $out ]; then
-    $HIPCC --offload-arch=gfx950 -shared -fPIC -o $out $(for f in $UNITS; do echo $dir/$f.o; done)
+    $HIPCC --offload-arch=gfx950 -shared -fPIC -o $out $(for f in $UNITS; do echo $dir/$f.o; done) -lhiprtc
   fi
   echo built $(pwd)/$out
 }

@@ -49,6 +49,8 @@ struct gs_ctx {
     void *h_stage_dev = nullptr;  // the device-side address of h_stage
     void *d_stage = nullptr;
     uint64_t stage_bytes = 0;
+    uint64_t jit_launches = 0;    // compiled-program launches so far (gs_air_jit_launches)
+    bool air_jit = false;         // AIR programs compiled with hiprtc instead of interpreted (gs_air_jit / GSTARK_AIR_JIT=1)
     // deferred read-backs (gs_defer_begin / gs_defer_end): gathers only record the device addresses of the 16-byte words they want;
     // gs_defer_end fetches all of them with ONE kernel and one synchronisation
     struct DeferredCopy { void *dst; uint64_t first_word, bytes; };
@@ -96,6 +98,13 @@ static inline unsigned gs_grid(uint64_t work_items, unsigned block = 256, unsign
     if (g > cap) g = cap;
     return (unsigned)g;
 }
+
+// air_jit.hip: GS_OK = the compiled kernel was launched, GS_ERR_UNSUPPORTED = interpret instead
+int gs_jit_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const uint32_t *icode, uint32_t init_ninstr, uint32_t vm_regs,
+                          uint32_t registers, const uint64_t *soff, const uint64_t *slen, const fe *dconst, const fe *dstat, const fe *drows,
+                          uint64_t segments, uint64_t seglen, fe *out);
+int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, uint32_t vm_regs, uint32_t registers, const uint64_t *soff,
+                       const uint64_t *slen, const fe *dconst, const fe *p, uint64_t nc, uint64_t shift, const fe *statics, fe *out);
 
 // NTT entry points implemented in ntt.hip and used by other units
 void gs_plans_destroy(gs_ctx *c);

@@ -1,5 +1,6 @@
 // ctx.hip — context, device memory cache, host<->device copies, gather.  C ABI: include/gstark.h.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -48,9 +49,18 @@ int gs_ctx_create(int device, void *hip_stream, gs_ctx **out) {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GS_ERR_DEVICE; }
         c->own_stream = true;
     }
+    const char *jit = getenv("GSTARK_AIR_JIT");
+    c->air_jit = jit && jit[0] && jit[0] != '0';
     *out = c;
     return GS_OK;
 }
+
+int gs_air_jit(gs_ctx *c, int enable) {
+    if (!c) return GS_ERR_ARG;
+    c->air_jit = enable != 0;
+    return GS_OK;
+}
+uint64_t gs_air_jit_launches(const gs_ctx *c) { return c ? c->jit_launches : 0; }
 
 void gs_ctx_destroy(gs_ctx *c) {
     if (!c) return;

@@ -275,6 +275,12 @@ int gs_air_trace_segments(gs_ctx *ctx, const uint32_t *code_host, uint32_t ninst
                           const uint8_t *static_values_host, const uint32_t *static_periods_host, uint32_t nstatic,
                           const uint8_t *first_rows_host /* segments x registers */, uint64_t segments, uint64_t segment_len,
                           void *out /* registers x (segments*segment_len) */);
+/* AIR programs compiled instead of interpreted (the reference's air-assembly generates code for an AIR when it is instantiated):
+ * with enable != 0, gs_air_trace_segments and gs_air_constraints turn their program into HIP source, compile it once per process
+ * (hiprtc, a few seconds) and launch that; same values; the interpreter remains the fallback.  Off by default (a single proof does
+ * not pay for the compilation); GSTARK_AIR_JIT=1 in the environment turns it on for every context. */
+int gs_air_jit(gs_ctx *ctx, int enable);
+uint64_t gs_air_jit_launches(const gs_ctx *ctx);       /* how many launches ran compiled programs so far (0: everything was interpreted) */
 int gs_air_constraints(gs_ctx *ctx, const uint32_t *code_host, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts,
                        uint32_t vm_regs, uint32_t registers, uint32_t constraints, const void *p_comp /* registers x nc */,
                        uint64_t nc, uint64_t shift, const void *static_tables /* device, concatenated */,

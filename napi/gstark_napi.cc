@@ -61,6 +61,8 @@ const FnDesc kFns[] = {
     {"gs_vec_exp", "cpbup"},
     {"gs_combine_many", "cabiup"},
     {"gs_combine", "cppuo"},
+    {"gs_air_jit", "ci"},
+    {"gs_air_jit_launches", "c"},
     {"gs_defer_begin", "c"},
     {"gs_defer_end", "c"},
     {"gs_pluck", "cpuuup"},

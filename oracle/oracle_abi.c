@@ -71,6 +71,8 @@ int gs_gather(gs_ctx *c, const void *src, uint64_t rec, const uint64_t *idx, uin
     return GS_OK;
 }
 
+int gs_air_jit(gs_ctx *c, int enable) { (void)c; (void)enable; return GS_OK; }   /* the oracle interprets */
+uint64_t gs_air_jit_launches(const gs_ctx *c) { (void)c; return 0; }
 int gs_defer_begin(gs_ctx *c) { (void)c; return GS_OK; }   /* host memory: every read-back is immediate */
 int gs_defer_end(gs_ctx *c) { (void)c; return GS_OK; }
 

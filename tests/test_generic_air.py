@@ -277,6 +277,23 @@ def test_segmented_hash_chains_hip_equals_oracle(hip_backend, oracle_backend, ki
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('kind,steps', [('rescue', 1024), ('poseidon', 2048)])
+def test_compiled_air_programs_equal_interpreted(hip_backend, kind, steps):
+    """gs_air_jit: the transition function and the constraint evaluator compiled with hiprtc (csrc/air_jit.hip) give the
+    interpreter's trace and the same proof bytes — and they really ran (gs_air_jit_launches)."""
+    from genstark_amd._abi import Backend
+    compiled = Backend(device=0).jit()
+    try:
+        assert compiled.jit_launches == 0
+        data = check_segmented(compiled, kind, steps)            # also compares the device trace with host integers
+        assert compiled.jit_launches >= 2, 'the programs were interpreted: hiprtc failed?'
+        assert hip_backend.jit_launches == 0
+        assert data == check_segmented(hip_backend, kind, steps)
+    finally:
+        compiled.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('kind', ['rescue', 'poseidon'])
 def test_segmented_2p16_configs_verify(hip_backend, kind):
     """BASELINE configs[2] / configs[3] in the reference's sense: 2^16 steps = 2048 Rescue hashes / 1024 Poseidon hashes."""
