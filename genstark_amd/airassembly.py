@@ -457,7 +457,7 @@ class AssemblyAir:
         return row
 
     # -- static registers for given shapes
-    def _columns(self, layout, inputs, secret_only=False):
+    def _columns(self, layout, inputs):
         """Full-length integer columns in lib order (None where `inputs` does not provide one: secret registers on the verifier side)."""
         ex, p, cols, j = self.export, self.module.modulus, [], 0
         for s in ex.statics:

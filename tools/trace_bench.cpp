@@ -7,13 +7,13 @@
 #include "../genstark_amd/csrc/host_field.h"
 
 template <int V>
-static double run(uint64_t steps, const std::vector<hu128> &rc, hu128 seed, std::vector<hu128> &t) {
+static double run(uint64_t steps, const std::vector<hfe> &rc, hfe seed, std::vector<hfe> &t) {
     auto t0 = std::chrono::steady_clock::now();
-    hu128 x = seed;
+    hfe x = seed;
     uint32_t ri = 0, nrc = (uint32_t)rc.size();
     for (uint64_t i = 0; i < steps; i++) {
-        hu128 y = (V & 2) ? hf_cube_weak(x) : hf_mul_weak(hf_mul_weak(x, x), x);
-        hu128 sum = y + rc[ri];
+        hfe y = (V & 2) ? hf_cube_weak(x) : hf_mul_weak(hf_mul_weak(x, x), x);
+        hfe sum = y + rc[ri];
         if (V & 1) {          // weak chain, canonicalisation off the critical path
             t[i] = hf_canon(x);
             if (__builtin_expect(sum < y, 0)) sum += HF_C;
@@ -31,9 +31,9 @@ static double run(uint64_t steps, const std::vector<hu128> &rc, hu128 seed, std:
 
 int main() {
     const uint64_t steps = 1 << 20;
-    std::vector<hu128> rc(64), t0(steps), t1(steps), t2(steps), t3(steps);
+    std::vector<hfe> rc(64), t0(steps), t1(steps), t2(steps), t3(steps);
     for (int i = 0; i < 64; i++) rc[i] = hf_pow(3, 1000 + i);
-    hu128 seed = 3;
+    hfe seed = 3;
     for (int rep = 0; rep < 4; rep++) {
         double a = run<0>(steps, rc, seed, t0), b = run<1>(steps, rc, seed, t1), c = run<2>(steps, rc, seed, t2), d = run<3>(steps, rc, seed, t3);
         bool ok = true;
