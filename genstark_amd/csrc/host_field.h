@@ -115,6 +115,7 @@ static inline hfe hf_pow(hfe b, hfe e) {
     return r;
 }
 static inline hfe hf_inv(hfe a) { return a ? hf_pow(a, hf_p() - 2) : 0; }
+static inline bool hf_is_zero(hfe a) { return a == 0; }
 static inline hfe hf_load(const uint8_t *b) { hfe v; memcpy(&v, b, 16); return v; }
 static inline void hf_store(uint8_t *b, hfe v) { memcpy(b, &v, 16); }
 // one step of the MiMC recurrence x <- x^3 + k (examples/mimc/utils.ts:7-15) on the weak cube

@@ -17,5 +17,6 @@ static inline hfe hf_mul(hfe a, hfe b) { return hf_wrap(fe_mul(a.v, b.v)); }
 static inline hfe hf_pow(hfe b, hfe e) { return hf_wrap(fe_pow(b.v, e.v)); }
 static inline hfe hf_inv(hfe a) { return hf_wrap(fe_inv(a.v)); }
 static inline hfe hf_mimc_step(hfe x, hfe k) { return hf_add(hf_mul(hf_mul(x, x), x), k); }   // examples/mimc/utils.ts:7-15
+static inline bool hf_is_zero(hfe a) { return fe_is_zero(a.v); }
 static inline hfe hf_load(const uint8_t *b) { hfe r; memcpy(&r.v, b, sizeof(fe)); return r; }
 static inline void hf_store(uint8_t *b, hfe x) { memcpy(b, &x.v, sizeof(fe)); }

@@ -14,7 +14,7 @@ extern "C" {
 
 int gs_small_interpolate(const uint8_t *xs_host, const uint8_t *ys_host, uint32_t n, uint8_t *coeffs_out) {
     if (!xs_host || !ys_host || !coeffs_out || n == 0 || n > 4096) return GS_ERR_ARG;
-    std::vector<hfe> x(n), y(n), master(n + 1, 0), q(n), out(n, 0);
+    std::vector<hfe> x(n), y(n), master(n + 1, 0), out(n, 0);
     for (uint32_t i = 0; i < n; i++) { x[i] = hf_load(xs_host + GS_ELT * i); y[i] = hf_load(ys_host + GS_ELT * i); }
     // master polynomial M(X) = prod (X - x_i)
     master[0] = 1;
@@ -23,17 +23,35 @@ int gs_small_interpolate(const uint8_t *xs_host, const uint8_t *ys_host, uint32_
         for (uint32_t d = i + 1; d >= 1; d--) master[d] = hf_add(master[d - 1], hf_mul(master[d], nx));
         master[0] = hf_mul(master[0], nx);
     }
+    // Lagrange denominators q_j(x_j) = M'(x_j), all inverted with ONE field inversion (Montgomery's trick): a Fermat inversion is
+    // ~250 products, n of them were 40 % of the work at n ~ 100 (remainder check of a degree-6 AIR)
+    const bool keep = n <= 512;                                // keep the n quotients (n coefficients each: 4 MB at most) or recompute them
+    std::vector<hfe> den(n), pre(n), qs(keep ? (size_t)n * n : n);
     for (uint32_t j = 0; j < n; j++) {
-        // q = M / (X - x_j) by synthetic division; the Lagrange denominator is q(x_j)
-        hfe carry = 0;
-        for (uint32_t d = n; d >= 1; d--) {
+        hfe carry = 0, dj = 0;
+        for (uint32_t d = n; d >= 1; d--) {       // q_j = M / (X - x_j) by synthetic division, evaluated at x_j on the fly (Horner)
             carry = hf_add(master[d], hf_mul(carry, x[j]));
-            q[d - 1] = carry;
+            dj = hf_add(hf_mul(dj, x[j]), carry);
+            if (keep) qs[(size_t)j * n + d - 1] = carry;
         }
-        hfe den = 0;
-        for (uint32_t d = n; d-- > 0;) den = hf_add(hf_mul(den, x[j]), q[d]);
-        hfe s = hf_mul(y[j], hf_inv(den));
-        for (uint32_t d = 0; d < n; d++) out[d] = hf_add(out[d], hf_mul(q[d], s));
+        den[j] = dj;
+    }
+    hfe acc = 1;
+    for (uint32_t j = 0; j < n; j++) { pre[j] = acc; if (!hf_is_zero(den[j])) acc = hf_mul(acc, den[j]); }
+    hfe inv_all = hf_inv(acc);
+    for (uint32_t j = n; j-- > 0;) {
+        hfe inv_j = 0;                            // a repeated x makes its denominator zero: 0^-1 = 0, as before
+        if (!hf_is_zero(den[j])) { inv_j = hf_mul(inv_all, pre[j]); inv_all = hf_mul(inv_all, den[j]); }
+        const hfe sc = hf_mul(y[j], inv_j);
+        if (!keep) {
+            hfe carry = 0;
+            for (uint32_t d = n; d >= 1; d--) {
+                carry = hf_add(master[d], hf_mul(carry, x[j]));
+                qs[d - 1] = carry;
+            }
+        }
+        const hfe *qj = keep ? &qs[(size_t)j * n] : qs.data();
+        for (uint32_t d = 0; d < n; d++) out[d] = hf_add(out[d], hf_mul(qj[d], sc));
     }
     for (uint32_t d = 0; d < n; d++) hf_store(coeffs_out + GS_ELT * d, out[d]);
     return GS_OK;
