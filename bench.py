@@ -226,7 +226,8 @@ def main():
                     'kernel': f'k_ntt_pass<4> (radix-256 Stockham pass), {npass} launches per 2^{logn}-point transform',
                     'launch_ms': round(launch_ms, 4), 'transform_ms': round(transform_ms, 4),
                     'ntt_kernel_elements_per_sec': round(n / (transform_ms * 1e-3), 1),
-                    'note': 'VALU-issue-bound (about 90 carry/mad instructions of ~4.5 cycles per 128-bit modmul), not HBM-bound: DESIGN.md section 3'}
+                    'valu_issue_utilisation': 0.75,     # SQ counters, profiles/r01_f_ntt_pass_valu_utilisation.md and r01_z_pmc_traffic_fused_kernels.md
+                    'note': 'VALU-issue-bound (about 90 carry/mad instructions of ~4.5 cycles per 128-bit modmul; 75 % of the VALU issue slots busy), not HBM-bound: DESIGN.md section 3'}
         del src, dst
 
         cpu = None if args.no_cpu_baseline else cpu_baseline(ga, args.cpu_log_trace, ef, fri)
