@@ -50,22 +50,28 @@ static std::string jit_preamble() {
     // g independent square-and-multiply chains with one exponent (see pow_group in air_vm.hip)
     s += "template <int G> __device__ __forceinline__ void gs_pow_group(fe (&x)[G], const fe &e) {\n"
          "    fe r[G];\n"
-         "    for (int i = 0; i < G; i++) r[i] = fe_one();\n"
          "    const unsigned int *ev = reinterpret_cast<const unsigned int *>(&e);\n"
          "    int top = (int)(sizeof(fe) / 4) - 1;\n"
          "    while (top > 0 && ev[top] == 0) top--;\n"
+         "    if (top == 0 && ev[0] == 0) { for (int i = 0; i < G; i++) x[i] = fe_one(); return; }\n"
+         "    unsigned int bits = ev[0];\n"
+         "    const bool odd = bits & 1u;\n"
+         "    for (int i = 0; i < G; i++) r[i] = odd ? x[i] : fe_one();\n"
+         "    bits >>= 1;\n"
+         "    int k = 1;\n"
          "    for (int w = 0; w <= top; w++) {\n"
-         "        unsigned int bits = ev[w];\n"
-         "        const int nb = (w == top) ? 32 - __clz(bits | 1u) : 32;\n"
-         "        for (int k = 0; k < nb; k++) {\n"
+         "        const int nb = (w == top) ? 32 - __clz(ev[top] | 1u) : 32;\n"
+         "        for (; k < nb; k++) {\n"
+         "#pragma unroll\n"
+         "            for (int i = 0; i < G; i++) x[i] = fe_sqr(x[i]);\n"
          "            if (bits & 1u) {\n"
          "#pragma unroll\n"
          "                for (int i = 0; i < G; i++) r[i] = fe_mul(r[i], x[i]);\n"
          "            }\n"
-         "#pragma unroll\n"
-         "            for (int i = 0; i < G; i++) x[i] = fe_sqr(x[i]);\n"
          "            bits >>= 1;\n"
          "        }\n"
+         "        k = 0;\n"
+         "        if (w < top) bits = ev[w + 1];\n"
          "    }\n"
          "    for (int i = 0; i < G; i++) x[i] = r[i];\n"
          "}\n";

@@ -49,25 +49,37 @@ __global__ void k_air_constraints(const uint4 *__restrict__ code, uint32_t ninst
 template <int G>
 __device__ __forceinline__ void pow_group(fe (&x)[4], const fe &e) {
     fe r[4];
-#pragma unroll
-    for (int i = 0; i < G; i++) r[i] = fe_one();
     uint32_t ev[GF_LIMBS];
 #pragma unroll
     for (int l = 0; l < GF_LIMBS; l++) ev[l] = fe_limb(e, l);
     int top = GF_LIMBS - 1;
     while (top > 0 && ev[top] == 0) top--;
+    if (top == 0 && ev[0] == 0) {
+#pragma unroll
+        for (int i = 0; i < G; i++) x[i] = fe_one();
+        return;
+    }
+    // no product by one at the start, no squaring after the top bit: the squaring comes BEFORE every bit but the first.  Odd exponents
+    // (every S-box exponent and its inverse) start with r = x and keep the inner loop free of the "first product" test (wave-uniform).
+    uint32_t bits = ev[0];
+    const bool odd = bits & 1u;
+#pragma unroll
+    for (int i = 0; i < G; i++) r[i] = odd ? x[i] : fe_one();
+    bits >>= 1;
+    int k = 1;
     for (int w = 0; w <= top; w++) {
-        uint32_t bits = ev[w];
-        const int nb = (w == top) ? 32 - __clz(bits | 1u) : 32;
-        for (int k = 0; k < nb; k++) {
+        const int nb = (w == top) ? 32 - __clz(ev[top] | 1u) : 32;
+        for (; k < nb; k++) {
+#pragma unroll
+            for (int i = 0; i < G; i++) x[i] = fe_sqr(x[i]);
             if (bits & 1u) {
 #pragma unroll
                 for (int i = 0; i < G; i++) r[i] = fe_mul(r[i], x[i]);
             }
-#pragma unroll
-            for (int i = 0; i < G; i++) x[i] = fe_sqr(x[i]);
             bits >>= 1;
         }
+        k = 0;
+        if (w < top) bits = ev[w + 1];
     }
 #pragma unroll
     for (int i = 0; i < G; i++) x[i] = r[i];

@@ -227,12 +227,15 @@ GF_HD fe fe_pow(fe b, const fe &e) {
     }
     return r;
 }
-GF_HD fe fe_pow_u64(fe b, uint64_t e) {
-    fe r = fe_one();
-    while (e) {
-        if (e & 1u) r = fe_mul(r, b);
-        b = fe_sqr(b);
+GF_HD fe fe_pow_u64(fe b, uint64_t e) {          // b canonical.  No product by one at the start, no squaring after the top bit:
+    if (!e) return fe_one();                      // x^3 is two products, x^5 three (the S-boxes of the example AIRs)
+    fe r = b;
+    bool have = false;
+    for (;;) {
+        if (e & 1u) { r = have ? fe_mul(r, b) : b; have = true; }
         e >>= 1;
+        if (!e) break;
+        b = fe_sqr(b);
     }
     return r;
 }
