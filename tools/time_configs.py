@@ -19,7 +19,7 @@ f = PrimeField(backend=be)
 rows = []
 
 
-def run(name, stark, assertions, seed, reps=5):
+def run(name, stark, assertions, seed, reps=5, make_air=None):
     log = ga.Logger(echo=False, sync=be.sync)
     for _ in range(2):
         proof = stark.prove(assertions, [], seed)
@@ -52,12 +52,25 @@ def run(name, stark, assertions, seed, reps=5):
         t0 = time.perf_counter()
         assert hv.verify(assertions, hv.parse(data))
         th = (time.perf_counter() - t0) * 1e3
+    tj = None
+    if make_air is not None:             # the same statement with the AIR's programs compiled (gs_air_jit) instead of interpreted
+        bj = Backend(device=0).jit()
+        sj = Stark(make_air(PrimeField(backend=bj)), stark_opts[name])
+        nj = NativeProver(sj)
+        tj = []
+        for i in range(reps + 2):
+            t0 = time.perf_counter()
+            dj = nj.prove_bytes(assertions, [], seed)
+            if i >= 2:
+                tj.append((time.perf_counter() - t0) * 1e3)
+        assert dj == data and bj.jit_launches > 0
     s2 = Stark(stark.air, stark_opts[name], log)
     s2.prove(assertions, [], seed)
     phases = {k.strip(): v for k, v in log.phases}
     trace_ms = phases.get('Generated execution trace', 0.0)
     ths = f'{th:.1f}' if th else '-'
-    rows.append(f'| {name} | {min(tn):.2f} | {sum(tn) / len(tn):.2f} | {min(t):.2f} | {trace_ms:.2f} | {tv:.1f} | {ths} | {len(data)} | {stark.securityLevel} |')
+    tjs = f'{min(tj):.2f}' if tj else '-'
+    rows.append(f'| {name} | {min(tn):.2f} | {tjs} | {sum(tn) / len(tn):.2f} | {min(t):.2f} | {trace_ms:.2f} | {tv:.1f} | {ths} | {len(data)} | {stark.securityLevel} |')
 
 
 stark_opts = {}
@@ -90,14 +103,14 @@ air = rescue4x128_air(1 << 16, 16, f, segmented=True)
 seeds = [[42 + s, 43 + 2 * s] for s in range(2048)]
 tr = air.initProvingContext([], seeds).generateExecutionTrace()
 a = [{'step': 31, 'register': 0, 'value': tr.getValue(0, 31)}, {'step': 65535, 'register': 1, 'value': tr.getValue(1, 65535)}]
-run(name, Stark(air, stark_opts[name]), a, seeds)
+run(name, Stark(air, stark_opts[name]), a, seeds, make_air=lambda fj: rescue4x128_air(1 << 16, 16, fj, segmented=True))
 name = 'Poseidon 6x128, 1024 hashes x 64 steps = 2^16 (segmented), E=16, exe 68 / fri 24, blake2s256'
 stark_opts[name] = stark_opts['Rescue 4x128 2^16 steps (4 registers, degree 3), E=16, exe 68 / fri 24, blake2s256']
 air = poseidon6x128_air(1 << 16, 16, f, segmented=True)
 seeds = [[1 + s, 2, 3 + s, 4] for s in range(1024)]
 tr = air.initProvingContext([], seeds).generateExecutionTrace()
 a = [{'step': 63, 'register': 0, 'value': tr.getValue(0, 63)}, {'step': 65535, 'register': 1, 'value': tr.getValue(1, 65535)}]
-run(name, Stark(air, stark_opts[name]), a, seeds)
+run(name, Stark(air, stark_opts[name]), a, seeds, make_air=lambda fj: poseidon6x128_air(1 << 16, 16, fj, segmented=True))
 # configs[4]: MiMC 2^20 (the bench workload) for reference
 name = 'MiMC-128 2^20 steps, E=16, exe 48 / fri 64, blake2s256'
 stark_opts[name] = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 48, 'friQueryCount': 64}
@@ -108,6 +121,6 @@ run(name, st, a, [3])
 
 print('# prove() wall-clock of the BASELINE configurations, 1 x MI355X (HIP backend), host-side trace generation included\n')
 print('command: `python tools/time_configs.py` (2 warm-up proofs, 5 timed; native driver = csrc/prover.cc, Python mirror = stark.prove(), same bytes asserted; verify() timed once on the host)\n')
-print('| configuration | prove() native driver best ms | mean ms | Python mirror best ms | of which trace generation ms | verify() ms (device-side field) | verify() ms (HostField, no GPU) | proof bytes | security level |')
-print('|---|---:|---:|---:|---:|---:|---:|---:|---:|')
+print('| configuration | prove() native driver best ms | same with compiled AIR programs (gs_air_jit) | mean ms | Python mirror best ms | of which trace generation ms | verify() ms (device-side field) | verify() ms (HostField, no GPU) | proof bytes | security level |')
+print('|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|')
 print('\n'.join(rows))
