@@ -16,12 +16,14 @@ from ._abi import Backend
 
 
 class ProverPool:
-    def __init__(self, stark_factory, lanes=2, backend_factory=None, native=False):
+    def __init__(self, stark_factory, lanes=2, backend_factory=None, native=False, jit=True):
         """stark_factory(backend) -> Stark; backend_factory() -> Backend, called once inside every lane's thread (the HIP
-        current device is per-thread state, gs_ctx_create sets it for the calling thread)."""
+        current device is per-thread state, gs_ctx_create sets it for the calling thread).  jit: a pool is a long-lived service,
+        so its lanes have AIR programs compiled (gs_air_jit: once per process, shared by the lanes) instead of interpreted."""
         if lanes < 1:
             raise ValueError('lanes must be >= 1')
         self.lanes = lanes
+        self.jit = jit
         self.native = native        # lanes prove through the native driver (genstark_amd/native.py): the GIL is released for a whole proof
         self._jobs = queue.Queue()
         self._errors = []
@@ -37,7 +39,10 @@ class ProverPool:
 
     def _lane(self, index, stark_factory, backend_factory):
         try:
-            stark = stark_factory(backend_factory())
+            backend = backend_factory()
+            if self.jit and hasattr(backend, 'jit'):
+                backend.jit()
+            stark = stark_factory(backend)
             if self.native:
                 from .native import NativeProver
                 stark = NativeProver(stark)

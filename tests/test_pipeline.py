@@ -88,3 +88,27 @@ def test_pool_reports_missing_library():
 @pytest.mark.gpu
 def test_pool_matches_sequential_proofs_hip():
     check_pool(lambda: Backend(device=0), 3)
+
+
+@pytest.mark.gpu
+def test_pool_compiles_air_programs_and_matches_sequential_proofs_hip():
+    """A pool's lanes have AIR programs compiled (gs_air_jit, once per process): same bytes as the sequential, interpreted prover."""
+    from genstark_amd.field import PrimeField
+    from genstark_amd.poseidon import poseidon6x128_air
+    from genstark_amd.stark import Stark
+    opts = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 40, 'friQueryCount': 16}
+    make = lambda backend: Stark(poseidon6x128_air(1024, 16, PrimeField(backend=backend), segmented=True), opts)
+    seeds = [[1 + s, 2, 3 + s, 4] for s in range(16)]
+    seq_backend = Backend(device=0)
+    seq = make(seq_backend)
+    trace = seq.air.initProvingContext([], seeds).generateExecutionTrace()
+    assertions = [{'step': 63, 'register': 0, 'value': trace.getValue(0, 63)}, {'step': 1023, 'register': 1, 'value': trace.getValue(1, 1023)}]
+    expected = seq.serialize(seq.prove(assertions, [], seeds))
+    assert seq_backend.jit_launches == 0
+    jobs = [(assertions, [], seeds)] * 6
+    for native in (False, True):
+        with ProverPool(make, lanes=2, backend_factory=lambda: Backend(device=0), native=native) as pool:
+            out = pool.prove_many_bytes(jobs) if native else [seq.serialize(p) for p in pool.prove_many(jobs)]
+            assert out == [expected] * 6
+            launches = pool.on_every_lane(lambda s: (s.stark if native else s).air.field.backend.jit_launches)
+            assert all(n > 0 for n in launches)
