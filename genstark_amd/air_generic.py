@@ -464,3 +464,23 @@ class GenericAir:
             out.append(row)
             row = self.transitionProgram.run(row, None, [v[i % len(v)] for v in statics])
         return out
+
+    def compileCheck(self, lib=None):
+        """Does the code generated for this AIR's programs build for gfx950 (gs_air_jit_check: compiler only, no device)?  Returns
+        [(name, ok, compiler log)] for the trace program (segmented AIRs: those are the ones the device traces) and the constraint
+        program.  `lib`: a loaded flavour of the library; default: the one built for the AIR's field."""
+        from ._abi import GS_OK, HIP_LIB_PATHS, load_library
+        lib = lib or getattr(getattr(self.field, 'backend', None), 'lib', None) or load_library(HIP_LIB_PATHS[self.field.modulus])
+        periods = [len(v) for v in self.staticRegisters] + [self.steps] * self.secretInputCount
+        lens = (C.c_uint64 * max(len(periods), 1))(*periods)
+        log, out = C.create_string_buffer(4096), []
+
+        def check(name, kind, prog, init):
+            code, ninstr, consts, nconsts, nregs = prog.abi_args(self.field.elementSize)
+            icode, ininstr = init.abi_args(self.field.elementSize)[:2] if init is not None else (None, 0)
+            rc = lib.gs_air_jit_check(kind, code, ninstr, icode, ininstr, consts, nconsts, nregs, self.traceRegisterCount, lens, len(periods), log, len(log))
+            out.append((name, rc == GS_OK, log.value.decode(errors='replace')))
+        if self.segmentLength is not None:
+            check('trace', 0, self.transitionProgram, self.initProgram)
+        check('constraints', 1, self.evaluationProgram, None)
+        return out

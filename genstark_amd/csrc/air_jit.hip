@@ -47,40 +47,114 @@ static std::string jit_preamble() {
     s += "#define GS_WIDE_BITS " GS_STR(GS_WIDE_BITS) "\n";
 #endif
     s += "#include \"gs_field.cuh\"\n";
-    // g independent square-and-multiply chains with one exponent (see pow_group in air_vm.hip)
-    s += "template <int G> __device__ __forceinline__ void gs_pow_group(fe (&x)[G], const fe &e) {\n"
-         "    fe r[G];\n"
-         "    const unsigned int *ev = reinterpret_cast<const unsigned int *>(&e);\n"
-         "    int top = (int)(sizeof(fe) / 4) - 1;\n"
-         "    while (top > 0 && ev[top] == 0) top--;\n"
-         "    if (top == 0 && ev[0] == 0) { for (int i = 0; i < G; i++) x[i] = fe_one(); return; }\n"
-         "    unsigned int bits = ev[0];\n"
-         "    const bool odd = bits & 1u;\n"
-         "    for (int i = 0; i < G; i++) r[i] = odd ? x[i] : fe_one();\n"
-         "    bits >>= 1;\n"
-         "    int k = 1;\n"
-         "    for (int w = 0; w <= top; w++) {\n"
-         "        const int nb = (w == top) ? 32 - __clz(ev[top] | 1u) : 32;\n"
-         "        for (; k < nb; k++) {\n"
+    // the straight-line products: a call in the multi-limb fields (a product is ~400 instructions there; inlining a hundred of
+    // them costs minutes of compilation and buys nothing), inlined in the others
+#if defined(GS_WIDE_BITS)
+    s += "static __device__ __noinline__ fe gs_mul(const fe &a, const fe &b) { return fe_mul(a, b); }\n";
+#else
+    s += "#define gs_mul fe_mul\n";
+#endif
+#if defined(GS_WIDE_BITS)
+    s += "static __device__ __noinline__ fe gs_sqr(const fe &a) { return fe_mul(a, a); }\n";
+#else
+    s += "#define gs_sqr fe_sqr\n";
+#endif
+    // an element read from lane `src` of the group of L consecutive lanes the caller belongs to
+    s += "template <int L> __device__ __forceinline__ fe gs_from_lane(const fe &v, int src) {\n"
+         "    fe r;\n"
+         "    const unsigned int *pv = reinterpret_cast<const unsigned int *>(&v);\n"
+         "    unsigned int *pr = reinterpret_cast<unsigned int *>(&r);\n"
          "#pragma unroll\n"
-         "            for (int i = 0; i < G; i++) x[i] = fe_sqr(x[i]);\n"
-         "            if (bits & 1u) {\n"
-         "#pragma unroll\n"
-         "                for (int i = 0; i < G; i++) r[i] = fe_mul(r[i], x[i]);\n"
-         "            }\n"
-         "            bits >>= 1;\n"
-         "        }\n"
-         "        k = 0;\n"
-         "        if (w < top) bits = ev[w + 1];\n"
-         "    }\n"
-         "    for (int i = 0; i < G; i++) x[i] = r[i];\n"
+         "    for (int i = 0; i < (int)(sizeof(fe) / 4); i++) pr[i] = __shfl(pv[i], src, L);\n"
+         "    return r;\n"
          "}\n";
     return s;
 }
 
+// What the generator knows besides the program: the constant pool (exponents become addition chains at generation time) and, in
+// the trace kernel, how many lanes work on one segment.
+struct JitGen {
+    const uint8_t *consts = nullptr;   // host copy, nconsts x GS_ELT bytes
+    uint32_t nconsts = 0;
+    uint32_t lanes = 1;                // 1, 2 or 4 consecutive lanes per segment (trace kernel only)
+};
+
+// x <- x^e as a fixed addition chain: left-to-right sliding windows over the bits of e (little-endian 32-bit limbs), the window
+// width chosen by counting products.  The inverse S-box of Rescue (a 128-bit exponent) is 127 squarings + 32 products instead of
+// the 127 + 64 of square-and-multiply; a Fermat inversion in the 224-bit field 224 + 53 instead of 224 + 222.
+struct PowPlan {
+    uint32_t table_max = 1;                                    // odd powers x^1 .. x^table_max are needed
+    std::vector<std::pair<uint32_t, uint32_t>> steps;          // (squarings, odd power to multiply by; 0 = none); first: (0, start)
+    uint32_t cost = 0;
+};
+static PowPlan pow_plan(const std::vector<uint32_t> &e, int nbits, int w) {
+    PowPlan pl;
+    auto bit = [&](int i) { return (e[i / 32] >> (i % 32)) & 1u; };
+    int i = nbits - 1;
+    uint32_t pending = 0;
+    bool first = true;
+    while (i >= 0) {
+        if (!bit(i)) { pending++; i--; continue; }
+        int j = i - w + 1 < 0 ? 0 : i - w + 1;
+        while (!bit(j)) j++;
+        uint32_t val = 0;
+        for (int k = i; k >= j; k--) val = 2 * val + bit(k);
+        if (first) pl.steps.push_back({0, val});
+        else { pl.steps.push_back({pending + (uint32_t)(i - j + 1), val}); pl.cost += pending + (i - j + 1) + 1; }
+        first = false;
+        pending = 0;
+        if (val > pl.table_max) pl.table_max = val;
+        i = j - 1;
+    }
+    if (pending) { pl.steps.push_back({pending, 0}); pl.cost += pending; }
+    if (pl.table_max > 1) pl.cost += 1 + (pl.table_max - 1) / 2;
+    return pl;
+}
+static void emit_pow(std::string &s, const char *x, const std::vector<uint32_t> &e) {
+    char buf[160];
+    int nbits = 0;
+    for (int i = (int)e.size() * 32 - 1; i >= 0 && !nbits; i--)
+        if ((e[i / 32] >> (i % 32)) & 1u) nbits = i + 1;
+    if (!nbits) { snprintf(buf, sizeof buf, "            %s = fe_one();\n", x); s += buf; return; }
+    PowPlan best = pow_plan(e, nbits, 1);
+    for (int w = 2; w <= 5; w++) {
+        PowPlan pl = pow_plan(e, nbits, w);
+        if (pl.cost < best.cost) best = pl;
+    }
+    if (best.steps.size() == 1 && best.steps[0].second == 1) return;     // x^1
+    s += "            {\n";
+    snprintf(buf, sizeof buf, "                const fe p1 = %s;\n", x); s += buf;
+    if (best.table_max > 1) {
+        s += "                const fe p2 = gs_sqr(p1);\n";
+        for (uint32_t v = 3; v <= best.table_max; v += 2) { snprintf(buf, sizeof buf, "                const fe p%u = gs_mul(p%u, p2);\n", v, v - 2); s += buf; }
+    }
+    snprintf(buf, sizeof buf, "                fe acc = p%u;\n", best.steps[0].second); s += buf;
+    for (size_t k = 1; k < best.steps.size(); k++) {
+        const uint32_t sq = best.steps[k].first, val = best.steps[k].second;
+        if (sq >= 4) { snprintf(buf, sizeof buf, "#pragma nounroll\n                for (int q = 0; q < %u; q++) acc = gs_sqr(acc);\n", sq); s += buf; }
+        else for (uint32_t q = 0; q < sq; q++) s += "                acc = gs_sqr(acc);\n";
+        if (val) { snprintf(buf, sizeof buf, "                acc = gs_mul(acc, p%u);\n", val); s += buf; }
+    }
+    snprintf(buf, sizeof buf, "                %s = acc;\n            }\n", x); s += buf;
+}
+
+// adjacent exponentiations with one exponent whose results do not feed each other (the S-boxes of a round)
+static uint32_t pow_group_size(const uint32_t *code, uint32_t ninstr, uint32_t pc) {
+    const uint32_t op = code[4 * pc], b = code[4 * pc + 3];
+    uint32_t g = 1;
+    while (g < 4 && pc + g < ninstr) {
+        const uint32_t *nx = code + 4 * (pc + g);
+        bool ok = nx[0] == op && nx[3] == b;
+        for (uint32_t i = 0; ok && i < g; i++) ok = nx[2] != code[4 * (pc + i) + 1];
+        if (!ok) break;
+        g++;
+    }
+    return g;
+}
+
 // straight-line statements for one program; `index` names the loop variable static tables are indexed by
-static bool jit_body(std::string &s, const uint32_t *code, uint32_t ninstr, const uint64_t *soff, const uint64_t *slen, bool allow_statics,
-                     const char *cur, const char *nxt, const char *index, const char *sink) {
+static bool jit_body(std::string &s, const JitGen &gen, const uint32_t *code, uint32_t ninstr, const uint64_t *soff, const uint64_t *slen,
+                     bool allow_statics, const char *cur, const char *nxt, const char *index, const char *sink) {
     char buf[256];
     for (uint32_t pc = 0; pc < ninstr; pc++) {
         const uint32_t op = code[4 * pc], d = code[4 * pc + 1], a = code[4 * pc + 2], b = code[4 * pc + 3];
@@ -98,33 +172,31 @@ static bool jit_body(std::string &s, const uint32_t *code, uint32_t ninstr, cons
                 break;
             case J_ADDV: snprintf(buf, sizeof buf, "        t%u = fe_add(t%u, t%u);\n", d, a, b); break;
             case J_SUBV: snprintf(buf, sizeof buf, "        t%u = fe_sub(t%u, t%u);\n", d, a, b); break;
-            case J_MULV: snprintf(buf, sizeof buf, "        t%u = fe_mul(t%u, t%u);\n", d, a, b); break;
+            case J_MULV: snprintf(buf, sizeof buf, "        t%u = gs_mul(t%u, t%u);\n", d, a, b); break;
             case J_POW:
             case J_POWC: {
-                // adjacent exponentiations with the same exponent whose results do not feed each other: interleaved chains
-                uint32_t g = 1;
-                while (g < 4 && pc + g < ninstr) {
-                    const uint32_t *nx = code + 4 * (pc + g);
-                    bool ok = nx[0] == op && nx[3] == b;
-                    for (uint32_t i = 0; ok && i < g; i++) ok = nx[2] != code[4 * (pc + i) + 1];
-                    if (!ok) break;
-                    g++;
+                std::vector<uint32_t> e(GS_ELT / 4, 0u);
+                if (op == J_POW) e[0] = b;
+                else {
+                    if (!gen.consts || b >= gen.nconsts) return false;
+                    memcpy(e.data(), gen.consts + (size_t)b * GS_ELT, GS_ELT);
                 }
-                if (op == J_POW && b <= 8 && g == 1) {
-                    snprintf(buf, sizeof buf, "        t%u = fe_pow_u64(t%u, %uull);\n", d, a, b);
-                    break;
-                }
+                const uint32_t g = pow_group_size(code, ninstr, pc);
+                bool wide_exponent = false;
+                for (size_t i = 1; i < e.size(); i++) wide_exponent |= e[i] != 0;
                 s += "        {\n";
-                snprintf(buf, sizeof buf, "            fe x[%u] = {", g);
-                s += buf;
-                for (uint32_t i = 0; i < g; i++) { snprintf(buf, sizeof buf, "%st%u", i ? ", " : "", code[4 * (pc + i) + 2]); s += buf; }
-                s += "};\n";
-                if (op == J_POWC) snprintf(buf, sizeof buf, "            const fe e = consts[%u];\n", b);
-                else snprintf(buf, sizeof buf, "            const fe e = fe_make(%uu, 0u, 0u, 0u);\n", b);
-                s += buf;
-                snprintf(buf, sizeof buf, "            gs_pow_group<%u>(x, e);\n", g);
-                s += buf;
-                for (uint32_t i = 0; i < g; i++) { snprintf(buf, sizeof buf, "            t%u = x[%u];\n", code[4 * (pc + i) + 1], i); s += buf; }
+                if (gen.lanes > 1 && g > 1 && wide_exponent) {
+                    // a long chain per member and nothing else to overlap it with: one member per lane of the segment's group
+                    snprintf(buf, sizeof buf, "            fe x = t%u;\n", code[4 * pc + 2]); s += buf;
+                    if (g > gen.lanes) return false;         // (lanes is chosen as the largest group's size)
+                    for (uint32_t i = 1; i < g; i++) { snprintf(buf, sizeof buf, "            if (sub == %uu) x = t%u;\n", i, code[4 * (pc + i) + 2]); s += buf; }
+                    emit_pow(s, "x", e);
+                    for (uint32_t i = 0; i < g; i++) { snprintf(buf, sizeof buf, "            t%u = gs_from_lane<%u>(x, %u);\n", code[4 * (pc + i) + 1], gen.lanes, i); s += buf; }
+                } else {
+                    for (uint32_t i = 0; i < g; i++) { snprintf(buf, sizeof buf, "            fe x%u = t%u;\n", i, code[4 * (pc + i) + 2]); s += buf; }
+                    for (uint32_t i = 0; i < g; i++) { snprintf(buf, sizeof buf, "x%u", i); emit_pow(s, std::string(buf).c_str(), e); }
+                    for (uint32_t i = 0; i < g; i++) { snprintf(buf, sizeof buf, "            t%u = x%u;\n", code[4 * (pc + i) + 1], i); s += buf; }
+                }
                 snprintf(buf, sizeof buf, "        }\n");
                 pc += g - 1;
                 break;
@@ -137,16 +209,27 @@ static bool jit_body(std::string &s, const uint32_t *code, uint32_t ninstr, cons
     return true;
 }
 
-static JitKernel *jit_get(gs_ctx *c, const std::string &source, const char *entry) {
-    std::lock_guard<std::mutex> lock(g_jit_mutex);
-    auto it = g_jit_cache.find(source);
-    if (it != g_jit_cache.end()) return it->second.failed ? nullptr : &it->second;
-    JitKernel &k = g_jit_cache[source];
-    k.failed = true;
+// lanes per segment for a trace program: the size of its largest group of long exponentiations (rounded up to a power of 2)
+static uint32_t trace_lanes(const JitGen &gen, const uint32_t *code, uint32_t ninstr) {
+    uint32_t lanes = 1;
+    for (uint32_t pc = 0; pc < ninstr; pc++) {
+        if (code[4 * pc] != J_POWC || !gen.consts || code[4 * pc + 3] >= gen.nconsts) continue;
+        const uint8_t *e = gen.consts + (size_t)code[4 * pc + 3] * GS_ELT;
+        bool wide_exponent = false;
+        for (int i = 4; i < GS_ELT; i++) wide_exponent |= e[i] != 0;
+        const uint32_t g = pow_group_size(code, ninstr, pc);
+        if (wide_exponent && g > lanes) lanes = g;
+        pc += g - 1;
+    }
+    return lanes == 3 ? 4 : lanes;
+}
+
+// hiprtc: source -> gfx950 code object (no device needed); false + log on failure
+static bool jit_compile(const std::string &source, const char *entry, std::vector<char> &code, std::string &log) {
     hiprtcProgram prog;
     const char *header_names[] = {"gs_field.cuh"};
     const char *headers[] = {kFieldHeader};
-    if (hiprtcCreateProgram(&prog, source.c_str(), "gs_air_jit.hip", 1, headers, header_names) != HIPRTC_SUCCESS) return nullptr;
+    if (hiprtcCreateProgram(&prog, source.c_str(), "gs_air_jit.hip", 1, headers, header_names) != HIPRTC_SUCCESS) { log = "hiprtcCreateProgram failed"; return false; }
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
     const char *verbose = getenv("GSTARK_AIR_JIT_VERBOSE");
     if (verbose) fprintf(stderr, "[gstark] compiling an AIR program (%zu bytes of source, entry %s)\n", source.size(), entry);
@@ -154,18 +237,29 @@ static JitKernel *jit_get(gs_ctx *c, const std::string &source, const char *entr
     if (r != HIPRTC_SUCCESS) {
         size_t ls = 0;
         hiprtcGetProgramLogSize(prog, &ls);
-        std::string log(ls, 0);
+        log.assign(ls, 0);
         if (ls) hiprtcGetProgramLog(prog, &log[0]);
-        gs_fail(c, GS_ERR_DEVICE, "air jit: %.400s", log.c_str());
         if (verbose) fprintf(stderr, "[gstark] hiprtc failed, interpreting instead:\n%s\n%.3000s\n", log.c_str(), verbose[0] == '2' ? source.c_str() : "");
         hiprtcDestroyProgram(&prog);
-        return nullptr;
+        return false;
     }
     size_t cs = 0;
     hiprtcGetCodeSize(prog, &cs);
-    std::vector<char> code(cs);
+    code.resize(cs);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
+    return true;
+}
+
+static JitKernel *jit_get(gs_ctx *c, const std::string &source, const char *entry) {
+    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    auto it = g_jit_cache.find(source);
+    if (it != g_jit_cache.end()) return it->second.failed ? nullptr : &it->second;
+    JitKernel &k = g_jit_cache[source];
+    k.failed = true;
+    std::vector<char> code;
+    std::string log;
+    if (!jit_compile(source, entry, code, log)) { gs_fail(c, GS_ERR_DEVICE, "air jit: %.400s", log.c_str()); return nullptr; }
     if (hipModuleLoadData(&k.module, code.data()) != hipSuccess) return nullptr;
     if (hipModuleGetFunction(&k.fn, k.module, entry) != hipSuccess) return nullptr;
     k.failed = false;
@@ -174,14 +268,20 @@ static JitKernel *jit_get(gs_ctx *c, const std::string &source, const char *entr
 
 // ---- trace segments --------------------------------------------------------------------------------------------------------------
 // returns GS_OK when the compiled kernel was launched, GS_ERR_UNSUPPORTED when the caller should interpret instead
-int gs_jit_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const uint32_t *icode, uint32_t init_ninstr, uint32_t vm_regs,
-                          uint32_t registers, const uint64_t *soff, const uint64_t *slen, const fe *dconst, const fe *dstat, const fe *drows,
-                          uint64_t segments, uint64_t seglen, fe *out) {
-    std::string s = jit_preamble();
+static bool jit_trace_source(std::string &s, JitGen &gen, const uint32_t *code, uint32_t ninstr, const uint32_t *icode, uint32_t init_ninstr,
+                             uint32_t vm_regs, uint32_t registers, const uint64_t *soff, const uint64_t *slen) {
+    s = jit_preamble();
     char buf[256];
+    // One thread per segment pays the full latency of every dependent product (one wave per SIMD at best: nothing to hide it with),
+    // and an S-box layer of long exponentiations is `registers` such chains one after the other.  With L lanes per segment every
+    // lane runs the whole program (redundantly: the lanes are free) but only ITS member of such a layer, and the lanes swap results.
+    gen.lanes = trace_lanes(gen, code, ninstr);
+    snprintf(buf, sizeof buf, "#define GS_LANES %uu\n", gen.lanes); s += buf;
     s += "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void gs_jit_trace(const fe *__restrict__ consts, const fe *__restrict__ statics, const fe *__restrict__ first_rows,\n"
          "                                         unsigned long long segments, unsigned long long seglen, fe *__restrict__ out) {\n"
-         "    const unsigned long long g = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;\n"
+         "    const unsigned long long tid = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;\n"
+         "    const unsigned long long g = tid / GS_LANES;\n"
+         "    const unsigned int sub = (unsigned int)(tid % GS_LANES);\n"
          "    if (g >= segments) return;\n"
          "    const unsigned long long steps = segments * seglen;\n";
     for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "    fe r%u = first_rows[g * %uull + %uull], n%u;\n", r, registers, r, r); s += buf; }
@@ -189,33 +289,43 @@ int gs_jit_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t ninstr, cons
     if (init_ninstr) {
         s += "    {\n";
         for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "        n%u = r%u;\n", r, r); s += buf; }
-        if (!jit_body(s, icode, init_ninstr, soff, slen, false, "r", nullptr, "0ull", "n")) return GS_ERR_UNSUPPORTED;
+        if (!jit_body(s, gen, icode, init_ninstr, soff, slen, false, "r", nullptr, "0ull", "n")) return false;
         for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "        r%u = n%u;\n", r, r); s += buf; }
         s += "    }\n";
     }
     s += "    for (unsigned long long k = 0; k < seglen; k++) {\n"
          "        const unsigned long long i = g * seglen + k;\n";
-    for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "        out[%uull * steps + i] = r%u;\n", r, r); s += buf; }
+    for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "        if (sub == %uu) out[%uull * steps + i] = r%u;\n", r % gen.lanes, r, r); s += buf; }
     s += "        if (k + 1 == seglen) break;\n";
     for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "        n%u = r%u;\n", r, r); s += buf; }
-    if (!jit_body(s, code, ninstr, soff, slen, true, "r", nullptr, "i", "n")) return GS_ERR_UNSUPPORTED;
+    if (!jit_body(s, gen, code, ninstr, soff, slen, true, "r", nullptr, "i", "n")) return false;
     for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "        r%u = n%u;\n", r, r); s += buf; }
     s += "    }\n}\n";
+    return true;
+}
+
+int gs_jit_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const uint32_t *icode, uint32_t init_ninstr, const uint8_t *consts_host,
+                          uint32_t nconsts, uint32_t vm_regs, uint32_t registers, const uint64_t *soff, const uint64_t *slen, const fe *dconst,
+                          const fe *dstat, const fe *drows, uint64_t segments, uint64_t seglen, fe *out) {
+    std::string s;
+    JitGen gen;
+    gen.consts = consts_host;
+    gen.nconsts = nconsts;
+    if (!jit_trace_source(s, gen, code, ninstr, icode, init_ninstr, vm_regs, registers, soff, slen)) return GS_ERR_UNSUPPORTED;
     JitKernel *k = jit_get(c, s, "gs_jit_trace");
     if (!k) return GS_ERR_UNSUPPORTED;
     unsigned long long a_segments = segments, a_seglen = seglen;
     void *args[] = {(void *)&dconst, (void *)&dstat, (void *)&drows, (void *)&a_segments, (void *)&a_seglen, (void *)&out};
-    const unsigned block = 64, grid = (unsigned)((segments + block - 1) / block);
+    const unsigned block = 64, grid = (unsigned)((segments * gen.lanes + block - 1) / block);
     if (hipModuleLaunchKernel(k->fn, grid, 1, 1, block, 1, 1, 0, c->stream, args, nullptr) != hipSuccess) return GS_ERR_UNSUPPORTED;
     c->jit_launches++;
     return GS_OK;
 }
 
 // ---- constraints -----------------------------------------------------------------------------------------------------------------
-int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, uint32_t vm_regs, uint32_t registers, const uint64_t *soff,
-                       const uint64_t *slen, const fe *dconst, const fe *p, uint64_t nc, uint64_t shift, const fe *statics, fe *out) {
-    (void)registers;
-    std::string s = jit_preamble();
+static bool jit_constraints_source(std::string &s, const JitGen &gen, const uint32_t *code, uint32_t ninstr, uint32_t vm_regs, const uint64_t *soff,
+                                   const uint64_t *slen) {
+    s = jit_preamble();
     char buf[256];
     s += "extern \"C\" __global__ __launch_bounds__(128) void gs_jit_constraints(const fe *__restrict__ consts, const fe *__restrict__ p, unsigned long long nc,\n"
          "                                               unsigned long long shift, const fe *__restrict__ statics, fe *__restrict__ out) {\n";
@@ -235,12 +345,24 @@ int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, uint32_
             // runs of arithmetic go through the common generator (so that exponentiation groups are found)
             uint32_t end = pc;
             while (end < ninstr && tmp[4 * end] != J_LOADR && tmp[4 * end] != J_LOADN && tmp[4 * end] != J_OUT) end++;
-            if (!jit_body(body, tmp.data() + 4 * pc, end - pc, soff, slen, true, "r", nullptr, "j", "n")) return GS_ERR_UNSUPPORTED;
+            if (!jit_body(body, gen, tmp.data() + 4 * pc, end - pc, soff, slen, true, "r", nullptr, "j", "n")) return false;
             pc = end - 1;
         }
     }
     s += body;
     s += "    }\n}\n";
+    return true;
+}
+
+int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs,
+                       uint32_t registers, const uint64_t *soff, const uint64_t *slen, const fe *dconst, const fe *p, uint64_t nc, uint64_t shift,
+                       const fe *statics, fe *out) {
+    (void)registers;
+    std::string s;
+    JitGen gen;
+    gen.consts = consts_host;
+    gen.nconsts = nconsts;
+    if (!jit_constraints_source(s, gen, code, ninstr, vm_regs, soff, slen)) return GS_ERR_UNSUPPORTED;
     JitKernel *k = jit_get(c, s, "gs_jit_constraints");
     if (!k) return GS_ERR_UNSUPPORTED;
     unsigned long long a_nc = nc, a_shift = shift;
@@ -249,4 +371,28 @@ int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, uint32_
     if (hipModuleLaunchKernel(k->fn, grid, 1, 1, block, 1, 1, 0, c->stream, args, nullptr) != hipSuccess) return GS_ERR_UNSUPPORTED;
     c->jit_launches++;
     return GS_OK;
+}
+
+// Compile-only check (no device, no context): does the generated source for this program build for gfx950?  kind 0: trace segments
+// (code + optional init program), kind 1: constraints.  The "does it build" tier of the tests runs it on machines without a GPU.
+extern "C" int gs_air_jit_check(int kind, const uint32_t *code, uint32_t ninstr, const uint32_t *init_code, uint32_t init_ninstr,
+                                const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs, uint32_t registers, const uint64_t *static_lens,
+                                uint32_t nstatic, char *log_out, uint64_t log_cap) {
+    if (!code || !ninstr || nstatic > GS_AIR_MAX_REGISTERS || (nstatic && !static_lens) || (nconsts && !consts_host)) return GS_ERR_ARG;
+    JitGen gen;
+    gen.consts = consts_host;
+    gen.nconsts = nconsts;
+    uint64_t soff[GS_AIR_MAX_REGISTERS], slen[GS_AIR_MAX_REGISTERS], off = 0;
+    for (uint32_t s = 0; s < GS_AIR_MAX_REGISTERS; s++) {
+        soff[s] = off;
+        slen[s] = s < nstatic ? static_lens[s] : 1;
+        if (s < nstatic) off += static_lens[s];
+    }
+    std::string src, log;
+    const bool ok = kind == 0 ? jit_trace_source(src, gen, code, ninstr, init_code, init_ninstr, vm_regs, registers, soff, slen)
+                              : jit_constraints_source(src, gen, code, ninstr, vm_regs, soff, slen);
+    std::vector<char> obj;
+    const bool built = ok && jit_compile(src, kind == 0 ? "gs_jit_trace" : "gs_jit_constraints", obj, log);
+    if (log_out && log_cap) snprintf(log_out, log_cap, "%s", !ok ? "the program has an instruction the generator does not know" : log.c_str());
+    return built ? GS_OK : GS_ERR_UNSUPPORTED;
 }

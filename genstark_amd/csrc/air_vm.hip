@@ -10,7 +10,6 @@
 
 enum { OP_LOADC = 0, OP_LOADR = 1, OP_LOADN = 2, OP_LOADS = 3, OP_ADDV = 4, OP_SUBV = 5, OP_MULV = 6, OP_POW = 7, OP_POWC = 8, OP_OUT = 9 };
 
-#define GS_HOST_TRACE_MAX_SEGMENTS 8   // fewer segments than this: one host core beats one device thread per segment
 
 struct StaticDesc {
     uint64_t offset[GS_AIR_MAX_REGISTERS];  // element offset into the concatenated table
@@ -280,7 +279,7 @@ int gs_air_constraints(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, co
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // host buffers are pageable and owned by the caller
     if (e != hipSuccess) { gs_tmp_free(c, dprog); return gs_fail(c, GS_ERR_DEVICE, "air_constraints upload: %s", hipGetErrorString(e)); }
     if (c->air_jit) {   // compiled form of the program (air_jit.hip); the interpreter below is the fallback
-        int jrc = gs_jit_constraints(c, code_host, ninstr, vm_regs, registers, sd.offset, sd.len, (const fe *)((uint8_t *)dprog + code_bytes),
+        int jrc = gs_jit_constraints(c, code_host, ninstr, consts_host, nconsts, vm_regs, registers, sd.offset, sd.len, (const fe *)((uint8_t *)dprog + code_bytes),
                                      (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, (fe *)out);
         if (jrc == GS_OK) { gs_tmp_free(c, dprog); return GS_OK; }
     }
@@ -318,7 +317,7 @@ int gs_air_trace_segments(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr,
             nstat += static_periods_host[s];
         }
     }
-    if (segments <= GS_HOST_TRACE_MAX_SEGMENTS)
+    if (segments <= c->host_trace_segments)
         return host_trace(c, code_host, ninstr, init_code_host, init_ninstr, consts_host, nconsts, vm_regs, registers, static_values_host,
                           static_periods_host, nstatic, first_rows_host, segments, segment_len, out);
     // program, constants, static values and first rows -> one device block (pageable caller memory: one sync)
@@ -338,7 +337,7 @@ int gs_air_trace_segments(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr,
     const uint4 *dcode = (const uint4 *)p, *dinit = (const uint4 *)(p + main_b);
     const fe *dconst = (const fe *)(p + code_b), *dstat = (const fe *)(p + code_b + const_b), *drows = (const fe *)(p + code_b + const_b + stat_b);
     if (c->air_jit) {   // compiled form of the program (air_jit.hip); the interpreter below is the fallback
-        int jrc = gs_jit_trace_segments(c, code_host, ninstr, init_code_host, init_ninstr, vm_regs, registers, sd.offset, sd.len, dconst, dstat, drows,
+        int jrc = gs_jit_trace_segments(c, code_host, ninstr, init_code_host, init_ninstr, consts_host, nconsts, vm_regs, registers, sd.offset, sd.len, dconst, dstat, drows,
                                         segments, segment_len, (fe *)out);
         if (jrc == GS_OK) { gs_tmp_free(c, d); return GS_OK; }
     }

@@ -32,6 +32,8 @@ GF_HD void fe_set_limb(fe &a, int i, uint32_t v) { a.w[i] = v; }
 
 struct NttPlan;  // ntt.hip
 
+#define GS_HOST_TRACE_MAX_SEGMENTS 8   // default of gs_ctx::host_trace_segments
+
 struct gs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -50,6 +52,7 @@ struct gs_ctx {
     void *d_stage = nullptr;
     uint64_t stage_bytes = 0;
     uint64_t jit_launches = 0;    // compiled-program launches so far (gs_air_jit_launches)
+    uint64_t host_trace_segments = GS_HOST_TRACE_MAX_SEGMENTS;   // traces of at most this many segments run on a host core (GSTARK_HOST_TRACE_SEGMENTS; air_vm.hip)
     bool air_jit = false;         // AIR programs compiled with hiprtc instead of interpreted (gs_air_jit / GSTARK_AIR_JIT=1)
     // deferred read-backs (gs_defer_begin / gs_defer_end): gathers only record the device addresses of the 16-byte words they want;
     // gs_defer_end fetches all of them with ONE kernel and one synchronisation
@@ -100,11 +103,12 @@ static inline unsigned gs_grid(uint64_t work_items, unsigned block = 256, unsign
 }
 
 // air_jit.hip: GS_OK = the compiled kernel was launched, GS_ERR_UNSUPPORTED = interpret instead
-int gs_jit_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const uint32_t *icode, uint32_t init_ninstr, uint32_t vm_regs,
-                          uint32_t registers, const uint64_t *soff, const uint64_t *slen, const fe *dconst, const fe *dstat, const fe *drows,
-                          uint64_t segments, uint64_t seglen, fe *out);
-int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, uint32_t vm_regs, uint32_t registers, const uint64_t *soff,
-                       const uint64_t *slen, const fe *dconst, const fe *p, uint64_t nc, uint64_t shift, const fe *statics, fe *out);
+int gs_jit_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const uint32_t *icode, uint32_t init_ninstr, const uint8_t *consts_host,
+                          uint32_t nconsts, uint32_t vm_regs, uint32_t registers, const uint64_t *soff, const uint64_t *slen, const fe *dconst,
+                          const fe *dstat, const fe *drows, uint64_t segments, uint64_t seglen, fe *out);
+int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs,
+                       uint32_t registers, const uint64_t *soff, const uint64_t *slen, const fe *dconst, const fe *p, uint64_t nc, uint64_t shift,
+                       const fe *statics, fe *out);
 
 // NTT entry points implemented in ntt.hip and used by other units
 void gs_plans_destroy(gs_ctx *c);

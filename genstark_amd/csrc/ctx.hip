@@ -51,6 +51,8 @@ int gs_ctx_create(int device, void *hip_stream, gs_ctx **out) {
     }
     const char *jit = getenv("GSTARK_AIR_JIT");
     c->air_jit = jit && jit[0] && jit[0] != '0';
+    c->host_trace_segments = GS_HOST_TRACE_MAX_SEGMENTS;
+    if (const char *hs = getenv("GSTARK_HOST_TRACE_SEGMENTS")) c->host_trace_segments = strtoull(hs, nullptr, 10);
     *out = c;
     return GS_OK;
 }

@@ -281,6 +281,12 @@ int gs_air_trace_segments(gs_ctx *ctx, const uint32_t *code_host, uint32_t ninst
  * not pay for the compilation); GSTARK_AIR_JIT=1 in the environment turns it on for every context. */
 int gs_air_jit(gs_ctx *ctx, int enable);
 uint64_t gs_air_jit_launches(const gs_ctx *ctx);       /* how many launches ran compiled programs so far (0: everything was interpreted) */
+/* Compile-only check, no context and no device: GS_OK when the source generated for the program builds for gfx950 (kind 0: the
+ * trace program with its optional init program, arguments as gs_air_trace_segments; kind 1: the constraint program, arguments as
+ * gs_air_constraints).  GS_ERR_UNSUPPORTED otherwise, with the compiler's log (NUL-terminated, truncated) in log_out. */
+int gs_air_jit_check(int kind, const uint32_t *code_host, uint32_t ninstr, const uint32_t *init_code_host, uint32_t init_ninstr,
+                     const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs, uint32_t registers,
+                     const uint64_t *static_lens_host, uint32_t nstatic, char *log_out, uint64_t log_cap);
 int gs_air_constraints(gs_ctx *ctx, const uint32_t *code_host, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts,
                        uint32_t vm_regs, uint32_t registers, uint32_t constraints, const void *p_comp /* registers x nc */,
                        uint64_t nc, uint64_t shift, const void *static_tables /* device, concatenated */,

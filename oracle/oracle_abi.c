@@ -73,6 +73,13 @@ int gs_gather(gs_ctx *c, const void *src, uint64_t rec, const uint64_t *idx, uin
 
 int gs_air_jit(gs_ctx *c, int enable) { (void)c; (void)enable; return GS_OK; }   /* the oracle interprets */
 uint64_t gs_air_jit_launches(const gs_ctx *c) { (void)c; return 0; }
+int gs_air_jit_check(int kind, const uint32_t *code, uint32_t ninstr, const uint32_t *icode, uint32_t init_ninstr, const uint8_t *consts,
+                     uint32_t nconsts, uint32_t vm_regs, uint32_t registers, const uint64_t *lens, uint32_t nstatic, char *log_out,
+                     uint64_t log_cap) {
+    (void)consts; (void)nconsts; (void)kind; (void)code; (void)ninstr; (void)icode; (void)init_ninstr; (void)vm_regs; (void)registers; (void)lens; (void)nstatic;
+    if (log_out && log_cap) snprintf(log_out, log_cap, "the oracle has no code generator");
+    return GS_ERR_UNSUPPORTED;
+}
 int gs_defer_begin(gs_ctx *c) { (void)c; return GS_OK; }   /* host memory: every read-back is immediate */
 int gs_defer_end(gs_ctx *c) { (void)c; return GS_OK; }
 

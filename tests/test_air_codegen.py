@@ -1,0 +1,49 @@
+"""The code generator of csrc/air_jit.hip, checked where there is no GPU: gs_air_jit_check turns an AIR program into HIP source and
+runs the compiler (hiprtc cross-compiles gfx950 without a device) — the "does it build" tier for what a serving prover compiles at
+run time.  The values the compiled programs compute are compared with the interpreter's in the gpu tier
+(test_generic_air.py::test_compiled_air_programs_equal_interpreted, test_pipeline.py)."""
+import ctypes as C
+
+import pytest
+
+from genstark_amd import lib224, poseidon
+from genstark_amd._abi import GS_OK, HIP_LIB_PATHS, MODULUS_128, MODULUS_224, load_library
+from genstark_amd.pointmul import point_mul_air
+from genstark_amd.field import PrimeField
+from test_generic_air import rescue4x128_air
+from test_wide_fields import oracle_for
+
+
+@pytest.fixture(scope='module')
+def hip_libs():
+    """The product libraries, loaded without a context (no device needed for the compiler)."""
+    return {m: load_library(HIP_LIB_PATHS[m]) for m in (MODULUS_128, MODULUS_224)}
+
+
+def builds(air, lib):
+    results = air.compileCheck(lib)
+    assert [name for name, _, _ in results] == (['trace', 'constraints'] if air.segmentLength is not None else ['constraints'])
+    for name, ok, log in results:
+        assert ok, f'{name} program does not build:\n{log}'
+
+
+def test_example_air_programs_build_for_gfx950(oracle_backend, hip_libs):
+    f = PrimeField(backend=oracle_backend)              # the AIR objects only need a field to reduce their constants with
+    builds(rescue4x128_air(1024, 16, f, segmented=True), hip_libs[MODULUS_128])      # examples/rescue/hash4x128.ts
+    builds(poseidon.poseidon6x128_air(2048, 16, f, segmented=True), hip_libs[MODULUS_128])   # examples/poseidon/hash6x128.ts
+    builds(rescue4x128_air(64, 16, f), hip_libs[MODULUS_128])                        # unsegmented: constraints only
+
+
+def test_wide_field_air_programs_build_for_gfx950(hip_libs):
+    f = PrimeField(backend=oracle_for('p224'))
+    builds(point_mul_air(f), hip_libs[MODULUS_224])                                  # examples/elliptic/pointmul.aa (divisions: POWC)
+    builds(lib224.verify_schnorr_signature_air(f), hip_libs[MODULUS_224])            # assembly/lib224.aa, 14 registers
+
+
+def test_unknown_instruction_is_refused_with_a_reason(hip_libs):
+    lib = hip_libs[MODULUS_128]
+    log = C.create_string_buffer(256)
+    bad = (C.c_uint32 * 4)(99, 0, 0, 0)
+    assert lib.gs_air_jit_check(1, bad, 1, None, 0, None, 0, 4, 1, None, 0, log, len(log)) != GS_OK
+    assert b'instruction' in log.value
+    assert lib.gs_air_jit_check(1, None, 0, None, 0, None, 0, 4, 1, None, 0, log, len(log)) != GS_OK       # no program

@@ -165,3 +165,33 @@ def test_wide_field_hip(name):
 @pytest.mark.gpu
 def test_point_multiplication_hip():
     assert check_point_mul(hip_for('p224')) == check_point_mul(oracle_for('p224'))
+
+
+def point_mul16(backend):
+    """16 multiplications in one trace: the size where the device runs the transition program (one thread per multiplication)."""
+    f = PrimeField(backend=backend)
+    air = point_mul_air(f, 16)
+    ks = [EC_SCALAR + 7 * i for i in range(16)]
+    raw = [[EC_POINT[0]] * 16, [EC_POINT[1]] * 16, [to_bits(k) for k in ks]]
+    inputs, seeds = air.expandInputs(raw), air.segmentSeeds(raw)
+    trace = air.initProvingContext(inputs, seeds).generateExecutionTrace().toValues()
+    stark = Stark(air, EC_OPTIONS)
+    assertions = [{'step': 256 * i + 255, 'register': 2, 'value': ec_multiply(MODULUS_224, EC_POINT, ks[i])[0]} for i in (0, 9, 15)]
+    data = stark.serialize(stark.prove(assertions, inputs, seeds))
+    assert stark.verify(assertions, stark.parse(data))
+    return trace, data
+
+
+@pytest.mark.gpu
+def test_compiled_point_multiplication_equals_interpreted():
+    """gs_air_jit in the 224-bit flavour (products are calls there, csrc/air_jit.hip): same trace, same proof bytes, and the compiled
+    programs really ran."""
+    plain, compiled = hip_for('p224'), hip_for('p224').jit()
+    try:
+        want = point_mul16(plain)
+        assert compiled.jit_launches == 0
+        assert point_mul16(compiled) == want
+        assert compiled.jit_launches >= 2 and plain.jit_launches == 0
+    finally:
+        compiled.close()
+        plain.close()
