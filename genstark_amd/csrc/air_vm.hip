@@ -194,6 +194,45 @@ static int check_program(gs_ctx *c, const uint32_t *code, uint32_t ninstr, uint3
 // One host core interprets the program on native limbs (host_field.h): the whole trace of an unsegmented AIR (steps are
 // sequentially dependent), and segmented AIRs with only a few segments — one device thread per segment is an order of magnitude
 // slower than a host core per step, which only pays off when many segments run side by side.
+// x^e for an element-sized exponent: left-to-right windows of 4 bits over a table of the odd powers x, x^3 .. x^15 (short exponents:
+// plain square-and-multiply).  A 128-bit exponent is 127 squarings + ~34 products instead of ~64; p - 2 of the 224-bit field, almost
+// all ones, 224 + 53 instead of 224 + 222.  Same element: the chain does not change the value.
+#ifndef HF_CHAIN_MUL
+#define HF_CHAIN_MUL hf_mul
+#define HF_CHAIN_END(x) (x)
+#endif
+static hfe host_pow(hfe x, hfe e) {
+    uint8_t eb[GS_ELT];
+    hf_store(eb, e);
+    int nbits = 0;
+    for (int i = GS_ELT * 8 - 1; i >= 0 && !nbits; i--)
+        if ((eb[i / 8] >> (i % 8)) & 1) nbits = i + 1;
+    if (nbits <= 16) return hf_pow(x, e);
+    auto bit = [&](int i) { return (eb[i / 8] >> (i % 8)) & 1; };
+    hfe tab[8];                                  // tab[k] = x^(2k+1)
+    const hfe x2 = HF_CHAIN_MUL(x, x);
+    tab[0] = x;
+    for (int k = 1; k < 8; k++) tab[k] = HF_CHAIN_MUL(tab[k - 1], x2);
+    hfe acc = x;
+    bool first = true;
+    int i = nbits - 1;
+    while (i >= 0) {
+        if (!bit(i)) { acc = HF_CHAIN_MUL(acc, acc); i--; continue; }
+        int j = i - 3 < 0 ? 0 : i - 3;
+        while (!bit(j)) j++;
+        int val = 0;
+        for (int k = i; k >= j; k--) val = 2 * val + bit(k);
+        if (first) acc = tab[val >> 1];
+        else {
+            for (int k = i; k >= j; k--) acc = HF_CHAIN_MUL(acc, acc);
+            acc = HF_CHAIN_MUL(acc, tab[val >> 1]);
+        }
+        first = false;
+        i = j - 1;
+    }
+    return HF_CHAIN_END(acc);
+}
+
 static void host_run(const uint32_t *code, uint32_t ninstr, const std::vector<hfe> &consts, std::vector<hfe> &vm, const std::vector<hfe> &row,
                      std::vector<hfe> &next, const std::vector<std::vector<hfe>> *statics, uint64_t i) {
     for (uint32_t pc = 0; pc < ninstr; pc++) {
@@ -206,7 +245,7 @@ static void host_run(const uint32_t *code, uint32_t ninstr, const std::vector<hf
             case OP_SUBV: vm[dst] = hf_sub(vm[a], vm[b]); break;
             case OP_MULV: vm[dst] = hf_mul(vm[a], vm[b]); break;
             case OP_POW: vm[dst] = hf_pow(vm[a], (hfe)b); break;
-            case OP_POWC: vm[dst] = hf_pow(vm[a], consts[b]); break;
+            case OP_POWC: vm[dst] = host_pow(vm[a], consts[b]); break;
             default: next[dst] = vm[a]; break;
         }
     }

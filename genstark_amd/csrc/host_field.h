@@ -99,6 +99,9 @@ static inline hfe hf_canon(hfe x) {
     while (x >= hf_p()) x -= hf_p();
     return x;
 }
+// products inside a long chain whose end is canonicalised once (host_pow in air_vm.hip)
+#define HF_CHAIN_MUL hf_mul_weak
+#define HF_CHAIN_END hf_canon
 static inline hfe hf_add(hfe a, hfe b) {
     hfe s = a + b;
     if (s < a || s >= hf_p()) s -= hf_p();
