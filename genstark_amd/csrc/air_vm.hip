@@ -191,48 +191,60 @@ static int check_program(gs_ctx *c, const uint32_t *code, uint32_t ninstr, uint3
     return GS_OK;
 }
 
-// One host core interprets the program on native limbs (host_field.h): the whole trace of an unsegmented AIR (steps are
-// sequentially dependent), and segmented AIRs with only a few segments — one device thread per segment is an order of magnitude
-// slower than a host core per step, which only pays off when many segments run side by side.
-// x^e for an element-sized exponent: left-to-right windows of 4 bits over a table of the odd powers x, x^3 .. x^15 (short exponents:
+// x^e for element-sized exponents: left-to-right windows of 4 bits over a table of the odd powers x, x^3 .. x^15 (short exponents:
 // plain square-and-multiply).  A 128-bit exponent is 127 squarings + ~34 products instead of ~64; p - 2 of the 224-bit field, almost
 // all ones, 224 + 53 instead of 224 + 222.  Same element: the chain does not change the value.
 #ifndef HF_CHAIN_MUL
 #define HF_CHAIN_MUL hf_mul
 #define HF_CHAIN_END(x) (x)
 #endif
-static hfe host_pow(hfe x, hfe e) {
+// x[k] <- x[k]^e for g <= 4 independent bases in lock step: a host core overlaps the products of the g chains (one chain alone is
+// bound by the latency of a product, ~2.5x its issue cost).
+static void host_pow_group(hfe *x, int g, hfe e) {
     uint8_t eb[GS_ELT];
     hf_store(eb, e);
     int nbits = 0;
     for (int i = GS_ELT * 8 - 1; i >= 0 && !nbits; i--)
         if ((eb[i / 8] >> (i % 8)) & 1) nbits = i + 1;
-    if (nbits <= 16) return hf_pow(x, e);
+    if (nbits <= 16) {
+        for (int k = 0; k < g; k++) x[k] = hf_pow(x[k], e);
+        return;
+    }
     auto bit = [&](int i) { return (eb[i / 8] >> (i % 8)) & 1; };
-    hfe tab[8];                                  // tab[k] = x^(2k+1)
-    const hfe x2 = HF_CHAIN_MUL(x, x);
-    tab[0] = x;
-    for (int k = 1; k < 8; k++) tab[k] = HF_CHAIN_MUL(tab[k - 1], x2);
-    hfe acc = x;
+    hfe tab[4][8], acc[4];                       // tab[k][m] = x[k]^(2m+1)
+    for (int k = 0; k < g; k++) {
+        const hfe x2 = HF_CHAIN_MUL(x[k], x[k]);
+        tab[k][0] = x[k];
+        for (int m = 1; m < 8; m++) tab[k][m] = HF_CHAIN_MUL(tab[k][m - 1], x2);
+    }
     bool first = true;
     int i = nbits - 1;
     while (i >= 0) {
-        if (!bit(i)) { acc = HF_CHAIN_MUL(acc, acc); i--; continue; }
+        if (!bit(i)) {
+            for (int k = 0; k < g; k++) acc[k] = HF_CHAIN_MUL(acc[k], acc[k]);
+            i--;
+            continue;
+        }
         int j = i - 3 < 0 ? 0 : i - 3;
         while (!bit(j)) j++;
         int val = 0;
-        for (int k = i; k >= j; k--) val = 2 * val + bit(k);
-        if (first) acc = tab[val >> 1];
-        else {
-            for (int k = i; k >= j; k--) acc = HF_CHAIN_MUL(acc, acc);
-            acc = HF_CHAIN_MUL(acc, tab[val >> 1]);
+        for (int q = i; q >= j; q--) val = 2 * val + bit(q);
+        if (first) {
+            for (int k = 0; k < g; k++) acc[k] = tab[k][val >> 1];
+        } else {
+            for (int q = i; q >= j; q--)
+                for (int k = 0; k < g; k++) acc[k] = HF_CHAIN_MUL(acc[k], acc[k]);
+            for (int k = 0; k < g; k++) acc[k] = HF_CHAIN_MUL(acc[k], tab[k][val >> 1]);
         }
         first = false;
         i = j - 1;
     }
-    return HF_CHAIN_END(acc);
+    for (int k = 0; k < g; k++) x[k] = HF_CHAIN_END(acc[k]);
 }
 
+// One host core interprets the program on native limbs (host_field.h): the whole trace of an unsegmented AIR (steps are
+// sequentially dependent), and segmented AIRs with only a few segments — one device thread per segment is an order of magnitude
+// slower than a host core per step, which only pays off when many segments run side by side.
 static void host_run(const uint32_t *code, uint32_t ninstr, const std::vector<hfe> &consts, std::vector<hfe> &vm, const std::vector<hfe> &row,
                      std::vector<hfe> &next, const std::vector<std::vector<hfe>> *statics, uint64_t i) {
     for (uint32_t pc = 0; pc < ninstr; pc++) {
@@ -245,7 +257,23 @@ static void host_run(const uint32_t *code, uint32_t ninstr, const std::vector<hf
             case OP_SUBV: vm[dst] = hf_sub(vm[a], vm[b]); break;
             case OP_MULV: vm[dst] = hf_mul(vm[a], vm[b]); break;
             case OP_POW: vm[dst] = hf_pow(vm[a], (hfe)b); break;
-            case OP_POWC: vm[dst] = host_pow(vm[a], consts[b]); break;
+            case OP_POWC: {
+                // adjacent exponentiations with this exponent whose results do not feed each other (an S-box layer): in lock step
+                int g = 1;
+                while (g < 4 && pc + g < ninstr) {
+                    const uint32_t *nx = code + 4 * (pc + g);
+                    bool ok = nx[0] == OP_POWC && nx[3] == b;
+                    for (int k = 0; ok && k < g; k++) ok = nx[2] != code[4 * (pc + k) + 1];
+                    if (!ok) break;
+                    g++;
+                }
+                hfe x[4];
+                for (int k = 0; k < g; k++) x[k] = vm[code[4 * (pc + k) + 2]];
+                host_pow_group(x, g, consts[b]);
+                for (int k = 0; k < g; k++) vm[code[4 * (pc + k) + 1]] = x[k];
+                pc += g - 1;
+                break;
+            }
             default: next[dst] = vm[a]; break;
         }
     }
