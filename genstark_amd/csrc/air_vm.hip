@@ -85,19 +85,31 @@ __device__ __forceinline__ void pow_group(fe (&x)[4], const fe &e) {
     for (int i = 0; i < G; i++) x[i] = r[i];
 }
 
-// one thread per independent trace segment: the same register machine, next-row outputs go to a private row buffer
+__device__ __forceinline__ fe fe_from_lane(const fe &v, int src, int width) {
+    fe r = v;
+#pragma unroll
+    for (int l = 0; l < GF_LIMBS; l++) fe_set_limb(r, l, (uint32_t)__shfl((int)fe_limb(v, l), src, width));
+    return r;
+}
+
+// `lanes` (1 or 4) consecutive threads per independent trace segment: the same register machine, next-row outputs go to a private
+// row buffer.  With 4 lanes every lane interprets the whole program, but a group of adjacent long exponentiations (an S-box layer)
+// is one member per lane, results swapped with shuffles: a segment's time is the latency of its dependent products, and the other
+// lanes of the wave are idle anyway (see air_jit.hip, which does the same in generated code).
 template <int NREG, bool LDS>
 __global__ void k_air_trace_segments(const uint4 *__restrict__ code, uint32_t ninstr, const uint4 *__restrict__ icode, uint32_t init_ninstr,
                                      const fe *__restrict__ consts,
                                      const fe *__restrict__ statics, StaticDesc sd, const fe *__restrict__ first_rows, uint32_t registers,
-                                     uint64_t segments, uint64_t seglen, uint32_t nvm, fe *__restrict__ out) {
+                                     uint64_t segments, uint64_t seglen, uint32_t nvm, uint32_t lanes, fe *__restrict__ out) {
     // The interpreter's register file (vm), the current row and the row being produced are indexed by the instruction stream:
     // as private arrays they live in scratch memory, and with one wave per SIMD nothing hides a scratch round trip (~670 cycles
     // per VM instruction measured).  LDS variant: slot s of lane l at lds[s * 64 + l] (16-byte words, conflict-free).
     extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem[];
     fe *const lds = reinterpret_cast<fe *>(vm_smem) + threadIdx.x;
     fe p_vm[LDS ? 1 : NREG], p_row[LDS ? 1 : GS_AIR_MAX_REGISTERS], p_next[LDS ? 1 : GS_AIR_MAX_REGISTERS];
-    const uint64_t g = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t g = tid / lanes;
+    const uint32_t sub = (uint32_t)(tid % lanes);
     if (g >= segments) return;
     const uint64_t steps = segments * seglen;
 #define vm(i) (*(LDS ? &lds[(uint32_t)(i) * 64] : &p_vm[LDS ? 0 : (i)]))
@@ -123,7 +135,10 @@ __global__ void k_air_trace_segments(const uint4 *__restrict__ code, uint32_t ni
     }
     for (uint64_t k = 0; k < seglen; k++) {
         const uint64_t i = g * seglen + k;
-        for (uint32_t r = 0; r < registers; r++) { out[(uint64_t)r * steps + i] = row(r); next(r) = row(r); }
+        for (uint32_t r = 0; r < registers; r++) {
+            if (r % lanes == sub) out[(uint64_t)r * steps + i] = row(r);
+            next(r) = row(r);
+        }
         if (k + 1 == seglen) break;
         for (uint32_t pc = 0; pc < ninstr; pc++) {
             const uint4 ins = code[pc];
@@ -148,8 +163,18 @@ __global__ void k_air_trace_segments(const uint4 *__restrict__ code, uint32_t ni
                         g++;
                     }
                     fe x[4];
-                    for (uint32_t i = 0; i < g; i++) x[i] = vm(code[pc + i].z);
                     const fe e = ins.x == OP_POWC ? consts[b] : fe_make(b, 0, 0, 0);
+                    bool long_e = false;
+#pragma unroll
+                    for (int l = 1; l < GF_LIMBS; l++) long_e |= fe_limb(e, l) != 0;
+                    if (lanes > 1 && g > 1 && long_e) {          // one member per lane (g <= 4 = lanes)
+                        x[0] = vm(code[pc + (sub < g ? sub : 0)].z);
+                        pow_group<1>(x, e);
+                        for (uint32_t i = 0; i < g; i++) vm(code[pc + i].y) = fe_from_lane(x[0], (int)i, (int)lanes);
+                        pc += g - 1;
+                        break;
+                    }
+                    for (uint32_t i = 0; i < g; i++) x[i] = vm(code[pc + i].z);
                     if (g == 4) pow_group<4>(x, e);
                     else if (g == 3) pow_group<3>(x, e);
                     else if (g == 2) pow_group<2>(x, e);
@@ -358,11 +383,20 @@ int gs_air_trace_segments(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr,
                                         segments, segment_len, (fe *)out);
         if (jrc == GS_OK) { gs_tmp_free(c, d); return GS_OK; }
     }
-    dim3 block(64), grid((unsigned)((segments + 63) / 64));   // one wave per 64 segments: spread the few long-running threads over the CUs
+    // 4 lanes per segment when the program has a layer of long exponentiations to split (same rule as the code generator's)
+    uint32_t lanes = 1;
+    for (uint32_t pc = 0; pc + 1 < ninstr && lanes == 1; pc++) {
+        const uint32_t *in = code_host + 4 * pc, *nx = in + 4;
+        if (in[0] != OP_POWC || nx[0] != OP_POWC || nx[3] != in[3] || nx[2] == in[1]) continue;
+        const uint8_t *ex = consts_host + (size_t)in[3] * GS_ELT;
+        for (int i = 4; i < GS_ELT; i++)
+            if (ex[i]) lanes = 4;
+    }
+    dim3 block(64), grid((unsigned)((segments * lanes + 63) / 64));   // one wave per 64 / lanes segments: the few long-running threads spread over the CUs
     const uint64_t lds_bytes = ((uint64_t)vm_regs + 2ull * registers) * 64 * GS_ELT;
 #define GS_LAUNCH_TRACE(N, L, SH)                                                                                                        \
     hipLaunchKernelGGL((k_air_trace_segments<N, L>), grid, block, SH, c->stream, dcode, ninstr, dinit, init_ninstr, dconst, dstat, sd, drows, \
-                       registers, segments, segment_len, vm_regs, (fe *)out)
+                       registers, segments, segment_len, vm_regs, lanes, (fe *)out)
     if (lds_bytes <= 160 * 1024) {   // gfx950: 160 KB of LDS per workgroup
         static bool attr_set = false;
         if (!attr_set) {
