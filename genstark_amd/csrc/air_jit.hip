@@ -81,7 +81,9 @@ struct JitGen {
 
 // x <- x^e as a fixed addition chain: left-to-right sliding windows over the bits of e (little-endian 32-bit limbs), the window
 // width chosen by counting products.  The inverse S-box of Rescue (a 128-bit exponent) is 127 squarings + 32 products instead of
-// the 127 + 64 of square-and-multiply; a Fermat inversion in the 224-bit field 224 + 53 instead of 224 + 222.
+// the 127 + 64 of square-and-multiply; a Fermat inversion in the 224-bit field 224 + 53 instead of 224 + 222.  (Right to left the
+// squarings and the running product are independent chains, but a wave issues in order and a loop does not interleave them: measured
+// in the trace kernel, 2.2 ms against 1.8 ms for the windows.)
 struct PowPlan {
     uint32_t table_max = 1;                                    // odd powers x^1 .. x^table_max are needed
     std::vector<std::pair<uint32_t, uint32_t>> steps;          // (squarings, odd power to multiply by; 0 = none); first: (0, start)
