@@ -12,6 +12,7 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "common.h"
@@ -154,7 +155,8 @@ static uint32_t pow_group_size(const uint32_t *code, uint32_t ninstr, uint32_t p
     return g;
 }
 
-// straight-line statements for one program; `index` names the loop variable static tables are indexed by
+// straight-line statements for a constraint program (one thread per domain point: throughput-bound, no lanes); `index` names the
+// loop variable static tables are indexed by
 static bool jit_body(std::string &s, const JitGen &gen, const uint32_t *code, uint32_t ninstr, const uint64_t *soff, const uint64_t *slen,
                      bool allow_statics, const char *cur, const char *nxt, const char *index, const char *sink) {
     char buf[256];
@@ -184,21 +186,10 @@ static bool jit_body(std::string &s, const JitGen &gen, const uint32_t *code, ui
                     memcpy(e.data(), gen.consts + (size_t)b * GS_ELT, GS_ELT);
                 }
                 const uint32_t g = pow_group_size(code, ninstr, pc);
-                bool wide_exponent = false;
-                for (size_t i = 1; i < e.size(); i++) wide_exponent |= e[i] != 0;
                 s += "        {\n";
-                if (gen.lanes > 1 && g > 1 && wide_exponent) {
-                    // a long chain per member and nothing else to overlap it with: one member per lane of the segment's group
-                    snprintf(buf, sizeof buf, "            fe x = t%u;\n", code[4 * pc + 2]); s += buf;
-                    if (g > gen.lanes) return false;         // (lanes is chosen as the largest group's size)
-                    for (uint32_t i = 1; i < g; i++) { snprintf(buf, sizeof buf, "            if (sub == %uu) x = t%u;\n", i, code[4 * (pc + i) + 2]); s += buf; }
-                    emit_pow(s, "x", e);
-                    for (uint32_t i = 0; i < g; i++) { snprintf(buf, sizeof buf, "            t%u = gs_from_lane<%u>(x, %u);\n", code[4 * (pc + i) + 1], gen.lanes, i); s += buf; }
-                } else {
-                    for (uint32_t i = 0; i < g; i++) { snprintf(buf, sizeof buf, "            fe x%u = t%u;\n", i, code[4 * (pc + i) + 2]); s += buf; }
-                    for (uint32_t i = 0; i < g; i++) { snprintf(buf, sizeof buf, "x%u", i); emit_pow(s, std::string(buf).c_str(), e); }
-                    for (uint32_t i = 0; i < g; i++) { snprintf(buf, sizeof buf, "            t%u = x%u;\n", code[4 * (pc + i) + 1], i); s += buf; }
-                }
+                for (uint32_t i = 0; i < g; i++) { snprintf(buf, sizeof buf, "            fe x%u = t%u;\n", i, code[4 * (pc + i) + 2]); s += buf; }
+                for (uint32_t i = 0; i < g; i++) { snprintf(buf, sizeof buf, "x%u", i); emit_pow(s, std::string(buf).c_str(), e); }
+                for (uint32_t i = 0; i < g; i++) { snprintf(buf, sizeof buf, "            t%u = x%u;\n", code[4 * (pc + i) + 1], i); s += buf; }
                 snprintf(buf, sizeof buf, "        }\n");
                 pc += g - 1;
                 break;
@@ -211,19 +202,267 @@ static bool jit_body(std::string &s, const JitGen &gen, const uint32_t *code, ui
     return true;
 }
 
-// lanes per segment for a trace program: the size of its largest group of long exponentiations (rounded up to a power of 2)
-static uint32_t trace_lanes(const JitGen &gen, const uint32_t *code, uint32_t ninstr) {
-    uint32_t lanes = 1;
+// ---- trace programs: products scheduled by depth and spread over the lanes of a segment ------------------------------------------
+// A thread of the trace kernel has its SIMD to itself, so it pays the full latency of every product it waits for, and the compiler
+// does not overlap inlined 128-bit products either: a compiled Poseidon round (36 MDS products + 18 S-box products) costs
+// 54 x ~750 cycles.  The program is therefore put in SSA form and every product gets a depth (1 + the depth of its operands;
+// additions, loads and outputs do not add depth): products of one depth are independent, and L of them run as ONE round — lane i of
+// the segment's group multiplies the i-th pair, the results are broadcast with shuffles, every lane continues with all values.
+// Cheap operations run redundantly on all lanes.  Long exponentiations of one depth and exponent are rounds of their own (one
+// member per lane).  L = 1, 2, 4 or 8 by the widest depth.
+struct SsaNode {
+    enum Kind { ZERO, CONSTV, ROW, STATICV, ADD, SUB, MUL, POWLONG, OUT } kind = ZERO;
+    int a = -1, b = -1;        // operand nodes (MUL/ADD/SUB/POWLONG/OUT: a; b for binary) or the index of a constant/register/static
+    uint32_t aux = 0;          // POWLONG: constant index of the exponent; OUT: destination register
+    int depth = 0;
+};
+
+static bool ssa_build(std::vector<SsaNode> &nodes, const JitGen &gen, const uint32_t *code, uint32_t ninstr, uint32_t vm_regs, bool allow_statics) {
+    std::vector<int> cur(vm_regs, -1);
+    auto add = [&](SsaNode n) { nodes.push_back(n); return (int)nodes.size() - 1; };
+    auto use = [&](uint32_t r) {
+        if (cur[r] < 0) { SsaNode z; cur[r] = add(z); }
+        return cur[r];
+    };
+    auto binary = [&](SsaNode::Kind k, int x, int y) {
+        SsaNode n;
+        n.kind = k; n.a = x; n.b = y;
+        n.depth = std::max(nodes[x].depth, nodes[y].depth) + (k == SsaNode::MUL ? 1 : 0);
+        return add(n);
+    };
     for (uint32_t pc = 0; pc < ninstr; pc++) {
-        if (code[4 * pc] != J_POWC || !gen.consts || code[4 * pc + 3] >= gen.nconsts) continue;
-        const uint8_t *e = gen.consts + (size_t)code[4 * pc + 3] * GS_ELT;
-        bool wide_exponent = false;
-        for (int i = 4; i < GS_ELT; i++) wide_exponent |= e[i] != 0;
-        const uint32_t g = pow_group_size(code, ninstr, pc);
-        if (wide_exponent && g > lanes) lanes = g;
-        pc += g - 1;
+        const uint32_t op = code[4 * pc], d = code[4 * pc + 1], a = code[4 * pc + 2], b = code[4 * pc + 3];
+        if (op != J_OUT && d >= vm_regs) return false;
+        SsaNode n;
+        switch (op) {
+            case J_LOADC: n.kind = SsaNode::CONSTV; n.a = (int)a; cur[d] = add(n); break;
+            case J_LOADR: n.kind = SsaNode::ROW; n.a = (int)a; cur[d] = add(n); break;
+            case J_LOADS:
+                if (!allow_statics) return false;
+                n.kind = SsaNode::STATICV; n.a = (int)a; cur[d] = add(n);
+                break;
+            case J_ADDV: case J_SUBV: case J_MULV: {
+                if (a >= vm_regs || b >= vm_regs) return false;
+                const int x = use(a), y = use(b);
+                cur[d] = binary(op == J_ADDV ? SsaNode::ADD : (op == J_SUBV ? SsaNode::SUB : SsaNode::MUL), x, y);
+                break;
+            }
+            case J_POW: case J_POWC: {
+                if (a >= vm_regs) return false;
+                const int x = use(a);
+                uint64_t e = b;
+                if (op == J_POWC) {
+                    if (!gen.consts || b >= gen.nconsts) return false;
+                    const uint8_t *eb = gen.consts + (size_t)b * GS_ELT;
+                    bool wide_exponent = false;
+                    for (int i = 4; i < GS_ELT; i++) wide_exponent |= eb[i] != 0;
+                    if (wide_exponent) {
+                        n.kind = SsaNode::POWLONG; n.a = x; n.aux = b; n.depth = nodes[x].depth + 1;
+                        cur[d] = add(n);
+                        break;
+                    }
+                    e = (uint64_t)eb[0] | ((uint64_t)eb[1] << 8) | ((uint64_t)eb[2] << 16) | ((uint64_t)eb[3] << 24);
+                }
+                if (e == 0) { n.kind = SsaNode::CONSTV; n.a = -1; cur[d] = add(n); break; }      // x^0 = 1 (a = -1: the literal one)
+                int top = 63;
+                while (!((e >> top) & 1)) top--;
+                int acc = x;                                                                   // left to right: x^3 two products, x^5 three
+                for (int i = top - 1; i >= 0; i--) {
+                    acc = binary(SsaNode::MUL, acc, acc);
+                    if ((e >> i) & 1) acc = binary(SsaNode::MUL, acc, x);
+                }
+                cur[d] = acc;
+                break;
+            }
+            case J_OUT:
+                if (a >= vm_regs) return false;
+                n.kind = SsaNode::OUT; n.a = use(a); n.aux = d; n.depth = nodes[n.a].depth;
+                add(n);
+                break;
+            default: return false;      // J_LOADN does not occur in trace programs
+        }
     }
-    return lanes == 3 ? 4 : lanes;
+    return true;
+}
+
+// Long exponentiations that do not depend on each other should share a round even when their operands are ready at different depths
+// (the two slopes of a point addition: one inversion waits for the doubled point, the other does not): the earlier one is delayed to
+// the depth of the later one — a delay of a few products against a whole exponentiation saved — and the depths are recomputed.
+static void ssa_align_pows(std::vector<SsaNode> &nodes) {
+    const int n = (int)nodes.size();
+    std::vector<int> pows;
+    for (int id = 0; id < n; id++)
+        if (nodes[id].kind == SsaNode::POWLONG) pows.push_back(id);
+    if (pows.size() < 2) return;
+    auto operands = [&](int id, int out[2]) {
+        const SsaNode &x = nodes[id];
+        out[0] = out[1] = -1;
+        switch (x.kind) {
+            case SsaNode::ADD: case SsaNode::SUB: case SsaNode::MUL: out[0] = x.a; out[1] = x.b; break;
+            case SsaNode::POWLONG: case SsaNode::OUT: out[0] = x.a; break;
+            default: break;
+        }
+    };
+    // reach[k][id]: node id depends on pows[k]
+    std::vector<std::vector<bool>> reach(pows.size(), std::vector<bool>(n, false));
+    for (size_t k = 0; k < pows.size(); k++)
+        for (int id = pows[k] + 1; id < n; id++) {
+            int op[2];
+            operands(id, op);
+            for (int o : op)
+                if (o >= 0 && (o == pows[k] || reach[k][o])) reach[k][id] = true;
+        }
+    std::vector<int> forced(n, 0);
+    std::vector<bool> grouped(pows.size(), false);
+    for (size_t k = 0; k < pows.size(); k++) {
+        if (grouped[k]) continue;
+        std::vector<size_t> group = {k};
+        grouped[k] = true;
+        for (size_t j = k + 1; j < pows.size() && group.size() < 8; j++) {
+            if (grouped[j] || nodes[pows[j]].aux != nodes[pows[k]].aux) continue;
+            bool independent = true;
+            for (size_t g : group) independent &= !reach[g][pows[j]] && !reach[j][pows[g]];
+            if (independent) { group.push_back(j); grouped[j] = true; }
+        }
+        int depth = 0;
+        for (size_t g : group) depth = std::max(depth, nodes[pows[g]].depth);
+        for (size_t g : group) forced[pows[g]] = depth;
+        // the delay moves everything behind the group: recompute before the next group is formed
+        for (int id = 0; id < n; id++) {
+            int op[2], d = 0;
+            operands(id, op);
+            for (int o : op)
+                if (o >= 0) d = std::max(d, nodes[o].depth);
+            if (nodes[id].kind == SsaNode::MUL || nodes[id].kind == SsaNode::POWLONG) d++;
+            nodes[id].depth = std::max(d, forced[id]);
+        }
+    }
+}
+
+static uint32_t ssa_lanes(const std::vector<SsaNode> &nodes) {
+    std::map<int, uint32_t> per_depth;
+    uint32_t widest = 1;
+    for (const SsaNode &n : nodes) {
+#if defined(GS_WIDE_BITS)
+        // a multi-limb product issues for longer than it takes to complete: nothing to gain from spreading single products
+        // (measured: point multiplication 154 -> 222 ms); the long exponentiations still go one per lane
+        if (n.kind == SsaNode::MUL) continue;
+#endif
+        if (n.kind == SsaNode::MUL || n.kind == SsaNode::POWLONG) widest = std::max(widest, ++per_depth[n.depth * 2 + (n.kind == SsaNode::POWLONG)]);
+    }
+    return widest >= 8 ? 8 : (widest >= 3 ? 4 : widest);
+}
+
+// `hoisted` receives declarations that belong before the step loop: the constants the body uses, and per round of products by
+// constants the ONE constant each lane needs (a lane-dependent, step-independent load instead of L loads and selects per step).
+static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &const_declared, const std::vector<SsaNode> &nodes, const JitGen &gen,
+                     const uint64_t *soff, const uint64_t *slen, const char *index, const char *sink, const char *tag) {
+    char buf[256];
+    const uint32_t L = gen.lanes;
+    int max_depth = 0;
+    for (const SsaNode &n : nodes) max_depth = std::max(max_depth, n.depth);
+    auto name = [&](int id) {
+        const SsaNode &n = nodes[id];
+        char t[48];
+        if (n.kind == SsaNode::ZERO) return std::string("fe_zero()");
+        if (n.kind == SsaNode::ROW) { snprintf(t, sizeof t, "r%d", n.a); return std::string(t); }
+        if (n.kind == SsaNode::CONSTV) {
+            if (n.a < 0) return std::string("fe_one()");
+            if (!const_declared[n.a]) {
+                snprintf(t, sizeof t, "    const fe c%d = consts[%d];\n", n.a, n.a);
+                hoisted += t;
+                const_declared[n.a] = true;
+            }
+            snprintf(t, sizeof t, "c%d", n.a);
+            return std::string(t);
+        }
+        snprintf(t, sizeof t, "%s%d", tag, id);
+        return std::string(t);
+    };
+    auto is_const = [&](int id) { return nodes[id].kind == SsaNode::CONSTV && nodes[id].a >= 0; };
+    int round_no = 0;
+    for (int depth = 0; depth <= max_depth; depth++) {
+        // the products of this depth, L per round
+        std::vector<int> muls, pows;
+        for (int id = 0; id < (int)nodes.size(); id++) {
+            if (nodes[id].depth != depth) continue;
+            if (nodes[id].kind == SsaNode::MUL) muls.push_back(id);
+            if (nodes[id].kind == SsaNode::POWLONG) pows.push_back(id);
+        }
+        if (L > 1) {   // products by constants first, so that rounds are all-constant where they can be
+            std::stable_partition(muls.begin(), muls.end(), [&](int id) { return is_const(nodes[id].a) || is_const(nodes[id].b); });
+        }
+        for (size_t base = 0; base < muls.size(); base += L) {
+            const size_t m = std::min<size_t>(L, muls.size() - base);
+            if (L == 1) {
+                const SsaNode &n = nodes[muls[base]];
+                s += "        const fe " + name(muls[base]) + " = gs_mul(" + name(n.a) + ", " + name(n.b) + ");\n";
+                continue;
+            }
+            // operands: (variable, constant) when every product of the round has a constant side
+            std::vector<int> xa(m), xb(m);
+            bool by_consts = true, squares = true;
+            for (size_t i = 0; i < m; i++) {
+                const SsaNode &n = nodes[muls[base + i]];
+                xa[i] = n.a; xb[i] = n.b;
+                if (is_const(xa[i]) && !is_const(xb[i])) std::swap(xa[i], xb[i]);
+                by_consts &= is_const(xb[i]);
+                squares &= n.a == n.b;
+            }
+            for (size_t i = 0; i < m; i++) s += "        fe " + name(muls[base + i]) + ";\n";
+            s += "        {\n            fe xa = " + name(xa[0]) + ";\n";
+            for (size_t i = 1; i < m; i++) { snprintf(buf, sizeof buf, "            if (sub == %zuu) xa = ", i); s += buf + name(xa[i]) + ";\n"; }
+            if (squares) s += "            const fe xr = gs_sqr(xa);\n";
+            else if (by_consts) {
+                snprintf(buf, sizeof buf, "    const fe %sk%d = consts[", tag, round_no); hoisted += buf;
+                for (size_t i = m - 1; i >= 1; i--) { snprintf(buf, sizeof buf, "sub == %zuu ? %du : ", i, nodes[xb[i]].a); hoisted += buf; }
+                snprintf(buf, sizeof buf, "%du];\n", nodes[xb[0]].a); hoisted += buf;
+                snprintf(buf, sizeof buf, "            const fe xr = gs_mul(xa, %sk%d);\n", tag, round_no); s += buf;
+            } else {
+                s += "            fe xb = " + name(xb[0]) + ";\n";
+                for (size_t i = 1; i < m; i++) { snprintf(buf, sizeof buf, "            if (sub == %zuu) xb = ", i); s += buf + name(xb[i]) + ";\n"; }
+                s += "            const fe xr = gs_mul(xa, xb);\n";
+            }
+            for (size_t i = 0; i < m; i++) { snprintf(buf, sizeof buf, " = gs_from_lane<%u>(xr, %zu);\n", L, i); s += "            " + name(muls[base + i]) + buf; }
+            s += "        }\n";
+            round_no++;
+        }
+        // long exponentiations of this depth: one member per lane, grouped by exponent
+        std::vector<bool> done(pows.size(), false);
+        for (size_t first = 0; first < pows.size(); first++) {
+            if (done[first]) continue;
+            std::vector<int> members;
+            for (size_t k = first; k < pows.size() && members.size() < L; k++)
+                if (!done[k] && nodes[pows[k]].aux == nodes[pows[first]].aux) { members.push_back(pows[k]); done[k] = true; }
+            std::vector<uint32_t> e(GS_ELT / 4, 0u);
+            memcpy(e.data(), gen.consts + (size_t)nodes[pows[first]].aux * GS_ELT, GS_ELT);
+            for (int id : members) s += "        fe " + name(id) + ";\n";
+            s += "        {\n            fe x = " + name(nodes[members[0]].a) + ";\n";
+            for (size_t i = 1; i < members.size(); i++) { snprintf(buf, sizeof buf, "            if (sub == %zuu) x = ", i); s += buf + name(nodes[members[i]].a) + ";\n"; }
+            emit_pow(s, "x", e);
+            for (size_t i = 0; i < members.size(); i++) {
+                if (L == 1) s += "            " + name(members[i]) + " = x;\n";
+                else { snprintf(buf, sizeof buf, " = gs_from_lane<%u>(x, %zu);\n", L, i); s += "            " + name(members[i]) + buf; }
+            }
+            s += "        }\n";
+        }
+        // everything cheap of this depth, in program order
+        for (int id = 0; id < (int)nodes.size(); id++) {
+            const SsaNode &n = nodes[id];
+            if (n.depth != depth) continue;
+            switch (n.kind) {
+                case SsaNode::STATICV:
+                    if (slen[n.a] & (slen[n.a] - 1)) snprintf(buf, sizeof buf, " = statics[%lluull + %s %% %lluull];\n", (unsigned long long)soff[n.a], index, (unsigned long long)slen[n.a]);
+                    else snprintf(buf, sizeof buf, " = statics[%lluull + (%s & %lluull)];\n", (unsigned long long)soff[n.a], index, (unsigned long long)(slen[n.a] - 1));
+                    s += "        const fe " + name(id) + buf;
+                    break;
+                case SsaNode::ADD: s += "        const fe " + name(id) + " = fe_add(" + name(n.a) + ", " + name(n.b) + ");\n"; break;
+                case SsaNode::SUB: s += "        const fe " + name(id) + " = fe_sub(" + name(n.a) + ", " + name(n.b) + ");\n"; break;
+                case SsaNode::OUT: snprintf(buf, sizeof buf, "        %s%u = ", sink, n.aux); s += buf + name(n.a) + ";\n"; break;
+                default: break;
+            }
+        }
+    }
 }
 
 // hiprtc: source -> gfx950 code object (no device needed); false + log on failure
@@ -274,10 +513,12 @@ static bool jit_trace_source(std::string &s, JitGen &gen, const uint32_t *code, 
                              uint32_t vm_regs, uint32_t registers, const uint64_t *soff, const uint64_t *slen) {
     s = jit_preamble();
     char buf[256];
-    // One thread per segment pays the full latency of every dependent product (one wave per SIMD at best: nothing to hide it with),
-    // and an S-box layer of long exponentiations is `registers` such chains one after the other.  With L lanes per segment every
-    // lane runs the whole program (redundantly: the lanes are free) but only ITS member of such a layer, and the lanes swap results.
-    gen.lanes = trace_lanes(gen, code, ninstr);
+    std::vector<SsaNode> main_nodes, init_nodes;
+    if (!ssa_build(main_nodes, gen, code, ninstr, vm_regs, true)) return false;
+    if (init_ninstr && !ssa_build(init_nodes, gen, icode, init_ninstr, vm_regs, false)) return false;
+    ssa_align_pows(main_nodes);
+    ssa_align_pows(init_nodes);
+    gen.lanes = std::max(ssa_lanes(main_nodes), ssa_lanes(init_nodes));
     snprintf(buf, sizeof buf, "#define GS_LANES %uu\n", gen.lanes); s += buf;
     s += "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void gs_jit_trace(const fe *__restrict__ consts, const fe *__restrict__ statics, const fe *__restrict__ first_rows,\n"
          "                                         unsigned long long segments, unsigned long long seglen, fe *__restrict__ out) {\n"
@@ -287,11 +528,15 @@ static bool jit_trace_source(std::string &s, JitGen &gen, const uint32_t *code, 
          "    if (g >= segments) return;\n"
          "    const unsigned long long steps = segments * seglen;\n";
     for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "    fe r%u = first_rows[g * %uull + %uull], n%u;\n", r, registers, r, r); s += buf; }
-    for (uint32_t t = 0; t < vm_regs; t++) { snprintf(buf, sizeof buf, "    fe t%u;\n", t); s += buf; }
+    std::vector<bool> const_declared(gen.nconsts, false);
+    std::string hoisted, init_body, main_body;
+    if (init_ninstr) ssa_emit(init_body, hoisted, const_declared, init_nodes, gen, soff, slen, "0ull", "n", "u");
+    ssa_emit(main_body, hoisted, const_declared, main_nodes, gen, soff, slen, "i", "n", "v");
+    s += hoisted;
     if (init_ninstr) {
         s += "    {\n";
         for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "        n%u = r%u;\n", r, r); s += buf; }
-        if (!jit_body(s, gen, icode, init_ninstr, soff, slen, false, "r", nullptr, "0ull", "n")) return false;
+        s += init_body;
         for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "        r%u = n%u;\n", r, r); s += buf; }
         s += "    }\n";
     }
@@ -300,7 +545,7 @@ static bool jit_trace_source(std::string &s, JitGen &gen, const uint32_t *code, 
     for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "        if (sub == %uu) out[%uull * steps + i] = r%u;\n", r % gen.lanes, r, r); s += buf; }
     s += "        if (k + 1 == seglen) break;\n";
     for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "        n%u = r%u;\n", r, r); s += buf; }
-    if (!jit_body(s, gen, code, ninstr, soff, slen, true, "r", nullptr, "i", "n")) return false;
+    s += main_body;
     for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "        r%u = n%u;\n", r, r); s += buf; }
     s += "    }\n}\n";
     return true;
