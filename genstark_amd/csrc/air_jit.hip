@@ -211,9 +211,9 @@ static bool jit_body(std::string &s, const JitGen &gen, const uint32_t *code, ui
 // Cheap operations run redundantly on all lanes.  Long exponentiations of one depth and exponent are rounds of their own (one
 // member per lane).  L = 1, 2, 4 or 8 by the widest depth.
 struct SsaNode {
-    enum Kind { ZERO, CONSTV, ROW, STATICV, ADD, SUB, MUL, POWLONG, OUT } kind = ZERO;
+    enum Kind { ZERO, CONSTV, ROW, STATICV, ADD, SUB, MUL, POWLONG, POWSHORT, OUT } kind = ZERO;
     int a = -1, b = -1;        // operand nodes (MUL/ADD/SUB/POWLONG/OUT: a; b for binary) or the index of a constant/register/static
-    uint32_t aux = 0;          // POWLONG: constant index of the exponent; OUT: destination register
+    uint32_t aux = 0;          // POWLONG: constant index of the exponent; POWSHORT: the exponent; OUT: destination register
     int depth = 0;
 };
 
@@ -264,14 +264,12 @@ static bool ssa_build(std::vector<SsaNode> &nodes, const JitGen &gen, const uint
                     e = (uint64_t)eb[0] | ((uint64_t)eb[1] << 8) | ((uint64_t)eb[2] << 16) | ((uint64_t)eb[3] << 24);
                 }
                 if (e == 0) { n.kind = SsaNode::CONSTV; n.a = -1; cur[d] = add(n); break; }      // x^0 = 1 (a = -1: the literal one)
-                int top = 63;
-                while (!((e >> top) & 1)) top--;
-                int acc = x;                                                                   // left to right: x^3 two products, x^5 three
-                for (int i = top - 1; i >= 0; i--) {
-                    acc = binary(SsaNode::MUL, acc, acc);
-                    if ((e >> i) & 1) acc = binary(SsaNode::MUL, acc, x);
-                }
-                cur[d] = acc;
+                if (e == 1) { cur[d] = x; break; }
+                if (e >> 32) return false;
+                // an S-box: a short chain of products that stays on ONE lane (x^5: square, square, multiply) — a round of its own
+                // kind, so that the lanes exchange the powers only, not every intermediate square
+                n.kind = SsaNode::POWSHORT; n.a = x; n.aux = (uint32_t)e; n.depth = nodes[x].depth + 1;
+                cur[d] = add(n);
                 break;
             }
             case J_OUT:
@@ -299,7 +297,7 @@ static void ssa_align_pows(std::vector<SsaNode> &nodes) {
         out[0] = out[1] = -1;
         switch (x.kind) {
             case SsaNode::ADD: case SsaNode::SUB: case SsaNode::MUL: out[0] = x.a; out[1] = x.b; break;
-            case SsaNode::POWLONG: case SsaNode::OUT: out[0] = x.a; break;
+            case SsaNode::POWLONG: case SsaNode::POWSHORT: case SsaNode::OUT: out[0] = x.a; break;
             default: break;
         }
     };
@@ -333,7 +331,7 @@ static void ssa_align_pows(std::vector<SsaNode> &nodes) {
             operands(id, op);
             for (int o : op)
                 if (o >= 0) d = std::max(d, nodes[o].depth);
-            if (nodes[id].kind == SsaNode::MUL || nodes[id].kind == SsaNode::POWLONG) d++;
+            if (nodes[id].kind == SsaNode::MUL || nodes[id].kind == SsaNode::POWLONG || nodes[id].kind == SsaNode::POWSHORT) d++;
             nodes[id].depth = std::max(d, forced[id]);
         }
     }
@@ -348,7 +346,11 @@ static uint32_t ssa_lanes(const std::vector<SsaNode> &nodes) {
         // (measured: point multiplication 154 -> 222 ms); the long exponentiations still go one per lane
         if (n.kind == SsaNode::MUL) continue;
 #endif
-        if (n.kind == SsaNode::MUL || n.kind == SsaNode::POWLONG) widest = std::max(widest, ++per_depth[n.depth * 2 + (n.kind == SsaNode::POWLONG)]);
+#if defined(GS_WIDE_BITS)
+        if (n.kind == SsaNode::POWSHORT) continue;
+#endif
+        if (n.kind == SsaNode::MUL || n.kind == SsaNode::POWLONG || n.kind == SsaNode::POWSHORT)
+            widest = std::max(widest, ++per_depth[n.depth * 3 + (n.kind == SsaNode::POWLONG ? 1 : (n.kind == SsaNode::POWSHORT ? 2 : 0))]);
     }
     return widest >= 8 ? 8 : (widest >= 3 ? 4 : widest);
 }
@@ -387,7 +389,7 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
         for (int id = 0; id < (int)nodes.size(); id++) {
             if (nodes[id].depth != depth) continue;
             if (nodes[id].kind == SsaNode::MUL) muls.push_back(id);
-            if (nodes[id].kind == SsaNode::POWLONG) pows.push_back(id);
+            if (nodes[id].kind == SsaNode::POWLONG || nodes[id].kind == SsaNode::POWSHORT) pows.push_back(id);
         }
         if (L > 1) {   // products by constants first, so that rounds are all-constant where they can be
             std::stable_partition(muls.begin(), muls.end(), [&](int id) { return is_const(nodes[id].a) || is_const(nodes[id].b); });
@@ -423,8 +425,9 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
                 for (size_t i = 1; i < m; i++) { snprintf(buf, sizeof buf, "            if (sub == %zuu) xb = ", i); s += buf + name(xb[i]) + ";\n"; }
                 s += "            const fe xr = gs_mul(xa, xb);\n";
             }
-            for (size_t i = 0; i < m; i++) { snprintf(buf, sizeof buf, " = gs_from_lane<%u>(xr, %zu);\n", L, i); s += "            " + name(muls[base + i]) + buf; }
-            s += "        }\n";
+            s += "            gs_swap[threadIdx.x] = xr;\n            __syncthreads();\n";
+            for (size_t i = 0; i < m; i++) { snprintf(buf, sizeof buf, " = gs_swap[gs_group + %zu];\n", i); s += "            " + name(muls[base + i]) + buf; }
+            s += "            __syncthreads();\n        }\n";
             round_no++;
         }
         // long exponentiations of this depth: one member per lane, grouped by exponent
@@ -433,17 +436,20 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
             if (done[first]) continue;
             std::vector<int> members;
             for (size_t k = first; k < pows.size() && members.size() < L; k++)
-                if (!done[k] && nodes[pows[k]].aux == nodes[pows[first]].aux) { members.push_back(pows[k]); done[k] = true; }
+                if (!done[k] && nodes[pows[k]].kind == nodes[pows[first]].kind && nodes[pows[k]].aux == nodes[pows[first]].aux) { members.push_back(pows[k]); done[k] = true; }
             std::vector<uint32_t> e(GS_ELT / 4, 0u);
-            memcpy(e.data(), gen.consts + (size_t)nodes[pows[first]].aux * GS_ELT, GS_ELT);
+            if (nodes[pows[first]].kind == SsaNode::POWSHORT) e[0] = nodes[pows[first]].aux;
+            else memcpy(e.data(), gen.consts + (size_t)nodes[pows[first]].aux * GS_ELT, GS_ELT);
             for (int id : members) s += "        fe " + name(id) + ";\n";
             s += "        {\n            fe x = " + name(nodes[members[0]].a) + ";\n";
             for (size_t i = 1; i < members.size(); i++) { snprintf(buf, sizeof buf, "            if (sub == %zuu) x = ", i); s += buf + name(nodes[members[i]].a) + ";\n"; }
             emit_pow(s, "x", e);
+            if (L > 1) s += "            gs_swap[threadIdx.x] = x;\n            __syncthreads();\n";
             for (size_t i = 0; i < members.size(); i++) {
                 if (L == 1) s += "            " + name(members[i]) + " = x;\n";
-                else { snprintf(buf, sizeof buf, " = gs_from_lane<%u>(x, %zu);\n", L, i); s += "            " + name(members[i]) + buf; }
+                else { snprintf(buf, sizeof buf, " = gs_swap[gs_group + %zu];\n", i); s += "            " + name(members[i]) + buf; }
             }
+            if (L > 1) s += "            __syncthreads();\n";
             s += "        }\n";
         }
         // everything cheap of this depth, in program order
@@ -451,11 +457,21 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
             const SsaNode &n = nodes[id];
             if (n.depth != depth) continue;
             switch (n.kind) {
-                case SsaNode::STATICV:
-                    if (slen[n.a] & (slen[n.a] - 1)) snprintf(buf, sizeof buf, " = statics[%lluull + %s %% %lluull];\n", (unsigned long long)soff[n.a], index, (unsigned long long)slen[n.a]);
-                    else snprintf(buf, sizeof buf, " = statics[%lluull + (%s & %lluull)];\n", (unsigned long long)soff[n.a], index, (unsigned long long)(slen[n.a] - 1));
+                case SsaNode::STATICV: {
+                    // the value of the NEXT step is requested now and used one iteration later: nothing hides a load's latency here
+                    char at[160], next_at[160];
+                    if (slen[n.a] & (slen[n.a] - 1)) {
+                        snprintf(at, sizeof at, "statics[%lluull + (g * seglen) %% %lluull]", (unsigned long long)soff[n.a], (unsigned long long)slen[n.a]);
+                        snprintf(next_at, sizeof next_at, "statics[%lluull + (%s + 1ull) %% %lluull]", (unsigned long long)soff[n.a], index, (unsigned long long)slen[n.a]);
+                    } else {
+                        snprintf(at, sizeof at, "statics[%lluull + ((g * seglen) & %lluull)]", (unsigned long long)soff[n.a], (unsigned long long)(slen[n.a] - 1));
+                        snprintf(next_at, sizeof next_at, "statics[%lluull + ((%s + 1ull) & %lluull)]", (unsigned long long)soff[n.a], index, (unsigned long long)(slen[n.a] - 1));
+                    }
+                    snprintf(buf, sizeof buf, "    fe %sq%d = %s;\n", tag, id, at); hoisted += buf;
+                    snprintf(buf, sizeof buf, " = %sq%d;\n        %sq%d = %s;\n", tag, id, tag, id, next_at);
                     s += "        const fe " + name(id) + buf;
                     break;
+                }
                 case SsaNode::ADD: s += "        const fe " + name(id) + " = fe_add(" + name(n.a) + ", " + name(n.b) + ");\n"; break;
                 case SsaNode::SUB: s += "        const fe " + name(id) + " = fe_sub(" + name(n.a) + ", " + name(n.b) + ");\n"; break;
                 case SsaNode::OUT: snprintf(buf, sizeof buf, "        %s%u = ", sink, n.aux); s += buf + name(n.a) + ";\n"; break;
@@ -474,6 +490,12 @@ static bool jit_compile(const std::string &source, const char *entry, std::vecto
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
     const char *verbose = getenv("GSTARK_AIR_JIT_VERBOSE");
     if (verbose) fprintf(stderr, "[gstark] compiling an AIR program (%zu bytes of source, entry %s)\n", source.size(), entry);
+    if (const char *dump = getenv("GSTARK_AIR_JIT_DUMP")) {          // keep the generated source (<dir>/<entry>_<n>.hip) for inspection
+        static int dumped = 0;
+        char path[512];
+        snprintf(path, sizeof path, "%s/%s_%d.hip", dump, entry, dumped++);
+        if (FILE *f = fopen(path, "w")) { fputs(source.c_str(), f); fclose(f); }
+    }
     hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t ls = 0;
@@ -525,6 +547,10 @@ static bool jit_trace_source(std::string &s, JitGen &gen, const uint32_t *code, 
          "    const unsigned long long tid = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;\n"
          "    const unsigned long long g = tid / GS_LANES;\n"
          "    const unsigned int sub = (unsigned int)(tid % GS_LANES);\n"
+         "    // results of a round change lanes through LDS: one 16-byte write per lane, one read per result (a block is one wave:\n"
+         "    // the barriers only order the accesses)\n"
+         "    __shared__ fe gs_swap[64];\n"
+         "    const unsigned int gs_group = threadIdx.x & ~(GS_LANES - 1u);\n"
          "    if (g >= segments) return;\n"
          "    const unsigned long long steps = segments * seglen;\n";
     for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "    fe r%u = first_rows[g * %uull + %uull], n%u;\n", r, registers, r, r); s += buf; }
