@@ -60,6 +60,15 @@ static std::string jit_preamble() {
 #else
     s += "#define gs_sqr fe_sqr\n";
 #endif
+    // c ? a : b limb by limb: written as a conditional copy of the struct, the compiler parks the candidates in scratch memory and
+    // loads through a selected pointer (seen in the ISA: 64 scratch accesses per Poseidon step)
+    s += "__device__ __forceinline__ fe gs_pick(bool c, fe a, const fe b) {\n"
+         "    unsigned int *pa = reinterpret_cast<unsigned int *>(&a);\n"
+         "    const unsigned int *pb = reinterpret_cast<const unsigned int *>(&b);\n"
+         "#pragma unroll\n"
+         "    for (int i = 0; i < (int)(sizeof(fe) / 4); i++) pa[i] = c ? pa[i] : pb[i];\n"
+         "    return a;\n"
+         "}\n";
     // an element read from lane `src` of the group of L consecutive lanes the caller belongs to
     s += "template <int L> __device__ __forceinline__ fe gs_from_lane(const fe &v, int src) {\n"
          "    fe r;\n"
@@ -352,7 +361,7 @@ static uint32_t ssa_lanes(const std::vector<SsaNode> &nodes) {
         if (n.kind == SsaNode::MUL || n.kind == SsaNode::POWLONG || n.kind == SsaNode::POWSHORT)
             widest = std::max(widest, ++per_depth[n.depth * 3 + (n.kind == SsaNode::POWLONG ? 1 : (n.kind == SsaNode::POWSHORT ? 2 : 0))]);
     }
-    return widest >= 8 ? 8 : (widest >= 3 ? 4 : widest);
+    return widest >= 12 ? 16 : (widest >= 5 ? 8 : (widest >= 3 ? 4 : widest));
 }
 
 // `hoisted` receives declarations that belong before the step loop: the constants the body uses, and per round of products by
@@ -413,7 +422,7 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
             }
             for (size_t i = 0; i < m; i++) s += "        fe " + name(muls[base + i]) + ";\n";
             s += "        {\n            fe xa = " + name(xa[0]) + ";\n";
-            for (size_t i = 1; i < m; i++) { snprintf(buf, sizeof buf, "            if (sub == %zuu) xa = ", i); s += buf + name(xa[i]) + ";\n"; }
+            for (size_t i = 1; i < m; i++) { snprintf(buf, sizeof buf, "            xa = gs_pick(sub == %zuu, ", i); s += buf + name(xa[i]) + ", xa);\n"; }
             if (squares) s += "            const fe xr = gs_sqr(xa);\n";
             else if (by_consts) {
                 snprintf(buf, sizeof buf, "    const fe %sk%d = consts[", tag, round_no); hoisted += buf;
@@ -422,7 +431,7 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
                 snprintf(buf, sizeof buf, "            const fe xr = gs_mul(xa, %sk%d);\n", tag, round_no); s += buf;
             } else {
                 s += "            fe xb = " + name(xb[0]) + ";\n";
-                for (size_t i = 1; i < m; i++) { snprintf(buf, sizeof buf, "            if (sub == %zuu) xb = ", i); s += buf + name(xb[i]) + ";\n"; }
+                for (size_t i = 1; i < m; i++) { snprintf(buf, sizeof buf, "            xb = gs_pick(sub == %zuu, ", i); s += buf + name(xb[i]) + ", xb);\n"; }
                 s += "            const fe xr = gs_mul(xa, xb);\n";
             }
             s += "            gs_swap[threadIdx.x] = xr;\n            __syncthreads();\n";
@@ -442,7 +451,7 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
             else memcpy(e.data(), gen.consts + (size_t)nodes[pows[first]].aux * GS_ELT, GS_ELT);
             for (int id : members) s += "        fe " + name(id) + ";\n";
             s += "        {\n            fe x = " + name(nodes[members[0]].a) + ";\n";
-            for (size_t i = 1; i < members.size(); i++) { snprintf(buf, sizeof buf, "            if (sub == %zuu) x = ", i); s += buf + name(nodes[members[i]].a) + ";\n"; }
+            for (size_t i = 1; i < members.size(); i++) { snprintf(buf, sizeof buf, "            x = gs_pick(sub == %zuu, ", i); s += buf + name(nodes[members[i]].a) + ", x);\n"; }
             emit_pow(s, "x", e);
             if (L > 1) s += "            gs_swap[threadIdx.x] = x;\n            __syncthreads();\n";
             for (size_t i = 0; i < members.size(); i++) {
