@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 
 #include "common.h"
@@ -68,15 +69,6 @@ static std::string jit_preamble() {
          "#pragma unroll\n"
          "    for (int i = 0; i < (int)(sizeof(fe) / 4); i++) pa[i] = c ? pa[i] : pb[i];\n"
          "    return a;\n"
-         "}\n";
-    // an element read from lane `src` of the group of L consecutive lanes the caller belongs to
-    s += "template <int L> __device__ __forceinline__ fe gs_from_lane(const fe &v, int src) {\n"
-         "    fe r;\n"
-         "    const unsigned int *pv = reinterpret_cast<const unsigned int *>(&v);\n"
-         "    unsigned int *pr = reinterpret_cast<unsigned int *>(&r);\n"
-         "#pragma unroll\n"
-         "    for (int i = 0; i < (int)(sizeof(fe) / 4); i++) pr[i] = __shfl(pv[i], src, L);\n"
-         "    return r;\n"
          "}\n";
     return s;
 }
@@ -500,7 +492,7 @@ static bool jit_compile(const std::string &source, const char *entry, std::vecto
     const char *verbose = getenv("GSTARK_AIR_JIT_VERBOSE");
     if (verbose) fprintf(stderr, "[gstark] compiling an AIR program (%zu bytes of source, entry %s)\n", source.size(), entry);
     if (const char *dump = getenv("GSTARK_AIR_JIT_DUMP")) {          // keep the generated source (<dir>/<entry>_<n>.hip) for inspection
-        static int dumped = 0;
+        static std::atomic<int> dumped{0};
         char path[512];
         snprintf(path, sizeof path, "%s/%s_%d.hip", dump, entry, dumped++);
         if (FILE *f = fopen(path, "w")) { fputs(source.c_str(), f); fclose(f); }
