@@ -2,12 +2,14 @@
 //
 // The reference's air-assembly GENERATES code for an AIR's transition function and constraint evaluator when a module is
 // instantiated ("generated JS over BigInt").  The register machine of air_vm.hip is the portable form of the same
-// programs; here they are turned into straight-line HIP source — VM registers become variables, static-register offsets and
-// periods become literals — compiled once per program with hiprtc for gfx950 and cached for the process.  The compiler then keeps
-// the state in VGPRs and schedules independent products side by side, which an interpreter stepping through LDS cannot: the
-// interpreter spends ~2 400 cycles per VM instruction with one wave per SIMD, a compiled S-box + MDS round is bound by its
-// dependency chains only.  Same arithmetic (the field header the library itself is built from is embedded in the source), same
-// values; any failure to compile falls back to the interpreter.
+// programs; here they are turned into HIP source — static-register offsets and periods become literals, exponents become fixed
+// addition chains — compiled once per program with hiprtc for gfx950 and cached for the process.
+//   constraint programs (one thread per domain point, throughput-bound): VM registers become variables, straight-line code;
+//   trace programs (a few thousand independent segments at most: one wave per SIMD, every dependent product paid at full
+//   latency): SSA form, products scheduled by depth and spread over the 2-16 lanes that share a segment, S-box layers one member
+//   per lane, results exchanged through LDS (see "trace programs" below).
+// Same arithmetic (the field header the library itself is built from is embedded in the source), same values; any failure to
+// compile falls back to the interpreter.  gs_air_jit_check generates + compiles without a device (CPU test tier).
 #include <hip/hiprtc.h>
 
 #include <stdlib.h>
