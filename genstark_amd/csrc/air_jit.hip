@@ -345,12 +345,9 @@ static uint32_t ssa_lanes(const std::vector<SsaNode> &nodes) {
     uint32_t widest = 1;
     for (const SsaNode &n : nodes) {
 #if defined(GS_WIDE_BITS)
-        // a multi-limb product issues for longer than it takes to complete: nothing to gain from spreading single products
-        // (measured: point multiplication 154 -> 222 ms); the long exponentiations still go one per lane
-        if (n.kind == SsaNode::MUL) continue;
-#endif
-#if defined(GS_WIDE_BITS)
-        if (n.kind == SsaNode::POWSHORT) continue;
+        // multi-limb flavours: the group is as wide as the layer of long exponentiations (a step is their chain of ~280 products;
+        // more lanes for the sake of the few single products changes nothing: point multiplication 79.5 vs 79.7 ms)
+        if (n.kind == SsaNode::MUL || n.kind == SsaNode::POWSHORT) continue;
 #endif
         if (n.kind == SsaNode::MUL || n.kind == SsaNode::POWLONG || n.kind == SsaNode::POWSHORT)
             widest = std::max(widest, ++per_depth[n.depth * 3 + (n.kind == SsaNode::POWLONG ? 1 : (n.kind == SsaNode::POWSHORT ? 2 : 0))]);
@@ -386,6 +383,7 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
     };
     auto is_const = [&](int id) { return nodes[id].kind == SsaNode::CONSTV && nodes[id].a >= 0; };
     int round_no = 0;
+    const bool spread = L > 1;
     for (int depth = 0; depth <= max_depth; depth++) {
         // the products of this depth, L per round
         std::vector<int> muls, pows;
@@ -394,12 +392,12 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
             if (nodes[id].kind == SsaNode::MUL) muls.push_back(id);
             if (nodes[id].kind == SsaNode::POWLONG || nodes[id].kind == SsaNode::POWSHORT) pows.push_back(id);
         }
-        if (L > 1) {   // products by constants first, so that rounds are all-constant where they can be
+        if (spread) {   // products by constants first, so that rounds are all-constant where they can be
             std::stable_partition(muls.begin(), muls.end(), [&](int id) { return is_const(nodes[id].a) || is_const(nodes[id].b); });
         }
-        for (size_t base = 0; base < muls.size(); base += L) {
+        for (size_t base = 0; base < muls.size(); base += spread ? L : 1) {
             const size_t m = std::min<size_t>(L, muls.size() - base);
-            if (L == 1) {
+            if (!spread) {
                 const SsaNode &n = nodes[muls[base]];
                 s += "        const fe " + name(muls[base]) + " = gs_mul(" + name(n.a) + ", " + name(n.b) + ");\n";
                 continue;

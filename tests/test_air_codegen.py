@@ -47,3 +47,42 @@ def test_unknown_instruction_is_refused_with_a_reason(hip_libs):
     assert lib.gs_air_jit_check(1, bad, 1, None, 0, None, 0, 4, 1, None, 0, log, len(log)) != GS_OK
     assert b'instruction' in log.value
     assert lib.gs_air_jit_check(1, None, 0, None, 0, None, 0, 4, 1, None, 0, log, len(log)) != GS_OK       # no program
+
+
+def generated_trace_source(air, lib, tmp_path, monkeypatch):
+    tmp_path.mkdir(parents=True, exist_ok=True)
+    """The HIP source the generator writes for the AIR's trace program (GSTARK_AIR_JIT_DUMP keeps it)."""
+    monkeypatch.setenv('GSTARK_AIR_JIT_DUMP', str(tmp_path))
+    builds(air, lib)
+    files = sorted(p for p in tmp_path.iterdir() if p.name.startswith('gs_jit_trace_'))
+    assert files, 'no trace kernel was generated'
+    return files[-1].read_text()
+
+
+def test_trace_kernels_spread_products_over_lanes(oracle_backend, hip_libs, tmp_path, monkeypatch):
+    """Shape of the generated trace kernels (csrc/air_jit.hip): products of one depth share a round over the lanes of
+    a segment's group; S-box layers are one member per lane; operands are picked limb-wise (never `if (sub == i) x = v`, which the
+    compiler turns into scratch traffic); the lanes exchange results through LDS."""
+    f = PrimeField(backend=oracle_backend)
+    src = generated_trace_source(poseidon.poseidon6x128_air(2048, 16, f, segmented=True), hip_libs[MODULUS_128], tmp_path / 'p', monkeypatch)
+    assert '#define GS_LANES 16u' in src                        # 36 MDS products of one depth -> 16 lanes, 3 rounds
+    body = src[src.index('for (unsigned long long k = 0'):]
+    assert body.count('gs_mul(') + body.count('gs_sqr(') <= 8   # per lane and step: the x^5 chain + 3 MDS rounds (+ leftovers), not 54
+    assert 'gs_pick(sub ==' in body and 'gs_swap[threadIdx.x]' in body
+    assert [line for line in body.split('\n') if 'if (sub ==' in line and 'out[' not in line] == []
+    assert 'consts[sub ==' in src[:src.index('for (unsigned long long k = 0')]      # per-lane MDS constants, loaded before the step loop
+
+    src = generated_trace_source(rescue4x128_air(1024, 16, f, segmented=True), hip_libs[MODULUS_128], tmp_path / 'r', monkeypatch)
+    assert '#define GS_LANES 16u' in src                        # two 4x4 MDS products per step: 16 products of one depth
+    body = src[src.index('for (unsigned long long k = 0'):]
+    assert body.count('#pragma nounroll') >= 1                  # the inverse S-box: squaring runs of the fixed addition chain
+    assert body.count('gs_swap[threadIdx.x] = x;') >= 2         # S-box layers (x^3 and x^(1/3)): one member per lane
+
+
+def test_point_multiplication_inversions_share_a_round(hip_libs, tmp_path, monkeypatch):
+    f = PrimeField(backend=oracle_for('p224'))
+    tmp_path.mkdir(exist_ok=True)
+    src = generated_trace_source(point_mul_air(f), hip_libs[MODULUS_224], tmp_path, monkeypatch)
+    assert '#define GS_LANES 4u' in src                         # three independent inversions per step: the two slopes and the one of
+    body = src[src.index('for (unsigned long long k = 0'):]     # the next multiplication's first row
+    assert body.count('const fe p3 = gs_mul(p1, p2);') == 1     # ONE Fermat chain in the step: the inversions share a round
