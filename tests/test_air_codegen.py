@@ -86,3 +86,14 @@ def test_point_multiplication_inversions_share_a_round(hip_libs, tmp_path, monke
     assert '#define GS_LANES 4u' in src                         # three independent inversions per step: the two slopes and the one of
     body = src[src.index('for (unsigned long long k = 0'):]     # the next multiplication's first row
     assert body.count('const fe p3 = gs_mul(p1, p2);') == 1     # ONE Fermat chain in the step: the inversions share a round
+
+
+def test_small_field_constraint_program_builds_for_gfx950():
+    """The generator in a small-field flavour (64-bit elements in 16-byte slots): the constraint program of Rescue 2x64."""
+    import os
+    from conftest import ROOT, _build_oracle
+    from genstark_amd._abi import Backend, MODULUS_64
+    from genstark_amd.rescue import rescue2x64_air
+    _build_oracle()
+    f = PrimeField(backend=Backend(lib_path=os.path.join(ROOT, 'oracle', 'liboracle_q64.so'), allow_test_double=True))
+    builds(rescue2x64_air(32, 16, f), load_library(HIP_LIB_PATHS[MODULUS_64]))
