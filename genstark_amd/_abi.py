@@ -12,8 +12,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, 'csrc', 'libgstark_hip.so')
 # one build flavour of the library per field (csrc/build.sh): the 128-bit field of the hot path and the small prime fields of the
-# reference's examples (csrc/gf_small.cuh: same kernels, same 16-byte element layout, plain arithmetic), and the two multi-limb
-# primes of its examples (csrc/gf_wide.cuh: same kernels, 32-byte elements)
+# reference's examples (csrc/gf_small.h: same kernels, same 16-byte element layout, plain arithmetic), and the two multi-limb
+# primes of its examples (csrc/gf_wide.h: same kernels, 32-byte elements)
 MODULUS_128 = 2**128 - 9 * 2**32 + 1
 MODULUS_64 = 2**64 - 21 * 2**30 + 1        # examples/rescue/hash2x64.ts:10
 MODULUS_32 = 2**32 - 3 * 2**25 + 1         # examples/demo/fibonacci.ts:14, README.md:23 (Foo)

@@ -50,7 +50,7 @@ static std::string jit_preamble() {
 #elif defined(GS_WIDE_BITS)
     s += "#define GS_WIDE_BITS " GS_STR(GS_WIDE_BITS) "\n";
 #endif
-    s += "#include \"gs_field.cuh\"\n";
+    s += "#include \"gs_field.h\"\n";
     // the straight-line products: a call in the multi-limb fields (a product is ~400 instructions there; inlining a hundred of
     // them costs minutes of compilation and buys nothing), inlined in the others
 #if defined(GS_WIDE_BITS)
@@ -485,7 +485,7 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
 // hiprtc: source -> gfx950 code object (no device needed); false + log on failure
 static bool jit_compile(const std::string &source, const char *entry, std::vector<char> &code, std::string &log) {
     hiprtcProgram prog;
-    const char *header_names[] = {"gs_field.cuh"};
+    const char *header_names[] = {"gs_field.h"};
     const char *headers[] = {kFieldHeader};
     if (hiprtcCreateProgram(&prog, source.c_str(), "gs_air_jit.hip", 1, headers, header_names) != HIPRTC_SUCCESS) { log = "hiprtcCreateProgram failed"; return false; }
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};

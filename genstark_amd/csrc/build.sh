@@ -3,13 +3,13 @@
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=1000000 -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
 UNITS="ctx ntt pointwise hash air_mimc air_vm air_jit small"
-HDRS="gf128.cuh gf_small.cuh gf_wide.cuh common.h host_field.h host_field_small.h host_field_wide.h host_sha256.h hash_core.cuh ../../include/gstark.h"
+HDRS="gf128_lazy.h host_pow.h gf128.h gf_small.h gf_wide.h common.h host_field.h host_field_small.h host_field_wide.h host_sha256.h hash_core.h ../../include/gstark.h"
 # one library per field: the 128-bit field of the hot path, and two "plumbing" flavours of the same sources for the small prime
-# fields of the reference's examples (gf_small.cuh): 2^64 - 21*2^30 + 1 (rescue/hash2x64.ts) and 2^32 - 3*2^25 + 1 (demo/fibonacci.ts)
+# fields of the reference's examples (gf_small.h): 2^64 - 21*2^30 + 1 (rescue/hash2x64.ts) and 2^32 - 3*2^25 + 1 (demo/fibonacci.ts)
 # the field headers as string literals: the source text hiprtc compiles AIR programs against (air_jit.hip)
-for pair in gf128.cuh:jit_gf128.inc gf_small.cuh:jit_gf_small.inc gf_wide.cuh:jit_gf_wide.inc; do
+for pair in gf128.h:jit_gf128.inc gf_small.h:jit_gf_small.inc gf_wide.h:jit_gf_wide.inc; do
   src=${pair%%:*}; dst=${pair##*:}
   if [ ! -f $dst ] || [ $src -nt $dst ]; then { printf 'R"GSJIT('; cat $src; printf ')GSJIT"\n'; } > $dst; fi
 done
@@ -32,7 +32,7 @@ build_flavour build libgstark_hip.so "" &
 build_flavour build_q64 libgstark_hip_q64.so "-DGS_SMALL_Q=18446744051160973313ull" &
 build_flavour build_q32 libgstark_hip_q32.so "-DGS_SMALL_Q=4194304001ull" &
 build_flavour build_q17 libgstark_hip_q17.so "-DGS_SMALL_Q=96769ull" &        # examples/demo/staticVariables.ts:11
-# ... and the two multi-limb fields (gf_wide.cuh, 32-byte elements): 2^256 - 351*2^32 + 1 (mimc/mimc256.ts), 2^224 - 2^96 + 1 (lib224.aa)
+# ... and the two multi-limb fields (gf_wide.h, 32-byte elements): 2^256 - 351*2^32 + 1 (mimc/mimc256.ts), 2^224 - 2^96 + 1 (lib224.aa)
 build_flavour build_p256 libgstark_hip_p256.so "-DGS_WIDE_BITS=256" &
 build_flavour build_p224 libgstark_hip_p224.so "-DGS_WIDE_BITS=224" &
 wait

@@ -11,11 +11,11 @@
 
 #include "../../include/gstark.h"
 #if defined(GS_SMALL_Q)
-#include "gf_small.cuh"   // build flavour for a prime below 2^64 (same names, same 16-byte elements)
+#include "gf_small.h"   // build flavour for a prime below 2^64 (same names, same 16-byte elements)
 #elif defined(GS_WIDE_BITS)
-#include "gf_wide.cuh"    // build flavour for the 256- / 224-bit primes (same names, 32-byte elements)
+#include "gf_wide.h"    // build flavour for the 256- / 224-bit primes (same names, 32-byte elements)
 #else
-#include "gf128.cuh"
+#include "gf128.h"
 #endif
 
 // bytes of one element in memory and on the ABI (gs_element_size()), and the same in 16-byte words

@@ -1,4 +1,4 @@
-// gf128.cuh — arithmetic in GF(p), p = 2^128 - 9*2^32 + 1, for gfx950 device code (and, for the
+// gf128.h — arithmetic in GF(p), p = 2^128 - 9*2^32 + 1, for gfx950 device code (and, for the
 // CPU unit tests of this header only, plain host C++).
 //
 // Elements are kept CANONICAL (value < p) in memory: the same 16 little-endian bytes are hashed into
@@ -11,7 +11,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define GF_HD __host__ __device__ __forceinline__
 #else
 #define GF_HD inline

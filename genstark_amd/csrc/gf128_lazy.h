@@ -1,0 +1,248 @@
+// gf128_lazy.h — "lazy" arithmetic in GF(p), p = 2^128 - 9*2^32 + 1, for the butterfly networks of ntt.hip (gfx950).
+//
+// Why a second representation beside gf128.h's canonical four 32-bit limbs: on gfx950 a carry-chain instruction
+// (v_add_co / v_addc_co) and every three-operand instruction cost about twice a plain two-operand 32-bit operation, and a
+// canonical add/sub needs 8 carry operations + 4 selects (tools/microbench4.hip, profiles/r02_a_instruction_costs.md).
+// Here an element is five SIGNED 32-bit limbs in radix B = 2^26,
+//        value = l0 + l1*B + l2*B^2 + l3*B^3 + l4*B^4   (any integer congruent to the element mod p),
+// so that
+//   * add / sub are five independent v_add_u32 / v_sub_u32 — no carries, no selects, no reduction: limbs simply grow by
+//     one bit per butterfly level (six bits of headroom = a whole radix-16 network between two multiplications);
+//   * a product is 25 x v_mad_i64_i32 into 64-bit column accumulators (no carry chains either) followed by ONE carry
+//     propagation done with v_alignbit / v_and / v_mad, and the fold 2^130 == 2304*B - 4 (mod p)  [2^128 == 9*2^32 - 1];
+//   * for a multiplier known in advance (the radix-16 twiddles, the same for every lane) the five shifted copies
+//     W_i = w * B^i mod p are tabulated, which removes the four high columns and their fold entirely ("W-form").
+// Canonical 16-byte elements exist only in memory: lz_unpack after the load, lz_pack before the store.
+//
+// Bounds (checked by tests/test_lazy_field.py over extreme and random inputs, and by the interval notes below):
+//   NN ("near-normalised", what lz_unpack, lz_mul_* and lz_norm return):
+//        l0 in (-2^8, B + 2^8), l1 in (-2^17, B + 2^17), l2, l3 in [0, B), l4 in [0, 2^24)
+//   a multiplier input x may be any sum/difference of up to 6 NN values (sum of |limbs| < 2^30.6 is what the column
+//   accumulators need: |column| < 2^57 so that a carry fits 32 bits); the radix-16 DIF network only ever multiplies
+//   differences, which are at most 4 NN values apart.
+#pragma once
+#include <stdint.h>
+
+#include "gf128.h"
+
+#define LZ_B 26
+#define LZ_M 0x3ffffff
+
+// Small constant multipliers of the folds.  Left visible, the compiler strength-reduces "x * -256" and friends into 64-bit
+// shift/subtract sequences (carry chains: exactly what this file avoids); laundered through an SGPR they stay one
+// v_mad_i64_i32 each.
+GF_HD int32_t lz_k(int32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+s"(x));
+#endif
+    return x;
+}
+#define LZ_K(x) lz_k(x)
+
+struct lz {
+    int32_t l[5];
+};
+
+// W-form of a multiplier: row i holds the NN limbs of (w * B^i mod p), canonical (limbs 0..3 < 2^26, limb 4 < 2^24)
+struct lzw {
+    int32_t w[5][5];
+};
+
+GF_HD lz lz_unpack(const fe &a) {   // 8 operations; the result is exactly normalised (l4 < 2^24)
+    lz r;
+    r.l[0] = (int32_t)(a.w0 & LZ_M);
+    r.l[1] = (int32_t)(((a.w0 >> 26) | (a.w1 << 6)) & LZ_M);
+    r.l[2] = (int32_t)(((a.w1 >> 20) | (a.w2 << 12)) & LZ_M);
+    r.l[3] = (int32_t)(((a.w2 >> 14) | (a.w3 << 18)) & LZ_M);
+    r.l[4] = (int32_t)(a.w3 >> 8);
+    return r;
+}
+
+GF_HD lz lz_add(const lz &a, const lz &b) {
+    lz r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+GF_HD lz lz_sub(const lz &a, const lz &b) {
+    lz r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) r.l[i] = a.l[i] - b.l[i];
+    return r;
+}
+
+// carry of a 64-bit column into the next limb: bits 26..57 as a signed 32-bit value (exact for |c| < 2^57); one v_alignbit_b32
+GF_HD int32_t lz_carry(int64_t c) { return (int32_t)(c >> LZ_B); }
+GF_HD int32_t lz_low(int64_t c) { return (int32_t)((uint32_t)c & LZ_M); }
+
+// the common tail of both products: five 64-bit columns c[0..4] (value = sum c[j] B^j, |c[j]| < 2^57 - 2^44) -> NN limbs
+GF_HD lz lz_fold_columns(int64_t c[5]) {
+    lz y;
+    // top column first: everything above 2^130 comes down as T0 * (2304*B - 4)
+    const int32_t t0 = lz_carry(c[4]);
+    int32_t y4 = lz_low(c[4]);
+    c[1] += (int64_t)t0 * LZ_K(2304);
+    c[0] += (int64_t)t0 * LZ_K(-4);
+    int32_t k = lz_carry(c[0]);
+    y.l[0] = lz_low(c[0]);
+    c[1] += k;
+    k = lz_carry(c[1]);
+    y.l[1] = lz_low(c[1]);
+    c[2] += k;
+    k = lz_carry(c[2]);
+    y.l[2] = lz_low(c[2]);
+    c[3] += k;
+    k = lz_carry(c[3]);
+    y.l[3] = lz_low(c[3]);
+    // k (|k| < 2^31) lands on limb 4: its low 26 bits stay, what is left of it and bits 24.. of limb 4 are folded once more,
+    // now at 2^128 == 576*B - 1  (t1 is a handful of bits)
+    y4 += k & LZ_M;
+    const int32_t t1 = ((k >> LZ_B) << 2) + (y4 >> 24);
+    y.l[4] = y4 & 0xffffff;
+    y.l[1] += t1 * 576;
+    y.l[0] -= t1;
+    return y;
+}
+
+// x * w, the multiplier given by its W-form (lane-uniform on the GPU: the 25 words sit in SGPRs)
+GF_HD lz lz_mul_u(const lz &x, const lzw &W) {
+    int64_t c[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        int64_t s = (int64_t)x.l[0] * W.w[0][j];
+#pragma unroll
+        for (int i = 1; i < 5; i++) s += (int64_t)x.l[i] * W.w[i][j];
+        c[j] = s;
+    }
+    return lz_fold_columns(c);
+}
+
+// x * w, the multiplier an ordinary NN element (per-lane twiddles read from a table): nine columns, the four high ones
+// (weight 2^130 * B^k) are brought down first.  A 64-bit column is split as c = h * 2^32 + l (h signed, l unsigned: its two registers):
+//     c * 2^130 == 2304*B*c - 4*c,   2304*c = 2304*l + 147456*B*h,   4*c = 4*l + 256*B*h        (2^32 = 64*B)
+GF_HD lz lz_mul_v(const lz &x, const lz &w) {
+    int64_t c[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        int64_t s = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < 5) s += (int64_t)x.l[i] * w.l[j];
+        }
+        c[k] = s;
+    }
+#pragma unroll
+    for (int k = 8; k >= 5; k--) {   // top down: column 8 spills into column 5, which is folded last
+        const int32_t h = (int32_t)(c[k] >> 32);
+        const uint32_t lo = (uint32_t)c[k];
+        // -4*lo as an unsigned product: 4 * ~lo = 4 * (2^32 - 1) - 4 * lo; the constant is taken back right away (the compiler
+        // folds the four of them into the first addend of columns 0..3)
+        c[k - 3] += (int64_t)h * LZ_K(147456);
+        c[k - 4] += (int64_t)((uint64_t)lo * (uint32_t)LZ_K(2304));
+        c[k - 4] += (int64_t)h * LZ_K(-256);
+        c[k - 5] += (int64_t)((uint64_t)(~lo) * (uint32_t)LZ_K(4)) - (((int64_t)1 << 34) - 4);
+    }
+    return lz_fold_columns(c);
+}
+
+// carry propagation without a product (elements that skip a twiddle): any limbs |l_i| < 2^31 - 2^6 -> NN
+GF_HD lz lz_norm(const lz &x) {
+    lz y;
+    int32_t k = x.l[0] >> LZ_B;
+    y.l[0] = x.l[0] & LZ_M;
+    int32_t v = x.l[1] + k;
+    k = v >> LZ_B;
+    y.l[1] = v & LZ_M;
+    v = x.l[2] + k;
+    k = v >> LZ_B;
+    y.l[2] = v & LZ_M;
+    v = x.l[3] + k;
+    k = v >> LZ_B;
+    y.l[3] = v & LZ_M;
+    v = x.l[4] + k;
+    const int32_t t = v >> 24;     // |t| < 2^7
+    y.l[4] = v & 0xffffff;
+    y.l[1] += t * 576;
+    y.l[0] -= t;
+    return y;
+}
+
+// any lazy value (|l_i| <= 2^30 + 2^22, |l4| <= 2^28 + 2^12) -> the canonical 16-byte element.
+// A multiple of p is added first so that the value is positive, carries are propagated exactly, the part above 2^128 is folded
+// with 2^128 == C = 9*2^32 - 1 in saturated 128-bit arithmetic (one more conditional +C if that overflows, then the final
+// conditional -p): the quotient estimate can be off by one, so the last two steps cannot be skipped.
+GF_HD fe lz_pack(const lz &x) {
+    // 32*p in radix 2^26 = 2^133 - 576*32*B + 32: limbs {32, -18432, 0, 0, 2^29} (value-equal; the limbs need not be normalised)
+    int32_t v = x.l[0] + 32;
+    int32_t k = v >> LZ_B;
+    const uint32_t l0 = (uint32_t)(v & LZ_M);
+    v = x.l[1] - 18432 + k;
+    k = v >> LZ_B;
+    const uint32_t l1 = (uint32_t)(v & LZ_M);
+    v = x.l[2] + k;
+    k = v >> LZ_B;
+    const uint32_t l2 = (uint32_t)(v & LZ_M);
+    v = x.l[3] + k;
+    k = v >> LZ_B;
+    const uint32_t l3 = (uint32_t)(v & LZ_M);
+    const uint32_t l4 = (uint32_t)(x.l[4] + (1 << 29) + k);   // >= 0: the whole value is positive; < 2^30 + 2^28
+    const uint32_t t = l4 >> 24;                               // quotient by 2^128, < 2^7
+    fe r;
+    r.w0 = l0 | (l1 << 26);
+    r.w1 = (l1 >> 6) | (l2 << 20);
+    r.w2 = (l2 >> 12) | (l3 << 14);
+    r.w3 = (l3 >> 18) | ((l4 & 0xffffff) << 8);
+    // r + t*C = r - t + 9t * 2^32
+    uint32_t b, c;
+    r.w0 = gf_subc(r.w0, t, 0u, b);
+    r.w1 = gf_subc(r.w1, 0u, b, b);
+    r.w2 = gf_subc(r.w2, 0u, b, b);
+    r.w3 = gf_subc(r.w3, 0u, b, b);        // b set: r < t, only when r is tiny — the addition below then carries out and cancels it
+    r.w1 = gf_addc(r.w1, 9u * t, 0u, c);
+    r.w2 = gf_addc(r.w2, 0u, c, c);
+    r.w3 = gf_addc(r.w3, 0u, c, c);
+    // net overflow past 2^128 (c without b): fold it once more, +C; cannot overflow again (the wrapped value is < 2^43)
+    const uint32_t m = 0u - (c & ~b);
+    r.w0 = gf_addc(r.w0, m, 0u, c);
+    r.w1 = gf_addc(r.w1, m & 8u, c, c);
+    r.w2 = gf_addc(r.w2, 0u, c, c);
+    r.w3 = gf_addc(r.w3, 0u, c, c);
+    // canonical: subtract p when r >= p, i.e. when r + C overflows
+    fe s;
+    s.w0 = gf_addc(r.w0, 0xFFFFFFFFu, 0u, c);
+    s.w1 = gf_addc(r.w1, 8u, c, c);
+    s.w2 = gf_addc(r.w2, 0u, c, c);
+    s.w3 = gf_addc(r.w3, 0u, c, c);
+    fe o;
+    o.w0 = c ? s.w0 : r.w0;
+    o.w1 = c ? s.w1 : r.w1;
+    o.w2 = c ? s.w2 : r.w2;
+    o.w3 = c ? s.w3 : r.w3;
+    return o;
+}
+
+// multiply an NN value by B modulo p (one limb up; the limb that falls off the top comes back as 2304*B - 4): the building
+// block of the W-form.  Input NN, output NN.
+GF_HD lz lz_shift_limb(const lz &x) {
+    int64_t c[5];
+    c[0] = (int64_t)x.l[4] * LZ_K(-4);
+    c[1] = (int64_t)x.l[4] * LZ_K(2304) + x.l[0];
+    c[2] = x.l[1];
+    c[3] = x.l[2];
+    c[4] = x.l[3];
+    return lz_fold_columns(c);
+}
+
+// W-form of a canonical element (host: plan tables; device: per-lane running products)
+GF_HD void lz_wform(const fe &w, lzw &W) {
+    fe cur = w;
+    const fe Bm = fe_make(1u << 26, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        lz u = lz_unpack(cur);
+#pragma unroll
+        for (int j = 0; j < 5; j++) W.w[i][j] = u.l[j];
+        if (i < 4) cur = fe_mul(cur, Bm);
+    }
+}

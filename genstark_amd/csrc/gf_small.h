@@ -1,5 +1,5 @@
-// gf_small.cuh — GF(q) for a prime q < 2^64 fixed at build time (-DGS_SMALL_Q=<q>ull), with the names and the 16-byte element
-// layout of gf128.cuh, so that every kernel of the library compiles for it unchanged (build flavours libgstark_hip_q64.so /
+// gf_small.h — GF(q) for a prime q < 2^64 fixed at build time (-DGS_SMALL_Q=<q>ull), with the names and the 16-byte element
+// layout of gf128.h, so that every kernel of the library compiles for it unchanged (build flavours libgstark_hip_q64.so /
 // libgstark_hip_q32.so: the fields of examples/rescue/hash2x64.ts:10 and examples/demo/fibonacci.ts:14).
 //
 // The reference itself accelerates only the 128-bit field (galois' wasm path; every other modulus runs its generic BigInt
@@ -9,14 +9,14 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define GF_HD __host__ __device__ __forceinline__
 #else
 #define GF_HD inline
 #endif
 
 #ifndef GS_SMALL_Q
-#error "gf_small.cuh needs -DGS_SMALL_Q=<prime below 2^64>"
+#error "gf_small.h needs -DGS_SMALL_Q=<prime below 2^64>"
 #endif
 
 struct alignas(16) fe {

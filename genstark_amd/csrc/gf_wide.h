@@ -1,5 +1,5 @@
-// gf_wide.cuh — GF(p) for the two multi-limb primes of the reference's examples, fixed at build time (-DGS_WIDE_BITS=256 |
-// 224), with the names of gf128.cuh so that every kernel of the library compiles for them unchanged (build flavours
+// gf_wide.h — GF(p) for the two multi-limb primes of the reference's examples, fixed at build time (-DGS_WIDE_BITS=256 |
+// 224), with the names of gf128.h so that every kernel of the library compiles for them unchanged (build flavours
 // libgstark_hip_p256.so / libgstark_hip_p224.so):
 //     p256 = 2^256 - 351*2^32 + 1     examples/mimc/mimc256.ts:13
 //     p224 = 2^224 - 2^96 + 1         assembly/lib224.aa:3, examples/elliptic/pointmul.aa
@@ -11,14 +11,14 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define GF_HD __host__ __device__ __forceinline__
 #else
 #define GF_HD inline
 #endif
 
 #ifndef GS_WIDE_BITS
-#error "gf_wide.cuh needs -DGS_WIDE_BITS=256 or 224"
+#error "gf_wide.h needs -DGS_WIDE_BITS=256 or 224"
 #endif
 
 #define GF_LIMBS 8                       // storage limbs of an element

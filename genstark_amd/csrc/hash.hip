@@ -7,7 +7,7 @@
 // are compile-time constants), the 32-byte digest is stored as two 128-bit words.
 #include "common.h"
 
-#include "hash_core.cuh"
+#include "hash_core.h"
 
 // Digest of a message made of `nwords16` 16-byte words; word16(i) returns the i-th one (little-endian
 // memory order).  ALG: 0 = sha256, 1 = blake2s256.  Output: 8 x u32 in memory (byte) order.

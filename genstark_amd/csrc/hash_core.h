@@ -1,4 +1,4 @@
-// hash_core.cuh — BLAKE2s-256 and SHA-256 compression functions for gfx950 device code: everything in registers,
+// hash_core.h — BLAKE2s-256 and SHA-256 compression functions for gfx950 device code: everything in registers,
 // rounds fully unrolled so the message-schedule indices are compile-time constants.  Used by hash.hip (leaf / row /
 // node hashing, Merkle construction) and tools/microbench_hash.hip.
 #pragma once

@@ -1,6 +1,6 @@
 // host_field.h — GF(p) arithmetic on native 64-bit limbs for the few HOST-side pieces of the library:
 // the serial MiMC recurrence (air_mimc.hip) and O(n^2) Lagrange interpolation of <= a few hundred points
-// (small.hip).  Same modulus and canonical representation as gf128.cuh.
+// (small.hip).  Same modulus and canonical representation as gf128.h.
 #pragma once
 #if defined(GS_SMALL_Q)
 #include "host_field_small.h"

@@ -1,4 +1,4 @@
-// host_field_small.h — the host-side GF(q) helpers of host_field.h for the small-field build flavours (see gf_small.cuh):
+// host_field_small.h — the host-side GF(q) helpers of host_field.h for the small-field build flavours (see gf_small.h):
 // same names, an element is an unsigned __int128 whose value is below q < 2^64.
 #pragma once
 #include <stdint.h>

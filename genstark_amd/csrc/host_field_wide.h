@@ -1,4 +1,4 @@
-// host_field_wide.h — the host-side GF(p) helpers of host_field.h for the 256- / 224-bit build flavours (see gf_wide.cuh):
+// host_field_wide.h — the host-side GF(p) helpers of host_field.h for the 256- / 224-bit build flavours (see gf_wide.h):
 // same names; an element wraps the device header's `fe` (its functions are host + device) and converts from small integers.
 #pragma once
 #include <stdint.h>

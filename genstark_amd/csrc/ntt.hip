@@ -24,6 +24,12 @@
 
 #include "common.h"
 
+#if !defined(GS_SMALL_Q) && !defined(GS_WIDE_BITS)
+#define GS_NTT_LAZY 1      // the 128-bit field of the hot path: butterflies in five-limb lazy form (gf128_lazy.h)
+#include "gf128_lazy.h"
+struct alignas(32) lz8 { int32_t l[8]; };   // an NN element as a table entry: five limbs, 32-byte stride
+#endif
+
 struct NttPlan {
     fe omega;
     uint64_t n = 0;
@@ -36,6 +42,11 @@ struct NttPlan {
     fe *twp[4] = {nullptr, nullptr, nullptr, nullptr}; // inter-pass twiddles omega_{Ns*R}^(jq*k) as a [k][jq] table (passes >= 1, when small)
     fe w16[8];                                         // omega_16^i
     fe *inv_table = nullptr;                           // 1 / (omega^j - 1), j < n, [0] = 0 (built on first use: gs_plan_inverse_table)
+#ifdef GS_NTT_LAZY
+    lzw *wtab = nullptr;                               // device: W-forms of omega_16^1..7 and of 1/n (read with scalar loads)
+    lz8 *wRz[4] = {nullptr, nullptr, nullptr, nullptr};   // wR[i] as NN limbs
+    lz8 *wRz_scaled = nullptr;                         // the last pass's table times 1/n (inverse transforms: the scale rides on the exchange twiddle)
+#endif
 };
 
 struct PassArgs {
@@ -81,6 +92,256 @@ __device__ __forceinline__ void ntt_dif_reg(fe (&x)[1 << LOGN], const fe (&w16)[
         }
     }
 }
+
+
+#ifdef GS_NTT_LAZY
+// ======================================================================================================================
+// The pass kernel of the 128-bit field, butterflies in the lazy five-limb form of gf128_lazy.h.
+//
+// Same decomposition, indexing and LDS exchange as k_ntt_pass below (which stays for the other field flavours); what changes
+// is the arithmetic and therefore the shape of a workgroup:
+//   * elements are unpacked to 5 x 26-bit limbs right after the 16-byte load and packed (canonical) right before the store;
+//     add/sub inside the networks are 5 plain 32-bit operations, no carries, no reduction;
+//   * the radix-16 twiddles are kernel arguments in W-form (25 SGPR words each): lz_mul_u, no high columns;
+//   * per-lane twiddles (inter-pass table / running product, exchange table) go through lz_mul_v;
+//   * a thread still owns 16 elements (80 VGPRs); a workgroup is 128 threads on a tile of 2048 elements, the exchange buffer
+//     holds the five limb planes (40 KiB: four workgroups = eight waves per CU), bank-conflict free on both sides
+//     (consecutive lanes -> consecutive words on the write side, an XOR swizzle of the bank bits on the read side).
+struct LzPassArgs {
+    uint64_t n, in_len, in_stride, out_stride;
+    int logn, logNs, logWj, log_lo;
+    int scale;      // multiply every output by ninv (inverse transform, passes without an exchange stage)
+    int exq0;       // the exchange table carries a common factor (1/n): output qa = 0 takes wR[0] as well
+    const fe *tw_lo, *tw_hi, *twp;
+    const lz8 *wR;
+    const lzw *wtab;   // W-forms: [0..6] omega_16^1..7, [7] 1/n.  Read with scalar loads right before each use (see LZ_FENCE)
+};
+
+// The W-form of a lane-uniform multiplier is 25 SGPR words.  Left alone, the scheduler hoists the scalar loads of all seven
+// radix-16 twiddles to the top of the unrolled network (175 live SGPRs -> spills to VGPR lanes, one v_readlane per use);
+// a compiler-only memory fence before each product keeps every load next to its use.
+#define LZ_FENCE() asm volatile("" ::: "memory")
+// ... and read through the constant address space: a lane-uniform load from it is always a scalar load, whatever stores and
+// fences surround it (the table is written once, when the plan is made, long before any kernel that reads it is launched)
+typedef const lzw *lzw_cptr;
+__device__ __forceinline__ lzw lz_load_w(const lzw *p) {
+    lzw W;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(4))) int32_t *q = (const __attribute__((address_space(4))) int32_t *)(const int32_t *)p;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int j = 0; j < 5; j++) W.w[i][j] = q[i * 5 + j];
+#else
+    W = *p;
+#endif
+    return W;
+}
+
+__device__ __forceinline__ lz lz_load8(const lz8 *__restrict__ p) {
+    const int4 a = *reinterpret_cast<const int4 *>(p);
+    lz r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = p->l[4];
+    return r;
+}
+
+__device__ __forceinline__ lz lz_pow_lookup(const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn, uint64_t e) {
+    lz x = lz_unpack(tw_lo[e & ((1ull << log_lo) - 1)]);
+    if (logn > log_lo) x = lz_mul_v(x, lz_unpack(tw_hi[e >> log_lo]));  // wave-uniform
+    return x;
+}
+
+// decimation in frequency on N = 2^LOGN lazy registers, w[i - 1] = W-form of omega_16^i; result bit-reversed.
+// Inputs NN; a product is only ever applied to a difference (at most 2^3 NN values apart); outputs are sums of up to N NN values.
+template <int LOGN, int S>
+__device__ __forceinline__ void ntt_dif_lz_level(lz (&x)[1 << LOGN], lzw_cptr w) {
+    constexpr int N = 1 << LOGN;
+#pragma unroll
+    for (int b = 0; b < N; b += 2 * S) {
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            const lz u = x[b + i], v = x[b + i + S];
+            x[b + i] = lz_add(u, v);
+            const lz d = lz_sub(u, v);
+            constexpr int unit = (N / 2 / S) * (16 / N);
+            const int tw = i * unit;
+            if (tw) { LZ_FENCE(); const lzw W = lz_load_w(w + (tw - 1)); x[b + i + S] = lz_mul_u(d, W); } else x[b + i + S] = d;
+        }
+    }
+    if constexpr (S > 1) ntt_dif_lz_level<LOGN, S / 2>(x, w);   // one level per instantiation: a single loop over the levels is too big to unroll
+}
+template <int LOGN>
+__device__ __forceinline__ void ntt_dif_lz(lz (&x)[1 << LOGN], lzw_cptr w) {
+    if constexpr (LOGN > 0) ntt_dif_lz_level<LOGN, (1 << LOGN) / 2>(x, w);
+}
+
+// word index of element e in one limb plane of the exchange buffer (see the header comment)
+__device__ __forceinline__ int lz_slot(int e, int logWj) {
+    if (logWj >= 5 || logWj == 0) return e;
+    return e ^ (((e >> (4 + logWj)) & ((32 >> logWj) - 1)) << logWj);
+}
+
+// TW: 0 = first pass (logNs == 0: no input twiddle; the tile's output is one contiguous block of R*Wj elements, written through an
+// LDS transpose), 1 = input twiddles from the [k][jq] table, 2 = from the power tables + a running product
+template <int LB, int TW>
+__global__ __launch_bounds__(128, 2) void k_ntt_pass_lz(const fe *__restrict__ in, fe *__restrict__ out, LzPassArgs a) {
+    constexpr int RB = 1 << LB, R = 16 * RB, GB = 16 / RB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    int32_t *lds = reinterpret_cast<int32_t *>(lds_raw);      // five planes of R*Wj words
+    fe *ldsf = reinterpret_cast<fe *>(lds_raw);               // first pass: the output transpose, Wj rows of R + 1 elements
+
+    const int t = threadIdx.x;
+    const int Wj = 1 << a.logWj;
+    const int plane = R << a.logWj;
+    const int jj = t & (Wj - 1);
+    const int kk = t >> a.logWj;  // < RB
+    const uint64_t j = (uint64_t)blockIdx.x * Wj + jj;
+    const uint64_t nR = a.n >> (4 + LB);
+    const fe *src = in + (uint64_t)blockIdx.y * a.in_stride;
+    fe *dst = out + (uint64_t)blockIdx.y * a.out_stride;
+
+    // ---- stage A: 16 strided loads (coalesced across jj), Stockham input twiddle, radix-16 in registers
+    lz v[16];
+    constexpr bool FIRST = (TW == 0);
+    const bool pruned = FIRST && a.in_len <= nR * RB;   // low-degree extension by >= 16x: only m = 0 is in range (first pass, no twiddle)
+    if (pruned) {
+        const uint64_t idx = j + (uint64_t)kk * nR;
+        fe x0 = idx < a.in_len ? src[idx] : fe_zero();
+        v[0] = lz_unpack(x0);
+#pragma unroll
+        for (int m = 1; m < 16; m++) v[m] = v[0];   // the 16-point transform of (v0, 0, ..., 0) is v0 everywhere
+    } else {
+        fe raw[16];
+        if (!FIRST || a.in_len >= a.n) {   // every pass but a zero-extending first one: 16 unconditional loads in flight
+#pragma unroll
+            for (int m = 0; m < 16; m++) raw[m] = src[j + (uint64_t)(kk + RB * m) * nR];
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                const uint64_t idx = j + (uint64_t)(kk + RB * m) * nR;
+                raw[m] = src[idx < a.in_len ? idx : 0];          // branch-free: an in-range address, the value dropped below
+                if (idx >= a.in_len) raw[m] = fe_zero();
+            }
+        }
+        const uint64_t Ns = 1ull << a.logNs;
+        const uint64_t jq = j & (Ns - 1);
+        if constexpr (TW == 1) {
+            // precomputed [k][jq] table (cache resident)
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                if ((m & 3) == 0) { LZ_FENCE(); __builtin_amdgcn_sched_barrier(0); }   // four twiddle loads and four products at a time: the 16 data loads above already hold 64 VGPRs
+                v[m] = lz_mul_v(lz_unpack(raw[m]), lz_unpack(a.twp[((uint64_t)(kk + RB * m) << a.logNs) + jq]));
+            }
+        } else if constexpr (TW == 2) {
+            // v[m] *= omega_{Ns*R}^(jq * (kk + RB*m)): start value + running product; the step is put in W-form once
+            const uint64_t eu = a.n >> (a.logNs + 4 + LB);
+            lz cur = lz_pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * kk * eu);
+            lz row = lz_pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * RB * eu);
+            lzw step;
+#pragma unroll
+            for (int r = 0; r < 5; r++) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    step.w[r][c] = row.l[c];
+                    // opaque to the optimizer: with the rows' value ranges visible, hipcc (ROCm 7.2) miscompiles the products below
+                    // (tools/lazy_device_check.hip test 3 catches it); table multipliers come from memory and are opaque anyway
+                    asm volatile("" : "+v"(step.w[r][c]));
+                }
+                if (r < 4) row = lz_shift_limb(row);
+            }
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                v[m] = lz_mul_v(lz_unpack(raw[m]), cur);
+                if (m < 15) cur = lz_mul_u(cur, step);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; m++) v[m] = lz_unpack(raw[m]);
+        }
+        ntt_dif_lz<4>(v, (lzw_cptr)a.wtab);  // A[qa] = v[brev(qa,4)], sums of up to 16 NN values
+    }
+
+    const uint64_t Ns = 1ull << a.logNs;
+    const uint64_t jq = j & (Ns - 1);
+    const uint64_t jbase = (j - jq) * R + jq;
+    constexpr bool first = FIRST;
+
+    if constexpr (RB == 1) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            lz x = v[brev(q, 4)];
+            if (a.scale) { LZ_FENCE(); const lzw W = lz_load_w(a.wtab + 7); x = lz_mul_u(lz_norm(x), W); }
+            const fe y = lz_pack(x);
+            if (first) ldsf[jj * (R + 1) + q] = y;
+            else dst[jbase + (uint64_t)q * Ns] = y;
+        }
+        if (!first) return;
+    } else {
+        // ---- exchange through LDS with the A->B twiddle omega_R^(kk*qa): normalise (the network grew the limbs by four bits),
+        //      multiply, store the five limbs into their planes
+#pragma unroll
+        for (int qa = 0; qa < 16; qa++) {
+            if ((qa & 3) == 0) LZ_FENCE();   // same for the exchange twiddles
+            lz x = lz_norm(v[brev(qa, 4)]);
+            if (qa != 0) x = lz_mul_v(x, lz_load8(a.wR + ((kk * qa) & (R - 1))));
+            else if (a.exq0) x = lz_mul_v(x, lz_load8(a.wR));
+            const int slot = lz_slot((qa * RB + kk) * Wj + jj, a.logWj);
+#pragma unroll
+            for (int l = 0; l < 5; l++) lds[l * plane + slot] = x.l[l];
+        }
+        __syncthreads();
+        // ---- stage B: GB radix-RB networks per thread (g = kk indexes the group of qa values)
+        lz xb[GB][RB];
+#pragma unroll
+        for (int u = 0; u < GB; u++) {
+            const int qa = kk * GB + u;
+#pragma unroll
+            for (int k2 = 0; k2 < RB; k2++) {
+                const int slot = lz_slot((qa * RB + k2) * Wj + jj, a.logWj);
+#pragma unroll
+                for (int l = 0; l < 5; l++) xb[u][k2].l[l] = lds[l * plane + slot];
+            }
+        }
+        if (first) __syncthreads();  // the exchange buffer is reused for the output transpose below
+#pragma unroll
+        for (int u = 0; u < GB; u++) {
+            const int qa = kk * GB + u;
+            ntt_dif_lz<LB>(xb[u], (lzw_cptr)a.wtab);
+#pragma unroll
+            for (int qb = 0; qb < RB; qb++) {
+                const fe y = lz_pack(xb[u][brev(qb, LB)]);
+                const int q = qa + 16 * qb;
+                if (first) ldsf[jj * (R + 1) + q] = y;
+                else dst[jbase + (uint64_t)q * Ns] = y;
+            }
+        }
+        if (!first) return;
+    }
+    // ---- first pass only: y[j*R + q] for the tile is contiguous; stream it out of LDS coalesced
+    __syncthreads();
+    const int T = RB * Wj;  // threads in this block
+    fe *tile = dst + (uint64_t)blockIdx.x * Wj * R;
+#pragma unroll 4
+    for (int e = t; e < R * Wj; e += T) {
+        const int ej = e / R, eq = e % R;
+        tile[e] = ldsf[ej * (R + 1) + eq];
+    }
+}
+
+// dst[i] = NN limbs of src[i] * mult (mult = 1: a plain change of layout)
+__global__ void k_build_lz_table(const fe *__restrict__ src, lz8 *__restrict__ dst, uint64_t count, fe mult, int use_mult) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        fe x = src[i];
+        if (use_mult) x = fe_mul(x, mult);
+        const lz u = lz_unpack(x);
+        lz8 o;
+        for (int l = 0; l < 5; l++) o.l[l] = u.l[l];
+        o.l[5] = o.l[6] = o.l[7] = 0;
+        dst[i] = o;
+    }
+}
+#endif  // GS_NTT_LAZY
 
 template <int LB>
 __global__ __launch_bounds__(256) void k_ntt_pass(const fe *__restrict__ in, fe *__restrict__ out, PassArgs a) {
@@ -264,6 +525,20 @@ static int plan_get(gs_ctx *c, const fe &omega, uint64_t n, NttPlan **out) {
         p->npass = np;
         fe w16 = fe_pow_u64(omega, n / 16), cur = fe_one();
         for (int i = 0; i < 8; i++) { p->w16[i] = cur; cur = fe_mul(cur, w16); }
+#ifdef GS_NTT_LAZY
+        {
+            lzw host[8];
+            for (int i = 1; i < 8; i++) lz_wform(p->w16[i], host[i - 1]);
+            lz_wform(fe_inv(fe_from_u64(n)), host[7]);
+            if ((rc = gs_alloc(c, sizeof host, &q))) { delete p; return rc; }
+            p->wtab = (lzw *)q;
+            if (hipMemcpyAsync(p->wtab, host, sizeof host, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) {   // `host` is a stack buffer: the copy must be over before it goes
+                delete p;
+                return gs_fail(c, GS_ERR_DEVICE, "ntt: twiddle upload failed");
+            }
+        }
+#endif
         uint64_t Ns_acc = 1;
         for (int i = 0; i < np; i++) {
             p->L[i] = base + (i < extra ? 1 : 0);
@@ -284,6 +559,15 @@ static int plan_get(gs_ctx *c, const fe &omega, uint64_t n, NttPlan **out) {
                     p->wR[i] = (fe *)q;
                     if ((rc = gs_power_series_dev(c, fe_pow_u64(omega, n / R), R, p->wR[i]))) { delete p; return rc; }
                 }
+#ifdef GS_NTT_LAZY
+                for (int k = 0; k < i; k++)
+                    if (p->L[k] == p->L[i]) p->wRz[i] = p->wRz[k];
+                if (!p->wRz[i]) {
+                    if ((rc = gs_alloc(c, R * sizeof(lz8), &q))) { delete p; return rc; }
+                    p->wRz[i] = (lz8 *)q;
+                    hipLaunchKernelGGL(k_build_lz_table, dim3(gs_grid(R)), dim3(256), 0, c->stream, p->wR[i], p->wRz[i], R, fe_one(), 0);
+                }
+#endif
             }
         }
     }
@@ -351,6 +635,28 @@ static void launch_pass(gs_ctx *c, const fe *in, fe *out, const PassArgs &a, uin
     hipLaunchKernelGGL(k_ntt_pass<LB>, dim3((unsigned)tiles, rows), dim3(RB * Wj), lds, c->stream, in, out, a);
 }
 
+
+#ifdef GS_NTT_LAZY
+template <int LB>
+static void launch_pass_lz(gs_ctx *c, const fe *in, fe *out, const LzPassArgs &a, uint32_t rows) {
+    constexpr int RB = 1 << LB, R = 16 * RB;
+    const int Wj = 1 << a.logWj;
+    const uint64_t tiles = (a.n / R) / Wj;
+    const bool first = a.logNs == 0;
+    size_t lds = 0;
+    if (RB > 1) lds = (size_t)5 * 4 * R * Wj;
+    if (first) { const size_t tr = (size_t)Wj * (R + 1) * sizeof(fe); if (tr > lds) lds = tr; }
+    if (first) hipLaunchKernelGGL((k_ntt_pass_lz<LB, 0>), dim3((unsigned)tiles, rows), dim3(RB * Wj), lds, c->stream, in, out, a);
+    else if (a.twp) hipLaunchKernelGGL((k_ntt_pass_lz<LB, 1>), dim3((unsigned)tiles, rows), dim3(RB * Wj), lds, c->stream, in, out, a);
+    else hipLaunchKernelGGL((k_ntt_pass_lz<LB, 2>), dim3((unsigned)tiles, rows), dim3(RB * Wj), lds, c->stream, in, out, a);
+}
+
+static bool ntt_lazy_enabled() {   // GSTARK_NTT_LAZY=0 keeps the canonical-limb kernel (A/B measurements)
+    const char *e = getenv("GSTARK_NTT_LAZY");   // read per call: tools/ntt_ab.py flips it inside one process
+    return !(e && e[0] == '0');
+}
+#endif
+
 // rows transforms of size n; row r reads in[r*in_stride .. +in_len) (zero-extended) and writes out[r*n .. +n)
 static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint64_t in_stride, const fe &omega, uint64_t n,
                    bool inverse, fe *out) {
@@ -389,6 +695,53 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
     for (int i = 0; i < p->npass; i++) {
         const int remaining = p->npass - 1 - i;
         fe *dst = (remaining % 2 == 0) ? out : tmp;
+        const int LB = p->L[i] - 4;
+        const uint64_t R = 1ull << p->L[i];
+        const bool last = (i == p->npass - 1);
+#ifdef GS_NTT_LAZY
+        if (ntt_lazy_enabled()) {
+            LzPassArgs a;
+            a.n = n;
+            a.in_len = (i == 0) ? in_len : n;
+            a.in_stride = (i == 0) ? in_stride : n;
+            a.out_stride = n;
+            a.logn = p->logn;
+            a.logNs = logNs;
+            uint64_t Wj = 128 >> LB;
+            if (Wj > n / R) Wj = n / R;
+            a.logWj = gs_log2(Wj);
+            a.log_lo = p->log_lo;
+            a.tw_lo = p->tw_lo;
+            a.tw_hi = p->tw_hi;
+            a.twp = p->twp[i];
+            a.wR = p->wRz[i];
+            a.scale = 0;
+            a.exq0 = 0;
+            if (inverse && last) {
+                if (LB > 0) {   // the 1/n scale rides on the exchange twiddles of the last pass
+                    if (!p->wRz_scaled) {
+                        void *q;
+                        if ((rc = gs_alloc(c, R * sizeof(lz8), &q))) { if (tmp) gs_tmp_free(c, tmp); return rc; }
+                        p->wRz_scaled = (lz8 *)q;
+                        hipLaunchKernelGGL(k_build_lz_table, dim3(gs_grid(R)), dim3(256), 0, c->stream, p->wR[i], p->wRz_scaled, R, ninv, 1);
+                    }
+                    a.wR = p->wRz_scaled;
+                    a.exq0 = 1;
+                } else {
+                    a.scale = 1;
+                }
+            }
+            a.wtab = p->wtab;
+            switch (LB) {
+                case 0: launch_pass_lz<0>(c, src, dst, a, rows); break;
+                case 1: launch_pass_lz<1>(c, src, dst, a, rows); break;
+                case 2: launch_pass_lz<2>(c, src, dst, a, rows); break;
+                case 3: launch_pass_lz<3>(c, src, dst, a, rows); break;
+                default: launch_pass_lz<4>(c, src, dst, a, rows); break;
+            }
+        } else
+#endif
+        {
         PassArgs a;
         a.n = n;
         a.in_len = (i == 0) ? in_len : n;
@@ -396,13 +749,11 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
         a.out_stride = n;
         a.logn = p->logn;
         a.logNs = logNs;
-        const int LB = p->L[i] - 4;
-        const uint64_t R = 1ull << p->L[i];
         uint64_t Wj = 256 >> LB;
         if (Wj > n / R) Wj = n / R;
         a.logWj = gs_log2(Wj);
         a.log_lo = p->log_lo;
-        a.scale = (inverse && i == p->npass - 1) ? 1 : 0;
+        a.scale = (inverse && last) ? 1 : 0;
         a.tw_lo = p->tw_lo;
         a.tw_hi = p->tw_hi;
         a.wR = p->wR[i];
@@ -415,6 +766,7 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
             case 2: launch_pass<2>(c, src, dst, a, rows); break;
             case 3: launch_pass<3>(c, src, dst, a, rows); break;
             default: launch_pass<4>(c, src, dst, a, rows); break;
+        }
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {

@@ -1,5 +1,5 @@
 """The reference's AirAssembly library for the 224-bit field 2^224 - 2^96 + 1, assembly/lib224.aa, as GenericAirs on the wide build
-flavour of the library (csrc/gf_wide.cuh), driven like examples/assembly/lib224.ts drives them:
+flavour of the library (csrc/gf_wide.h), driven like examples/assembly/lib224.ts drives them:
 
     ComputePoseidonHash      3 registers, Poseidon of width 3 (x^5, 8 full + 55 partial rounds), lib224.aa:329-364
     ComputeMerkleRoot        6 registers, one authentication path of single-element nodes, :367-389

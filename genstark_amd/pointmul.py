@@ -1,5 +1,5 @@
 """The reference's elliptic-curve example, examples/elliptic/pointmul.aa driven like examples/elliptic/pointMul.ts, as a GenericAir
-over the 224-bit field 2^224 - 2^96 + 1 (the wide build flavour of the library, csrc/gf_wide.cuh): double-and-add multiplication
+over the 224-bit field 2^224 - 2^96 + 1 (the wide build flavour of the library, csrc/gf_wide.h): double-and-add multiplication
 of a point of the curve y^2 = x^3 + a*x + b, a = p - 3 (pointmul.aa:3), by a secret 256-bit scalar.  8 registers, 256 steps per
 multiplication:
 

@@ -1,6 +1,6 @@
 /*
  * oracle/gf_small.h — TEST INFRASTRUCTURE (CPU oracle).  The arithmetic of oracle/gf128.h for a prime q < 2^64 fixed at build time
- * (-DGS_SMALL_Q=<q>ull): the checker of the small-field build flavours of the HIP library (genstark_amd/csrc/gf_small.cuh).
+ * (-DGS_SMALL_Q=<q>ull): the checker of the small-field build flavours of the HIP library (genstark_amd/csrc/gf_small.h).
  * Plain remainders of 128-bit integers: the mathematical definition, nothing shared with the device code.
  * parity unpinned (see gf128.h).
  */

@@ -2,7 +2,7 @@
  * oracle/gf_wide.h — TEST INFRASTRUCTURE (CPU oracle).  The arithmetic of oracle/gf128.h for the two multi-limb primes of the
  * reference's examples, fixed at build time (-DGS_WIDE_BITS=256: 2^256 - 351*2^32 + 1, examples/mimc/mimc256.ts:13;
  * -DGS_WIDE_BITS=224: 2^224 - 2^96 + 1, assembly/lib224.aa:3): the checker of the wide build flavours of the HIP library
- * (genstark_amd/csrc/gf_wide.cuh).  Elements are 32 bytes little-endian.
+ * (genstark_amd/csrc/gf_wide.h).  Elements are 32 bytes little-endian.
  *
  * The mathematical definition on C23 bit-precise integers — the 512-bit product a * b reduced with 2^BITS == 2^BITS - p until it
  * fits, then by subtraction (a generic 512-bit `%` gives the same values ten times slower: -DGS_ORACLE_PLAIN_MOD selects it) —

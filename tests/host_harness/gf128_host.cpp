@@ -1,6 +1,6 @@
-// Host-side harness for tests/: compiles genstark_amd/csrc/gf128.cuh and hash_dev.cuh with g++ so the
+// Host-side harness for tests/: compiles genstark_amd/csrc/gf128.h and hash_dev.h with g++ so the
 // exact device arithmetic can be unit-tested on a machine without a GPU.  Not part of the product.
-#include "../../genstark_amd/csrc/gf128.cuh"
+#include "../../genstark_amd/csrc/gf128.h"
 #include <string.h>
 extern "C" {
 static fe ld(const uint8_t *p) { fe r; memcpy(&r, p, 16); return r; }

@@ -35,7 +35,7 @@ def test_hip_library_exports_every_symbol():
 
 
 def test_field_flavours_export_every_symbol():
-    """The q64 / q32 builds (csrc/gf_small.cuh) and the p256 / p224 builds (csrc/gf_wide.cuh) of the same sources: same ABI, their
+    """The q64 / q32 builds (csrc/gf_small.h) and the p256 / p224 builds (csrc/gf_wide.h) of the same sources: same ABI, their
     own modulus and element size."""
     for modulus, path in _abi.HIP_LIB_PATHS.items():
         assert os.path.exists(path), f'{path}: run __graft_entry__.build() first'
@@ -51,13 +51,13 @@ def test_field_flavours_export_every_symbol():
 
 
 def test_small_field_device_header_on_host(tmp_path, rng):
-    """gf_small.cuh compiled for the host (the same GF_HD functions the kernels inline) against Python integers, both moduli."""
+    """gf_small.h compiled for the host (the same GF_HD functions the kernels inline) against Python integers, both moduli."""
     src = tmp_path / 'h.cpp'
     src.write_text('#include <stdint.h>\n#include "%s"\n'
                    'extern "C" void ops(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *add, uint64_t *sub, uint64_t *mul, uint64_t *inv) {\n'
                    '  for (uint64_t i = 0; i < n; i++) { fe x = fe_from(a[i]), y = fe_from(b[i]);\n'
                    '    add[i] = fe_u64(fe_add(x, y)); sub[i] = fe_u64(fe_sub(x, y)); mul[i] = fe_u64(fe_mul(x, y)); inv[i] = fe_u64(fe_inv(x)); } }\n'
-                   % os.path.join(ROOT, 'genstark_amd', 'csrc', 'gf_small.cuh'))
+                   % os.path.join(ROOT, 'genstark_amd', 'csrc', 'gf_small.h'))
     for q in (_abi.MODULUS_64, _abi.MODULUS_32, _abi.MODULUS_17):
         so = str(tmp_path / f'h_{q}.so')
         subprocess.check_call(['g++', '-O2', '-shared', '-fPIC', f'-DGS_SMALL_Q={q}ull', '-o', so, str(src)])
@@ -75,14 +75,14 @@ def test_small_field_device_header_on_host(tmp_path, rng):
 
 
 def test_wide_field_device_header_on_host(tmp_path, rng):
-    """gf_wide.cuh compiled for the host (the same GF_HD functions the kernels inline) against Python integers, both moduli."""
+    """gf_wide.h compiled for the host (the same GF_HD functions the kernels inline) against Python integers, both moduli."""
     src = tmp_path / 'w.cpp'
     src.write_text('#include <stdint.h>\n#include <string.h>\n#include "%s"\n'
                    'extern "C" void ops(const uint8_t *a, const uint8_t *b, uint64_t n, uint8_t *add, uint8_t *sub, uint8_t *mul, uint8_t *inv) {\n'
                    '  for (uint64_t i = 0; i < n; i++) { fe x, y, r; memcpy(&x, a + 32 * i, 32); memcpy(&y, b + 32 * i, 32);\n'
                    '    r = fe_add(x, y); memcpy(add + 32 * i, &r, 32); r = fe_sub(x, y); memcpy(sub + 32 * i, &r, 32);\n'
                    '    r = fe_mul(x, y); memcpy(mul + 32 * i, &r, 32); if (i < 200) { r = fe_inv(x); memcpy(inv + 32 * i, &r, 32); } } }\n'
-                   % os.path.join(ROOT, 'genstark_amd', 'csrc', 'gf_wide.cuh'))
+                   % os.path.join(ROOT, 'genstark_amd', 'csrc', 'gf_wide.h'))
     for bits, p in ((256, _abi.MODULUS_256), (224, _abi.MODULUS_224)):
         so = str(tmp_path / f'w_{bits}.so')
         subprocess.check_call(['g++', '-O2', '-shared', '-fPIC', '-Wno-unknown-pragmas', f'-DGS_WIDE_BITS={bits}', '-o', so, str(src)])
@@ -114,7 +114,7 @@ def test_missing_library_fails_loudly(tmp_path):
 
 @pytest.mark.parametrize('compiler', ['g++', '/opt/rocm/lib/llvm/bin/clang++'])
 def test_device_field_header_on_host(tmp_path, compiler, rng):
-    """genstark_amd/csrc/gf128.cuh (the arithmetic every kernel uses) compiled for the host: both the
+    """genstark_amd/csrc/gf128.h (the arithmetic every kernel uses) compiled for the host: both the
     portable carry path (g++) and the __builtin_addc path the device build takes (clang)."""
     if not os.path.exists(compiler) and compiler != 'g++':
         pytest.skip('ROCm clang not present')

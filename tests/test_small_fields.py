@@ -1,4 +1,4 @@
-"""The small prime fields of the reference's examples on the build flavours of the library (genstark_amd/csrc/gf_small.cuh; SURVEY
+"""The small prime fields of the reference's examples on the build flavours of the library (genstark_amd/csrc/gf_small.h; SURVEY
 8f-3): 2^64 - 21*2^30 + 1 (examples/rescue/hash2x64.ts) and 2^32 - 3*2^25 + 1 (examples/demo/fibonacci.ts, the README's Foo).
 Same kernels, same 16-byte element layout, plain arithmetic.  Known answers: the Rescue 2x64 trace the example prints
 (hash2x64.ts:137-215), the Fibonacci results of fibonacci.ts:9-11, Foo 1 -> 127.  CPU: the oracle flavours; GPU: HIP flavours,

@@ -1,4 +1,4 @@
-"""The two multi-limb prime fields of the reference's examples on the build flavours of the library (genstark_amd/csrc/gf_wide.cuh;
+"""The two multi-limb prime fields of the reference's examples on the build flavours of the library (genstark_amd/csrc/gf_wide.h;
 SURVEY 8f-3): 2^256 - 351*2^32 + 1 (examples/mimc/mimc256.ts:13) and 2^224 - 2^96 + 1 (assembly/lib224.aa:3).  Same kernels,
 32-byte elements.  The reference pins nothing for these fields beyond prove -> verify round trips (mimc256.ts:70-85), so the
 checks are: every vector member against Python integers, NTT against direct evaluation, MiMC-256 with the example's options

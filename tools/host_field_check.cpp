@@ -7,7 +7,7 @@
 #include <string.h>
 #if defined(GS_WIDE_BITS)
 #define GS_ELT 32
-#include "../genstark_amd/csrc/gf_wide.cuh"
+#include "../genstark_amd/csrc/gf_wide.h"
 #else
 #define GS_ELT 16
 #endif

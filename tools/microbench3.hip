@@ -4,7 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
-#include "../genstark_amd/csrc/gf128.cuh"
+#include "../genstark_amd/csrc/gf128.h"
 
 // two independent products, statement-interleaved
 #define ROW2(A, B, ai_a, ai_b, OA, OB)                                                                             \

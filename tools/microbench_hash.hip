@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 
-#include "../genstark_amd/csrc/hash_core.cuh"
+#include "../genstark_amd/csrc/hash_core.h"
 
 template <int ALG>
 __global__ void k(uint32_t *out, int iters) {

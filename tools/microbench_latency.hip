@@ -3,7 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench_latency.hip -o tools/microbench_latency && tools/microbench_latency
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-#include "../genstark_amd/csrc/gf128.cuh"
+#include "../genstark_amd/csrc/gf128.h"
 
 template <int CHAINS>
 __global__ void k_chain(const fe *in, fe *out, int iters) {
