@@ -28,16 +28,33 @@
 #define LZ_B 26
 #define LZ_M 0x3ffffff
 
-// Small constant multipliers of the folds.  Left visible, the compiler strength-reduces "x * -256" and friends into 64-bit
-// shift/subtract sequences (carry chains: exactly what this file avoids); laundered through an SGPR they stay one
-// v_mad_i64_i32 each.
-GF_HD int32_t lz_k(int32_t x) {
+// Products by the small constants of the folds (2304, -4, 147456, -256, 4).  Written in C the compiler either strength-reduces them
+// into 64-bit shift/subtract sequences (carry chains: exactly what this file avoids) or, when the constant lives in another basic
+// block, widens them to full 64 x 64-bit products (four instructions); one explicit v_mad each keeps them what they are.
+GF_HD int64_t lz_mad_ik(int32_t a, int32_t k, int64_t c) {      // c + a * k, signed
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm("" : "+s"(x));
+    int64_t d;
+    uint64_t carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(k), "v"(c));
+    return d;
+#else
+    return c + (int64_t)a * k;
 #endif
-    return x;
 }
-#define LZ_K(x) lz_k(x)
+GF_HD int64_t lz_mad_uk(uint32_t a, uint32_t k, int64_t c) {    // c + a * k, unsigned factors
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t d;
+    uint64_t carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(k), "v"(c));
+    return d;
+#else
+    return c + (int64_t)((uint64_t)a * k);
+#endif
+}
+struct lzk {   // kept so that call sites read the same on host and device; carries nothing any more
+    int unused;
+};
+GF_HD lzk lzk_make() { lzk K; K.unused = 0; return K; }
 
 struct lz {
     int32_t l[5];
@@ -76,13 +93,13 @@ GF_HD int32_t lz_carry(int64_t c) { return (int32_t)(c >> LZ_B); }
 GF_HD int32_t lz_low(int64_t c) { return (int32_t)((uint32_t)c & LZ_M); }
 
 // the common tail of both products: five 64-bit columns c[0..4] (value = sum c[j] B^j, |c[j]| < 2^57 - 2^44) -> NN limbs
-GF_HD lz lz_fold_columns(int64_t c[5]) {
+GF_HD lz lz_fold_columns(int64_t c[5], const lzk &K) {
     lz y;
     // top column first: everything above 2^130 comes down as T0 * (2304*B - 4)
     const int32_t t0 = lz_carry(c[4]);
     int32_t y4 = lz_low(c[4]);
-    c[1] += (int64_t)t0 * LZ_K(2304);
-    c[0] += (int64_t)t0 * LZ_K(-4);
+    c[1] = lz_mad_ik(t0, 2304, c[1]);
+    c[0] = lz_mad_ik(t0, -4, c[0]);
     int32_t k = lz_carry(c[0]);
     y.l[0] = lz_low(c[0]);
     c[1] += k;
@@ -105,7 +122,7 @@ GF_HD lz lz_fold_columns(int64_t c[5]) {
 }
 
 // x * w, the multiplier given by its W-form (lane-uniform on the GPU: the 25 words sit in SGPRs)
-GF_HD lz lz_mul_u(const lz &x, const lzw &W) {
+GF_HD lz lz_mul_u(const lz &x, const lzw &W, const lzk &K) {
     int64_t c[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) {
@@ -114,13 +131,13 @@ GF_HD lz lz_mul_u(const lz &x, const lzw &W) {
         for (int i = 1; i < 5; i++) s += (int64_t)x.l[i] * W.w[i][j];
         c[j] = s;
     }
-    return lz_fold_columns(c);
+    return lz_fold_columns(c, K);
 }
 
 // x * w, the multiplier an ordinary NN element (per-lane twiddles read from a table): nine columns, the four high ones
 // (weight 2^130 * B^k) are brought down first.  A 64-bit column is split as c = h * 2^32 + l (h signed, l unsigned: its two registers):
 //     c * 2^130 == 2304*B*c - 4*c,   2304*c = 2304*l + 147456*B*h,   4*c = 4*l + 256*B*h        (2^32 = 64*B)
-GF_HD lz lz_mul_v(const lz &x, const lz &w) {
+GF_HD lz lz_mul_v(const lz &x, const lz &w, const lzk &K) {
     int64_t c[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) {
@@ -138,12 +155,12 @@ GF_HD lz lz_mul_v(const lz &x, const lz &w) {
         const uint32_t lo = (uint32_t)c[k];
         // -4*lo as an unsigned product: 4 * ~lo = 4 * (2^32 - 1) - 4 * lo; the constant is taken back right away (the compiler
         // folds the four of them into the first addend of columns 0..3)
-        c[k - 3] += (int64_t)h * LZ_K(147456);
-        c[k - 4] += (int64_t)((uint64_t)lo * (uint32_t)LZ_K(2304));
-        c[k - 4] += (int64_t)h * LZ_K(-256);
-        c[k - 5] += (int64_t)((uint64_t)(~lo) * (uint32_t)LZ_K(4)) - (((int64_t)1 << 34) - 4);
+        c[k - 3] = lz_mad_ik(h, 147456, c[k - 3]);
+        c[k - 4] = lz_mad_uk(lo, 2304u, c[k - 4]);
+        c[k - 4] = lz_mad_ik(h, -256, c[k - 4]);
+        c[k - 5] = lz_mad_uk(~lo, 4u, c[k - 5]) - (((int64_t)1 << 34) - 4);
     }
-    return lz_fold_columns(c);
+    return lz_fold_columns(c, K);
 }
 
 // carry propagation without a product (elements that skip a twiddle): any limbs |l_i| < 2^31 - 2^6 -> NN
@@ -168,46 +185,56 @@ GF_HD lz lz_norm(const lz &x) {
     return y;
 }
 
-// any lazy value (|l_i| <= 2^30 + 2^22, |l4| <= 2^28 + 2^12) -> the canonical 16-byte element.
-// A multiple of p is added first so that the value is positive, carries are propagated exactly, the part above 2^128 is folded
-// with 2^128 == C = 9*2^32 - 1 in saturated 128-bit arithmetic (one more conditional +C if that overflows, then the final
-// conditional -p): the quotient estimate can be off by one, so the last two steps cannot be skipped.
-GF_HD fe lz_pack(const lz &x) {
+// any lazy value (|l_i| <= 2^30 + 2^22, |l4| <= 2^28 + 2^12) -> a 16-byte element: the canonical residue (CANONICAL = true, what
+// leaves the library) or any representative below 2^128 (false: intermediate passes, read back by lz_unpack).
+// Almost everything happens in the limb domain with plain 32-bit operations: a multiple of p makes the value positive, carries are
+// propagated exactly, the part above 2^128 comes back as t * (576*B - 1) and the carries are propagated once more.  What is left for
+// saturated 128-bit arithmetic is the one-in-2^86 case that this sum reaches 2^128 again (one conditional +C, cannot repeat: the
+// wrapped value is tiny) and, for the canonical form, the final conditional -p.
+template <bool CANONICAL>
+GF_HD fe lz_pack_t(const lz &x) {
     // 32*p in radix 2^26 = 2^133 - 576*32*B + 32: limbs {32, -18432, 0, 0, 2^29} (value-equal; the limbs need not be normalised)
     int32_t v = x.l[0] + 32;
     int32_t k = v >> LZ_B;
-    const uint32_t l0 = (uint32_t)(v & LZ_M);
+    int32_t l0 = v & LZ_M;
     v = x.l[1] - 18432 + k;
     k = v >> LZ_B;
-    const uint32_t l1 = (uint32_t)(v & LZ_M);
+    int32_t l1 = v & LZ_M;
     v = x.l[2] + k;
     k = v >> LZ_B;
-    const uint32_t l2 = (uint32_t)(v & LZ_M);
+    int32_t l2 = v & LZ_M;
     v = x.l[3] + k;
     k = v >> LZ_B;
-    const uint32_t l3 = (uint32_t)(v & LZ_M);
-    const uint32_t l4 = (uint32_t)(x.l[4] + (1 << 29) + k);   // >= 0: the whole value is positive; < 2^30 + 2^28
-    const uint32_t t = l4 >> 24;                               // quotient by 2^128, < 2^7
+    int32_t l3 = v & LZ_M;
+    int32_t l4 = x.l[4] + (1 << 29) + k;      // >= 0: the whole value is positive; < 2^30 + 2^28
+    const int32_t t = l4 >> 24;                 // quotient by 2^128, < 2^7
+    l4 &= 0xffffff;
+    // + t * (2^128 mod p) = t * (576*B - 1), then exact carries again (l0 may have gone slightly negative)
+    v = l0 - t;
+    k = v >> LZ_B;
+    const uint32_t m0 = (uint32_t)(v & LZ_M);
+    v = l1 + 576 * t + k;
+    k = v >> LZ_B;
+    const uint32_t m1 = (uint32_t)(v & LZ_M);
+    v = l2 + k;
+    k = v >> LZ_B;
+    const uint32_t m2 = (uint32_t)(v & LZ_M);
+    v = l3 + k;
+    k = v >> LZ_B;
+    const uint32_t m3 = (uint32_t)(v & LZ_M);
+    const uint32_t m4 = (uint32_t)(l4 + k);     // <= 2^24: bit 24 set means the sum reached 2^128 (then everything below is tiny)
     fe r;
-    r.w0 = l0 | (l1 << 26);
-    r.w1 = (l1 >> 6) | (l2 << 20);
-    r.w2 = (l2 >> 12) | (l3 << 14);
-    r.w3 = (l3 >> 18) | ((l4 & 0xffffff) << 8);
-    // r + t*C = r - t + 9t * 2^32
-    uint32_t b, c;
-    r.w0 = gf_subc(r.w0, t, 0u, b);
-    r.w1 = gf_subc(r.w1, 0u, b, b);
-    r.w2 = gf_subc(r.w2, 0u, b, b);
-    r.w3 = gf_subc(r.w3, 0u, b, b);        // b set: r < t, only when r is tiny — the addition below then carries out and cancels it
-    r.w1 = gf_addc(r.w1, 9u * t, 0u, c);
-    r.w2 = gf_addc(r.w2, 0u, c, c);
-    r.w3 = gf_addc(r.w3, 0u, c, c);
-    // net overflow past 2^128 (c without b): fold it once more, +C; cannot overflow again (the wrapped value is < 2^43)
-    const uint32_t m = 0u - (c & ~b);
-    r.w0 = gf_addc(r.w0, m, 0u, c);
+    r.w0 = m0 | (m1 << 26);
+    r.w1 = (m1 >> 6) | (m2 << 20);
+    r.w2 = (m2 >> 12) | (m3 << 14);
+    r.w3 = (m3 >> 18) | (m4 << 8);              // bit 24 of m4 falls off the top: r = value mod 2^128
+    const uint32_t m = 0u - (m4 >> 24);
+    uint32_t c;
+    r.w0 = gf_addc(r.w0, m, 0u, c);             // + C = 9*2^32 - 1 when it did
     r.w1 = gf_addc(r.w1, m & 8u, c, c);
     r.w2 = gf_addc(r.w2, 0u, c, c);
     r.w3 = gf_addc(r.w3, 0u, c, c);
+    if (!CANONICAL) return r;
     // canonical: subtract p when r >= p, i.e. when r + C overflows
     fe s;
     s.w0 = gf_addc(r.w0, 0xFFFFFFFFu, 0u, c);
@@ -221,17 +248,19 @@ GF_HD fe lz_pack(const lz &x) {
     o.w3 = c ? s.w3 : r.w3;
     return o;
 }
+GF_HD fe lz_pack(const lz &x) { return lz_pack_t<true>(x); }
+GF_HD fe lz_pack_weak(const lz &x) { return lz_pack_t<false>(x); }
 
 // multiply an NN value by B modulo p (one limb up; the limb that falls off the top comes back as 2304*B - 4): the building
 // block of the W-form.  Input NN, output NN.
-GF_HD lz lz_shift_limb(const lz &x) {
+GF_HD lz lz_shift_limb(const lz &x, const lzk &K) {
     int64_t c[5];
-    c[0] = (int64_t)x.l[4] * LZ_K(-4);
-    c[1] = (int64_t)x.l[4] * LZ_K(2304) + x.l[0];
+    c[0] = lz_mad_ik(x.l[4], -4, 0);
+    c[1] = lz_mad_ik(x.l[4], 2304, (int64_t)x.l[0]);
     c[2] = x.l[1];
     c[3] = x.l[2];
     c[4] = x.l[3];
-    return lz_fold_columns(c);
+    return lz_fold_columns(c, K);
 }
 
 // W-form of a canonical element (host: plan tables; device: per-lane running products)

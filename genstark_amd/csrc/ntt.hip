@@ -112,6 +112,7 @@ struct LzPassArgs {
     int logn, logNs, logWj, log_lo;
     int scale;      // multiply every output by ninv (inverse transform, passes without an exchange stage)
     int exq0;       // the exchange table carries a common factor (1/n): output qa = 0 takes wR[0] as well
+    int weak;       // not the last pass: store any representative below 2^128 (lz_pack_weak), the next pass unpacks it
     const fe *tw_lo, *tw_hi, *twp;
     const lz8 *wR;
     const lzw *wtab;   // W-forms: [0..6] omega_16^1..7, [7] 1/n.  Read with scalar loads right before each use (see LZ_FENCE)
@@ -128,10 +129,14 @@ __device__ __forceinline__ lzw lz_load_w(const lzw *p) {
     lzw W;
 #if defined(__HIP_DEVICE_COMPILE__)
     const __attribute__((address_space(4))) int32_t *q = (const __attribute__((address_space(4))) int32_t *)(const int32_t *)p;
+    // 8 + 8 + 8 + 1 words: narrower scalar loads than the dwordx16 the compiler would merge these into leave the SGPR allocator
+    // room (a dwordx16 destination needs 16 consecutive, aligned registers; two multipliers are live at a time)
 #pragma unroll
-    for (int i = 0; i < 5; i++)
+    for (int g = 0; g < 25; g += 8) {
 #pragma unroll
-        for (int j = 0; j < 5; j++) W.w[i][j] = q[i * 5 + j];
+        for (int e = g; e < g + 8 && e < 25; e++) W.w[e / 5][e % 5] = q[e];
+        asm volatile("" ::: "memory");
+    }
 #else
     W = *p;
 #endif
@@ -146,34 +151,50 @@ __device__ __forceinline__ lz lz_load8(const lz8 *__restrict__ p) {
     return r;
 }
 
-__device__ __forceinline__ lz lz_pow_lookup(const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn, uint64_t e) {
+__device__ __forceinline__ lz lz_pow_lookup(const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn, uint64_t e, const lzk &K) {
     lz x = lz_unpack(tw_lo[e & ((1ull << log_lo) - 1)]);
-    if (logn > log_lo) x = lz_mul_v(x, lz_unpack(tw_hi[e >> log_lo]));  // wave-uniform
+    if (logn > log_lo) x = lz_mul_v(x, lz_unpack(tw_hi[e >> log_lo]), K);  // wave-uniform
     return x;
 }
 
 // decimation in frequency on N = 2^LOGN lazy registers, w[i - 1] = W-form of omega_16^i; result bit-reversed.
 // Inputs NN; a product is only ever applied to a difference (at most 2^3 NN values apart); outputs are sums of up to N NN values.
 template <int LOGN, int S>
-__device__ __forceinline__ void ntt_dif_lz_level(lz (&x)[1 << LOGN], lzw_cptr w) {
+__device__ __forceinline__ void ntt_dif_lz_level(lz (&x)[1 << LOGN], lzw_cptr w, const lzk &K) {
     constexpr int N = 1 << LOGN;
+    constexpr int unit = (N / 2 / S) * (16 / N);   // butterfly i of a block takes omega_16^(i * unit)
+    // the butterflies of this level: sums in place, differences where the products will find them
 #pragma unroll
     for (int b = 0; b < N; b += 2 * S) {
 #pragma unroll
         for (int i = 0; i < S; i++) {
             const lz u = x[b + i], v = x[b + i + S];
             x[b + i] = lz_add(u, v);
-            const lz d = lz_sub(u, v);
-            constexpr int unit = (N / 2 / S) * (16 / N);
-            const int tw = i * unit;
-            if (tw) { LZ_FENCE(); const lzw W = lz_load_w(w + (tw - 1)); x[b + i + S] = lz_mul_u(d, W); } else x[b + i + S] = d;
+            x[b + i + S] = lz_sub(u, v);
         }
     }
-    if constexpr (S > 1) ntt_dif_lz_level<LOGN, S / 2>(x, w);   // one level per instantiation: a single loop over the levels is too big to unroll
+    // the products, software-pipelined on the scalar side: the 25 words of the NEXT multiplier are requested before the
+    // current product starts, and nothing moves across the end of a product — two multipliers (50 SGPRs) are live, never seven
+    if constexpr (S > 1) {
+        lzw Wn = lz_load_w(w + (unit - 1));
+#pragma unroll
+        for (int p = 1; p < N / 2; p++) {
+            const int i = p % S;
+            if (i == 0) continue;
+            const int b = (p / S) * 2 * S;
+            const lzw W = Wn;
+            int pn = p + 1;
+            if (pn % S == 0) pn++;
+            if (pn < N / 2) Wn = lz_load_w(w + ((pn % S) * unit - 1));
+            x[b + i + S] = lz_mul_u(x[b + i + S], W, K);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ntt_dif_lz_level<LOGN, S / 2>(x, w, K);   // one level per instantiation: a single loop over the levels is too big to unroll
+    }
 }
 template <int LOGN>
-__device__ __forceinline__ void ntt_dif_lz(lz (&x)[1 << LOGN], lzw_cptr w) {
-    if constexpr (LOGN > 0) ntt_dif_lz_level<LOGN, (1 << LOGN) / 2>(x, w);
+__device__ __forceinline__ void ntt_dif_lz(lz (&x)[1 << LOGN], lzw_cptr w, const lzk &K) {
+    if constexpr (LOGN > 0) ntt_dif_lz_level<LOGN, (1 << LOGN) / 2>(x, w, K);
 }
 
 // word index of element e in one limb plane of the exchange buffer (see the header comment)
@@ -191,6 +212,7 @@ __global__ __launch_bounds__(128, 2) void k_ntt_pass_lz(const fe *__restrict__ i
     int32_t *lds = reinterpret_cast<int32_t *>(lds_raw);      // five planes of R*Wj words
     fe *ldsf = reinterpret_cast<fe *>(lds_raw);               // first pass: the output transpose, Wj rows of R + 1 elements
 
+    const lzk K = lzk_make();
     const int t = threadIdx.x;
     const int Wj = 1 << a.logWj;
     const int plane = R << a.logWj;
@@ -231,13 +253,13 @@ __global__ __launch_bounds__(128, 2) void k_ntt_pass_lz(const fe *__restrict__ i
 #pragma unroll
             for (int m = 0; m < 16; m++) {
                 if ((m & 3) == 0) { LZ_FENCE(); __builtin_amdgcn_sched_barrier(0); }   // four twiddle loads and four products at a time: the 16 data loads above already hold 64 VGPRs
-                v[m] = lz_mul_v(lz_unpack(raw[m]), lz_unpack(a.twp[((uint64_t)(kk + RB * m) << a.logNs) + jq]));
+                v[m] = lz_mul_v(lz_unpack(raw[m]), lz_unpack(a.twp[((uint64_t)(kk + RB * m) << a.logNs) + jq]), K);
             }
         } else if constexpr (TW == 2) {
             // v[m] *= omega_{Ns*R}^(jq * (kk + RB*m)): start value + running product; the step is put in W-form once
             const uint64_t eu = a.n >> (a.logNs + 4 + LB);
-            lz cur = lz_pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * kk * eu);
-            lz row = lz_pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * RB * eu);
+            lz cur = lz_pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * kk * eu, K);
+            lz row = lz_pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * RB * eu, K);
             lzw step;
 #pragma unroll
             for (int r = 0; r < 5; r++) {
@@ -248,18 +270,18 @@ __global__ __launch_bounds__(128, 2) void k_ntt_pass_lz(const fe *__restrict__ i
                     // (tools/lazy_device_check.hip test 3 catches it); table multipliers come from memory and are opaque anyway
                     asm volatile("" : "+v"(step.w[r][c]));
                 }
-                if (r < 4) row = lz_shift_limb(row);
+                if (r < 4) row = lz_shift_limb(row, K);
             }
 #pragma unroll
             for (int m = 0; m < 16; m++) {
-                v[m] = lz_mul_v(lz_unpack(raw[m]), cur);
-                if (m < 15) cur = lz_mul_u(cur, step);
+                v[m] = lz_mul_v(lz_unpack(raw[m]), cur, K);
+                if (m < 15) cur = lz_mul_u(cur, step, K);
             }
         } else {
 #pragma unroll
             for (int m = 0; m < 16; m++) v[m] = lz_unpack(raw[m]);
         }
-        ntt_dif_lz<4>(v, (lzw_cptr)a.wtab);  // A[qa] = v[brev(qa,4)], sums of up to 16 NN values
+        ntt_dif_lz<4>(v, (lzw_cptr)a.wtab, K);  // A[qa] = v[brev(qa,4)], sums of up to 16 NN values
     }
 
     const uint64_t Ns = 1ull << a.logNs;
@@ -271,8 +293,8 @@ __global__ __launch_bounds__(128, 2) void k_ntt_pass_lz(const fe *__restrict__ i
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             lz x = v[brev(q, 4)];
-            if (a.scale) { LZ_FENCE(); const lzw W = lz_load_w(a.wtab + 7); x = lz_mul_u(lz_norm(x), W); }
-            const fe y = lz_pack(x);
+            if (a.scale) { LZ_FENCE(); const lzw W = lz_load_w(a.wtab + 7); x = lz_mul_u(lz_norm(x), W, K); }
+            const fe y = a.weak ? lz_pack_weak(x) : lz_pack(x);
             if (first) ldsf[jj * (R + 1) + q] = y;
             else dst[jbase + (uint64_t)q * Ns] = y;
         }
@@ -283,9 +305,12 @@ __global__ __launch_bounds__(128, 2) void k_ntt_pass_lz(const fe *__restrict__ i
 #pragma unroll
         for (int qa = 0; qa < 16; qa++) {
             if ((qa & 3) == 0) LZ_FENCE();   // same for the exchange twiddles
-            lz x = lz_norm(v[brev(qa, 4)]);
-            if (qa != 0) x = lz_mul_v(x, lz_load8(a.wR + ((kk * qa) & (R - 1))));
-            else if (a.exq0) x = lz_mul_v(x, lz_load8(a.wR));
+            // outputs 0 and 8 of the network are sums of all 16 inputs: too large for the product (and output 0 may skip it);
+            // the other fourteen are at most 9 NN values apart, which the signed-digit table entries absorb
+            lz x = v[brev(qa, 4)];
+            if (qa == 0 || qa == 8) x = lz_norm(x);
+            if (qa != 0) x = lz_mul_v(x, lz_load8(a.wR + ((kk * qa) & (R - 1))), K);
+            else if (a.exq0) x = lz_mul_v(x, lz_load8(a.wR), K);
             const int slot = lz_slot((qa * RB + kk) * Wj + jj, a.logWj);
 #pragma unroll
             for (int l = 0; l < 5; l++) lds[l * plane + slot] = x.l[l];
@@ -307,10 +332,10 @@ __global__ __launch_bounds__(128, 2) void k_ntt_pass_lz(const fe *__restrict__ i
 #pragma unroll
         for (int u = 0; u < GB; u++) {
             const int qa = kk * GB + u;
-            ntt_dif_lz<LB>(xb[u], (lzw_cptr)a.wtab);
+            ntt_dif_lz<LB>(xb[u], (lzw_cptr)a.wtab, K);
 #pragma unroll
             for (int qb = 0; qb < RB; qb++) {
-                const fe y = lz_pack(xb[u][brev(qb, LB)]);
+                const fe y = a.weak ? lz_pack_weak(xb[u][brev(qb, LB)]) : lz_pack(xb[u][brev(qb, LB)]);
                 const int q = qa + 16 * qb;
                 if (first) ldsf[jj * (R + 1) + q] = y;
                 else dst[jbase + (uint64_t)q * Ns] = y;
@@ -334,7 +359,11 @@ __global__ void k_build_lz_table(const fe *__restrict__ src, lz8 *__restrict__ d
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
         fe x = src[i];
         if (use_mult) x = fe_mul(x, mult);
-        const lz u = lz_unpack(x);
+        lz u = lz_unpack(x);
+        // signed digits, |limb| <= 2^25: the exchange stage multiplies sums of up to 9 NN values by these entries without
+        // normalising them first (lz_mul_v needs |column| < 2^57: 2^25 * 9 * 2^28.1 is below that, 2^26 * ... is not)
+        for (int l = 0; l < 4; l++)
+            if (u.l[l] >= (1 << 25)) { u.l[l] -= 1 << 26; u.l[l + 1] += 1; }
         lz8 o;
         for (int l = 0; l < 5; l++) o.l[l] = u.l[l];
         o.l[5] = o.l[6] = o.l[7] = 0;
@@ -717,6 +746,7 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
             a.wR = p->wRz[i];
             a.scale = 0;
             a.exq0 = 0;
+            a.weak = last ? 0 : 1;
             if (inverse && last) {
                 if (LB > 0) {   // the 1/n scale rides on the exchange twiddles of the last pass
                     if (!p->wRz_scaled) {

@@ -109,6 +109,13 @@ def test_pack_is_canonical_for_every_lazy_value(lib, terms):
     lib.z_pack(limbs_buf(rows), back, n)
     got = [int.from_bytes(back.raw[16 * i:16 * i + 16], 'little') for i in range(n)]
     assert got == [value(r) % P for r in rows]
+    # the weak form (intermediate passes): any representative below 2^128; unpacking it gives exactly normalised limbs again
+    lib.z_pack_weak(limbs_buf(rows), back, n)
+    weak = [int.from_bytes(back.raw[16 * i:16 * i + 16], 'little') for i in range(n)]
+    assert [w % P for w in weak] == got
+    o = out_limbs(n)
+    lib.z_unpack(back.raw, o, n)
+    assert all(value(r) == w and is_nn(r) for r, w in zip(rows_of(o, n), weak))
 
 
 @pytest.mark.parametrize('terms', [1, 4, 16])
@@ -142,6 +149,34 @@ def test_products(lib, terms):
     lib.z_mul_u_rows(limbs_buf(xs), limbs_buf(wl), o, n)
     for x, w, y in zip(xs, wl, rows_of(o, n)):
         assert value(y) % P == value(x) * value(w) % P and is_nn(y), ('mul_u_rows', x, w, y)
+
+
+def test_product_of_unnormalised_sums_by_signed_digit_multiplier(lib):
+    """the exchange stage of the pass kernel: network outputs (sums of up to 9 NN values) times table entries recoded to signed
+    digits |limb| <= 2^25 (k_build_lz_table), no normalisation in between"""
+    rng = random.Random(77)
+    n = 6000
+    xs = [lazy_combo(rng, 9, extreme=(i % 2 == 0)) for i in range(n)]
+    ws = []
+    for i in range(n):
+        w = rng.randrange(P) if i % 5 else rng.choice([P - 1, (1 << 128) - (1 << 103), sum(((1 << 25) - 1) << (26 * k) for k in range(5)) % P,
+                                                         sum((1 << 25) << (26 * k) for k in range(4))])
+        l = [w % B, (w >> 26) % B, (w >> 52) % B, (w >> 78) % B, w >> 104]
+        for k in range(4):
+            if l[k] >= 1 << 25:
+                l[k] -= 1 << 26
+                l[k + 1] += 1
+        assert value(l) == w and all(abs(t) <= 1 << 25 for t in l)
+        ws.append(l)
+    o = out_limbs(n)
+    lib.z_mul_v(limbs_buf(xs), limbs_buf(ws), o, n)
+    for x, w, y in zip(xs, ws, rows_of(o, n)):
+        assert value(y) % P == value(x) * value(w) % P and is_nn(y), (x, w, y)
+    # interval check of the columns for this class of inputs
+    nn_hi = [B + (1 << 8), B + (1 << 17), B, B, 1 << 24]
+    x9 = [9 * h for h in nn_hi]
+    cols = [sum(x9[i] * (1 << 25) for i in range(5) if 0 <= k - i < 5) for k in range(9)]
+    assert max(cols) + 2 * (2304 * (1 << 31) + 147456 * (1 << 25) + (1 << 40)) < (1 << 57) - (1 << 44)
 
 
 def test_shift_limb(lib):

@@ -23,15 +23,16 @@ __global__ void k_check(const fe *__restrict__ a, const fe *__restrict__ b, cons
     if (i >= n) return;
     const fe x = a[i], y = b[i];
     const lz lx = lz_unpack(x), ly = lz_unpack(y);
+    const lzk K = lzk_make();
     unsigned bad = 0, bit = 1;
 #define CHK(cond) do { if (!(cond)) bad |= bit; bit <<= 1; } while (0)
     // 1. per-lane product
-    CHK(fe_eq(lz_pack(lz_mul_v(lx, ly)), fe_mul(x, y)));
+    CHK(fe_eq(lz_pack(lz_mul_v(lx, ly, K)), fe_mul(x, y)));
     // 2. tabulated multiplier (scalar loads)
     const int t = (int)(blockIdx.x % nw);
     asm volatile("" ::: "memory");
     const lzw W = load_w(wtab + t);
-    CHK(fe_eq(lz_pack(lz_mul_u(lx, W)), fe_mul(x, wcan[t])));
+    CHK(fe_eq(lz_pack(lz_mul_u(lx, W, K)), fe_mul(x, wcan[t])));
     // 3. W-form built in registers from a per-lane value, running product of 5 steps
     lzw S;
     lz row = ly;
@@ -39,12 +40,12 @@ __global__ void k_check(const fe *__restrict__ a, const fe *__restrict__ b, cons
     for (int r = 0; r < 5; r++) {
 #pragma unroll
         for (int c = 0; c < 5; c++) { S.w[r][c] = row.l[c]; asm volatile("" : "+v"(S.w[r][c])); }   // as ntt.hip does (see there)
-        if (r < 4) row = lz_shift_limb(row);
+        if (r < 4) row = lz_shift_limb(row, K);
     }
     lz cur = lx;
     fe ref = x;
 #pragma unroll
-    for (int s = 0; s < 5; s++) { cur = lz_mul_u(cur, S); ref = fe_mul(ref, y); }
+    for (int s = 0; s < 5; s++) { cur = lz_mul_u(cur, S, K); ref = fe_mul(ref, y); }
     CHK(fe_eq(lz_pack(cur), ref));
     // 4. a small butterfly network: sums and differences of 16 values, then norm + product + pack
     lz acc = lx; fe racc = x;
@@ -54,9 +55,9 @@ __global__ void k_check(const fe *__restrict__ a, const fe *__restrict__ b, cons
 #pragma unroll
     for (int s = 0; s < 3; s++) { dif = lz_sub(dif, (s & 1) ? lx : ly); rdif = fe_sub(rdif, (s & 1) ? x : y); }
     CHK(fe_eq(lz_pack(acc), racc));
-    CHK(fe_eq(lz_pack(lz_mul_v(lz_norm(acc), ly)), fe_mul(racc, y)));
-    CHK(fe_eq(lz_pack(lz_mul_v(dif, ly)), fe_mul(rdif, y)));
-    CHK(fe_eq(lz_pack(lz_mul_u(dif, W)), fe_mul(rdif, wcan[t])));
+    CHK(fe_eq(lz_pack(lz_mul_v(lz_norm(acc), ly, K)), fe_mul(racc, y)));
+    CHK(fe_eq(lz_pack(lz_mul_v(dif, ly, K)), fe_mul(rdif, y)));
+    CHK(fe_eq(lz_pack(lz_mul_u(dif, W, K)), fe_mul(rdif, wcan[t])));
     if (bad) atomicAdd(err, 1u);
     for (int k = 0; k < 7; k++) if (bad & (1u << k)) atomicAdd(err + 1 + k, 1u);
 }

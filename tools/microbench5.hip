@@ -1,0 +1,122 @@
+// tools/microbench5.hip — the arithmetic cores of k_ntt_pass_lz in isolation (registers only, no memory traffic): how far is the
+// pass kernel from what its own instruction stream can do at 1, 2, 3, 4 waves per SIMD?
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -pragma-unroll-threshold=1000000 tools/microbench5.hip -o tools/microbench5
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include "../genstark_amd/csrc/gf128_lazy.h"
+
+__device__ __forceinline__ lzw load_w(const lzw *p) {
+    lzw W;
+    const __attribute__((address_space(4))) int32_t *q = (const __attribute__((address_space(4))) int32_t *)(const int32_t *)p;
+#pragma unroll
+    for (int g = 0; g < 25; g += 8) {
+#pragma unroll
+        for (int e = g; e < g + 8 && e < 25; e++) W.w[e / 5][e % 5] = q[e];
+        asm volatile("" ::: "memory");
+    }
+    return W;
+}
+template <int S>
+__device__ __forceinline__ void dif_level(lz (&x)[16], const lzw *w, const lzk &K) {
+    constexpr int unit = 8 / S;
+#pragma unroll
+    for (int b = 0; b < 16; b += 2 * S)
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            const lz u = x[b + i], v = x[b + i + S];
+            x[b + i] = lz_add(u, v);
+            const lz d = lz_sub(u, v);
+            const int tw = i * unit;
+            if (tw) { asm volatile("" ::: "memory"); const lzw W = load_w(w + tw - 1); x[b + i + S] = lz_mul_u(d, W, K); } else x[b + i + S] = d;
+        }
+    if constexpr (S > 1) dif_level<S / 2>(x, w, K);
+}
+#define ITERS 40
+// (a) radix-16 DIF with tabulated multipliers, renormalised every round
+__global__ __launch_bounds__(128) void k_dif(const fe *in, fe *out, const lzw *w) {
+    const lzk K = lzk_make();
+    lz v[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) v[m] = lz_unpack(in[threadIdx.x + 128 * m]);
+    for (int it = 0; it < ITERS; it++) {
+        dif_level<8>(v, w, K);
+#pragma unroll
+        for (int m = 0; m < 16; m++) v[m] = lz_norm(v[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) out[blockIdx.x * 2048 + threadIdx.x + 128 * m] = lz_pack(v[m]);
+}
+// (b) 16 per-lane products per round
+__global__ __launch_bounds__(128) void k_mulv(const fe *in, fe *out, const lzw *w) {
+    const lzk K = lzk_make();
+    lz v[16], t[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) { v[m] = lz_unpack(in[threadIdx.x + 128 * m]); t[m] = lz_unpack(in[threadIdx.x + 128 * m + 64]); }
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) v[m] = lz_mul_v(v[m], t[m], K);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) out[blockIdx.x * 2048 + threadIdx.x + 128 * m] = lz_pack(v[m]);
+}
+// (c) 16 packs + unpacks per round
+__global__ __launch_bounds__(128) void k_pack(const fe *in, fe *out, const lzw *w) {
+    lz v[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) v[m] = lz_unpack(in[threadIdx.x + 128 * m]);
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) { v[m] = lz_add(v[m], v[(m + 1) & 15]); v[m] = lz_unpack(lz_pack(v[m])); }
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) out[blockIdx.x * 2048 + threadIdx.x + 128 * m] = lz_pack(v[m]);
+}
+// (d) canonical-limb products (the arithmetic of k_ntt_pass) for reference
+__global__ __launch_bounds__(128) void k_femul(const fe *in, fe *out, const lzw *w) {
+    fe v[16], t[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) { v[m] = in[threadIdx.x + 128 * m]; t[m] = in[threadIdx.x + 128 * m + 64]; }
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) v[m] = fe_mul(v[m], t[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) out[blockIdx.x * 2048 + threadIdx.x + 128 * m] = v[m];
+}
+
+typedef void (*kern_t)(const fe *, fe *, const lzw *);
+int main() {
+    hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    fe *in, *out; lzw *w;
+    const int blocks = cus * 16;
+    hipMalloc(&in, 4096 * 16); hipMalloc(&out, (size_t)blocks * 2048 * 16); hipMalloc(&w, 8 * sizeof(lzw));
+    hipMemset(in, 0x5a, 4096 * 16); hipMemset(w, 0x01, 8 * sizeof(lzw));
+    struct { const char *name; kern_t k; double units; const char *unit; } es[] = {
+        {"radix-16 DIF (17 mul_u + 64 add/sub) + 16 norm", k_dif, 1, "per network"},
+        {"lz_mul_v", k_mulv, 16, "per product"},
+        {"lz_pack + lz_unpack + add", k_pack, 16, "per element"},
+        {"fe_mul (canonical limbs)", k_femul, 16, "per product"},
+    };
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    printf("%-50s %10s %10s %10s %10s   ns per wave per SIMD (wall clock; k waves per SIMD forced by LDS size, 128-thread blocks)\n", "core", "1 w/SIMD", "2 w/SIMD", "3 w/SIMD", "4 w/SIMD");
+    for (auto &e : es) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(e.k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        printf("%-50s", e.name);
+        for (int wps : {1, 2, 3, 4}) {
+            const size_t lds = (size_t)(160 * 1024) / (2 * wps);   // 2-wave blocks: 2*wps blocks per CU
+            hipLaunchKernelGGL(e.k, dim3(blocks), dim3(128), lds, 0, in, out, w);
+            hipDeviceSynchronize();
+            float best = 1e30f;
+            for (int r = 0; r < 3; r++) {
+                hipEventRecord(e0); hipLaunchKernelGGL(e.k, dim3(blocks), dim3(128), lds, 0, in, out, w); hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+            }
+            // waves per SIMD in total = blocks * 2 / (cus * 4)
+            const double waves_per_simd = (double)blocks * 2 / (cus * 4);
+            printf(" %10.1f", best * 1e6 / (waves_per_simd * ITERS * e.units));
+        }
+        printf("  %s\n", e.unit);
+    }
+    return 0;
+}
