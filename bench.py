@@ -13,10 +13,16 @@ step; independent proofs do.  Rank r proves its own trace (seed 3 + r) on its ow
 data-path collective (RCCL is used only for the barrier and the max-over-ranks reduction of the timing).
 
 `value` = NTT points transformed per second at whole-prove() level, aggregated over ranks:
-          (points of every forward/inverse NTT inside one prove()) * K * N / max-over-ranks wall time.
-`roofline` describes the dominant kernel (one radix-256 NTT pass, k_ntt_pass<4>), timed live with events on the
-stream the kernels run on.  `cpu_baseline` is the same host logic on the CPU oracle backend (C, 1 thread) on a
-bounded sample (smaller trace), in the same unit.
+          (points of the transforms the timed driver LAUNCHED, from its own counters: gs_prover_last_stats) * K * N
+          / max-over-ranks wall time.  For MiMC-128 that is the trace iNTT (T points) and the low-degree extension (N points)
+          plus two small transforms of the round-constant register: the composition polynomial is evaluated directly on the
+          evaluation domain (gs_mimc_composition), no transform is credited that did not run.
+`prove_ms` (= ms_per_step) is the other half of BASELINE.json's metric; `phases_ms` comes from the driver's own clock.
+`roofline` describes the dominant kernel (one radix-256 NTT pass, k_ntt_pass_lz<4, *>), timed live with events on the
+stream the kernels run on; `roofline.second_roof` is the VALU-issue roof measured in the same run (tools/microbench5: the
+kernel's own product routines on registers only); `roofline.traffic` is read from the PMC counters by a rocprofv3 child
+process of this run (tools/pmc_traffic.py).  `cpu_baseline` is the same prove() on the CPU oracle's implementation of the
+C ABI: single-threaded and on every host core (OpenMP build of the same source), on bounded samples.
 """
 import argparse
 import json
@@ -30,12 +36,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
-def ntt_points_per_prove(steps, ef):
-    """Points of the radix-2 transforms one MiMC prove() runs: iNTT(T) of the trace, LDE NTT(N),
-    NTT(4T) of P on the composition domain, iNTT(4T) + NTT(N) of the combined constraint polynomial.
-    (The two boundary-polynomial evaluations over N are Horner evaluations of <= 3 coefficients: not counted.)"""
-    n, nc = steps * ef, steps * 4
-    return steps + n + nc + nc + n
+def expected_ntt_points(steps, ef):
+    """What the native driver launches as NTT passes for MiMC-128 (counted by the driver itself; this closed form is only the
+    cross-check): iNTT(T) of the trace + LDE NTT(N) + iNTT(64·cf) and NTT(64·E) of the 64-periodic round-constant register."""
+    return steps + steps * ef + 64 * 4 + 64 * ef
 
 
 def make_stark(ga, backend, steps, ef, fri, logger=None):
@@ -49,25 +53,120 @@ def assertions_for(stark, steps, seed):
             {'step': steps - 1, 'register': 0, 'value': trace.getValue(0, steps - 1)}]
 
 
-def cpu_baseline(ga, log_steps, ef, fri):
-    """The same prove() on the CPU oracle's implementation of the C ABI (oracle/oracle_abi.c: plain C, one thread)."""
-    from genstark_amd._abi import Backend
+def cpu_prove(ga, lib, log_steps, ef, exe, fri, threads):
+    """one prove() through the native driver on the CPU oracle's implementation of the C ABI, in a child process pinned to
+    `threads` OpenMP threads; returns (seconds, ntt_points)"""
     import subprocess
-    lib = os.path.join(ROOT, 'oracle', 'liboracle.so')
+    code = (
+        'import sys, time, json; sys.path.insert(0, %r)\n'
+        'import genstark_amd as ga\n'
+        'from genstark_amd._abi import Backend\n'
+        'from genstark_amd.native import NativeProver\n'
+        'be = Backend(lib_path=%r, allow_test_double=True)\n'
+        'steps = 1 << %d\n'
+        'st = ga.instantiateMimc(steps, {"hashAlgorithm": "blake2s256", "extensionFactor": %d, "exeQueryCount": %d, "friQueryCount": %d}, backend=be)\n'
+        'tr = st.generateExecutionTrace([], [3])["dTrace"]\n'
+        'a = [{"step": 0, "register": 0, "value": tr.getValue(0, 0)}, {"step": steps - 1, "register": 0, "value": tr.getValue(0, steps - 1)}]\n'
+        'p = NativeProver(st)\n'
+        't0 = time.perf_counter(); d = p.prove_bytes(a, [], [3]); dt = time.perf_counter() - t0\n'
+        'assert st.verify(a, st.parse(d))\n'
+        'print(json.dumps({"s": dt, "points": p.last_stats()["ntt_points"]}))\n') % (ROOT, lib, log_steps, ef, exe, fri)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND='false', OMP_WAIT_POLICY='passive')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
+    if r.returncode:
+        raise RuntimeError(r.stderr[-400:])
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    return j['s'], j['points']
+
+
+def cpu_baseline(ga, ef, fri):
+    """the CPU path timed on this box's host cores, single-threaded AND on all cores, core count stated, for C2
+    (2^13 steps, E=16, exe 48, fri 24) and for the largest trace that stays within the time budget.  "port": the oracle's plain-C
+    implementation of the same C ABI under the same native driver (oracle/liboracle_omp.so = oracle_abi.c built with -fopenmp)."""
+    import subprocess
+    lib = os.path.join(ROOT, 'oracle', 'liboracle_omp.so')
     if not os.path.exists(lib):
-        subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), '-s'])
-    be = Backend(lib_path=lib, allow_test_double=True)
-    steps = 1 << log_steps
-    stark = make_stark(ga, be, steps, ef, fri)
-    a = assertions_for(stark, steps, 3)
-    t0 = time.perf_counter()
-    proof = stark.prove(a, [], [3])
-    dt = time.perf_counter() - t0
-    assert len(stark.serialize(proof)) == stark.sizeOf(proof)
-    return {'value': ntt_points_per_prove(steps, ef) / dt, 'unit': 'elements/s', 'cores': 1, 'kind': 'port',
-            'sample': f'one prove() of MiMC-128 2^{log_steps} steps, E={ef}, friQueryCount={fri} on the C oracle backend '
-                      f'({dt:.1f} s); NTT points / wall time', 'prove_ms': dt * 1e3,
-            'host_cpus_visible': os.cpu_count()}
+        subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), '-s', 'liboracle_omp.so'])
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    rows = []
+    budget = time.perf_counter() + 50.0
+    # C2 first: one thread, then a sweep of thread counts up to every visible CPU — a container may see more CPUs than its quota
+    # lets it run (the first all-256 attempt on the GPU box was 100x slower than one thread); `cores` = the count that won
+    s_, pts = cpu_prove(ga, lib, 13, 16, 48, 24, 1)
+    rows.append({'config': 'C2: 2^13 steps, E=16, exe 48, fri 24', 'threads': 1, 'prove_ms': round(s_ * 1e3, 1), 'elements_per_s': pts / s_})
+    cores, best_c2 = 1, s_
+    for threads in [t for t in (4, 8, 16, 32, 64, 128) if t < visible] + [visible]:
+        try:
+            s_, pts = cpu_prove(ga, lib, 13, 16, 48, 24, threads)
+        except Exception:   # noqa: BLE001  (timeout: oversubscribed)
+            break
+        rows.append({'config': 'C2: 2^13 steps, E=16, exe 48, fri 24', 'threads': threads, 'prove_ms': round(s_ * 1e3, 1), 'elements_per_s': pts / s_})
+        if s_ < best_c2:
+            cores, best_c2 = threads, s_
+        elif s_ > 3 * best_c2:
+            break
+    # then the headline shape (E, fri of the workload) at growing trace lengths while the budget lasts: all cores, and one thread
+    best = None
+    one = None
+    for log_steps in (14, 16, 18, 20):
+        if best is not None and best['s'] * 4.5 > budget - time.perf_counter():
+            break
+        s_, pts = cpu_prove(ga, lib, log_steps, ef, 48, fri, cores)
+        best = {'log': log_steps, 's': s_, 'points': pts}
+        rows.append({'config': f'2^{log_steps} steps, E={ef}, exe 48, fri {fri}', 'threads': cores, 'prove_ms': round(s_ * 1e3, 1), 'elements_per_s': pts / s_})
+    for log_steps in (14, 16):
+        if one is not None and one['s'] * 4.5 > budget + 15.0 - time.perf_counter():
+            break
+        s_, pts = cpu_prove(ga, lib, log_steps, ef, 48, fri, 1)
+        one = {'log': log_steps, 's': s_, 'points': pts}
+        rows.append({'config': f'2^{log_steps} steps, E={ef}, exe 48, fri {fri}', 'threads': 1, 'prove_ms': round(s_ * 1e3, 1), 'elements_per_s': pts / s_})
+    return {'value': best['points'] / best['s'], 'unit': 'elements/s', 'cores': cores, 'kind': 'port',
+            'sample': f'one prove() of MiMC-128 2^{best["log"]} steps, E={ef}, friQueryCount={fri} through the native driver on the CPU oracle '
+                      f'(oracle_abi.c, OpenMP, {cores} threads): {best["s"]:.2f} s; NTT points launched / wall time',
+            'prove_ms': round(best['s'] * 1e3, 1),
+            'single_thread': {'value': one['points'] / one['s'], 'unit': 'elements/s', 'cores': 1, 'prove_ms': round(one['s'] * 1e3, 1),
+                              'sample': f'the same at 2^{one["log"]} steps on one thread'},
+            'all_runs': rows, 'host_cpus_visible': visible,
+            'cores_note': f'{visible} CPUs visible; {cores} threads was the fastest of the sweep on C2 and is what "all cores" uses'}
+
+
+def second_roof(n, transform_ms, npass):
+    """The roof the NTT kernel actually sits under: VALU issue.  tools/microbench5 runs the kernel's own product routines on
+    registers only (no memory traffic) in THIS run; the pass kernel's work in the same currency: per 16 elements a pass does two
+    radix-16 networks, 15 per-lane exchange products and (all passes but the first) 16 per-lane input products, 16 pack+unpack."""
+    import subprocess
+    exe = os.path.join(ROOT, 'tools', 'microbench5')
+    if not os.path.exists(exe):
+        return {'error': 'tools/microbench5 not built'}
+    try:
+        r = subprocess.run([exe, '--json'], capture_output=True, text=True, timeout=120)
+        m = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:   # noqa: BLE001
+        return {'error': repr(e)[:200]}
+    occ = 2                                           # waves per SIMD of k_ntt_pass_lz (LDS: four 128-thread workgroups per CU)
+    dif, mulv, pack = m['dif16_network_ns'][occ - 1], m['mul_v_ns'][occ - 1], m['pack_unpack_add_ns'][occ - 1]
+    per_wave_pass_first = 2 * dif + 15 * mulv + 16 * pack          # ns of pure arithmetic per wave (64 lanes x 16 elements) per pass
+    per_wave_pass_later = per_wave_pass_first + 16 * mulv
+    waves = n / 16 / 64
+    simds = m['cus'] * 4
+    floor_ms = (per_wave_pass_first + (npass - 1) * per_wave_pass_later) * waves / simds * 1e-6
+    return {'bound': 'valu-issue', 'unit': 'ms per transform', 'peak': round(floor_ms, 4), 'achieved': round(transform_ms, 4),
+            'frac': round(floor_ms / transform_ms, 4),
+            'measured_ns_per_wave': {'radix16_network_17_products_64_addsub_16_norm': dif, 'per_lane_product': mulv, 'pack_unpack_add': pack,
+                                     'canonical_limb_fe_mul_for_reference': m['fe_mul_ns'][occ - 1], 'waves_per_simd': occ},
+            'note': 'peak = time the kernel\'s own instruction stream needs with no memory stall at all (registers-only microbenchmark of '
+                    'the same routines at the same occupancy, same run); frac = peak / achieved = share of the kernel time that is '
+                    'arithmetic issue'}
+
+
+def pmc_traffic(logn):
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'pmc_traffic.py'), str(logn)], capture_output=True, text=True, timeout=420)
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        return j.get('hbm_bytes_per_launch'), j
+    except Exception as e:   # noqa: BLE001
+        return None, {'error': repr(e)[:200]}
 
 
 def main():
@@ -78,8 +177,8 @@ def main():
     ap.add_argument('--log-trace', type=int, default=20, help='log2 of the MiMC trace length (BASELINE: 20)')
     ap.add_argument('--extension-factor', type=int, default=16)
     ap.add_argument('--fri-queries', type=int, default=64)
-    ap.add_argument('--cpu-log-trace', type=int, default=16, help='trace length of the bounded CPU-baseline sample')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 child process that measures roofline.traffic')
     ap.add_argument('--sharded-leg-timeout', type=float, default=90.0,
                     help='N > 1 only: seconds allowed for the extra one-proof-across-all-ranks leg (0 = skip it)')
     ap.add_argument('--lanes', type=int, default=8, help='prover lanes of the extra throughput-mode leg (0 = skip it)')
@@ -149,10 +248,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     step_ms = []
+    launched = []
     for _ in range(args.steps):
         ts = time.perf_counter()
         data = prover.prove_bytes(a, [], [seed])
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 3))
+        launched.append(prover.last_stats())
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -160,6 +261,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
+    points = launched[-1]['ntt_points']                  # what the timed driver launched as NTT passes, from its own counters
+    assert all(st['ntt_points'] == points for st in launched)
+    if args.log_trace >= 8:
+        assert points == expected_ntt_points(steps, ef), (points, expected_ntt_points(steps, ef))
     proof = stark.parse(data)
     # the Python mirror on the same statement: same bytes, its own wall-clock (not part of `value`)
     mirror_ms = []
@@ -181,17 +286,15 @@ def main():
 
     out = None
     if rank == 0 and cpu_mode:
-        points = ntt_points_per_prove(steps, ef)
         out = {'metric': 'NTT GF(p) elements/sec over whole prove() (MiMC-128)', 'value': points * world / (ms_per_step * 1e-3),
                'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'data': 'synthetic', 'test_double': True,
                'config': {'workload': f'MiMC-128 prove(), 2^{args.log_trace} steps', 'ntt_points_per_prove': points}}
     elif rank == 0:
-        # ---- per-phase breakdown (labels of README.md:62-73), one extra instrumented prove() outside the timed region
-        logger = ga.Logger(echo=False, sync=backend.sync)
-        s2 = make_stark(ga, backend, steps, ef, fri, logger)
-        s2.prove(a, [], [seed])
-        phases = {label.strip(): round(ms, 3) for label, ms in logger.phases}
+        # ---- per-phase breakdown of the LAST TIMED step, from the native driver's own clock (host wall-clock at its phase
+        # boundaries; it adds no device synchronisation, so a phase lasts until its last blocking call returned)
+        phases = launched[-1]['phases_ms']
+        driver_total_ms = launched[-1]['total_ms']
 
         # ---- roofline of the dominant kernel: one radix-256 NTT pass over n = T*E points
         import ctypes as C
@@ -217,22 +320,19 @@ def main():
         # algorithmic bytes: 32 B per element per transform -> one pass launch does 1/npass of a transform
         alg_bytes_per_launch = 32.0 * n / npass
         achieved = alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'ntt_pass_traffic.json')
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        traffic, traffic_detail = (None, {'skipped': True}) if args.no_pmc else pmc_traffic(logn)
         roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                    'kernel': f'k_ntt_pass<4> (radix-256 Stockham pass), {npass} launches per 2^{logn}-point transform',
+                    'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child processes of this run (tools/pmc_traffic.py)',
+                    'traffic_detail': traffic_detail,
+                    'kernel': f'k_ntt_pass_lz<4, *> (radix-256 Stockham pass, lazy five-limb butterflies), {npass} launches per 2^{logn}-point transform',
                     'launch_ms': round(launch_ms, 4), 'transform_ms': round(transform_ms, 4),
                     'ntt_kernel_elements_per_sec': round(n / (transform_ms * 1e-3), 1),
-                    'valu_issue_utilisation': 0.75,     # SQ counters, profiles/r01_f_ntt_pass_valu_utilisation.md and r01_z_pmc_traffic_fused_kernels.md
-                    'note': 'VALU-issue-bound (about 90 carry/mad instructions of ~4.5 cycles per 128-bit modmul; 75 % of the VALU issue slots busy), not HBM-bound: DESIGN.md section 3'}
+                    'second_roof': second_roof(n, transform_ms, npass)}
         del src, dst
 
-        cpu = None if args.no_cpu_baseline else cpu_baseline(ga, args.cpu_log_trace, ef, fri)
+        cpu = None if args.no_cpu_baseline else cpu_baseline(ga, ef, fri)
 
-        points = ntt_points_per_prove(steps, ef)
         # ---- extra leg (reported beside `value`, never as `value`): throughput of a proving service that keeps several
         # independent proofs in flight on this GPU (genstark_amd/pipeline.py); every proof runs the unmodified prove()
         pipelined = None
@@ -252,14 +352,15 @@ def main():
                          'note': 'independent proofs in flight on one GPU (one library context + HIP stream per lane): a lane\'s '
                                  'host-side trace recurrence overlaps the other lanes\' kernels; latency of one proof is prove_ms'}
         out = {
-            'metric': 'NTT GF(p) elements/sec over whole prove() (MiMC-128)', 'value': points * world / (ms_per_step * 1e-3),
+            'metric': 'prove() ms + NTT GF(p) elements/sec, MiMC-128 2^20 steps: NTT points launched per second of whole prove()', 'value': points * world / (ms_per_step * 1e-3),
             'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u128 (4x u32 limbs, GF(2^128-9*2^32+1))',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u128 (GF(2^128-9*2^32+1): 4x u32 limbs in memory, 5x 26-bit limbs inside the NTT networks)',
             'data': 'synthetic',
             'config': {'workload': f'MiMC-128 prove(), 2^{args.log_trace} steps, extensionFactor {ef}, exeQueryCount 48, '
                                    f'friQueryCount {fri}, blake2s256; one independent proof per GPU',
-                       'evaluation_domain': n, 'ntt_points_per_prove': points, 'proof_bytes': len(data)},
-            'prove_ms': ms_per_step, 'per_step_ms': step_ms, 'python_mirror_prove_ms': mirror_ms, 'phases_ms': phases, 'roofline': roofline, 'cpu_baseline': cpu,
+                       'evaluation_domain': n, 'ntt_points_per_prove': points, 'ntt_transforms_per_prove': launched[-1]['ntt_transforms'],
+                       'ntt_points_source': 'gs_prover_last_stats: rows * n of every transform the timed driver launched', 'proof_bytes': len(data)},
+            'prove_ms': ms_per_step, 'per_step_ms': step_ms, 'python_mirror_prove_ms': mirror_ms, 'phases_ms': phases, 'phases_source': 'native driver clock, last timed step', 'driver_total_ms': driver_total_ms, 'roofline': roofline, 'cpu_baseline': cpu,
             'pipelined': pipelined,
         }
     # ---- extra leg for N > 1 (reported beside `value`, never as `value`): ONE proof of the same workload across all ranks

@@ -234,6 +234,23 @@ std::vector<uint64_t> unique_in_order(const std::vector<uint64_t> &v) {
 
 }  // namespace
 
+// What the last prove() on this thread did: wall-clock of the phases (host clock at the phase boundaries; no device
+// synchronisation is added, so a phase lasts until its last BLOCKING call returned) and the transform work it launched.
+static thread_local gs_prover_stats g_stats;
+
+// the two transform entry points, counted: rows * n points per call.  The library serves a transform of fewer than 256 points
+// or of a polynomial of at most 8 coefficients with a Horner kernel (ntt.hip: ntt_run), which is not an NTT: counted apart.
+static int counted_interpolate_roots(gs_ctx *c, const void *ys, uint32_t rows, const uint8_t *omega, uint64_t n, void *out) {
+    if (n >= 256) { g_stats.ntt_points += (uint64_t)rows * n; g_stats.ntt_transforms += rows; }
+    else g_stats.horner_points += (uint64_t)rows * n;
+    return A.gs_interpolate_roots(c, ys, rows, omega, n, out);
+}
+static int counted_eval_polys_at_roots(gs_ctx *c, const void *polys, uint32_t rows, uint64_t poly_len, const uint8_t *omega, uint64_t n, void *out) {
+    if (n >= 256 && poly_len > 8) { g_stats.ntt_points += (uint64_t)rows * n; g_stats.ntt_transforms += rows; }
+    else g_stats.horner_points += (uint64_t)rows * n;
+    return A.gs_eval_polys_at_roots(c, polys, rows, poly_len, omega, n, out);
+}
+
 extern "C" {
 
 int gs_prover_bind(void *dl_handle) {
@@ -270,6 +287,12 @@ int gs_prover_prove(gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, 
     }
 }
 
+int gs_prover_last_stats(struct gs_prover_stats *out) {
+    if (!out) return GS_ERR_ARG;
+    *out = g_stats;
+    return GS_OK;
+}
+
 }  // extern "C"
 
 namespace {
@@ -288,13 +311,19 @@ struct Layer {           // one FRI layer: the tree / rows it queries and the ch
 // GSTARK_PROVER_TIMING=1: host wall-clock at the phase boundaries on stderr (no device synchronisation is added, so a phase
 // shows the time until its last BLOCKING call returned)
 struct PhaseClock {
-    bool on = getenv("GSTARK_PROVER_TIMING") != nullptr;
+    bool on = getenv("GSTARK_PROVER_TIMING") != nullptr;      // also echo the marks on stderr
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    PhaseClock() { memset(&g_stats, 0, sizeof g_stats); }
     void mark(const char *what) {
-        if (!on) return;
         auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[prover] %-44s %8.3f ms  (+%.3f)\n", what, std::chrono::duration<double, std::milli>(now - t0).count(),
-                std::chrono::duration<double, std::milli>(now - last).count());
+        const double total = std::chrono::duration<double, std::milli>(now - t0).count();
+        const double delta = std::chrono::duration<double, std::milli>(now - last).count();
+        if (g_stats.nphases < GS_PROVER_MAX_PHASES) {
+            snprintf(g_stats.phase_label[g_stats.nphases], sizeof g_stats.phase_label[0], "%s", what);
+            g_stats.phase_ms[g_stats.nphases++] = delta;
+        }
+        g_stats.total_ms = total;
+        if (on) fprintf(stderr, "[prover] %-44s %8.3f ms  (+%.3f)\n", what, total, delta);
         last = now;
     }
 };
@@ -388,10 +417,10 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     // 3 ----- P(x) and its low-degree extension (:106-109)
     Buf pPolys(x, (uint64_t)R * T * ELEM), pEval(x, (uint64_t)R * N * ELEM);
     le16(exec_rou, s16);
-    x.check(A.gs_interpolate_roots(x.c, trace.p, R, s16, T, pPolys.p), "gs_interpolate_roots(trace)");
+    x.check(counted_interpolate_roots(x.c, trace.p, R, s16, T, pPolys.p), "gs_interpolate_roots(trace)");
     trace.release();
     le16(omega, s16);
-    x.check(A.gs_eval_polys_at_roots(x.c, pPolys.p, R, T, s16, N, pEval.p), "gs_eval_polys_at_roots(P)");
+    x.check(counted_eval_polys_at_roots(x.c, pPolys.p, R, T, s16, N, pEval.p), "gs_eval_polys_at_roots(P)");
     std::vector<const void *> pRows(R);
     for (uint32_t r = 0; r < R; r++) pRows[r] = pEval.at((uint64_t)r * N * ELEM);
     std::vector<const void *> eVectors(pRows);                    // [P_0.., S_0..] (lib/Stark.ts:113-114)
@@ -446,9 +475,9 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         const uint64_t klen_n = air.k_len * (N / Nc);
         Buf kPoly(x, air.k_len * ELEM), kN(x, klen_n * ELEM);
         le16(hf_pow(omega, (hfe)(N / air.k_len)), s16);
-        x.check(A.gs_interpolate_roots(x.c, air.k_table, 1, s16, air.k_len, kPoly.p), "gs_interpolate_roots(K)");
+        x.check(counted_interpolate_roots(x.c, air.k_table, 1, s16, air.k_len, kPoly.p), "gs_interpolate_roots(K)");
         le16(hf_pow(omega, (hfe)(N / klen_n)), s16);
-        x.check(A.gs_eval_polys_at_roots(x.c, kPoly.p, 1, air.k_len, s16, klen_n, kN.p), "gs_eval_polys_at_roots(K)");
+        x.check(counted_eval_polys_at_roots(x.c, kPoly.p, 1, air.k_len, s16, klen_n, kN.p), "gs_eval_polys_at_roots(K)");
         const RegData &d = rdata[0];
         const uint32_t m = (uint32_t)d.xs.size();
         Bytes xs(m * 16), ys(m * 16), ipoly(m * 16);
@@ -486,9 +515,9 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
             const uint64_t klen_n = air.k_len * (N / Nc);
             Buf kPoly(x, air.k_len * ELEM), kN(x, klen_n * ELEM);
             le16(hf_pow(omega, (hfe)(N / air.k_len)), s16);
-            x.check(A.gs_interpolate_roots(x.c, air.k_table, 1, s16, air.k_len, kPoly.p), "gs_interpolate_roots(K)");
+            x.check(counted_interpolate_roots(x.c, air.k_table, 1, s16, air.k_len, kPoly.p), "gs_interpolate_roots(K)");
             le16(hf_pow(omega, (hfe)(N / klen_n)), s16);
-            x.check(A.gs_eval_polys_at_roots(x.c, kPoly.p, 1, air.k_len, s16, klen_n, kN.p), "gs_eval_polys_at_roots(K)");
+            x.check(counted_eval_polys_at_roots(x.c, kPoly.p, 1, air.k_len, s16, klen_n, kN.p), "gs_eval_polys_at_roots(K)");
             x.check(A.gs_mimc_constraints(x.c, pRows[0], N, N / T, kN.p, klen_n, q.p), "gs_mimc_constraints");
         } else {
             // P over the composition domain is every (N/Nc)-th element of the extension just computed (:76)
@@ -521,9 +550,9 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
             Buf qc(x, Nc * ELEM), qcPoly(x, Nc * ELEM);
             x.check(A.gs_combine_many(x.c, qa.data(), dco.data(), dcount, Nc, qc.p), "gs_combine_many(Q)");
             le16(comp_rou, s16);
-            x.check(A.gs_interpolate_roots(x.c, qc.p, 1, s16, Nc, qcPoly.p), "gs_interpolate_roots(Q)");
+            x.check(counted_interpolate_roots(x.c, qc.p, 1, s16, Nc, qcPoly.p), "gs_interpolate_roots(Q)");
             le16(omega, s16);
-            x.check(A.gs_eval_polys_at_roots(x.c, qcPoly.p, 1, Nc, s16, N, qe.p), "gs_eval_polys_at_roots(Q)");
+            x.check(counted_eval_polys_at_roots(x.c, qcPoly.p, 1, Nc, s16, N, qe.p), "gs_eval_polys_at_roots(Q)");
         }
         // 5.4 D(x) = Q(x) / Z(x) (:113-121)
         Buf dEval(x, N * ELEM);
@@ -563,7 +592,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         Buf iPolys = upload_rows(ipolys, ilen);
         Buf iValues(x, (uint64_t)bcount * N * ELEM), pi(x, (uint64_t)bcount * N * ELEM), bEval(x, (uint64_t)bcount * N * ELEM);
         le16(omega, s16);
-        x.check(A.gs_eval_polys_at_roots(x.c, iPolys.p, bcount, ilen, s16, N, iValues.p), "gs_eval_polys_at_roots(I)");
+        x.check(counted_eval_polys_at_roots(x.c, iPolys.p, bcount, ilen, s16, N, iValues.p), "gs_eval_polys_at_roots(I)");
         std::vector<const void *> pv;
         for (auto &d : rdata) pv.push_back(pRows[d.reg]);
         x.check(A.gs_sub_matrix_from_vectors(x.c, pv.data(), iValues.p, bcount, N, pi.p), "gs_sub_matrix_from_vectors");
@@ -581,7 +610,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
             x.check(A.gs_div_by_domain_roots(x.c, pi.p, bcount, N, s16, at.data(), per_row.data(), (uint32_t)max_roots, bEval.p), "gs_div_by_domain_roots");
         } else {
             Buf zPolys = upload_rows(zpolys, zlen), zValues(x, (uint64_t)bcount * N * ELEM);
-            x.check(A.gs_eval_polys_at_roots(x.c, zPolys.p, bcount, zlen, s16, N, zValues.p), "gs_eval_polys_at_roots(Zb)");
+            x.check(counted_eval_polys_at_roots(x.c, zPolys.p, bcount, zlen, s16, N, zValues.p), "gs_eval_polys_at_roots(Zb)");
             x.check(A.gs_vec_div(x.c, pi.p, zValues.p, (uint64_t)bcount * N, bEval.p), "gs_vec_div(B)");
         }
         iValues.release(); pi.release();

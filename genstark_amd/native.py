@@ -38,6 +38,11 @@ class _Job(C.Structure):
                 ('air', _Air)]
 
 
+class _Stats(C.Structure):
+    _fields_ = [('ntt_points', C.c_uint64), ('ntt_transforms', C.c_uint64), ('horner_points', C.c_uint64), ('nphases', C.c_uint32),
+                ('total_ms', C.c_double), ('phase_ms', C.c_double * 16), ('phase_label', (C.c_char * 48) * 16)]
+
+
 _bound = {}
 
 
@@ -62,6 +67,8 @@ def _driver(backend):
         lib.gs_prover_bind.restype = C.c_int
         lib.gs_prover_prove.argtypes = [C.c_void_p, C.POINTER(_Job), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
         lib.gs_prover_prove.restype = C.c_int
+        lib.gs_prover_last_stats.argtypes = [C.POINTER(_Stats)]
+        lib.gs_prover_last_stats.restype = C.c_int
         rc = lib.gs_prover_bind(C.c_void_p(backend.lib._handle))
         if rc:
             raise GstarkError(f'gs_prover_bind failed ({rc}): the ABI library lacks an entry point the driver needs')
@@ -187,6 +194,19 @@ class NativeProver:
         if rc:
             raise StarkError(f'native prove() failed ({rc}): {err.value.decode(errors="replace")}')
         return C.string_at(out, n.value)
+
+    def last_stats(self):
+        """What the last prove_bytes() on this thread did, from the driver's own clock and counters (gs_prover_last_stats):
+        {'total_ms', 'phases_ms': {label: ms}, 'ntt_points', 'ntt_transforms', 'horner_points'}."""
+        st = _Stats()
+        rc = self.lib.gs_prover_last_stats(C.byref(st))
+        if rc:
+            raise GstarkError(f'gs_prover_last_stats failed ({rc})')
+        phases = {}
+        for i in range(st.nphases):
+            phases[bytes(st.phase_label[i]).split(b'\0', 1)[0].decode()] = round(st.phase_ms[i], 4)
+        return {'total_ms': round(st.total_ms, 4), 'phases_ms': phases, 'ntt_points': int(st.ntt_points),
+                'ntt_transforms': int(st.ntt_transforms), 'horner_points': int(st.horner_points)}
 
     def prove(self, assertions, inputs=None, seed=None):
         return self.stark.parse(self.prove_bytes(assertions, inputs, seed))

@@ -57,12 +57,25 @@ struct gs_prover_job {
 };
 
 
+/* What the last gs_prover_prove() on the calling thread did (bench.py reports it; nothing in the proof depends on it). */
+#define GS_PROVER_MAX_PHASES 16
+struct gs_prover_stats {
+    uint64_t ntt_points;         /* points of the transforms launched as NTT passes: sum of rows * n over gs_interpolate_roots / gs_eval_polys_at_roots calls */
+    uint64_t ntt_transforms;     /* ... and how many transforms that was */
+    uint64_t horner_points;      /* points of the calls the library serves with its Horner kernel instead (fewer than 256 points, or at most 8 coefficients) */
+    uint32_t nphases;
+    double total_ms;             /* host wall-clock of the whole call */
+    double phase_ms[GS_PROVER_MAX_PHASES];       /* host wall-clock between phase boundaries; no device synchronisation is added */
+    char phase_label[GS_PROVER_MAX_PHASES][48];
+};
+
 /* Resolves the gs_* entry points from `dl_handle` (the handle dlopen() returned for the ABI library).  GS_ERR_UNSUPPORTED if one
  * is missing. */
 int gs_prover_bind(void *dl_handle);
 /* The serialized proof into out[0..cap); *len receives its size (GS_ERR_ARG with *len set when cap is too small).  On failure
  * err[0..errcap) holds the reference's message where there is one ("Assertion at step ... conflicts with execution trace"). */
 int gs_prover_prove(gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, uint64_t cap, uint64_t *len, char *err, uint64_t errcap);
+int gs_prover_last_stats(struct gs_prover_stats *out);
 
 #ifdef __cplusplus
 }

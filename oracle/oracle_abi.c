@@ -83,44 +83,77 @@ int gs_air_jit_check(int kind, const uint32_t *code, uint32_t ninstr, const uint
 int gs_defer_begin(gs_ctx *c) { (void)c; return GS_OK; }   /* host memory: every read-back is immediate */
 int gs_defer_end(gs_ctx *c) { (void)c; return GS_OK; }
 
+/* The loops below are independent per index; built with -fopenmp (liboracle_omp.so: the all-cores CPU baseline of bench.py) they
+ * run on every host core, built without it (liboracle.so, the checker) the pragmas vanish.  Loops that carry a running product
+ * are cut into fixed blocks, each block starting from its own power (fe_exp): same values, block by block. */
+#if defined(_OPENMP)
+#include <omp.h>
+#define PAR_FOR _Pragma("omp parallel for schedule(static)")
+#else
+#define PAR_FOR
+#endif
+#define BLOCK 4096   /* elements per block of a running product */
+
 #define EL(p, i) fe_load((const uint8_t *)(p) + FE_BYTES * (uint64_t)(i))
 #define ST(p, i, v) fe_store((uint8_t *)(p) + FE_BYTES * (uint64_t)(i), (v))
 
 int gs_power_series(gs_ctx *c, const gs_elt *base, uint64_t n, void *out) {
     (void)c;
-    fe b = fe_load(base), x = 1;
-    for (uint64_t i = 0; i < n; i++) { ST(out, i, x); x = fe_mul(x, b); }
+    fe b = fe_load(base);
+    PAR_FOR
+    for (uint64_t s0 = 0; s0 < n; s0 += BLOCK) {
+        fe x = fe_exp(b, (fexp)s0);
+        for (uint64_t i = s0; i < n && i < s0 + BLOCK; i++) { ST(out, i, x); x = fe_mul(x, b); }
+    }
     return GS_OK;
 }
 int gs_vec_add(gs_ctx *c, const void *a, const void *b, uint64_t n, void *o) {
-    (void)c; for (uint64_t i = 0; i < n; i++) ST(o, i, fe_add(EL(a, i), EL(b, i))); return GS_OK;
+    (void)c;
+    PAR_FOR
+    for (uint64_t i = 0; i < n; i++) ST(o, i, fe_add(EL(a, i), EL(b, i)));
+    return GS_OK;
 }
 int gs_vec_sub(gs_ctx *c, const void *a, const void *b, uint64_t n, void *o) {
-    (void)c; for (uint64_t i = 0; i < n; i++) ST(o, i, fe_sub(EL(a, i), EL(b, i))); return GS_OK;
+    (void)c;
+    PAR_FOR
+    for (uint64_t i = 0; i < n; i++) ST(o, i, fe_sub(EL(a, i), EL(b, i)));
+    return GS_OK;
 }
 int gs_vec_mul(gs_ctx *c, const void *a, const void *b, uint64_t n, void *o) {
-    (void)c; for (uint64_t i = 0; i < n; i++) ST(o, i, fe_mul(EL(a, i), EL(b, i))); return GS_OK;
+    (void)c;
+    PAR_FOR
+    for (uint64_t i = 0; i < n; i++) ST(o, i, fe_mul(EL(a, i), EL(b, i)));
+    return GS_OK;
 }
 int gs_vec_add_scalar(gs_ctx *c, const void *a, const gs_elt *s, uint64_t n, void *o) {
-    (void)c; fe k = fe_load(s); for (uint64_t i = 0; i < n; i++) ST(o, i, fe_add(EL(a, i), k)); return GS_OK;
+    (void)c; fe k = fe_load(s);
+    PAR_FOR
+    for (uint64_t i = 0; i < n; i++) ST(o, i, fe_add(EL(a, i), k));
+    return GS_OK;
 }
 int gs_vec_sub_scalar(gs_ctx *c, const void *a, const gs_elt *s, uint64_t n, void *o) {
-    (void)c; fe k = fe_load(s); for (uint64_t i = 0; i < n; i++) ST(o, i, fe_sub(EL(a, i), k)); return GS_OK;
+    (void)c; fe k = fe_load(s);
+    PAR_FOR
+    for (uint64_t i = 0; i < n; i++) ST(o, i, fe_sub(EL(a, i), k));
+    return GS_OK;
 }
 int gs_vec_mul_scalar(gs_ctx *c, const void *a, const gs_elt *s, uint64_t n, void *o) {
-    (void)c; fe k = fe_load(s); for (uint64_t i = 0; i < n; i++) ST(o, i, fe_mul(EL(a, i), k)); return GS_OK;
+    (void)c; fe k = fe_load(s);
+    PAR_FOR
+    for (uint64_t i = 0; i < n; i++) ST(o, i, fe_mul(EL(a, i), k));
+    return GS_OK;
 }
 
-/* serial Montgomery-trick inversion, zeros map to zero */
-static int batch_inv(const void *a, uint64_t n, fe *out) {
+/* Montgomery-trick inversion, zeros map to zero: serial inside a block of BLOCK elements (one field inversion per block) */
+static void batch_inv_block(const void *a, uint64_t lo, uint64_t hi, fe *out) {
     fe acc = 1;
-    for (uint64_t i = 0; i < n; i++) {
+    for (uint64_t i = lo; i < hi; i++) {
         out[i] = acc;
         fe v = EL(a, i);
         if (v) acc = fe_mul(acc, v);
     }
     fe inv = fe_inv(acc);
-    for (uint64_t i = n; i-- > 0;) {
+    for (uint64_t i = hi; i-- > lo;) {
         fe v = EL(a, i);
         if (v) {
             fe r = fe_mul(out[i], inv);
@@ -128,12 +161,17 @@ static int batch_inv(const void *a, uint64_t n, fe *out) {
             out[i] = r;
         } else out[i] = 0;
     }
+}
+static int batch_inv(const void *a, uint64_t n, fe *out) {
+    PAR_FOR
+    for (uint64_t s0 = 0; s0 < n; s0 += BLOCK) batch_inv_block(a, s0, s0 + BLOCK < n ? s0 + BLOCK : n, out);
     return 0;
 }
 int gs_vec_inv(gs_ctx *c, const void *a, uint64_t n, void *o) {
     fe *t = (fe *)malloc((n ? n : 1) * sizeof(fe));
     if (!t) return fail(c, GS_ERR_OOM, "malloc failed");
     batch_inv(a, n, t);
+    PAR_FOR
     for (uint64_t i = 0; i < n; i++) ST(o, i, t[i]);
     free(t);
     return GS_OK;
@@ -142,17 +180,20 @@ int gs_vec_div(gs_ctx *c, const void *a, const void *b, uint64_t n, void *o) {
     fe *t = (fe *)malloc((n ? n : 1) * sizeof(fe));
     if (!t) return fail(c, GS_ERR_OOM, "malloc failed");
     batch_inv(b, n, t);
+    PAR_FOR
     for (uint64_t i = 0; i < n; i++) ST(o, i, fe_mul(EL(a, i), t[i]));
     free(t);
     return GS_OK;
 }
 int gs_vec_exp(gs_ctx *c, const void *a, const gs_elt *e, uint64_t n, void *o) {
     (void)c; fexp ee = fe_load(e);
+    PAR_FOR
     for (uint64_t i = 0; i < n; i++) ST(o, i, fe_exp(EL(a, i), ee));
     return GS_OK;
 }
 int gs_combine_many(gs_ctx *c, const void *const *vecs, const uint8_t *coeffs, uint32_t count, uint64_t n, void *o) {
     if (count == 0 || count > GS_MAX_COMBINE) return fail(c, GS_ERR_ARG, "combine_many: bad count");
+    PAR_FOR
     for (uint64_t i = 0; i < n; i++) {
         fe s = 0;
         for (uint32_t j = 0; j < count; j++) s = fe_add(s, fe_mul(EL(vecs[j], i), fe_load(coeffs + FE_BYTES * j)));
@@ -168,6 +209,7 @@ int gs_combine(gs_ctx *c, const void *a, const void *b, uint64_t n, gs_elt *out)
 }
 int gs_pluck(gs_ctx *c, const void *v, uint64_t vlen, uint64_t skip, uint64_t times, void *o) {
     if (!vlen) return fail(c, GS_ERR_ARG, "pluck: empty vector");
+    PAR_FOR
     for (uint64_t i = 0; i < times; i++) ST(o, i, EL(v, (i * skip) % vlen));
     return GS_OK;
 }
@@ -179,11 +221,17 @@ int gs_zero_poly_inverses(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t s
     uint8_t *den = (uint8_t *)malloc((n ? n : 1) * FE_BYTES);
     fe *inv = (fe *)malloc((n ? n : 1) * sizeof(fe));
     if (!den || !inv) { free(den); free(inv); return fail(c, GS_ERR_OOM, "malloc failed"); }
-    fe d = 1;
-    for (uint64_t i = 0; i < n; i++) { ST(den, i, fe_sub(d, 1)); d = fe_mul(d, ws); }      /* omega^(i*steps) - 1 */
+    PAR_FOR
+    for (uint64_t s0 = 0; s0 < n; s0 += BLOCK) {
+        fe d = fe_exp(ws, (fexp)s0);
+        for (uint64_t i = s0; i < n && i < s0 + BLOCK; i++) { ST(den, i, fe_sub(d, 1)); d = fe_mul(d, ws); }      /* omega^(i*steps) - 1 */
+    }
     batch_inv(den, n, inv);
-    fe x = 1;
-    for (uint64_t i = 0; i < n; i++) { ST(o, i, fe_mul(fe_sub(x, xl), inv[i])); x = fe_mul(x, w); }
+    PAR_FOR
+    for (uint64_t s0 = 0; s0 < n; s0 += BLOCK) {
+        fe x = fe_exp(w, (fexp)s0);
+        for (uint64_t i = s0; i < n && i < s0 + BLOCK; i++) { ST(o, i, fe_mul(fe_sub(x, xl), inv[i])); x = fe_mul(x, w); }
+    }
     free(den); free(inv);
     return GS_OK;
 }
@@ -196,15 +244,20 @@ int gs_div_by_domain_roots(gs_ctx *c, const void *num, uint32_t rows, uint64_t n
     if (!den || !inv) { free(den); free(inv); return fail(c, GS_ERR_OOM, "malloc failed"); }
     for (uint32_t r = 0; r < rows; r++) {
         if (roots_per_row[r] > max_roots || roots_per_row[r] > 4) { free(den); free(inv); return fail(c, GS_ERR_UNSUPPORTED, "div_by_domain_roots: at most 4 roots per row"); }
-        fe x = 1, root[4];
+        fe root[4];
         for (uint32_t a = 0; a < roots_per_row[r]; a++) root[a] = fe_exp(w, (fexp)(root_index[(uint64_t)r * max_roots + a] % n));
-        for (uint64_t i = 0; i < n; i++) {
-            fe z = 1;
-            for (uint32_t a = 0; a < roots_per_row[r]; a++) z = fe_mul(z, fe_sub(x, root[a]));
-            ST(den, i, z);
-            x = fe_mul(x, w);
+        PAR_FOR
+        for (uint64_t s0 = 0; s0 < n; s0 += BLOCK) {
+            fe x = fe_exp(w, (fexp)s0);
+            for (uint64_t i = s0; i < n && i < s0 + BLOCK; i++) {
+                fe z = 1;
+                for (uint32_t a = 0; a < roots_per_row[r]; a++) z = fe_mul(z, fe_sub(x, root[a]));
+                ST(den, i, z);
+                x = fe_mul(x, w);
+            }
         }
         batch_inv(den, n, inv);
+        PAR_FOR
         for (uint64_t i = 0; i < n; i++) ST(o, (uint64_t)r * n + i, fe_mul(EL(num, (uint64_t)r * n + i), inv[i]));
     }
     free(den); free(inv);
@@ -213,12 +266,14 @@ int gs_div_by_domain_roots(gs_ctx *c, const void *num, uint32_t rows, uint64_t n
 int gs_transpose_vector(gs_ctx *c, const void *v, uint64_t n, uint32_t cols, uint64_t step, void *o) {
     if (!cols || !step || n % ((uint64_t)cols * step)) return fail(c, GS_ERR_ARG, "transpose_vector: n %% (cols*step) != 0");
     uint64_t rows = n / ((uint64_t)cols * step);
+    PAR_FOR
     for (uint64_t r = 0; r < rows; r++)
         for (uint32_t k = 0; k < cols; k++) ST(o, r * cols + k, EL(v, (r + (uint64_t)k * rows) * step));
     return GS_OK;
 }
 int gs_transpose_matrix(gs_ctx *c, const void *m, uint64_t rows, uint64_t cols, void *o) {
     (void)c;
+    PAR_FOR
     for (uint64_t r = 0; r < rows; r++)
         for (uint64_t k = 0; k < cols; k++) ST(o, k * rows + r, EL(m, r * cols + k));
     return GS_OK;
@@ -230,26 +285,35 @@ int gs_sub_matrix_from_vectors(gs_ctx *c, const void *const *vecs, const void *m
     return GS_OK;
 }
 
-/* in-place iterative radix-2 decimation-in-time NTT over natural-order input */
+/* in-place iterative radix-2 decimation-in-time NTT over natural-order input; tw[k] = omega^k for k < n/2 */
 static void ntt_inplace(fe *a, uint64_t n, fe omega) {
-    for (uint64_t i = 1, j = 0; i < n; i++) { /* bit reversal */
-        uint64_t bit = n >> 1;
-        for (; j & bit; bit >>= 1) j ^= bit;
-        j ^= bit;
+    if (n < 2) return;
+    fe *tw = (fe *)malloc((n / 2) * sizeof(fe));
+    if (!tw) abort();
+    PAR_FOR
+    for (uint64_t s0 = 0; s0 < n / 2; s0 += BLOCK) {
+        fe x = fe_exp(omega, (fexp)s0);
+        for (uint64_t k = s0; k < n / 2 && k < s0 + BLOCK; k++) { tw[k] = x; x = fe_mul(x, omega); }
+    }
+    int bits = 0;
+    while (((uint64_t)1 << bits) < n) bits++;
+    PAR_FOR
+    for (uint64_t i = 0; i < n; i++) { /* bit reversal */
+        uint64_t j = 0;
+        for (int b = 0; b < bits; b++) j |= ((i >> b) & 1) << (bits - 1 - b);
         if (i < j) { fe t = a[i]; a[i] = a[j]; a[j] = t; }
     }
     for (uint64_t len = 2; len <= n; len <<= 1) {
-        fe wl = fe_exp(omega, n / len);
-        for (uint64_t i = 0; i < n; i += len) {
-            fe w = 1;
-            for (uint64_t j = 0; j < len / 2; j++) {
-                fe u = a[i + j], v = fe_mul(a[i + j + len / 2], w);
-                a[i + j] = fe_add(u, v);
-                a[i + j + len / 2] = fe_sub(u, v);
-                w = fe_mul(w, wl);
-            }
+        const uint64_t half = len / 2, stride = n / len;
+        PAR_FOR
+        for (uint64_t b = 0; b < n / 2; b++) {       /* butterfly b: block b / half, position b % half */
+            const uint64_t j = b % half, i = (b / half) * len;
+            fe u = a[i + j], v = fe_mul(a[i + j + half], tw[j * stride]);
+            a[i + j] = fe_add(u, v);
+            a[i + j + half] = fe_sub(u, v);
         }
     }
+    free(tw);
 }
 static int check_root(gs_ctx *c, fe w, uint64_t n) { /* omega must generate the n-th roots of unity */
     if (n == 1) return w == 1 ? GS_OK : fail(c, GS_ERR_ARG, "ntt: omega must be 1 for n = 1");
@@ -263,8 +327,10 @@ int gs_eval_polys_at_roots(gs_ctx *c, const void *polys, uint32_t rows, uint64_t
     if (!t) return fail(c, GS_ERR_OOM, "malloc failed");
     fe w = fe_load(omega);
     for (uint32_t r = 0; r < rows; r++) {
+        PAR_FOR
         for (uint64_t i = 0; i < n; i++) t[i] = i < plen ? EL(polys, (uint64_t)r * plen + i) : 0;
         ntt_inplace(t, n, w);
+        PAR_FOR
         for (uint64_t i = 0; i < n; i++) ST(out, (uint64_t)r * n + i, t[i]);
     }
     free(t);
@@ -277,8 +343,10 @@ int gs_interpolate_roots(gs_ctx *c, const void *ys, uint32_t rows, const gs_elt 
     if (!t) return fail(c, GS_ERR_OOM, "malloc failed");
     fe winv = fe_inv(fe_load(omega)), ninv = fe_inv((fe)n);
     for (uint32_t r = 0; r < rows; r++) {
+        PAR_FOR
         for (uint64_t i = 0; i < n; i++) t[i] = EL(ys, (uint64_t)r * n + i);
         ntt_inplace(t, n, winv);
+        PAR_FOR
         for (uint64_t i = 0; i < n; i++) ST(out, (uint64_t)r * n + i, fe_mul(t[i], ninv));
     }
     free(t);
@@ -294,10 +362,22 @@ int gs_eval_poly_at(gs_ctx *c, const void *poly, uint64_t len, const gs_elt *x, 
 /* cubic through 4 points by Lagrange basis expansion */
 static void lagrange4(const fe x[4], const fe y[4], fe cof[4]) {
     cof[0] = cof[1] = cof[2] = cof[3] = 0;
+    /* the four denominators prod_{m != j} (x_j - x_m), inverted together (one field inversion per row; a zero denominator -
+     * repeated x - inverts to zero like fe_inv does) */
+    fe den[4], pre[4], acc = 1;
+    for (int j = 0; j < 4; j++) {
+        den[j] = 1;
+        for (int m = 0; m < 4; m++) if (m != j) den[j] = fe_mul(den[j], fe_sub(x[j], x[m]));
+        pre[j] = acc;
+        if (den[j]) acc = fe_mul(acc, den[j]);
+    }
+    fe inv = fe_inv(acc);
+    for (int j = 3; j >= 0; j--) {
+        if (den[j]) { fe r = fe_mul(pre[j], inv); inv = fe_mul(inv, den[j]); den[j] = r; }
+    }
     for (int j = 0; j < 4; j++) {
         fe num[4] = {1, 0, 0, 0}; /* prod_{m != j} (X - x_m), ascending coefficients */
         int deg = 0;
-        fe den = 1;
         for (int m = 0; m < 4; m++) {
             if (m == j) continue;
             fe nx = fe_neg(x[m]), nw[4] = {0, 0, 0, 0};
@@ -307,9 +387,8 @@ static void lagrange4(const fe x[4], const fe y[4], fe cof[4]) {
             }
             deg++;
             for (int d = 0; d <= deg; d++) num[d] = nw[d];
-            den = fe_mul(den, fe_sub(x[j], x[m]));
         }
-        fe s = fe_mul(y[j], fe_inv(den));
+        fe s = fe_mul(y[j], den[j]);
         for (int d = 0; d < 4; d++) cof[d] = fe_add(cof[d], fe_mul(num[d], s));
     }
 }
@@ -339,17 +418,26 @@ int gs_fri_fold(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const
     if (m < 4 || m * step != n) return fail(c, GS_ERR_ARG, "fri_fold: column length * step != n");
     fe w = fe_load(omega), X = fe_load(xp);
     uint64_t rows = m / 4;
-    for (uint64_t r = 0; r < rows; r++) {
-        fe x[4], y[4], k[4], s = 0;
-        for (int j = 0; j < 4; j++) { x[j] = fe_exp(w, (fexp)((r + (uint64_t)j * rows) * step)); y[j] = EL(column, r + (uint64_t)j * rows); }
-        lagrange4(x, y, k);
-        for (int j = 3; j >= 0; j--) s = fe_add(fe_mul(s, X), k[j]);
-        ST(out, r, s);
+    /* row r sits at x_r = omega^(r*step), its three companions at x_r * zeta^j with zeta = omega^(rows*step) (a 4th root of unity) */
+    const fe g = fe_exp(w, (fexp)step), zeta = fe_exp(w, (fexp)(rows * step));
+    PAR_FOR
+    for (uint64_t s0 = 0; s0 < rows; s0 += BLOCK) {
+        fe xr = fe_exp(g, (fexp)s0);
+        for (uint64_t r = s0; r < rows && r < s0 + BLOCK; r++, xr = fe_mul(xr, g)) {
+            fe x[4], y[4], k[4], s = 0;
+            x[0] = xr;
+            for (int j = 1; j < 4; j++) x[j] = fe_mul(x[j - 1], zeta);
+            for (int j = 0; j < 4; j++) y[j] = EL(column, r + (uint64_t)j * rows);
+            lagrange4(x, y, k);
+            for (int j = 3; j >= 0; j--) s = fe_add(fe_mul(s, X), k[j]);
+            ST(out, r, s);
+        }
     }
     return GS_OK;
 }
 int gs_eval_quartic_batch(gs_ctx *c, const void *polys, uint64_t rows, const gs_elt *x, void *out) {
     (void)c; fe xx = fe_load(x);
+    PAR_FOR
     for (uint64_t r = 0; r < rows; r++) {
         fe s = EL(polys, r * 4 + 3);
         for (int j = 2; j >= 0; j--) s = fe_add(fe_mul(s, xx), EL(polys, r * 4 + j));
@@ -363,8 +451,9 @@ int gs_hash_digest(gs_ctx *c, gs_hash_alg alg, const uint8_t *msg, uint64_t len,
 }
 int gs_hash_merge_rows(gs_ctx *c, gs_hash_alg alg, const void *const *vecs, uint32_t count, uint64_t n, void *out) {
     if (count == 0 || count > GS_MAX_COMBINE) return fail(c, GS_ERR_ARG, "hash_merge_rows: bad count");
-    uint8_t buf[FE_BYTES * GS_MAX_COMBINE];
+    PAR_FOR
     for (uint64_t i = 0; i < n; i++) {
+        uint8_t buf[FE_BYTES * GS_MAX_COMBINE];
         for (uint32_t j = 0; j < count; j++) memcpy(buf + FE_BYTES * j, (const uint8_t *)vecs[j] + FE_BYTES * i, FE_BYTES);
         orc_hash((int)alg, buf, FE_BYTES * (size_t)count, (uint8_t *)out + 32 * i);
     }
@@ -372,6 +461,7 @@ int gs_hash_merge_rows(gs_ctx *c, gs_hash_alg alg, const void *const *vecs, uint
 }
 int gs_hash_digest_values(gs_ctx *c, gs_hash_alg alg, const void *buf, uint64_t vs, uint64_t count, void *out) {
     (void)c;
+    PAR_FOR
     for (uint64_t i = 0; i < count; i++) orc_hash((int)alg, (const uint8_t *)buf + vs * i, (size_t)vs, (uint8_t *)out + 32 * i);
     return GS_OK;
 }
@@ -379,8 +469,12 @@ int gs_merkle_build(gs_ctx *c, gs_hash_alg alg, const void *leaves, uint64_t n, 
     if (!is_pow2(n) || n < 2) return fail(c, GS_ERR_ARG, "merkle_build: n must be a power of two >= 2");
     uint8_t *nd = (uint8_t *)nodes;
     memset(nd, 0, 32);
+    PAR_FOR
     for (uint64_t i = 0; i < n / 2; i++) orc_hash((int)alg, (const uint8_t *)leaves + 64 * i, 64, nd + 32 * (n / 2 + i));
-    for (uint64_t i = n / 2; i-- > 1;) orc_hash((int)alg, nd + 64 * i, 64, nd + 32 * i);
+    for (uint64_t lvl = n / 4; lvl >= 1; lvl >>= 1) {      /* nodes [lvl, 2*lvl): one level, children in [2*lvl, 4*lvl) */
+        PAR_FOR
+        for (uint64_t i = lvl; i < 2 * lvl; i++) orc_hash((int)alg, nd + 64 * i, 64, nd + 32 * i);
+    }
     return GS_OK;
 }
 
@@ -395,6 +489,7 @@ int gs_mimc_trace(gs_ctx *c, const gs_elt *seed, const uint8_t *rc, uint32_t nrc
 }
 int gs_mimc_constraints(gs_ctx *c, const void *p, uint64_t nc, uint64_t shift, const void *k, uint64_t klen, void *out) {
     if (!klen || !nc) return fail(c, GS_ERR_ARG, "mimc_constraints: empty");
+    PAR_FOR
     for (uint64_t j = 0; j < nc; j++) {
         fe x = EL(p, j), nx = EL(p, (j + shift) % nc);
         fe t = fe_add(fe_mul(fe_mul(x, x), x), EL(k, j % klen));
@@ -417,18 +512,23 @@ int gs_mimc_composition(gs_ctx *c, const void *p, uint64_t n, uint64_t steps, co
     if (!den || !inv) { free(den); free(inv); return fail(c, GS_ERR_OOM, "malloc failed"); }
     /* x^steps, x^q_inc, x^b_inc along the domain: running products of omega^steps, omega^q_inc, omega^b_inc */
     const fe ws = fe_exp(w, (fexp)steps), wq = fe_exp(w, (fexp)q_inc), wb = fe_exp(w, (fexp)b_inc);
-    fe x = 1, xs = 1, xq = 1, xb = 1;
-    for (uint64_t i = 0; i < n; i++) {
-        fe zb = 1;
-        for (uint32_t a = 0; a < nroots; a++) zb = fe_mul(zb, fe_sub(x, root[a]));
-        ST(den, i, fe_sub(xs, 1));
-        ST(den, n + i, zb);
-        x = fe_mul(x, w);
-        xs = fe_mul(xs, ws);
+    PAR_FOR
+    for (uint64_t s0 = 0; s0 < n; s0 += BLOCK) {
+        fe x = fe_exp(w, (fexp)s0), xs = fe_exp(ws, (fexp)s0);
+        for (uint64_t i = s0; i < n && i < s0 + BLOCK; i++) {
+            fe zb = 1;
+            for (uint32_t a = 0; a < nroots; a++) zb = fe_mul(zb, fe_sub(x, root[a]));
+            ST(den, i, fe_sub(xs, 1));
+            ST(den, n + i, zb);
+            x = fe_mul(x, w);
+            xs = fe_mul(xs, ws);
+        }
     }
     batch_inv(den, 2 * n, inv);
-    x = 1;
-    for (uint64_t i = 0; i < n; i++, xq = fe_mul(xq, wq), xb = fe_mul(xb, wb)) {
+    PAR_FOR
+    for (uint64_t s0 = 0; s0 < n; s0 += BLOCK) {
+      fe x = fe_exp(w, (fexp)s0), xq = fe_exp(wq, (fexp)s0), xb = fe_exp(wb, (fexp)s0);
+      for (uint64_t i = s0; i < n && i < s0 + BLOCK; i++, xq = fe_mul(xq, wq), xb = fe_mul(xb, wb)) {
         fe pi = EL(p, i), pn = EL(p, (i + n / steps) % n);
         fe q = fe_sub(pn, fe_add(fe_mul(fe_mul(pi, pi), pi), EL(k, i % klen)));
         fe d = fe_mul(fe_mul(fe_mul(q, fe_add(d0, fe_mul(d1, xq))), fe_sub(x, x_last)), inv[i]);
@@ -439,6 +539,7 @@ int gs_mimc_composition(gs_ctx *c, const void *p, uint64_t n, uint64_t steps, co
         if (lc_coeffs) r = fe_add(r, fe_mul(pi, fe_add(fe_load(lc_coeffs), fe_mul(fe_load(lc_coeffs + FE_BYTES), xb))));
         ST(out, i, r);
         x = fe_mul(x, w);
+      }
     }
     free(den); free(inv);
     return GS_OK;

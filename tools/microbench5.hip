@@ -3,6 +3,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -pragma-unroll-threshold=1000000 tools/microbench5.hip -o tools/microbench5
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <string.h>
 #include "../genstark_amd/csrc/gf128_lazy.h"
 
 __device__ __forceinline__ lzw load_w(const lzw *p) {
@@ -85,7 +86,9 @@ __global__ __launch_bounds__(128) void k_femul(const fe *in, fe *out, const lzw 
 }
 
 typedef void (*kern_t)(const fe *, fe *, const lzw *);
-int main() {
+// `--json`: one JSON object on stdout (bench.py: the second roof of the NTT pass kernel, measured in the same run)
+int main(int argc, char **argv) {
+    const bool json = argc > 1 && !strcmp(argv[1], "--json");
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
     fe *in, *out; lzw *w;
@@ -99,10 +102,12 @@ int main() {
         {"fe_mul (canonical limbs)", k_femul, 16, "per product"},
     };
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    printf("%-50s %10s %10s %10s %10s   ns per wave per SIMD (wall clock; k waves per SIMD forced by LDS size, 128-thread blocks)\n", "core", "1 w/SIMD", "2 w/SIMD", "3 w/SIMD", "4 w/SIMD");
+    if (!json) printf("%-50s %10s %10s %10s %10s   ns per wave per SIMD (wall clock; k waves per SIMD forced by LDS size, 128-thread blocks)\n", "core", "1 w/SIMD", "2 w/SIMD", "3 w/SIMD", "4 w/SIMD");
+    double res[4][4];
+    int ei = 0;
     for (auto &e : es) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(e.k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        printf("%-50s", e.name);
+        if (!json) printf("%-50s", e.name);
         for (int wps : {1, 2, 3, 4}) {
             const size_t lds = (size_t)(160 * 1024) / (2 * wps);   // 2-wave blocks: 2*wps blocks per CU
             hipLaunchKernelGGL(e.k, dim3(blocks), dim3(128), lds, 0, in, out, w);
@@ -114,9 +119,17 @@ int main() {
             }
             // waves per SIMD in total = blocks * 2 / (cus * 4)
             const double waves_per_simd = (double)blocks * 2 / (cus * 4);
-            printf(" %10.1f", best * 1e6 / (waves_per_simd * ITERS * e.units));
+            res[ei][wps - 1] = best * 1e6 / (waves_per_simd * ITERS * e.units);
+            if (!json) printf(" %10.1f", res[ei][wps - 1]);
         }
-        printf("  %s\n", e.unit);
+        if (!json) printf("  %s\n", e.unit);
+        ei++;
+    }
+    if (json) {
+        const char *keys[4] = {"dif16_network_ns", "mul_v_ns", "pack_unpack_add_ns", "fe_mul_ns"};
+        printf("{\"cus\": %d, \"unit\": \"ns per wave per SIMD at 1,2,3,4 waves per SIMD\"", cus);
+        for (int k = 0; k < 4; k++) printf(", \"%s\": [%.2f, %.2f, %.2f, %.2f]", keys[k], res[k][0], res[k][1], res[k][2], res[k][3]);
+        printf("}\n");
     }
     return 0;
 }

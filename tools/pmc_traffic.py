@@ -1,0 +1,51 @@
+"""tools/pmc_traffic.py — HBM bytes per launch of the NTT pass kernels from the PMC counters, as MI355X_MICROARCH.md's HBM section
+prescribes: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes (they do not fit one), kernel-trace only beside them;
+on gfx950 FETCH_SIZE counts 128-byte requests of a wide coalesced streaming read at 64 bytes, so it is doubled; WRITE_SIZE as
+reported.  Both are in KiB.  Prints one JSON object; bench.py runs this on rank 0 at N = 1.
+usage: python tools/pmc_traffic.py [log2 n = 24] [outdir]"""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+logn = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+keep = sys.argv[2] if len(sys.argv) > 2 else None
+rocprof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+out = {'n': 1 << logn, 'commands': []}
+per_kernel = {}
+work = tempfile.mkdtemp(prefix='pmc_', dir='/tmp')
+env = dict(os.environ, TMPDIR='/tmp')
+for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+    d = os.path.join(work, counter)
+    cmd = [rocprof, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'p', '--',
+           sys.executable, os.path.join(ROOT, 'tools', 'ntt_only.py'), str(logn)]
+    out['commands'].append(' '.join(cmd[:8] + ['--', 'python', 'tools/ntt_only.py', str(logn)]))
+    subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+    files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+    if not files:
+        raise SystemExit(f'no counter file under {d}')
+    for row in csv.DictReader(open(files[0])):
+        if 'k_ntt_pass' not in row['Kernel_Name'] or row['Counter_Name'] != counter:
+            continue
+        name = row['Kernel_Name'].split('(')[0].replace('void ', '')
+        per_kernel.setdefault(name, {}).setdefault(counter, []).append(float(row['Counter_Value']))
+    if keep:
+        os.makedirs(keep, exist_ok=True)
+        shutil.copy(files[0], os.path.join(keep, f'pmc_{counter.lower()}_ntt_2p{logn}.csv'))
+kernels = {}
+for name, c in per_kernel.items():
+    f = sum(c.get('FETCH_SIZE', [0])) / max(1, len(c.get('FETCH_SIZE', [])))
+    w = sum(c.get('WRITE_SIZE', [0])) / max(1, len(c.get('WRITE_SIZE', [])))
+    kernels[name] = {'launches_sampled': len(c.get('FETCH_SIZE', [])), 'FETCH_SIZE_kib_avg': f, 'WRITE_SIZE_kib_avg': w,
+                     'hbm_bytes_per_launch': (2 * f + w) * 1024}
+out['kernels'] = kernels
+out['correction'] = 'bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes)'
+if kernels:
+    out['hbm_bytes_per_launch'] = sum(k['hbm_bytes_per_launch'] for k in kernels.values()) / len(kernels)
+shutil.rmtree(work, ignore_errors=True)
+print(json.dumps(out))
