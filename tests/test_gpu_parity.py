@@ -342,3 +342,121 @@ def test_randomized_differential_hip_vs_oracle(hip_backend, oracle_backend, seed
             vec, idx = rand_elements(rng, n), [rng.randrange(n) for _ in range(rng.randrange(1, 200))]
             both(lambda f, h: [f.interpolate(f.newVectorFrom(xs), f.newVectorFrom(ys)).toBuffer(), b''.join(f.newVectorFrom(vec).valuesAt(idx)),
                                f.mulPolys(f.newVectorFrom(vec[:90]), f.newVectorFrom(vec[-80:] if n >= 80 else vec)).toBuffer()])
+
+
+# ---- (e) byte parity with the C oracle AT the headline sizes -----------------------------
+# The oracle's loops are annotated for OpenMP (oracle/liboracle_omp.so: the same oracle_abi.c built with -fopenmp); on the GPU box's
+# host cores its 2^24-point transforms take seconds, so the comparison below is on EVERY output byte, not on properties.
+@pytest.fixture(scope='module')
+def oracle_omp_backend():
+    import subprocess
+    from genstark_amd._abi import Backend
+    lib = os.path.join(os.path.dirname(HERE), 'oracle', 'liboracle_omp.so')
+    if not os.path.exists(lib):
+        subprocess.check_call(['make', '-C', os.path.dirname(lib), '-s', 'liboracle_omp.so'])
+    cpus = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    os.environ.setdefault('OMP_NUM_THREADS', str(max(1, min(32, cpus))))      # read by libgomp when the library is loaded
+    os.environ.setdefault('OMP_WAIT_POLICY', 'passive')
+    return Backend(lib_path=lib, allow_test_double=True)
+
+
+def _dense_input(f, n, base):
+    """pseudo-random-looking dense coefficients without a host-side 2^24 loop: a power series of a generic element"""
+    return f.getPowerSeries(base, n)
+
+
+@pytest.mark.parametrize('logn', [21, 22, 24])
+def test_ntt_bytes_equal_oracle_at_headline_sizes(hip_backend, oracle_omp_backend, logn):
+    """forward (dense, un-pruned), zero-extended by 16 (the pruned LDE shape), zero-extended ragged, and inverse transforms of
+    2^21 / 2^22 / 2^24 points: every output byte of the HIP passes (three-pass plans: table twiddles AND the running-product
+    branch that only plans above 2^20 entries take) equals the oracle's radix-2 NTT."""
+    n = 1 << logn
+    fh, fo = PrimeField(backend=hip_backend), PrimeField(backend=oracle_omp_backend)
+    w = fh.getRootOfUnity(n)
+    assert w == fo.getRootOfUnity(n)
+    wb = w.to_bytes(16, 'little')
+    raw = _dense_input(fh, n, 0x1234567890abcdef1234567).toBuffer()
+    vh, vo = fh.newVector(n), fo.newVector(n)
+    hip_backend.upload(vh.ptr, raw); oracle_omp_backend.upload(vo.ptr, raw)
+    for kind, plen in (('fwd', n), ('fwd', n // 16), ('fwd', n // 16 + 12345), ('inv', n)):
+        outs = []
+        for be, f, v in ((hip_backend, fh, vh), (oracle_omp_backend, fo, vo)):
+            out = f.newVector(n)
+            if kind == 'fwd':
+                be.call('gs_eval_polys_at_roots', C.c_void_p(v.ptr), 1, plen, wb, n, C.c_void_p(out.ptr))
+            else:
+                be.call('gs_interpolate_roots', C.c_void_p(v.ptr), 1, wb, n, C.c_void_p(out.ptr))
+            outs.append(out.toBuffer())
+        assert outs[0] == outs[1], (logn, kind, plen)
+
+
+def test_mimc_composition_bytes_equal_oracle_at_2p24(hip_backend, oracle_omp_backend):
+    """gs_mimc_composition over the whole evaluation domain of the headline configuration (T = 2^20, E = 16), LinearCombination
+    folded in: every byte against the oracle's term-by-term evaluation."""
+    n, steps = 1 << 24, 1 << 20
+    rng = random.Random(2024)
+    fh, fo = PrimeField(backend=hip_backend), PrimeField(backend=oracle_omp_backend)
+    w = fh.getRootOfUnity(n)
+    raw = _dense_input(fh, n, 0xfedcba9876543210fedcba987654321).toBuffer()
+    k = to_bytes(rand_elements(rng, 64))
+    coeffs = to_bytes(rng.randrange(P) for _ in range(4))
+    ipoly = to_bytes(rng.randrange(P) for _ in range(2))
+    lc = to_bytes(rng.randrange(P) for _ in range(2))
+    roots = (C.c_uint64 * 2)(0, (steps - 1) * (n // steps))
+    outs = []
+    for be, f in ((hip_backend, fh), (oracle_omp_backend, fo)):
+        p, kv, out = f.newVector(n), f.newVector(64), f.newVector(n)
+        be.upload(p.ptr, raw); be.upload(kv.ptr, k)
+        be.call('gs_mimc_composition', C.c_void_p(p.ptr), n, steps, w.to_bytes(16, 'little'), C.c_void_p(kv.ptr), 64, coeffs, 2 * steps, 2 * steps,
+                ipoly, roots, 2, lc, C.c_void_p(out.ptr))
+        outs.append(out.toBuffer())
+    assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize('logn,depth', [(22, 0), (24, 0), (24, 1)])
+def test_fri_fold_bytes_equal_oracle_at_headline_sizes(hip_backend, oracle_omp_backend, logn, depth):
+    """gs_fri_fold on the first layers of the headline configuration: every folded value against the oracle's Lagrange
+    interpolation + Horner evaluation per row (lib/components/LowDegreeProver.ts:189-198)."""
+    n = 1 << logn
+    step = 4 ** depth
+    m = n // step
+    fh, fo = PrimeField(backend=hip_backend), PrimeField(backend=oracle_omp_backend)
+    w = fh.getRootOfUnity(n)
+    raw = _dense_input(fh, m, 0x31415926535897932384626433).toBuffer()
+    x = (0x2718281828459045235360287471352 % P).to_bytes(16, 'little')
+    outs = []
+    for be, f in ((hip_backend, fh), (oracle_omp_backend, fo)):
+        col, out = f.newVector(m), f.newVector(m // 4)
+        be.upload(col.ptr, raw)
+        be.call('gs_fri_fold', w.to_bytes(16, 'little'), n, step, C.c_void_p(col.ptr), m, x, C.c_void_p(out.ptr))
+        outs.append(out.toBuffer())
+    assert outs[0] == outs[1]
+
+
+def test_merkle_root_equals_oracle_at_2p24(hip_backend, oracle_omp_backend):
+    """leaf hashing + the whole tree over 2^24 rows (lib/Stark.ts:115-118): every node of the HIP tree equals the oracle's."""
+    n = 1 << 24
+    fh, fo = PrimeField(backend=hip_backend), PrimeField(backend=oracle_omp_backend)
+    raw = _dense_input(fh, n, 0x5eed5eed5eed5eed5eed5eed5eed).toBuffer()
+    nodes = []
+    for be, f in ((hip_backend, fh), (oracle_omp_backend, fo)):
+        v = f.newVector(n)
+        be.upload(v.ptr, raw)
+        leaves, tree = be.alloc(32 * n), be.alloc(32 * n)
+        ptrs = (C.c_void_p * 1)(v.ptr)
+        be.call('gs_hash_merge_rows', 1, ptrs, 1, n, C.c_void_p(leaves))       # blake2s256 = 1
+        be.call('gs_merkle_build', 1, C.c_void_p(leaves), n, C.c_void_p(tree))
+        nodes.append(be.download(tree, 32 * n))
+        be.free(leaves); be.free(tree)
+    assert nodes[0][32:] == nodes[1][32:]       # node 0 is unused
+
+
+def test_lazy_field_arithmetic_on_the_device():
+    """tools/lazy_device_check: every routine of gf128_lazy.h (the arithmetic inside the NTT pass kernels) executed on the GPU on
+    2^20 lanes, each result compared on the device with the canonical fe_mul / fe_add / fe_sub of gf128.h."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(HERE), 'tools', 'lazy_device_check')
+    if not os.path.exists(exe):
+        pytest.fail('tools/lazy_device_check is missing: run __graft_entry__.build()')
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and ' 0 mismatching' in r.stdout, r.stdout + r.stderr
