@@ -72,6 +72,15 @@ __global__ void k_hash_merge_rows(HashPtrArgs va, uint32_t count, uint64_t n, ui
         store_digest(out, i, d);
     }
 }
+// more than GS_MAX_COMBINE columns: the pointer table sits in device memory (one uniform scalar load per column)
+template <int ALG>
+__global__ void k_hash_merge_rows_table(const uint4 *const *__restrict__ tab, uint32_t count, uint64_t n, uint4 *__restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t d[8];
+        digest_words16<ALG>([&](uint32_t w) { return tab[w / GS_EW][i * GS_EW + w % GS_EW]; }, count * GS_EW, d);
+        store_digest(out, i, d);
+    }
+}
 // single-column fast path (MiMC: one register): no pointer-table indirection
 template <int ALG>
 __global__ void k_hash_merge_rows1(const uint4 *__restrict__ v, uint64_t n, uint4 *__restrict__ out) {
@@ -160,8 +169,24 @@ int gs_hash_merge_rows(gs_ctx *c, gs_hash_alg alg, const void *const *vecs_host,
     if (!c || !vecs_host || !out) return GS_ERR_ARG;
     int rc = check_alg(c, alg);
     if (rc) return rc;
-    if (count == 0 || count > GS_MAX_COMBINE) return gs_fail(c, GS_ERR_ARG, "hash_merge_rows: count must be in 1..%d", GS_MAX_COMBINE);
+    if (count == 0) return gs_fail(c, GS_ERR_ARG, "hash_merge_rows: no vectors");
     if (!n) return GS_OK;
+    if (count > GS_MAX_COMBINE) {
+        // an AIR with more registers than fit the kernel-argument table: the pointers go to device memory first (a blocking copy of
+        // 8 bytes per register; every column of a row is still hashed in one pass)
+        void *tab = nullptr;
+        if ((rc = gs_tmp_alloc(c, (uint64_t)count * sizeof(void *), &tab))) return rc;
+        hipError_t e = hipMemcpyAsync(tab, vecs_host, (size_t)count * sizeof(void *), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // vecs_host belongs to the caller
+        if (e != hipSuccess) { gs_tmp_free(c, tab); return gs_fail(c, GS_ERR_DEVICE, "hash_merge_rows: pointer table upload: %s", hipGetErrorString(e)); }
+        if (alg == GS_HASH_SHA256)
+            hipLaunchKernelGGL(k_hash_merge_rows_table<0>, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const uint4 *const *)tab, count, n, (uint4 *)out);
+        else
+            hipLaunchKernelGGL(k_hash_merge_rows_table<1>, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const uint4 *const *)tab, count, n, (uint4 *)out);
+        gs_tmp_free(c, tab);      // stream-ordered reuse (common.h)
+        GS_LAUNCH_CHECK(c);
+        return GS_OK;
+    }
     if (count == 1) {
         if (alg == GS_HASH_SHA256)
             hipLaunchKernelGGL(k_hash_merge_rows1<0>, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const uint4 *)vecs_host[0], n, (uint4 *)out);

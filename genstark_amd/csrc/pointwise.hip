@@ -195,9 +195,11 @@ struct CombineArgs {  // vector pointers and coefficients travel as kernel argum
     const fe *v[GS_MAX_COMBINE];
     fe k[GS_MAX_COMBINE];
 };
-__global__ void k_combine_many(CombineArgs va, uint32_t count, uint64_t n, fe *__restrict__ out) {
+// accumulate: out already holds the sum over the previous batch of GS_MAX_COMBINE vectors (gs_combine_many splits longer lists)
+__global__ void k_combine_many(CombineArgs va, uint32_t count, uint64_t n, int accumulate, fe *__restrict__ out) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         fe s = fe_mul(va.v[0][i], va.k[0]);
+        if (accumulate) s = fe_add(s, out[i]);
         for (uint32_t j = 1; j < count; j++) s = fe_add(s, fe_mul(va.v[j][i], va.k[j]));
         out[i] = s;
     }
@@ -449,15 +451,21 @@ int gs_vec_exp(gs_ctx *c, const void *a, const gs_elt *e, uint64_t n, void *out)
 
 int gs_combine_many(gs_ctx *c, const void *const *vecs_host, const uint8_t *coeffs_host, uint32_t count, uint64_t n, void *out) {
     if (!c || !vecs_host || !coeffs_host || !out) return GS_ERR_ARG;
-    if (count == 0 || count > GS_MAX_COMBINE) return gs_fail(c, GS_ERR_ARG, "combine_many: count must be in 1..%d", GS_MAX_COMBINE);
+    if (count == 0) return gs_fail(c, GS_ERR_ARG, "combine_many: no vectors");
     if (!n) return GS_OK;
-    CombineArgs va;
-    for (uint32_t j = 0; j < GS_MAX_COMBINE; j++) {
-        va.v[j] = (const fe *)vecs_host[j < count ? j : 0];
-        va.k[j] = j < count ? fe_from_bytes(coeffs_host + GS_ELT * j) : fe_zero();
+    // pointers and coefficients travel as kernel arguments, GS_MAX_COMBINE per launch; a longer list (an AIR with more than 32
+    // registers: LinearCombination.ts:36-64 combines 2*(registers) vectors) goes in batches that accumulate into `out`.
+    // `out` must not alias an input of a LATER batch (it never does in the reference's call sites: the result is a new vector).
+    for (uint32_t base = 0; base < count; base += GS_MAX_COMBINE) {
+        const uint32_t m = count - base < GS_MAX_COMBINE ? count - base : GS_MAX_COMBINE;
+        CombineArgs va;
+        for (uint32_t j = 0; j < GS_MAX_COMBINE; j++) {
+            va.v[j] = (const fe *)vecs_host[base + (j < m ? j : 0)];
+            va.k[j] = j < m ? fe_from_bytes(coeffs_host + GS_ELT * (base + j)) : fe_zero();
+        }
+        hipLaunchKernelGGL(k_combine_many, dim3(gs_grid(n)), dim3(256), 0, c->stream, va, m, n, base ? 1 : 0, (fe *)out);
+        GS_LAUNCH_CHECK(c);
     }
-    hipLaunchKernelGGL(k_combine_many, dim3(gs_grid(n)), dim3(256), 0, c->stream, va, count, n, (fe *)out);
-    GS_LAUNCH_CHECK(c);
     return GS_OK;
 }
 
@@ -550,12 +558,16 @@ int gs_transpose_matrix(gs_ctx *c, const void *m, uint64_t rows, uint64_t cols, 
 
 int gs_sub_matrix_from_vectors(gs_ctx *c, const void *const *vecs_host, const void *m, uint32_t rows, uint64_t cols, void *out) {
     if (!c || !vecs_host || !m || !out) return GS_ERR_ARG;
-    if (rows == 0 || rows > GS_MAX_COMBINE) return gs_fail(c, GS_ERR_ARG, "sub_matrix_from_vectors: rows must be in 1..%d", GS_MAX_COMBINE);
+    if (rows == 0) return gs_fail(c, GS_ERR_ARG, "sub_matrix_from_vectors: no rows");
     if (!cols) return GS_OK;
-    PtrArgs va;
-    for (uint32_t j = 0; j < GS_MAX_COMBINE; j++) va.v[j] = (const fe *)vecs_host[j < rows ? j : 0];
-    hipLaunchKernelGGL(k_sub_matrix_from_vectors, dim3(gs_grid(cols), rows), dim3(256), 0, c->stream, va, (const fe *)m, cols, (fe *)out);
-    GS_LAUNCH_CHECK(c);
+    for (uint32_t base = 0; base < rows; base += GS_MAX_COMBINE) {       // rows are independent: GS_MAX_COMBINE pointers per launch
+        const uint32_t r = rows - base < GS_MAX_COMBINE ? rows - base : GS_MAX_COMBINE;
+        PtrArgs va;
+        for (uint32_t j = 0; j < GS_MAX_COMBINE; j++) va.v[j] = (const fe *)vecs_host[base + (j < r ? j : 0)];
+        hipLaunchKernelGGL(k_sub_matrix_from_vectors, dim3(gs_grid(cols), r), dim3(256), 0, c->stream, va, (const fe *)m + (uint64_t)base * cols, cols,
+                           (fe *)out + (uint64_t)base * cols);
+        GS_LAUNCH_CHECK(c);
+    }
     return GS_OK;
 }
 

@@ -63,7 +63,8 @@ typedef uint8_t gs_elt;       /* first byte of one field element in HOST memory:
 
 #define GS_ELEMENT_BYTES 16   /* of the main (128-bit) library; gs_element_size() is authoritative */
 #define GS_DIGEST_BYTES 32
-#define GS_MAX_COMBINE 64     /* max vectors in gs_combine_many / gs_hash_merge_rows */
+#define GS_MAX_COMBINE 64     /* vectors per kernel launch of gs_combine_many / gs_hash_merge_rows / gs_sub_matrix_from_vectors: longer lists
+                                 (AIRs with more than 32 registers) are accepted and split inside the library */
 
 /* ---- context / memory -------------------------------------------------------------------------
  * Replaces: the galois wasm linear memory handed over as `wasmOptions.memory`

@@ -192,7 +192,7 @@ int gs_vec_exp(gs_ctx *c, const void *a, const gs_elt *e, uint64_t n, void *o) {
     return GS_OK;
 }
 int gs_combine_many(gs_ctx *c, const void *const *vecs, const uint8_t *coeffs, uint32_t count, uint64_t n, void *o) {
-    if (count == 0 || count > GS_MAX_COMBINE) return fail(c, GS_ERR_ARG, "combine_many: bad count");
+    if (count == 0) return fail(c, GS_ERR_ARG, "combine_many: bad count");
     PAR_FOR
     for (uint64_t i = 0; i < n; i++) {
         fe s = 0;
@@ -450,12 +450,14 @@ int gs_hash_digest(gs_ctx *c, gs_hash_alg alg, const uint8_t *msg, uint64_t len,
     (void)c; orc_hash((int)alg, msg, (size_t)len, out); return GS_OK;
 }
 int gs_hash_merge_rows(gs_ctx *c, gs_hash_alg alg, const void *const *vecs, uint32_t count, uint64_t n, void *out) {
-    if (count == 0 || count > GS_MAX_COMBINE) return fail(c, GS_ERR_ARG, "hash_merge_rows: bad count");
+    if (count == 0) return fail(c, GS_ERR_ARG, "hash_merge_rows: bad count");
     PAR_FOR
     for (uint64_t i = 0; i < n; i++) {
-        uint8_t buf[FE_BYTES * GS_MAX_COMBINE];
+        uint8_t small[FE_BYTES * GS_MAX_COMBINE], *buf = count <= GS_MAX_COMBINE ? small : (uint8_t *)malloc(FE_BYTES * (size_t)count);
+        if (!buf) abort();
         for (uint32_t j = 0; j < count; j++) memcpy(buf + FE_BYTES * j, (const uint8_t *)vecs[j] + FE_BYTES * i, FE_BYTES);
         orc_hash((int)alg, buf, FE_BYTES * (size_t)count, (uint8_t *)out + 32 * i);
+        if (buf != small) free(buf);
     }
     return GS_OK;
 }

@@ -331,7 +331,9 @@ def check_hashing(backend, rng, alg, n):
     for size in (16, 32, 64, 96, 128, 192):
         msg = bytes(rng.randrange(256) for _ in range(size))
         assert h.digest(msg) == H(msg) == h.digestOnDevice(msg)        # gs_hash_digest (device) and the host runtime agree
-    for k in (1, 2, 3, 6, 12):
+    for k in (1, 2, 3, 6, 12, 64, 65, 100):      # above GS_MAX_COMBINE = 64 the library switches to a pointer table in device memory
+        if k > 12 and n > 256:
+            continue
         cols = [rand_elements(rng, n) for _ in range(k)]
         got = h.mergeVectorRows([f.newVectorFrom(c) for c in cols]).toBuffer()
         for i in sorted(set([0, n - 1] + [rng.randrange(n) for _ in range(8)])):
@@ -427,3 +429,18 @@ def check_rescue_kat(backend):
     import rescue_kat
     assert rescue_kat.run(VecScalarField(backend)) == (302524937772545017647250309501879538110,
                                                        205025454306577433144586673939030012640)
+
+
+def check_many_vectors(backend, rng, n, count):
+    """combineManyVectors / subMatrixElementsFromVectors with more vectors than one kernel launch carries (GS_MAX_COMBINE = 64):
+    an AIR with more than 32 registers (LinearCombination.ts:36-64 combines 2 * registers vectors) must prove like any other."""
+    f = field_for(backend)
+    cols = [rand_elements(rng, n) for _ in range(count)]
+    ks = [rng.randrange(P) for _ in range(count)]
+    vecs = [f.newVectorFrom(c) for c in cols]
+    got = f.combineManyVectors(vecs, ks).toValues()
+    assert got == [sum(c[i] * k for c, k in zip(cols, ks)) % P for i in range(n)]
+    m = f.newMatrixFrom([rand_elements(rng, n) for _ in range(count)])
+    diff = f.subMatrixElementsFromVectors(vecs, m)
+    mv = m.toValues()
+    assert diff.toValues() == [[(cols[r][i] - mv[r][i]) % P for i in range(n)] for r in range(count)]

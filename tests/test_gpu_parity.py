@@ -344,6 +344,11 @@ def test_randomized_differential_hip_vs_oracle(hip_backend, oracle_backend, seed
                                f.mulPolys(f.newVectorFrom(vec[:90]), f.newVectorFrom(vec[-80:] if n >= 80 else vec)).toBuffer()])
 
 
+@pytest.mark.parametrize('n,count', [(33, 65), (1000, 150)])
+def test_more_vectors_than_one_launch_carries(hip_backend, rng, n, count):
+    cases.check_many_vectors(hip_backend, rng, n, count)
+
+
 # ---- (e) byte parity with the C oracle AT the headline sizes -----------------------------
 # The oracle's loops are annotated for OpenMP (oracle/liboracle_omp.so: the same oracle_abi.c built with -fopenmp); on the GPU box's
 # host cores its 2^24-point transforms take seconds, so the comparison below is on EVERY output byte, not on properties.

@@ -105,3 +105,8 @@ def test_kat_rescue_4x128():
 
 def test_kat_rescue_4x128_through_oracle_kernels(oracle_backend):
     cases.check_rescue_kat(oracle_backend)
+
+
+@pytest.mark.parametrize('n,count', [(33, 65), (1000, 150)])
+def test_more_vectors_than_one_launch_carries(oracle_backend, rng, n, count):
+    cases.check_many_vectors(oracle_backend, rng, n, count)
