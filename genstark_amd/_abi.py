@@ -143,6 +143,7 @@ class Backend:
             raise GstarkError(f'gs_ctx_create(device={device}) failed with {rc}: no gfx950 device? (no CPU fallback)')
         self.ctx = ctx
         self.device = device
+        self.stats = {}      # see call()
 
     def jit(self, enable=True):
         """Compile AIR programs (gs_air_jit) instead of interpreting them: for a prover that serves many proofs of one AIR."""
@@ -159,6 +160,16 @@ class Backend:
             self.ctx = None
 
     def call(self, name, *args):
+        # transform work launched through this backend, counted the way the native driver counts its own (gs_prover_last_stats):
+        # rows * n points per call, Horner-served calls (fewer than 256 points, or at most 8 coefficients) apart
+        if name == 'gs_eval_polys_at_roots':
+            rows, plen, n = int(args[1]), int(args[2]), int(args[4])
+            key = 'ntt_points' if n >= 256 and plen > 8 else 'horner_points'
+            self.stats[key] = self.stats.get(key, 0) + rows * n
+        elif name == 'gs_interpolate_roots':
+            rows, n = int(args[1]), int(args[3])
+            key = 'ntt_points' if n >= 256 else 'horner_points'
+            self.stats[key] = self.stats.get(key, 0) + rows * n
         rc = getattr(self.lib, name)(self.ctx, *args)
         if rc != GS_OK:
             raise GstarkError(f'{name} failed ({rc}): {self.lib.gs_last_error(self.ctx).decode()}')

@@ -40,11 +40,45 @@ class _Comm:
         if self.world & (self.world - 1):
             raise GstarkError('world size must be a power of two')
 
-    def all_gather_object(self, obj):
-        if self.world == 1:
-            return [obj]
-        out = [None] * self.world
-        dist.all_gather_object(out, obj, group=self.group)
+    def _xdev(self, backend):
+        """where exchange buffers live: the rank's GPU under RCCL; host memory under gloo (CPU tests, or several ranks sharing the
+        one GPU of a test box)"""
+        if backend.name != 'hip-gfx950' or (self.world > 1 and dist.get_backend(self.group) == 'gloo'):
+            return 'cpu'
+        return torch.device('cuda', backend.device)
+
+    def all_gather_bytes(self, backend, payload, size):
+        """Every rank contributes exactly `size` bytes (shorter payloads are zero-padded): ONE all_gather_into_tensor of a
+        (world, size) uint8 tensor — RCCL over xGMI on the GPU box, no pickling, no per-call staging through Python objects.
+        Returns the `world` contributions as bytes objects."""
+        if len(payload) > size:
+            raise GstarkError('all_gather_bytes: payload longer than the agreed size')
+        if self.world == 1 or size == 0:
+            return [bytes(payload) + bytes(size - len(payload))] * (1 if self.world == 1 else self.world)
+        dev = self._xdev(backend)
+        mine = torch.frombuffer(bytearray(bytes(payload) + bytes(size - len(payload))), dtype=torch.uint8)
+        if dev != 'cpu':
+            mine = mine.to(dev)
+        out = torch.empty(self.world * size, dtype=torch.uint8, device=dev)      # flat: rank r's contribution at [r*size, (r+1)*size)
+        dist.all_gather_into_tensor(out, mine, group=self.group)
+        raw = out.cpu().numpy().tobytes()
+        return [raw[r * size:(r + 1) * size] for r in range(self.world)]
+
+    def gather_owned(self, backend, owners, mine_bytes, item_bytes):
+        """`owners[i]` is the rank that holds item i (a deterministic plan, identical on every rank); `mine_bytes` are this rank's
+        items in plan order.  One fixed-size all-gather (every rank pads to the largest share) returns all items in plan order."""
+        counts = [0] * self.world
+        for o in owners:
+            counts[o] += 1
+        if len(mine_bytes) != counts[self.rank]:
+            raise GstarkError('gather_owned: this rank did not produce its share of the plan')
+        parts = self.all_gather_bytes(backend, b''.join(mine_bytes), max(counts) * item_bytes if counts else 0)
+        taken = [0] * self.world
+        out = []
+        for o in owners:
+            k = taken[o]
+            out.append(parts[o][k * item_bytes:(k + 1) * item_bytes])
+            taken[o] = k + 1
         return out
 
 
@@ -76,10 +110,7 @@ class DistVector:
         indexes = list(indexes)
         mine = [i for i in indexes if i % comm.world == comm.rank]
         got = self.local.backend.gather(self.local.ptr, self.elementSize, [i // comm.world for i in mine])
-        merged = {}
-        for part in comm.all_gather_object(dict(zip(mine, got))):
-            merged.update(part)
-        return [merged[i] for i in indexes]
+        return comm.gather_owned(self.local.backend, [i % comm.world for i in indexes], got, self.elementSize)
 
     def getValue(self, index):
         return int.from_bytes(self.valuesAt([index])[0], 'little')
@@ -87,7 +118,8 @@ class DistVector:
     def toBuffer(self):
         """The whole vector in natural order on the host (collective; remainder-sized vectors and tests only)."""
         comm = self.field.comm
-        parts = comm.all_gather_object(self.local.toBuffer())
+        mine = self.local.toBuffer()
+        parts = comm.all_gather_bytes(self.local.backend, mine, len(mine))
         es, m = self.elementSize, self.local.length
         out = bytearray(self.length * es)
         for g, raw in enumerate(parts):
@@ -126,15 +158,13 @@ class DistRowMatrix:
         indexes = list(indexes)
         mine = [i for i in indexes if i % comm.world == comm.rank]
         got = self.local.rowsToBuffers([i // comm.world for i in mine])
-        merged = {}
-        for part in comm.all_gather_object(dict(zip(mine, got))):
-            merged.update(part)
-        return [merged[i] for i in indexes]
+        return comm.gather_owned(self.field.backend, [i % comm.world for i in indexes], got, self.colCount * ELEMENT_SIZE)
 
     def toReplicated(self):
         """All rows on every rank (collective; the <= 64-row FRI remainder)."""
         comm, f = self.field.comm, self.field
-        parts = comm.all_gather_object(self.local.toBuffer())
+        mine = self.local.toBuffer()
+        parts = comm.all_gather_bytes(f.backend, mine, len(mine))
         rb = self.colCount * ELEMENT_SIZE
         out = bytearray(self.rowCount * rb)
         for g, raw in enumerate(parts):
@@ -432,7 +462,7 @@ class ShardedMerkleTree:
         self.leaves = Vector(backend, m, owner=self._blocked_owner, element_size=DIGEST_SIZE)
         self.sub = MerkleTree.create(self.leaves, hash_)
         # ---- top of the tree on every rank
-        roots = comm.all_gather_object(self.sub.root)
+        roots = comm.all_gather_bytes(backend, self.sub.root, DIGEST_SIZE)      # G sub-roots, 32 B each: one all-gather
         self.top = {g + h: roots[h] for h in range(g)}
         level = roots
         width = g
@@ -466,11 +496,19 @@ class ShardedMerkleTree:
         cols = batch_proof_plan(self.n, indexes)
         wanted = [('leaf', i) for i in indexes] + [e for col in cols for e in col]
         comm, backend = self.comm, self.field.backend
-        mine_leaf, mine_node = [], []
+        # the plan (which digest, on which rank) is the same on every rank; each rank gathers its share on its device and ONE
+        # fixed-size all-gather assembles the proof everywhere
+        plan, owners = [], []
+        seen = set()
         for kind, ix in wanted:
             owner, lk, li = self._owner_of(kind, ix)
-            if owner == comm.rank:
-                (mine_leaf if lk == 'leaf' else mine_node).append(((kind, ix), li))
+            if owner is None or (kind, ix) in seen:
+                continue
+            seen.add((kind, ix))
+            plan.append(((kind, ix), lk, li))
+            owners.append(owner)
+        mine_leaf = [(key, li) for (key, lk, li), o in zip(plan, owners) if o == comm.rank and lk == 'leaf']
+        mine_node = [(key, li) for (key, lk, li), o in zip(plan, owners) if o == comm.rank and lk == 'node']
         got = {}
         if mine_leaf:
             raw = backend.gather(self.leaves.ptr, DIGEST_SIZE, [li for _, li in mine_leaf])
@@ -478,9 +516,8 @@ class ShardedMerkleTree:
         if mine_node:
             raw = backend.gather(self.sub.nodes.ptr, DIGEST_SIZE, [li for _, li in mine_node])
             got.update({key: d for (key, _), d in zip(mine_node, raw)})
-        merged = {}
-        for part in comm.all_gather_object(got):
-            merged.update(part)
+        mine_in_plan_order = [got[key] for (key, _, _), o in zip(plan, owners) if o == comm.rank]
+        merged = dict(zip([key for key, _, _ in plan], comm.gather_owned(backend, owners, mine_in_plan_order, DIGEST_SIZE)))
 
         def fetch(kind, ix):
             owner, lk, li = self._owner_of(kind, ix)
