@@ -23,6 +23,7 @@ build_flavour() {   # <object dir> <output> <extra flags>
     if [ $need = 1 ]; then $HIPCC $FLAGS $extra -c $f.hip -o $dir/$f.o & pids+=($!); stale=1; fi
   done
   for p in "${pids[@]}"; do wait $p; done
+  for f in $UNITS; do [ $dir/$f.o -nt $out ] && stale=1; done      # an object compiled by hand is newer than the library too
   if [ $stale = 1 ] || [ ! -f $out ]; then
     $HIPCC --offload-arch=gfx950 -shared -fPIC -o $out $(for f in $UNITS; do echo $dir/$f.o; done) -lhiprtc
   fi

@@ -197,6 +197,25 @@ __device__ __forceinline__ void ntt_dif_lz(lz (&x)[1 << LOGN], lzw_cptr w, const
     if constexpr (LOGN > 0) ntt_dif_lz_level<LOGN, (1 << LOGN) / 2>(x, w, K);
 }
 
+// lz_pack with the canonical / weak choice as a lane-uniform runtime flag, branch-free: the final "- p when >= p" is computed
+// either way (8 operations) and taken only when asked for — a branch per element would split the unrolled stage into 32 blocks
+__device__ __forceinline__ fe lz_pack_flag(const lz &x, int weak) {
+    const fe r = lz_pack_weak(x);
+    uint32_t c;
+    fe s2;
+    s2.w0 = gf_addc(r.w0, 0xFFFFFFFFu, 0u, c);
+    s2.w1 = gf_addc(r.w1, 8u, c, c);
+    s2.w2 = gf_addc(r.w2, 0u, c, c);
+    s2.w3 = gf_addc(r.w3, 0u, c, c);
+    const bool take = c && !weak;
+    fe o;
+    o.w0 = take ? s2.w0 : r.w0;
+    o.w1 = take ? s2.w1 : r.w1;
+    o.w2 = take ? s2.w2 : r.w2;
+    o.w3 = take ? s2.w3 : r.w3;
+    return o;
+}
+
 // word index of element e in one limb plane of the exchange buffer (see the header comment)
 __device__ __forceinline__ int lz_slot(int e, int logWj) {
     if (logWj >= 5 || logWj == 0) return e;
@@ -351,6 +370,159 @@ __global__ __launch_bounds__(128, 2) void k_ntt_pass_lz(const fe *__restrict__ i
     for (int e = t; e < R * Wj; e += T) {
         const int ej = e / R, eq = e % R;
         tile[e] = ldsf[ej * (R + 1) + eq];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same pass as ONE WAVE per tile (R x Wj elements with RB * Wj = 64, i.e. 1024 elements): the sixteen threads that exchange
+// their radix-16 outputs sit in the same wave, so the exchange needs no workgroup barrier, and it goes through LDS one LIMB PLANE
+// at a time (write the 16 words of limb l, read back the 16 words of limb l of the other side; an in-order LDS queue per wave
+// makes that safe): 4 KiB of LDS per wave instead of 20.  What limits occupancy is then the register file alone: at <= 128 VGPRs
+// four waves per SIMD are resident, where the 128-thread kernel above has two (tools/microbench5: a radix-16 network takes
+// 2.3 us per wave at four waves per SIMD, 3.0 us at two).
+// Global accesses are 64 >> LB elements wide per row (LB = 4: 64 bytes); adjacent tiles are given to workgroups b and b + 8, which
+// the dispatcher places on the same XCD one after the other, so the two halves of a 128-byte line meet in that XCD's L2.
+// The first pass writes its tile (contiguous in q for RB = 16) straight from registers; first passes of other radices keep the
+// workgroup kernel (their stores would be 16-byte pieces).
+template <int LB, int TW>
+__global__ __launch_bounds__(64, TW == 0 ? 4 : 3) void k_ntt_wave(const fe *__restrict__ in, fe *__restrict__ out, LzPassArgs a) {
+    constexpr int RB = 1 << LB, R = 16 * RB, GB = 16 / RB, LOGWJ = 6 - LB, Wj = 64 >> LB;
+    constexpr bool FIRST = (TW == 0);
+    static_assert(!FIRST || LB == 4, "first passes of radix below 256 use k_ntt_pass_lz");
+    // one limb plane of the tile.  Element (qa, k2, jj) lives at word g*17*Wj + (u*RB + k2)*Wj + jj with qa = g*GB + u: one padding
+    // row of Wj words per reader group g keeps the reads conflict-free (g*17*Wj mod 32 = g*Wj), and both sides address it as
+    // ONE per-lane base plus a compile-time offset (no per-element address registers)
+    __shared__ int32_t plane[17 * 64];
+    const lzk K = lzk_make();
+    const int t = threadIdx.x;
+    const int jj = t & (Wj - 1);
+    const int kk = t >> LOGWJ;  // < RB
+    uint32_t tile = blockIdx.x;
+    if ((gridDim.x & 15) == 0) tile = (tile & ~15u) | ((tile & 7u) << 1) | ((tile >> 3) & 1u);   // blocks b, b + 8 (same XCD) <-> tiles 2i, 2i + 1
+    const uint64_t j = (uint64_t)tile * Wj + jj;
+    const uint64_t nR = a.n >> (4 + LB);
+    const fe *src = in + (uint64_t)blockIdx.y * a.in_stride;
+    fe *dst = out + (uint64_t)blockIdx.y * a.out_stride;
+    const uint64_t Ns = 1ull << a.logNs;
+    const uint64_t jq = j & (Ns - 1);
+
+    lz v[16];
+    const bool pruned = FIRST && a.in_len <= nR * RB;
+    if (pruned) {
+        const uint64_t idx = j + (uint64_t)kk * nR;
+        const fe x0 = src[idx < a.in_len ? idx : 0];
+        v[0] = lz_unpack(x0);
+        if (idx >= a.in_len) v[0] = lz_unpack(fe_zero());
+#pragma unroll
+        for (int m = 1; m < 16; m++) v[m] = v[0];
+    } else {
+        fe raw[16];
+        if (!FIRST || a.in_len >= a.n) {
+#pragma unroll
+            for (int m = 0; m < 16; m++) raw[m] = src[j + (uint64_t)(kk + RB * m) * nR];
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                const uint64_t idx = j + (uint64_t)(kk + RB * m) * nR;
+                raw[m] = src[idx < a.in_len ? idx : 0];
+                if (idx >= a.in_len) raw[m] = fe_zero();
+            }
+        }
+        if constexpr (TW == 1) {
+            // twiddle [k][jq] for k = kk + RB*m: all sixteen requested at once, like the data (the table sits in L2, but a load is
+            // still several product-times away; with three waves per SIMD the 168-VGPR budget holds both sets of 64)
+            const fe *tp = a.twp + ((uint64_t)kk << a.logNs) + jq;
+            const uint64_t tstep = (uint64_t)RB << a.logNs;
+            fe tws[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) { tws[m] = *tp; tp += tstep; }
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                v[m] = lz_mul_v(lz_unpack(raw[m]), lz_unpack(tws[m]), K);
+                if (m & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (TW == 2) {
+            const uint64_t eu = a.n >> (a.logNs + 4 + LB);
+            lz cur = lz_pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * kk * eu, K);
+            lz row = lz_pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * RB * eu, K);
+            lzw step;
+#pragma unroll
+            for (int r = 0; r < 5; r++) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    step.w[r][c] = row.l[c];
+                    asm volatile("" : "+v"(step.w[r][c]));      // see k_ntt_pass_lz
+                }
+                if (r < 4) row = lz_shift_limb(row, K);
+            }
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                __builtin_amdgcn_sched_barrier(0);
+                v[m] = lz_mul_v(lz_unpack(raw[m]), cur, K);
+                if (m < 15) cur = lz_mul_u(cur, step, K);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; m++) v[m] = lz_unpack(raw[m]);
+        }
+        ntt_dif_lz<4>(v, (lzw_cptr)a.wtab, K);
+    }
+
+    // The radix-16 network above needs ~125 of the 128 VGPRs four waves per SIMD leave: nothing else may live across it.  Lane and
+    // tile coordinates are therefore derived AGAIN from the thread index here (the asm makes the copy opaque, so the compiler
+    // cannot keep the earlier values alive instead of recomputing them).
+    int t2 = threadIdx.x;
+    asm volatile("" : "+v"(t2));
+    const int jj2 = t2 & (Wj - 1);
+    const int kk2 = t2 >> LOGWJ;
+    const uint64_t j2 = (uint64_t)tile * Wj + jj2;
+    const uint64_t jq2 = j2 & (Ns - 1);
+    const uint64_t jbase = (j2 - jq2) * R + jq2;
+    if constexpr (RB == 1) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            lz x = v[brev(q, 4)];
+            if (a.scale) { LZ_FENCE(); const lzw W = lz_load_w(a.wtab + 7); x = lz_mul_u(lz_norm(x), W, K); }
+            dst[jbase + (uint64_t)q * Ns] = lz_pack_flag(x, a.weak);
+        }
+    } else {
+        // ---- exchange twiddles in place, then the exchange itself, limb plane by limb plane
+        const int kx = kk2;
+#pragma unroll
+        for (int qa = 0; qa < 16; qa++) {
+            if ((qa & 1) == 0) { LZ_FENCE(); __builtin_amdgcn_sched_barrier(0); }
+            lz x = v[brev(qa, 4)];
+            if (qa == 0 || qa == 8) x = lz_norm(x);
+            if (qa != 0) x = lz_mul_v(x, lz_load8(a.wR + ((kx * qa) & (R - 1))), K);
+            else if (a.exq0) x = lz_mul_v(x, lz_load8(a.wR), K);
+            v[brev(qa, 4)] = x;
+        }
+        lz xb[GB][RB];
+#pragma unroll
+        for (int l = 0; l < 5; l++) {
+#pragma unroll
+            for (int qa = 0; qa < 16; qa++) plane[(qa / GB) * 17 * Wj + (qa % GB) * RB * Wj + t2] = v[brev(qa, 4)].l[l];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < GB; u++)
+#pragma unroll
+                for (int k2 = 0; k2 < RB; k2++) xb[u][k2].l[l] = plane[kk2 * 17 * Wj + jj2 + (u * RB + k2) * Wj];
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int u = 0; u < GB; u++) {
+            const int qa = kk2 * GB + u;
+            ntt_dif_lz<LB>(xb[u], (lzw_cptr)a.wtab, K);
+            // output q = qa + 16*qb: ONE running pointer, stepped by 16*Ns elements (16 separate 64-bit addresses would cost 32 VGPRs)
+            fe *o = FIRST ? dst + j2 * R + qa : dst + jbase + (uint64_t)qa * Ns;
+            const uint64_t ostep = FIRST ? 16 : (Ns << 4);
+#pragma unroll
+            for (int qb = 0; qb < RB; qb++) {
+                *o = lz_pack_flag(xb[u][brev(qb, LB)], a.weak);
+                o += ostep;
+                if ((qb & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
 }
 
@@ -680,6 +852,20 @@ static void launch_pass_lz(gs_ctx *c, const fe *in, fe *out, const LzPassArgs &a
     else hipLaunchKernelGGL((k_ntt_pass_lz<LB, 2>), dim3((unsigned)tiles, rows), dim3(RB * Wj), lds, c->stream, in, out, a);
 }
 
+template <int LB>
+static void launch_pass_wave(gs_ctx *c, const fe *in, fe *out, const LzPassArgs &a, uint32_t rows) {
+    constexpr int RB = 1 << LB, R = 16 * RB, Wj = 64 >> LB;
+    const uint64_t tiles = (a.n / R) / Wj;
+    if (a.logNs == 0) {
+        if constexpr (LB == 4) hipLaunchKernelGGL((k_ntt_wave<4, 0>), dim3((unsigned)tiles, rows), dim3(64), 0, c->stream, in, out, a);
+    } else if (a.twp) hipLaunchKernelGGL((k_ntt_wave<LB, 1>), dim3((unsigned)tiles, rows), dim3(64), 0, c->stream, in, out, a);
+    else hipLaunchKernelGGL((k_ntt_wave<LB, 2>), dim3((unsigned)tiles, rows), dim3(64), 0, c->stream, in, out, a);
+}
+static bool ntt_wave_enabled() {   // GSTARK_NTT_WAVE=0 keeps the 128-thread workgroup kernel everywhere (A/B measurements)
+    const char *e = getenv("GSTARK_NTT_WAVE");
+    return !(e && e[0] == '0');
+}
+
 static bool ntt_lazy_enabled() {   // GSTARK_NTT_LAZY=0 keeps the canonical-limb kernel (A/B measurements)
     const char *e = getenv("GSTARK_NTT_LAZY");   // read per call: tools/ntt_ab.py flips it inside one process
     return !(e && e[0] == '0');
@@ -762,6 +948,17 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
                 }
             }
             a.wtab = p->wtab;
+            const bool wave = ntt_wave_enabled() && n >= 1024 && (logNs > 0 || LB == 4);
+            if (wave) {
+                a.logWj = 6 - LB;
+                switch (LB) {
+                    case 0: launch_pass_wave<0>(c, src, dst, a, rows); break;
+                    case 1: launch_pass_wave<1>(c, src, dst, a, rows); break;
+                    case 2: launch_pass_wave<2>(c, src, dst, a, rows); break;
+                    case 3: launch_pass_wave<3>(c, src, dst, a, rows); break;
+                    default: launch_pass_wave<4>(c, src, dst, a, rows); break;
+                }
+            } else
             switch (LB) {
                 case 0: launch_pass_lz<0>(c, src, dst, a, rows); break;
                 case 1: launch_pass_lz<1>(c, src, dst, a, rows); break;
