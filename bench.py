@@ -143,17 +143,19 @@ def second_roof(n, transform_ms, npass):
         m = json.loads(r.stdout.strip().splitlines()[-1])
     except Exception as e:   # noqa: BLE001
         return {'error': repr(e)[:200]}
-    occ = 2                                           # waves per SIMD of k_ntt_pass_lz (LDS: four 128-thread workgroups per CU)
-    dif, mulv, pack = m['dif16_network_ns'][occ - 1], m['mul_v_ns'][occ - 1], m['pack_unpack_add_ns'][occ - 1]
-    per_wave_pass_first = 2 * dif + 15 * mulv + 16 * pack          # ns of pure arithmetic per wave (64 lanes x 16 elements) per pass
-    per_wave_pass_later = per_wave_pass_first + 16 * mulv
+    # waves per SIMD of k_ntt_wave: 4 on a first pass (<= 128 VGPRs), 3 on the passes that carry input twiddles (<= 168)
+    o1, o2 = 4, 3
+    per_wave_pass_first = 2 * m['dif16_network_ns'][o1 - 1] + 15 * m['mul_v_ns'][o1 - 1] + 16 * m['pack_unpack_add_ns'][o1 - 1]
+    per_wave_pass_later = 2 * m['dif16_network_ns'][o2 - 1] + 31 * m['mul_v_ns'][o2 - 1] + 16 * m['pack_unpack_add_ns'][o2 - 1]
+    dif, mulv, pack, occ = m['dif16_network_ns'], m['mul_v_ns'], m['pack_unpack_add_ns'], [o1, o2]
     waves = n / 16 / 64
     simds = m['cus'] * 4
     floor_ms = (per_wave_pass_first + (npass - 1) * per_wave_pass_later) * waves / simds * 1e-6
     return {'bound': 'valu-issue', 'unit': 'ms per transform', 'peak': round(floor_ms, 4), 'achieved': round(transform_ms, 4),
             'frac': round(floor_ms / transform_ms, 4),
-            'measured_ns_per_wave': {'radix16_network_17_products_64_addsub_16_norm': dif, 'per_lane_product': mulv, 'pack_unpack_add': pack,
-                                     'canonical_limb_fe_mul_for_reference': m['fe_mul_ns'][occ - 1], 'waves_per_simd': occ},
+            'measured_ns_per_wave_at_1_2_3_4_waves_per_simd': {'radix16_network_17_products_64_addsub_16_norm': dif, 'per_lane_product': mulv,
+                                                               'pack_unpack_add': pack, 'canonical_limb_fe_mul_for_reference': m['fe_mul_ns']},
+            'kernel_waves_per_simd': {'first_pass': occ[0], 'twiddled_passes': occ[1]},
             'note': 'peak = time the kernel\'s own instruction stream needs with no memory stall at all (registers-only microbenchmark of '
                     'the same routines at the same occupancy, same run); frac = peak / achieved = share of the kernel time that is '
                     'arithmetic issue'}

@@ -30,7 +30,7 @@ for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
     if not files:
         raise SystemExit(f'no counter file under {d}')
     for row in csv.DictReader(open(files[0])):
-        if 'k_ntt_pass' not in row['Kernel_Name'] or row['Counter_Name'] != counter:
+        if 'k_ntt_' not in row['Kernel_Name'] or row['Counter_Name'] != counter:
             continue
         name = row['Kernel_Name'].split('(')[0].replace('void ', '')
         per_kernel.setdefault(name, {}).setdefault(counter, []).append(float(row['Counter_Value']))
