@@ -448,6 +448,36 @@ class GenericAir:
     def initProvingContext(self, inputs=None, seed=None):
         return GenericProvingContext(self, self.firstRows(seed), inputs)
 
+    def descriptor(self, seed=None):
+        """The AIR as plain JSON-able data for the node-side twin (js/air_generic.js, reached by the reference's Stark.js through
+        `instantiate({generic: ...})` of js/shims/@guildofweavers/air-assembly): field, trace shape, static registers and the three
+        programs in the {op, dst, a, b} encoding of include/gstark.h; integers that may exceed 2^53 travel as decimal strings.
+        The node side builds first rows by zero-padding prove()'s seed; an AIR whose init() does anything else must pass the
+        `seed` it will be proved with, and the rows init() gives for it are pinned in the descriptor instead."""
+        if self.secretInputCount:
+            raise GstarkError('secret input registers have no node-side twin')
+        prog = lambda pr: None if pr is None else {'code': [w for ins in pr.code for w in ins], 'consts': [str(v) for v in pr.consts],
+                                                   'nregs': pr.nregs, 'nout': pr.nout}
+        d = {'modulus': str(self.field.modulus), 'steps': self.steps, 'registers': self.traceRegisterCount,
+             'constraintDegrees': list(self.constraintDegrees), 'extensionFactor': self.extensionFactor, 'secretInputCount': 0,
+             'staticRegisters': [[str(v) for v in values] for values in self.staticRegisters],
+             'transition': prog(self.transitionProgram), 'evaluation': prog(self.evaluationProgram), 'init': prog(self.initProgram)}
+        if self.segmentLength is not None:
+            d['segmentLength'] = self.segmentLength
+        if seed is not None:
+            d['firstRows'] = [[str(v % self.field.modulus) for v in row] for row in self.firstRows(seed)]
+            return d
+        for width in range(self.traceRegisterCount + 1):          # which seed width does init() zero-pad?
+            probe = list(range(3, 3 + width))
+            try:
+                row = [v % self.field.modulus for v in self.init(probe)]
+            except Exception:
+                continue
+            if row == probe + [0] * (self.traceRegisterCount - width):
+                d['seedWidth'] = width
+                return d
+        raise GstarkError('init() is not a zero-padding of the seed: pass the seed to pin the first rows in the descriptor')
+
     def initVerificationContext(self, inputShapes=None, publicInputs=None):
         return GenericVerificationContext(self)
 

@@ -1,0 +1,60 @@
+"""Rescue 4x128 / Poseidon 6x128 proofs shared by the fixture generator (tests/golden/make_golden.py), the reference-driver tests
+(tests/test_reference_driver.py) and the N-API tests: what is proved (`GENERIC_CASES`), how the AIR and its assertions are built
+on a backend (`build`), and the case record the node runner (tests/golden/run_reference_stark.js) takes (`node_case`)."""
+from genstark_amd import poseidon
+from genstark_amd.field import PrimeField
+from genstark_amd.rescue import rescue4x128_air
+from genstark_amd.stark import Stark
+
+RESCUE_OPTS = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 68, 'friQueryCount': 24}     # hash4x128.ts:41-47
+POSEIDON_OPTS = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 68, 'friQueryCount': 24}   # hash6x128.ts:35-41
+
+# name -> (kind, steps, segmented).  The last two are BASELINE.json's C3 / C4 shapes: 2^16 steps = 2 048 Rescue hashes of 32 steps,
+# 1 024 Poseidon hashes of 64 steps (one per Merkle-path node).
+GENERIC_CASES = {
+    'rescue_64': ('rescue', 64, False),
+    'rescue_seg_128': ('rescue', 128, True),
+    'poseidon_128': ('poseidon', 128, False),
+    'poseidon_seg_256': ('poseidon', 256, True),
+    'rescue_c3_65536': ('rescue', 1 << 16, True),
+    'poseidon_c4_65536': ('poseidon', 1 << 16, True),
+}
+SMALL = ['rescue_64', 'rescue_seg_128', 'poseidon_128', 'poseidon_seg_256']
+
+
+def build(name, backend):
+    """-> (air, stark, seed, assertions): assertions pin the first digest, the last one and a mid-trace value (host integers)."""
+    kind, steps, segmented = GENERIC_CASES[name]
+    f = PrimeField(backend=backend)
+    if kind == 'rescue':
+        air, per, opts = rescue4x128_air(steps, 16, f, segmented=segmented), 32, RESCUE_OPTS
+        seed = [[42 + s, 43 + 2 * s] for s in range(steps // per)] if segmented else [42, 43]
+        digest_regs = (0, 1)
+    else:
+        air, per, opts = poseidon.poseidon6x128_air(steps, 16, f, segmented=segmented), 64, POSEIDON_OPTS
+        seed = [[1 + s, 2, 3 + s, 4] for s in range(steps // per)] if segmented else [1, 2, 3, 4]
+        digest_regs = (0, 1)
+    if steps <= 4096:
+        full = air.hostTrace(seed)                       # host integers, independent of the backend
+    else:                                                # C3 / C4 shapes: the backend's own trace (itself checked against host integers at small sizes)
+        full = list(zip(*air.initProvingContext([], seed).generateExecutionTrace().toValues()))
+    last = steps - 1 if segmented else per - 1
+    assertions = [{'step': per - 1, 'register': r, 'value': full[per - 1][r]} for r in digest_regs]
+    assertions += [{'step': last, 'register': digest_regs[0], 'value': full[last][digest_regs[0]]}] if last != per - 1 else []
+    assertions += [{'step': steps // 2, 'register': air.traceRegisterCount - 1, 'value': full[steps // 2][air.traceRegisterCount - 1]}]
+    return air, Stark(air, opts), seed, assertions
+
+
+def node_case(name, backend):
+    """The record run_reference_stark.js takes: the AIR's descriptor + options + seed + assertions, big integers as decimal strings."""
+    air, stark, seed, assertions = build(name, backend)
+    kind, steps, segmented = GENERIC_CASES[name]
+    opts = RESCUE_OPTS if kind == 'rescue' else POSEIDON_OPTS
+    strs = lambda v: [strs(x) for x in v] if isinstance(v, list) else str(v)
+    try:
+        desc = air.descriptor()
+    except Exception:                         # init() does more than pad the seed (unsegmented Rescue): pin the first row
+        desc = air.descriptor(seed)
+    return {'name': name, 'generic': desc, 'extension_factor': opts['extensionFactor'], 'exe_query_count': opts['exeQueryCount'],
+            'fri_query_count': opts['friQueryCount'], 'hash_algorithm': opts['hashAlgorithm'], 'seed': strs(seed),
+            'assertions': [dict(a, value=str(a['value'])) for a in assertions]}

@@ -111,5 +111,41 @@ def run_reference_driver(oracle_cases, ref):
     os.remove(tmp_out)
 
 
+def run_reference_driver_generic(ref, names=None):
+    """reference_driver_generic.json: the reference's compiled Stark.js proving Rescue 4x128 / Poseidon 6x128 (tests/generic_cases.py,
+    up to BASELINE.json's C3 / C4 shapes) over the drop-in modules — `instantiate({generic: descriptor})` of
+    js/shims/@guildofweavers/air-assembly, js/air_generic.js, N-API, C ABI — on the CPU oracle backend.  Kept per proof: hash,
+    size, roots (the descriptors are re-derived from genstark_amd/rescue.py / poseidon.py by whoever checks)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import generic_cases
+    from genstark_amd._abi import Backend
+    subprocess.check_call(['bash', os.path.join(ROOT, 'napi', 'build.sh')])
+    subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), '-s'])
+    lib = os.path.join(ROOT, 'oracle', 'liboracle.so')
+    backend = Backend(lib_path=lib, allow_test_double=True)
+    names = names or list(generic_cases.GENERIC_CASES)
+    tmp_in, tmp_out = os.path.join(HERE, '_generic_cases.json'), os.path.join(HERE, '_generic_out.json')
+    with open(tmp_in, 'w') as f:
+        json.dump([generic_cases.node_case(n, backend) for n in names], f)
+    env = dict(os.environ, NODE_PATH=os.path.join(ROOT, 'js', 'shims'), GSTARK_LIB=lib, GSTARK_ALLOW_TEST_DOUBLE='1')
+    subprocess.check_call(['node', os.path.join(HERE, 'run_reference_stark.js'), os.path.join(ref, 'bin', 'lib'), tmp_in, tmp_out], env=env)
+    out = json.load(open(tmp_out))
+    for rec in out:
+        data = bytes.fromhex(rec.pop('proofHex'))
+        rec.pop('nativeDriverEqualsReference', None)
+        rec['proofSize'], rec['proofSha256'] = len(data), hashlib.sha256(data).hexdigest()
+    with open(os.path.join(HERE, 'reference_driver_generic.json'), 'w') as f:
+        json.dump({'generator': 'genSTARK bin/lib/Stark.js (unmodified) under node, over js/shims ({generic: descriptor}) + oracle backend; '
+                                'cases: tests/generic_cases.py', 'results': out}, f, indent=0)
+    os.remove(tmp_in)
+    os.remove(tmp_out)
+
+
 if __name__ == '__main__':
-    main()
+    import sys
+    if sys.argv[1:2] == ['generic']:
+        run_reference_driver_generic(os.environ.get('GENSTARK_REFERENCE', '/root/reference'), sys.argv[2:] or None)
+    else:
+        main()
+        run_reference_driver_generic(os.environ.get('GENSTARK_REFERENCE', '/root/reference'))

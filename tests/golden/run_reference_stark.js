@@ -18,17 +18,21 @@ const noopLogger = { start() { return () => {}; }, sub() { return () => {}; }, d
 for (const c of cases) {
     const options = { hashAlgorithm: c.hash_algorithm, extensionFactor: c.extension_factor, exeQueryCount: c.exe_query_count, friQueryCount: c.fri_query_count };
     // c.modulus (optional, decimal string): a field other than the 128-bit one — one field per process (js/galois.js)
-    const wide = c.modulus !== undefined;
-    const stark = new Stark({ mimc: wide ? { steps: c.steps, modulus: BigInt(c.modulus) } : { steps: c.steps } }, 'mimc', options, noopLogger);
+    // c.generic (optional): an AIR given as register-machine programs (GenericAir.descriptor() of genstark_amd/air_generic.py —
+    // the reference's Rescue / Poseidon examples); c.seed is then the (possibly nested) list of seed values as decimal strings
+    const wide = c.modulus !== undefined, generic = c.generic !== undefined;
+    const schema = generic ? { generic: c.generic } : { mimc: wide ? { steps: c.steps, modulus: BigInt(c.modulus) } : { steps: c.steps } };
+    const stark = new Stark(schema, generic ? 'default' : 'mimc', options, noopLogger);
     const assertions = c.assertions.map(a => ({ step: a.step, register: a.register, value: BigInt(a.value) }));
-    const proof = stark.prove(assertions, [], [BigInt(c.seed)]);
+    const big = v => Array.isArray(v) ? v.map(big) : BigInt(v);
+    const proof = stark.prove(assertions, [], generic ? big(c.seed) : [BigInt(c.seed)]);
     const bytes = stark.serialize(proof);
     if (bytes.byteLength !== stark.sizeOf(proof)) throw new Error('size mismatch');
     const ok = stark.verify(assertions, stark.parse(bytes));
     let tamperRejected = false;
     try { const bad = Buffer.from(bytes); bad[40] ^= 1; stark.verify(assertions, stark.parse(bad)); } catch (e) { tamperRejected = true; }
-    const nativeBytes = wide ? null : proveMimcSerialized(new MimcAir(c.steps, c.extension_factor), options, assertions, BigInt(c.seed));   // the native driver is 128-bit only
-    out.push({ name: c.name, nativeDriverEqualsReference: wide ? null : Buffer.from(bytes).equals(nativeBytes), proofHex: bytes.toString('hex'), evRoot: proof.evRoot.toString('hex'), lcRoot: proof.ldProof.lcRoot.toString('hex'),
+    const nativeBytes = (wide || generic) ? null : proveMimcSerialized(new MimcAir(c.steps, c.extension_factor), options, assertions, BigInt(c.seed));   // the native driver is 128-bit only
+    out.push({ name: c.name, nativeDriverEqualsReference: (wide || generic) ? null : Buffer.from(bytes).equals(nativeBytes), proofHex: bytes.toString('hex'), evRoot: proof.evRoot.toString('hex'), lcRoot: proof.ldProof.lcRoot.toString('hex'),
                friLayers: proof.ldProof.components.length, remainderLength: proof.ldProof.remainder.length, verified: ok === true,
                tamperRejected, securityLevel: stark.securityLevel });
     console.log(c.name, bytes.byteLength, 'verified', ok, 'security', stark.securityLevel);

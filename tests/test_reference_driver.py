@@ -105,3 +105,57 @@ def test_reference_stark_js_runs_live_over_another_field(name, tmp_path):
     rec = json.loads(cout.read_text())[0]
     assert rec['verified'] and rec['tamperRejected']
     assert rec['proofHex'] == want.hex()
+
+
+# ---- AIRs given as register-machine programs: Rescue 4x128 / Poseidon 6x128 through instantiate({generic: descriptor}) ----------
+import generic_cases
+
+with open(os.path.join(HERE, 'golden', 'reference_driver_generic.json')) as f:
+    DRIVER_GENERIC = {r['name']: r for r in json.load(f)['results']}
+
+
+def _generic_mirror_matches(backend, names):
+    for name in names:
+        rec = DRIVER_GENERIC[name]
+        assert rec['verified'] is True and rec['tamperRejected'] is True
+        air, stark, seed, assertions = generic_cases.build(name, backend)
+        proof = stark.prove(assertions, [], seed)
+        data = stark.serialize(proof)
+        assert (len(data), hashlib.sha256(data).hexdigest()) == (rec['proofSize'], rec['proofSha256']), name
+        assert proof['evRoot'].hex() == rec['evRoot'] and len(proof['ldProof']['components']) == rec['friLayers']
+        assert stark.securityLevel == rec['securityLevel']
+
+
+def test_generic_fixture_covers_the_c3_c4_shapes():
+    assert set(DRIVER_GENERIC) == set(generic_cases.GENERIC_CASES)
+    assert generic_cases.GENERIC_CASES['rescue_c3_65536'][1] == generic_cases.GENERIC_CASES['poseidon_c4_65536'][1] == 1 << 16
+
+
+def test_python_mirror_reproduces_reference_driver_generic_proofs(oracle_backend):
+    """What the reference's Stark.js proved over the {generic: ...} descriptors == what the Python host proves from the AIR itself."""
+    _generic_mirror_matches(oracle_backend, generic_cases.SMALL)
+
+
+@pytest.mark.gpu
+def test_hip_backend_reproduces_reference_driver_generic_proofs(hip_backend):
+    """... and on the HIP backend, up to BASELINE.json's C3 (2 048 Rescue hashes) and C4 (1 024 Poseidon hashes) shapes."""
+    _generic_mirror_matches(hip_backend, list(generic_cases.GENERIC_CASES))
+
+
+@pytest.mark.skipif(not (os.path.isdir(REF_LIB) and shutil.which('node') and os.path.exists('/usr/include/node/node_api.h')),
+                    reason='needs the genSTARK checkout and node (build container only)')
+def test_reference_stark_js_proves_generic_airs_live(oracle_backend, tmp_path):
+    """The reference's own Stark.js, handed `{generic: descriptor}` as its schema, proves and verifies Rescue / Poseidon over the
+    drop-in modules (js/air_generic.js -> N-API -> gs_air_trace / gs_air_trace_segments / gs_air_constraints): the committed
+    fixture's bytes, and a tampered proof is rejected by the reference's verifier running the BigInt constraint interpreter."""
+    subprocess.check_call(['bash', os.path.join(ROOT, 'napi', 'build.sh')])
+    cin, cout = tmp_path / 'cases.json', tmp_path / 'out.json'
+    cin.write_text(json.dumps([generic_cases.node_case(n, oracle_backend) for n in generic_cases.SMALL]))
+    env = dict(os.environ, NODE_PATH=os.path.join(ROOT, 'js', 'shims'), GSTARK_LIB=ORACLE_LIB, GSTARK_ALLOW_TEST_DOUBLE='1')
+    r = subprocess.run(['node', os.path.join(HERE, 'golden', 'run_reference_stark.js'), REF_LIB, str(cin), str(cout)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for rec in json.loads(cout.read_text()):
+        assert rec['verified'] and rec['tamperRejected']
+        data = bytes.fromhex(rec['proofHex'])
+        assert (len(data), hashlib.sha256(data).hexdigest()) == (DRIVER_GENERIC[rec['name']]['proofSize'], DRIVER_GENERIC[rec['name']]['proofSha256'])
