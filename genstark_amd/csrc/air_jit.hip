@@ -546,13 +546,14 @@ static bool jit_trace_source(std::string &s, JitGen &gen, const uint32_t *code, 
     s += "extern \"C\" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void gs_jit_trace(const fe *__restrict__ consts, const fe *__restrict__ statics, const fe *__restrict__ first_rows,\n"
          "                                         unsigned long long segments, unsigned long long seglen, fe *__restrict__ out) {\n"
          "    const unsigned long long tid = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;\n"
-         "    const unsigned long long g = tid / GS_LANES;\n"
+         "    // every thread runs every step (and reaches every barrier): the lanes past the last segment recompute it and store nothing\n"
+         "    const bool gs_live = tid / GS_LANES < segments;\n"
+         "    const unsigned long long g = gs_live ? tid / GS_LANES : segments - 1ull;\n"
          "    const unsigned int sub = (unsigned int)(tid % GS_LANES);\n"
          "    // results of a round change lanes through LDS: one 16-byte write per lane, one read per result (a block is one wave:\n"
          "    // the barriers only order the accesses)\n"
          "    __shared__ fe gs_swap[64];\n"
          "    const unsigned int gs_group = threadIdx.x & ~(GS_LANES - 1u);\n"
-         "    if (g >= segments) return;\n"
          "    const unsigned long long steps = segments * seglen;\n";
     for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "    fe r%u = first_rows[g * %uull + %uull], n%u;\n", r, registers, r, r); s += buf; }
     std::vector<bool> const_declared(gen.nconsts, false);
@@ -569,7 +570,7 @@ static bool jit_trace_source(std::string &s, JitGen &gen, const uint32_t *code, 
     }
     s += "    for (unsigned long long k = 0; k < seglen; k++) {\n"
          "        const unsigned long long i = g * seglen + k;\n";
-    for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "        if (sub == %uu) out[%uull * steps + i] = r%u;\n", r % gen.lanes, r, r); s += buf; }
+    for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "        if (gs_live && sub == %uu) out[%uull * steps + i] = r%u;\n", r % gen.lanes, r, r); s += buf; }
     s += "        if (k + 1 == seglen) break;\n";
     for (uint32_t r = 0; r < registers; r++) { snprintf(buf, sizeof buf, "        n%u = r%u;\n", r, r); s += buf; }
     s += main_body;
@@ -590,7 +591,9 @@ int gs_jit_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t ninstr, cons
     if (!k) return GS_ERR_UNSUPPORTED;
     unsigned long long a_segments = segments, a_seglen = seglen;
     void *args[] = {(void *)&dconst, (void *)&dstat, (void *)&drows, (void *)&a_segments, (void *)&a_seglen, (void *)&out};
-    const unsigned block = 64, grid = (unsigned)((segments * gen.lanes + block - 1) / block);
+    constexpr unsigned block = 64;
+    static_assert(block == 64, "gs_jit_trace: gs_swap[64], __launch_bounds__(64) and the lane groups assume one wave64 per block");
+    const unsigned grid = (unsigned)((segments * gen.lanes + block - 1) / block);
     if (hipModuleLaunchKernel(k->fn, grid, 1, 1, block, 1, 1, 0, c->stream, args, nullptr) != hipSuccess) return GS_ERR_UNSUPPORTED;
     c->jit_launches++;
     return GS_OK;

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,9 @@ struct gs_ctx {
     char err[512] = {0};
     // size-bucketed cache of device blocks: gs_free parks a block here instead of hipFree (which would
     // synchronise the device); every consumer is ordered on `stream`, so immediate reuse is safe.
+    // gs_alloc / gs_free / gs_cache_trim take `blocks_mutex`: a host-language finaliser may release a vector from another thread than
+    // the one driving the context (everything else of a context stays single-threaded, include/gstark.h)
+    std::mutex blocks_mutex;
     std::multimap<uint64_t, void *> free_blocks;
     std::map<void *, uint64_t> live_blocks;
     uint64_t cached_bytes = 0;

@@ -96,6 +96,7 @@ static uint64_t round_block(uint64_t bytes) {
 int gs_alloc(gs_ctx *c, uint64_t bytes, void **dptr) {
     if (!c || !dptr) return GS_ERR_ARG;
     uint64_t sz = round_block(bytes);
+    std::lock_guard<std::mutex> lock(c->blocks_mutex);
     auto it = c->free_blocks.find(sz);
     void *p = nullptr;
     if (it != c->free_blocks.end()) {
@@ -123,6 +124,7 @@ int gs_alloc(gs_ctx *c, uint64_t bytes, void **dptr) {
 int gs_free(gs_ctx *c, void *dptr) {
     if (!c) return GS_ERR_ARG;
     if (!dptr) return GS_OK;
+    std::lock_guard<std::mutex> lock(c->blocks_mutex);
     auto it = c->live_blocks.find(dptr);
     if (it == c->live_blocks.end()) return gs_fail(c, GS_ERR_ARG, "gs_free: pointer was not allocated by gs_alloc");
     c->free_blocks.insert({it->second, dptr});
@@ -134,6 +136,7 @@ int gs_free(gs_ctx *c, void *dptr) {
 int gs_cache_trim(gs_ctx *c) {
     if (!c) return GS_ERR_ARG;
     GS_HIP(c, hipStreamSynchronize(c->stream));
+    std::lock_guard<std::mutex> lock(c->blocks_mutex);
     for (auto &kv : c->free_blocks) hipFree(kv.second);
     c->free_blocks.clear();
     c->cached_bytes = 0;

@@ -7,6 +7,7 @@ the Python mirror: no interpreter between two launches.  The driver is bound to 
 """
 import ctypes as C
 import os
+import threading
 
 from ._abi import GstarkError
 from .air import MimcAir
@@ -44,11 +45,17 @@ class _Stats(C.Structure):
 
 
 _bound = {}
+_bound_lock = threading.Lock()      # ProverPool lanes construct their NativeProver concurrently
 
 
 def _driver(backend):
     """libgstark_prover.so bound to the ABI library of `backend` (one private copy of the driver per ABI library)."""
     key = backend.lib._name
+    with _bound_lock:
+        return _driver_locked(backend, key)
+
+
+def _driver_locked(backend, key):
     if key not in _bound:
         if not os.path.exists(PROVER_LIB_PATH):
             raise GstarkError(f'{PROVER_LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"`')

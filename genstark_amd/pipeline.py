@@ -35,6 +35,7 @@ class ProverPool:
             t.start()
         self._ready.wait()
         if self._errors:
+            self.close()                # the lanes that did come up are waiting for jobs: release and join them
             raise self._errors[0]
 
     def _lane(self, index, stark_factory, backend_factory):

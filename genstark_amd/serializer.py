@@ -1,5 +1,6 @@
 """Mirror of lib/Serializer.ts:17-150 — proof wire format."""
 from . import utils
+from .errors import StarkError
 
 
 class Serializer:
@@ -49,37 +50,48 @@ class Serializer:
 
     def parseProof(self, buffer):  # :83-144
         ds, es = self.hashDigestSize, self.fieldElementSize
+        need = utils.need                                  # every read is bounds-checked: a truncated proof is a StarkError
+        need(buffer, 0, ds)
         evRoot = bytes(buffer[0:ds])
         evProof, offset = utils.readMerkleProof(buffer, ds, self._valueCount() * es, ds)
+        need(buffer, offset, ds)
         lcRoot = bytes(buffer[offset:offset + ds])
         offset += ds
         lcProof, offset = utils.readMerkleProof(buffer, offset, es * 4, ds)
+        need(buffer, offset, 1)
         componentCount = buffer[offset]
         offset += 1
         components = []
         for _ in range(componentCount):
+            need(buffer, offset, ds)
             columnRoot = bytes(buffer[offset:offset + ds])
             offset += ds
             columnProof, offset = utils.readMerkleProof(buffer, offset, es * 4, ds)
             polyProof, offset = utils.readMerkleProof(buffer, offset, es * 4, ds)
             components.append({'columnRoot': columnRoot, 'columnProof': columnProof, 'polyProof': polyProof})
+        need(buffer, offset, 1)
         remainderLength = buffer[offset] or utils.MAX_ARRAY_LENGTH
         offset += 1
         remainder = []
         for _ in range(remainderLength):
             remainder.append(utils.readBigInt(buffer, offset, es))
             offset += es
+        need(buffer, offset, 1)
         inputCount = buffer[offset]
         offset += 1
         inputShapes = []
         for _ in range(inputCount):
+            need(buffer, offset, 1)
             rank = buffer[offset]
             offset += 1
+            need(buffer, offset, 4 * rank)
             shape = []
             for _ in range(rank):
                 shape.append(int.from_bytes(buffer[offset:offset + 4], 'little'))
                 offset += 4
             inputShapes.append(shape)
+        if offset != len(buffer):
+            raise StarkError('malformed proof: bytes left over after the last field')
         return {'evRoot': evRoot, 'evProof': evProof,
                 'ldProof': {'lcRoot': lcRoot, 'lcProof': lcProof, 'components': components, 'remainder': remainder},
                 'iShapes': inputShapes}

@@ -144,6 +144,8 @@ class Stark:
         augmentedPositions = self.getAugmentedPositions(positions, evaluationDomainSize)
         log('Computed positions for evaluation spot checks')
         pEvaluations, sEvaluations = {}, {}
+        if len(proof['evProof']['values']) != len(augmentedPositions):
+            raise StarkError('malformed proof: the evaluation proof does not hold one leaf per queried position')
         for i, mergedEvaluations in enumerate(proof['evProof']['values']):
             p, s = self.parseValues(mergedEvaluations)
             pEvaluations[augmentedPositions[i]] = p
@@ -159,13 +161,18 @@ class Stark:
             raise StarkError('Verification of evaluation Merkle proof failed', error)
         log('Verified evaluation merkle proof')
         lcValues = []
-        for step in positions:
-            x = context.field.exp(context.rootOfUnity, step)
-            pValues = pEvaluations[step]
-            nValues = pEvaluations[(step + extensionFactor) % evaluationDomainSize]
-            sValues = sEvaluations[step]
-            cValue = cPoly.evaluateAt(x, pValues, nValues, sValues, context)
-            lcValues.append(lCombination.computeOne(x, cValue, pValues, sValues))
+        try:
+            for step in positions:
+                x = context.field.exp(context.rootOfUnity, step)
+                pValues = pEvaluations[step]
+                nValues = pEvaluations[(step + extensionFactor) % evaluationDomainSize]
+                sValues = sEvaluations[step]
+                cValue = cPoly.evaluateAt(x, pValues, nValues, sValues, context)
+                lcValues.append(lCombination.computeOne(x, cValue, pValues, sValues))
+        except StarkError:
+            raise
+        except (IndexError, KeyError, ValueError) as error:       # a proof whose shape does not fit the AIR
+            raise StarkError('malformed proof', error)
         log('Verified transition and boundary constraints')
         try:
             ldProver = LowDegreeProver(self.indexGenerator, self.hash, context)

@@ -25,7 +25,16 @@ def rehashMerkleProofValues(proof, hash_):
 
 
 # ---- big integers (serialization.ts:131-146): LE 32-bit limbs == little-endian bytes
+def need(buffer, offset, size):
+    """A read of `size` bytes at `offset` must lie inside the buffer (the reference's Buffer reads throw RangeError; a Python
+    slice would silently come back short)."""
+    if offset < 0 or size < 0 or offset + size > len(buffer):
+        from .errors import StarkError
+        raise StarkError('malformed proof: truncated')
+
+
 def readBigInt(buffer, offset, elementSize):
+    need(buffer, offset, (elementSize >> 2) * 4)
     return int.from_bytes(buffer[offset:offset + (elementSize >> 2) * 4], 'little')
 
 
@@ -46,8 +55,10 @@ def writeArray(buffer, offset, array):
 
 
 def readArray(buffer, offset, elementSize):
+    need(buffer, offset, 1)
     n = buffer[offset] or MAX_ARRAY_LENGTH
     offset += 1
+    need(buffer, offset, n * elementSize)
     values = []
     for _ in range(n):
         values.append(bytes(buffer[offset:offset + elementSize]))
@@ -70,8 +81,10 @@ def writeMatrix(buffer, offset, matrix, leafSize):
 
 
 def readMatrix(buffer, offset, leafSize, nodeSize):
+    need(buffer, offset, 1)
     columnCount = buffer[offset] or MAX_ARRAY_LENGTH
     offset += 1
+    need(buffer, offset, columnCount)
     heads = list(buffer[offset:offset + columnCount])
     offset += columnCount
     matrix = []
@@ -80,6 +93,7 @@ def readMatrix(buffer, offset, leafSize, nodeSize):
         first = leafSize if (head & 1) else nodeSize
         for j in range(head >> 1):
             size = first if j == 0 else nodeSize
+            need(buffer, offset, size)
             column.append(bytes(buffer[offset:offset + size]))
             offset += size
         matrix.append(column)
@@ -96,6 +110,7 @@ def writeMerkleProof(buffer, offset, proof, leafSize):
 def readMerkleProof(buffer, offset, leafSize, nodeSize):
     values, offset = readArray(buffer, offset, leafSize)
     nodes, offset = readMatrix(buffer, offset, leafSize, nodeSize)
+    need(buffer, offset, 1)
     depth = buffer[offset]
     return {'values': values, 'nodes': nodes, 'depth': depth}, offset + 1
 

@@ -25,7 +25,9 @@
  *    gs_gather and gs_sync block until the stream is drained.  Like the reference (synchronous,
  *    single-threaded JS) a context must not be used from two threads at once; a thread other than the
  *    one that called gs_ctx_create must make the context's device its current HIP device first
- *    (hipSetDevice is per-thread state; several contexts, one per thread, may share a GPU).
+ *    (hipSetDevice is per-thread state; several contexts, one per thread, may share a GPU).  The one exception is
+ *    gs_free: it only parks the block in the context's cache (under a lock shared with gs_alloc), so a garbage
+ *    collector's finaliser may call it from any thread.
  *  - The library is built once per field: libgstark_hip.so computes in GF(2^128 - 9*2^32 + 1), the flavours
  *    libgstark_hip_q64.so / _q32.so / _q17.so in GF(2^64 - 21*2^30 + 1) / GF(2^32 - 3*2^25 + 1) / GF(96769) with 16-byte elements, the flavours
  *    libgstark_hip_p256.so / _p224.so in GF(2^256 - 351*2^32 + 1) / GF(2^224 - 2^96 + 1) with 32-byte elements

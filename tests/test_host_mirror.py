@@ -88,6 +88,32 @@ def test_tampered_proofs_are_rejected(oracle_backend):
         stark.verify(wrong, stark.parse(data))
 
 
+def test_malformed_proofs_are_typed_rejections(oracle_backend):
+    """A truncated / over-long / reshaped proof is a StarkError, never a bare IndexError or a silently short read (the
+    reference's Buffer reads throw RangeError: lib/Serializer.ts:83-144)."""
+    case = GOLDEN[0]
+    stark, proof, data = run_golden_case(case, oracle_backend)
+    assertions = golden_assertions(case)
+    for cut in list(range(0, 70)) + list(range(70, len(data), 97)) + [len(data) - 1]:
+        with pytest.raises(StarkError, match='malformed proof'):
+            stark.parse(data[:cut])
+    with pytest.raises(StarkError, match='bytes left over'):
+        stark.parse(data + b'\x00')
+    assert stark.parse(bytearray(data)) == stark.parse(data)
+    # every single-byte corruption of the header region either parses to something verify() rejects with StarkError, or fails to parse
+    for off in range(0, len(data), max(1, len(data) // 150)):
+        try:
+            ok = stark.verify(assertions, stark.parse(_flip(data, off)))
+        except StarkError:
+            continue
+        assert ok is True           # a flipped bit in padding the verifier never reads would be acceptable; there is none in this format
+        raise AssertionError(f'corruption at byte {off} was accepted')
+    short = stark.parse(data)
+    short['evProof']['values'] = short['evProof']['values'][:-1]
+    with pytest.raises(StarkError):
+        stark.verify(assertions, short)
+
+
 def test_error_behaviour(oracle_backend):
     case = GOLDEN[0]
     stark = make_stark(case, oracle_backend)

@@ -112,3 +112,23 @@ def test_pool_compiles_air_programs_and_matches_sequential_proofs_hip():
             assert out == [expected] * 6
             launches = pool.on_every_lane(lambda s: (s.stark if native else s).air.field.backend.jit_launches)
             assert all(n > 0 for n in launches)
+
+
+def test_pool_constructor_failure_releases_the_healthy_lanes(oracle_backend):
+    """One lane failing to come up must not leave the others blocked on the job queue forever."""
+    import threading
+    calls, lock = [], threading.Lock()
+    make = factory(CASE)
+
+    def flaky(backend):
+        with lock:
+            calls.append(1)
+            n = len(calls)
+        if n == 2:
+            raise RuntimeError('lane construction failed')
+        return make(backend)
+    before = {t.ident for t in threading.enumerate()}
+    with pytest.raises(RuntimeError, match='lane construction failed'):
+        ProverPool(flaky, lanes=3, backend_factory=lambda: Backend(lib_path=ORACLE_LIB, allow_test_double=True), native=True)
+    assert len(calls) == 3
+    assert {t.ident for t in threading.enumerate()} <= before       # every lane thread was joined
