@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=1000000 -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
 UNITS="ctx ntt pointwise hash air_mimc air_vm air_jit small"
-HDRS="gf128_lazy.h host_pow.h gf128.h gf_small.h gf_wide.h common.h host_field.h host_field_small.h host_field_wide.h host_sha256.h hash_core.h ../../include/gstark.h"
+HDRS="gf128_lazy.h ntt_mfma.h host_pow.h gf128.h gf_small.h gf_wide.h common.h host_field.h host_field_small.h host_field_wide.h host_sha256.h hash_core.h ../../include/gstark.h"
 # one library per field: the 128-bit field of the hot path, and two "plumbing" flavours of the same sources for the small prime
 # fields of the reference's examples (gf_small.h): 2^64 - 21*2^30 + 1 (rescue/hash2x64.ts) and 2^32 - 3*2^25 + 1 (demo/fibonacci.ts)
 # the field headers as string literals: the source text hiprtc compiles AIR programs against (air_jit.hip)

@@ -46,6 +46,10 @@ struct NttPlan {
     lzw *wtab = nullptr;                               // device: W-forms of omega_16^1..7 and of 1/n (read with scalar loads)
     lz8 *wRz[4] = {nullptr, nullptr, nullptr, nullptr};   // wR[i] as NN limbs
     lz8 *wRz_scaled = nullptr;                         // the last pass's table times 1/n (inverse transforms: the scale rides on the exchange twiddle)
+    int4 *mf_tab = nullptr;                            // matrix-core passes (ntt_mfma.h): the 4 KB operand table of omega_16
+    fe *mf_wR_scaled = nullptr;                        // omega_256^e / n
+    int mf_offs[16];
+    fe mf_bias0;
 #endif
 };
 
@@ -861,6 +865,27 @@ static void launch_pass_wave(gs_ctx *c, const fe *in, fe *out, const LzPassArgs 
     } else if (a.twp) hipLaunchKernelGGL((k_ntt_wave<LB, 1>), dim3((unsigned)tiles, rows), dim3(64), 0, c->stream, in, out, a);
     else hipLaunchKernelGGL((k_ntt_wave<LB, 2>), dim3((unsigned)tiles, rows), dim3(64), 0, c->stream, in, out, a);
 }
+#include "ntt_mfma.h"
+__global__ void k_mf_scale_table(const fe *__restrict__ in, fe *__restrict__ out, fe k) { out[threadIdx.x] = fe_mul(in[threadIdx.x], k); }
+static void launch_pass_mfma(gs_ctx *c, const fe *in, fe *out, const MfPassArgs &a, uint32_t rows) {
+    const uint64_t tiles = (a.n >> 8) / MF_COLS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_mfma<0>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_mfma<1>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_mfma<2>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)(tiles / MF_WAVES), rows), block(64 * MF_WAVES);
+    if (a.logNs == 0) hipLaunchKernelGGL((k_ntt_mfma<0>), grid, block, MF_LDS_BYTES, c->stream, in, out, a);
+    else if (a.twp) hipLaunchKernelGGL((k_ntt_mfma<1>), grid, block, MF_LDS_BYTES, c->stream, in, out, a);
+    else hipLaunchKernelGGL((k_ntt_mfma<2>), grid, block, MF_LDS_BYTES, c->stream, in, out, a);
+}
+static bool ntt_mfma_enabled() {   // GSTARK_NTT_MFMA=1: radix-256 passes on the matrix cores (A/B measurements; read per call)
+    const char *e = getenv("GSTARK_NTT_MFMA");
+    return e && e[0] == '1';
+}
+
 static bool ntt_wave_enabled() {   // GSTARK_NTT_WAVE=0 keeps the 128-thread workgroup kernel everywhere (A/B measurements)
     const char *e = getenv("GSTARK_NTT_WAVE");
     return !(e && e[0] == '0');
@@ -949,7 +974,35 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
             }
             a.wtab = p->wtab;
             const bool wave = ntt_wave_enabled() && n >= 1024 && (logNs > 0 || LB == 4);
-            if (wave) {
+            if (LB == 4 && n >= (1ull << 16) && ntt_mfma_enabled()) {
+                if (!p->mf_tab) {
+                    int8_t host[4096];
+                    mf_host_tables(p->w16[1], host, p->mf_offs, p->mf_bias0);
+                    void *q;
+                    if ((rc = gs_alloc(c, sizeof host, &q))) { if (tmp) gs_tmp_free(c, tmp); return rc; }
+                    if (hipMemcpyAsync(q, host, sizeof host, hipMemcpyHostToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+                        if (tmp) gs_tmp_free(c, tmp);
+                        return gs_fail(c, GS_ERR_DEVICE, "ntt: operand table upload failed");
+                    }
+                    p->mf_tab = (int4 *)q;
+                }
+                MfPassArgs m;
+                m.n = n; m.in_len = a.in_len; m.in_stride = a.in_stride; m.out_stride = n;
+                m.logn = p->logn; m.logNs = logNs; m.log_lo = p->log_lo; m.weak = last ? 0 : 1;
+                m.tw_lo = p->tw_lo; m.tw_hi = p->tw_hi; m.twp = p->twp[i]; m.wR = p->wR[i]; m.atab = p->mf_tab;
+                for (int k = 0; k < 16; k++) m.offs[k] = p->mf_offs[k];
+                m.bias0 = p->mf_bias0;
+                if (inverse && last) {
+                    if (!p->mf_wR_scaled) {
+                        void *q;
+                        if ((rc = gs_alloc(c, 256 * GS_ELT, &q))) { if (tmp) gs_tmp_free(c, tmp); return rc; }
+                        p->mf_wR_scaled = (fe *)q;
+                        hipLaunchKernelGGL(k_mf_scale_table, dim3(1), dim3(256), 0, c->stream, p->wR[i], p->mf_wR_scaled, ninv);
+                    }
+                    m.wR = p->mf_wR_scaled;
+                }
+                launch_pass_mfma(c, src, dst, m, rows);
+            } else if (wave) {
                 a.logWj = 6 - LB;
                 switch (LB) {
                     case 0: launch_pass_wave<0>(c, src, dst, a, rows); break;
