@@ -18,7 +18,7 @@ data-path collective (RCCL is used only for the barrier and the max-over-ranks r
           plus two small transforms of the round-constant register: the composition polynomial is evaluated directly on the
           evaluation domain (gs_mimc_composition), no transform is credited that did not run.
 `prove_ms` (= ms_per_step) is the other half of BASELINE.json's metric; `phases_ms` comes from the driver's own clock.
-`roofline` describes the dominant kernel (one radix-256 NTT pass, k_ntt_pass_lz<4, *>), timed live with events on the
+`roofline` describes the dominant kernel (one radix-256 NTT pass, k_ntt_wave<4, *>), timed live with events on the
 stream the kernels run on; `roofline.second_roof` is the VALU-issue roof measured in the same run (tools/microbench5: the
 kernel's own product routines on registers only); `roofline.traffic` is read from the PMC counters by a rocprofv3 child
 process of this run (tools/pmc_traffic.py).  `cpu_baseline` is the same prove() on the CPU oracle's implementation of the
@@ -328,7 +328,7 @@ def main():
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                     'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child processes of this run (tools/pmc_traffic.py)',
                     'traffic_detail': traffic_detail,
-                    'kernel': f'k_ntt_pass_lz<4, *> (radix-256 Stockham pass, lazy five-limb butterflies), {npass} launches per 2^{logn}-point transform',
+                    'kernel': f'k_ntt_wave<4, *> (radix-256 Stockham pass, one wave per tile, lazy five-limb butterflies), {npass} launches per 2^{logn}-point transform',
                     'launch_ms': round(launch_ms, 4), 'transform_ms': round(transform_ms, 4),
                     'ntt_kernel_elements_per_sec': round(n / (transform_ms * 1e-3), 1),
                     'second_roof': second_roof(n, transform_ms, npass)}
