@@ -24,7 +24,11 @@ for (const c of JSON.parse(fs.readFileSync(process.argv[2], 'utf8'))) {
     const r = [], nx = [];
     for (let i = 0; i < air.traceRegisterCount; i++) { r.push(pEv.getValue(i, pos)); nx.push(pEv.getValue(i, (pos + ef) % n)); }
     const at = air.initVerificationContext([], []).evaluateConstraintsAt(x, r, nx, []);
-    out.push({ name: c.name, trace: sha(trace.toBuffer()), constraints: sha(q.toBuffer()), statics: sha(statics.toBuffer()),
+    // ONE call of the native driver (js/prover.js -> N-API -> csrc/prover.cc) for the whole proof
+    const { proveGenericSerialized } = require(path.join(__dirname, 'prover.js'));
+    const options = { hashAlgorithm: c.hash_algorithm, extensionFactor: c.extension_factor, exeQueryCount: c.exe_query_count, friQueryCount: c.fri_query_count };
+    const proof = proveGenericSerialized(air, options, c.assertions.map(a => ({ step: a.step, register: a.register, value: BigInt(a.value) })), big(c.seed));
+    out.push({ name: c.name, proofSize: proof.length, proofSha256: sha(proof), trace: sha(trace.toBuffer()), constraints: sha(q.toBuffer()), statics: sha(statics.toBuffer()),
                constraintsAt: at.map(String), rows: [trace.rowCount, q.rowCount, statics.rowCount], cols: [trace.colCount, q.colCount] });
 }
 fs.writeFileSync(process.argv[3], JSON.stringify(out));

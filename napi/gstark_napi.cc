@@ -419,10 +419,106 @@ napi_value ProveMimcSerialized(napi_env env, napi_callback_info info) {
     return buf;
 }
 
+// proveGenericSerialized(ctx, proverLibPath, job) -> Buffer: the same ONE call for an AIR given as register-machine programs (kind 1 of
+// gs_prover_air: what js/air_generic.js holds for the reference's Rescue / Poseidon examples).
+//   job = { steps, extensionFactor, exeQueryCount, friQueryCount, hashAlg, rootOfUnity: Buffer(16), assertions: [...], registers, degrees: number[],
+//           tCode / iCode / eCode: number[] (4 words per instruction), consts: Buffer(16 * nconsts), vmRegs, staticValues: Buffer, staticPeriods: number[],
+//           staticTables: BigInt (device pointer), staticLens: number[], firstRows: Buffer, segments, segmentLen }
+napi_value ProveGenericSerialized(napi_env env, napi_callback_info info) {
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    void *ctx;
+    NAPI_OK(env, napi_get_value_external(env, argv[0], &ctx));
+    if (!g_lib) { napi_throw_error(env, nullptr, "call load(path) first"); return nullptr; }
+    typedef int (*bindfn)(void *);
+    typedef int (*provefn)(gs_ctx *, const gs_prover_job *, uint8_t *, uint64_t, uint64_t *, char *, uint64_t);
+    if (!g_prover) {
+        char path[1024];
+        size_t len;
+        NAPI_OK(env, napi_get_value_string_utf8(env, argv[1], path, sizeof path, &len));
+        void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { napi_throw_error(env, nullptr, (std::string("cannot load ") + path + ": " + dlerror()).c_str()); return nullptr; }
+        bindfn bf = (bindfn)dlsym(lib, "gs_prover_bind");
+        if (!bf || bf(g_lib) != GS_OK) { napi_throw_error(env, nullptr, "gs_prover_bind failed"); return nullptr; }
+        g_prover = lib;
+    }
+    auto prop = [&](const char *name) { napi_value v; napi_get_named_property(env, argv[2], name, &v); return v; };
+    auto u64 = [&](const char *name, uint64_t *out) { return get_u64(env, prop(name), out); };
+    auto bytes = [&](napi_value v, const uint8_t **data, size_t *len) { void *d; bool ok = napi_get_buffer_info(env, v, &d, len) == napi_ok; *data = (const uint8_t *)d; return ok; };
+    auto words = [&](const char *name, std::vector<uint32_t> &out) {
+        napi_value arr = prop(name);
+        uint32_t n = 0;
+        if (napi_get_array_length(env, arr, &n) != napi_ok) return false;
+        out.resize(n);
+        for (uint32_t i = 0; i < n; i++) {
+            napi_value e;
+            uint64_t x;
+            if (napi_get_element(env, arr, i, &e) != napi_ok || !get_u64(env, e, &x)) return false;
+            out[i] = (uint32_t)x;
+        }
+        return true;
+    };
+    gs_prover_job job;
+    memset(&job, 0, sizeof job);
+    uint64_t t, ef, exe, fri, alg, regs, vmregs, tables, segments, seglen;
+    const uint8_t *rou, *consts, *svals, *first;
+    size_t nrou, nconsts, nsvals, nfirst;
+    std::vector<uint32_t> degrees, tcode, icode, ecode, periods, lens32;
+    if (!u64("steps", &t) || !u64("extensionFactor", &ef) || !u64("exeQueryCount", &exe) || !u64("friQueryCount", &fri) || !u64("hashAlg", &alg) ||
+        !u64("registers", &regs) || !u64("vmRegs", &vmregs) || !u64("staticTables", &tables) || !u64("segments", &segments) || !u64("segmentLen", &seglen) ||
+        !bytes(prop("rootOfUnity"), &rou, &nrou) || nrou != 16 || !bytes(prop("consts"), &consts, &nconsts) || nconsts % 16 ||
+        !bytes(prop("staticValues"), &svals, &nsvals) || !bytes(prop("firstRows"), &first, &nfirst) || !words("degrees", degrees) || !words("tCode", tcode) ||
+        !words("iCode", icode) || !words("eCode", ecode) || !words("staticPeriods", periods) || !words("staticLens", lens32) || tcode.size() % 4 || icode.size() % 4 ||
+        ecode.size() % 4 || lens32.size() != periods.size() || nfirst != (segments ? segments : 1) * regs * 16) {
+        napi_throw_type_error(env, nullptr, "proveGenericSerialized: malformed job");
+        return nullptr;
+    }
+    std::vector<uint64_t> lens(lens32.begin(), lens32.end());
+    job.steps = t; job.extension_factor = (uint32_t)ef; job.exe_query_count = (uint32_t)exe; job.fri_query_count = (uint32_t)fri; job.hash_alg = (int32_t)alg;
+    memcpy(job.root_of_unity, rou, 16);
+    gs_prover_air &a = job.air;
+    a.kind = 1; a.registers = (uint32_t)regs; a.nconstraints = (uint32_t)degrees.size(); a.degrees = degrees.data();
+    a.t_code = tcode.data(); a.t_ninstr = (uint32_t)(tcode.size() / 4);
+    a.i_code = icode.empty() ? nullptr : icode.data(); a.i_ninstr = (uint32_t)(icode.size() / 4);
+    a.e_code = ecode.data(); a.e_ninstr = (uint32_t)(ecode.size() / 4);
+    a.consts = consts; a.nconsts = (uint32_t)(nconsts / 16); a.vm_regs = (uint32_t)vmregs;
+    a.static_values = svals; a.static_periods = periods.data(); a.nstatic = (uint32_t)periods.size();
+    a.static_tables = (const void *)(uintptr_t)tables; a.static_lens = lens.data();
+    a.first_rows = first; a.segments = segments; a.segment_len = seglen;
+    napi_value arr = prop("assertions");
+    uint32_t na = 0;
+    NAPI_OK(env, napi_get_array_length(env, arr, &na));
+    std::vector<gs_assertion> as(na);
+    for (uint32_t i = 0; i < na; i++) {
+        napi_value e, v;
+        NAPI_OK(env, napi_get_element(env, arr, i, &e));
+        uint64_t step, reg;
+        const uint8_t *val; size_t nval;
+        napi_get_named_property(env, e, "step", &v);
+        bool ok = get_u64(env, v, &step);
+        napi_get_named_property(env, e, "register", &v);
+        ok = ok && get_u64(env, v, &reg);
+        napi_get_named_property(env, e, "value", &v);
+        ok = ok && bytes(v, &val, &nval) && nval == 16;
+        if (!ok) { napi_throw_type_error(env, nullptr, "proveGenericSerialized: malformed assertion"); return nullptr; }
+        as[i].step = step; as[i].reg = (uint32_t)reg; memcpy(as[i].value, val, 16);
+    }
+    job.assertions = as.data(); job.nassertions = na;
+    std::vector<uint8_t> out(1 << 22);
+    uint64_t n = 0;
+    char err[512] = {0};
+    int rcode = ((provefn)dlsym(g_prover, "gs_prover_prove"))((gs_ctx *)ctx, &job, out.data(), out.size(), &n, err, sizeof err);
+    if (rcode != GS_OK) { napi_throw_error(env, nullptr, (std::string("native prove() failed: ") + err).c_str()); return nullptr; }
+    napi_value buf;
+    NAPI_OK(env, napi_create_buffer_copy(env, (size_t)n, out.data(), nullptr, &buf));
+    return buf;
+}
+
 napi_value Init(napi_env env, napi_value exports) {
     const struct { const char *name; napi_callback cb; } fns[] = {
         {"load", Load}, {"fieldInfo", FieldInfo}, {"ctxCreate", CtxCreate}, {"ctxDestroy", CtxDestroy}, {"alloc", Alloc}, {"call", Call},
-        {"merkleProveBatch", MerkleProveBatch}, {"proveMimcSerialized", ProveMimcSerialized},
+        {"merkleProveBatch", MerkleProveBatch}, {"proveMimcSerialized", ProveMimcSerialized}, {"proveGenericSerialized", ProveGenericSerialized},
     };
     for (auto &f : fns) {
         napi_value fn;

@@ -12,7 +12,7 @@ const cases = JSON.parse(fs.readFileSync(process.argv[3], 'utf8'));
 // the native driver (C++ above the C ABI) behind the same addon: its bytes must equal what the reference's Stark.js produces
 const repoJs = path.join(__dirname, '..', '..', 'js');
 const { MimcAir } = require(path.join(repoJs, 'air_mimc.js'));
-const { proveMimcSerialized } = require(path.join(repoJs, 'prover.js'));
+const { proveMimcSerialized, proveGenericSerialized } = require(path.join(repoJs, 'prover.js'));
 const out = [];
 const noopLogger = { start() { return () => {}; }, sub() { return () => {}; }, done() {} };
 for (const c of cases) {
@@ -31,8 +31,10 @@ for (const c of cases) {
     const ok = stark.verify(assertions, stark.parse(bytes));
     let tamperRejected = false;
     try { const bad = Buffer.from(bytes); bad[40] ^= 1; stark.verify(assertions, stark.parse(bad)); } catch (e) { tamperRejected = true; }
-    const nativeBytes = (wide || generic) ? null : proveMimcSerialized(new MimcAir(c.steps, c.extension_factor), options, assertions, BigInt(c.seed));   // the native driver is 128-bit only
-    out.push({ name: c.name, nativeDriverEqualsReference: (wide || generic) ? null : Buffer.from(bytes).equals(nativeBytes), proofHex: bytes.toString('hex'), evRoot: proof.evRoot.toString('hex'), lcRoot: proof.ldProof.lcRoot.toString('hex'),
+    // (init programs extend the transition program's pool in place: pools of a descriptor with an init program cannot be concatenated blindly,
+    //  proveGenericSerialized checks)
+    const nativeBytes = wide ? null : generic ? proveGenericSerialized(stark.air, options, assertions, big(c.seed)) : proveMimcSerialized(new MimcAir(c.steps, c.extension_factor), options, assertions, BigInt(c.seed));   // the native driver is 128-bit only
+    out.push({ name: c.name, nativeDriverEqualsReference: wide ? null : Buffer.from(bytes).equals(nativeBytes), proofHex: bytes.toString('hex'), evRoot: proof.evRoot.toString('hex'), lcRoot: proof.ldProof.lcRoot.toString('hex'),
                friLayers: proof.ldProof.components.length, remainderLength: proof.ldProof.remainder.length, verified: ok === true,
                tamperRejected, securityLevel: stark.securityLevel });
     console.log(c.name, bytes.byteLength, 'verified', ok, 'security', stark.securityLevel);

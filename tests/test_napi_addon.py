@@ -60,7 +60,11 @@ def _generic_members(backend, lib_env, names, tmp_path):
     r = subprocess.run([NODE, os.path.join(ROOT, 'js', 'smoke_generic.js'), str(cin), str(cout)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     sha = lambda b: hashlib.sha256(b).hexdigest()
+    with open(os.path.join(ROOT, 'tests', 'golden', 'reference_driver_generic.json')) as fh:
+        fixture = {r['name']: r for r in json.load(fh)['results']}
     for rec in json.loads(cout.read_text()):
+        # the native driver called from node: the bytes the reference's own Stark.js produced for this case (committed fixture)
+        assert (rec['proofSize'], rec['proofSha256']) == (fixture[rec['name']]['proofSize'], fixture[rec['name']]['proofSha256']), rec['name']
         air, stark, seed, _ = generic_cases.build(rec['name'], backend)
         f = air.field
         ctx = air.initProvingContext([], seed)

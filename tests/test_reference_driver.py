@@ -159,3 +159,5 @@ def test_reference_stark_js_proves_generic_airs_live(oracle_backend, tmp_path):
         assert rec['verified'] and rec['tamperRejected']
         data = bytes.fromhex(rec['proofHex'])
         assert (len(data), hashlib.sha256(data).hexdigest()) == (DRIVER_GENERIC[rec['name']]['proofSize'], DRIVER_GENERIC[rec['name']]['proofSha256'])
+        # ... and ONE call of the native driver through the same addon (js/prover.js proveGenericSerialized -> csrc/prover.cc) gives these bytes
+        assert rec['nativeDriverEqualsReference'] is True
