@@ -28,6 +28,7 @@
 #define GS_NTT_LAZY 1      // the 128-bit field of the hot path: butterflies in five-limb lazy form (gf128_lazy.h)
 #include "gf128_lazy.h"
 struct alignas(32) lz8 { int32_t l[8]; };   // an NN element as a table entry: five limbs, 32-byte stride
+struct alignas(16) lzw28 { int32_t w[28]; };   // a table entry in W-form: rows w * B^i mod p (i < 5) as signed digits |limb| <= 2^25, 25 words + padding
 #endif
 
 struct NttPlan {
@@ -46,6 +47,8 @@ struct NttPlan {
     lzw *wtab = nullptr;                               // device: W-forms of omega_16^1..7 and of 1/n (read with scalar loads)
     lz8 *wRz[4] = {nullptr, nullptr, nullptr, nullptr};   // wR[i] as NN limbs
     lz8 *wRz_scaled = nullptr;                         // the last pass's table times 1/n (inverse transforms: the scale rides on the exchange twiddle)
+    lzw28 *wRw[4] = {nullptr, nullptr, nullptr, nullptr}; // wR[i] in W-form (five pre-shifted rows per entry): the exchange product then has five columns, not nine
+    lzw28 *wRw_scaled = nullptr;
     int4 *mf_tab = nullptr;                            // matrix-core passes (ntt_mfma.h): the 4 KB operand table of omega_16
     fe *mf_wR_scaled = nullptr;                        // omega_256^e / n
     int mf_offs[16];
@@ -119,6 +122,7 @@ struct LzPassArgs {
     int weak;       // not the last pass: store any representative below 2^128 (lz_pack_weak), the next pass unpacks it
     const fe *tw_lo, *tw_hi, *twp;
     const lz8 *wR;
+    const lzw28 *wRw;  // the same table in W-form, or null (GSTARK_NTT_WEXCH=0)
     const lzw *wtab;   // W-forms: [0..6] omega_16^1..7, [7] 1/n.  Read with scalar loads right before each use (see LZ_FENCE)
 };
 
@@ -147,6 +151,18 @@ __device__ __forceinline__ lzw lz_load_w(const lzw *p) {
     return W;
 }
 
+__device__ __forceinline__ lzw lz_load_w28(const lzw28 *__restrict__ p) {
+    const int4 *q = reinterpret_cast<const int4 *>(p);
+    int32_t t[28];
+#pragma unroll
+    for (int k = 0; k < 7; k++) { const int4 a = q[k]; t[4 * k] = a.x; t[4 * k + 1] = a.y; t[4 * k + 2] = a.z; t[4 * k + 3] = a.w; }
+    lzw W;
+#pragma unroll
+    for (int r = 0; r < 5; r++)
+#pragma unroll
+        for (int l = 0; l < 5; l++) W.w[r][l] = t[5 * r + l];
+    return W;
+}
 __device__ __forceinline__ lz lz_load8(const lz8 *__restrict__ p) {
     const int4 a = *reinterpret_cast<const int4 *>(p);
     lz r;
@@ -497,8 +513,13 @@ __global__ __launch_bounds__(64, TW == 0 ? 4 : 3) void k_ntt_wave(const fe *__re
             if ((qa & 1) == 0) { LZ_FENCE(); __builtin_amdgcn_sched_barrier(0); }
             lz x = v[brev(qa, 4)];
             if (qa == 0 || qa == 8) x = lz_norm(x);
+#ifdef GS_NTT_WEXCH_BUILD      // the table in W-form — five columns, no high columns to bring down (measured: see DESIGN 3.1)
+            if (qa != 0) x = lz_mul_u(x, lz_load_w28(a.wRw + ((kx * qa) & (R - 1))), K);
+            else if (a.exq0) x = lz_mul_u(x, lz_load_w28(a.wRw), K);
+#else
             if (qa != 0) x = lz_mul_v(x, lz_load8(a.wR + ((kx * qa) & (R - 1))), K);
             else if (a.exq0) x = lz_mul_v(x, lz_load8(a.wR), K);
+#endif
             v[brev(qa, 4)] = x;
         }
         lz xb[GB][RB];
@@ -543,6 +564,24 @@ __global__ void k_build_lz_table(const fe *__restrict__ src, lz8 *__restrict__ d
         lz8 o;
         for (int l = 0; l < 5; l++) o.l[l] = u.l[l];
         o.l[5] = o.l[6] = o.l[7] = 0;
+        dst[i] = o;
+    }
+}
+__global__ void k_build_lzw_table(const fe *__restrict__ src, lzw28 *__restrict__ dst, uint64_t count, fe mult, int use_mult) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        fe x = src[i];
+        if (use_mult) x = fe_mul(x, mult);
+        lzw W;
+        lz_wform(x, W);
+        lzw28 o;
+        for (int r = 0; r < 5; r++) {
+            int32_t u[5];
+            for (int l = 0; l < 5; l++) u[l] = W.w[r][l];
+            for (int l = 0; l < 4; l++)      // signed digits, as in k_build_lz_table: the exchange inputs are sums of up to 9 NN values
+                if (u[l] >= (1 << 25)) { u[l] -= 1 << 26; u[l + 1] += 1; }
+            for (int l = 0; l < 5; l++) o.w[5 * r + l] = u[l];
+        }
+        o.w[25] = o.w[26] = o.w[27] = 0;
         dst[i] = o;
     }
 }
@@ -766,11 +805,16 @@ static int plan_get(gs_ctx *c, const fe &omega, uint64_t n, NttPlan **out) {
                 }
 #ifdef GS_NTT_LAZY
                 for (int k = 0; k < i; k++)
-                    if (p->L[k] == p->L[i]) p->wRz[i] = p->wRz[k];
+                    if (p->L[k] == p->L[i]) { p->wRz[i] = p->wRz[k]; p->wRw[i] = p->wRw[k]; }
                 if (!p->wRz[i]) {
                     if ((rc = gs_alloc(c, R * sizeof(lz8), &q))) { delete p; return rc; }
                     p->wRz[i] = (lz8 *)q;
                     hipLaunchKernelGGL(k_build_lz_table, dim3(gs_grid(R)), dim3(256), 0, c->stream, p->wR[i], p->wRz[i], R, fe_one(), 0);
+#ifdef GS_NTT_WEXCH_BUILD
+                    if ((rc = gs_alloc(c, R * sizeof(lzw28), &q))) { delete p; return rc; }
+                    p->wRw[i] = (lzw28 *)q;
+                    hipLaunchKernelGGL(k_build_lzw_table, dim3(gs_grid(R)), dim3(256), 0, c->stream, p->wR[i], p->wRw[i], R, fe_one(), 0);
+#endif
                 }
 #endif
             }
@@ -891,6 +935,14 @@ static bool ntt_wave_enabled() {   // GSTARK_NTT_WAVE=0 keeps the 128-thread wor
     return !(e && e[0] == '0');
 }
 
+static bool ntt_wexch_enabled() {   // build with -DGS_NTT_WEXCH_BUILD: k_ntt_wave takes its exchange twiddles from the W-form table
+#ifdef GS_NTT_WEXCH_BUILD
+    return true;
+#else
+    return false;
+#endif
+}
+
 static bool ntt_lazy_enabled() {   // GSTARK_NTT_LAZY=0 keeps the canonical-limb kernel (A/B measurements)
     const char *e = getenv("GSTARK_NTT_LAZY");   // read per call: tools/ntt_ab.py flips it inside one process
     return !(e && e[0] == '0');
@@ -955,6 +1007,8 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
             a.tw_hi = p->tw_hi;
             a.twp = p->twp[i];
             a.wR = p->wRz[i];
+            const bool wexch = ntt_wexch_enabled();
+            a.wRw = wexch ? p->wRw[i] : nullptr;
             a.scale = 0;
             a.exq0 = 0;
             a.weak = last ? 0 : 1;
@@ -967,6 +1021,15 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
                         hipLaunchKernelGGL(k_build_lz_table, dim3(gs_grid(R)), dim3(256), 0, c->stream, p->wR[i], p->wRz_scaled, R, ninv, 1);
                     }
                     a.wR = p->wRz_scaled;
+                    if (wexch) {
+                        if (!p->wRw_scaled) {
+                            void *q;
+                            if ((rc = gs_alloc(c, R * sizeof(lzw28), &q))) { if (tmp) gs_tmp_free(c, tmp); return rc; }
+                            p->wRw_scaled = (lzw28 *)q;
+                            hipLaunchKernelGGL(k_build_lzw_table, dim3(gs_grid(R)), dim3(256), 0, c->stream, p->wR[i], p->wRw_scaled, R, ninv, 1);
+                        }
+                        a.wRw = p->wRw_scaled;
+                    }
                     a.exq0 = 1;
                 } else {
                     a.scale = 1;
