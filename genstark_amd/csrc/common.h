@@ -55,6 +55,7 @@ struct gs_ctx {
     void *h_stage_dev = nullptr;  // the device-side address of h_stage
     void *d_stage = nullptr;
     uint64_t stage_bytes = 0;
+    void *fri_x = nullptr;        // the evaluation point gs_fri_fold_seeded derives on the device
     uint64_t jit_launches = 0;    // compiled-program launches so far (gs_air_jit_launches)
     uint64_t host_trace_segments = GS_HOST_TRACE_MAX_SEGMENTS;   // traces of at most this many segments run on a host core (GSTARK_HOST_TRACE_SEGMENTS; air_vm.hip)
     bool air_jit = false;         // AIR programs compiled with hiprtc instead of interpreted (gs_air_jit / GSTARK_AIR_JIT=1)

@@ -153,6 +153,32 @@ static int check_alg(gs_ctx *c, gs_hash_alg alg) {
     return GS_OK;
 }
 
+// field.prng(seed) for a 32-byte seed already on the device: sha256(seed) as a big-endian integer, mod p (byte-wise Horner: the same
+// code serves every field flavour).  One lane; the point of it is that the host does not have to see the seed.
+__global__ void k_prng_point(const uint32_t *__restrict__ seed, fe *__restrict__ out) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = bswap32(seed[i]);
+    w[8] = 0x80000000u;
+#pragma unroll
+    for (int i = 9; i < 15; i++) w[i] = 0;
+    w[15] = 256;                                     // message length in bits
+    sha256_compress(h, w);
+    fe x = fe_zero();
+    const fe b = fe_make(256u, 0u, 0u, 0u);
+    for (int i = 0; i < 8; i++)
+        for (int k = 3; k >= 0; k--) x = fe_add(fe_mul(x, b), fe_make((h[i] >> (8 * k)) & 0xFFu, 0u, 0u, 0u));
+    *out = x;
+}
+int gs_prng_point_dev(gs_ctx *c, const void *seed32_dev, fe *out_dev) {
+    if (((uintptr_t)seed32_dev) & 3) return gs_fail(c, GS_ERR_ARG, "prng_point: the seed must be 4-byte aligned");
+    hipLaunchKernelGGL(k_prng_point, dim3(1), dim3(64), 0, c->stream, (const uint32_t *)seed32_dev, out_dev);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
 extern "C" {
 
 int gs_hash_digest_values(gs_ctx *c, gs_hash_alg alg, const void *buf, uint64_t value_size, uint64_t count, void *out) {

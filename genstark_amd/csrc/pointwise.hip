@@ -364,7 +364,8 @@ __global__ void k_quartic_eval(const fe *__restrict__ polys, uint64_t rows, fe x
 // (column[r], column[r + rows], column[r + 2 rows], column[r + 3 rows]) at x_r zeta^c; the cubic through them evaluated at X is
 // (u0 + u1 t + u2 t^2 + u3 t^3) / 4 with u = the inverse 4-point DFT above and t = X / x_r.
 __global__ void k_fri_fold(const fe *__restrict__ column, uint64_t rows, uint64_t step, uint64_t n, const fe *__restrict__ tw_lo,
-                           const fe *__restrict__ tw_hi, int log_lo, int logn, fe zeta_inv, fe inv4, fe X, fe *__restrict__ out) {
+                           const fe *__restrict__ tw_hi, int log_lo, int logn, fe zeta_inv, fe inv4, fe X, const fe *__restrict__ Xdev, fe *__restrict__ out) {
+    if (Xdev) X = *Xdev;                               // the evaluation point was derived on the device (gs_fri_fold_seeded)
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * blockDim.x) {
         fe y0 = column[r], y1 = column[r + rows], y2 = column[r + 2 * rows], y3 = column[r + 3 * rows];
         fe s0 = fe_add(y0, y2), s1 = fe_sub(y0, y2), s2 = fe_add(y1, y3);
@@ -611,8 +612,7 @@ int gs_interpolate_quartic_domain(gs_ctx *c, const gs_elt *omega, uint64_t n, ui
     return GS_OK;
 }
 
-int gs_fri_fold(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const gs_elt *x, void *out) {
-    if (!c || !omega || !column || !x || !out) return GS_ERR_ARG;
+static int fri_fold_launch(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, fe x, const fe *x_dev, void *out) {
     if (!gs_is_pow2(n) || n < 4 || m < 4 || m * step != n) return gs_fail(c, GS_ERR_ARG, "fri_fold: column length * step != n");
     if (column == out) return gs_fail(c, GS_ERR_ARG, "fri_fold: output must not alias the column");
     fe w = fe_from_bytes(omega);
@@ -624,9 +624,24 @@ int gs_fri_fold(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const
     fe zeta_inv = fe_mul(fe_mul(zeta, zeta), zeta);  // zeta^3 = zeta^-1
     fe inv4 = fe_inv(fe_from_u64(4));
     hipLaunchKernelGGL(k_fri_fold, dim3(gs_grid(m / 4)), dim3(256), 0, c->stream, (const fe *)column, m / 4, step, n, lo, hi, log_lo, gs_log2(n),
-                       zeta_inv, inv4, fe_from_bytes(x), (fe *)out);
+                       zeta_inv, inv4, x, x_dev, (fe *)out);
     GS_LAUNCH_CHECK(c);
     return GS_OK;
+}
+int gs_fri_fold(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const gs_elt *x, void *out) {
+    if (!c || !omega || !column || !x || !out) return GS_ERR_ARG;
+    return fri_fold_launch(c, omega, n, step, column, m, fe_from_bytes(x), nullptr, out);
+}
+extern "C++" int gs_prng_point_dev(gs_ctx *c, const void *seed32_dev, fe *out_dev);   // hash.hip
+int gs_fri_fold_seeded(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const void *seed32_dev, void *out) {
+    if (!c || !omega || !column || !seed32_dev || !out) return GS_ERR_ARG;
+    if (!c->fri_x) {   // 16 bytes that live as long as the context: every use is ordered on the context's stream
+        int rc = gs_alloc(c, GS_ELT, &c->fri_x);
+        if (rc) return rc;
+    }
+    int rc = gs_prng_point_dev(c, seed32_dev, (fe *)c->fri_x);
+    if (rc) return rc;
+    return fri_fold_launch(c, omega, n, step, column, m, fe_zero(), (const fe *)c->fri_x, out);
 }
 
 int gs_eval_quartic_batch(gs_ctx *c, const void *polys, uint64_t rows, const gs_elt *x, void *out) {

@@ -36,7 +36,7 @@ namespace {
     X(gs_eval_polys_at_roots) X(gs_interpolate_roots) X(gs_interpolate_quartic_domain) X(gs_eval_quartic_batch)                \
     X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
     X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
-    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_defer_begin) X(gs_defer_end)
+    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end)
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
     GS_API_LIST(X)
@@ -156,15 +156,24 @@ struct Tree {
     uint64_t n = 0;
     Bytes root;
 };
-Tree build_tree(Ctx &x, int alg, Buf &&leaves, uint64_t n) {
+// read_root = false leaves the root on the device (nodes + DIGEST): the FRI layers derive their evaluation points from it there
+// (gs_fri_fold_seeded) and fetch_roots() reads all of them back in one round trip
+Tree build_tree(Ctx &x, int alg, Buf &&leaves, uint64_t n, bool read_root = true) {
     Tree t;
     t.n = n;
     t.leaves = std::move(leaves);
     t.nodes = Buf(x, n * DIGEST);
     x.check(A.gs_merkle_build(x.c, (gs_hash_alg)alg, t.leaves.p, n, t.nodes.p), "gs_merkle_build");
     t.root.resize(DIGEST);
-    x.check(A.gs_download(x.c, t.root.data(), t.nodes.at(DIGEST), DIGEST), "gs_download(root)");
+    if (read_root) x.check(A.gs_download(x.c, t.root.data(), t.nodes.at(DIGEST), DIGEST), "gs_download(root)");
     return t;
+}
+void fetch_roots(Ctx &x, const std::vector<Tree *> &trees) {
+    if (trees.empty()) return;
+    const uint64_t one = 1;                        // record 1 of the node array (32-byte records) is the root
+    x.check(A.gs_defer_begin(x.c), "gs_defer_begin");
+    for (Tree *t : trees) x.check(A.gs_gather(x.c, t->nodes.p, DIGEST, &one, 1, t->root.data()), "gs_gather(root)");
+    x.check(A.gs_defer_end(x.c), "gs_defer_end");
 }
 // The query answers of a proof are issued inside one deferral window (gs_defer_begin / gs_defer_end): the calls below queue the
 // device work into buffers that stay put (std::deque) and `unpack` builds the proof objects after the single synchronisation.
@@ -665,17 +674,12 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     {
         Buf h(x, N / 4 * DIGEST);
         hash_rows4(x, alg, lEval.p, N / 4, h.p);                                                      // :45
-        pTree0 = build_tree(x, alg, std::move(h), N / 4);
+        pTree0 = build_tree(x, alg, std::move(h), N / 4, false);
     }
-    const uint32_t exe_count = (uint32_t)std::min<uint64_t>(job.exe_query_count, N - N / E);
-    std::vector<uint64_t> exe_positions = query_indexes(pTree0.root, exe_count, N, (uint32_t)E);   // QueryIndexGenerator.ts:28-32
-    std::vector<uint64_t> lc_positions;
-    for (uint64_t p : exe_positions) lc_positions.push_back(p % (N / 4));
-    lc_positions = unique_in_order(lc_positions);                                                 // LowDegreeProver.ts:302-309
-    MerkleProof lcProof = prove_batch(x, pTree0, lc_positions);
-    gather_rows4(x, lEval.p, N / 4, lc_positions, &lcProof);
 
-    // layers (:176-221): the loop below is the recursion unrolled; queries are answered afterwards
+    // layers (:176-221): the loop below is the recursion unrolled.  No root is read back inside it: the point every layer folds at,
+    // prng(root of the tree above) (:194), is derived on the device from the root where it lies (gs_fri_fold_seeded), so all layers
+    // are enqueued without a round trip; the roots (the proof needs them, and so do the query positions) come back together below
     std::vector<Layer> layers;
     Tree *pTree = &pTree0;
     const void *column_src = lEval.p;   // the current layer's values in natural order (the remainder at the end)
@@ -695,23 +699,38 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         L.column_length = rows;
         L.next = Buf(x, rows * ELEM);
         le16(omega, s16);
-        le16(prng_one(pTree->root), s16b);                                                        // :194
-        x.check(A.gs_fri_fold(x.c, s16, N, step, column_src, len, s16b, L.next.p), "gs_fri_fold");     // :189-198
+        x.check(A.gs_fri_fold_seeded(x.c, s16, N, step, column_src, len, pTree->nodes.at(DIGEST), L.next.p), "gs_fri_fold_seeded");   // :189-198
         Buf h(x, rows / 4 * DIGEST);
         hash_rows4(x, alg, L.next.p, rows / 4, h.p);                                                  // :201
-        L.cTree = build_tree(x, alg, std::move(h), rows / 4);
+        L.cTree = build_tree(x, alg, std::move(h), rows / 4, false);
         column_src = L.next.p;
         pTree = &L.cTree;
         len = rows;
         max_degree_plus1 /= 4;
         depth++;
     }
-    clock.mark("FRI layers (roots read back one by one)");
-    // remainder (:179-187): the natural-order vector the last polyValues came from
+    clock.mark("FRI layers issued");
+    // one round trip: every root and the remainder (:179-187: the natural-order vector the last polyValues came from)
     std::vector<F> remainder(len);
+    Bytes remainder_raw(len * ELEM);
     {
-        Bytes raw(len * ELEM);
-        x.check(A.gs_download(x.c, raw.data(), column_src, len * ELEM), "gs_download(remainder)");
+        std::vector<uint64_t> all(len);
+        for (uint64_t i = 0; i < len; i++) all[i] = i;
+        const uint64_t one = 1;                        // record 1 of a node array (32-byte records) is the root
+        x.check(A.gs_defer_begin(x.c), "gs_defer_begin");
+        x.check(A.gs_gather(x.c, pTree0.nodes.p, DIGEST, &one, 1, pTree0.root.data()), "gs_gather(root)");
+        for (Layer &L : layers) x.check(A.gs_gather(x.c, L.cTree.nodes.p, DIGEST, &one, 1, L.cTree.root.data()), "gs_gather(root)");
+        x.check(A.gs_gather(x.c, column_src, ELEM, all.data(), len, remainder_raw.data()), "gs_gather(remainder)");
+        x.check(A.gs_defer_end(x.c), "gs_defer_end");
+    }
+    clock.mark("FRI roots + remainder read back (1 round trip)");
+    const uint32_t exe_count = (uint32_t)std::min<uint64_t>(job.exe_query_count, N - N / E);
+    std::vector<uint64_t> exe_positions = query_indexes(pTree0.root, exe_count, N, (uint32_t)E);   // QueryIndexGenerator.ts:28-32
+    std::vector<uint64_t> lc_positions;
+    for (uint64_t p : exe_positions) lc_positions.push_back(p % (N / 4));
+    lc_positions = unique_in_order(lc_positions);                                                 // LowDegreeProver.ts:302-309
+    {
+        Bytes &raw = remainder_raw;
         for (uint64_t i = 0; i < len; i++) remainder[i] = from16(raw.data() + 16 * i);
         // verifyRemainder (:223-252)
         F rou = omega;
@@ -738,13 +757,16 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
             }
         }
     }
-    clock.mark("remainder read back + checked");
+    clock.mark("remainder checked");
     // queries of every layer (:209-219) and the spot checks of the evaluation tree (lib/Stark.ts:146-152, 274-296): every position
     // follows from roots the host already holds, so all the answers are requested in one deferral window — one round trip
     struct Component { Bytes columnRoot; MerkleProof columnProof, polyProof; };
     std::vector<Component> components(layers.size());
     Readbacks rb;
     x.check(A.gs_defer_begin(x.c), "gs_defer_begin");
+    MerkleProof lcProof;                                                                          // LowDegreeProver.ts:52-54
+    rb.prove_batch(x, pTree0, lc_positions, &lcProof);
+    rb.gather_rows4(x, lEval.p, N / 4, lc_positions, &lcProof);
     for (size_t d = 0; d < layers.size(); d++) {
         Layer &L = layers[d];
         std::vector<uint64_t> positions = query_indexes(L.cTree.root, job.fri_query_count, L.column_length, (uint32_t)E);

@@ -177,6 +177,11 @@ int gs_eval_quartic_batch(gs_ctx *ctx, const void *polys, uint64_t rows, const g
  * evalQuarticBatch fused — the transposed matrix and the cubics are never written): rows = m/4, m * step = n,
  *     out[r] = P_r(x),  P_r the cubic through (omega^((r + c*rows) * step), column[r + c*rows]), c < 4. */
 int gs_fri_fold(gs_ctx *ctx, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const gs_elt *x, void *out);
+/* The same folding step with x = field.prng(seed) derived ON THE DEVICE from a 32-byte seed in device memory — the root of the tree
+ * that commits to `column`'s parent (nodes + 32 of gs_merkle_build), LowDegreeProver.ts:194: prng(seed) = sha256(seed) read as a
+ * big-endian integer, mod p.  The host never needs the root to issue the next layer: a driver enqueues every FRI layer without a
+ * round trip and reads all the roots back once. */
+int gs_fri_fold_seeded(gs_ctx *ctx, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const void *seed32_dev, void *out);
 
 /* ---- hashing / Merkle (merkle package) --------------------------------------------------------- */
 /* Hash.digest(Buffer) on host bytes (verifier side; lib/utils/index.ts:37) — runs on the device

@@ -78,6 +78,7 @@ const FnDesc kFns[] = {
     {"gs_interpolate_quartic_domain", "cbuupup"},
     {"gs_eval_quartic_batch", "cpubp"},
     {"gs_fri_fold", "cbuupubp"},
+    {"gs_fri_fold_seeded", "cbuupupp"},
     {"gs_hash_digest", "cibuo"},
     {"gs_hash_merge_rows", "ciaiup"},
     {"gs_hash_digest_values", "cipuup"},

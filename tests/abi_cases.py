@@ -156,7 +156,18 @@ def check_fri_fold(backend, rng, logn, depth):
                     num, den = num * (x - xk) % P, den * (xj - xk) % P
             acc = (acc + yj * num * pow(den, P - 2, P)) % P
         assert out.getValue(r) == acc
-    return out.toBuffer()
+    # gs_fri_fold_seeded: the same step with x = prng(seed) = sha256(seed) as a big-endian integer mod p, derived where the seed
+    # lies (a 32-byte digest in device memory — LowDegreeProver.ts:194 takes the root of the tree above)
+    import hashlib
+    seed = bytes(rng.randrange(256) for _ in range(32))
+    xs_ = int.from_bytes(hashlib.sha256(seed).digest(), 'big') % P
+    sv = f.newVector(2)
+    f.backend.upload(sv.ptr, seed)
+    got, want2 = f.newVector(m // 4), f.newVector(m // 4)
+    f.backend.call('gs_fri_fold_seeded', f.le(w), n, step, C.c_void_p(column.ptr), m, C.c_void_p(sv.ptr), C.c_void_p(got.ptr))
+    f.backend.call('gs_fri_fold', f.le(w), n, step, C.c_void_p(column.ptr), m, f.le(xs_), C.c_void_p(want2.ptr))
+    assert got.toBuffer() == want2.toBuffer()
+    return out.toBuffer() + got.toBuffer()
 
 
 def check_mimc_composition(backend, rng, logn, logsteps, nroots):
