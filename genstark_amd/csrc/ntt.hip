@@ -130,6 +130,8 @@ struct LzPassArgs {
 // radix-16 twiddles to the top of the unrolled network (175 live SGPRs -> spills to VGPR lanes, one v_readlane per use);
 // a compiler-only memory fence before each product keeps every load next to its use.
 #define LZ_FENCE() asm volatile("" ::: "memory")
+// makes a value opaque where it stands (no instruction): it is computed before this point and cannot be rematerialised after it
+#define LZ_PIN(x) asm volatile("" : "+v"((x).l[0]), "+v"((x).l[1]), "+v"((x).l[2]), "+v"((x).l[3]), "+v"((x).l[4]))
 // ... and read through the constant address space: a lane-uniform load from it is always a scalar load, whatever stores and
 // fences surround it (the table is written once, when the plan is made, long before any kernel that reads it is launched)
 typedef const lzw *lzw_cptr;
@@ -191,6 +193,10 @@ __device__ __forceinline__ void ntt_dif_lz_level(lz (&x)[1 << LOGN], lzw_cptr w,
             const lz u = x[b + i], v = x[b + i + S];
             x[b + i] = lz_add(u, v);
             x[b + i + S] = lz_sub(u, v);
+            // pin both results HERE: left alone, the compiler sinks each subtraction down to the product that consumes it, which keeps
+            // the inputs of all the level's butterflies alive beside their sums (~50 extra VGPRs on the twiddled passes: round 2's spills)
+            LZ_PIN(x[b + i]);
+            LZ_PIN(x[b + i + S]);
         }
     }
     // the products, software-pipelined on the scalar side: the 25 words of the NEXT multiplier are requested before the
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(128, 2) void k_ntt_pass_lz(const fe *__restrict__ i
 // The first pass writes its tile (contiguous in q for RB = 16) straight from registers; first passes of other radices keep the
 // workgroup kernel (their stores would be 16-byte pieces).
 template <int LB, int TW>
-__global__ __launch_bounds__(64, TW == 0 ? 4 : 3) void k_ntt_wave(const fe *__restrict__ in, fe *__restrict__ out, LzPassArgs a) {
+__global__ __launch_bounds__(64, 4) void k_ntt_wave(const fe *__restrict__ in, fe *__restrict__ out, LzPassArgs a) {
     constexpr int RB = 1 << LB, R = 16 * RB, GB = 16 / RB, LOGWJ = 6 - LB, Wj = 64 >> LB;
     constexpr bool FIRST = (TW == 0);
     static_assert(!FIRST || LB == 4, "first passes of radix below 256 use k_ntt_pass_lz");
@@ -422,7 +428,6 @@ __global__ __launch_bounds__(64, TW == 0 ? 4 : 3) void k_ntt_wave(const fe *__re
     const uint64_t j = (uint64_t)tile * Wj + jj;
     const uint64_t nR = a.n >> (4 + LB);
     const fe *src = in + (uint64_t)blockIdx.y * a.in_stride;
-    fe *dst = out + (uint64_t)blockIdx.y * a.out_stride;
     const uint64_t Ns = 1ull << a.logNs;
     const uint64_t jq = j & (Ns - 1);
 
@@ -449,38 +454,36 @@ __global__ __launch_bounds__(64, TW == 0 ? 4 : 3) void k_ntt_wave(const fe *__re
             }
         }
         if constexpr (TW == 1) {
-            // twiddle [k][jq] for k = kk + RB*m: all sixteen requested at once, like the data (the table sits in L2, but a load is
-            // still several product-times away; with three waves per SIMD the 168-VGPR budget holds both sets of 64)
+            // twiddle [k][jq] for k = kk + RB*m, streamed FOUR at a time behind the sixteen data loads: raw[] shrinks by 16 registers per
+            // group while v[] grows by 20, so the live set stays under the 128 VGPRs that four waves per SIMD leave (all sixteen
+            // twiddles at once cost 64 more registers: three waves and 48-72 bytes of scratch per lane in round 2)
             const fe *tp = a.twp + ((uint64_t)kk << a.logNs) + jq;
             const uint64_t tstep = (uint64_t)RB << a.logNs;
-            fe tws[16];
-#pragma unroll
-            for (int m = 0; m < 16; m++) { tws[m] = *tp; tp += tstep; }
+            fe tws[4];
 #pragma unroll
             for (int m = 0; m < 16; m++) {
-                v[m] = lz_mul_v(lz_unpack(raw[m]), lz_unpack(tws[m]), K);
-                if (m & 1) __builtin_amdgcn_sched_barrier(0);
+                if ((m & 3) == 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { tws[u] = *tp; tp += tstep; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                v[m] = lz_mul_v(lz_unpack(raw[m]), lz_unpack(tws[m & 3]), K);
             }
+            __builtin_amdgcn_sched_barrier(0);
         } else if constexpr (TW == 2) {
+            // v[m] *= omega^(jq * (kk + RB*m) * eu): start value + running product.  The step is a per-lane value (jq differs between
+            // the lanes of a tile), and its W-form would be 25 VGPRs: a plain five-limb multiplier and lz_mul_v keep the pass at four
+            // waves per SIMD with nothing in scratch
             const uint64_t eu = a.n >> (a.logNs + 4 + LB);
             lz cur = lz_pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * kk * eu, K);
-            lz row = lz_pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * RB * eu, K);
-            lzw step;
-#pragma unroll
-            for (int r = 0; r < 5; r++) {
-#pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    step.w[r][c] = row.l[c];
-                    asm volatile("" : "+v"(step.w[r][c]));      // see k_ntt_pass_lz
-                }
-                if (r < 4) row = lz_shift_limb(row, K);
-            }
+            const lz step = lz_pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * RB * eu, K);
 #pragma unroll
             for (int m = 0; m < 16; m++) {
                 __builtin_amdgcn_sched_barrier(0);
                 v[m] = lz_mul_v(lz_unpack(raw[m]), cur, K);
-                if (m < 15) cur = lz_mul_u(cur, step, K);
+                if (m < 15) cur = lz_mul_v(cur, step, K);
             }
+            __builtin_amdgcn_sched_barrier(0);
         } else {
 #pragma unroll
             for (int m = 0; m < 16; m++) v[m] = lz_unpack(raw[m]);
@@ -488,38 +491,48 @@ __global__ __launch_bounds__(64, TW == 0 ? 4 : 3) void k_ntt_wave(const fe *__re
         ntt_dif_lz<4>(v, (lzw_cptr)a.wtab, K);
     }
 
-    // The radix-16 network above needs ~125 of the 128 VGPRs four waves per SIMD leave: nothing else may live across it.  Lane and
-    // tile coordinates are therefore derived AGAIN from the thread index here (the asm makes the copy opaque, so the compiler
-    // cannot keep the earlier values alive instead of recomputing them).
+    // The radix-16 network above needs ~125 of the 128 VGPRs four waves per SIMD leave, and two W-forms (50 SGPRs) at a time:
+    // nothing else may live across it, in either register file.  Lane and tile coordinates are therefore derived AGAIN from the
+    // thread index here, and every kernel argument the second half uses is read AGAIN from the kernel-argument segment through a
+    // pointer the compiler cannot see through (by-value arguments are preloaded at the top and stay live: with ~40 argument
+    // words beside the W-forms the scalar file overflowed into v_writelane / v_readlane traffic and, with it, into scratch).
+    typedef const __attribute__((address_space(4))) unsigned char *kseg_t;
+    typedef const __attribute__((address_space(4))) LzPassArgs *kargs_t;
+    kseg_t kp = (kseg_t)__builtin_amdgcn_kernarg_segment_ptr();
     int t2 = threadIdx.x;
-    asm volatile("" : "+v"(t2));
+    asm volatile("" : "+s"(kp), "+v"(t2) : : "memory");
+    fe *const out2 = *(fe *const __attribute__((address_space(4))) *)(kp + 8);
+    const kargs_t b = (kargs_t)(kp + 16);
+    fe *const dst = out2 + (uint64_t)blockIdx.y * b->out_stride;
+    const uint64_t Ns2 = 1ull << b->logNs;
+    const int weak = b->weak;
+    uint32_t tile2 = blockIdx.x;
+    if ((gridDim.x & 15) == 0) tile2 = (tile2 & ~15u) | ((tile2 & 7u) << 1) | ((tile2 >> 3) & 1u);
     const int jj2 = t2 & (Wj - 1);
     const int kk2 = t2 >> LOGWJ;
-    const uint64_t j2 = (uint64_t)tile * Wj + jj2;
-    const uint64_t jq2 = j2 & (Ns - 1);
+    const uint64_t j2 = (uint64_t)tile2 * Wj + jj2;
+    const uint64_t jq2 = j2 & (Ns2 - 1);
     const uint64_t jbase = (j2 - jq2) * R + jq2;
     if constexpr (RB == 1) {
+        const int scale = b->scale;
+        const lzw_cptr wt = b->wtab;
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             lz x = v[brev(q, 4)];
-            if (a.scale) { LZ_FENCE(); const lzw W = lz_load_w(a.wtab + 7); x = lz_mul_u(lz_norm(x), W, K); }
-            dst[jbase + (uint64_t)q * Ns] = lz_pack_flag(x, a.weak);
+            if (scale) { LZ_FENCE(); const lzw W = lz_load_w(wt + 7); x = lz_mul_u(lz_norm(x), W, K); }
+            dst[jbase + (uint64_t)q * Ns2] = lz_pack_flag(x, weak);
         }
     } else {
         // ---- exchange twiddles in place, then the exchange itself, limb plane by limb plane
-        const int kx = kk2;
+        const lz8 *const wR = b->wR;
+        const int exq0 = b->exq0;
 #pragma unroll
         for (int qa = 0; qa < 16; qa++) {
             if ((qa & 1) == 0) { LZ_FENCE(); __builtin_amdgcn_sched_barrier(0); }
             lz x = v[brev(qa, 4)];
             if (qa == 0 || qa == 8) x = lz_norm(x);
-#ifdef GS_NTT_WEXCH_BUILD      // the table in W-form — five columns, no high columns to bring down (measured: see DESIGN 3.1)
-            if (qa != 0) x = lz_mul_u(x, lz_load_w28(a.wRw + ((kx * qa) & (R - 1))), K);
-            else if (a.exq0) x = lz_mul_u(x, lz_load_w28(a.wRw), K);
-#else
-            if (qa != 0) x = lz_mul_v(x, lz_load8(a.wR + ((kx * qa) & (R - 1))), K);
-            else if (a.exq0) x = lz_mul_v(x, lz_load8(a.wR), K);
-#endif
+            if (qa != 0) x = lz_mul_v(x, lz_load8(wR + ((kk2 * qa) & (R - 1))), K);
+            else if (exq0) x = lz_mul_v(x, lz_load8(wR), K);
             v[brev(qa, 4)] = x;
         }
         lz xb[GB][RB];
@@ -534,18 +547,19 @@ __global__ __launch_bounds__(64, TW == 0 ? 4 : 3) void k_ntt_wave(const fe *__re
                 for (int k2 = 0; k2 < RB; k2++) xb[u][k2].l[l] = plane[kk2 * 17 * Wj + jj2 + (u * RB + k2) * Wj];
             __builtin_amdgcn_wave_barrier();
         }
+        const lzw_cptr wt = b->wtab;
 #pragma unroll
         for (int u = 0; u < GB; u++) {
             const int qa = kk2 * GB + u;
-            ntt_dif_lz<LB>(xb[u], (lzw_cptr)a.wtab, K);
+            ntt_dif_lz<LB>(xb[u], wt, K);
             // output q = qa + 16*qb: ONE running pointer, stepped by 16*Ns elements (16 separate 64-bit addresses would cost 32 VGPRs)
-            fe *o = FIRST ? dst + j2 * R + qa : dst + jbase + (uint64_t)qa * Ns;
-            const uint64_t ostep = FIRST ? 16 : (Ns << 4);
+            fe *o = FIRST ? dst + j2 * R + qa : dst + jbase + (uint64_t)qa * Ns2;
+            const uint64_t ostep = FIRST ? 16 : (Ns2 << 4);
 #pragma unroll
             for (int qb = 0; qb < RB; qb++) {
-                *o = lz_pack_flag(xb[u][brev(qb, LB)], a.weak);
+                *o = lz_pack_flag(xb[u][brev(qb, LB)], weak);
                 o += ostep;
-                if ((qb & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                if ((qb & 3) == 3 || qb == RB - 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
