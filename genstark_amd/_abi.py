@@ -85,6 +85,7 @@ _SIGNATURES = {
     'gs_hash_merge_rows': (_int, [_vp, _int, _pvp, _u32, _u64, _vp]),
     'gs_hash_digest_values': (_int, [_vp, _int, _vp, _u64, _u64, _vp]),
     'gs_merkle_build': (_int, [_vp, _int, _vp, _u64, _vp]),
+    'gs_merkle_commit_rows': (_int, [_vp, _int, _pvp, _u32, _u64, _vp, _vp]),
     'gs_merkle_prove_batch': (_int, [_vp, _vp, _vp, _u64, C.POINTER(_u64), _u32, _vp, C.POINTER(_u32), C.POINTER(_u32), _vp, _u64]),
     'gs_small_interpolate': (_int, [_bytes, _bytes, _u32, _vp]),
     'gs_small_eval_poly': (_int, [_bytes, _u32, _bytes, _u32, _vp]),

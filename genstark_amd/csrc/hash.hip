@@ -111,29 +111,150 @@ __global__ void k_hash_values64(const uint4 *__restrict__ buf, uint64_t count, u
         store_digest(out, i, d);
     }
 }
-// top of the tree: nodes[1 .. 2*width) for width <= 256 computed by one workgroup through LDS
+// ---------------------------------------------------------------------------------------------------------------------------
+// Merkle construction, fused (round 3).  A tree is built by at most a handful of launches instead of one per level:
+//   k_merkle_fused   — wide layers, streaming.  One thread owns 2^(lv-1) consecutive digests of a first layer and the lv - 1 layers
+//                      of nodes above them (lv <= 4: 8 + 4 + 2 + 1 = 15 compressions), depth first: it keeps one pending digest
+//                      per height (in LDS, [height][word][thread]: conflict-free, and indexable — a register array indexed by the
+//                      height would live in scratch), so a node is hashed the moment its second child exists and no layer is read
+//                      back from memory.  The code is a LOOP around two compression sites (first layer, node): unrolled, fifteen
+//                      inlined compressions would be 120 KB of straight-line code per wave against a 64 KB instruction cache.
+//   k_merkle_subtree — layers of at most 2^15 digests.  One workgroup owns `chunk` (<= 1024) consecutive digests of a layer and the
+//                      whole subtree above them, level by level through LDS (heap layout: levels occupy disjoint slots, one barrier
+//                      per level); with chunk = layer width it finishes the tree (root at nodes[1], nodes[0] = 0).
+// The first layer of either kernel is (SRC 0) a node layer, H(child[2i] || child[2i+1]) of the digests below, or the tree's LEAVES
+// hashed from the committed vectors themselves: (1) H(v[i]), (2) H(v_0[i] || ... || v_{count-1}[i]) — mergeVectorRows fused into
+// the construction (gs_merkle_commit_rows).
+template <int ALG, int SRC>
+__device__ __forceinline__ void first_layer_digest(const HashPtrArgs &va, uint32_t count, const uint4 *__restrict__ child, uint64_t i, uint32_t d[8]) {
+    if constexpr (SRC == 0) {
+        const uint4 *p = child + 4 * i;
+        const uint4 x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3];
+        digest_words16<ALG>([&](uint32_t w) { return w == 0 ? x0 : (w == 1 ? x1 : (w == 2 ? x2 : x3)); }, 4, d);
+    } else if constexpr (SRC == 1) {
+        const uint4 *p = va.v[0] + i * GS_EW;
+        digest_words16<ALG>([&](uint32_t w) { return p[w]; }, GS_EW, d);
+    } else {
+        digest_words16<ALG>([&](uint32_t w) { return va.v[w / GS_EW][i * GS_EW + w % GS_EW]; }, count * GS_EW, d);
+    }
+}
 template <int ALG>
-__global__ void k_merkle_top(uint4 *__restrict__ nodes, uint32_t width) {
-    __shared__ uint4 sh[2 * 512];  // sh[2*i], sh[2*i+1] = digest of heap node i (i < 512)
-    // load level [width, 2*width)
-    for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) {
-        sh[2 * (width + i)] = nodes[2 * (uint64_t)(width + i)];
-        sh[2 * (width + i) + 1] = nodes[2 * (uint64_t)(width + i) + 1];
+__device__ __forceinline__ void merge_digests(const uint32_t l[8], const uint32_t r[8], uint32_t d[8]) {
+    const uint4 x0 = make_uint4(l[0], l[1], l[2], l[3]), x1 = make_uint4(l[4], l[5], l[6], l[7]);
+    const uint4 x2 = make_uint4(r[0], r[1], r[2], r[3]), x3 = make_uint4(r[4], r[5], r[6], r[7]);
+    digest_words16<ALG>([&](uint32_t w) { return w == 0 ? x0 : (w == 1 ? x1 : (w == 2 ? x2 : x3)); }, 4, d);
+}
+
+#define GS_MERKLE_MAX_LV 4
+template <int ALG, int SRC>
+__global__ __launch_bounds__(256) void k_merkle_fused(HashPtrArgs va, uint32_t count, const uint4 *__restrict__ child, uint64_t groups, int lv,
+                                                      uint4 *__restrict__ outA, uint4 *__restrict__ nodes, uint64_t wA) {
+    __shared__ uint32_t pending[GS_MERKLE_MAX_LV - 1][8][256];
+    const int K = 1 << (lv - 1), tid = threadIdx.x;
+    for (uint64_t g = blockIdx.x * (uint64_t)256 + tid; g < groups; g += (uint64_t)gridDim.x * 256) {
+        for (int k = 0; k < K; k++) {
+            uint64_t idx = g * K + k;
+            uint32_t cur[8];
+            first_layer_digest<ALG, SRC>(va, count, child, idx, cur);
+            store_digest(outA, idx, cur);
+            int h = 0;
+            for (; (k >> h) & 1; h++) {       // the left sibling at this height is waiting: hash the pair, go one layer up
+                uint32_t l[8];
+#pragma unroll
+                for (int w = 0; w < 8; w++) l[w] = pending[h][w][tid];
+                merge_digests<ALG>(l, cur, cur);
+                idx >>= 1;
+                store_digest(nodes, (wA >> (h + 1)) + idx, cur);
+            }
+            if (h < lv - 1) {
+#pragma unroll
+                for (int w = 0; w < 8; w++) pending[h][w][tid] = cur[w];
+            }
+        }
+    }
+}
+
+#define GS_MERKLE_CHUNK 1024
+template <int ALG, int SRC>
+__global__ __launch_bounds__(256) void k_merkle_subtree(HashPtrArgs va, uint32_t count, const uint4 *__restrict__ layerA, uint4 *__restrict__ outA,
+                                                        uint4 *__restrict__ nodes, uint64_t wA, uint32_t chunk) {
+    __shared__ uint4 sh[4 * GS_MERKLE_CHUNK];   // digest of subtree-heap node s at sh[2s], sh[2s + 1]; the first layer is s in [chunk, 2 chunk)
+    const uint64_t base = (uint64_t)blockIdx.x * chunk;
+    for (uint32_t i = threadIdx.x; i < chunk; i += 256) {
+        if constexpr (SRC == 0) {
+            sh[2 * (chunk + i)] = layerA[2 * (base + i)];
+            sh[2 * (chunk + i) + 1] = layerA[2 * (base + i) + 1];
+        } else {
+            uint32_t d[8];
+            first_layer_digest<ALG, SRC>(va, count, nullptr, base + i, d);
+            store_digest(outA, base + i, d);
+            sh[2 * (chunk + i)] = make_uint4(d[0], d[1], d[2], d[3]);
+            sh[2 * (chunk + i) + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+        }
     }
     __syncthreads();
-    for (uint32_t w = width / 2; w >= 1; w >>= 1) {
-        for (uint32_t i = threadIdx.x; i < w; i += blockDim.x) {
-            const uint32_t node = w + i;
-            uint4 x0 = sh[4 * node], x1 = sh[4 * node + 1], x2 = sh[4 * node + 2], x3 = sh[4 * node + 3];
+    uint64_t wl = wA >> 1;       // width of the layer being produced: it lives at nodes[wl .. 2 wl)
+    for (uint32_t m = chunk / 2; m >= 1; m >>= 1, wl >>= 1) {
+        for (uint32_t i = threadIdx.x; i < m; i += 256) {
+            const uint32_t s = m + i;
+            const uint4 x0 = sh[4 * s], x1 = sh[4 * s + 1], x2 = sh[4 * s + 2], x3 = sh[4 * s + 3];
             uint32_t d[8];
             digest_words16<ALG>([&](uint32_t k) { return k == 0 ? x0 : (k == 1 ? x1 : (k == 2 ? x2 : x3)); }, 4, d);
-            sh[2 * node] = make_uint4(d[0], d[1], d[2], d[3]);
-            sh[2 * node + 1] = make_uint4(d[4], d[5], d[6], d[7]);
-            store_digest(nodes, node, d);
+            sh[2 * s] = make_uint4(d[0], d[1], d[2], d[3]);
+            sh[2 * s + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+            store_digest(nodes, wl + (uint64_t)blockIdx.x * m + i, d);
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { nodes[0] = make_uint4(0, 0, 0, 0); nodes[1] = make_uint4(0, 0, 0, 0); }
+    if (chunk == wA && threadIdx.x == 0) { nodes[0] = make_uint4(0, 0, 0, 0); nodes[1] = make_uint4(0, 0, 0, 0); }
+}
+
+#define GS_MERKLE_SUBW (1ull << 15)   // layers at most this wide go to k_merkle_subtree (below it a streaming launch is latency-bound)
+// leaves (n digests, given or hashed from `count` columns when src != 0) -> nodes (heap order).  src as SRC above.
+template <int ALG>
+static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count, const void *leaves_in, void *leaves_out, uint64_t n, uint4 *nd) {
+    const dim3 blk(256);
+    uint64_t w = n;                              // the widest complete layer and where its digests are
+    const uint4 *cur = (const uint4 *)leaves_in;
+    if (src != 0) {
+        uint4 *lo = (uint4 *)leaves_out;
+        if (n > GS_MERKLE_SUBW) {
+            // a thread's 2^(lv-1) consecutive leaves are 128-byte-strided loads per column, re-touched on every iteration: with several
+            // columns the re-reads saturate the L2 at lv = 4 (2^22 rows x 4 columns: 448 us against 316 us at lv = 2 and 356 us
+            // unfused, profiles/r03_b_merkle_fused_depth.txt); one column streams a single line per thread and takes all four layers
+            int lv = 1;
+            const int maxlv = src == 2 ? 2 : GS_MERKLE_MAX_LV;
+            while (lv < maxlv && (n >> lv) >= GS_MERKLE_SUBW) lv++;         // layers n, n/2, ..., n >> (lv - 1)
+            const uint64_t groups = n >> (lv - 1);
+            if (src == 1) hipLaunchKernelGGL((k_merkle_fused<ALG, 1>), dim3(gs_grid(groups)), blk, 0, c->stream, va, count, nullptr, groups, lv, lo, nd, n);
+            else hipLaunchKernelGGL((k_merkle_fused<ALG, 2>), dim3(gs_grid(groups)), blk, 0, c->stream, va, count, nullptr, groups, lv, lo, nd, n);
+            w = n >> (lv - 1);
+            cur = lv == 1 ? lo : nd + 2 * w;
+        } else {
+            const uint32_t chunk = (uint32_t)(n < GS_MERKLE_CHUNK ? n : GS_MERKLE_CHUNK);
+            if (src == 1) hipLaunchKernelGGL((k_merkle_subtree<ALG, 1>), dim3((unsigned)(n / chunk)), blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk);
+            else hipLaunchKernelGGL((k_merkle_subtree<ALG, 2>), dim3((unsigned)(n / chunk)), blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk);
+            w = n / chunk;
+            cur = nd + 2 * w;
+            if (w == 1) { GS_LAUNCH_CHECK(c); return GS_OK; }
+        }
+    }
+    while (w > GS_MERKLE_SUBW) {                  // node layers w/2, ..., w >> lv from the digests of layer w
+        int lv = 1;
+        while (lv < GS_MERKLE_MAX_LV && (w >> (lv + 1)) >= GS_MERKLE_SUBW) lv++;
+        const uint64_t groups = w >> lv;
+        hipLaunchKernelGGL((k_merkle_fused<ALG, 0>), dim3(gs_grid(groups)), blk, 0, c->stream, va, 0u, cur, groups, lv, nd + 2 * (w / 2), nd, w / 2);
+        w >>= lv;
+        cur = nd + 2 * w;
+    }
+    while (w > 1) {                               // subtrees of <= 1024 digests, then the subtree over their roots
+        const uint32_t chunk = (uint32_t)(w < GS_MERKLE_CHUNK ? w : GS_MERKLE_CHUNK);
+        hipLaunchKernelGGL((k_merkle_subtree<ALG, 0>), dim3((unsigned)(w / chunk)), blk, 0, c->stream, va, 0u, cur, nullptr, nd, w, chunk);
+        w /= chunk;
+        cur = nd + 2 * w;
+    }
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
 }
 
 template <int ALG>
@@ -235,26 +356,27 @@ int gs_merkle_build(gs_ctx *c, gs_hash_alg alg, const void *leaves, uint64_t n, 
     int rc = check_alg(c, alg);
     if (rc) return rc;
     if (!gs_is_pow2(n) || n < 2) return gs_fail(c, GS_ERR_ARG, "merkle_build: n must be a power of two >= 2");
-    uint4 *nd = (uint4 *)nodes;
-    // bottom level: parents of leaf pairs -> nodes[n/2 .. n)
-    if (alg == GS_HASH_SHA256) rc = hash_values_launch<0>(c, leaves, 64, n / 2, nd + 2 * (n / 2));
-    else rc = hash_values_launch<1>(c, leaves, 64, n / 2, nd + 2 * (n / 2));
+    if (((uintptr_t)leaves | (uintptr_t)nodes) & 15) return gs_fail(c, GS_ERR_ARG, "merkle_build: buffers must be 16-byte aligned");
+    HashPtrArgs va;
+    for (uint32_t j = 0; j < GS_MAX_COMBINE; j++) va.v[j] = nullptr;
+    return alg == GS_HASH_SHA256 ? merkle_run<0>(c, 0, va, 0, leaves, nullptr, n, (uint4 *)nodes) : merkle_run<1>(c, 0, va, 0, leaves, nullptr, n, (uint4 *)nodes);
+}
+
+int gs_merkle_commit_rows(gs_ctx *c, gs_hash_alg alg, const void *const *vecs_host, uint32_t count, uint64_t n, void *leaves, void *nodes) {
+    if (!c || !vecs_host || !leaves || !nodes) return GS_ERR_ARG;
+    int rc = check_alg(c, alg);
     if (rc) return rc;
-    // wide levels: one streaming launch each; nodes[w .. 2w) <- pairs of nodes[2w .. 4w)
-    uint64_t w = n / 4;
-    for (; w >= 256; w >>= 1) {
-        if (alg == GS_HASH_SHA256) rc = hash_values_launch<0>(c, nd + 2 * (2 * w), 64, w, nd + 2 * w);
-        else rc = hash_values_launch<1>(c, nd + 2 * (2 * w), 64, w, nd + 2 * w);
-        if (rc) return rc;
+    if (count == 0) return gs_fail(c, GS_ERR_ARG, "merkle_commit_rows: no vectors");
+    if (!gs_is_pow2(n) || n < 2) return gs_fail(c, GS_ERR_ARG, "merkle_commit_rows: n must be a power of two >= 2");
+    if (((uintptr_t)leaves | (uintptr_t)nodes) & 15) return gs_fail(c, GS_ERR_ARG, "merkle_commit_rows: buffers must be 16-byte aligned");
+    if (count > GS_MAX_COMBINE) {      // more columns than fit the kernel-argument table: the two members one after the other
+        if ((rc = gs_hash_merge_rows(c, alg, vecs_host, count, n, leaves))) return rc;
+        return gs_merkle_build(c, alg, leaves, n, nodes);
     }
-    // the last <= 8 levels in one workgroup: level [have, 2*have) is complete, have <= 256
-    uint32_t have = (uint32_t)(2 * w);
-    if (have < 1) have = 1;
-    if (have > n / 2) have = (uint32_t)(n / 2);
-    if (alg == GS_HASH_SHA256) hipLaunchKernelGGL(k_merkle_top<0>, dim3(1), dim3(256), 0, c->stream, nd, have);
-    else hipLaunchKernelGGL(k_merkle_top<1>, dim3(1), dim3(256), 0, c->stream, nd, have);
-    GS_LAUNCH_CHECK(c);
-    return GS_OK;
+    HashPtrArgs va;
+    for (uint32_t j = 0; j < GS_MAX_COMBINE; j++) va.v[j] = (const uint4 *)vecs_host[j < count ? j : 0];
+    const int src = count == 1 ? 1 : 2;
+    return alg == GS_HASH_SHA256 ? merkle_run<0>(c, src, va, count, nullptr, leaves, n, (uint4 *)nodes) : merkle_run<1>(c, src, va, count, nullptr, leaves, n, (uint4 *)nodes);
 }
 
 int gs_hash_digest(gs_ctx *c, gs_hash_alg alg, const uint8_t *msg_host, uint64_t len, uint8_t out_host[32]) {

@@ -34,7 +34,7 @@ namespace {
     X(gs_alloc) X(gs_free) X(gs_upload) X(gs_download) X(gs_gather) X(gs_last_error) X(gs_power_series) X(gs_vec_add) X(gs_vec_mul) \
     X(gs_vec_sub_scalar) X(gs_vec_div) X(gs_combine_many) X(gs_pluck) X(gs_transpose_vector) X(gs_sub_matrix_from_vectors)     \
     X(gs_eval_polys_at_roots) X(gs_interpolate_roots) X(gs_interpolate_quartic_domain) X(gs_eval_quartic_batch)                \
-    X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
+    X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_commit_rows) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
     X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
     X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end)
 struct Api {
@@ -156,25 +156,28 @@ struct Tree {
     uint64_t n = 0;
     Bytes root;
 };
+// Hash.mergeVectorRows(vectors) + MerkleTree.create (lib/Stark.ts:115-118; LowDegreeProver.ts:45-46, 201-202) as one ABI call.
 // read_root = false leaves the root on the device (nodes + DIGEST): the FRI layers derive their evaluation points from it there
-// (gs_fri_fold_seeded) and fetch_roots() reads all of them back in one round trip
-Tree build_tree(Ctx &x, int alg, Buf &&leaves, uint64_t n, bool read_root = true) {
+// (gs_fri_fold_seeded) and all roots come back in one round trip
+Tree commit_rows(Ctx &x, int alg, const void *const *vecs, uint32_t count, uint64_t n, bool read_root = true) {
     Tree t;
     t.n = n;
-    t.leaves = std::move(leaves);
+    t.leaves = Buf(x, n * DIGEST);
     t.nodes = Buf(x, n * DIGEST);
-    x.check(A.gs_merkle_build(x.c, (gs_hash_alg)alg, t.leaves.p, n, t.nodes.p), "gs_merkle_build");
+    x.check(A.gs_merkle_commit_rows(x.c, (gs_hash_alg)alg, vecs, count, n, t.leaves.p, t.nodes.p), "gs_merkle_commit_rows");
     t.root.resize(DIGEST);
     if (read_root) x.check(A.gs_download(x.c, t.root.data(), t.nodes.at(DIGEST), DIGEST), "gs_download(root)");
     return t;
 }
-void fetch_roots(Ctx &x, const std::vector<Tree *> &trees) {
-    if (trees.empty()) return;
-    const uint64_t one = 1;                        // record 1 of the node array (32-byte records) is the root
-    x.check(A.gs_defer_begin(x.c), "gs_defer_begin");
-    for (Tree *t : trees) x.check(A.gs_gather(x.c, t->nodes.p, DIGEST, &one, 1, t->root.data()), "gs_gather(root)");
-    x.check(A.gs_defer_end(x.c), "gs_defer_end");
-}
+// gs_defer_begin ... gs_defer_end as a scope: when a call inside the window throws, the window is still closed (the context would
+// otherwise stay in deferral mode and the next prove() on it would fail with "already deferring")
+struct DeferWindow {
+    Ctx &x;
+    bool open = false;
+    explicit DeferWindow(Ctx &cx) : x(cx) { x.check(A.gs_defer_begin(x.c), "gs_defer_begin"); open = true; }
+    void end() { open = false; x.check(A.gs_defer_end(x.c), "gs_defer_end"); }
+    ~DeferWindow() { if (open) A.gs_defer_end(x.c); }
+};
 // The query answers of a proof are issued inside one deferral window (gs_defer_begin / gs_defer_end): the calls below queue the
 // device work into buffers that stay put (std::deque) and `unpack` builds the proof objects after the single synchronisation.
 struct Readbacks {
@@ -227,11 +230,12 @@ void gather_rows4(Ctx &x, const void *column, uint64_t rows, const std::vector<u
     Readbacks rb;
     rb.gather_rows4(x, column, rows, positions, mp);
 }
-// digests of those rows (Hash.digestValues of the transposed matrix, LowDegreeProver.ts:45,201) = mergeVectorRows of the four quarters
-void hash_rows4(Ctx &x, int alg, const void *column, uint64_t rows, void *digests) {
+// tree over the rows of transposeVector(column, 4) (Hash.digestValues of the transposed matrix + MerkleTree.create, LowDegreeProver.ts:45-46,
+// 201-202): the row digests are mergeVectorRows of the four quarters of the column (the same 64-byte messages)
+Tree commit_rows4(Ctx &x, int alg, const void *column, uint64_t rows) {
     const void *quarters[4];
     for (uint64_t c = 0; c < 4; c++) quarters[c] = (const uint8_t *)column + c * rows * ELEM;
-    x.check(A.gs_hash_merge_rows(x.c, (gs_hash_alg)alg, quarters, 4, rows, digests), "gs_hash_merge_rows(rows of 4)");
+    return commit_rows(x, alg, quarters, 4, rows, false);
 }
 std::vector<uint64_t> unique_in_order(const std::vector<uint64_t> &v) {
     std::vector<uint64_t> out;
@@ -437,12 +441,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     const uint32_t V = (uint32_t)eVectors.size();
 
     // 4 ----- evaluation Merkle tree (:113-118)
-    Tree eTree;
-    {
-        Buf hashed(x, N * DIGEST);
-        x.check(A.gs_hash_merge_rows(x.c, (gs_hash_alg)alg, eVectors.data(), V, N, hashed.p), "gs_hash_merge_rows");
-        eTree = build_tree(x, alg, std::move(hashed), N);
-    }
+    Tree eTree = commit_rows(x, alg, eVectors.data(), V, N);
 
     clock.mark("P(x), extension, evaluation tree root");
     // 5 ----- composition polynomial (CompositionPolynomial.ts:29-146)
@@ -670,12 +669,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     if (N < 128) fail(GS_ERR_ARG, "Invalid array length");
     // transposeVector(v, 4) is never materialised: row r of it is v[r], v[r + rows], v[r + 2 rows], v[r + 3 rows], which the hashing,
     // folding and gathering below read in place
-    Tree pTree0;
-    {
-        Buf h(x, N / 4 * DIGEST);
-        hash_rows4(x, alg, lEval.p, N / 4, h.p);                                                      // :45
-        pTree0 = build_tree(x, alg, std::move(h), N / 4, false);
-    }
+    Tree pTree0 = commit_rows4(x, alg, lEval.p, N / 4);                                               // :45-46
 
     // layers (:176-221): the loop below is the recursion unrolled.  No root is read back inside it: the point every layer folds at,
     // prng(root of the tree above) (:194), is derived on the device from the root where it lies (gs_fri_fold_seeded), so all layers
@@ -700,9 +694,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         L.next = Buf(x, rows * ELEM);
         le16(omega, s16);
         x.check(A.gs_fri_fold_seeded(x.c, s16, N, step, column_src, len, pTree->nodes.at(DIGEST), L.next.p), "gs_fri_fold_seeded");   // :189-198
-        Buf h(x, rows / 4 * DIGEST);
-        hash_rows4(x, alg, L.next.p, rows / 4, h.p);                                                  // :201
-        L.cTree = build_tree(x, alg, std::move(h), rows / 4, false);
+        L.cTree = commit_rows4(x, alg, L.next.p, rows / 4);                                           // :201-202
         column_src = L.next.p;
         pTree = &L.cTree;
         len = rows;
@@ -717,11 +709,11 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         std::vector<uint64_t> all(len);
         for (uint64_t i = 0; i < len; i++) all[i] = i;
         const uint64_t one = 1;                        // record 1 of a node array (32-byte records) is the root
-        x.check(A.gs_defer_begin(x.c), "gs_defer_begin");
+        DeferWindow win(x);
         x.check(A.gs_gather(x.c, pTree0.nodes.p, DIGEST, &one, 1, pTree0.root.data()), "gs_gather(root)");
         for (Layer &L : layers) x.check(A.gs_gather(x.c, L.cTree.nodes.p, DIGEST, &one, 1, L.cTree.root.data()), "gs_gather(root)");
         x.check(A.gs_gather(x.c, column_src, ELEM, all.data(), len, remainder_raw.data()), "gs_gather(remainder)");
-        x.check(A.gs_defer_end(x.c), "gs_defer_end");
+        win.end();
     }
     clock.mark("FRI roots + remainder read back (1 round trip)");
     const uint32_t exe_count = (uint32_t)std::min<uint64_t>(job.exe_query_count, N - N / E);
@@ -763,7 +755,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     struct Component { Bytes columnRoot; MerkleProof columnProof, polyProof; };
     std::vector<Component> components(layers.size());
     Readbacks rb;
-    x.check(A.gs_defer_begin(x.c), "gs_defer_begin");
+    DeferWindow win(x);
     MerkleProof lcProof;                                                                          // LowDegreeProver.ts:52-54
     rb.prove_batch(x, pTree0, lc_positions, &lcProof);
     rb.gather_rows4(x, lEval.p, N / 4, lc_positions, &lcProof);
@@ -791,7 +783,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     std::vector<MerkleProof> cols(V);
     for (uint32_t r = 0; r < V; r++) rb.gather(x, eVectors[r], ELEM, aug, 1, V == 1 ? &evProof : &cols[r]);
     clock.mark("query positions + batch-proof plans");
-    x.check(A.gs_defer_end(x.c), "gs_defer_end");
+    win.end();
     clock.mark("query answers fetched (one round trip)");
     if (V > 1) {
         evProof.value_size = (uint64_t)V * ELEM;

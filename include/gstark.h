@@ -199,6 +199,12 @@ int gs_hash_digest_values(gs_ctx *ctx, gs_hash_alg alg, const void *buf, uint64_
  * nodes[0] is zero.  n must be a power of two >= 2.  lib/Stark.ts:118; LowDegreeProver.ts:46,164,202.
  * (.root / .proveBatch read nodes through gs_gather.) */
 int gs_merkle_build(gs_ctx *ctx, gs_hash_alg alg, const void *leaves, uint64_t n, void *nodes);
+/* Hash.mergeVectorRows(vectors) followed by MerkleTree.create(hashedRows, hash) — lib/Stark.ts:115-118, LowDegreeProver.ts:45-46,
+ * 201-202 — as ONE entry: leaves[i] = H(v_0[i] || ... || v_{k-1}[i]) (n digests, written: proveBatch reads them) and the tree over
+ * them in `nodes` (layout as gs_merkle_build).  Same bytes as the two members called one after the other; the device hashes the
+ * leaves and the layers above them in the same launches (csrc/hash.hip).  n a power of two >= 2. */
+int gs_merkle_commit_rows(gs_ctx *ctx, gs_hash_alg alg, const void *const *vecs_host, uint32_t count, uint64_t n,
+                          void *leaves, void *nodes);
 
 /* MerkleTree.proveBatch(indexes): lib/Stark.ts:150; LowDegreeProver.ts:52,213,216.  Plans the batch proof on the
  * host and fetches every needed digest in one device gather.  Outputs (host): values_out = count digests in

@@ -489,6 +489,12 @@ int gs_merkle_build(gs_ctx *c, gs_hash_alg alg, const void *leaves, uint64_t n, 
     }
     return GS_OK;
 }
+int gs_merkle_commit_rows(gs_ctx *c, gs_hash_alg alg, const void *const *vecs, uint32_t count, uint64_t n, void *leaves, void *nodes) {
+    /* Hash.mergeVectorRows then MerkleTree.create (lib/Stark.ts:115-118), literally */
+    int rc = gs_hash_merge_rows(c, alg, vecs, count, n, leaves);
+    if (rc) return rc;
+    return gs_merkle_build(c, alg, leaves, n, nodes);
+}
 
 int gs_mimc_trace(gs_ctx *c, const gs_elt *seed, const uint8_t *rc, uint32_t nrc, uint64_t steps, void *out) {
     if (!nrc || !steps) return fail(c, GS_ERR_ARG, "mimc_trace: empty");

@@ -2,11 +2,13 @@
 host mirror on a given backend and compared with an independent expectation (Python big-int arithmetic,
 hashlib, oracle/pyref.py).  Used with the CPU oracle backend (-m "not gpu": pins the oracle) and with the
 HIP backend (-m gpu: the parity tests proper, which additionally compare HIP bytes with oracle bytes)."""
+import ctypes as C
 import hashlib
 
 from conftest import P, from_bytes, rand_elements, to_bytes
 from genstark_amd.field import PrimeField
 from genstark_amd.merkle import MerkleTree, createHash
+from genstark_amd._abi import HASH_ALGS
 from oracle import pyref
 
 PF = pyref.Field()
@@ -389,6 +391,44 @@ def check_merkle(backend, rng, alg, logn):
         bad = dict(proof)
         bad['values'] = [bytes(32)] + proof['values'][1:]
         assert not MerkleTree.verifyBatch(tree.root, idx, bad, h)
+
+
+def merkle_commit_bytes(backend, alg, cols_raw, n, fused=True):
+    """(leaves, nodes) bytes of gs_merkle_commit_rows over the given columns (raw element bytes); fused=False: the two members
+    gs_hash_merge_rows + gs_merkle_build one after the other (what the fused entry must equal)."""
+    be = backend
+    es = be.element_size
+    ptrs = []
+    for raw in cols_raw:
+        assert len(raw) == es * n
+        p = be.alloc(len(raw)); be.upload(p, raw); ptrs.append(p)
+    leaves, nodes = be.alloc(32 * n), be.alloc(32 * n)
+    arr = (C.c_void_p * len(ptrs))(*ptrs)
+    a = HASH_ALGS[alg]
+    if fused:
+        be.call('gs_merkle_commit_rows', a, arr, len(ptrs), n, C.c_void_p(leaves), C.c_void_p(nodes))
+    else:
+        be.call('gs_hash_merge_rows', a, arr, len(ptrs), n, C.c_void_p(leaves))
+        be.call('gs_merkle_build', a, C.c_void_p(leaves), n, C.c_void_p(nodes))
+    out = be.download(leaves, 32 * n), be.download(nodes, 32 * n)
+    for p in ptrs + [leaves, nodes]:
+        be.free(p)
+    return out
+
+
+def check_merkle_commit(backend, rng, alg, logn, count):
+    """gs_merkle_commit_rows = mergeVectorRows + MerkleTree.create (lib/Stark.ts:115-118) against hashlib, every node."""
+    H = _h(alg)
+    n = 1 << logn
+    es = backend.element_size
+    cols = [bytes(rng.getrandbits(8) for _ in range(es * n)) if n <= 4096 else rng.randbytes(es * n) for _ in range(count)]
+    leaves, nodes = merkle_commit_bytes(backend, alg, cols, n)
+    want_leaves = [H(b''.join(c[es * i:es * i + es] for c in cols)) for i in range(n)]
+    assert [leaves[32 * i:32 * i + 32] for i in range(n)] == want_leaves
+    ref = pyref.MerkleTree(want_leaves, H)
+    assert nodes[:32] == b'\0' * 32
+    assert [nodes[32 * i:32 * i + 32] for i in range(1, n)] == ref.nodes[1:]
+    assert merkle_commit_bytes(backend, alg, cols, n, fused=False) == (leaves, nodes)
 
 
 def check_mimc_air(backend, rng, steps):

@@ -107,6 +107,29 @@ def test_merkle(hip_backend, rng, alg, logn):
     cases.check_merkle(hip_backend, rng, alg, logn)
 
 
+# every branch of the construction plan (csrc/hash.hip: merkle_run): one subtree workgroup (n <= 1024), subtrees + the tree over their
+# roots (n <= 2^15), streaming layers with 1..4 fused layers above the leaves, a second streaming launch (n >= 2^20)
+@pytest.mark.parametrize('alg,logn,count', [('blake2s256', 1, 1), ('sha256', 1, 4), ('blake2s256', 3, 2), ('blake2s256', 10, 4), ('sha256', 10, 1),
+                                            ('blake2s256', 11, 1), ('blake2s256', 13, 6), ('sha256', 12, 3)])
+def test_merkle_commit_rows(hip_backend, rng, alg, logn, count):
+    cases.check_merkle_commit(hip_backend, rng, alg, logn, count)
+
+
+@pytest.mark.parametrize('alg,logn,count', [('blake2s256', 15, 1), ('blake2s256', 16, 4), ('sha256', 16, 1), ('blake2s256', 17, 2), ('blake2s256', 18, 1),
+                                            ('blake2s256', 19, 4), ('sha256', 19, 2), ('blake2s256', 20, 1), ('blake2s256', 21, 4), ('blake2s256', 22, 1)])
+def test_merkle_commit_rows_equals_oracle(hip_backend, oracle_omp_backend, alg, logn, count):
+    """the fused entry on HIP against the oracle's mergeVectorRows + MerkleTree.create, every leaf digest and every node; and
+    gs_merkle_build alone (digests given) on the same leaves"""
+    n = 1 << logn
+    r = random.Random(logn * 131 + count)
+    cols = [r.randbytes(16 * n) for _ in range(count)]
+    got = cases.merkle_commit_bytes(hip_backend, alg, cols, n)
+    want = cases.merkle_commit_bytes(oracle_omp_backend, alg, cols, n)
+    assert got[0] == want[0]
+    assert got[1][32:] == want[1][32:]
+    assert cases.merkle_commit_bytes(hip_backend, alg, cols, n, fused=False)[1][32:] == want[1][32:]
+
+
 def test_mimc_air(hip_backend, rng):
     cases.check_mimc_air(hip_backend, rng, 128)
 

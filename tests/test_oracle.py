@@ -73,6 +73,11 @@ def test_merkle(oracle_backend, rng, alg, logn):
     cases.check_merkle(oracle_backend, rng, alg, logn)
 
 
+@pytest.mark.parametrize('alg,logn,count', [('sha256', 1, 1), ('blake2s256', 1, 4), ('blake2s256', 6, 2), ('sha256', 8, 6), ('blake2s256', 11, 1)])
+def test_merkle_commit_rows(oracle_backend, rng, alg, logn, count):
+    cases.check_merkle_commit(oracle_backend, rng, alg, logn, count)
+
+
 def test_mimc_air(oracle_backend, rng):
     cases.check_mimc_air(oracle_backend, rng, 128)
 

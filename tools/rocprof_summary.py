@@ -23,5 +23,5 @@ print('\n## launch shapes (NTT / hash / inversion kernels)\n')
 print('| kernel | grid_x | wg_x | lds bytes | vgpr | agpr | sgpr | scratch | calls | avg us |')
 print('|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|')
 for r in extra:
-    if 'ntt' in r[0] or 'hash' in r[0] or 'batch_inv' in r[0]:
+    if 'ntt' in r[0] or 'hash' in r[0] or 'batch_inv' in r[0] or 'merkle' in r[0]:
         print(f'| `{r[0][:60]}` | ' + ' | '.join(str(x) for x in r[1:9]) + f' | {r[9] / 1e3:.2f} |')
