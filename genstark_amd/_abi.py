@@ -52,6 +52,8 @@ _SIGNATURES = {
     'gs_air_jit': (_int, [_vp, _int]),
     'gs_air_jit_launches': (_u64, [_vp]),
     'gs_air_jit_check': (_int, [_int, _vp, _u32, _vp, _u32, _bytes, _u32, _u32, _u32, _vp, _u32, _vp, _u64]),
+    'gs_gather_words': (_int, [_vp, _vp, _u64, _vp]),
+    'gs_transpose_records': (_int, [_vp, _vp, _u64, _u64, _u64, _vp]),
     'gs_defer_begin': (_int, [_vp]),
     'gs_defer_end': (_int, [_vp]),
     'gs_gather': (_int, [_vp, _vp, _u64, C.POINTER(_u64), _u64, _vp]),

@@ -38,5 +38,12 @@ build_flavour build_p256 libgstark_hip_p256.so "-DGS_WIDE_BITS=256" &
 build_flavour build_p224 libgstark_hip_p224.so "-DGS_WIDE_BITS=224" &
 wait
 # the native prove() driver: plain C++ above the C ABI (binds to whichever implementation of it the caller loaded)
-g++ -O2 -std=c++17 -shared -fPIC -Wall -Wno-unused-function prover.cc -ldl -o libgstark_prover.so
+if [ ! -f libgstark_prover.so ] || [ prover.cc -nt libgstark_prover.so ] || [ prover_dist.h -nt libgstark_prover.so ] || [ ../../include/gstark_comm.h -nt libgstark_prover.so ] || [ ../../include/gstark.h -nt libgstark_prover.so ]; then
+  g++ -O2 -std=c++17 -shared -fPIC -Wall -Wno-unused-function prover.cc -ldl -o libgstark_prover.so
+fi
 echo built $(pwd)/libgstark_prover.so
+# the communicator of a distributed proof over RCCL / xGMI (include/gstark_comm.h): host code against librccl + the HIP runtime
+if [ ! -f libgstark_rccl.so ] || [ comm_rccl.cc -nt libgstark_rccl.so ] || [ ../../include/gstark_comm.h -nt libgstark_rccl.so ]; then
+  $HIPCC --offload-arch=gfx950 -O2 -std=c++17 -shared -fPIC -Wall comm_rccl.cc -o libgstark_rccl.so -L/opt/rocm/lib -lrccl -ldl
+fi
+echo built $(pwd)/libgstark_rccl.so

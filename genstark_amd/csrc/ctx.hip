@@ -295,6 +295,34 @@ extern "C" int gs_gather(gs_ctx *c, const void *src, uint64_t rec_bytes, const u
     return GS_OK;
 }
 
+// dst[t] = the record word at (r, c) of a rows x cols matrix of rec16-word records, written transposed
+__global__ void k_transpose_records(const uint4 *__restrict__ src, uint64_t rows, uint64_t cols, uint32_t rec16, uint4 *__restrict__ dst) {
+    const uint64_t total = rows * cols * rec16;
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t o = t % rec16, e = t / rec16;        // destination record e = c * rows + r: consecutive lanes write consecutive words
+        const uint64_t r = e % rows, cc = e / rows;
+        dst[t] = src[(r * cols + cc) * rec16 + o];
+    }
+}
+extern "C" int gs_gather_words(gs_ctx *c, const void *addrs, uint64_t count, void *dst) {
+    if (!c || (!addrs && count) || (!dst && count)) return GS_ERR_ARG;
+    if (!count) return GS_OK;
+    if (((uintptr_t)addrs & 7) || ((uintptr_t)dst & 15)) return gs_fail(c, GS_ERR_ARG, "gather_words: misaligned buffer");
+    hipLaunchKernelGGL(k_gather_words, dim3(gs_grid(count)), dim3(256), 0, c->stream, (const uint64_t *)addrs, count, (uint4 *)dst);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+extern "C" int gs_transpose_records(gs_ctx *c, const void *src, uint64_t rows, uint64_t cols, uint64_t rec_bytes, void *dst) {
+    if (!c || !src || !dst) return GS_ERR_ARG;
+    if (!rec_bytes || rec_bytes % 16) return gs_fail(c, GS_ERR_ARG, "transpose_records: record size must be a multiple of 16");
+    if (!rows || !cols) return GS_OK;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return gs_fail(c, GS_ERR_ARG, "transpose_records: misaligned buffer");
+    hipLaunchKernelGGL(k_transpose_records, dim3(gs_grid(rows * cols * (rec_bytes / 16))), dim3(256), 0, c->stream, (const uint4 *)src, rows, cols,
+                       (uint32_t)(rec_bytes / 16), (uint4 *)dst);
+    GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
 extern "C" int gs_defer_begin(gs_ctx *c) {
     if (!c) return GS_ERR_ARG;
     if (c->defer) return gs_fail(c, GS_ERR_ARG, "defer_begin: already deferring");

@@ -24,6 +24,7 @@
 
 #include "../../include/gstark.h"
 #include "../../include/gstark_prover.h"
+#include "../../include/gstark_comm.h"
 #include "host_field.h"
 #include "host_sha256.h"
 
@@ -36,7 +37,8 @@ namespace {
     X(gs_eval_polys_at_roots) X(gs_interpolate_roots) X(gs_interpolate_quartic_domain) X(gs_eval_quartic_batch)                \
     X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_commit_rows) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
     X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
-    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end)
+    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end) \
+    X(gs_vec_mul_scalar) X(gs_copy) X(gs_gather_words) X(gs_transpose_records)
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
     GS_API_LIST(X)
@@ -813,3 +815,6 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     out.push_back(0);    // no input shapes (iShapes = [])
     clock.mark("serialized");
 }
+
+// ---- one proof across several GPUs (same helpers, same coefficient streams, same wire format)
+#include "prover_dist.h"

@@ -44,6 +44,16 @@ class _Stats(C.Structure):
                 ('total_ms', C.c_double), ('phase_ms', C.c_double * 16), ('phase_label', (C.c_char * 48) * 16)]
 
 
+class GsComm(C.Structure):
+    """struct gs_comm of include/gstark_comm.h: the table of collectives gs_prover_prove_dist is handed (genstark_amd/comm.py builds them)."""
+    _fields_ = [('self', C.c_void_p), ('rank', C.c_int32), ('size', C.c_int32),
+                ('all_gather', C.c_void_p), ('all_to_all', C.c_void_p), ('take_timings', C.c_void_p), ('name', C.c_char_p)]
+
+
+class _Collective(C.Structure):
+    _fields_ = [('label', C.c_char * 40), ('kind', C.c_uint32), ('bytes', C.c_uint64), ('ms', C.c_double)]
+
+
 _bound = {}
 _bound_lock = threading.Lock()      # ProverPool lanes construct their NativeProver concurrently
 
@@ -76,6 +86,10 @@ def _driver_locked(backend, key):
         lib.gs_prover_prove.restype = C.c_int
         lib.gs_prover_last_stats.argtypes = [C.POINTER(_Stats)]
         lib.gs_prover_last_stats.restype = C.c_int
+        lib.gs_prover_prove_dist.argtypes = [C.c_void_p, C.POINTER(_Job), C.POINTER(GsComm), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
+        lib.gs_prover_prove_dist.restype = C.c_int
+        lib.gs_prover_last_collectives.argtypes = [C.POINTER(_Collective), C.c_uint32, C.POINTER(C.c_uint32)]
+        lib.gs_prover_last_collectives.restype = C.c_int
         rc = lib.gs_prover_bind(C.c_void_p(backend.lib._handle))
         if rc:
             raise GstarkError(f'gs_prover_bind failed ({rc}): the ABI library lacks an entry point the driver needs')
@@ -92,8 +106,6 @@ class NativeProver:
         from .field import MODULUS
         if self.field.modulus != MODULUS:
             raise GstarkError('the native driver is built for the 128-bit field; use Stark.prove() on the small-field builds')
-        if hasattr(self.field, 'comm'):
-            raise GstarkError('the native driver proves on one device; use the distributed field with Stark.prove()')
         self.lib = _driver(self.backend)
         self._keep = []
         self._out = C.create_string_buffer(1 << 22)
@@ -116,8 +128,10 @@ class NativeProver:
         else:
             raise GstarkError('the native driver knows the MiMC AIR and GenericAir')
 
-    def prove_bytes(self, assertions, inputs=None, seed=None):
-        """The serialized proof of Stark.prove(assertions, inputs, seed): stark.serialize(stark.prove(...)) byte for byte."""
+    def prove_bytes(self, assertions, inputs=None, seed=None, comm=None):
+        """The serialized proof of Stark.prove(assertions, inputs, seed): stark.serialize(stark.prove(...)) byte for byte.
+        comm (a GsComm, genstark_amd/comm.py): ONE proof across the communicator's ranks (gs_prover_prove_dist; every rank calls this
+        with the same statement and receives the same bytes)."""
         stark, air, f = self.stark, self.stark.air, self.field
         if not isinstance(assertions, list):
             raise TypeError('Assertions parameter must be an array')
@@ -199,7 +213,10 @@ class NativeProver:
         out = self._out        # one output buffer per prover (a lane of a pool has its own prover): no 4 MB allocation + copy per proof
         n = C.c_uint64()
         err = C.create_string_buffer(512)
-        rc = self.lib.gs_prover_prove(self.backend.ctx, C.byref(job), C.cast(out, C.c_void_p), cap, C.byref(n), err, 512)
+        if comm is None:
+            rc = self.lib.gs_prover_prove(self.backend.ctx, C.byref(job), C.cast(out, C.c_void_p), cap, C.byref(n), err, 512)
+        else:
+            rc = self.lib.gs_prover_prove_dist(self.backend.ctx, C.byref(job), C.byref(comm), C.cast(out, C.c_void_p), cap, C.byref(n), err, 512)
         if rc:
             raise StarkError(f'native prove() failed ({rc}): {err.value.decode(errors="replace")}')
         return C.string_at(out, n.value)
@@ -216,6 +233,17 @@ class NativeProver:
             phases[bytes(st.phase_label[i]).split(b'\0', 1)[0].decode()] = round(st.phase_ms[i], 4)
         return {'total_ms': round(st.total_ms, 4), 'phases_ms': phases, 'ntt_points': int(st.ntt_points),
                 'ntt_transforms': int(st.ntt_transforms), 'horner_points': int(st.horner_points)}
+
+    def last_collectives(self):
+        """The collectives the last distributed prove_bytes() on this thread issued: [{'label', 'kind', 'bytes', 'ms'}] (ms: device
+        time when the communicator measures it, else None)."""
+        arr = (_Collective * 256)()
+        n = C.c_uint32()
+        rc = self.lib.gs_prover_last_collectives(arr, 256, C.byref(n))
+        if rc:
+            raise GstarkError(f'gs_prover_last_collectives failed ({rc})')
+        return [{'label': arr[i].label.decode(), 'kind': 'all_to_all' if arr[i].kind else 'all_gather', 'bytes': int(arr[i].bytes),
+                 'ms': (round(arr[i].ms, 4) if arr[i].ms >= 0 else None)} for i in range(min(n.value, 256))]
 
     def prove(self, assertions, inputs=None, seed=None):
         return self.stark.parse(self.prove_bytes(assertions, inputs, seed))

@@ -91,6 +91,13 @@ int gs_copy(gs_ctx *ctx, void *dst, const void *src, uint64_t bytes);
  * Copies `count` records of `rec_bytes` at record indices idx[] (host) from src to host_out. */
 int gs_gather(gs_ctx *ctx, const void *src, uint64_t rec_bytes, const uint64_t *idx_host,
               uint64_t count, void *host_out);
+/* Device-to-device forms used where the result travels on to another device (csrc/prover_dist.cc: query answers of a proof that
+ * is spread over several GPUs are packed by their owners and exchanged with one collective):
+ *   gs_gather_words:      dst[t] = the 16-byte word at DEVICE ADDRESS addrs[t] (addrs: count 64-bit addresses in device memory).
+ *   gs_transpose_records: dst[c*rows + r] = src[r*cols + c] for records of rec_bytes (a multiple of 16) — strided shares of a vector,
+ *                         gathered rank after rank, back into natural order; the re-sharding of leaf digests before a Merkle subtree. */
+int gs_gather_words(gs_ctx *ctx, const void *addrs, uint64_t count, void *dst);
+int gs_transpose_records(gs_ctx *ctx, const void *src, uint64_t rows, uint64_t cols, uint64_t rec_bytes, void *dst);
 /* Deferred read-backs: between gs_defer_begin and gs_defer_end, gs_gather and gs_merkle_prove_batch queue their device work and
  * return at once (shapes — ncols_out, col_lens_out — are filled immediately, they are host knowledge); the host output buffers,
  * which must stay valid, are filled by gs_defer_end after ONE synchronisation for the whole window.  The ~40 query answers of a

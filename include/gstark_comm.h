@@ -1,0 +1,51 @@
+/* gstark_comm.h — the communicator the native driver uses when ONE proof is spread over several GPUs (gs_prover_prove_dist,
+ * csrc/prover_dist.h).
+ *
+ * A communicator is a table of two collectives over DEVICE buffers of the bound ABI library.  They are enqueued on the stream of
+ * the gs_ctx they are handed (gs_stream) and return at once: the driver never copies exchanged data through the host.  The product
+ * implementation is RCCL over xGMI (csrc/comm_rccl.cc -> libgstark_rccl.so: ncclAllGather, grouped ncclSend / ncclRecv on a
+ * communicator the library owns, one rank per process and GPU); the tests inject others through the same table (threads of one
+ * process exchanging through gs_copy: ranks that share the box's single GPU, or the oracle's host memory).
+ * The exchanged layouts (which strided share goes where) are decided by the driver, not here. */
+#ifndef GSTARK_COMM_H
+#define GSTARK_COMM_H
+
+#include "gstark_prover.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gs_comm gs_comm;
+struct gs_comm {
+    void *self;
+    int32_t rank, size;              /* size: a power of two */
+    /* every rank contributes `bytes` bytes at `send`; `recv` (size * bytes) receives rank r's contribution at r * bytes */
+    int (*all_gather)(void *self, gs_ctx *ctx, const void *send, void *recv, uint64_t bytes);
+    /* piece h of `send` (bytes each) goes to rank h; piece h of `recv` is what rank h sent here */
+    int (*all_to_all)(void *self, gs_ctx *ctx, const void *send, void *recv, uint64_t bytes);
+    /* optional (may be NULL): device time of the collectives issued since the last call, in issue order; returns how many were
+     * written (<= cap).  Blocks until they have completed. */
+    uint32_t (*take_timings)(void *self, double *ms_out, uint32_t cap);
+    const char *name;                /* "rccl", "threads", ... (reported by bench.py) */
+};
+
+/* One proof of `job` across the comm->size ranks (every rank calls this with the same job; SPMD).  Every rank receives the same
+ * serialized proof — byte for byte what gs_prover_prove gives on one device.  Requirements: steps * extension_factor divisible by
+ * 4 * size^2, extension_factor divisible by size, no secret registers. */
+int gs_prover_prove_dist(gs_ctx *ctx, const struct gs_prover_job *job, const gs_comm *comm, uint8_t *out, uint64_t cap, uint64_t *len,
+                         char *err, uint64_t errcap);
+
+/* The collectives the last gs_prover_prove_dist on the calling thread issued, in order. */
+struct gs_prover_collective {
+    char label[40];
+    uint32_t kind;                   /* 0 = all_gather, 1 = all_to_all */
+    uint64_t bytes;                  /* contributed by this rank (all_gather) / sent to every peer (all_to_all) */
+    double ms;                       /* device time when the communicator measures it (take_timings), else -1 */
+};
+int gs_prover_last_collectives(struct gs_prover_collective *out, uint32_t cap, uint32_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

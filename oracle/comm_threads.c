@@ -1,0 +1,84 @@
+/* comm_threads.c — TEST DOUBLE of the communicator of include/gstark_comm.h: the ranks are threads of one process.
+ *
+ * Test infrastructure (tests/ only; the product communicator is csrc/comm_rccl.cc).  Each rank drives its own gs_ctx of whatever ABI
+ * library the test loaded — the oracle's (host memory) in the CPU tier, libgstark_hip.so with several contexts on the box's single
+ * GPU in the -m gpu tier.  A collective is: drain my stream (gs_sync), meet at a barrier, copy the peers' pieces with gs_copy on my
+ * own stream, drain, meet again.  Same layouts as RCCL's ncclAllGather and a grouped ncclSend/ncclRecv exchange. */
+#define _POSIX_C_SOURCE 200809L
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/gstark_comm.h"
+
+#define MAX_RANKS 64
+
+typedef int (*copy_fn)(gs_ctx *, void *, const void *, uint64_t);
+typedef int (*sync_fn)(gs_ctx *);
+
+struct group {
+    int size;
+    pthread_barrier_t bar;
+    const void *send[MAX_RANKS];
+    copy_fn copy;
+    sync_fn sync;
+    volatile int failed;
+};
+struct rank_state {
+    struct group *grp;
+    int rank;
+};
+
+static int meet(struct group *g) {
+    pthread_barrier_wait(&g->bar);
+    return g->failed ? GS_ERR_DEVICE : GS_OK;
+}
+
+static int exchange(struct rank_state *st, gs_ctx *ctx, const void *send, void *recv, uint64_t bytes, int all_to_all) {
+    struct group *g = st->grp;
+    int rc = g->sync(ctx);
+    if (rc) g->failed = 1;
+    g->send[st->rank] = send;
+    if ((rc = meet(g))) return rc;
+    for (int h = 0; h < g->size && !rc; h++) {
+        const uint8_t *src = (const uint8_t *)g->send[h] + (all_to_all ? (uint64_t)st->rank * bytes : 0);
+        rc = g->copy(ctx, (uint8_t *)recv + (uint64_t)h * bytes, src, bytes);
+    }
+    if (!rc) rc = g->sync(ctx);
+    if (rc) g->failed = 1;
+    int rc2 = meet(g);
+    return rc ? rc : rc2;
+}
+static int t_all_gather(void *self, gs_ctx *ctx, const void *send, void *recv, uint64_t bytes) {
+    return exchange((struct rank_state *)self, ctx, send, recv, bytes, 0);
+}
+static int t_all_to_all(void *self, gs_ctx *ctx, const void *send, void *recv, uint64_t bytes) {
+    return exchange((struct rank_state *)self, ctx, send, recv, bytes, 1);
+}
+
+/* `size` communicators (one per rank thread) over the ABI library behind `abi_dl_handle`; out[r] is rank r's. */
+int gs_threads_comm_create(int size, void *abi_dl_handle, gs_comm *out) {
+    if (size < 1 || size > MAX_RANKS || !abi_dl_handle || !out) return GS_ERR_ARG;
+    struct group *g = (struct group *)calloc(1, sizeof *g);
+    if (!g) return GS_ERR_OOM;
+    g->size = size;
+    g->copy = (copy_fn)dlsym(abi_dl_handle, "gs_copy");
+    g->sync = (sync_fn)dlsym(abi_dl_handle, "gs_sync");
+    if (!g->copy || !g->sync || pthread_barrier_init(&g->bar, NULL, (unsigned)size)) { free(g); return GS_ERR_UNSUPPORTED; }
+    for (int r = 0; r < size; r++) {
+        struct rank_state *st = (struct rank_state *)calloc(1, sizeof *st);
+        if (!st) return GS_ERR_OOM;
+        st->grp = g;
+        st->rank = r;
+        memset(&out[r], 0, sizeof out[r]);
+        out[r].self = st;
+        out[r].rank = r;
+        out[r].size = size;
+        out[r].all_gather = t_all_gather;
+        out[r].all_to_all = t_all_to_all;
+        out[r].take_timings = NULL;
+        out[r].name = "threads";
+    }
+    return GS_OK;
+}

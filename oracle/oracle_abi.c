@@ -271,6 +271,18 @@ int gs_transpose_vector(gs_ctx *c, const void *v, uint64_t n, uint32_t cols, uin
         for (uint32_t k = 0; k < cols; k++) ST(o, r * cols + k, EL(v, (r + (uint64_t)k * rows) * step));
     return GS_OK;
 }
+int gs_gather_words(gs_ctx *c, const void *addrs, uint64_t count, void *dst) {
+    (void)c;
+    const uint64_t *a = (const uint64_t *)addrs;
+    for (uint64_t t = 0; t < count; t++) memcpy((uint8_t *)dst + 16 * t, (const void *)(uintptr_t)a[t], 16);
+    return GS_OK;
+}
+int gs_transpose_records(gs_ctx *c, const void *src, uint64_t rows, uint64_t cols, uint64_t rec, void *dst) {
+    if (!rec || rec % 16) return fail(c, GS_ERR_ARG, "transpose_records: record size must be a multiple of 16");
+    for (uint64_t r = 0; r < rows; r++)
+        for (uint64_t k = 0; k < cols; k++) memcpy((uint8_t *)dst + (k * rows + r) * rec, (const uint8_t *)src + (r * cols + k) * rec, rec);
+    return GS_OK;
+}
 int gs_transpose_matrix(gs_ctx *c, const void *m, uint64_t rows, uint64_t cols, void *o) {
     (void)c;
     PAR_FOR
