@@ -366,93 +366,101 @@ def main():
             'prove_ms': ms_per_step, 'per_step_ms': step_ms, 'python_mirror_prove_ms': mirror_ms, 'phases_ms': phases, 'phases_source': 'native driver clock, last timed step', 'driver_total_ms': driver_total_ms, 'roofline': roofline, 'cpu_baseline': cpu,
             'pipelined': pipelined,
         }
-    # ---- N > 1: the headline is ONE proof across all ranks (genstark_amd/distributed.py: the evaluation domain
-    # strided over the ranks — low-degree extension, pointwise work, FRI folding are local; one digest re-shard (point-to-point)
-    # and one all-gather of G sub-roots per Merkle tree; query answers in one fixed-size all-gather).  The independent-proofs
-    # measurement above becomes the separate `replicas` line.  The leg runs under a watchdog: whatever happens in it, every rank
-    # leaves within --sharded-leg-timeout seconds and rank 0 still prints ONE valid line (the replicas line, with the error).
+    # ---- N > 1.  `value` stays the BASELINE metric on the BASELINE workload with one independent MiMC-128 proof per GPU (weak
+    # scaling, no data-path collective: a single MiMC proof is bounded by the serial trace recurrence of its one register, SURVEY 8e
+    # "Fallback").  Beside it, the `one_proof` object: ONE proof across all ranks through the native distributed driver
+    # (csrc/prover_dist.h, gs_prover_prove_dist) over RCCL (csrc/comm_rccl.cc) — C4 (BASELINE configs[3]: Poseidon, 6 registers,
+    # 2^16 steps = 1 024 hash chains, trace generation sharded by segment) is the strong-scaling measurement, with the same proof on
+    # ONE GPU timed in the same run; C5 (the headline statement as one proof) is reported with it.  Every collective is listed with
+    # its bytes and device time.  The leg runs under a watchdog: whatever happens in it, every rank leaves within
+    # --sharded-leg-timeout seconds and rank 0 still prints ONE valid line.
     if dist is not None and args.sharded_leg_timeout > 0:
         import hashlib
         import threading
         result = {}
 
-        def one_proof_across_ranks(dstark, a0, inputs, reps):
-            pr = dstark.prove(a0, [], inputs)                                   # warm-up: plans, block cache
-            backend.stats.clear()
+        def timed_dist(nat, a0, inputs, sd, comm, reps):
+            nat.prove_bytes(a0, inputs, sd, comm=comm)                            # warm-up: plans, block cache, RCCL channels
             barrier()
             ts = time.perf_counter()
             for _ in range(reps):
-                pr = dstark.prove(a0, [], inputs)
+                blob = nat.prove_bytes(a0, inputs, sd, comm=comm)
             barrier()
             ms = (time.perf_counter() - ts) / reps * 1e3
-            t = torch.tensor([ms, backend.stats.get('ntt_points', 0) / reps], device='cpu' if cpu_mode else 'cuda', dtype=torch.float64)
-            tmax, tsum = t.clone(), t.clone()
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-            blob = dstark.serialize(pr)
+            t = torch.tensor([ms], device='cpu' if cpu_mode else 'cuda', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
             digests = [None] * world
             dist.all_gather_object(digests, hashlib.sha256(blob).hexdigest())          # verification only, not on the data path
-            return float(tmax[0]), float(tsum[1]), blob, len(set(digests)) == 1
+            return float(t[0]), blob, len(set(digests)) == 1, nat.last_collectives(), nat.last_stats()
 
         def leg():
             try:
                 if not cpu_mode:
                     torch.cuda.set_device(local_rank)      # the HIP current device is per-thread state
                     torch.cuda.set_stream(stream)
-                from genstark_amd.air import MimcAir
-                from genstark_amd.distributed import DistField
-                from genstark_amd.stark import Stark
-                # C5: the same statement on every rank
-                a0 = assertions_for(stark, steps, 3)
-                opts = {'hashAlgorithm': 'blake2s256', 'extensionFactor': ef, 'exeQueryCount': 48, 'friQueryCount': fri}
-                dstark = Stark(MimcAir(steps, ef, DistField(backend, n)), opts)
-                ms, launched_all, blob, same = one_proof_across_ranks(dstark, a0, [3], args.steps)
-                ok = same and (rank != 0 or stark.verify(a0, stark.parse(blob)))
-                result['c5'] = {'ms_per_proof': round(ms, 3), 'ranks': world, 'proofs_timed': args.steps, 'proof_bytes': len(blob),
-                                'ntt_points_launched_all_ranks_per_proof': launched_all,
-                                'same_bytes_on_every_rank_and_verified': bool(ok)}
-                # C4 (BASELINE configs[3]): Poseidon, 6 state registers, 2^16 steps, E = 16 — one proof across the ranks
+                from genstark_amd.comm import RcclComm, TorchComm
+                if cpu_mode:
+                    comm = TorchComm(backend)
+                else:
+                    uid = [RcclComm.unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(uid, src=0)                              # control path: 128 bytes, once
+                    comm = RcclComm(backend, rank, world, uid[0])
+                result['comm'] = {'name': 'rccl' if not cpu_mode else 'torch.distributed (test double run)', 'ranks': world}
+                result['rccl_ranks'] = world if not cpu_mode else 0
+                # C4 (BASELINE configs[3]): Poseidon 6x128, 2^16 steps as 1 024 independent 64-step hash chains, E = 16
                 if args.c4_log_trace > 0:
                     from genstark_amd.poseidon import poseidon6x128_air
-                    from genstark_amd.field import PrimeField
+                    from genstark_amd.stark import Stark
                     t4 = 1 << args.c4_log_trace
                     opts4 = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 48, 'friQueryCount': 24}
-                    ref_air = poseidon6x128_air(t4, 16, PrimeField(backend=backend))
-                    tr = ref_air.initProvingContext([], [1, 2, 3, 4]).generateExecutionTrace()
-                    a4 = [{'step': 0, 'register': 0, 'value': tr.getValue(0, 0)}, {'step': t4 - 1, 'register': 5, 'value': tr.getValue(5, t4 - 1)}]
-                    d4 = Stark(poseidon6x128_air(t4, 16, DistField(backend, t4 * 16)), opts4)
-                    ms4, launched4, blob4, same4 = one_proof_across_ranks(d4, a4, [1, 2, 3, 4], max(1, min(args.steps, 3)))
-                    ok4 = same4 and (rank != 0 or Stark(ref_air, opts4).verify(a4, Stark(ref_air, opts4).parse(blob4)))
-                    result['c4'] = {'workload': f'Poseidon 6x128, 2^{args.c4_log_trace} steps, E=16, exe 48, fri 24, blake2s256', 'ms_per_proof': round(ms4, 3),
-                                    'ranks': world, 'proof_bytes': len(blob4), 'ntt_points_launched_all_ranks_per_proof': launched4,
-                                    'same_bytes_on_every_rank_and_verified': bool(ok4)}
+                    air4 = poseidon6x128_air(t4, 16, stark.air.field, segmented=True)
+                    seed4 = [[1 + s_, 2, 3 + s_, 4] for s_ in range(t4 // 64)]
+                    stark4 = Stark(air4, opts4)
+                    tr = air4.initProvingContext([], seed4).generateExecutionTrace()
+                    a4 = [{'step': 63, 'register': 0, 'value': tr.getValue(0, 63)}, {'step': t4 - 1, 'register': 5, 'value': tr.getValue(5, t4 - 1)}]
+                    nat4 = NativeProver(stark4)
+                    single = nat4.prove_bytes(a4, [], seed4)                                # the same statement on ONE GPU (every rank, concurrently)
+                    reps4 = max(3, args.steps)
+                    barrier()
+                    ts = time.perf_counter()
+                    for _ in range(reps4):
+                        single = nat4.prove_bytes(a4, [], seed4)
+                    single_ms = (time.perf_counter() - ts) / reps4 * 1e3
+                    ms4, blob4, same4, colls4, st4 = timed_dist(nat4, a4, [], seed4, comm.comm, reps4)
+                    ok4 = same4 and blob4 == single and (rank != 0 or stark4.verify(a4, stark4.parse(blob4)))
+                    result['c4'] = {'workload': f'Poseidon 6x128, 2^{args.c4_log_trace} steps = {t4 // 64} hash chains, E=16, exe 48, fri 24, blake2s256',
+                                    'ms_per_proof': round(ms4, 3), 'single_gpu_ms_per_proof': round(single_ms, 3),
+                                    'speedup_vs_one_gpu': round(single_ms / ms4, 3), 'ranks': world, 'proofs_timed': reps4, 'proof_bytes': len(blob4),
+                                    'scaling': 'strong', 'phases_ms': st4['phases_ms'], 'collectives': colls4,
+                                    'collective_bytes_per_rank': sum(c['bytes'] * (world if c['kind'] == 'all_to_all' else 1) for c in colls4),
+                                    'same_bytes_as_the_single_gpu_proof_on_every_rank_and_verified': bool(ok4)}
+                # C5: the headline statement as ONE proof (every rank the same seed)
+                a0 = assertions_for(stark, steps, 3)
+                want = prover.prove_bytes(a0, [], [3])
+                ms, blob, same, colls, st5 = timed_dist(prover, a0, [], [3], comm.comm, args.steps)
+                ok = same and blob == want and (rank != 0 or stark.verify(a0, stark.parse(blob)))
+                result['c5'] = {'workload': f'MiMC-128 2^{args.log_trace} steps, E={ef}: ONE proof across {world} ranks', 'ms_per_proof': round(ms, 3),
+                                'ranks': world, 'proofs_timed': args.steps, 'proof_bytes': len(blob), 'scaling': 'strong',
+                                'phases_ms': st5['phases_ms'], 'collectives': colls,
+                                'note': 'bounded from below by the serial x^3 + k recurrence of the one trace register (replicated on every rank)',
+                                'same_bytes_as_the_single_gpu_proof_on_every_rank_and_verified': bool(ok)}
             except BaseException as e:                                          # never take the main line down
                 result['error'] = repr(e)[:300]
 
         th = threading.Thread(target=leg, daemon=True)
         th.start()
         th.join(args.sharded_leg_timeout)
+        snap = dict(result)                    # the leg may still be running: report what it had at the deadline, ignore later writes
         if th.is_alive():
-            result['error'] = f'timed out after {args.sharded_leg_timeout} s'
+            snap['error'] = f'timed out after {args.sharded_leg_timeout} s'
         if out is not None:
-            c5 = result.get('c5')
-            if c5 and c5.get('same_bytes_on_every_rank_and_verified') and 'error' not in result:
-                replicas = {k: out[k] for k in ('value', 'unit', 'ms_per_step', 'scaling', 'steps') if k in out}
-                replicas['note'] = 'one independent proof per GPU, no data-path collective (the fallback line of SURVEY.md 8e); NOT the scaling curve'
-                out['replicas'] = replicas
-                out['value'] = out['config']['ntt_points_per_prove'] / (c5['ms_per_proof'] * 1e-3)
-                out['ms_per_step'] = out['prove_ms'] = c5['ms_per_proof']
-                out['scaling'] = 'strong'
-                out['config']['workload'] = out['config']['workload'].replace('one independent proof per GPU', f'ONE proof across {world} GPUs')
-                out['config']['parallelism'] = (f'evaluation domain strided over {world} ranks: local coset NTTs / pointwise / FRI folds, one point-to-point digest '
-                                                're-shard + one all-gather of sub-roots per Merkle tree (RCCL); trace recurrence and composition-domain '
-                                                'work replicated; Python SPMD driver over the C ABI (genstark_amd/distributed.py)')
-                out['config']['ntt_points_note'] = ('numerator = the transform points of the statement as the single-GPU driver counts them (same as at N = 1); '
-                                                    'ntt_points_launched_all_ranks_per_proof also counts the replicated composition-domain transforms')
-                for k in ('per_step_ms', 'phases_ms', 'phases_source', 'driver_total_ms', 'python_mirror_prove_ms'):
-                    if k in out:
-                        out.setdefault('replicas_detail', {})[k] = out.pop(k)
-            out['sharded'] = result
+            out['config']['parallelism'] = (f'value: {world} independent proofs, one per GPU (no data-path collective). one_proof: the evaluation domain '
+                                            f'strided over {world} ranks — coset NTTs, constraint evaluation, pointwise work and FRI folds local; trace '
+                                            'segments generated by their owners; per Merkle tree one all-to-all of leaf digests + one all-gather of '
+                                            'sub-roots; all query answers in one all-gather; native driver (csrc/prover_dist.h) over RCCL on device buffers')
+            out['one_proof'] = snap
+            out['rccl_ranks'] = snap.get('rccl_ranks')
+            out['collectives'] = (snap.get('c4') or snap.get('c5') or {}).get('collectives', [])
             print(json.dumps(out), flush=True)
         sys.stdout.flush()
         os._exit(0)      # the line is out; a rank may be stuck in (or may have bailed out of) a collective of the extra leg, so no
