@@ -238,7 +238,9 @@ def main():
     # the product's prove(): the native driver (csrc/prover.cc — lib/Stark.ts:81-163 as C++ above the C ABI); the Python mirror
     # of the same sequence (stark.prove) is timed beside it outside the timed region and must give the same bytes
     from genstark_amd.native import NativeProver
-    prover = NativeProver(stark)
+    from genstark_amd.prover import Prover
+    # the timed object: Prover = the AIR + options handed straight to the native driver (no mirror object involved)
+    prover = Prover(stark.air, {'hashAlgorithm': 'blake2s256', 'extensionFactor': ef, 'exeQueryCount': 48, 'friQueryCount': fri})
     data = None
     for _ in range(args.warmup):
         data = prover.prove_bytes(a, [], [seed])
@@ -342,7 +344,7 @@ def main():
         if args.lanes > 0 and world == 1:
             from genstark_amd.pipeline import ProverPool
             job = (a, [], [seed])
-            with ProverPool(lambda be: make_stark(ga, be, steps, ef, fri), lanes=args.lanes,
+            with ProverPool(lambda be: ga.mimcProver(steps, {'hashAlgorithm': 'blake2s256', 'extensionFactor': ef, 'exeQueryCount': 48, 'friQueryCount': fri}, backend=be), lanes=args.lanes,
                             backend_factory=lambda: Backend(device=local_rank), native=True) as pool:
                 for _ in range(max(args.warmup, 1)):
                     pool.on_every_lane(lambda s: s.prove_bytes(*job))
@@ -361,6 +363,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': f'MiMC-128 prove(), 2^{args.log_trace} steps, extensionFactor {ef}, exeQueryCount 48, '
                                    f'friQueryCount {fri}, blake2s256; one independent proof per GPU',
+                       'secret_registers': 0,
                        'evaluation_domain': n, 'ntt_points_per_prove': points, 'ntt_transforms_per_prove': launched[-1]['ntt_transforms'],
                        'ntt_points_source': 'gs_prover_last_stats: rows * n of every transform the timed driver launched', 'proof_bytes': len(data)},
             'prove_ms': ms_per_step, 'per_step_ms': step_ms, 'python_mirror_prove_ms': mirror_ms, 'phases_ms': phases, 'phases_source': 'native driver clock, last timed step', 'driver_total_ms': driver_total_ms, 'roofline': roofline, 'cpu_baseline': cpu,
@@ -410,7 +413,7 @@ def main():
                 # C4 (BASELINE configs[3]): Poseidon 6x128, 2^16 steps as 1 024 independent 64-step hash chains, E = 16
                 if args.c4_log_trace > 0:
                     from genstark_amd.poseidon import poseidon6x128_air
-                    from genstark_amd.stark import Stark
+                    from genstark_amd._mirror.stark import Stark
                     t4 = 1 << args.c4_log_trace
                     opts4 = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 48, 'friQueryCount': 24}
                     air4 = poseidon6x128_air(t4, 16, stark.air.field, segmented=True)

@@ -2,9 +2,9 @@
 
 prove()/fri() (:39-68, :176-221) run on the device: transpose-4, row hashing, Merkle build, cubic
 interpolation + evaluation per row; verify() (:70-172) touches a few hundred elements on the host."""
-from ..errors import StarkError
-from ..merkle import MerkleTree
-from ..utils import readBigInt, rehashMerkleProofValues
+from ...errors import StarkError
+from ...merkle import MerkleTree
+from ...utils import readBigInt, rehashMerkleProofValues
 
 MAX_REMAINDER_LENGTH = 256  # :12
 

@@ -5,7 +5,7 @@ hashed as Buffer.from(value.toString(16), 'hex') (odd trailing nibble dropped; :
 """
 import ctypes as C
 
-from ..field import sha256_bigint
+from ...field import sha256_bigint
 
 
 class QueryIndexGenerator:

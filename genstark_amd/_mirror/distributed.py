@@ -27,9 +27,9 @@ import ctypes as C
 import torch
 import torch.distributed as dist
 
-from ._abi import GstarkError
-from .field import ELEMENT_SIZE, Matrix, PrimeField, Vector
-from .merkle import DIGEST_SIZE, Hash, MerkleTree
+from .._abi import GstarkError
+from ..field import ELEMENT_SIZE, Matrix, PrimeField, Vector
+from ..merkle import DIGEST_SIZE, Hash, MerkleTree
 
 
 class _Comm:

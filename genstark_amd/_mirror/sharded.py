@@ -22,8 +22,8 @@ import ctypes as C
 import torch
 import torch.distributed as dist
 
-from .field import ELEMENT_SIZE, Matrix, Vector
-from .merkle import DIGEST_SIZE, MerkleTree
+from ..field import ELEMENT_SIZE, Matrix, Vector
+from ..merkle import DIGEST_SIZE, MerkleTree
 
 
 class _TensorOwner:

@@ -5,10 +5,10 @@ import math
 import os
 
 from .components import CompositionPolynomial, LinearCombination, LowDegreeProver, QueryIndexGenerator
-from .errors import StarkError
-from .merkle import MerkleTree, createHash
-from .serializer import Serializer
-from .utils import NoopLogger, powLog2, readBigInt, rehashMerkleProofValues, sizeOf
+from ..errors import StarkError
+from ..merkle import MerkleTree, createHash
+from ..serializer import Serializer
+from ..utils import NoopLogger, powLog2, readBigInt, rehashMerkleProofValues, sizeOf
 
 DEFAULT_EXE_QUERY_COUNT = 80   # :13-17
 DEFAULT_FRI_QUERY_COUNT = 40

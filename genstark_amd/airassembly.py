@@ -568,7 +568,7 @@ class AssemblyAir:
 
 def instantiate(source, component='default', options=None, logger=None, field=None):
     """index.ts:18-33: AirAssembly source (text, bytes or a path to an .aa file) + export name + StarkOptions -> Stark."""
-    from .stark import Stark
+    from ._mirror.stark import Stark      # index.ts:18-33 returns a Stark object: the restated caller (prove / verify / serialize)
     if isinstance(source, str) and '(' not in source:
         with open(source) as fh:
             source = fh.read()

@@ -1,8 +1,8 @@
 """Binding of the native prove() driver (genstark_amd/csrc/prover.cc -> libgstark_prover.so).
 
-`NativeProver(stark)` proves the same statements as `stark.prove()` — same AIR, same options, same bytes
-(tests/test_native_prover.py) — with the whole call sequence of lib/Stark.ts:81-163 issued by native host code instead of
-the Python mirror: no interpreter between two launches.  The driver is bound to the ABI library the Stark's backend loaded
+`NativeProver(stark)` proves the same statements as the mirror's `stark.prove()` — same AIR, same options, same bytes
+(tests/test_native_prover.py) — with the whole call sequence of lib/Stark.ts:81-163 issued by native host code: no interpreter
+between two launches.  The product entry is genstark_amd.prover.Prover (an AIR + options, no mirror object involved).  The driver is bound to the ABI library the Stark's backend loaded
 (the HIP library in the product; the oracle's implementation only when a test injected it), it never falls back to anything.
 """
 import ctypes as C
@@ -99,8 +99,14 @@ def _driver_locked(backend, key):
 
 class NativeProver:
     def __init__(self, stark):
+        """stark: anything that names the statement's AIR and security options — genstark_amd.prover.Prover (the product entry), or
+        the mirror's Stark (tests compare the two drivers on one object)."""
         self.stark = stark
         air = stark.air
+        if hasattr(stark, 'indexGenerator'):         # the mirror's Stark
+            self._exe, self._fri, self._alg = stark.indexGenerator.exeQueryCount, stark.indexGenerator.friQueryCount, stark.hash.alg
+        else:
+            self._exe, self._fri, self._alg = stark.exeQueryCount, stark.friQueryCount, stark.hashAlg
         self.field = air.field
         self.backend = self.field.backend
         from .field import MODULUS
@@ -139,8 +145,8 @@ class NativeProver:
             raise TypeError('At least one assertion must be provided')
         job = _Job()
         job.steps, job.extension_factor = air.steps, air.extensionFactor
-        job.exe_query_count, job.fri_query_count = stark.indexGenerator.exeQueryCount, stark.indexGenerator.friQueryCount
-        job.hash_alg = stark.hash.alg
+        job.exe_query_count, job.fri_query_count = self._exe, self._fri
+        job.hash_alg = self._alg
         job.root_of_unity[:] = _le(self.rootOfUnity)
         arr = (_Assertion * len(assertions))()
         for i, a in enumerate(assertions):

@@ -17,7 +17,7 @@ from ._abi import Backend
 
 class ProverPool:
     def __init__(self, stark_factory, lanes=2, backend_factory=None, native=False, jit=True):
-        """stark_factory(backend) -> Stark; backend_factory() -> Backend, called once inside every lane's thread (the HIP
+        """stark_factory(backend) -> genstark_amd.prover.Prover (or the mirror's Stark); backend_factory() -> Backend, called once inside every lane's thread (the HIP
         current device is per-thread state, gs_ctx_create sets it for the calling thread).  jit: a pool is a long-lived service,
         so its lanes have AIR programs compiled (gs_air_jit: once per process, shared by the lanes) instead of interpreted."""
         if lanes < 1:
@@ -44,7 +44,7 @@ class ProverPool:
             if self.jit and hasattr(backend, 'jit'):
                 backend.jit()
             stark = stark_factory(backend)
-            if self.native:
+            if self.native and not hasattr(stark, 'prove_bytes'):      # a mirror Stark: wrap it; a Prover already is the native driver
                 from .native import NativeProver
                 stark = NativeProver(stark)
             self.starks[index] = stark

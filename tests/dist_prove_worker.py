@@ -14,9 +14,9 @@ import torch.distributed as dist
 import genstark_amd as ga
 from genstark_amd._abi import Backend
 from genstark_amd.air import MimcAir
-from genstark_amd.distributed import DistField
+from genstark_amd._mirror.distributed import DistField
 from genstark_amd.field import PrimeField
-from genstark_amd.stark import Stark
+from genstark_amd._mirror.stark import Stark
 
 
 def build(kind, steps, ef, field):

@@ -4,7 +4,7 @@ on a backend (`build`), and the case record the node runner (tests/golden/run_re
 from genstark_amd import poseidon
 from genstark_amd.field import PrimeField
 from genstark_amd.rescue import rescue4x128_air
-from genstark_amd.stark import Stark
+from genstark_amd._mirror.stark import Stark
 
 RESCUE_OPTS = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 68, 'friQueryCount': 24}     # hash4x128.ts:41-47
 POSEIDON_OPTS = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 68, 'friQueryCount': 24}   # hash6x128.ts:35-41

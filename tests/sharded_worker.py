@@ -13,7 +13,7 @@ import torch.distributed as dist
 from genstark_amd._abi import Backend
 from genstark_amd.field import PrimeField
 from genstark_amd.merkle import MerkleTree, createHash
-from genstark_amd.sharded import domain_sharded_commit, owned_registers, sharded_commit
+from genstark_amd._mirror.sharded import domain_sharded_commit, owned_registers, sharded_commit
 
 P = 2**128 - 9 * 2**32 + 1
 

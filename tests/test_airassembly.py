@@ -19,7 +19,7 @@ from genstark_amd.errors import StarkError
 from genstark_amd.field import PrimeField
 from genstark_amd.hostfield import HostField
 from genstark_amd.pointmul import point_mul_air, to_bits
-from genstark_amd.stark import Stark
+from genstark_amd._mirror.stark import Stark
 
 AA = os.path.join(ROOT, 'tests', 'golden', 'aa')
 REF = '/root/reference'

@@ -39,7 +39,7 @@ def test_distributed_prove_gloo(oracle_backend, world, kind, log_t, ef, alg):
 def test_batch_proof_plan_matches_library(oracle_backend):
     """The host plan the sharded tree uses must select exactly the digests gs_merkle_prove_batch returns."""
     import random
-    from genstark_amd.distributed import batch_proof_plan
+    from genstark_amd._mirror.distributed import batch_proof_plan
     from genstark_amd.field import PrimeField
     from genstark_amd.merkle import MerkleTree, createHash
     f = PrimeField(backend=oracle_backend)

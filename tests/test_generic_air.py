@@ -10,7 +10,7 @@ from genstark_amd.air_generic import GenericAir, Program, const, reg
 from genstark_amd.errors import StarkError
 from genstark_amd.field import PrimeField
 from genstark_amd.rescue import rescue4x128_air
-from genstark_amd.stark import Stark
+from genstark_amd._mirror.stark import Stark
 
 RESCUE_KAT = (302524937772545017647250309501879538110, 205025454306577433144586673939030012640)   # hash4x128.ts:115-118
 RESCUE_OPTS = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 68, 'friQueryCount': 24}   # hash4x128.ts:41-47

@@ -10,7 +10,7 @@ import genstark_amd as ga
 from genstark_amd.air import MimcAir
 from genstark_amd.errors import StarkError
 from genstark_amd.hostfield import HostField
-from genstark_amd.stark import Stark
+from genstark_amd._mirror.stark import Stark
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(HERE, 'golden', 'oracle_proofs.json')) as f:

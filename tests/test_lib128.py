@@ -8,7 +8,7 @@ import genstark_amd as ga
 from genstark_amd import lib128
 from genstark_amd.errors import StarkError
 from genstark_amd.field import PrimeField
-from genstark_amd.stark import Stark
+from genstark_amd._mirror.stark import Stark
 
 OPTS = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 32, 'exeQueryCount': 44, 'friQueryCount': 20}       # lib128.ts:33-39
 

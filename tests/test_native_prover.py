@@ -12,7 +12,7 @@ import genstark_amd as ga
 from genstark_amd.errors import StarkError
 from genstark_amd.field import PrimeField
 from genstark_amd.native import NativeProver
-from genstark_amd.stark import Stark
+from genstark_amd._mirror.stark import Stark
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(HERE, 'golden', 'oracle_proofs.json')) as f:
@@ -125,3 +125,31 @@ def test_native_prover_2p20_config(hip_backend):
     data = NativeProver(stark).prove_bytes(assertions, [], [3])
     assert data == stark.serialize(stark.prove(assertions, [], [3]))
     assert stark.verify(assertions, stark.parse(data))
+
+
+def test_product_prover_entry(oracle_backend):
+    """genstark_amd.prover.Prover: an AIR + options straight into the native driver (no mirror object), the reference's option rules
+    (lib/Stark.ts:318-344), bytes of the mirror, and the CPU verifier behind verify()."""
+    import sys
+    from genstark_amd.air import MimcAir, runMimc
+    from genstark_amd.field import PrimeField
+    from genstark_amd.prover import Prover
+    f = PrimeField(backend=oracle_backend)
+    opts = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 48, 'friQueryCount': 24}
+    air = MimcAir(256, 16, f)
+    controls = runMimc(f, 256, air.roundConstants, 3)
+    a = [{'step': 0, 'register': 0, 'value': 3}, {'step': 255, 'register': 0, 'value': controls[-1]}]
+    p = Prover(air, opts)
+    data = p.prove_bytes(a, [], [3])
+    from genstark_amd._mirror.stark import Stark
+    mirror = Stark(air, opts)
+    assert data == mirror.serialize(mirror.prove(a, [], [3]))
+    assert p.verify(a, data) and p.prove(a, [], [3])['evRoot'] == data[:32]
+    assert Prover(air).options == {'extensionFactor': 16, 'exeQueryCount': 80, 'friQueryCount': 40, 'hashAlgorithm': 'sha256'}
+    for bad, msg in (({'exeQueryCount': 129}, 'Execution sample size'), ({'friQueryCount': 65}, 'FRI sample size'), ({'hashAlgorithm': 'md5'}, 'not supported')):
+        with pytest.raises(TypeError, match=msg):
+            Prover(air, bad)
+    # importing the product entry does not load the mirror
+    import subprocess
+    code = 'import sys, genstark_amd, genstark_amd.prover; assert not any(m.startswith("genstark_amd._mirror") for m in sys.modules), sorted(sys.modules)'
+    assert subprocess.run([sys.executable, '-c', code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).returncode == 0

@@ -95,7 +95,7 @@ def test_pool_compiles_air_programs_and_matches_sequential_proofs_hip():
     """A pool's lanes have AIR programs compiled (gs_air_jit, once per process): same bytes as the sequential, interpreted prover."""
     from genstark_amd.field import PrimeField
     from genstark_amd.poseidon import poseidon6x128_air
-    from genstark_amd.stark import Stark
+    from genstark_amd._mirror.stark import Stark
     opts = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 40, 'friQueryCount': 16}
     make = lambda backend: Stark(poseidon6x128_air(1024, 16, PrimeField(backend=backend), segmented=True), opts)
     seeds = [[1 + s, 2, 3 + s, 4] for s in range(16)]

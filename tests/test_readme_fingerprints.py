@@ -17,7 +17,7 @@ from genstark_amd._abi import Backend
 from genstark_amd.air_generic import GenericAir
 from genstark_amd.field import PrimeField
 from genstark_amd.native import NativeProver
-from genstark_amd.stark import Stark
+from genstark_amd._mirror.stark import Stark
 
 #        name,                          published KB, steps, E, exe, fri, trace registers, secret registers, degree, element bytes
 ROWS = [('MiMC 128-bit 2^13',            94.58, 1 << 13, 16, 48, 24, 1, 1, 3, 16),       # README.md:75 (the log) and :211 (95 KB)

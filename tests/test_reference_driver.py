@@ -81,7 +81,7 @@ def test_reference_stark_js_runs_live_over_another_field(name, tmp_path):
     from genstark_amd._abi import MODULUS_64, MODULUS_256, Backend
     from genstark_amd.air import MimcAir, runMimc
     from genstark_amd.field import PrimeField
-    from genstark_amd.stark import Stark
+    from genstark_amd._mirror.stark import Stark
     from conftest import _build_oracle
     _build_oracle()
     subprocess.check_call(['bash', os.path.join(ROOT, 'napi', 'build.sh')])

@@ -10,7 +10,7 @@ import pytest
 
 from oracle import pyref
 from genstark_amd import utils as gutils
-from genstark_amd.components.query_index_generator import QueryIndexGenerator
+from genstark_amd._mirror.components.query_index_generator import QueryIndexGenerator
 from genstark_amd.serializer import Serializer
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -15,7 +15,7 @@ from genstark_amd.errors import StarkError
 from genstark_amd.field import PrimeField
 from genstark_amd.hostfield import HostField
 from genstark_amd.rescue import rescue2x64_air
-from genstark_amd.stark import Stark
+from genstark_amd._mirror.stark import Stark
 
 FLAVOURS = {'q64': MODULUS_64, 'q32': MODULUS_32, 'q17': MODULUS_17}
 # the STARK trace column of hash2x64.ts:149-213 (rounds 1, 2, 3, 5, 6, 7) and the digest of 42 (:101)

@@ -16,7 +16,7 @@ from genstark_amd.errors import StarkError
 from genstark_amd.field import PrimeField
 from genstark_amd.hostfield import HostField
 from genstark_amd.pointmul import ec_multiply, point_mul_air, to_bits
-from genstark_amd.stark import Stark
+from genstark_amd._mirror.stark import Stark
 from test_small_fields import check_arithmetic
 
 FLAVOURS = {'p256': MODULUS_256, 'p224': MODULUS_224}

@@ -7,7 +7,7 @@ from genstark_amd.field import PrimeField
 from genstark_amd.native import NativeProver
 from genstark_amd.poseidon import poseidon6x128_air
 from genstark_amd.rescue import rescue4x128_air
-from genstark_amd.stark import Stark
+from genstark_amd._mirror.stark import Stark
 be = Backend(device=0)
 if len(sys.argv) > 1 and sys.argv[1] == 'jit':
     be.jit()

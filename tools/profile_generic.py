@@ -8,7 +8,7 @@ from genstark_amd.field import PrimeField
 from genstark_amd.native import NativeProver
 from genstark_amd.poseidon import poseidon6x128_air
 from genstark_amd.rescue import rescue4x128_air
-from genstark_amd.stark import Stark
+from genstark_amd._mirror.stark import Stark
 
 f = PrimeField(backend=Backend(device=0))
 opts = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 68, 'friQueryCount': 24}

@@ -8,7 +8,7 @@ from genstark_amd._abi import Backend
 from genstark_amd.field import PrimeField
 from genstark_amd.native import NativeProver
 from genstark_amd.rescue import rescue4x128_air
-from genstark_amd.stark import Stark
+from genstark_amd._mirror.stark import Stark
 
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 5)

@@ -14,7 +14,7 @@ from genstark_amd.field import PrimeField
 from genstark_amd.hostfield import HostField
 from genstark_amd.pointmul import point_mul_air, to_bits
 from genstark_amd.rescue import rescue2x64_air
-from genstark_amd.stark import Stark
+from genstark_amd._mirror.stark import Stark
 
 rows = []
 

@@ -4,7 +4,7 @@ sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 from test_wide_fields import hip_for, EC_POINT, EC_SCALAR, EC_OPTIONS
 from genstark_amd.field import PrimeField
 from genstark_amd.pointmul import point_mul_air, to_bits
-from genstark_amd.stark import Stark
+from genstark_amd._mirror.stark import Stark
 
 for jit in (False, True):
     b = hip_for('p224')
