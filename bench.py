@@ -114,8 +114,8 @@ def cpu_baseline(ga, ef, fri):
         s_, pts = cpu_prove(ga, lib, log_steps, ef, 48, fri, cores)
         best = {'log': log_steps, 's': s_, 'points': pts}
         rows.append({'config': f'2^{log_steps} steps, E={ef}, exe 48, fri {fri}', 'threads': cores, 'prove_ms': round(s_ * 1e3, 1), 'elements_per_s': pts / s_})
-    for log_steps in (14, 16):
-        if one is not None and one['s'] * 4.5 > budget + 15.0 - time.perf_counter():
+    for log_steps in (14, 16, 18):
+        if one is not None and one['s'] * 4.5 > budget + 25.0 - time.perf_counter():
             break
         s_, pts = cpu_prove(ga, lib, log_steps, ef, 48, fri, 1)
         one = {'log': log_steps, 's': s_, 'points': pts}
@@ -130,35 +130,85 @@ def cpu_baseline(ga, ef, fri):
             'cores_note': f'{visible} CPUs visible; {cores} threads was the fastest of the sweep on C2 and is what "all cores" uses'}
 
 
-def second_roof(n, transform_ms, npass):
-    """The roof the NTT kernel actually sits under: VALU issue.  tools/microbench5 runs the kernel's own product routines on
-    registers only (no memory traffic) in THIS run; the pass kernel's work in the same currency: per 16 elements a pass does two
-    radix-16 networks, 15 per-lane exchange products and (all passes but the first) 16 per-lane input products, 16 pack+unpack."""
+# issue cost of one wave-instruction per SIMD with 4 waves resident, by class (tools/microbench4.hip -> profiles/r02_a_instruction_costs.txt)
+VALU_CLASS_NS = {'cheap': 1.1, 'vop3': 1.8, 'carry': 1.95, 'mad64': 2.0}
+
+
+def ntt_plan(logn, table_log=20):
+    """the pass structure csrc/ntt.hip builds for a 2^logn-point transform: [(log2 radix, twiddle source)], twiddle source 0 = first
+    pass (none), 1 = [k][jq] table (<= 2^20 entries), 2 = running product"""
+    np_ = (logn + 7) // 8
+    base, extra = logn // np_, logn % np_
+    out, acc = [], 0
+    for i in range(np_):
+        l = base + (1 if i < extra else 0)
+        out.append((l, 0 if i == 0 else (1 if acc + l <= table_log else 2)))
+        acc += l
+    return out
+
+
+def second_roof(n, transform_ms, npass, traffic_detail=None):
+    """The roof the NTT kernel actually sits under: VALU issue.  Two derivations, both from this run and this build:
+    (a) routines: tools/microbench5 runs the kernel's own product routines on registers only (no memory traffic); per 16 elements a
+        pass does two radix-16 networks, 15 per-lane exchange products, 16 per-lane input products on twiddled passes (+ 15 per-lane
+        chain products when the twiddles are a running product), 16 pack + unpack;
+    (b) counters: the kernels' VALU instruction count — SQ_INSTS_VALU of the same launches (rocprofv3 child process), checked against
+        the static instruction mix of the compiled kernels (csrc/ntt_isa_mix.json, straight-line code) — times the measured issue
+        cost of each instruction class."""
     import subprocess
+    logn = n.bit_length() - 1
+    plan = ntt_plan(logn)
+    out = {'bound': 'valu-issue', 'unit': 'ms per transform', 'achieved': round(transform_ms, 4), 'plan': plan}
     exe = os.path.join(ROOT, 'tools', 'microbench5')
-    if not os.path.exists(exe):
-        return {'error': 'tools/microbench5 not built'}
+    simds = 1024
+    if os.path.exists(exe):
+        try:
+            r = subprocess.run([exe, '--json'], capture_output=True, text=True, timeout=120)
+            m = json.loads(r.stdout.strip().splitlines()[-1])
+            simds = m['cus'] * 4
+            occ = 4                                  # every k_ntt_wave variant holds 4 waves per SIMD since round 3 (<= 128 VGPRs, no scratch)
+            dif, mulv, pack = m['dif16_network_ns'][occ - 1], m['mul_v_ns'][occ - 1], m['pack_unpack_add_ns'][occ - 1]
+            per_wave = [2 * dif + (15 + (16 if tw else 0) + (15 if tw == 2 else 0)) * mulv + 16 * pack for _, tw in plan]
+            floor_ms = sum(per_wave) * (n / 16 / 64) / simds * 1e-6
+            out.update({'peak': round(floor_ms, 4), 'frac': round(floor_ms / transform_ms, 4),
+                        'measured_ns_per_wave_at_1_2_3_4_waves_per_simd': {'radix16_network_17_products_64_addsub_16_norm': m['dif16_network_ns'],
+                                                                           'per_lane_product': m['mul_v_ns'], 'pack_unpack_add': m['pack_unpack_add_ns'],
+                                                                           'canonical_limb_fe_mul_for_reference': m['fe_mul_ns']},
+                        'kernel_waves_per_simd': occ,
+                        'note': 'peak = time the passes\' own routines need with no memory stall at all (registers-only microbenchmark at the '
+                                'kernel\'s occupancy, same run); frac = peak / achieved'})
+        except Exception as e:   # noqa: BLE001
+            out['error'] = repr(e)[:200]
+    else:
+        out['error'] = 'tools/microbench5 not built'
+    # (b) from the counters of the kernels themselves
     try:
-        r = subprocess.run([exe, '--json'], capture_output=True, text=True, timeout=120)
-        m = json.loads(r.stdout.strip().splitlines()[-1])
+        mix = json.load(open(os.path.join(ROOT, 'genstark_amd', 'csrc', 'ntt_isa_mix.json')))
+        waves = n / 16 / 64
+        rows, total_ns = [], 0.0
+        for l, tw in plan:
+            key = next((k for k in mix if f'k_ntt_waveILi{l - 4}ELi{tw}E' in k), None)
+            if key is None:
+                raise KeyError(f'k_ntt_wave<{l - 4}, {tw}>')
+            k = mix[key]
+            ns_per_wave = sum(k[c] * VALU_CLASS_NS[c] for c in VALU_CLASS_NS)
+            counted = None
+            for name, d in ((traffic_detail or {}).get('kernels') or {}).items():
+                if name.replace(' ', '').startswith(f'k_ntt_wave<{l - 4},{tw}>') and d.get('SQ_INSTS_VALU_avg'):
+                    counted = d['SQ_INSTS_VALU_avg']
+            insts = counted if counted else k['valu'] * waves
+            rows.append({'kernel': f'k_ntt_wave<{l - 4}, {tw}>', 'static_valu_per_wave': k['valu'], 'mix': {c: k[c] for c in VALU_CLASS_NS},
+                         'SQ_INSTS_VALU_per_launch': counted, 'static_valu_per_launch': k['valu'] * waves,
+                         'issue_floor_us': round(insts * (ns_per_wave / k['valu']) / simds * 1e-3, 1)})
+            total_ns += insts * (ns_per_wave / k['valu']) / simds
+        out['from_counters'] = {'peak': round(total_ns * 1e-6, 4), 'frac': round(total_ns * 1e-6 / transform_ms, 4), 'passes': rows,
+                                'class_cost_ns': VALU_CLASS_NS,
+                                'note': 'VALU wave-instructions of each pass (SQ_INSTS_VALU when the PMC pass ran, else the static count of the '
+                                        'straight-line kernel x waves) x issue cost of their classes / SIMDs: dependency stalls inside the '
+                                        'routines are NOT in this floor, which is why it is lower than `peak`'}
     except Exception as e:   # noqa: BLE001
-        return {'error': repr(e)[:200]}
-    # waves per SIMD of k_ntt_wave: 4 on a first pass (<= 128 VGPRs), 3 on the passes that carry input twiddles (<= 168)
-    o1, o2 = 4, 3
-    per_wave_pass_first = 2 * m['dif16_network_ns'][o1 - 1] + 15 * m['mul_v_ns'][o1 - 1] + 16 * m['pack_unpack_add_ns'][o1 - 1]
-    per_wave_pass_later = 2 * m['dif16_network_ns'][o2 - 1] + 31 * m['mul_v_ns'][o2 - 1] + 16 * m['pack_unpack_add_ns'][o2 - 1]
-    dif, mulv, pack, occ = m['dif16_network_ns'], m['mul_v_ns'], m['pack_unpack_add_ns'], [o1, o2]
-    waves = n / 16 / 64
-    simds = m['cus'] * 4
-    floor_ms = (per_wave_pass_first + (npass - 1) * per_wave_pass_later) * waves / simds * 1e-6
-    return {'bound': 'valu-issue', 'unit': 'ms per transform', 'peak': round(floor_ms, 4), 'achieved': round(transform_ms, 4),
-            'frac': round(floor_ms / transform_ms, 4),
-            'measured_ns_per_wave_at_1_2_3_4_waves_per_simd': {'radix16_network_17_products_64_addsub_16_norm': dif, 'per_lane_product': mulv,
-                                                               'pack_unpack_add': pack, 'canonical_limb_fe_mul_for_reference': m['fe_mul_ns']},
-            'kernel_waves_per_simd': {'first_pass': occ[0], 'twiddled_passes': occ[1]},
-            'note': 'peak = time the kernel\'s own instruction stream needs with no memory stall at all (registers-only microbenchmark of '
-                    'the same routines at the same occupancy, same run); frac = peak / achieved = share of the kernel time that is '
-                    'arithmetic issue'}
+        out['from_counters'] = {'error': repr(e)[:200]}
+    return out
 
 
 def pmc_traffic(logn):
@@ -333,7 +383,7 @@ def main():
                     'kernel': f'k_ntt_wave<4, *> (radix-256 Stockham pass, one wave per tile, lazy five-limb butterflies), {npass} launches per 2^{logn}-point transform',
                     'launch_ms': round(launch_ms, 4), 'transform_ms': round(transform_ms, 4),
                     'ntt_kernel_elements_per_sec': round(n / (transform_ms * 1e-3), 1),
-                    'second_roof': second_roof(n, transform_ms, npass)}
+                    'second_roof': second_roof(n, transform_ms, npass, traffic_detail)}
         del src, dst
 
         cpu = None if args.no_cpu_baseline else cpu_baseline(ga, ef, fri)
@@ -357,7 +407,7 @@ def main():
                          'note': 'independent proofs in flight on one GPU (one library context + HIP stream per lane): a lane\'s '
                                  'host-side trace recurrence overlaps the other lanes\' kernels; latency of one proof is prove_ms'}
         out = {
-            'metric': 'prove() ms + NTT GF(p) elements/sec, MiMC-128 2^20 steps: NTT points launched per second of whole prove()', 'value': points * world / (ms_per_step * 1e-3),
+            'metric': 'prove() ms + NTT GF(p) elements/sec, MiMC-128 2^20 steps: value = NTT points launched per second of whole prove() (68 % of which is the serial host trace recurrence); the kernel-level figures are roofline.ntt_kernel_elements_per_sec and pipelined.ms_per_proof', 'value': points * world / (ms_per_step * 1e-3),
             'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u128 (GF(2^128-9*2^32+1): 4x u32 limbs in memory, 5x 26-bit limbs inside the NTT networks)',
             'data': 'synthetic',

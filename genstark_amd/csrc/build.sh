@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=1000000 -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result"
 UNITS="ctx ntt pointwise hash air_mimc air_vm air_jit small"
-HDRS="gf128_lazy.h ntt_mfma.h host_pow.h gf128.h gf_small.h gf_wide.h common.h host_field.h host_field_small.h host_field_wide.h host_sha256.h hash_core.h ../../include/gstark.h"
+HDRS="gf128_lazy.h host_pow.h gf128.h gf_small.h gf_wide.h common.h host_field.h host_field_small.h host_field_wide.h host_sha256.h hash_core.h ../../include/gstark.h"
 # one library per field: the 128-bit field of the hot path, and two "plumbing" flavours of the same sources for the small prime
 # fields of the reference's examples (gf_small.h): 2^64 - 21*2^30 + 1 (rescue/hash2x64.ts) and 2^32 - 3*2^25 + 1 (demo/fibonacci.ts)
 # the field headers as string literals: the source text hiprtc compiles AIR programs against (air_jit.hip)
@@ -37,6 +37,10 @@ build_flavour build_q17 libgstark_hip_q17.so "-DGS_SMALL_Q=96769ull" &        # 
 build_flavour build_p256 libgstark_hip_p256.so "-DGS_WIDE_BITS=256" &
 build_flavour build_p224 libgstark_hip_p224.so "-DGS_WIDE_BITS=224" &
 wait
+# static VALU instruction mix of the NTT pass kernels (bench.py: roofline.second_roof): from the device assembly of ntt.hip
+if [ ! -f ntt_isa_mix.json ] || [ ntt.hip -nt ntt_isa_mix.json ] || [ gf128_lazy.h -nt ntt_isa_mix.json ]; then
+  $HIPCC $FLAGS -S --cuda-device-only ntt.hip -o build/ntt.s 2>/dev/null && python3 ../../tools/valu_mix.py build/ntt.s > ntt_isa_mix.json.tmp && mv ntt_isa_mix.json.tmp ntt_isa_mix.json
+fi
 # the native prove() driver: plain C++ above the C ABI (binds to whichever implementation of it the caller loaded)
 if [ ! -f libgstark_prover.so ] || [ prover.cc -nt libgstark_prover.so ] || [ prover_dist.h -nt libgstark_prover.so ] || [ ../../include/gstark_comm.h -nt libgstark_prover.so ] || [ ../../include/gstark.h -nt libgstark_prover.so ]; then
   g++ -O2 -std=c++17 -shared -fPIC -Wall -Wno-unused-function prover.cc -ldl -o libgstark_prover.so

@@ -28,7 +28,6 @@
 #define GS_NTT_LAZY 1      // the 128-bit field of the hot path: butterflies in five-limb lazy form (gf128_lazy.h)
 #include "gf128_lazy.h"
 struct alignas(32) lz8 { int32_t l[8]; };   // an NN element as a table entry: five limbs, 32-byte stride
-struct alignas(16) lzw28 { int32_t w[28]; };   // a table entry in W-form: rows w * B^i mod p (i < 5) as signed digits |limb| <= 2^25, 25 words + padding
 #endif
 
 struct NttPlan {
@@ -47,12 +46,12 @@ struct NttPlan {
     lzw *wtab = nullptr;                               // device: W-forms of omega_16^1..7 and of 1/n (read with scalar loads)
     lz8 *wRz[4] = {nullptr, nullptr, nullptr, nullptr};   // wR[i] as NN limbs
     lz8 *wRz_scaled = nullptr;                         // the last pass's table times 1/n (inverse transforms: the scale rides on the exchange twiddle)
-    lzw28 *wRw[4] = {nullptr, nullptr, nullptr, nullptr}; // wR[i] in W-form (five pre-shifted rows per entry): the exchange product then has five columns, not nine
-    lzw28 *wRw_scaled = nullptr;
-    int4 *mf_tab = nullptr;                            // matrix-core passes (ntt_mfma.h): the 4 KB operand table of omega_16
+#ifdef GS_NTT_EXPERIMENTS
+    int4 *mf_tab = nullptr;                            // matrix-core passes (tools/ntt_mfma.h): the 4 KB operand table of omega_16
     fe *mf_wR_scaled = nullptr;                        // omega_256^e / n
     int mf_offs[16];
     fe mf_bias0;
+#endif
 #endif
 };
 
@@ -122,7 +121,6 @@ struct LzPassArgs {
     int weak;       // not the last pass: store any representative below 2^128 (lz_pack_weak), the next pass unpacks it
     const fe *tw_lo, *tw_hi, *twp;
     const lz8 *wR;
-    const lzw28 *wRw;  // the same table in W-form, or null (GSTARK_NTT_WEXCH=0)
     const lzw *wtab;   // W-forms: [0..6] omega_16^1..7, [7] 1/n.  Read with scalar loads right before each use (see LZ_FENCE)
 };
 
@@ -153,18 +151,6 @@ __device__ __forceinline__ lzw lz_load_w(const lzw *p) {
     return W;
 }
 
-__device__ __forceinline__ lzw lz_load_w28(const lzw28 *__restrict__ p) {
-    const int4 *q = reinterpret_cast<const int4 *>(p);
-    int32_t t[28];
-#pragma unroll
-    for (int k = 0; k < 7; k++) { const int4 a = q[k]; t[4 * k] = a.x; t[4 * k + 1] = a.y; t[4 * k + 2] = a.z; t[4 * k + 3] = a.w; }
-    lzw W;
-#pragma unroll
-    for (int r = 0; r < 5; r++)
-#pragma unroll
-        for (int l = 0; l < 5; l++) W.w[r][l] = t[5 * r + l];
-    return W;
-}
 __device__ __forceinline__ lz lz_load8(const lz8 *__restrict__ p) {
     const int4 a = *reinterpret_cast<const int4 *>(p);
     lz r;
@@ -581,24 +567,6 @@ __global__ void k_build_lz_table(const fe *__restrict__ src, lz8 *__restrict__ d
         dst[i] = o;
     }
 }
-__global__ void k_build_lzw_table(const fe *__restrict__ src, lzw28 *__restrict__ dst, uint64_t count, fe mult, int use_mult) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
-        fe x = src[i];
-        if (use_mult) x = fe_mul(x, mult);
-        lzw W;
-        lz_wform(x, W);
-        lzw28 o;
-        for (int r = 0; r < 5; r++) {
-            int32_t u[5];
-            for (int l = 0; l < 5; l++) u[l] = W.w[r][l];
-            for (int l = 0; l < 4; l++)      // signed digits, as in k_build_lz_table: the exchange inputs are sums of up to 9 NN values
-                if (u[l] >= (1 << 25)) { u[l] -= 1 << 26; u[l + 1] += 1; }
-            for (int l = 0; l < 5; l++) o.w[5 * r + l] = u[l];
-        }
-        o.w[25] = o.w[26] = o.w[27] = 0;
-        dst[i] = o;
-    }
-}
 #endif  // GS_NTT_LAZY
 
 template <int LB>
@@ -736,10 +704,17 @@ __global__ void k_build_pass_twiddles(fe *__restrict__ out, uint64_t Ns, uint64_
     }
 }
 
-static uint64_t max_pass_twiddle_entries() {  // 16 MiB per table by default; larger passes keep the running product
+// inter-pass twiddle tables of up to 2^20 entries (16 MiB, L2 resident); larger passes keep the running product.  A [k][jq] table of
+// 2^24 entries for the third pass of a 2^24-point transform was measured (round 3): 0.697 ms against 0.670 ms per transform — the
+// table read costs what the saved chain products bring (profiles/r03_a_ntt_time_twiddle_log24.txt)
+static uint64_t max_pass_twiddle_entries() {
+#ifdef GS_NTT_EXPERIMENTS
     static uint64_t v = 0;
     if (!v) { const char *e = getenv("GSTARK_NTT_TWIDDLE_LOG"); v = 1ull << (e ? atoi(e) : 20); }
     return v;
+#else
+    return 1ull << 20;
+#endif
 }
 
 static std::string plan_key(const fe &omega, uint64_t n) {
@@ -819,16 +794,11 @@ static int plan_get(gs_ctx *c, const fe &omega, uint64_t n, NttPlan **out) {
                 }
 #ifdef GS_NTT_LAZY
                 for (int k = 0; k < i; k++)
-                    if (p->L[k] == p->L[i]) { p->wRz[i] = p->wRz[k]; p->wRw[i] = p->wRw[k]; }
+                    if (p->L[k] == p->L[i]) p->wRz[i] = p->wRz[k];
                 if (!p->wRz[i]) {
                     if ((rc = gs_alloc(c, R * sizeof(lz8), &q))) { delete p; return rc; }
                     p->wRz[i] = (lz8 *)q;
                     hipLaunchKernelGGL(k_build_lz_table, dim3(gs_grid(R)), dim3(256), 0, c->stream, p->wR[i], p->wRz[i], R, fe_one(), 0);
-#ifdef GS_NTT_WEXCH_BUILD
-                    if ((rc = gs_alloc(c, R * sizeof(lzw28), &q))) { delete p; return rc; }
-                    p->wRw[i] = (lzw28 *)q;
-                    hipLaunchKernelGGL(k_build_lzw_table, dim3(gs_grid(R)), dim3(256), 0, c->stream, p->wR[i], p->wRw[i], R, fe_one(), 0);
-#endif
                 }
 #endif
             }
@@ -923,7 +893,11 @@ static void launch_pass_wave(gs_ctx *c, const fe *in, fe *out, const LzPassArgs 
     } else if (a.twp) hipLaunchKernelGGL((k_ntt_wave<LB, 1>), dim3((unsigned)tiles, rows), dim3(64), 0, c->stream, in, out, a);
     else hipLaunchKernelGGL((k_ntt_wave<LB, 2>), dim3((unsigned)tiles, rows), dim3(64), 0, c->stream, in, out, a);
 }
-#include "ntt_mfma.h"
+// ---- A/B variants measured in rounds 1-2 and NOT adopted: compiled only into the experiments library
+// (tools/build_experiments.sh -> tools/ab/libgstark_hip_exp.so, -DGS_NTT_EXPERIMENTS), where environment switches select them
+// per call.  The product library contains one kernel family per field flavour and reads no environment variable here.
+#ifdef GS_NTT_EXPERIMENTS
+#include "../../tools/ntt_mfma.h"
 __global__ void k_mf_scale_table(const fe *__restrict__ in, fe *__restrict__ out, fe k) { out[threadIdx.x] = fe_mul(in[threadIdx.x], k); }
 static void launch_pass_mfma(gs_ctx *c, const fe *in, fe *out, const MfPassArgs &a, uint32_t rows) {
     const uint64_t tiles = (a.n >> 8) / MF_COLS;
@@ -949,18 +923,15 @@ static bool ntt_wave_enabled() {   // GSTARK_NTT_WAVE=0 keeps the 128-thread wor
     return !(e && e[0] == '0');
 }
 
-static bool ntt_wexch_enabled() {   // build with -DGS_NTT_WEXCH_BUILD: k_ntt_wave takes its exchange twiddles from the W-form table
-#ifdef GS_NTT_WEXCH_BUILD
-    return true;
-#else
-    return false;
-#endif
-}
-
 static bool ntt_lazy_enabled() {   // GSTARK_NTT_LAZY=0 keeps the canonical-limb kernel (A/B measurements)
     const char *e = getenv("GSTARK_NTT_LAZY");   // read per call: tools/ntt_ab.py flips it inside one process
     return !(e && e[0] == '0');
 }
+#else
+static constexpr bool ntt_mfma_enabled() { return false; }
+static constexpr bool ntt_wave_enabled() { return true; }
+static constexpr bool ntt_lazy_enabled() { return true; }
+#endif  // GS_NTT_EXPERIMENTS
 #endif
 
 // rows transforms of size n; row r reads in[r*in_stride .. +in_len) (zero-extended) and writes out[r*n .. +n)
@@ -1021,8 +992,6 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
             a.tw_hi = p->tw_hi;
             a.twp = p->twp[i];
             a.wR = p->wRz[i];
-            const bool wexch = ntt_wexch_enabled();
-            a.wRw = wexch ? p->wRw[i] : nullptr;
             a.scale = 0;
             a.exq0 = 0;
             a.weak = last ? 0 : 1;
@@ -1035,15 +1004,6 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
                         hipLaunchKernelGGL(k_build_lz_table, dim3(gs_grid(R)), dim3(256), 0, c->stream, p->wR[i], p->wRz_scaled, R, ninv, 1);
                     }
                     a.wR = p->wRz_scaled;
-                    if (wexch) {
-                        if (!p->wRw_scaled) {
-                            void *q;
-                            if ((rc = gs_alloc(c, R * sizeof(lzw28), &q))) { if (tmp) gs_tmp_free(c, tmp); return rc; }
-                            p->wRw_scaled = (lzw28 *)q;
-                            hipLaunchKernelGGL(k_build_lzw_table, dim3(gs_grid(R)), dim3(256), 0, c->stream, p->wR[i], p->wRw_scaled, R, ninv, 1);
-                        }
-                        a.wRw = p->wRw_scaled;
-                    }
                     a.exq0 = 1;
                 } else {
                     a.scale = 1;
@@ -1051,6 +1011,7 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
             }
             a.wtab = p->wtab;
             const bool wave = ntt_wave_enabled() && n >= 1024 && (logNs > 0 || LB == 4);
+#ifdef GS_NTT_EXPERIMENTS
             if (LB == 4 && n >= (1ull << 16) && ntt_mfma_enabled()) {
                 if (!p->mf_tab) {
                     int8_t host[4096];
@@ -1079,7 +1040,9 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
                     m.wR = p->mf_wR_scaled;
                 }
                 launch_pass_mfma(c, src, dst, m, rows);
-            } else if (wave) {
+            } else
+#endif
+            if (wave) {
                 a.logWj = 6 - LB;
                 switch (LB) {
                     case 0: launch_pass_wave<0>(c, src, dst, a, rows); break;

@@ -418,38 +418,6 @@ def test_ntt_bytes_equal_oracle_at_headline_sizes(hip_backend, oracle_omp_backen
         assert outs[0] == outs[1], (logn, kind, plen)
 
 
-@pytest.mark.parametrize('logn', [16, 24])
-def test_ntt_matrix_core_passes_bytes(hip_backend, oracle_backend, logn, monkeypatch):
-    """The opt-in radix-256 passes whose butterfly networks run on the matrix cores (GSTARK_NTT_MFMA=1, csrc/ntt_mfma.h: the 16-point
-    DFT as an i8 digit matrix, v_mfma_i32_32x32x32_i8): every output byte equals the default kernels' — forward, several rows,
-    zero-extended (ragged, pruned low-degree extension and just past it) and inverse — and, at 2^16, the oracle's."""
-    n = 1 << logn
-    fh = PrimeField(backend=hip_backend)
-    w = fh.getRootOfUnity(n)
-    wb = w.to_bytes(16, 'little')
-    rows = 3 if logn <= 16 else 1
-    src = _dense_input(fh, n * rows, 0x9abcdef0123456789abcdef + logn)
-
-    def run(kind, plen):
-        out = fh.newVector(n * rows)
-        if kind == 'fwd':
-            hip_backend.call('gs_eval_polys_at_roots', C.c_void_p(src.ptr), rows, plen, wb, n, C.c_void_p(out.ptr))
-        else:
-            hip_backend.call('gs_interpolate_roots', C.c_void_p(src.ptr), rows, wb, n, C.c_void_p(out.ptr))
-        return out.toBuffer()
-    for kind, plen in (('fwd', n), ('fwd', n // 2 + 3), ('fwd', n // 16), ('fwd', n // 16 - 5), ('fwd', n // 16 + 7), ('inv', n)):
-        monkeypatch.setenv('GSTARK_NTT_MFMA', '1')
-        got = run(kind, plen)
-        monkeypatch.setenv('GSTARK_NTT_MFMA', '0')
-        assert got == run(kind, plen), (logn, kind, plen)
-        if logn == 16 and kind == 'fwd' and plen == n:
-            fo = PrimeField(backend=oracle_backend)
-            vo, oo = fo.newVector(n * rows), fo.newVector(n * rows)
-            oracle_backend.upload(vo.ptr, src.toBuffer())
-            oracle_backend.call('gs_eval_polys_at_roots', C.c_void_p(vo.ptr), rows, plen, wb, n, C.c_void_p(oo.ptr))
-            assert got == oo.toBuffer()
-
-
 def test_mimc_composition_bytes_equal_oracle_at_2p24(hip_backend, oracle_omp_backend):
     """gs_mimc_composition over the whole evaluation domain of the headline configuration (T = 2^20, E = 16), LinearCombination
     folded in: every byte against the oracle's term-by-term evaluation."""

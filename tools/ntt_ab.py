@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from genstark_amd._abi import Backend
 from genstark_amd.field import PrimeField
 
-be = Backend(); f = PrimeField(backend=be)
+EXP = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ab', 'libgstark_hip_exp.so')   # tools/build_experiments.sh: the build with the A/B switches
+be = Backend(lib_path=EXP); f = PrimeField(backend=be)
 max_log = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 
 

@@ -1,4 +1,4 @@
-"""A/B of the matrix-core radix-256 passes (GSTARK_NTT_MFMA=1, csrc/ntt_mfma.h) against the default kernels on the GPU: bytes for
+"""A/B of the matrix-core radix-256 passes (GSTARK_NTT_MFMA=1, tools/ntt_mfma.h) against the default kernels on the GPU: bytes for
 2^16 and 2^24 (the sizes whose plans are made of radix-256 passes only) — forward, inverse, zero-extended, low-degree extension,
 several rows — then timings.   usage: python tools/ntt_mfma_ab.py [24]"""
 import ctypes as C, os, sys, time
@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from genstark_amd._abi import Backend
 from genstark_amd.field import PrimeField
 
-be = Backend(); f = PrimeField(backend=be)
+EXP = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ab', 'libgstark_hip_exp.so')   # tools/build_experiments.sh: the build with the A/B switches
+be = Backend(lib_path=EXP); f = PrimeField(backend=be)
 sizes = [16, 24] if (len(sys.argv) < 2 or int(sys.argv[1]) >= 24) else [16]
 
 

@@ -1,5 +1,6 @@
 """tools/pmc_traffic.py — HBM bytes per launch of the NTT pass kernels from the PMC counters, as MI355X_MICROARCH.md's HBM section
-prescribes: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes (they do not fit one), kernel-trace only beside them;
+prescribes: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes (they do not fit one), kernel-trace only beside them (a third pass
+reads SQ_INSTS_VALU: the wave-level VALU instruction count bench.py's second roof is checked against);
 on gfx950 FETCH_SIZE counts 128-byte requests of a wide coalesced streaming read at 64 bytes, so it is doubled; WRITE_SIZE as
 reported.  Both are in KiB.  Prints one JSON object; bench.py runs this on rank 0 at N = 1.
 usage: python tools/pmc_traffic.py [log2 n = 24] [outdir]"""
@@ -20,7 +21,7 @@ out = {'n': 1 << logn, 'commands': []}
 per_kernel = {}
 work = tempfile.mkdtemp(prefix='pmc_', dir='/tmp')
 env = dict(os.environ, TMPDIR='/tmp')
-for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+for counter in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_VALU'):
     d = os.path.join(work, counter)
     cmd = [rocprof, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'p', '--',
            sys.executable, os.path.join(ROOT, 'tools', 'ntt_only.py'), str(logn)]
@@ -41,8 +42,9 @@ kernels = {}
 for name, c in per_kernel.items():
     f = sum(c.get('FETCH_SIZE', [0])) / max(1, len(c.get('FETCH_SIZE', [])))
     w = sum(c.get('WRITE_SIZE', [0])) / max(1, len(c.get('WRITE_SIZE', [])))
+    v = c.get('SQ_INSTS_VALU', [])
     kernels[name] = {'launches_sampled': len(c.get('FETCH_SIZE', [])), 'FETCH_SIZE_kib_avg': f, 'WRITE_SIZE_kib_avg': w,
-                     'hbm_bytes_per_launch': (2 * f + w) * 1024}
+                     'hbm_bytes_per_launch': (2 * f + w) * 1024, 'SQ_INSTS_VALU_avg': (sum(v) / len(v)) if v else None}
 out['kernels'] = kernels
 out['correction'] = 'bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes)'
 if kernels:

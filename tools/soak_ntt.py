@@ -9,7 +9,7 @@ from genstark_amd.field import PrimeField
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
-hip = Backend(device=0)
+hip = Backend(device=0, lib_path=os.path.join(root, 'tools', 'ab', 'libgstark_hip_exp.so'))   # tools/build_experiments.sh: the build with the A/B switches
 orc = Backend(lib_path=os.path.join(root, 'oracle', 'liboracle.so'), allow_test_double=True)
 fh, fo = PrimeField(backend=hip), PrimeField(backend=orc)
 bad, t0 = 0, time.time()
