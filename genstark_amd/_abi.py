@@ -82,6 +82,7 @@ _SIGNATURES = {
     'gs_interpolate_quartic_domain': (_int, [_vp, _bytes, _u64, _u64, _vp, _u64, _vp]),
     'gs_fri_fold': (_int, [_vp, _bytes, _u64, _u64, _vp, _u64, _bytes, _vp]),
     'gs_fri_fold_seeded': (_int, [_vp, _bytes, _u64, _u64, _vp, _u64, _vp, _vp]),
+    'gs_fri_fold_seeded_scaled': (_int, [_vp, _bytes, _u64, _u64, _vp, _u64, _vp, _bytes, _vp]),
     'gs_eval_quartic_batch': (_int, [_vp, _vp, _u64, _bytes, _vp]),
     'gs_hash_digest': (_int, [_vp, _int, _bytes, _u64, _vp]),
     'gs_hash_merge_rows': (_int, [_vp, _int, _pvp, _u32, _u64, _vp]),
@@ -150,8 +151,8 @@ class Backend:
         self.stats = {}      # see call()
 
     def jit(self, enable=True):
-        """Compile AIR programs (gs_air_jit) instead of interpreting them: for a prover that serves many proofs of one AIR."""
-        self.call('gs_air_jit', 1 if enable else 0)
+        """AIR programs compiled on first use (True), always interpreted (False) or compiled when already built ('auto', the default of a new context): gs_air_jit."""
+        self.call('gs_air_jit', 2 if enable == 'auto' else (1 if enable else 0))
         return self
 
     @property

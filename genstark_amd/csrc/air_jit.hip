@@ -1,4 +1,6 @@
-// air_jit.hip — AIR programs compiled instead of interpreted (opt-in: gs_air_jit(ctx, 1) or GSTARK_AIR_JIT=1).
+// air_jit.hip — AIR programs compiled instead of interpreted.  Default (auto): a program runs compiled whenever its code object already
+// exists (this process or the on-disk cache) and is built in the background otherwise; gs_air_jit(ctx, 1) / GSTARK_AIR_JIT=1 compile on
+// first use, gs_air_jit(ctx, 0) / GSTARK_AIR_JIT=0 always interpret.
 //
 // The reference's air-assembly GENERATES code for an AIR's transition function and constraint evaluator when a module is
 // instantiated ("generated JS over BigInt").  The register machine of air_vm.hip is the portable form of the same
@@ -11,6 +13,10 @@
 // Same arithmetic (the field header the library itself is built from is embedded in the source), same values; any failure to
 // compile falls back to the interpreter.  gs_air_jit_check generates + compiles without a device (CPU test tier).
 #include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <thread>
 
 #include <stdlib.h>
 
@@ -19,6 +25,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "host_sha256.h"
 
 enum { J_LOADC = 0, J_LOADR = 1, J_LOADN = 2, J_LOADS = 3, J_ADDV = 4, J_SUBV = 5, J_MULV = 6, J_POW = 7, J_POWC = 8, J_OUT = 9 };
 
@@ -39,6 +46,8 @@ struct JitKernel {
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
     bool failed = false;
+    bool compiling = false;          // a background thread is building the code object (auto mode)
+    std::vector<char> code;          // built (or read from the disk cache) but not loaded yet: the next launch loads it
 };
 static std::mutex g_jit_mutex;
 static std::map<std::string, JitKernel> g_jit_cache;   // per process: the lanes of a pool share the compiled programs
@@ -515,19 +524,109 @@ static bool jit_compile(const std::string &source, const char *entry, std::vecto
     return true;
 }
 
+// ---- code objects on disk: <dir>/<sha256 of the generated source>.hsaco.  A compiled program outlives the process that built it, so
+// "compile when an AIR is instantiated" costs its seconds once per machine, and the default mode (auto) can use compiled programs
+// whenever they already exist without ever making a proof wait for the compiler.
+static std::string jit_cache_path(const std::string &source, const char *entry) {
+    const char *dir = getenv("GSTARK_JIT_CACHE_DIR");
+    std::string base;
+    if (dir && dir[0]) base = dir;
+    else {
+        const char *home = getenv("HOME");
+        base = std::string(home && home[0] ? home : "/tmp") + "/.cache/gstark_jit";
+    }
+    if (base == "0" || base == "off") return "";
+    std::string acc;
+    for (size_t i = 1; i <= base.size(); i++)          // mkdir -p
+        if (i == base.size() || base[i] == '/') { acc = base.substr(0, i); mkdir(acc.c_str(), 0755); }
+    std::string keyed = std::string(entry) + "|gfx950|v1|" + source;
+    uint8_t d[32];
+    host_sha256((const uint8_t *)keyed.data(), keyed.size(), d);
+    char hex[65];
+    for (int i = 0; i < 32; i++) snprintf(hex + 2 * i, 3, "%02x", d[i]);
+    return base + "/" + hex + ".hsaco";
+}
+static bool jit_disk_read(const std::string &path, std::vector<char> &code) {
+    if (path.empty()) return false;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    bool ok = n > 0;
+    if (ok) { code.resize((size_t)n); ok = fread(code.data(), 1, (size_t)n, f) == (size_t)n; }
+    fclose(f);
+    return ok;
+}
+static void jit_disk_write(const std::string &path, const std::vector<char> &code) {
+    if (path.empty() || code.empty()) return;
+    char tmp[32];
+    snprintf(tmp, sizeof tmp, ".%d.tmp", (int)getpid());
+    const std::string t = path + tmp;
+    FILE *f = fopen(t.c_str(), "wb");
+    if (!f) return;
+    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+    fclose(f);
+    if (ok) rename(t.c_str(), path.c_str()); else remove(t.c_str());
+}
+static bool jit_load(JitKernel &k, const char *entry) {
+    if (hipModuleLoadData(&k.module, k.code.data()) != hipSuccess) return false;
+    if (hipModuleGetFunction(&k.fn, k.module, entry) != hipSuccess) return false;
+    std::vector<char>().swap(k.code);
+    return true;
+}
+
+// mode 1 (gs_air_jit(ctx, 1)): the kernel, compiling it now if nobody has yet.  mode 2 (auto, the default): the kernel if this process
+// or the disk cache already holds it; otherwise null — the caller interprets this time — and ONE background thread builds it for the
+// launches (and processes) to come.
 static JitKernel *jit_get(gs_ctx *c, const std::string &source, const char *entry) {
-    std::lock_guard<std::mutex> lock(g_jit_mutex);
+    std::unique_lock<std::mutex> lock(g_jit_mutex);
     auto it = g_jit_cache.find(source);
-    if (it != g_jit_cache.end()) return it->second.failed ? nullptr : &it->second;
+    if (it != g_jit_cache.end()) {
+        JitKernel &k = it->second;
+        if (k.fn) return &k;
+        if (k.failed) return nullptr;
+        if (!k.code.empty()) { if (jit_load(k, entry)) return &k; k.failed = true; return nullptr; }
+        if (k.compiling && c->air_jit != 1) return nullptr;           // still being built in the background: interpret
+        if (k.compiling) {                                            // mode on: wait for the builder instead of compiling twice
+            while (k.compiling) { lock.unlock(); usleep(2000); lock.lock(); }
+            if (k.failed || k.code.empty()) return nullptr;
+            if (jit_load(k, entry)) return &k;
+            k.failed = true;
+            return nullptr;
+        }
+    }
     JitKernel &k = g_jit_cache[source];
-    k.failed = true;
-    std::vector<char> code;
-    std::string log;
-    if (!jit_compile(source, entry, code, log)) { gs_fail(c, GS_ERR_DEVICE, "air jit: %.400s", log.c_str()); return nullptr; }
-    if (hipModuleLoadData(&k.module, code.data()) != hipSuccess) return nullptr;
-    if (hipModuleGetFunction(&k.fn, k.module, entry) != hipSuccess) return nullptr;
-    k.failed = false;
-    return &k;
+    const std::string path = jit_cache_path(source, entry);
+    if (jit_disk_read(path, k.code)) {
+        if (jit_load(k, entry)) return &k;
+        k.failed = false;                                             // a stale / truncated file: fall through and rebuild
+        std::vector<char>().swap(k.code);
+    }
+    if (c->air_jit == 1) {
+        k.failed = true;
+        std::string log;
+        if (!jit_compile(source, entry, k.code, log)) { gs_fail(c, GS_ERR_DEVICE, "air jit: %.400s", log.c_str()); return nullptr; }
+        jit_disk_write(path, k.code);
+        if (!jit_load(k, entry)) return nullptr;
+        k.failed = false;
+        return &k;
+    }
+    k.compiling = true;
+    std::thread([source, path, entry]() {
+        static std::mutex one_at_a_time;          // hiprtc builds one program at a time (two concurrent builds: the second came back empty)
+        std::vector<char> code;
+        std::string log;
+        bool ok;
+        { std::lock_guard<std::mutex> b(one_at_a_time); ok = jit_compile(source, entry, code, log); }
+        if (!ok && getenv("GSTARK_AIR_JIT_VERBOSE")) fprintf(stderr, "[gstark] background build of %s failed: %.600s\n", entry, log.c_str());
+        if (ok) jit_disk_write(path, code);
+        std::lock_guard<std::mutex> g(g_jit_mutex);
+        JitKernel &kk = g_jit_cache[source];
+        if (ok) kk.code.swap(code); else kk.failed = true;
+        kk.compiling = false;
+    }).detach();
+    return nullptr;
 }
 
 // ---- trace segments --------------------------------------------------------------------------------------------------------------

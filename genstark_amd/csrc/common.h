@@ -58,7 +58,7 @@ struct gs_ctx {
     void *fri_x = nullptr;        // the evaluation point gs_fri_fold_seeded derives on the device
     uint64_t jit_launches = 0;    // compiled-program launches so far (gs_air_jit_launches)
     uint64_t host_trace_segments = GS_HOST_TRACE_MAX_SEGMENTS;   // traces of at most this many segments run on a host core (GSTARK_HOST_TRACE_SEGMENTS; air_vm.hip)
-    bool air_jit = false;         // AIR programs compiled with hiprtc instead of interpreted (gs_air_jit / GSTARK_AIR_JIT=1)
+    int air_jit = 2;              // AIR programs: 0 interpreted, 1 compiled on first use (hiprtc), 2 auto = compiled when the code object already exists (gs_air_jit / GSTARK_AIR_JIT)
     // deferred read-backs (gs_defer_begin / gs_defer_end): gathers only record the device addresses of the 16-byte words they want;
     // gs_defer_end fetches all of them with ONE kernel and one synchronisation
     struct DeferredCopy { void *dst; uint64_t first_word, bytes; };

@@ -49,8 +49,8 @@ int gs_ctx_create(int device, void *hip_stream, gs_ctx **out) {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GS_ERR_DEVICE; }
         c->own_stream = true;
     }
-    const char *jit = getenv("GSTARK_AIR_JIT");
-    c->air_jit = jit && jit[0] && jit[0] != '0';
+    const char *jit = getenv("GSTARK_AIR_JIT");     // 0: interpret, 1: compile on first use, unset / "auto": compiled when already built (air_jit.hip)
+    c->air_jit = !jit || !jit[0] || jit[0] == 'a' ? 2 : (jit[0] != '0' ? 1 : 0);
     c->host_trace_segments = GS_HOST_TRACE_MAX_SEGMENTS;
     if (const char *hs = getenv("GSTARK_HOST_TRACE_SEGMENTS")) c->host_trace_segments = strtoull(hs, nullptr, 10);
     *out = c;
@@ -59,7 +59,7 @@ int gs_ctx_create(int device, void *hip_stream, gs_ctx **out) {
 
 int gs_air_jit(gs_ctx *c, int enable) {
     if (!c) return GS_ERR_ARG;
-    c->air_jit = enable != 0;
+    c->air_jit = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     return GS_OK;
 }
 uint64_t gs_air_jit_launches(const gs_ctx *c) { return c ? c->jit_launches : 0; }

@@ -860,11 +860,10 @@ static void launch_pass(gs_ctx *c, const fe *in, fe *out, const PassArgs &a, uin
     const uint64_t tiles = (a.n / R) / Wj;
     const bool need_lds = (RB > 1) || (a.logNs == 0);
     const size_t lds = need_lds ? (size_t)Wj * (R + 1) * GS_ELT : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass<LB>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_EW == 1 ? 96 * 1024 : 160 * 1024);
-        attr_set = true;
-    }
+    // the attribute is per device and the library may serve several contexts / devices from several threads: no process-wide
+    // "already set" flag; only tiles above the 64 KiB default need it (the multi-limb flavours)
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass<LB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(k_ntt_pass<LB>, dim3((unsigned)tiles, rows), dim3(RB * Wj), lds, c->stream, in, out, a);
 }
 
@@ -901,13 +900,7 @@ static void launch_pass_wave(gs_ctx *c, const fe *in, fe *out, const LzPassArgs 
 __global__ void k_mf_scale_table(const fe *__restrict__ in, fe *__restrict__ out, fe k) { out[threadIdx.x] = fe_mul(in[threadIdx.x], k); }
 static void launch_pass_mfma(gs_ctx *c, const fe *in, fe *out, const MfPassArgs &a, uint32_t rows) {
     const uint64_t tiles = (a.n >> 8) / MF_COLS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_mfma<0>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_mfma<1>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_mfma<2>), hipFuncAttributeMaxDynamicSharedMemorySize, MF_LDS_BYTES);
-        attr_set = true;
-    }
+    static_assert(MF_LDS_BYTES <= 64 * 1024, "below the default dynamic LDS limit: no attribute needed");
     const dim3 grid((unsigned)(tiles / MF_WAVES), rows), block(64 * MF_WAVES);
     if (a.logNs == 0) hipLaunchKernelGGL((k_ntt_mfma<0>), grid, block, MF_LDS_BYTES, c->stream, in, out, a);
     else if (a.twp) hipLaunchKernelGGL((k_ntt_mfma<1>), grid, block, MF_LDS_BYTES, c->stream, in, out, a);

@@ -365,7 +365,7 @@ __global__ void k_quartic_eval(const fe *__restrict__ polys, uint64_t rows, fe x
 // (u0 + u1 t + u2 t^2 + u3 t^3) / 4 with u = the inverse 4-point DFT above and t = X / x_r.
 __global__ void k_fri_fold(const fe *__restrict__ column, uint64_t rows, uint64_t step, uint64_t n, const fe *__restrict__ tw_lo,
                            const fe *__restrict__ tw_hi, int log_lo, int logn, fe zeta_inv, fe inv4, fe X, const fe *__restrict__ Xdev, fe *__restrict__ out) {
-    if (Xdev) X = *Xdev;                               // the evaluation point was derived on the device (gs_fri_fold_seeded)
+    if (Xdev) X = fe_mul(*Xdev, X);                    // the evaluation point was derived on the device (gs_fri_fold_seeded): X holds its scale
     for (uint64_t r = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * blockDim.x) {
         fe y0 = column[r], y1 = column[r + rows], y2 = column[r + 2 * rows], y3 = column[r + 3 * rows];
         fe s0 = fe_add(y0, y2), s1 = fe_sub(y0, y2), s2 = fe_add(y1, y3);
@@ -633,15 +633,23 @@ int gs_fri_fold(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const
     return fri_fold_launch(c, omega, n, step, column, m, fe_from_bytes(x), nullptr, out);
 }
 extern "C++" int gs_prng_point_dev(gs_ctx *c, const void *seed32_dev, fe *out_dev);   // hash.hip
+int gs_fri_fold_seeded_scaled(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const void *seed32_dev,
+                              const gs_elt *scale, void *out);
 int gs_fri_fold_seeded(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const void *seed32_dev, void *out) {
-    if (!c || !omega || !column || !seed32_dev || !out) return GS_ERR_ARG;
+    uint8_t one[sizeof(fe)];
+    fe_to_bytes(one, fe_one());
+    return gs_fri_fold_seeded_scaled(c, omega, n, step, column, m, seed32_dev, one, out);
+}
+int gs_fri_fold_seeded_scaled(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const void *seed32_dev,
+                              const gs_elt *scale, void *out) {
+    if (!c || !omega || !column || !seed32_dev || !scale || !out) return GS_ERR_ARG;
     if (!c->fri_x) {   // 16 bytes that live as long as the context: every use is ordered on the context's stream
         int rc = gs_alloc(c, GS_ELT, &c->fri_x);
         if (rc) return rc;
     }
     int rc = gs_prng_point_dev(c, seed32_dev, (fe *)c->fri_x);
     if (rc) return rc;
-    return fri_fold_launch(c, omega, n, step, column, m, fe_zero(), (const fe *)c->fri_x, out);
+    return fri_fold_launch(c, omega, n, step, column, m, fe_from_bytes(scale), (const fe *)c->fri_x, out);
 }
 
 int gs_eval_quartic_batch(gs_ctx *c, const void *polys, uint64_t rows, const gs_elt *x, void *out) {

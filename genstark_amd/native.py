@@ -210,8 +210,9 @@ class NativeProver:
             ja.static_values, ja.static_periods, ja.nstatic = svals, periods, len(plist)
             ja.static_tables, ja.static_lens = tables.ptr, lens
             # thousands of values per proof for a segmented AIR: no per-value function call, no reduction of values already in range
-            p_, tb = f.modulus, int.to_bytes
-            first = b''.join([tb(v, 16, 'little') if 0 <= v < p_ else tb(v % p_, 16, 'little') for row in rows for v in row])
+            # (exact ints take the fast path; integer-likes such as numpy.int64 go through int())
+            p_, tb, es = f.modulus, int.to_bytes, f.elementSize
+            first = b''.join([tb(v, es, 'little') if type(v) is int and 0 <= v < p_ else tb(int(v) % p_, es, 'little') for row in rows for v in row])
             ja.first_rows = first
             ja.segments, ja.segment_len = (len(rows), air.segmentLength) if air.segmentLength else (0, 0)
             keep += [t_code, e_code, consts, svals, periods, lens, first]

@@ -4,7 +4,8 @@ from .errors import StarkError
 
 
 class Serializer:
-    def __init__(self, config, hashDigestSize):
+    def __init__(self, config, hashDigestSize, strict=False):
+        self.strict = strict          # True: parseProof also rejects bytes after the last field (the reference ignores them)
         self.fieldElementSize = config.field.elementSize
         self.tRegisterCount = config.traceRegisterCount
         self.sRegisterCount = config.secretInputCount
@@ -90,7 +91,7 @@ class Serializer:
                 shape.append(int.from_bytes(buffer[offset:offset + 4], 'little'))
                 offset += 4
             inputShapes.append(shape)
-        if offset != len(buffer):
+        if self.strict and offset != len(buffer):      # the reference's parseProof ignores trailing bytes (lib/Serializer.ts:81-144): opt-in only
             raise StarkError('malformed proof: bytes left over after the last field')
         return {'evRoot': evRoot, 'evProof': evProof,
                 'ldProof': {'lcRoot': lcRoot, 'lcProof': lcProof, 'components': components, 'remainder': remainder},

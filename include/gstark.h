@@ -189,6 +189,10 @@ int gs_fri_fold(gs_ctx *ctx, const gs_elt *omega, uint64_t n, uint64_t step, con
  * big-endian integer, mod p.  The host never needs the root to issue the next layer: a driver enqueues every FRI layer without a
  * round trip and reads all the roots back once. */
 int gs_fri_fold_seeded(gs_ctx *ctx, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const void *seed32_dev, void *out);
+/* ... with x = field.prng(seed) * scale: the fold on ONE RANK'S SHARE of a column that is spread over several GPUs sees the domain
+ * scaled by shift^-step (csrc/prover_dist.h), and asks for the same point in its own coordinates. */
+int gs_fri_fold_seeded_scaled(gs_ctx *ctx, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m,
+                              const void *seed32_dev, const gs_elt *scale, void *out);
 
 /* ---- hashing / Merkle (merkle package) --------------------------------------------------------- */
 /* Hash.digest(Buffer) on host bytes (verifier side; lib/utils/index.ts:37) — runs on the device
@@ -297,9 +301,11 @@ int gs_air_trace_segments(gs_ctx *ctx, const uint32_t *code_host, uint32_t ninst
                           const uint8_t *first_rows_host /* segments x registers */, uint64_t segments, uint64_t segment_len,
                           void *out /* registers x (segments*segment_len) */);
 /* AIR programs compiled instead of interpreted (the reference's air-assembly generates code for an AIR when it is instantiated):
- * with enable != 0, gs_air_trace_segments and gs_air_constraints turn their program into HIP source, compile it once per process
- * (hiprtc, a few seconds) and launch that; same values; the interpreter remains the fallback.  Off by default (a single proof does
- * not pay for the compilation); GSTARK_AIR_JIT=1 in the environment turns it on for every context. */
+ * gs_air_trace_segments and gs_air_constraints turn their program into HIP source, compile it with hiprtc (about a second per
+ * kernel) and launch that; same values; the interpreter remains the fallback.  Code objects are kept per process and on disk
+ * (GSTARK_JIT_CACHE_DIR, default ~/.cache/gstark_jit).  enable = 2 (the default of a new context, GSTARK_AIR_JIT unset or "auto"):
+ * compiled whenever the code object already exists, otherwise interpreted NOW and built in the background for later launches and
+ * processes; 1 (GSTARK_AIR_JIT=1): compile on first use; 0 (GSTARK_AIR_JIT=0): always interpret. */
 int gs_air_jit(gs_ctx *ctx, int enable);
 uint64_t gs_air_jit_launches(const gs_ctx *ctx);       /* how many launches ran compiled programs so far (0: everything was interpreted) */
 /* Compile-only check, no context and no device: GS_OK when the source generated for the program builds for gfx950 (kind 0: the

@@ -447,15 +447,23 @@ int gs_fri_fold(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const
     }
     return GS_OK;
 }
-int gs_fri_fold_seeded(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const void *seed32, void *out) {
-    /* x = prng(seed) = sha256(seed) as a big-endian integer, mod p (LowDegreeProver.ts:194), then the plain folding step */
+int gs_fri_fold_seeded_scaled(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const void *seed32,
+                              const gs_elt *scale, void *out) {
+    /* x = prng(seed) * scale, prng(seed) = sha256(seed) as a big-endian integer, mod p (LowDegreeProver.ts:194), then the plain folding step */
     uint8_t d[32], xb[64];
     orc_sha256((const uint8_t *)seed32, 32, d);
     fe x = 0;
     for (int i = 0; i < 32; i++) x = fe_add(fe_mul(x, (fe)256), (fe)d[i]);
+    x = fe_mul(x, fe_load(scale));
     memset(xb, 0, sizeof xb);
     fe_store(xb, x);
     return gs_fri_fold(c, omega, n, step, column, m, (const gs_elt *)xb, out);
+}
+int gs_fri_fold_seeded(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const void *seed32, void *out) {
+    uint8_t one[FE_BYTES];
+    memset(one, 0, sizeof one);
+    one[0] = 1;
+    return gs_fri_fold_seeded_scaled(c, omega, n, step, column, m, seed32, one, out);
 }
 int gs_eval_quartic_batch(gs_ctx *c, const void *polys, uint64_t rows, const gs_elt *x, void *out) {
     (void)c; fe xx = fe_load(x);

@@ -5,6 +5,14 @@ import sys
 
 import pytest
 
+# AIR programs: the library's default is "auto" (compiled when a code object already exists, built in the background otherwise), which
+# depends on what earlier processes left in the on-disk cache.  The tests pin the mode instead: interpreted unless a test asks for
+# compiled programs (Backend.jit(True) / .jit('auto')), code objects in a directory of their own.
+import os as _os
+import tempfile as _tempfile
+_os.environ.setdefault('GSTARK_AIR_JIT', '0')
+_os.environ.setdefault('GSTARK_JIT_CACHE_DIR', _os.path.join(_tempfile.gettempdir(), 'gstark_jit_tests'))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 

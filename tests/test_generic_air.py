@@ -3,6 +3,8 @@ exercised with the Rescue 4x128 hash AIR of examples/rescue/hash4x128.ts (4 regi
 static registers) and with MiMC re-expressed generically (must reproduce the dedicated MiMC kernels' proof bytes)."""
 import hashlib
 
+import os
+
 import pytest
 
 import genstark_amd as ga
@@ -291,6 +293,48 @@ def test_compiled_air_programs_equal_interpreted(hip_backend, kind, steps):
         assert data == check_segmented(hip_backend, kind, steps)
     finally:
         compiled.close()
+
+
+AUTO_MODE_SCRIPT = '''
+import glob, os, sys, time
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import test_generic_air as t
+from genstark_amd._abi import Backend
+plain = Backend(device=0).jit(False)
+want = t.check_segmented(plain, "poseidon", 1024)
+assert plain.jit_launches == 0
+auto = Backend(device=0)                         # the default of a new context: auto
+first = t.check_segmented(auto, "poseidon", 1024)
+assert first == want and auto.jit_launches == 0, "the first proof must not wait for the compiler (nothing was built yet)"
+deadline = time.time() + 150
+files = []
+while (auto.jit_launches < 2 or len(files) < 2) and time.time() < deadline:      # two programs: the trace kernel and the constraint evaluator
+    time.sleep(0.5)
+    assert t.check_segmented(auto, "poseidon", 1024) == want
+    files = glob.glob(os.path.join(os.environ["GSTARK_JIT_CACHE_DIR"], "*.hsaco"))
+assert auto.jit_launches >= 2, "the background build never delivered"
+assert len(files) >= 2, files
+print("AUTO OK", len(files))
+'''
+
+
+@pytest.mark.gpu
+def test_air_programs_auto_mode(hip_backend, tmp_path):
+    """The default mode of a context (gs_air_jit 2, "auto"), in a fresh process with an empty code-object cache: the first proof never
+    waits for the compiler — it is interpreted while ONE background thread builds the programs; later launches run compiled; the code
+    objects land in the disk cache; a second process finds them there and runs compiled from its first proof.  Same bytes throughout."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSTARK_JIT_CACHE_DIR=str(tmp_path))
+    env.pop('GSTARK_AIR_JIT', None)
+    r = subprocess.run([sys.executable, '-c', f'ROOT = {root!r}\n' + AUTO_MODE_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'AUTO OK' in r.stdout, r.stderr[-3000:]
+    second = ('import os, sys\nROOT = %r\nsys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)\n'
+              'import test_generic_air as t\nfrom genstark_amd._abi import Backend\nb = Backend(device=0)\n'
+              't.check_segmented(b, "poseidon", 1024)\nassert b.jit_launches >= 2, b.jit_launches\nprint("WARM OK")\n') % root
+    r = subprocess.run([sys.executable, '-c', second], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'WARM OK' in r.stdout, r.stderr[-3000:]
 
 
 @pytest.mark.gpu
