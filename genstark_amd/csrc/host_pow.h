@@ -7,6 +7,9 @@
 #define HF_CHAIN_MUL hf_mul
 #define HF_CHAIN_END(x) (x)
 #endif
+#ifndef HF_CHAIN_ADD
+#define HF_CHAIN_ADD hf_add
+#endif
 // x[k] <- x[k]^e for g <= 4 independent bases in lock step: a host core overlaps the products of the g chains (one chain alone is
 // bound by the latency of a product, ~2.5x its issue cost).
 static void host_pow_group(hfe *x, int g, hfe e) {
