@@ -195,6 +195,25 @@ __global__ __launch_bounds__(256) void k_merkle_subtree(HashPtrArgs va, uint32_t
     __syncthreads();
     uint64_t wl = wA >> 1;       // width of the layer being produced: it lives at nodes[wl .. 2 wl)
     for (uint32_t m = chunk / 2; m >= 1; m >>= 1, wl >>= 1) {
+        if constexpr (ALG == 1) {
+            // levels no wider than 64 nodes are bound by the latency of ONE compression per level: four lanes per node (hash_core.h:
+            // b2s_node_quad) cut it 2.3x.  Quads are wholly active or wholly idle (4 m threads), as the lane rotations need.
+            if (m <= 64) {
+                if (threadIdx.x < 4 * m) {
+                    const uint32_t i = threadIdx.x >> 2, l = threadIdx.x & 3u, s = m + i;
+                    uint32_t *w = reinterpret_cast<uint32_t *>(sh);
+                    uint32_t lo, hi;
+                    b2s_node_quad(w + 16 * s, (int)l, lo, hi);
+                    w[8 * s + l] = lo;                       // digest of node s at words 8 s .. 8 s + 7; its children's were at 16 s .. 16 s + 15
+                    w[8 * s + 4 + l] = hi;
+                    uint32_t *g = reinterpret_cast<uint32_t *>(nodes) + 8 * (wl + (uint64_t)blockIdx.x * m + i);
+                    g[l] = lo;
+                    g[4 + l] = hi;
+                }
+                __syncthreads();
+                continue;
+            }
+        }
         for (uint32_t i = threadIdx.x; i < m; i += 256) {
             const uint32_t s = m + i;
             const uint4 x0 = sh[4 * s], x1 = sh[4 * s + 1], x2 = sh[4 * s + 2], x3 = sh[4 * s + 3];

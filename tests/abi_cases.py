@@ -431,6 +431,55 @@ def check_merkle_commit(backend, rng, alg, logn, count):
     assert merkle_commit_bytes(backend, alg, cols, n, fused=False) == (leaves, nodes)
 
 
+def check_device_record_ops(backend, rng):
+    """gs_gather_words, gs_transpose_records, gs_fri_fold_seeded_scaled (the entries the multi-GPU driver adds) against their
+    definitions."""
+    import hashlib
+    be = backend
+    f = field_for(be)
+    # gs_gather_words: dst[t] = the 16-byte word at device address addrs[t]
+    n = 257
+    src_raw = bytes(rng.getrandbits(8) for _ in range(16 * n))
+    src, dst = be.alloc(16 * n), be.alloc(16 * 40)
+    be.upload(src, src_raw)
+    picks = [rng.randrange(n) for _ in range(40)]
+    addrs = be.alloc(8 * 40)
+    be.upload(addrs, b''.join((src + 16 * i).to_bytes(8, 'little') for i in picks))
+    be.call('gs_gather_words', C.c_void_p(addrs), 40, C.c_void_p(dst))
+    assert be.download(dst, 16 * 40) == b''.join(src_raw[16 * i:16 * i + 16] for i in picks)
+    be.call('gs_gather_words', C.c_void_p(addrs), 0, C.c_void_p(dst))                      # empty: no-op
+    # gs_transpose_records: dst[c * rows + r] = src[r * cols + c]
+    for rows, cols, rec in ((8, 5, 32), (2, 64, 16), (1, 7, 48), (4, 1, 32)):
+        raw = bytes(rng.getrandbits(8) for _ in range(rows * cols * rec))
+        a, b = be.alloc(len(raw)), be.alloc(len(raw))
+        be.upload(a, raw)
+        be.call('gs_transpose_records', C.c_void_p(a), rows, cols, rec, C.c_void_p(b))
+        want = b''.join(raw[(r * cols + c) * rec:(r * cols + c + 1) * rec] for c in range(cols) for r in range(rows))
+        assert be.download(b, len(raw)) == want, (rows, cols, rec)
+        be.free(a); be.free(b)
+    try:
+        be.call('gs_transpose_records', C.c_void_p(src), 2, 2, 24, C.c_void_p(dst))
+        raise AssertionError('a record size that is not a multiple of 16 must be refused')
+    except Exception as e:      # noqa: BLE001
+        assert 'multiple of 16' in str(e)
+    # gs_fri_fold_seeded_scaled: the fold at prng(seed) * scale
+    n, step = 256, 4
+    m = n // step
+    w = f.getRootOfUnity(n)
+    column = f.newVectorFrom(rand_elements(rng, m))
+    seed = bytes(rng.randrange(256) for _ in range(32))
+    scale = rng.randrange(1, P)
+    x = int.from_bytes(hashlib.sha256(seed).digest(), 'big') % P * scale % P
+    sv = f.newVector(2)
+    be.upload(sv.ptr, seed)
+    got, want2 = f.newVector(m // 4), f.newVector(m // 4)
+    be.call('gs_fri_fold_seeded_scaled', f.le(w), n, step, C.c_void_p(column.ptr), m, C.c_void_p(sv.ptr), f.le(scale), C.c_void_p(got.ptr))
+    be.call('gs_fri_fold', f.le(w), n, step, C.c_void_p(column.ptr), m, f.le(x), C.c_void_p(want2.ptr))
+    assert got.toBuffer() == want2.toBuffer()
+    for p_ in (src, dst, addrs):
+        be.free(p_)
+
+
 def check_mimc_air(backend, rng, steps):
     from genstark_amd.air import MimcAir, runMimc
     f = field_for(backend)

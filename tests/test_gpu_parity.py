@@ -130,6 +130,11 @@ def test_merkle_commit_rows_equals_oracle(hip_backend, oracle_omp_backend, alg, 
     assert cases.merkle_commit_bytes(hip_backend, alg, cols, n, fused=False)[1][32:] == want[1][32:]
 
 
+def test_device_record_ops(hip_backend, rng):
+    for _ in range(3):
+        cases.check_device_record_ops(hip_backend, rng)
+
+
 def test_mimc_air(hip_backend, rng):
     cases.check_mimc_air(hip_backend, rng, 128)
 

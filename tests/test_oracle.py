@@ -78,6 +78,10 @@ def test_merkle_commit_rows(oracle_backend, rng, alg, logn, count):
     cases.check_merkle_commit(oracle_backend, rng, alg, logn, count)
 
 
+def test_device_record_ops(oracle_backend, rng):
+    cases.check_device_record_ops(oracle_backend, rng)
+
+
 def test_mimc_air(oracle_backend, rng):
     cases.check_mimc_air(oracle_backend, rng, 128)
 
