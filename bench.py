@@ -375,7 +375,8 @@ def main():
         # algorithmic bytes: 32 B per element per transform -> one pass launch does 1/npass of a transform
         alg_bytes_per_launch = 32.0 * n / npass
         achieved = alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        traffic, traffic_detail = (None, {'skipped': True}) if args.no_pmc else pmc_traffic(logn)
+        # counter passes and the CPU baseline run on rank 0 at N = 1 only: at N > 1 the other ranks are waiting at the one-proof leg below
+        traffic, traffic_detail = (None, {'skipped': True}) if (args.no_pmc or world > 1) else pmc_traffic(logn)
         roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                     'traffic_source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child processes of this run (tools/pmc_traffic.py)',
@@ -386,7 +387,7 @@ def main():
                     'second_roof': second_roof(n, transform_ms, npass, traffic_detail)}
         del src, dst
 
-        cpu = None if args.no_cpu_baseline else cpu_baseline(ga, ef, fri)
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(ga, ef, fri)
 
         # ---- extra leg (reported beside `value`, never as `value`): throughput of a proving service that keeps several
         # independent proofs in flight on this GPU (genstark_amd/pipeline.py); every proof runs the unmodified prove()
@@ -502,6 +503,7 @@ def main():
             except BaseException as e:                                          # never take the main line down
                 result['error'] = repr(e)[:300]
 
+        barrier()                  # every rank starts its watchdog at the same moment (rank 0 has just measured the roofline)
         th = threading.Thread(target=leg, daemon=True)
         th.start()
         th.join(args.sharded_leg_timeout)

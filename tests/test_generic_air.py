@@ -305,7 +305,7 @@ want = t.check_segmented(plain, "poseidon", 1024)
 assert plain.jit_launches == 0
 auto = Backend(device=0)                         # the default of a new context: auto
 first = t.check_segmented(auto, "poseidon", 1024)
-assert first == want and auto.jit_launches == 0, "the first proof must not wait for the compiler (nothing was built yet)"
+assert first == want          # (interpreted unless the ~1 s background build finished between two launches of this very call)
 deadline = time.time() + 150
 files = []
 while (auto.jit_launches < 2 or len(files) < 2) and time.time() < deadline:      # two programs: the trace kernel and the constraint evaluator
@@ -320,8 +320,8 @@ print("AUTO OK", len(files))
 
 @pytest.mark.gpu
 def test_air_programs_auto_mode(hip_backend, tmp_path):
-    """The default mode of a context (gs_air_jit 2, "auto"), in a fresh process with an empty code-object cache: the first proof never
-    waits for the compiler — it is interpreted while ONE background thread builds the programs; later launches run compiled; the code
+    """The default mode of a context (gs_air_jit 2, "auto"), in a fresh process with an empty code-object cache: the first launches never
+    wait for the compiler — they are interpreted while ONE background thread builds the programs; later launches run compiled; the code
     objects land in the disk cache; a second process finds them there and runs compiled from its first proof.  Same bytes throughout."""
     import subprocess
     import sys
