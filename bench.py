@@ -8,9 +8,12 @@ extensionFactor 16, exeQueryCount 48, friQueryCount 64, blake2s256): execution t
 Merkle trees, composition polynomial, linear combination, FRI, spot checks — nothing skipped.  The only input of
 prove() is the seed; every vector lives in HBM for the whole step.
 
-Multi-GPU: a single MiMC proof has one trace register, so nothing inside one proof shards without an exchange
-step; independent proofs do.  Rank r proves its own trace (seed 3 + r) on its own GPU: weak scaling, no
-data-path collective (RCCL is used only for the barrier and the max-over-ranks reduction of the timing).
+Multi-GPU (N > 1): `value` is one independent proof per GPU — rank r proves its own trace (seed 3 + r): weak scaling, no data-path
+collective (a single MiMC proof is bounded by the serial recurrence of its one trace register).  Beside it, `one_proof`: ONE proof
+across all ranks through the native distributed driver (csrc/prover_dist.h) over RCCL on device buffers (csrc/comm_rccl.cc) — C4
+(BASELINE configs[3]: Poseidon, 6 registers, 2^16 steps as 1 024 hash chains) with the single-GPU time of the same run (strong
+scaling), and C5 (the headline statement); `collectives[]` lists every exchange with its bytes and device time, `rccl_ranks` the
+communicator size.
 
 `value` = NTT points transformed per second at whole-prove() level, aggregated over ranks:
           (points of the transforms the timed driver LAUNCHED, from its own counters: gs_prover_last_stats) * K * N
