@@ -38,6 +38,12 @@ static const char *kFieldHeader =
 #include "jit_gf128.inc"
 #endif
     ;
+#if !defined(GS_SMALL_Q) && !defined(GS_WIDE_BITS)
+#define GS_JIT_LAZY 1          // the 128-bit field: long exponentiations run in the five-limb lazy form (gf128_lazy.h: lz_sqr, lz_mul_v)
+static const char *kLazyHeader =
+#include "jit_gf128_lazy.inc"
+    ;
+#endif
 
 #define GS_STR2(x) #x
 #define GS_STR(x) GS_STR2(x)
@@ -59,7 +65,11 @@ static std::string jit_preamble() {
 #elif defined(GS_WIDE_BITS)
     s += "#define GS_WIDE_BITS " GS_STR(GS_WIDE_BITS) "\n";
 #endif
+#ifdef GS_JIT_LAZY
+    s += "#include \"gf128_lazy.h\"\n";        // brings gf128.h with it
+#else
     s += "#include \"gs_field.h\"\n";
+#endif
     // the straight-line products: a call in the multi-limb fields (a product is ~400 instructions there; inlining a hundred of
     // them costs minutes of compilation and buys nothing), inlined in the others
 #if defined(GS_WIDE_BITS)
@@ -137,6 +147,28 @@ static void emit_pow(std::string &s, const char *x, const std::vector<uint32_t> 
         if (pl.cost < best.cost) best = pl;
     }
     if (best.steps.size() == 1 && best.steps[0].second == 1) return;     // x^1
+#ifdef GS_JIT_LAZY
+    // A long chain (Rescue's inverse S-box: 127 squarings + 32 products) runs in the lazy five-limb form from end to end: one unpack,
+    // lz_sqr (15 products + fold: ~53 instructions against the 84 of a canonical fe_mul) and lz_mul_v, one pack.  On a single wave per
+    // SIMD a chain of dependent products costs its instruction count, so this is the length of the trace kernel's critical path.
+    if (best.cost >= 8) {
+        s += "            {\n                const lzk K = lzk_make();\n";
+        snprintf(buf, sizeof buf, "                const lz p1 = lz_unpack(%s);\n", x); s += buf;
+        if (best.table_max > 1) {
+            s += "                const lz p2 = lz_sqr(p1, K);\n";
+            for (uint32_t v = 3; v <= best.table_max; v += 2) { snprintf(buf, sizeof buf, "                const lz p%u = lz_mul_v(p%u, p2, K);\n", v, v - 2); s += buf; }
+        }
+        snprintf(buf, sizeof buf, "                lz acc = p%u;\n", best.steps[0].second); s += buf;
+        for (size_t k = 1; k < best.steps.size(); k++) {
+            const uint32_t sq = best.steps[k].first, val = best.steps[k].second;
+            if (sq >= 4) { snprintf(buf, sizeof buf, "#pragma nounroll\n                for (int q = 0; q < %u; q++) acc = lz_sqr(acc, K);\n", sq); s += buf; }
+            else for (uint32_t q = 0; q < sq; q++) s += "                acc = lz_sqr(acc, K);\n";
+            if (val) { snprintf(buf, sizeof buf, "                acc = lz_mul_v(acc, p%u, K);\n", val); s += buf; }
+        }
+        snprintf(buf, sizeof buf, "                %s = lz_pack(acc);\n            }\n", x); s += buf;
+        return;
+    }
+#endif
     s += "            {\n";
     snprintf(buf, sizeof buf, "                const fe p1 = %s;\n", x); s += buf;
     if (best.table_max > 1) {
@@ -494,9 +526,16 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
 // hiprtc: source -> gfx950 code object (no device needed); false + log on failure
 static bool jit_compile(const std::string &source, const char *entry, std::vector<char> &code, std::string &log) {
     hiprtcProgram prog;
+#ifdef GS_JIT_LAZY
+    const char *header_names[] = {"gf128.h", "gf128_lazy.h"};
+    const char *headers[] = {kFieldHeader, kLazyHeader};
+    const int nheaders = 2;
+#else
     const char *header_names[] = {"gs_field.h"};
     const char *headers[] = {kFieldHeader};
-    if (hiprtcCreateProgram(&prog, source.c_str(), "gs_air_jit.hip", 1, headers, header_names) != HIPRTC_SUCCESS) { log = "hiprtcCreateProgram failed"; return false; }
+    const int nheaders = 1;
+#endif
+    if (hiprtcCreateProgram(&prog, source.c_str(), "gs_air_jit.hip", nheaders, headers, header_names) != HIPRTC_SUCCESS) { log = "hiprtcCreateProgram failed"; return false; }
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
     const char *verbose = getenv("GSTARK_AIR_JIT_VERBOSE");
     if (verbose) fprintf(stderr, "[gstark] compiling an AIR program (%zu bytes of source, entry %s)\n", source.size(), entry);
@@ -539,7 +578,12 @@ static std::string jit_cache_path(const std::string &source, const char *entry) 
     std::string acc;
     for (size_t i = 1; i <= base.size(); i++)          // mkdir -p
         if (i == base.size() || base[i] == '/') { acc = base.substr(0, i); mkdir(acc.c_str(), 0755); }
-    std::string keyed = std::string(entry) + "|gfx950|v1|" + source;
+    // the key covers everything the code object depends on: the generated source AND the field headers it is compiled against
+    std::string keyed = std::string(entry) + "|gfx950|v2|" + kFieldHeader;
+#ifdef GS_JIT_LAZY
+    keyed += kLazyHeader;
+#endif
+    keyed += "|" + source;
     uint8_t d[32];
     host_sha256((const uint8_t *)keyed.data(), keyed.size(), d);
     char hex[65];

@@ -9,7 +9,7 @@ HDRS="gf128_lazy.h host_pow.h gf128.h gf_small.h gf_wide.h common.h host_field.h
 # one library per field: the 128-bit field of the hot path, and two "plumbing" flavours of the same sources for the small prime
 # fields of the reference's examples (gf_small.h): 2^64 - 21*2^30 + 1 (rescue/hash2x64.ts) and 2^32 - 3*2^25 + 1 (demo/fibonacci.ts)
 # the field headers as string literals: the source text hiprtc compiles AIR programs against (air_jit.hip)
-for pair in gf128.h:jit_gf128.inc gf_small.h:jit_gf_small.inc gf_wide.h:jit_gf_wide.inc; do
+for pair in gf128.h:jit_gf128.inc gf128_lazy.h:jit_gf128_lazy.inc gf_small.h:jit_gf_small.inc gf_wide.h:jit_gf_wide.inc; do
   src=${pair%%:*}; dst=${pair##*:}
   if [ ! -f $dst ] || [ $src -nt $dst ]; then { printf 'R"GSJIT('; cat $src; printf ')GSJIT"\n'; } > $dst; fi
 done

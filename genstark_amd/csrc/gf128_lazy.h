@@ -137,6 +137,8 @@ GF_HD lz lz_mul_u(const lz &x, const lzw &W, const lzk &K) {
 // x * w, the multiplier an ordinary NN element (per-lane twiddles read from a table): nine columns, the four high ones
 // (weight 2^130 * B^k) are brought down first.  A 64-bit column is split as c = h * 2^32 + l (h signed, l unsigned: its two registers):
 //     c * 2^130 == 2304*B*c - 4*c,   2304*c = 2304*l + 147456*B*h,   4*c = 4*l + 256*B*h        (2^32 = 64*B)
+// nine columns (value = sum c[k] B^k, |c[k]| < 2^57) -> NN limbs: the four high ones first, then the common tail
+GF_HD lz lz_fold9(int64_t c[9], const lzk &K);
 GF_HD lz lz_mul_v(const lz &x, const lz &w, const lzk &K) {
     int64_t c[9];
 #pragma unroll
@@ -149,6 +151,25 @@ GF_HD lz lz_mul_v(const lz &x, const lz &w, const lzk &K) {
         }
         c[k] = s;
     }
+    return lz_fold9(c, K);
+}
+// x * x for an NN x: 15 products instead of 25 (the cross terms once, with a doubled factor: limbs stay below 2^27.1, a column is at
+// most three terms below 2^53.2).  What the long exponentiations of AIR programs are made of (csrc/air_jit.hip: emit_pow).
+GF_HD lz lz_sqr(const lz &x, const lzk &K) {
+    const int32_t d0 = 2 * x.l[0], d1 = 2 * x.l[1], d2 = 2 * x.l[2], d3 = 2 * x.l[3];
+    int64_t c[9];
+    c[0] = (int64_t)x.l[0] * x.l[0];
+    c[1] = (int64_t)d0 * x.l[1];
+    c[2] = (int64_t)d0 * x.l[2] + (int64_t)x.l[1] * x.l[1];
+    c[3] = (int64_t)d0 * x.l[3] + (int64_t)d1 * x.l[2];
+    c[4] = (int64_t)d0 * x.l[4] + (int64_t)d1 * x.l[3] + (int64_t)x.l[2] * x.l[2];
+    c[5] = (int64_t)d1 * x.l[4] + (int64_t)d2 * x.l[3];
+    c[6] = (int64_t)d2 * x.l[4] + (int64_t)x.l[3] * x.l[3];
+    c[7] = (int64_t)d3 * x.l[4];
+    c[8] = (int64_t)x.l[4] * x.l[4];
+    return lz_fold9(c, K);
+}
+GF_HD lz lz_fold9(int64_t c[9], const lzk &K) {
 #pragma unroll
     for (int k = 8; k >= 5; k--) {   // top down: column 8 spills into column 5, which is folded last
         const int32_t h = (int32_t)(c[k] >> 32);

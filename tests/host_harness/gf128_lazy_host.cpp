@@ -13,6 +13,11 @@ void z_pack(const int32_t *x, uint8_t *o, int n) { for (int i = 0; i < n; i++) s
 void z_pack_weak(const int32_t *x, uint8_t *o, int n) { for (int i = 0; i < n; i++) st(o + 16 * i, lz_pack_weak(ldl(x + 5 * i))); }
 void z_norm(const int32_t *x, int32_t *o, int n) { for (int i = 0; i < n; i++) stl(o + 5 * i, lz_norm(ldl(x + 5 * i))); }
 void z_shift(const int32_t *x, int32_t *o, int n) { for (int i = 0; i < n; i++) stl(o + 5 * i, lz_shift_limb(ldl(x + 5 * i), K)); }
+void z_sqr(const int32_t *x, int32_t *o, int n) { for (int i = 0; i < n; i++) stl(o + 5 * i, lz_sqr(ldl(x + 5 * i), K)); }
+// x^(2^k) * x as the exponentiation chains of the generated AIR kernels run it: k squarings and one product, no packing in between
+void z_sqr_chain(const int32_t *x, int k, int32_t *o, int n) {
+    for (int i = 0; i < n; i++) { const lz a = ldl(x + 5 * i); lz c = a; for (int q = 0; q < k; q++) c = lz_sqr(c, K); stl(o + 5 * i, lz_mul_v(c, a, K)); }
+}
 void z_mul_v(const int32_t *x, const int32_t *w, int32_t *o, int n) { for (int i = 0; i < n; i++) stl(o + 5 * i, lz_mul_v(ldl(x + 5 * i), ldl(w + 5 * i), K)); }
 // multiplier given as a canonical element: its W-form is built the way the plan builds the radix-16 twiddles
 void z_mul_u(const int32_t *x, const uint8_t *w, int32_t *o, int n) {

@@ -151,6 +151,22 @@ def test_products(lib, terms):
         assert value(y) % P == value(x) * value(w) % P and is_nn(y), ('mul_u_rows', x, w, y)
 
 
+def test_square_and_exponentiation_chain(lib):
+    """lz_sqr on NN inputs (ends of the limb intervals included) and k squarings + one product with no packing in between — what the
+    long exponentiations of compiled AIR programs are made of (csrc/air_jit.hip: emit_pow)"""
+    rng = random.Random(123)
+    n = 6000
+    xs = [rand_nn(rng, extreme=(i % 2 == 0)) for i in range(n)]
+    o = out_limbs(n)
+    lib.z_sqr(limbs_buf(xs), o, n)
+    for x, y in zip(xs, rows_of(o, n)):
+        assert value(y) % P == value(x) ** 2 % P and is_nn(y), ('sqr', x, y)
+    for k in (1, 5, 31):
+        lib.z_sqr_chain(limbs_buf(xs[:1500]), k, o, 1500)
+        for x, y in zip(xs[:1500], rows_of(o, 1500)):
+            assert value(y) % P == pow(value(x), 2 ** k + 1, P) and is_nn(y), ('chain', k, x, y)
+
+
 def test_product_of_unnormalised_sums_by_signed_digit_multiplier(lib):
     """the exchange stage of the pass kernel: network outputs (sums of up to 9 NN values) times table entries recoded to signed
     digits |limb| <= 2^25 (k_build_lz_table), no normalisation in between"""

@@ -58,8 +58,16 @@ __global__ void k_check(const fe *__restrict__ a, const fe *__restrict__ b, cons
     CHK(fe_eq(lz_pack(lz_mul_v(lz_norm(acc), ly, K)), fe_mul(racc, y)));
     CHK(fe_eq(lz_pack(lz_mul_v(dif, ly, K)), fe_mul(rdif, y)));
     CHK(fe_eq(lz_pack(lz_mul_u(dif, W, K)), fe_mul(rdif, wcan[t])));
+    // 8. squaring, and an exponentiation chain as compiled AIR programs run it (5 squarings + a product, nothing packed in between)
+    {
+        CHK(fe_eq(lz_pack(lz_sqr(lx, K)), fe_mul(x, x)));
+        lz c5 = lx; fe r5 = x;
+#pragma unroll 1
+        for (int q = 0; q < 5; q++) { c5 = lz_sqr(c5, K); r5 = fe_mul(r5, r5); }
+        CHK(fe_eq(lz_pack(lz_mul_v(c5, ly, K)), fe_mul(r5, y)));
+    }
     if (bad) atomicAdd(err, 1u);
-    for (int k = 0; k < 7; k++) if (bad & (1u << k)) atomicAdd(err + 1 + k, 1u);
+    for (int k = 0; k < 9; k++) if (bad & (1u << k)) atomicAdd(err + 1 + k, 1u);
 }
 
 static uint64_t sm(uint64_t &s) { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
@@ -78,15 +86,15 @@ int main() {
     };
     for (uint64_t i = 0; i < n; i++) { a[i] = rnd(i); b[i] = rnd(i + 3); }
     for (int i = 0; i < nw; i++) { wc[i] = rnd(i * 5 + 1); lz_wform(wc[i], wt[i]); }
-    fe *da, *db, *dwc; lzw *dwt; unsigned *derr, herr[8] = {0};
-    hipMalloc(&da, n * 16); hipMalloc(&db, n * 16); hipMalloc(&dwc, nw * 16); hipMalloc(&dwt, nw * sizeof(lzw)); hipMalloc(&derr, 32);
+    fe *da, *db, *dwc; lzw *dwt; unsigned *derr, herr[12] = {0};
+    hipMalloc(&da, n * 16); hipMalloc(&db, n * 16); hipMalloc(&dwc, nw * 16); hipMalloc(&dwt, nw * sizeof(lzw)); hipMalloc(&derr, 48);
     hipMemcpy(da, a.data(), n * 16, hipMemcpyHostToDevice); hipMemcpy(db, b.data(), n * 16, hipMemcpyHostToDevice);
     hipMemcpy(dwc, wc.data(), nw * 16, hipMemcpyHostToDevice); hipMemcpy(dwt, wt.data(), nw * sizeof(lzw), hipMemcpyHostToDevice);
-    hipMemset(derr, 0, 32);
+    hipMemset(derr, 0, 48);
     hipLaunchKernelGGL(k_check, dim3((unsigned)(n / 256)), dim3(256), 0, 0, da, db, dwt, dwc, nw, n, derr);
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; }
-    hipMemcpy(herr, derr, 32, hipMemcpyDeviceToHost);
-    printf("lazy_device_check: %llu lanes, %u mismatching (per test: mul_v %u, mul_u table %u, running W-form %u, sum16 %u, norm+mul_v %u, diff mul_v %u, diff mul_u %u)\n",
-           (unsigned long long)n, herr[0], herr[1], herr[2], herr[3], herr[4], herr[5], herr[6], herr[7]);
+    hipMemcpy(herr, derr, 48, hipMemcpyDeviceToHost);
+    printf("lazy_device_check: %llu lanes, %u mismatching (per test: mul_v %u, mul_u table %u, running W-form %u, sum16 %u, norm+mul_v %u, diff mul_v %u, diff mul_u %u, sqr %u, sqr chain %u)\n",
+           (unsigned long long)n, herr[0], herr[1], herr[2], herr[3], herr[4], herr[5], herr[6], herr[7], herr[8], herr[9]);
     return herr[0] ? 1 : 0;
 }
