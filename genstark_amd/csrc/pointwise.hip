@@ -77,6 +77,39 @@ __device__ __forceinline__ fe fe_shfl(const fe &v, int lane) {
     return o;
 }
 
+#if !defined(GS_SMALL_Q) && !defined(GS_WIDE_BITS)
+#include "gf128_lazy.h"
+// a^(p-2) on ONE lane while the rest of the workgroup waits: 127 squarings + 12 products, all dependent.  In the lazy five-limb form a
+// squaring is ~53 instructions instead of 84 (gf128_lazy.h: lz_sqr), and on a lone wave the chain costs its instruction count.
+// p - 2 = 2^128 - 9*2^32 - 1: 64 ones | 28 ones, 0110 | 32 ones (most significant first), as fe_inv (gf128.h).  0 -> 0.
+__device__ __forceinline__ fe fe_inv_chain(const fe &a) {
+    const lzk K = lzk_make();
+    auto sqn = [&](lz v, int n) {
+#pragma unroll 1
+        for (int i = 0; i < n; i++) v = lz_sqr(v, K);
+        return v;
+    };
+    const lz x1 = lz_unpack(a);
+    const lz x2 = lz_mul_v(lz_sqr(x1, K), x1, K);
+    const lz x4 = lz_mul_v(sqn(x2, 2), x2, K);
+    const lz x8 = lz_mul_v(sqn(x4, 4), x4, K);
+    const lz x16 = lz_mul_v(sqn(x8, 8), x8, K);
+    const lz x32 = lz_mul_v(sqn(x16, 16), x16, K);
+    const lz x64 = lz_mul_v(sqn(x32, 32), x32, K);
+    lz x28 = lz_mul_v(sqn(x16, 8), x8, K);
+    x28 = lz_mul_v(sqn(x28, 4), x4, K);
+    lz r = lz_mul_v(sqn(x64, 28), x28, K);
+    r = lz_sqr(r, K);                                   // 0
+    r = lz_mul_v(lz_sqr(r, K), x1, K);                  // 1
+    r = lz_mul_v(lz_sqr(r, K), x1, K);                  // 1
+    r = lz_sqr(r, K);                                   // 0
+    r = lz_mul_v(sqn(r, 32), x32, K);
+    return lz_pack(r);
+}
+#else
+__device__ __forceinline__ fe fe_inv_chain(const fe &a) { return fe_inv(a); }
+#endif
+
 #define GS_BINV_THREADS 1024
 __global__ __launch_bounds__(GS_BINV_THREADS) void k_batch_inv(const fe *__restrict__ a, const fe *__restrict__ num, uint64_t n, uint64_t tot,
                                                              fe *__restrict__ out) {
@@ -116,7 +149,7 @@ __global__ __launch_bounds__(GS_BINV_THREADS) void k_batch_inv(const fe *__restr
             if (lane >= d) p2 = fe_mul(p2, up);
             if (lane + d < 64) s2 = fe_mul(s2, down);
         }
-        const fe block_inv = fe_inv(fe_shfl(p2, GS_BINV_THREADS / 64 - 1));
+        const fe block_inv = fe_inv_chain(fe_shfl(p2, GS_BINV_THREADS / 64 - 1));
         fe b2 = fe_shfl_up(p2, 1), a2 = fe_shfl_down(s2, 1);
         if (lane == 0) b2 = fe_one();
         if (lane >= GS_BINV_THREADS / 64 - 1) a2 = fe_one();

@@ -4,7 +4,7 @@ from genstark_amd._abi import Backend
 from genstark_amd.field import PrimeField
 be = Backend(); f = PrimeField(backend=be)
 P = f.modulus
-for logn in (16, 20, 24):
+for logn in (14, 17, 20, 24):
     n = 1 << logn
     a = f.getPowerSeries(0x123456789abcdef123, n); out = f.newVector(n)
     args = (C.c_void_p(a.ptr), n, C.c_void_p(out.ptr))
