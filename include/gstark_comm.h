@@ -28,6 +28,9 @@ struct gs_comm {
      * written (<= cap).  Blocks until they have completed. */
     uint32_t (*take_timings)(void *self, double *ms_out, uint32_t cap);
     const char *name;                /* "rccl", "threads", ... (reported by bench.py) */
+    /* tuning: a FRI layer (after the first) with fewer values than this is all-gathered once and finished on every rank instead of
+     * being folded on shares (two collectives per layer are not worth a latency-bound layer).  0 = the default (2^22 values). */
+    uint64_t fri_gather_below;
 };
 
 /* One proof of `job` across the comm->size ranks (every rank calls this with the same job; SPMD).  Every rank receives the same

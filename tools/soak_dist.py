@@ -71,6 +71,9 @@ while done < cases:
         for be in bes: be.close()
         continue
     comms, keep = thread_comms(bes[0], G)
+    gather_below = rng.choice([0, 1, 1 << 10, 1 << 14])          # FRI tail: default threshold, never gathered, gathered at various depths
+    for r in range(G):
+        comms[r].fri_gather_below = gather_below
     outs, errs = [None] * G, [None] * G
 
     def run(r):
