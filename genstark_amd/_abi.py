@@ -56,6 +56,8 @@ _SIGNATURES = {
     'gs_transpose_records': (_int, [_vp, _vp, _u64, _u64, _u64, _vp]),
     'gs_defer_begin': (_int, [_vp]),
     'gs_defer_end': (_int, [_vp]),
+    'gs_readback_post': (_int, [_vp, _vp, _u32, C.POINTER(C.c_uint64)]),
+    'gs_readback_wait': (_int, [_vp, _u64, _vp]),
     'gs_gather': (_int, [_vp, _vp, _u64, C.POINTER(_u64), _u64, _vp]),
     'gs_power_series': (_int, [_vp, _bytes, _u64, _vp]),
     'gs_vec_add': (_int, [_vp, _vp, _vp, _u64, _vp]),

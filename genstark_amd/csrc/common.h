@@ -71,6 +71,13 @@ struct gs_ctx {
     uint64_t trace_bytes = 0;
     hipEvent_t trace_done = nullptr;
     bool trace_pending = false;
+    // posted read-backs (gs_readback_post / gs_readback_wait): a ring of small slots in mapped pinned memory, one event per slot;
+    // the host waits for THAT slot's event only, whatever else is queued behind it on the stream
+    static constexpr uint32_t RB_SLOTS = 64, RB_SLOT_BYTES = 256;
+    void *h_rb = nullptr, *h_rb_dev = nullptr;
+    hipEvent_t rb_events[RB_SLOTS] = {};
+    uint32_t rb_bytes[RB_SLOTS] = {};
+    uint64_t rb_next = 0;
 };
 
 int gs_fail(gs_ctx *c, int code, const char *fmt, ...);

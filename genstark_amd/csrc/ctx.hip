@@ -75,6 +75,8 @@ void gs_ctx_destroy(gs_ctx *c) {
     if (c->d_stage) hipFree(c->d_stage);
     if (c->h_trace) hipHostFree(c->h_trace);
     if (c->trace_done) hipEventDestroy(c->trace_done);
+    if (c->h_rb) hipHostFree(c->h_rb);
+    for (hipEvent_t e : c->rb_events) if (e) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -173,6 +175,39 @@ int gs_copy(gs_ctx *c, void *dst, const void *src, uint64_t bytes) {
 __global__ void k_gather_words(const uint64_t *__restrict__ addr, uint64_t total, uint4 *__restrict__ out) {
     for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x)
         out[t] = *reinterpret_cast<const uint4 *>(addr[t]);
+}
+
+// words 16-byte words from src into a slot of mapped pinned host memory
+__global__ void k_post_words(const uint4 *__restrict__ src, uint32_t words, uint4 *__restrict__ out) {
+    if (threadIdx.x < words) out[threadIdx.x] = src[threadIdx.x];
+}
+
+extern "C" int gs_readback_post(gs_ctx *c, const void *src, uint32_t bytes, uint64_t *ticket) {
+    if (!c || !src || !ticket) return GS_ERR_ARG;
+    if (!bytes || bytes > gs_ctx::RB_SLOT_BYTES || (bytes & 15)) return gs_fail(c, GS_ERR_ARG, "readback_post: 16..%u bytes, a multiple of 16", gs_ctx::RB_SLOT_BYTES);
+    if (!c->h_rb) {
+        GS_HIP(c, hipHostMalloc(&c->h_rb, (size_t)gs_ctx::RB_SLOTS * gs_ctx::RB_SLOT_BYTES, hipHostMallocMapped));
+        GS_HIP(c, hipHostGetDevicePointer(&c->h_rb_dev, c->h_rb, 0));
+    }
+    const uint32_t slot = (uint32_t)(c->rb_next % gs_ctx::RB_SLOTS);
+    if (!c->rb_events[slot]) GS_HIP(c, hipEventCreateWithFlags(&c->rb_events[slot], hipEventDisableTiming));
+    else GS_HIP(c, hipEventSynchronize(c->rb_events[slot]));          // a ticket 64 posts old (abandoned or not): its copy has long landed
+    hipLaunchKernelGGL(k_post_words, dim3(1), dim3(64), 0, c->stream, (const uint4 *)src, bytes / 16,
+                       (uint4 *)((uint8_t *)c->h_rb_dev + (size_t)slot * gs_ctx::RB_SLOT_BYTES));
+    GS_LAUNCH_CHECK(c);
+    GS_HIP(c, hipEventRecord(c->rb_events[slot], c->stream));
+    c->rb_bytes[slot] = bytes;
+    *ticket = c->rb_next++;
+    return GS_OK;
+}
+
+extern "C" int gs_readback_wait(gs_ctx *c, uint64_t ticket, void *host_dst) {
+    if (!c || !host_dst) return GS_ERR_ARG;
+    if (ticket >= c->rb_next || c->rb_next - ticket > gs_ctx::RB_SLOTS) return gs_fail(c, GS_ERR_ARG, "readback_wait: ticket %llu is not outstanding", (unsigned long long)ticket);
+    const uint32_t slot = (uint32_t)(ticket % gs_ctx::RB_SLOTS);
+    GS_HIP(c, hipEventSynchronize(c->rb_events[slot]));
+    memcpy(host_dst, (const uint8_t *)c->h_rb + (size_t)slot * gs_ctx::RB_SLOT_BYTES, c->rb_bytes[slot]);
+    return GS_OK;
 }
 
 int gs_defer_flush(gs_ctx *c) {

@@ -37,7 +37,7 @@ namespace {
     X(gs_eval_polys_at_roots) X(gs_interpolate_roots) X(gs_interpolate_quartic_domain) X(gs_eval_quartic_batch)                \
     X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_commit_rows) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
     X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
-    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end) \
+    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end) X(gs_readback_post) X(gs_readback_wait) \
     X(gs_vec_mul_scalar) X(gs_copy) X(gs_gather_words) X(gs_transpose_records) X(gs_fri_fold_seeded_scaled)
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
@@ -531,9 +531,9 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
             x.check(A.gs_mimc_constraints(x.c, pRows[0], N, N / T, kN.p, klen_n, q.p), "gs_mimc_constraints");
         } else {
             // P over the composition domain is every (N/Nc)-th element of the extension just computed (:76)
+            // (the R rows are one contiguous R x N matrix and N / Nc divides N: ONE strided pick over the whole matrix gives R x Nc)
             Buf pComp(x, (uint64_t)R * Nc * ELEM);
-            for (uint32_t r = 0; r < R; r++)
-                x.check(A.gs_pluck(x.c, pRows[r], N, N / Nc, Nc, pComp.at((uint64_t)r * Nc * ELEM)), "gs_pluck(P over the composition domain)");
+            x.check(A.gs_pluck(x.c, pEval.p, (uint64_t)R * N, N / Nc, (uint64_t)R * Nc, pComp.p), "gs_pluck(P over the composition domain)");
             x.check(A.gs_air_constraints(x.c, air.e_code, air.e_ninstr, air.consts, air.nconsts, air.vm_regs, R, air.nconstraints, pComp.p, Nc,
                                          Nc / T, air.static_tables, air.static_lens, air.nstatic, q.p), "gs_air_constraints");
         }
@@ -675,7 +675,16 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
 
     // layers (:176-221): the loop below is the recursion unrolled.  No root is read back inside it: the point every layer folds at,
     // prng(root of the tree above) (:194), is derived on the device from the root where it lies (gs_fri_fold_seeded), so all layers
-    // are enqueued without a round trip; the roots (the proof needs them, and so do the query positions) come back together below
+    // are enqueued without a round trip.  Every tree's root is POSTED behind it (gs_readback_post): the host picks each one up as
+    // soon as that tree exists and derives the layer's query positions and batch-proof plans while the device folds the layers below
+    auto post_root = [&](const Tree &t) {
+        uint64_t ticket = 0;
+        x.check(A.gs_readback_post(x.c, t.nodes.at(DIGEST), (uint32_t)DIGEST, &ticket), "gs_readback_post(root)");
+        return ticket;
+    };
+    auto await_root = [&](uint64_t ticket, Tree &t) { x.check(A.gs_readback_wait(x.c, ticket, t.root.data()), "gs_readback_wait(root)"); };
+    std::vector<uint64_t> tickets;
+    tickets.push_back(post_root(pTree0));
     std::vector<Layer> layers;
     Tree *pTree = &pTree0;
     const void *column_src = lEval.p;   // the current layer's values in natural order (the remainder at the end)
@@ -697,32 +706,66 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         le16(omega, s16);
         x.check(A.gs_fri_fold_seeded(x.c, s16, N, step, column_src, len, pTree->nodes.at(DIGEST), L.next.p), "gs_fri_fold_seeded");   // :189-198
         L.cTree = commit_rows4(x, alg, L.next.p, rows / 4);                                           // :201-202
+        tickets.push_back(post_root(L.cTree));
         column_src = L.next.p;
         pTree = &L.cTree;
         len = rows;
         max_degree_plus1 /= 4;
         depth++;
     }
+    if (layers.size() > 60) fail(GS_ERR_ARG, "too many FRI components");
     clock.mark("FRI layers issued");
-    // one round trip: every root and the remainder (:179-187: the natural-order vector the last polyValues came from)
+    // Everything the proof reads back — the queried rows and their batch proofs of every tree, the remainder (:179-187: the natural-
+    // order vector the last polyValues came from) — is requested in ONE deferral window; the requests are planned root by root as
+    // the roots arrive, the window closes with the single synchronisation of the proof
+    struct Component { Bytes columnRoot; MerkleProof columnProof, polyProof; };
+    std::vector<Component> components(layers.size());
+    Readbacks rb;
+    DeferWindow win(x);
+    // spot checks of the evaluation tree (lib/Stark.ts:146-152, 274-296) and of the linear combination (LowDegreeProver.ts:52-54,
+    // 302-309): positions from the root of the first FRI tree
+    await_root(tickets[0], pTree0);
+    const uint32_t exe_count = (uint32_t)std::min<uint64_t>(job.exe_query_count, N - N / E);
+    const std::vector<uint64_t> exe_positions = query_indexes(pTree0.root, exe_count, N, (uint32_t)E);   // QueryIndexGenerator.ts:28-32
+    std::vector<uint64_t> lc_positions;
+    for (uint64_t p : exe_positions) lc_positions.push_back(p % (N / 4));
+    lc_positions = unique_in_order(lc_positions);
+    MerkleProof lcProof;
+    rb.prove_batch(x, pTree0, lc_positions, &lcProof);
+    rb.gather_rows4(x, lEval.p, N / 4, lc_positions, &lcProof);
+    std::vector<uint64_t> aug;
+    for (uint64_t p : exe_positions) { aug.push_back(p); aug.push_back((p + E) % N); }
+    aug = unique_in_order(aug);
+    MerkleProof evProof;
+    rb.prove_batch(x, eTree, aug, &evProof);
+    // the leaves of the evaluation tree are the committed vectors' elements side by side (lib/Stark.ts:284-296)
+    std::vector<MerkleProof> cols(V);
+    for (uint32_t r = 0; r < V; r++) rb.gather(x, eVectors[r], ELEM, aug, 1, V == 1 ? &evProof : &cols[r]);
+    // queries of every layer (:209-219)
+    for (size_t d = 0; d < layers.size(); d++) {
+        Layer &L = layers[d];
+        await_root(tickets[d + 1], L.cTree);
+        std::vector<uint64_t> positions = query_indexes(L.cTree.root, job.fri_query_count, L.column_length, (uint32_t)E);
+        std::vector<uint64_t> rows_wanted;
+        for (uint64_t p : positions) rows_wanted.push_back(p % (L.column_length / 4));
+        rows_wanted = unique_in_order(rows_wanted);
+        Component &c = components[d];
+        c.columnRoot = L.cTree.root;
+        rb.prove_batch(x, L.cTree, rows_wanted, &c.columnProof);
+        rb.gather_rows4(x, L.next.p, L.column_length / 4, rows_wanted, &c.columnProof);
+        rb.prove_batch(x, *L.pTree, positions, &c.polyProof);
+        rb.gather_rows4(x, L.column, L.rows, positions, &c.polyProof);
+    }
     std::vector<F> remainder(len);
     Bytes remainder_raw(len * ELEM);
     {
         std::vector<uint64_t> all(len);
         for (uint64_t i = 0; i < len; i++) all[i] = i;
-        const uint64_t one = 1;                        // record 1 of a node array (32-byte records) is the root
-        DeferWindow win(x);
-        x.check(A.gs_gather(x.c, pTree0.nodes.p, DIGEST, &one, 1, pTree0.root.data()), "gs_gather(root)");
-        for (Layer &L : layers) x.check(A.gs_gather(x.c, L.cTree.nodes.p, DIGEST, &one, 1, L.cTree.root.data()), "gs_gather(root)");
         x.check(A.gs_gather(x.c, column_src, ELEM, all.data(), len, remainder_raw.data()), "gs_gather(remainder)");
-        win.end();
     }
-    clock.mark("FRI roots + remainder read back (1 round trip)");
-    const uint32_t exe_count = (uint32_t)std::min<uint64_t>(job.exe_query_count, N - N / E);
-    std::vector<uint64_t> exe_positions = query_indexes(pTree0.root, exe_count, N, (uint32_t)E);   // QueryIndexGenerator.ts:28-32
-    std::vector<uint64_t> lc_positions;
-    for (uint64_t p : exe_positions) lc_positions.push_back(p % (N / 4));
-    lc_positions = unique_in_order(lc_positions);                                                 // LowDegreeProver.ts:302-309
+    clock.mark("roots awaited one by one; query positions + batch-proof plans (while the device folds)");
+    win.end();
+    clock.mark("remainder + query answers fetched (the one synchronisation)");
     {
         Bytes &raw = remainder_raw;
         for (uint64_t i = 0; i < len; i++) remainder[i] = from16(raw.data() + 16 * i);
@@ -752,41 +795,6 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         }
     }
     clock.mark("remainder checked");
-    // queries of every layer (:209-219) and the spot checks of the evaluation tree (lib/Stark.ts:146-152, 274-296): every position
-    // follows from roots the host already holds, so all the answers are requested in one deferral window — one round trip
-    struct Component { Bytes columnRoot; MerkleProof columnProof, polyProof; };
-    std::vector<Component> components(layers.size());
-    Readbacks rb;
-    DeferWindow win(x);
-    MerkleProof lcProof;                                                                          // LowDegreeProver.ts:52-54
-    rb.prove_batch(x, pTree0, lc_positions, &lcProof);
-    rb.gather_rows4(x, lEval.p, N / 4, lc_positions, &lcProof);
-    for (size_t d = 0; d < layers.size(); d++) {
-        Layer &L = layers[d];
-        std::vector<uint64_t> positions = query_indexes(L.cTree.root, job.fri_query_count, L.column_length, (uint32_t)E);
-        std::vector<uint64_t> aug;
-        for (uint64_t p : positions) aug.push_back(p % (L.column_length / 4));
-        aug = unique_in_order(aug);
-        Component &c = components[d];
-        c.columnRoot = L.cTree.root;
-        rb.prove_batch(x, L.cTree, aug, &c.columnProof);
-        rb.gather_rows4(x, L.next.p, L.column_length / 4, aug, &c.columnProof);
-        rb.prove_batch(x, *L.pTree, positions, &c.polyProof);
-        rb.gather_rows4(x, L.column, L.rows, positions, &c.polyProof);
-    }
-    // 8 ----- spot checks of the evaluation tree
-    std::vector<uint64_t> positions = query_indexes(pTree0.root, exe_count, N, (uint32_t)E);
-    std::vector<uint64_t> aug;
-    for (uint64_t p : positions) { aug.push_back(p); aug.push_back((p + E) % N); }
-    aug = unique_in_order(aug);
-    MerkleProof evProof;
-    rb.prove_batch(x, eTree, aug, &evProof);
-    // the leaves of the evaluation tree are the committed vectors' elements side by side (lib/Stark.ts:284-296)
-    std::vector<MerkleProof> cols(V);
-    for (uint32_t r = 0; r < V; r++) rb.gather(x, eVectors[r], ELEM, aug, 1, V == 1 ? &evProof : &cols[r]);
-    clock.mark("query positions + batch-proof plans");
-    win.end();
-    clock.mark("query answers fetched (one round trip)");
     if (V > 1) {
         evProof.value_size = (uint64_t)V * ELEM;
         evProof.nvalues = (uint32_t)aug.size();

@@ -105,6 +105,14 @@ int gs_transpose_records(gs_ctx *ctx, const void *src, uint64_t rows, uint64_t c
  * delivers what is queued first. */
 int gs_defer_begin(gs_ctx *ctx);
 int gs_defer_end(gs_ctx *ctx);
+/* Posted read-backs: gs_readback_post queues a copy of `bytes` (a multiple of 16, at most 256) from device memory behind the work
+ * already issued and returns a ticket at once; gs_readback_wait blocks until THAT copy has landed — not for whatever was queued
+ * after it — and delivers the bytes.  The FRI layers are issued without a round trip (LowDegreeProver.ts:176-221 as one queue);
+ * with every tree's root posted behind it, the host derives the query positions of a layer (QueryIndexGenerator.ts:39-67) and
+ * plans its batch proofs while the device is still folding the layers below.  At most 64 tickets are outstanding; older ones
+ * lapse. */
+int gs_readback_post(gs_ctx *ctx, const void *src, uint32_t bytes, uint64_t *ticket);
+int gs_readback_wait(gs_ctx *ctx, uint64_t ticket, void *host_dst);
 
 /* ---- vector arithmetic (FiniteField vector ops) ------------------------------------------------ */
 /* getPowerSeries(base, n): out[i] = base^i.  CompositionPolynomial.ts:94,132; LinearCombination.ts:46;

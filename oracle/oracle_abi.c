@@ -32,6 +32,9 @@ typedef u128 fexp;      /* an exponent as wide as an element */
 
 struct gs_ctx {
     char err[256];
+    uint8_t rb[64][256];      /* posted read-backs: the copy is taken at once (host memory), the ticket discipline is the library's */
+    uint32_t rb_bytes[64];
+    uint64_t rb_next;
 };
 
 static int fail(gs_ctx *c, int code, const char *msg) {
@@ -82,6 +85,20 @@ int gs_air_jit_check(int kind, const uint32_t *code, uint32_t ninstr, const uint
 }
 int gs_defer_begin(gs_ctx *c) { (void)c; return GS_OK; }   /* host memory: every read-back is immediate */
 int gs_defer_end(gs_ctx *c) { (void)c; return GS_OK; }
+int gs_readback_post(gs_ctx *c, const void *src, uint32_t bytes, uint64_t *ticket) {
+    if (!c || !src || !ticket) return GS_ERR_ARG;
+    if (!bytes || bytes > 256 || (bytes & 15)) return fail(c, GS_ERR_ARG, "readback_post: 16..256 bytes, a multiple of 16");
+    memcpy(c->rb[c->rb_next % 64], src, bytes);
+    c->rb_bytes[c->rb_next % 64] = bytes;
+    *ticket = c->rb_next++;
+    return GS_OK;
+}
+int gs_readback_wait(gs_ctx *c, uint64_t ticket, void *host_dst) {
+    if (!c || !host_dst) return GS_ERR_ARG;
+    if (ticket >= c->rb_next || c->rb_next - ticket > 64) return fail(c, GS_ERR_ARG, "readback_wait: ticket is not outstanding");
+    memcpy(host_dst, c->rb[ticket % 64], c->rb_bytes[ticket % 64]);
+    return GS_OK;
+}
 
 /* The loops below are independent per index; built with -fopenmp (liboracle_omp.so: the all-cores CPU baseline of bench.py) they
  * run on every host core, built without it (liboracle.so, the checker) the pragmas vanish.  Loops that carry a running product

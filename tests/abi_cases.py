@@ -448,6 +448,47 @@ def check_device_record_ops(backend, rng):
     be.call('gs_gather_words', C.c_void_p(addrs), 40, C.c_void_p(dst))
     assert be.download(dst, 16 * 40) == b''.join(src_raw[16 * i:16 * i + 16] for i in picks)
     be.call('gs_gather_words', C.c_void_p(addrs), 0, C.c_void_p(dst))                      # empty: no-op
+    # gs_readback_post / gs_readback_wait: the bytes as they were when the copy's turn came, picked up ticket by ticket in any order
+    tickets = []
+    for i in (5, 0, 200, 31):
+        t = C.c_uint64()
+        be.call('gs_readback_post', C.c_void_p(src + 16 * i), 32 if i != 200 else 256, C.byref(t))
+        tickets.append((i, t.value))
+    be.upload(src, bytes(16 * n))                                                           # later work on the same queue: not seen
+    for i, t in reversed(tickets):
+        nb = 32 if i != 200 else 256
+        out = C.create_string_buffer(nb)
+        be.call('gs_readback_wait', t, out)
+        assert out.raw == src_raw[16 * i:16 * i + nb], i
+    for bad in (0, 24, 272):
+        try:
+            be.call('gs_readback_post', C.c_void_p(src), bad, C.byref(C.c_uint64()))
+            raise AssertionError('readback sizes are multiples of 16 up to 256')
+        except AssertionError:
+            raise
+        except Exception as e:      # noqa: BLE001
+            assert 'multiple of 16' in str(e)
+    try:
+        be.call('gs_readback_wait', tickets[-1][1] + 1000, C.create_string_buffer(32))
+        raise AssertionError('a ticket that was never issued must be refused')
+    except AssertionError:
+        raise
+    except Exception as e:      # noqa: BLE001
+        assert 'not outstanding' in str(e)
+    for k in range(70):                                                                     # the ring wraps: 64 slots
+        t = C.c_uint64()
+        be.call('gs_readback_post', C.c_void_p(dst), 16, C.byref(t))
+    out = C.create_string_buffer(16)
+    be.call('gs_readback_wait', t.value, out)
+    assert out.raw == be.download(dst, 16)
+    try:
+        be.call('gs_readback_wait', t.value - 64, out)
+        raise AssertionError('a lapsed ticket must be refused')
+    except AssertionError:
+        raise
+    except Exception as e:      # noqa: BLE001
+        assert 'not outstanding' in str(e)
+    be.upload(src, src_raw)
     # gs_transpose_records: dst[c * rows + r] = src[r * cols + c]
     for rows, cols, rec in ((8, 5, 32), (2, 64, 16), (1, 7, 48), (4, 1, 32)):
         raw = bytes(rng.getrandbits(8) for _ in range(rows * cols * rec))

@@ -153,3 +153,14 @@ def test_product_prover_entry(oracle_backend):
     import subprocess
     code = 'import sys, genstark_amd, genstark_amd.prover; assert not any(m.startswith("genstark_amd._mirror") for m in sys.modules), sorted(sys.modules)'
     assert subprocess.run([sys.executable, '-c', code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).returncode == 0
+
+
+def test_packed_seed_gives_the_same_proof(oracle_backend):
+    """Prover.pack_seed: the first rows of a segmented statement packed once; the proof bytes do not change."""
+    import generic_cases as gc
+    from genstark_amd.prover import Prover
+    air, stark, seed, assertions = gc.build('rescue_seg_128', oracle_backend)
+    p = Prover(air, gc.RESCUE_OPTS)
+    packed = p.pack_seed(seed)
+    assert packed.rows == 4 and len(packed.first) == 4 * 4 * 16
+    assert p.prove_bytes(assertions, [], packed) == p.prove_bytes(assertions, [], seed) == stark.serialize(stark.prove(assertions, [], seed))
