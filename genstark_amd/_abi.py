@@ -70,6 +70,7 @@ _SIGNATURES = {
     'gs_vec_div': (_int, [_vp, _vp, _vp, _u64, _vp]),
     'gs_vec_exp': (_int, [_vp, _vp, _bytes, _u64, _vp]),
     'gs_combine_many': (_int, [_vp, _pvp, _bytes, _u32, _u64, _vp]),
+    'gs_combine_adjusted': (_int, [_vp, _pvp, _bytes, _bytes, _u32, _vp, _vp, _u64, _vp]),
     'gs_combine': (_int, [_vp, _vp, _vp, _u64, _vp]),
     'gs_pluck': (_int, [_vp, _vp, _u64, _u64, _u64, _vp]),
     'gs_zero_poly_inverses': (_int, [_vp, _bytes, _u64, _u64, _bytes, _vp]),

@@ -401,10 +401,18 @@ int gs_air_constraints(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, co
     const uint64_t code_bytes = ((uint64_t)ninstr * 16 + 255) & ~(uint64_t)255, const_bytes = (uint64_t)(nconsts ? nconsts : 1) * GS_ELT;
     void *dprog;
     if ((rc = gs_tmp_alloc(c, code_bytes + const_bytes, &dprog))) return rc;
-    hipError_t e = hipMemcpyAsync(dprog, code_host, (size_t)ninstr * 16, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && nconsts) e = hipMemcpyAsync((uint8_t *)dprog + code_bytes, consts_host, (size_t)nconsts * GS_ELT, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // host buffers are pageable and owned by the caller
-    if (e != hipSuccess) { gs_tmp_free(c, dprog); return gs_fail(c, GS_ERR_DEVICE, "air_constraints upload: %s", hipGetErrorString(e)); }
+    {   // assembled in the upload ring, one asynchronous copy (no round trip; the caller's buffers are free at once)
+        void *h = nullptr;
+        if ((rc = gs_push_reserve(c, code_bytes + const_bytes, &h)) == GS_OK) {
+            memcpy(h, code_host, (size_t)ninstr * 16);
+            if (nconsts) memcpy((uint8_t *)h + code_bytes, consts_host, (size_t)nconsts * GS_ELT);
+            rc = gs_push_commit(c, dprog, h, code_bytes + const_bytes);
+        } else if (rc == GS_ERR_UNSUPPORTED) {
+            rc = gs_push(c, dprog, code_host, (uint64_t)ninstr * 16);
+            if (rc == GS_OK && nconsts) rc = gs_push(c, (uint8_t *)dprog + code_bytes, consts_host, (uint64_t)nconsts * GS_ELT);
+        }
+        if (rc) { gs_tmp_free(c, dprog); return rc; }
+    }
     if (c->air_jit) {   // compiled form of the program (air_jit.hip); the interpreter below is the fallback
         int jrc = gs_jit_constraints(c, code_host, ninstr, consts_host, nconsts, vm_regs, registers, sd.offset, sd.len, (const fe *)((uint8_t *)dprog + code_bytes),
                                      (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, (fe *)out);
@@ -419,7 +427,7 @@ int gs_air_constraints(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, co
         hipLaunchKernelGGL(k_air_constraints<32>, grid, block, 0, c->stream, dcode, ninstr, dconst, (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, sd, (fe *)out);
     else
         hipLaunchKernelGGL(k_air_constraints<64>, grid, block, 0, c->stream, dcode, ninstr, dconst, (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, sd, (fe *)out);
-    e = hipGetLastError();
+    hipError_t e = hipGetLastError();
     gs_tmp_free(c, dprog);  // stream-ordered reuse: later users of the block are queued behind this kernel
     if (e != hipSuccess) return gs_fail(c, GS_ERR_DEVICE, "air_constraints launch: %s", hipGetErrorString(e));
     return GS_OK;
@@ -454,13 +462,26 @@ int gs_air_trace_segments(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr,
     void *d;
     if ((rc = gs_tmp_alloc(c, code_b + const_b + stat_b + rows_b, &d))) return rc;
     uint8_t *p = (uint8_t *)d;
-    hipError_t e = hipMemcpyAsync(p, code_host, (size_t)ninstr * 16, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && init_ninstr) e = hipMemcpyAsync(p + main_b, init_code_host, (size_t)init_ninstr * 16, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && nconsts) e = hipMemcpyAsync(p + code_b, consts_host, (size_t)nconsts * GS_ELT, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && nstat) e = hipMemcpyAsync(p + code_b + const_b, static_values_host, (size_t)nstat * GS_ELT, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(p + code_b + const_b + stat_b, first_rows_host, (size_t)rows_b, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { gs_tmp_free(c, d); return gs_fail(c, GS_ERR_DEVICE, "air_trace_segments upload: %s", hipGetErrorString(e)); }
+    {   // assembled in the upload ring, one asynchronous copy (no round trip; the caller's buffers are free at once)
+        void *h = nullptr;
+        const uint64_t total = code_b + const_b + stat_b + rows_b;
+        if ((rc = gs_push_reserve(c, total, &h)) == GS_OK) {
+            uint8_t *hp = (uint8_t *)h;
+            memcpy(hp, code_host, (size_t)ninstr * 16);
+            if (init_ninstr) memcpy(hp + main_b, init_code_host, (size_t)init_ninstr * 16);
+            if (nconsts) memcpy(hp + code_b, consts_host, (size_t)nconsts * GS_ELT);
+            if (nstat) memcpy(hp + code_b + const_b, static_values_host, (size_t)nstat * GS_ELT);
+            memcpy(hp + code_b + const_b + stat_b, first_rows_host, (size_t)rows_b);
+            rc = gs_push_commit(c, p, h, total);
+        } else if (rc == GS_ERR_UNSUPPORTED) {      // a very long list of first rows: part by part
+            rc = gs_push(c, p, code_host, (uint64_t)ninstr * 16);
+            if (rc == GS_OK && init_ninstr) rc = gs_push(c, p + main_b, init_code_host, (uint64_t)init_ninstr * 16);
+            if (rc == GS_OK && nconsts) rc = gs_push(c, p + code_b, consts_host, (uint64_t)nconsts * GS_ELT);
+            if (rc == GS_OK && nstat) rc = gs_push(c, p + code_b + const_b, static_values_host, nstat * GS_ELT);
+            if (rc == GS_OK) rc = gs_push(c, p + code_b + const_b + stat_b, first_rows_host, rows_b);
+        }
+        if (rc) { gs_tmp_free(c, d); return rc; }
+    }
     const uint4 *dcode = (const uint4 *)p, *dinit = (const uint4 *)(p + main_b);
     const fe *dconst = (const fe *)(p + code_b), *dstat = (const fe *)(p + code_b + const_b), *drows = (const fe *)(p + code_b + const_b + stat_b);
     if (c->air_jit) {   // compiled form of the program (air_jit.hip); the interpreter below is the fallback
@@ -494,7 +515,7 @@ int gs_air_trace_segments(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr,
     else if (vm_regs <= 32) GS_LAUNCH_TRACE(32, false, 0);
     else GS_LAUNCH_TRACE(64, false, 0);
 #undef GS_LAUNCH_TRACE
-    e = hipGetLastError();
+    hipError_t e = hipGetLastError();
     gs_tmp_free(c, d);
     if (e != hipSuccess) return gs_fail(c, GS_ERR_DEVICE, "air_trace_segments launch: %s", hipGetErrorString(e));
     return GS_OK;

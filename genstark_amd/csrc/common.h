@@ -71,13 +71,22 @@ struct gs_ctx {
     uint64_t trace_bytes = 0;
     hipEvent_t trace_done = nullptr;
     bool trace_pending = false;
-    // posted read-backs (gs_readback_post / gs_readback_wait): a ring of small slots in mapped pinned memory, one event per slot;
-    // the host waits for THAT slot's event only, whatever else is queued behind it on the stream
+    // posted read-backs (gs_readback_post / gs_readback_wait): a ring of small slots in coherent mapped pinned memory, [RB_SLOTS] x 256
+    // bytes of data followed by [RB_SLOTS] 64-bit flags.  The copying kernel writes the data, then (system-scope release) the slot's
+    // flag = ticket + 1; the host spins on that flag — no event packet on the stream (an event record costs the NEXT kernel ~6 us)
     static constexpr uint32_t RB_SLOTS = 64, RB_SLOT_BYTES = 256;
     void *h_rb = nullptr, *h_rb_dev = nullptr;
-    hipEvent_t rb_events[RB_SLOTS] = {};
     uint32_t rb_bytes[RB_SLOTS] = {};
     uint64_t rb_next = 0;
+    // upload ring (gs_push_reserve / gs_push_commit): small host payloads (programs, coefficient tables, first rows) are assembled
+    // in pinned memory and copied asynchronously — no synchronisation per upload; two halves, a half is reused only after the
+    // copies issued from it have completed (one event per half)
+    static constexpr uint64_t UP_HALF = 8ull << 20;
+    void *h_up = nullptr;
+    uint64_t up_off = 0;
+    int up_half = 0;
+    hipEvent_t up_done[2] = {};
+    bool up_pending[2] = {false, false};
 };
 
 int gs_fail(gs_ctx *c, int code, const char *fmt, ...);
@@ -100,6 +109,11 @@ static inline fe fe_from_u64(uint64_t v) { return fe_make((uint32_t)v, (uint32_t
 // staging helpers (ctx.hip)
 int gs_stage_reserve(gs_ctx *c, uint64_t bytes);
 int gs_defer_flush(gs_ctx *c);                                    // fetch and deliver every queued read-back
+// `bytes` of pinned staging to fill (GS_ERR_UNSUPPORTED: too large for the ring, use a blocking copy), then one asynchronous copy
+// of it to `dst`; the caller's own buffers are free again as soon as it has filled the staging
+int gs_push_reserve(gs_ctx *c, uint64_t bytes, void **host);
+int gs_push_commit(gs_ctx *c, void *dst, const void *host, uint64_t bytes);
+int gs_push(gs_ctx *c, void *dst, const void *host_src, uint64_t bytes);     // both steps for one source; blocking copy when too large
 int gs_trace_begin(gs_ctx *c, uint64_t bytes);   // h_trace has >= bytes and no upload of it is in flight
 int gs_trace_end(gs_ctx *c);                     // call after the last hipMemcpyAsync out of h_trace
 // temp device block from the cache (same lifetime rules as gs_alloc/gs_free)

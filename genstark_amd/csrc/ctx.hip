@@ -3,6 +3,8 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <chrono>
+#include <sched.h>
 
 int gs_fail(gs_ctx *c, int code, const char *fmt, ...) {
     if (c) {
@@ -75,8 +77,9 @@ void gs_ctx_destroy(gs_ctx *c) {
     if (c->d_stage) hipFree(c->d_stage);
     if (c->h_trace) hipHostFree(c->h_trace);
     if (c->trace_done) hipEventDestroy(c->trace_done);
+    if (c->h_up) hipHostFree(c->h_up);
+    for (hipEvent_t e : c->up_done) if (e) hipEventDestroy(e);
     if (c->h_rb) hipHostFree(c->h_rb);
-    for (hipEvent_t e : c->rb_events) if (e) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -148,10 +151,7 @@ int gs_cache_trim(gs_ctx *c) {
 int gs_upload(gs_ctx *c, void *dst, const void *host_src, uint64_t bytes) {
     if (!c || (!dst && bytes) || (!host_src && bytes)) return GS_ERR_ARG;
     if (!bytes) return GS_OK;
-    // pageable source: the runtime stages the copy; synchronise so the caller may reuse host_src at once
-    GS_HIP(c, hipMemcpyAsync(dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
-    GS_HIP(c, hipStreamSynchronize(c->stream));
-    return GS_OK;
+    return gs_push(c, dst, host_src, bytes);      // the caller may reuse host_src at once either way
 }
 
 int gs_download(gs_ctx *c, void *host_dst, const void *src, uint64_t bytes) {
@@ -177,25 +177,71 @@ __global__ void k_gather_words(const uint64_t *__restrict__ addr, uint64_t total
         out[t] = *reinterpret_cast<const uint4 *>(addr[t]);
 }
 
-// words 16-byte words from src into a slot of mapped pinned host memory
-__global__ void k_post_words(const uint4 *__restrict__ src, uint32_t words, uint4 *__restrict__ out) {
+int gs_push_reserve(gs_ctx *c, uint64_t bytes, void **host) {
+    const uint64_t H = gs_ctx::UP_HALF;
+    bytes = (bytes + 255) & ~(uint64_t)255;
+    if (bytes > H / 2) return GS_ERR_UNSUPPORTED;
+    if (!c->h_up) {
+        GS_HIP(c, hipHostMalloc(&c->h_up, 2 * H, hipHostMallocDefault));
+        for (hipEvent_t &e : c->up_done) GS_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (c->up_off + bytes > H) {                          // this half is full: mark its copies, move to the other one
+        GS_HIP(c, hipEventRecord(c->up_done[c->up_half], c->stream));
+        c->up_pending[c->up_half] = true;
+        c->up_half ^= 1;
+        c->up_off = 0;
+        if (c->up_pending[c->up_half]) {
+            GS_HIP(c, hipEventSynchronize(c->up_done[c->up_half]));
+            c->up_pending[c->up_half] = false;
+        }
+    }
+    *host = (uint8_t *)c->h_up + (uint64_t)c->up_half * H + c->up_off;
+    c->up_off += bytes;
+    return GS_OK;
+}
+
+int gs_push_commit(gs_ctx *c, void *dst, const void *host, uint64_t bytes) {
+    GS_HIP(c, hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return GS_OK;
+}
+
+int gs_push(gs_ctx *c, void *dst, const void *host_src, uint64_t bytes) {
+    void *h = nullptr;
+    int rc = gs_push_reserve(c, bytes, &h);
+    if (rc == GS_OK) {
+        memcpy(h, host_src, bytes);
+        return gs_push_commit(c, dst, h, bytes);
+    }
+    if (rc != GS_ERR_UNSUPPORTED) return rc;
+    // large and pageable: the runtime stages the copy; synchronise so the caller may reuse host_src at once
+    GS_HIP(c, hipMemcpyAsync(dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
+    GS_HIP(c, hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+// `words` 16-byte words from src into a slot of mapped pinned host memory, then the slot's flag (one wave; the release fence orders
+// the flag behind the data for the polling host)
+__global__ void k_post_words(const uint4 *__restrict__ src, uint32_t words, uint4 *__restrict__ out, unsigned long long *flag, unsigned long long value) {
     if (threadIdx.x < words) out[threadIdx.x] = src[threadIdx.x];
+    __threadfence_system();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 extern "C" int gs_readback_post(gs_ctx *c, const void *src, uint32_t bytes, uint64_t *ticket) {
     if (!c || !src || !ticket) return GS_ERR_ARG;
     if (!bytes || bytes > gs_ctx::RB_SLOT_BYTES || (bytes & 15)) return gs_fail(c, GS_ERR_ARG, "readback_post: 16..%u bytes, a multiple of 16", gs_ctx::RB_SLOT_BYTES);
+    const size_t data_bytes = (size_t)gs_ctx::RB_SLOTS * gs_ctx::RB_SLOT_BYTES;
     if (!c->h_rb) {
-        GS_HIP(c, hipHostMalloc(&c->h_rb, (size_t)gs_ctx::RB_SLOTS * gs_ctx::RB_SLOT_BYTES, hipHostMallocMapped));
+        GS_HIP(c, hipHostMalloc(&c->h_rb, data_bytes + gs_ctx::RB_SLOTS * sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(c->h_rb, 0, data_bytes + gs_ctx::RB_SLOTS * sizeof(uint64_t));
         GS_HIP(c, hipHostGetDevicePointer(&c->h_rb_dev, c->h_rb, 0));
     }
+    // a slot is reused 64 posts later; its older copy precedes this one on the stream, and flags are ticket numbers: no wait here
     const uint32_t slot = (uint32_t)(c->rb_next % gs_ctx::RB_SLOTS);
-    if (!c->rb_events[slot]) GS_HIP(c, hipEventCreateWithFlags(&c->rb_events[slot], hipEventDisableTiming));
-    else GS_HIP(c, hipEventSynchronize(c->rb_events[slot]));          // a ticket 64 posts old (abandoned or not): its copy has long landed
     hipLaunchKernelGGL(k_post_words, dim3(1), dim3(64), 0, c->stream, (const uint4 *)src, bytes / 16,
-                       (uint4 *)((uint8_t *)c->h_rb_dev + (size_t)slot * gs_ctx::RB_SLOT_BYTES));
+                       (uint4 *)((uint8_t *)c->h_rb_dev + (size_t)slot * gs_ctx::RB_SLOT_BYTES),
+                       (unsigned long long *)((uint8_t *)c->h_rb_dev + data_bytes) + slot, (unsigned long long)(c->rb_next + 1));
     GS_LAUNCH_CHECK(c);
-    GS_HIP(c, hipEventRecord(c->rb_events[slot], c->stream));
     c->rb_bytes[slot] = bytes;
     *ticket = c->rb_next++;
     return GS_OK;
@@ -205,7 +251,22 @@ extern "C" int gs_readback_wait(gs_ctx *c, uint64_t ticket, void *host_dst) {
     if (!c || !host_dst) return GS_ERR_ARG;
     if (ticket >= c->rb_next || c->rb_next - ticket > gs_ctx::RB_SLOTS) return gs_fail(c, GS_ERR_ARG, "readback_wait: ticket %llu is not outstanding", (unsigned long long)ticket);
     const uint32_t slot = (uint32_t)(ticket % gs_ctx::RB_SLOTS);
-    GS_HIP(c, hipEventSynchronize(c->rb_events[slot]));
+    const size_t data_bytes = (size_t)gs_ctx::RB_SLOTS * gs_ctx::RB_SLOT_BYTES;
+    const volatile uint64_t *flag = (const volatile uint64_t *)((const uint8_t *)c->h_rb + data_bytes) + slot;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto checked = t0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != ticket + 1) {
+        const auto now = std::chrono::steady_clock::now();
+        if (now - t0 < std::chrono::microseconds(20)) __builtin_ia32_pause();      // a copy that is about to land
+        else sched_yield();                                                        // a long wait: other lanes' host work goes first
+        if (now - checked > std::chrono::microseconds(200)) {      // is the queue still alive?  (an idle queue with the flag unset: the copy was lost)
+            checked = now;
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) return gs_fail(c, GS_ERR_DEVICE, "readback_wait: %s", hipGetErrorString(q));
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != ticket + 1) return gs_fail(c, GS_ERR_DEVICE, "readback_wait: the queue drained without delivering ticket %llu", (unsigned long long)ticket);
+        }
+    }
     memcpy(host_dst, (const uint8_t *)c->h_rb + (size_t)slot * gs_ctx::RB_SLOT_BYTES, c->rb_bytes[slot]);
     return GS_OK;
 }

@@ -350,9 +350,7 @@ int gs_hash_merge_rows(gs_ctx *c, gs_hash_alg alg, const void *const *vecs_host,
         // 8 bytes per register; every column of a row is still hashed in one pass)
         void *tab = nullptr;
         if ((rc = gs_tmp_alloc(c, (uint64_t)count * sizeof(void *), &tab))) return rc;
-        hipError_t e = hipMemcpyAsync(tab, vecs_host, (size_t)count * sizeof(void *), hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // vecs_host belongs to the caller
-        if (e != hipSuccess) { gs_tmp_free(c, tab); return gs_fail(c, GS_ERR_DEVICE, "hash_merge_rows: pointer table upload: %s", hipGetErrorString(e)); }
+        if ((rc = gs_push(c, tab, vecs_host, (uint64_t)count * sizeof(void *)))) { gs_tmp_free(c, tab); return rc; }      // vecs_host belongs to the caller
         if (alg == GS_HASH_SHA256)
             hipLaunchKernelGGL(k_hash_merge_rows_table<0>, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const uint4 *const *)tab, count, n, (uint4 *)out);
         else

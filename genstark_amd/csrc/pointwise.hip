@@ -238,6 +238,31 @@ __global__ void k_combine_many(CombineArgs va, uint32_t count, uint64_t n, int a
     }
 }
 
+// out[i] = sum_j k_j v_j[i]  +  powers[i] * sum_j kp_j v_j[i]  (+ plus[i]): a merge with its degree adjustment (gs_combine_adjusted)
+struct CombineAdjArgs {
+    const fe *v[GS_MAX_COMBINE];
+    fe k[GS_MAX_COMBINE];
+    fe kp[GS_MAX_COMBINE];
+};
+template <int HAS_K, int HAS_KP>
+__global__ void k_combine_adjusted(CombineAdjArgs va, uint32_t count, uint64_t n, const fe *__restrict__ powers, const fe *plus, fe *out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        fe x = va.v[0][i];
+        fe a = HAS_K ? fe_mul(x, va.k[0]) : x, b = HAS_KP ? fe_mul(x, va.kp[0]) : x;
+        for (uint32_t j = 1; j < count; j++) {
+            x = va.v[j][i];
+            if (HAS_K) a = fe_add(a, fe_mul(x, va.k[j]));
+            if (HAS_KP) b = fe_add(b, fe_mul(x, va.kp[j]));
+        }
+        fe s;
+        if (HAS_K && HAS_KP) s = fe_add(a, fe_mul(b, powers[i]));
+        else if (HAS_KP) s = fe_mul(b, powers[i]);
+        else s = a;
+        if (plus) s = fe_add(s, plus[i]);
+        out[i] = s;
+    }
+}
+
 // ---- dot product -> one element ---------------------------------------------------------------------
 __device__ __forceinline__ fe block_reduce_add(fe s, fe *sh) {
     // wave reduce via shuffles, then one LDS step across the (<= 4) waves of the block
@@ -498,6 +523,33 @@ int gs_combine_many(gs_ctx *c, const void *const *vecs_host, const uint8_t *coef
             va.k[j] = j < m ? fe_from_bytes(coeffs_host + GS_ELT * (base + j)) : fe_zero();
         }
         hipLaunchKernelGGL(k_combine_many, dim3(gs_grid(n)), dim3(256), 0, c->stream, va, m, n, base ? 1 : 0, (fe *)out);
+        GS_LAUNCH_CHECK(c);
+    }
+    return GS_OK;
+}
+
+int gs_combine_adjusted(gs_ctx *c, const void *const *vecs_host, const uint8_t *coeffs_host, const uint8_t *adj_coeffs_host, uint32_t count,
+                        const void *powers, const void *plus, uint64_t n, void *out) {
+    if (!c || !vecs_host || !out || (!coeffs_host && !adj_coeffs_host) || (adj_coeffs_host && !powers)) return GS_ERR_ARG;
+    if (count == 0) return gs_fail(c, GS_ERR_ARG, "combine_adjusted: no vectors");
+    if (!n) return GS_OK;
+    // GS_MAX_COMBINE vectors per launch (pointers and both coefficient lists as kernel arguments); later batches add to `out`
+    for (uint32_t base = 0; base < count; base += GS_MAX_COMBINE) {
+        const uint32_t m = count - base < GS_MAX_COMBINE ? count - base : GS_MAX_COMBINE;
+        CombineAdjArgs va;
+        for (uint32_t j = 0; j < GS_MAX_COMBINE; j++) {
+            va.v[j] = (const fe *)vecs_host[base + (j < m ? j : 0)];
+            va.k[j] = j < m && coeffs_host ? fe_from_bytes(coeffs_host + GS_ELT * (base + j)) : fe_zero();
+            va.kp[j] = j < m && adj_coeffs_host ? fe_from_bytes(adj_coeffs_host + GS_ELT * (base + j)) : fe_zero();
+        }
+        const fe *pl = base ? (const fe *)out : (const fe *)plus;
+        const dim3 grid(gs_grid(n)), block(256);
+        if (coeffs_host && adj_coeffs_host)
+            hipLaunchKernelGGL((k_combine_adjusted<1, 1>), grid, block, 0, c->stream, va, m, n, (const fe *)powers, pl, (fe *)out);
+        else if (adj_coeffs_host)
+            hipLaunchKernelGGL((k_combine_adjusted<0, 1>), grid, block, 0, c->stream, va, m, n, (const fe *)powers, pl, (fe *)out);
+        else
+            hipLaunchKernelGGL((k_combine_adjusted<1, 0>), grid, block, 0, c->stream, va, m, n, (const fe *)powers, pl, (fe *)out);
         GS_LAUNCH_CHECK(c);
     }
     return GS_OK;

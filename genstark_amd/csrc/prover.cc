@@ -33,7 +33,7 @@ namespace {
 // ---- the slice of the ABI this driver uses, resolved at bind time ------------------------------------------------------
 #define GS_API_LIST(X)                                                                                                        \
     X(gs_alloc) X(gs_free) X(gs_upload) X(gs_download) X(gs_gather) X(gs_last_error) X(gs_power_series) X(gs_vec_add) X(gs_vec_mul) \
-    X(gs_vec_sub_scalar) X(gs_vec_div) X(gs_combine_many) X(gs_pluck) X(gs_transpose_vector) X(gs_sub_matrix_from_vectors)     \
+    X(gs_vec_sub_scalar) X(gs_vec_div) X(gs_combine_many) X(gs_combine_adjusted) X(gs_pluck) X(gs_transpose_vector) X(gs_sub_matrix_from_vectors)     \
     X(gs_eval_polys_at_roots) X(gs_interpolate_roots) X(gs_interpolate_quartic_domain) X(gs_eval_quartic_batch)                \
     X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_commit_rows) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
     X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
@@ -280,6 +280,7 @@ int gs_prover_bind(void *dl_handle) {
 }
 
 static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out);
+static bool remainder_is_low_degree(const std::vector<F> &remainder, uint64_t E, uint64_t m, F rou, int method);
 
 // Serialized proof into out[0..cap); *len receives the size (also when cap is too small: GS_ERR_ARG then).
 int gs_prover_prove(gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, uint64_t cap, uint64_t *len, char *err, uint64_t errcap) {
@@ -298,6 +299,21 @@ int gs_prover_prove(gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, 
         return f.code ? f.code : GS_ERR_ARG;
     } catch (const std::exception &e) {
         if (err && errcap) snprintf(err, (size_t)errcap, "%s", e.what());
+        return GS_ERR_OOM;
+    }
+}
+
+int gs_prover_remainder_check(const uint8_t *values, uint64_t len, uint32_t extension_factor, uint64_t max_degree_plus1, const uint8_t *root_of_unity,
+                              int method) {
+    if (!values || !root_of_unity || !len || (method != 0 && method != 1)) return GS_ERR_ARG;
+    if (!g_bound) return GS_ERR_UNSUPPORTED;
+    try {
+        std::vector<F> v(len);
+        for (uint64_t i = 0; i < len; i++) v[i] = from16(values + 16 * i);
+        return remainder_is_low_degree(v, extension_factor, max_degree_plus1, from16(root_of_unity), method) ? 1 : 0;
+    } catch (const Fail &f) {
+        return f.code ? f.code : GS_ERR_ARG;
+    } catch (const std::exception &) {
         return GS_ERR_OOM;
     }
 }
@@ -342,6 +358,63 @@ struct PhaseClock {
         last = now;
     }
 };
+
+// LowDegreeProver.verifyRemainder (:223-252): the remainder — `len` values on the powers of `rou` (order len) — must agree, at
+// every position i that is not a multiple of E, with the polynomial of degree < m through the first m of those positions.
+//   method 0: as the reference does it (interpolate the first m, evaluate at the rest: ~3 m^2 products);
+//   method 1: the same predicate on coefficients.  The excluded points rou^(E j) are the B-th roots of unity, B = len / E, so the
+//     checked points are the roots of V(x) = (x^len - 1)/(x^B - 1) = 1 + x^B + x^2B + ...  Let g be the interpolant of ALL len values
+//     (an inverse transform of size len).  A polynomial f of degree < m agrees with g on the roots of V  <=>  g - f = V h with
+//     deg h < B  <=>  the coefficients g_k, k >= m, depend on k mod B only (V h is h's coefficients repeated E times).  That f is
+//     the reference's interpolant (degree < m through m of the points), so both methods accept exactly the same remainders;
+//     len log len products instead of 3 m^2.  Used when E divides len (always, for the domains of this prover).
+// returns true when the remainder passes
+static bool remainder_is_low_degree(const std::vector<F> &remainder, uint64_t E, uint64_t m, F rou, int method) {
+    const uint64_t len = remainder.size();
+    std::vector<uint64_t> positions;
+    for (uint64_t i = 0; i < len; i++) if (!E || i % E) positions.push_back(i);
+    if (m > positions.size()) fail(GS_ERR_ARG, "Remainder degree is greater than number of remainder values");
+    if (!m || m == positions.size()) return true;
+    if (method == 1 && E && len >= E && len % E == 0 && !(len & (len - 1))) {
+        const uint64_t B = len / E;
+        std::vector<F> g(len), w(len / 2 ? len / 2 : 1);
+        int lg = 0;
+        while ((1ull << lg) < len) lg++;
+        for (uint64_t i = 0; i < len; i++) {               // bit-reversed input, decimation in time
+            uint64_t r = 0;
+            for (int b = 0; b < lg; b++) r |= ((i >> b) & 1) << (lg - 1 - b);
+            g[r] = remainder[i];
+        }
+        const F inv = hf_pow(rou, (hfe)(len - 1));          // rou^-1
+        F cur = 1;
+        for (uint64_t i = 0; i < len / 2; i++) { w[i] = cur; cur = hf_mul(cur, inv); }
+        for (uint64_t half = 1; half < len; half <<= 1)
+            for (uint64_t base = 0; base < len; base += 2 * half)
+                for (uint64_t j = 0; j < half; j++) {
+                    const F t = hf_mul(g[base + half + j], w[j * (len / (2 * half))]);
+                    const F u = g[base + j];
+                    g[base + j] = hf_add(u, t);
+                    g[base + half + j] = hf_sub(u, t);
+                }
+        // (unscaled: the predicate compares coefficients with each other)
+        for (uint64_t k = m; k + B < len; k++)
+            if (g[k] != g[k + B]) return false;
+        return true;
+    }
+    std::vector<F> domain(len);
+    F cur = 1;
+    for (uint64_t i = 0; i < len; i++) { domain[i] = cur; cur = hf_mul(cur, rou); }
+    Bytes xs(m * 16), ys(m * 16), poly(m * 16);
+    for (uint64_t i = 0; i < m; i++) { le16(domain[positions[i]], xs.data() + 16 * i); le16(remainder[positions[i]], ys.data() + 16 * i); }
+    if (A.gs_small_interpolate(xs.data(), ys.data(), (uint32_t)m, poly.data())) fail(GS_ERR_ARG, "gs_small_interpolate failed");
+    const uint32_t rest = (uint32_t)(positions.size() - m);
+    Bytes rx(rest * 16), rv(rest * 16);
+    for (uint32_t i = 0; i < rest; i++) le16(domain[positions[m + i]], rx.data() + 16 * i);
+    if (A.gs_small_eval_poly(poly.data(), (uint32_t)m, rx.data(), rest, rv.data())) fail(GS_ERR_ARG, "gs_small_eval_poly failed");
+    for (uint32_t i = 0; i < rest; i++)
+        if (from16(rv.data() + 16 * i) != remainder[positions[m + i]]) return false;
+    return true;
+}
 
 static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     PhaseClock clock;
@@ -400,6 +473,20 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         x.check(A.gs_power_series(x.c, s16, N, psbPowers.p), "gs_power_series(psb)");
     }
 
+    // MiMC: the cyclic register K over the evaluation domain — its 64 coefficients from the composition-domain table, then its values
+    // at the (k_len * N/Nc)-th roots of unity (the constraint is evaluated on all N points from the extension of P)
+    Buf kN;
+    uint64_t klen_n = 0;
+    if (air.kind == 0) {
+        klen_n = air.k_len * (N / Nc);
+        Buf kPoly(x, air.k_len * ELEM);
+        kN = Buf(x, klen_n * ELEM);
+        le16(hf_pow(omega, (hfe)(N / air.k_len)), s16);
+        x.check(counted_interpolate_roots(x.c, air.k_table, 1, s16, air.k_len, kPoly.p), "gs_interpolate_roots(K)");
+        le16(hf_pow(omega, (hfe)(N / klen_n)), s16);
+        x.check(counted_eval_polys_at_roots(x.c, kPoly.p, 1, air.k_len, s16, klen_n, kN.p), "gs_eval_polys_at_roots(K)");
+    }
+
     clock.mark("context + trace-independent work issued");
     // 2 ----- execution trace (:97) and the assertions it must satisfy (:356-375)
     Buf trace(x, (uint64_t)R * T * ELEM);
@@ -412,20 +499,13 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     else
         x.check(A.gs_air_trace(x.c, air.t_code, air.t_ninstr, air.consts, air.nconsts, air.vm_regs, R, air.static_values, air.static_periods,
                                air.nstatic, air.first_rows, T, trace.p), "gs_air_trace");
-    {
-        std::vector<uint64_t> pos;
-        for (uint32_t i = 0; i < job.nassertions; i++) {
-            const gs_assertion &a = job.assertions[i];
-            if (a.reg >= R) fail(GS_ERR_ARG, "Invalid assertion: register %u is outside of register bank", a.reg);
-            if (a.step >= T) fail(GS_ERR_ARG, "Invalid assertion: step %llu is outside of execution trace", (unsigned long long)a.step);
-            pos.push_back((uint64_t)a.reg * T + a.step);
-        }
-        Bytes got(pos.size() * ELEM);
-        x.check(A.gs_gather(x.c, trace.p, ELEM, pos.data(), pos.size(), got.data()), "gs_gather(asserted cells)");
-        for (uint32_t i = 0; i < job.nassertions; i++)
-            if (memcmp(got.data() + i * ELEM, job.assertions[i].value, 16))
-                fail(GS_ERR_ARG, "Assertion at step %llu, register %u conflicts with execution trace", (unsigned long long)job.assertions[i].step,
-                     job.assertions[i].reg);
+    // the asserted cells (:356-375) are compared when the evaluation root comes back: one round trip for both
+    std::vector<uint64_t> asserted_at;
+    for (uint32_t i = 0; i < job.nassertions; i++) {
+        const gs_assertion &a = job.assertions[i];
+        if (a.reg >= R) fail(GS_ERR_ARG, "Invalid assertion: register %u is outside of register bank", a.reg);
+        if (a.step >= T) fail(GS_ERR_ARG, "Invalid assertion: step %llu is outside of execution trace", (unsigned long long)a.step);
+        asserted_at.push_back((uint64_t)a.reg * T + a.step);
     }
 
     clock.mark("execution trace (host recurrence)");
@@ -433,7 +513,6 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     Buf pPolys(x, (uint64_t)R * T * ELEM), pEval(x, (uint64_t)R * N * ELEM);
     le16(exec_rou, s16);
     x.check(counted_interpolate_roots(x.c, trace.p, R, s16, T, pPolys.p), "gs_interpolate_roots(trace)");
-    trace.release();
     le16(omega, s16);
     x.check(counted_eval_polys_at_roots(x.c, pPolys.p, R, T, s16, N, pEval.p), "gs_eval_polys_at_roots(P)");
     std::vector<const void *> pRows(R);
@@ -443,9 +522,9 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     const uint32_t V = (uint32_t)eVectors.size();
 
     // 4 ----- evaluation Merkle tree (:113-118)
-    Tree eTree = commit_rows(x, alg, eVectors.data(), V, N);
+    Tree eTree = commit_rows(x, alg, eVectors.data(), V, N, false);
 
-    clock.mark("P(x), extension, evaluation tree root");
+    clock.mark("P(x), extension, evaluation tree issued");
     // 5 ----- composition polynomial (CompositionPolynomial.ts:29-146)
     // boundary constraints per asserted register, in order of first appearance (BoundaryConstraints.ts:15-45)
     struct RegData { uint32_t reg; std::vector<F> xs, ys; std::vector<uint64_t> at; };   // at: positions of the xs in the evaluation domain
@@ -471,7 +550,23 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     uint32_t dcount = air.nconstraints;
     for (auto &g : groups) if (g.first < combination_degree) dcount += (uint32_t)g.second.size();
     uint32_t bcoef = bcount * (composition_degree > T ? 2 : 1);
-    std::vector<F> coefficients = prng_many(eTree.root, dcount + bcoef);
+    // The coefficients come from the evaluation root (:121): it is read where the first of them is needed, with the asserted cells —
+    // the work that needs neither (constraint evaluation, degree adjustment) is queued first and covers the round trip
+    std::vector<F> coefficients;
+    auto read_evaluation_root = [&] {
+        Bytes got(asserted_at.size() * ELEM);
+        const uint64_t one = 1;                        // record 1 of a node array (32-byte records) is the root
+        DeferWindow win(x);
+        x.check(A.gs_gather(x.c, trace.p, ELEM, asserted_at.data(), asserted_at.size(), got.data()), "gs_gather(asserted cells)");
+        x.check(A.gs_gather(x.c, eTree.nodes.p, DIGEST, &one, 1, eTree.root.data()), "gs_gather(root)");
+        win.end();
+        for (uint32_t i = 0; i < job.nassertions; i++)
+            if (memcmp(got.data() + i * ELEM, job.assertions[i].value, 16))
+                fail(GS_ERR_ARG, "Assertion at step %llu, register %u conflicts with execution trace", (unsigned long long)job.assertions[i].step,
+                     job.assertions[i].reg);
+        trace.release();
+        coefficients = prng_many(eTree.root, dcount + bcoef);
+    };
     auto coeff_bytes = [&](size_t from, size_t count) {
         Bytes b(count * 16);
         for (size_t i = 0; i < count; i++) le16(coefficients[from + i], b.data() + 16 * i);
@@ -481,13 +576,8 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     Buf cEval(x, N * ELEM);
     bool lc_fused = false;                     // cEval already holds L (LinearCombination folded into the composition kernel)
     if (fused) {
-        // K over the evaluation domain (see below), the interpolant through the assertions, then one kernel for :71-146
-        const uint64_t klen_n = air.k_len * (N / Nc);
-        Buf kPoly(x, air.k_len * ELEM), kN(x, klen_n * ELEM);
-        le16(hf_pow(omega, (hfe)(N / air.k_len)), s16);
-        x.check(counted_interpolate_roots(x.c, air.k_table, 1, s16, air.k_len, kPoly.p), "gs_interpolate_roots(K)");
-        le16(hf_pow(omega, (hfe)(N / klen_n)), s16);
-        x.check(counted_eval_polys_at_roots(x.c, kPoly.p, 1, air.k_len, s16, klen_n, kN.p), "gs_eval_polys_at_roots(K)");
+        // K over the evaluation domain (issued before the trace), the interpolant through the assertions, then one kernel for :71-146
+        read_evaluation_root();
         const RegData &d = rdata[0];
         const uint32_t m = (uint32_t)d.xs.size();
         Bytes xs(m * 16), ys(m * 16), ipoly(m * 16);
@@ -520,14 +610,6 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         const F q_rou = direct ? omega : comp_rou;
         Buf q(x, (uint64_t)air.nconstraints * Nq * ELEM);
         if (direct) {
-            // the cyclic register over the evaluation domain: K's 64 coefficients from its composition-domain table, then its values
-            // at the (k_len * N/Nc)-th roots of unity
-            const uint64_t klen_n = air.k_len * (N / Nc);
-            Buf kPoly(x, air.k_len * ELEM), kN(x, klen_n * ELEM);
-            le16(hf_pow(omega, (hfe)(N / air.k_len)), s16);
-            x.check(counted_interpolate_roots(x.c, air.k_table, 1, s16, air.k_len, kPoly.p), "gs_interpolate_roots(K)");
-            le16(hf_pow(omega, (hfe)(N / klen_n)), s16);
-            x.check(counted_eval_polys_at_roots(x.c, kPoly.p, 1, air.k_len, s16, klen_n, kN.p), "gs_eval_polys_at_roots(K)");
             x.check(A.gs_mimc_constraints(x.c, pRows[0], N, N / T, kN.p, klen_n, q.p), "gs_mimc_constraints");
         } else {
             // P over the composition domain is every (N/Nc)-th element of the extension just computed (:76)
@@ -537,28 +619,40 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
             x.check(A.gs_air_constraints(x.c, air.e_code, air.e_ninstr, air.consts, air.nconsts, air.vm_regs, R, air.nconstraints, pComp.p, Nc,
                                          Nc / T, air.static_tables, air.static_lens, air.nstatic, q.p), "gs_air_constraints");
         }
-        // 5.2 degree adjustment (:83-101) and 5.3 merge + extension (:103-111)
+        // 5.2 degree adjustment (:83-101) and 5.3 merge + extension (:103-111): the adjusted vectors q_i o powers are not
+        // materialised — gs_combine_adjusted merges sum k_i q_i + powers o sum k'_i q_i in one pass (one further pass per additional
+        // group of constraints with a degree of its own: different powers)
         std::vector<const void *> qa;
         for (uint32_t i = 0; i < air.nconstraints; i++) qa.push_back(q.at((uint64_t)i * Nq * ELEM));
-        std::vector<Buf> adjusted;
-        for (auto &g : groups) {
-            if (g.first == combination_degree) continue;
-            Buf powers(x, Nq * ELEM);
-            le16(hf_pow(q_rou, (hfe)(combination_degree - g.first)), s16);
-            x.check(A.gs_power_series(x.c, s16, Nq, powers.p), "gs_power_series(q powers)");
-            for (uint32_t i : g.second) {
-                adjusted.emplace_back(x, Nq * ELEM);
-                x.check(A.gs_vec_mul(x.c, qa[i], powers.p, Nq, adjusted.back().p), "gs_vec_mul");
-                qa.push_back(adjusted.back().p);
+        read_evaluation_root();
+        Buf qe(x, N * ELEM), qc;
+        if (!direct) qc = Buf(x, Nc * ELEM);
+        void *merged = direct ? qe.p : qc.p;
+        {
+            Bytes plain = coeff_bytes(0, air.nconstraints);
+            uint32_t next = air.nconstraints;                       // coefficients of the adjusted terms follow, group by group
+            bool first = true;
+            for (auto &g : groups) {
+                if (g.first == combination_degree) continue;
+                Buf powers(x, Nq * ELEM);
+                le16(hf_pow(q_rou, (hfe)(combination_degree - g.first)), s16);
+                x.check(A.gs_power_series(x.c, s16, Nq, powers.p), "gs_power_series(q powers)");
+                if (first) {                                         // every constraint's plain term + this group's adjusted terms
+                    Bytes adj(air.nconstraints * 16, 0);
+                    for (uint32_t i : g.second) le16(coefficients[next++], adj.data() + 16 * i);
+                    x.check(A.gs_combine_adjusted(x.c, qa.data(), plain.data(), adj.data(), air.nconstraints, powers.p, nullptr, Nq, merged), "gs_combine_adjusted(Q)");
+                } else {
+                    std::vector<const void *> members;
+                    Bytes adj(g.second.size() * 16);
+                    for (size_t k = 0; k < g.second.size(); k++) { members.push_back(qa[g.second[k]]); le16(coefficients[next++], adj.data() + 16 * k); }
+                    x.check(A.gs_combine_adjusted(x.c, members.data(), nullptr, adj.data(), (uint32_t)members.size(), powers.p, merged, Nq, merged), "gs_combine_adjusted(Q)");
+                }
+                first = false;
             }
+            if (first) x.check(A.gs_combine_many(x.c, qa.data(), plain.data(), air.nconstraints, Nq, merged), "gs_combine_many(Q)");
         }
-        Buf qe(x, N * ELEM);
-        Bytes dco = coeff_bytes(0, dcount);
-        if (direct) {
-            x.check(A.gs_combine_many(x.c, qa.data(), dco.data(), dcount, N, qe.p), "gs_combine_many(Q)");
-        } else {
-            Buf qc(x, Nc * ELEM), qcPoly(x, Nc * ELEM);
-            x.check(A.gs_combine_many(x.c, qa.data(), dco.data(), dcount, Nc, qc.p), "gs_combine_many(Q)");
+        if (!direct) {
+            Buf qcPoly(x, Nc * ELEM);
             le16(comp_rou, s16);
             x.check(counted_interpolate_roots(x.c, qc.p, 1, s16, Nc, qcPoly.p), "gs_interpolate_roots(Q)");
             le16(omega, s16);
@@ -624,20 +718,12 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
             x.check(A.gs_vec_div(x.c, pi.p, zValues.p, (uint64_t)bcount * N, bEval.p), "gs_vec_div(B)");
         }
         iValues.release(); pi.release();
-        // 5.6 degree adjustment of B (:124-138) and 5.7 merge (:140-146)
+        // 5.6 degree adjustment of B (:124-138) and 5.7 merge (:140-146), with D added in the same pass
         std::vector<const void *> ba;
         for (uint32_t i = 0; i < bcount; i++) ba.push_back(bEval.at((uint64_t)i * N * ELEM));
-        std::vector<Buf> badj;
-        if (b_inc > 0)
-            for (uint32_t i = 0; i < bcount; i++) {
-                badj.emplace_back(x, N * ELEM);
-                x.check(A.gs_vec_mul(x.c, ba[i], psbPowers.p, N, badj.back().p), "gs_vec_mul(B powers)");
-                ba.push_back(badj.back().p);
-            }
-        Buf bc(x, N * ELEM);
         Bytes bco = coeff_bytes(dcount, bcoef);
-        x.check(A.gs_combine_many(x.c, ba.data(), bco.data(), bcoef, N, bc.p), "gs_combine_many(B)");
-        x.check(A.gs_vec_add(x.c, dEval.p, bc.p, N, cEval.p), "gs_vec_add(C)");
+        x.check(A.gs_combine_adjusted(x.c, ba.data(), bco.data(), b_inc > 0 ? bco.data() + 16 * bcount : nullptr, bcount, b_inc > 0 ? psbPowers.p : nullptr,
+                                      dEval.p, N, cEval.p), "gs_combine_adjusted(B + D)");
     }
     if (!fused) zInverses.release();
 
@@ -647,26 +733,18 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         lEval = std::move(cEval);
     } else {
         lEval = Buf(x, N * ELEM);
-        std::vector<const void *> all(eVectors.begin(), eVectors.end());
-        std::vector<Buf> ps2;
-        if (b_inc > 0)                                             // psIncrementalDegree = compositionDegree - T, same powers
-            for (uint32_t r = 0; r < V; r++) {
-                ps2.emplace_back(x, N * ELEM);
-                x.check(A.gs_vec_mul(x.c, eVectors[r], psbPowers.p, N, ps2.back().p), "gs_vec_mul(P powers)");
-                all.push_back(ps2.back().p);
-            }
-        const uint32_t offset = dcount + bcoef, cnt = (uint32_t)all.size();
+        // psIncrementalDegree = compositionDegree - T: the same powers as B's; P_r o powers is not materialised, C is added in the pass
+        const uint32_t offset = dcount + bcoef, cnt = b_inc > 0 ? 2 * V : V;
         std::vector<F> co = prng_many(eTree.root, offset + cnt);
         Bytes cb(cnt * 16);
         for (uint32_t i = 0; i < cnt; i++) le16(co[offset + i], cb.data() + 16 * i);
-        Buf comb(x, N * ELEM);
-        x.check(A.gs_combine_many(x.c, all.data(), cb.data(), cnt, N, comb.p), "gs_combine_many(P)");
-        x.check(A.gs_vec_add(x.c, cEval.p, comb.p, N, lEval.p), "gs_vec_add(L)");
+        x.check(A.gs_combine_adjusted(x.c, eVectors.data(), cb.data(), b_inc > 0 ? cb.data() + 16 * V : nullptr, V, b_inc > 0 ? psbPowers.p : nullptr, cEval.p, N,
+                                      lEval.p), "gs_combine_adjusted(L)");
     }
     cEval.release();
     psbPowers.release();
 
-    clock.mark("composition + linear combination issued");
+    clock.mark("composition + linear combination issued (evaluation root read inside)");
     // 7 ----- low-degree proof (LowDegreeProver.ts:39-68, 176-221)
     if (N < 128) fail(GS_ERR_ARG, "Invalid array length");
     // transposeVector(v, 4) is never materialised: row r of it is v[r], v[r + rows], v[r + 2 rows], v[r + 3 rows], which the hashing,
@@ -756,6 +834,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         rb.prove_batch(x, *L.pTree, positions, &c.polyProof);
         rb.gather_rows4(x, L.column, L.rows, positions, &c.polyProof);
     }
+    clock.mark("roots awaited one by one; query positions + batch-proof plans (while the device folds)");
     std::vector<F> remainder(len);
     Bytes remainder_raw(len * ELEM);
     {
@@ -763,36 +842,16 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         for (uint64_t i = 0; i < len; i++) all[i] = i;
         x.check(A.gs_gather(x.c, column_src, ELEM, all.data(), len, remainder_raw.data()), "gs_gather(remainder)");
     }
-    clock.mark("roots awaited one by one; query positions + batch-proof plans (while the device folds)");
     win.end();
-    clock.mark("remainder + query answers fetched (the one synchronisation)");
+    clock.mark("remainder + query answers fetched (one synchronisation)");
     {
         Bytes &raw = remainder_raw;
         for (uint64_t i = 0; i < len; i++) remainder[i] = from16(raw.data() + 16 * i);
         // verifyRemainder (:223-252)
         F rou = omega;
         for (uint32_t d = 0; d < depth; d++) { rou = hf_mul(rou, rou); rou = hf_mul(rou, rou); }      // omega^(4^depth)
-        std::vector<uint64_t> positions;
-        for (uint64_t i = 0; i < len; i++) if (i % E) positions.push_back(i);
-        std::vector<F> domain(len);
-        F cur = 1;
-        for (uint64_t i = 0; i < len; i++) { domain[i] = cur; cur = hf_mul(cur, rou); }
-        if (max_degree_plus1 > positions.size()) fail(GS_ERR_ARG, "Remainder degree is greater than number of remainder values");
-        const uint32_t m = (uint32_t)max_degree_plus1;
-        if (m) {
-            Bytes xs(m * 16), ys(m * 16), poly(m * 16);
-            for (uint32_t i = 0; i < m; i++) { le16(domain[positions[i]], xs.data() + 16 * i); le16(remainder[positions[i]], ys.data() + 16 * i); }
-            if (A.gs_small_interpolate(xs.data(), ys.data(), m, poly.data())) fail(GS_ERR_ARG, "gs_small_interpolate failed");
-            const uint32_t rest = (uint32_t)positions.size() - m;
-            if (rest) {
-                Bytes rx(rest * 16), rv(rest * 16);
-                for (uint32_t i = 0; i < rest; i++) le16(domain[positions[m + i]], rx.data() + 16 * i);
-                if (A.gs_small_eval_poly(poly.data(), m, rx.data(), rest, rv.data())) fail(GS_ERR_ARG, "gs_small_eval_poly failed");
-                for (uint32_t i = 0; i < rest; i++)
-                    if (from16(rv.data() + 16 * i) != remainder[positions[m + i]])
-                        fail(GS_ERR_ARG, "Low degree proof failed: Remainder is not a valid degree %u polynomial", m - 1);
-            }
-        }
+        if (!remainder_is_low_degree(remainder, E, max_degree_plus1, rou, 1))
+            fail(GS_ERR_ARG, "Low degree proof failed: Remainder is not a valid degree %llu polynomial", (unsigned long long)(max_degree_plus1 - 1));
     }
     clock.mark("remainder checked");
     if (V > 1) {

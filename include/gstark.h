@@ -139,6 +139,14 @@ int gs_vec_exp(gs_ctx *ctx, const void *a, const gs_elt *e, uint64_t n, void *ou
  * device pointers; coeffs_host: count*16 bytes.  CompositionPolynomial.ts:105,142; LinearCombination.ts:60 */
 int gs_combine_many(gs_ctx *ctx, const void *const *vecs_host, const uint8_t *coeffs_host,
                     uint32_t count, uint64_t n, void *out);
+/* A merge together with its degree adjustment (CompositionPolynomial.ts:83-107 for Q, :124-146 for B; LinearCombination.ts:44-63):
+ *   out[i] = sum_j coeffs[j] * v_j[i]  +  powers[i] * sum_j adj_coeffs[j] * v_j[i]  (+ plus[i])
+ * — the reference materialises every adjusted vector v_j o powers (mulVectorElements) and merges 2*count vectors; the sum is the
+ * same field element (sum_j k'_j (v_j[i] powers[i]) = powers[i] sum_j k'_j v_j[i]), the vectors are read once and nothing
+ * intermediate is written.  coeffs_host or adj_coeffs_host may be NULL (that sum is absent; powers is only read with
+ * adj_coeffs_host); plus may be NULL, and may be `out`.  Called by the native driver. */
+int gs_combine_adjusted(gs_ctx *ctx, const void *const *vecs_host, const uint8_t *coeffs_host, const uint8_t *adj_coeffs_host, uint32_t count,
+                        const void *powers, const void *plus, uint64_t n, void *out);
 /* combineVectors(a, b) -> scalar sum_i a[i]*b[i] (host out).  CompositionPolynomial.ts:168,188 */
 int gs_combine(gs_ctx *ctx, const void *a, const void *b, uint64_t n, gs_elt *out_host);
 /* pluckVector(v, skip, times): out[i] = v[(i*skip) mod vlen], i < times.  ZeroPolynomial.ts:40 */

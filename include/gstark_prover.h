@@ -76,6 +76,12 @@ int gs_prover_bind(void *dl_handle);
  * err[0..errcap) holds the reference's message where there is one ("Assertion at step ... conflicts with execution trace"). */
 int gs_prover_prove(gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, uint64_t cap, uint64_t *len, char *err, uint64_t errcap);
 int gs_prover_last_stats(struct gs_prover_stats *out);
+/* LowDegreeProver.verifyRemainder (LowDegreeProver.ts:223-252) on its own, for tests: `len` values on the powers of root_of_unity
+ * (order len); 1 = the values at the positions that are not multiples of extension_factor lie on a polynomial of degree
+ * < max_degree_plus1, 0 = they do not, < 0 = error.  method 0: the reference's procedure (interpolate the first max_degree_plus1
+ * positions, evaluate at the rest); method 1: the coefficient form the driver uses — same verdict on every input. */
+int gs_prover_remainder_check(const uint8_t *values, uint64_t len, uint32_t extension_factor, uint64_t max_degree_plus1, const uint8_t *root_of_unity,
+                              int method);
 
 #ifdef __cplusplus
 }

@@ -218,6 +218,21 @@ int gs_combine_many(gs_ctx *c, const void *const *vecs, const uint8_t *coeffs, u
     }
     return GS_OK;
 }
+/* term by term as the reference builds it: every adjusted vector v_j o powers, then the merge of all 2*count terms, then + plus */
+int gs_combine_adjusted(gs_ctx *c, const void *const *vecs, const uint8_t *coeffs, const uint8_t *adj, uint32_t count, const void *powers,
+                        const void *plus, uint64_t n, void *o) {
+    if (!vecs || !o || (!coeffs && !adj) || (adj && !powers)) return GS_ERR_ARG;
+    if (count == 0) return fail(c, GS_ERR_ARG, "combine_adjusted: no vectors");
+    PAR_FOR
+    for (uint64_t i = 0; i < n; i++) {
+        fe s = 0;
+        if (coeffs) for (uint32_t j = 0; j < count; j++) s = fe_add(s, fe_mul(EL(vecs[j], i), fe_load(coeffs + FE_BYTES * j)));
+        if (adj) for (uint32_t j = 0; j < count; j++) s = fe_add(s, fe_mul(fe_mul(EL(vecs[j], i), EL(powers, i)), fe_load(adj + FE_BYTES * j)));
+        if (plus) s = fe_add(s, EL(plus, i));
+        ST(o, i, s);
+    }
+    return GS_OK;
+}
 int gs_combine(gs_ctx *c, const void *a, const void *b, uint64_t n, gs_elt *out) {
     (void)c; fe s = 0;
     for (uint64_t i = 0; i < n; i++) s = fe_add(s, fe_mul(EL(a, i), EL(b, i)));

@@ -585,3 +585,40 @@ def check_many_vectors(backend, rng, n, count):
     diff = f.subMatrixElementsFromVectors(vecs, m)
     mv = m.toValues()
     assert diff.toValues() == [[(cols[r][i] - mv[r][i]) % P for i in range(n)] for r in range(count)]
+
+
+def check_combine_adjusted(backend, rng, n=300):
+    """gs_combine_adjusted against its definition on Python integers and against the member sequence it replaces
+    (mulVectorElements per adjusted vector, combineManyVectors over all terms, addVectorElements): every combination of absent
+    parts, `plus` aliasing `out`, more vectors than one launch carries."""
+    be = backend
+    f = field_for(be)
+    for count in (1, 3, 6, 70):
+        cols = [rand_elements(rng, n) for _ in range(count)]
+        vecs = [f.newVectorFrom(c) for c in cols]
+        pw, pl = rand_elements(rng, n), rand_elements(rng, n)
+        pv, plv = f.newVectorFrom(pw), f.newVectorFrom(pl)
+        k, kp = [rng.randrange(P) for _ in range(count)], [rng.randrange(P) for _ in range(count)]
+        ptrs = (C.c_void_p * count)(*[v.ptr for v in vecs])
+        kb, kpb = b''.join(x.to_bytes(16, 'little') for x in k), b''.join(x.to_bytes(16, 'little') for x in kp)
+        for has_k, has_kp, has_plus in ((1, 1, 1), (1, 1, 0), (1, 0, 1), (1, 0, 0), (0, 1, 1), (0, 1, 0)):
+            out = f.newVector(n)
+            be.call('gs_combine_adjusted', ptrs, kb if has_k else None, kpb if has_kp else None, count, C.c_void_p(pv.ptr) if has_kp else None,
+                    C.c_void_p(plv.ptr) if has_plus else None, n, C.c_void_p(out.ptr))
+            want = [((sum(c[i] * a for c, a in zip(cols, k)) if has_k else 0) + (pw[i] * sum(c[i] * a for c, a in zip(cols, kp)) if has_kp else 0)
+                     + (pl[i] if has_plus else 0)) % P for i in range(n)]
+            assert out.toValues() == want, (count, has_k, has_kp, has_plus)
+        # the reference's member sequence (CompositionPolynomial.ts:83-107 / LinearCombination.ts:44-63)
+        adjusted = [f.mulVectorElements(v, pv) for v in vecs]
+        merged = f.addVectorElements(f.combineManyVectors(vecs + adjusted, k + kp), plv)
+        acc = f.newVectorFrom(pl)                                                       # plus = out (in place)
+        be.call('gs_combine_adjusted', ptrs, kb, kpb, count, C.c_void_p(pv.ptr), C.c_void_p(acc.ptr), n, C.c_void_p(acc.ptr))
+        assert acc.toValues() == merged.toValues(), count
+    for bad in ((None, None), ):
+        try:
+            be.call('gs_combine_adjusted', ptrs, None, None, count, None, None, n, C.c_void_p(acc.ptr))
+            raise AssertionError('no coefficient list at all must be refused')
+        except AssertionError:
+            raise
+        except Exception:      # noqa: BLE001
+            pass

@@ -148,7 +148,7 @@ def test_prover_library_exports_its_header():
     header = os.path.join(ROOT, 'include', 'gstark_prover.h')
     subprocess.check_call(['gcc', '-fsyntax-only', '-x', 'c', '-std=c11', header])
     names = set(re.findall(r'^int\s+(gs_prover_\w+)\s*\(', open(header).read(), flags=re.M))
-    assert names == {'gs_prover_bind', 'gs_prover_prove', 'gs_prover_last_stats'}
+    assert names == {'gs_prover_bind', 'gs_prover_prove', 'gs_prover_last_stats', 'gs_prover_remainder_check'}
     if not os.path.exists(PROVER_LIB_PATH):
         pytest.skip('libgstark_prover.so not built')
     import shutil

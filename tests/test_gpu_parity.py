@@ -133,6 +133,7 @@ def test_merkle_commit_rows_equals_oracle(hip_backend, oracle_omp_backend, alg, 
 def test_device_record_ops(hip_backend, rng):
     for _ in range(3):
         cases.check_device_record_ops(hip_backend, rng)
+        cases.check_combine_adjusted(hip_backend, rng)
 
 
 def test_mimc_air(hip_backend, rng):

@@ -164,3 +164,92 @@ def test_packed_seed_gives_the_same_proof(oracle_backend):
     packed = p.pack_seed(seed)
     assert packed.rows == 4 and len(packed.first) == 4 * 4 * 16
     assert p.prove_bytes(assertions, [], packed) == p.prove_bytes(assertions, [], seed) == stark.serialize(stark.prove(assertions, [], seed))
+
+
+def test_remainder_check_forms_agree(oracle_backend):
+    """verifyRemainder (LowDegreeProver.ts:223-252): the coefficient form the driver uses gives the reference procedure's verdict —
+    valid remainders of every degree, one value off, junk at the excluded positions, degree one too high — and the mirror's."""
+    import ctypes as C
+    import random
+    from genstark_amd.field import PrimeField
+    from genstark_amd.native import _driver
+    from genstark_amd._mirror.components.low_degree_prover import LowDegreeProver
+    from genstark_amd.errors import StarkError
+    f = PrimeField(backend=oracle_backend)
+    lib = _driver(oracle_backend)
+    lib.gs_prover_remainder_check.restype = C.c_int
+    lib.gs_prover_remainder_check.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_char_p, C.c_int]
+    rng = random.Random(20260927)
+    p = f.modulus
+
+    def verdicts(values, ef, m, rou):
+        raw = b''.join(v.to_bytes(16, 'little') for v in values)
+        r = rou.to_bytes(16, 'little')
+        return [lib.gs_prover_remainder_check(raw, len(values), ef, m, r, method) for method in (0, 1)]
+
+    def mirror(values, ef, m, rou):
+        ldp = LowDegreeProver.__new__(LowDegreeProver)
+        ldp.field, ldp.idxGenerator = f, type('G', (), {'extensionFactor': ef})()
+        try:
+            ldp.verifyRemainder(list(values), m, rou)
+            return 1
+        except StarkError:
+            return 0
+
+    cases = 0
+    for length, ef in ((256, 16), (256, 8), (128, 16), (64, 32), (256, 32), (64, 4), (16, 16), (32, 16)):
+        rou = f.getRootOfUnity(length)
+        checked = length - length // ef
+        for m in sorted({1, 2, 3, checked // 4, checked // 2, checked - 17, checked - 1, checked} - {0} | set()):
+            if m <= 0:
+                continue
+            poly = [rng.randrange(p) for _ in range(m)]
+            xs = [pow(rou, i, p) for i in range(length)]
+            good = [sum(c * pow(x, k, p) for k, c in enumerate(poly)) % p for x in xs]
+            junk = list(good)
+            for i in range(0, length, ef):
+                junk[i] = rng.randrange(p)                                   # the excluded positions carry anything
+            assert verdicts(good, ef, m, rou) == [1, 1] and verdicts(junk, ef, m, rou) == [1, 1], (length, ef, m)
+            if m < checked:
+                bad = list(junk)
+                at = rng.choice([i for i in range(length) if i % ef])
+                bad[at] = (bad[at] + 1 + rng.randrange(p - 1)) % p
+                assert verdicts(bad, ef, m, rou) == [0, 0], (length, ef, m, at)
+                over = [(v + pow(x, m, p)) % p for v, x in zip(good, xs)]      # degree exactly m: one too high
+                assert verdicts(over, ef, m, rou) == [0, 0], (length, ef, m)
+                if cases % 3 == 0:
+                    assert mirror(good, ef, m, rou) == 1 and mirror(bad, ef, m, rou) == 0 and mirror(over, ef, m, rou) == 0
+            cases += 1
+        rnd = [rng.randrange(p) for _ in range(length)]
+        assert verdicts(rnd, ef, checked // 2, rou) == [0, 0]
+        assert verdicts(rnd, ef, checked + 1, rou) == [-1, -1]                  # "Remainder degree is greater than number of remainder values"
+    assert cases > 40
+
+
+@pytest.mark.parametrize('degrees', [[3, 5, 3, 8], [4, 4, 3, 3], [3, 3, 3, 3], [3, 8, 8, 5], [2, 8, 8, 5]])
+def test_native_prover_mixed_constraint_degrees(oracle_backend, degrees):
+    """Constraint groups with degrees of their own (CompositionPolynomial.ts:83-107, :206-225): one group at the combination degree
+    (not adjusted), several below it (each with its own powers) — the merged form of the driver (gs_combine_adjusted) against the
+    mirror's member-by-member sequence, byte for byte.  The Rescue AIR with DECLARED degrees above the actual ones."""
+    from genstark_amd.field import PrimeField
+    from genstark_amd.native import NativeProver
+    from genstark_amd.rescue import rescue4x128_air
+    from genstark_amd._mirror.stark import Stark
+    f = PrimeField(backend=oracle_backend)
+    air = rescue4x128_air(64, 16, f)
+    air.constraintDegrees = list(degrees)
+    air.maxConstraintDegree = max(degrees)
+    air.compositionFactor = 1 << (air.maxConstraintDegree - 1).bit_length()
+    stark = Stark(air, {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 20, 'friQueryCount': 10})
+    full = air.hostTrace([42, 43])
+    assertions = [{'step': 31, 'register': 0, 'value': full[31][0]}, {'step': 63, 'register': 1, 'value': full[63][1]},
+                  {'step': 5, 'register': 3, 'value': full[5][3]}]
+    if degrees[0] < 3:        # a declared degree below the real one: the composition is not low-degree, BOTH drivers must say so
+        from genstark_amd.errors import StarkError
+        for prove in (lambda: stark.prove(assertions, [], [42, 43]), lambda: NativeProver(stark).prove_bytes(assertions, [], [42, 43])):
+            with pytest.raises(StarkError, match='Remainder is not a valid degree 111 polynomial'):
+                prove()
+        return
+    want = stark.serialize(stark.prove(assertions, [], [42, 43]))
+    assert NativeProver(stark).prove_bytes(assertions, [], [42, 43]) == want
+    assert stark.verify(assertions, stark.parse(want))

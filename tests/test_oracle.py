@@ -80,6 +80,7 @@ def test_merkle_commit_rows(oracle_backend, rng, alg, logn, count):
 
 def test_device_record_ops(oracle_backend, rng):
     cases.check_device_record_ops(oracle_backend, rng)
+    cases.check_combine_adjusted(oracle_backend, rng)
 
 
 def test_mimc_air(oracle_backend, rng):
