@@ -35,6 +35,8 @@ class RcclComm:
             lib.gs_rccl_comm_create.restype = C.c_int
             lib.gs_rccl_comm_destroy.argtypes = [C.POINTER(GsComm)]
             lib.gs_rccl_comm_destroy.restype = None
+            lib.gs_rccl_comm_timings.argtypes = [C.POINTER(GsComm), C.c_int]
+            lib.gs_rccl_comm_timings.restype = None
             cls._lib = lib
         return cls._lib
 
@@ -53,6 +55,12 @@ class RcclComm:
         if rc:
             raise GstarkError(f'gs_rccl_comm_create(rank {rank} of {size}) failed ({rc}): {err.value.decode(errors="replace")}')
         self.rank, self.size = rank, size
+
+    def timings(self, on):
+        """Per-collective device times (an event pair around each: `last_collectives()[i]['ms']`) on or off; off keeps the stream free
+        of event records — what a latency-bound proof wants."""
+        self.lib().gs_rccl_comm_timings(C.byref(self.comm), 1 if on else 0)
+        return self
 
     def close(self):
         if self.comm is not None:

@@ -23,17 +23,19 @@ struct RcclState {
     int rank = 0, size = 1, device = 0;
     void *(*stream_of)(gs_ctx *) = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, spare;
+    bool timings = true;          // an event pair around every collective (gs_rccl_comm_timings): each record costs the stream a few us
     char err[256] = {0};
 };
 
 bool begin(RcclState *s, hipStream_t st) {
+    if (!s->timings) return true;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (!s->spare.empty()) { ev = s->spare.back(); s->spare.pop_back(); }
     else if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) return false;
     s->timed.push_back(ev);
     return hipEventRecord(ev.first, st) == hipSuccess;
 }
-bool end(RcclState *s, hipStream_t st) { return hipEventRecord(s->timed.back().second, st) == hipSuccess; }
+bool end(RcclState *s, hipStream_t st) { return !s->timings || hipEventRecord(s->timed.back().second, st) == hipSuccess; }
 
 int r_all_gather(void *self, gs_ctx *ctx, const void *send, void *recv, uint64_t bytes) {
     RcclState *s = (RcclState *)self;
@@ -109,6 +111,12 @@ int gs_rccl_comm_create(void *abi_dl_handle, const uint8_t unique_id[128], int r
     out->take_timings = r_take_timings;
     out->name = "rccl";
     return GS_OK;
+}
+
+// on (default): every collective is bracketed by a HIP event pair and take_timings reports its device time; off: no events on the
+// stream (an event record delays the kernel behind it by a few microseconds — a latency-bound proof issues ~10 collectives)
+void gs_rccl_comm_timings(gs_comm *c, int on) {
+    if (c && c->self) ((RcclState *)c->self)->timings = on != 0;
 }
 
 void gs_rccl_comm_destroy(gs_comm *c) {
