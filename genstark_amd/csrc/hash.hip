@@ -175,12 +175,13 @@ __global__ __launch_bounds__(256) void k_merkle_fused(HashPtrArgs va, uint32_t c
 }
 
 #define GS_MERKLE_CHUNK 1024
+#define GS_MERKLE_SUBTREE_THREADS 1024      // one first-layer digest per thread, the 512-node level in one step, quads from 256 nodes down
 template <int ALG, int SRC>
-__global__ __launch_bounds__(256) void k_merkle_subtree(HashPtrArgs va, uint32_t count, const uint4 *__restrict__ layerA, uint4 *__restrict__ outA,
+__global__ __launch_bounds__(GS_MERKLE_SUBTREE_THREADS) void k_merkle_subtree(HashPtrArgs va, uint32_t count, const uint4 *__restrict__ layerA, uint4 *__restrict__ outA,
                                                         uint4 *__restrict__ nodes, uint64_t wA, uint32_t chunk) {
     __shared__ uint4 sh[4 * GS_MERKLE_CHUNK];   // digest of subtree-heap node s at sh[2s], sh[2s + 1]; the first layer is s in [chunk, 2 chunk)
     const uint64_t base = (uint64_t)blockIdx.x * chunk;
-    for (uint32_t i = threadIdx.x; i < chunk; i += 256) {
+    for (uint32_t i = threadIdx.x; i < chunk; i += GS_MERKLE_SUBTREE_THREADS) {
         if constexpr (SRC == 0) {
             sh[2 * (chunk + i)] = layerA[2 * (base + i)];
             sh[2 * (chunk + i) + 1] = layerA[2 * (base + i) + 1];
@@ -196,9 +197,10 @@ __global__ __launch_bounds__(256) void k_merkle_subtree(HashPtrArgs va, uint32_t
     uint64_t wl = wA >> 1;       // width of the layer being produced: it lives at nodes[wl .. 2 wl)
     for (uint32_t m = chunk / 2; m >= 1; m >>= 1, wl >>= 1) {
         if constexpr (ALG == 1) {
-            // levels no wider than 64 nodes are bound by the latency of ONE compression per level: four lanes per node (hash_core.h:
-            // b2s_node_quad) cut it 2.3x.  Quads are wholly active or wholly idle (4 m threads), as the lane rotations need.
-            if (m <= 64) {
+            // levels no wider than a quarter of the workgroup are bound by the latency of ONE compression per level: four lanes per
+            // node (hash_core.h: b2s_node_quad) cut it 2.3x.  Quads are wholly active or wholly idle (4 m threads), as the lane
+            // rotations need.
+            if (m <= GS_MERKLE_SUBTREE_THREADS / 4) {
                 if (threadIdx.x < 4 * m) {
                     const uint32_t i = threadIdx.x >> 2, l = threadIdx.x & 3u, s = m + i;
                     uint32_t *w = reinterpret_cast<uint32_t *>(sh);
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void k_merkle_subtree(HashPtrArgs va, uint32_t
                 continue;
             }
         }
-        for (uint32_t i = threadIdx.x; i < m; i += 256) {
+        for (uint32_t i = threadIdx.x; i < m; i += GS_MERKLE_SUBTREE_THREADS) {
             const uint32_t s = m + i;
             const uint4 x0 = sh[4 * s], x1 = sh[4 * s + 1], x2 = sh[4 * s + 2], x3 = sh[4 * s + 3];
             uint32_t d[8];
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void k_merkle_subtree(HashPtrArgs va, uint32_t
 // leaves (n digests, given or hashed from `count` columns when src != 0) -> nodes (heap order).  src as SRC above.
 template <int ALG>
 static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count, const void *leaves_in, void *leaves_out, uint64_t n, uint4 *nd) {
-    const dim3 blk(256);
+    const dim3 blk(256), sub_blk(GS_MERKLE_SUBTREE_THREADS);
     uint64_t w = n;                              // the widest complete layer and where its digests are
     const uint4 *cur = (const uint4 *)leaves_in;
     if (src != 0) {
@@ -251,8 +253,8 @@ static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count,
             cur = lv == 1 ? lo : nd + 2 * w;
         } else {
             const uint32_t chunk = (uint32_t)(n < GS_MERKLE_CHUNK ? n : GS_MERKLE_CHUNK);
-            if (src == 1) hipLaunchKernelGGL((k_merkle_subtree<ALG, 1>), dim3((unsigned)(n / chunk)), blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk);
-            else hipLaunchKernelGGL((k_merkle_subtree<ALG, 2>), dim3((unsigned)(n / chunk)), blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk);
+            if (src == 1) hipLaunchKernelGGL((k_merkle_subtree<ALG, 1>), dim3((unsigned)(n / chunk)), sub_blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk);
+            else hipLaunchKernelGGL((k_merkle_subtree<ALG, 2>), dim3((unsigned)(n / chunk)), sub_blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk);
             w = n / chunk;
             cur = nd + 2 * w;
             if (w == 1) { GS_LAUNCH_CHECK(c); return GS_OK; }
@@ -268,7 +270,7 @@ static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count,
     }
     while (w > 1) {                               // subtrees of <= 1024 digests, then the subtree over their roots
         const uint32_t chunk = (uint32_t)(w < GS_MERKLE_CHUNK ? w : GS_MERKLE_CHUNK);
-        hipLaunchKernelGGL((k_merkle_subtree<ALG, 0>), dim3((unsigned)(w / chunk)), blk, 0, c->stream, va, 0u, cur, nullptr, nd, w, chunk);
+        hipLaunchKernelGGL((k_merkle_subtree<ALG, 0>), dim3((unsigned)(w / chunk)), sub_blk, 0, c->stream, va, 0u, cur, nullptr, nd, w, chunk);
         w /= chunk;
         cur = nd + 2 * w;
     }
