@@ -10,7 +10,9 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshol
 mkdir -p build_exp ../../tools/ab
 pids=()
 for f in ctx ntt pointwise hash air_mimc air_vm air_jit small; do
-  if [ ! -f build_exp/$f.o ] || [ $f.hip -nt build_exp/$f.o ] || [ ../../tools/ntt_mfma.h -nt build_exp/$f.o ]; then $HIPCC $FLAGS -c $f.hip -o build_exp/$f.o & pids+=($!); fi
+  stale=0
+  for h in $f.hip ../../tools/ntt_mfma.h *.h ../../include/gstark.h; do [ $h -nt build_exp/$f.o ] && stale=1; done      # any header: the context struct is shared
+  if [ ! -f build_exp/$f.o ] || [ $stale = 1 ]; then $HIPCC $FLAGS -c $f.hip -o build_exp/$f.o & pids+=($!); fi
 done
 for p in "${pids[@]}"; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../../tools/ab/libgstark_hip_exp.so build_exp/*.o -lhiprtc
