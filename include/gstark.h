@@ -84,7 +84,9 @@ int gs_field_modulus(gs_elt *out_le);                  /* FiniteField.modulus */
 int gs_alloc(gs_ctx *ctx, uint64_t bytes, void **dptr);
 int gs_free(gs_ctx *ctx, void *dptr);                 /* parks the block in the context's cache (no device sync) */
 int gs_cache_trim(gs_ctx *ctx);                        /* synchronises and returns every cached block to the driver */
-int gs_upload(gs_ctx *ctx, void *dst, const void *host_src, uint64_t bytes);   /* newVectorFrom: BoundaryConstraints.ts:24,40 */
+/* newVectorFrom (BoundaryConstraints.ts:24,40).  host_src may be reused as soon as the call returns; the copy itself is ordered on
+ * the context's queue like every other entry (payloads up to 4 MiB are staged in pinned memory and do not block the host). */
+int gs_upload(gs_ctx *ctx, void *dst, const void *host_src, uint64_t bytes);
 int gs_download(gs_ctx *ctx, void *host_dst, const void *src, uint64_t bytes); /* toValues / toBuffer: CompositionPolynomial.ts:58 */
 int gs_copy(gs_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 /* rowsToBuffers / copyValue / MerkleTree node reads: lib/Stark.ts:290, LowDegreeProver.ts:53,214,217.
