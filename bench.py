@@ -195,20 +195,24 @@ def second_roof(n, transform_ms, npass, traffic_detail=None):
                 raise KeyError(f'k_ntt_wave<{l - 4}, {tw}>')
             k = mix[key]
             ns_per_wave = sum(k[c] * VALU_CLASS_NS[c] for c in VALU_CLASS_NS)
-            counted = None
+            counted = util = None
             for name, d in ((traffic_detail or {}).get('kernels') or {}).items():
                 if name.replace(' ', '').startswith(f'k_ntt_wave<{l - 4},{tw}>') and d.get('SQ_INSTS_VALU_avg'):
                     counted = d['SQ_INSTS_VALU_avg']
+                    util = d.get('valu_issue_utilisation')
             insts = counted if counted else k['valu'] * waves
             rows.append({'kernel': f'k_ntt_wave<{l - 4}, {tw}>', 'static_valu_per_wave': k['valu'], 'mix': {c: k[c] for c in VALU_CLASS_NS},
                          'SQ_INSTS_VALU_per_launch': counted, 'static_valu_per_launch': k['valu'] * waves,
-                         'issue_floor_us': round(insts * (ns_per_wave / k['valu']) / simds * 1e-3, 1)})
+                         'issue_floor_us': round(insts * (ns_per_wave / k['valu']) / simds * 1e-3, 1),
+                         'valu_issue_utilisation': util})
             total_ns += insts * (ns_per_wave / k['valu']) / simds
         out['from_counters'] = {'peak': round(total_ns * 1e-6, 4), 'frac': round(total_ns * 1e-6 / transform_ms, 4), 'passes': rows,
                                 'class_cost_ns': VALU_CLASS_NS,
                                 'note': 'VALU wave-instructions of each pass (SQ_INSTS_VALU when the PMC pass ran, else the static count of the '
                                         'straight-line kernel x waves) x issue cost of their classes / SIMDs: dependency stalls inside the '
-                                        'routines are NOT in this floor, which is why it is lower than `peak`'}
+                                        'routines are NOT in this floor, which is why it is lower than `peak`.  valu_issue_utilisation: '
+                                        'SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs of the same launches — the share of '
+                                        'its own cycles a SIMD spent issuing vector instructions, at whatever clock the part sustained'}
     except Exception as e:   # noqa: BLE001
         out['from_counters'] = {'error': repr(e)[:200]}
     return out

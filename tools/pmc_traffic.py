@@ -21,20 +21,23 @@ out = {'n': 1 << logn, 'commands': []}
 per_kernel = {}
 work = tempfile.mkdtemp(prefix='pmc_', dir='/tmp')
 env = dict(os.environ, TMPDIR='/tmp')
+GROUPS = {'FETCH_SIZE': ['FETCH_SIZE'], 'WRITE_SIZE': ['WRITE_SIZE'],
+          # the issue side, one pass: wave-level VALU instructions, the (quad-)cycles a SIMD spent issuing them, the kernel's own cycle count
+          'SQ_INSTS_VALU': ['SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'GRBM_GUI_ACTIVE']}
 for counter in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_VALU'):
     d = os.path.join(work, counter)
-    cmd = [rocprof, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'p', '--',
+    cmd = [rocprof, '--pmc', *GROUPS[counter], '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'p', '--',
            sys.executable, os.path.join(ROOT, 'tools', 'ntt_only.py'), str(logn)]
-    out['commands'].append(' '.join(cmd[:8] + ['--', 'python', 'tools/ntt_only.py', str(logn)]))
+    out['commands'].append(' '.join(cmd[:cmd.index('--')] + ['--', 'python', 'tools/ntt_only.py', str(logn)]))
     subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
     files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
     if not files:
         raise SystemExit(f'no counter file under {d}')
     for row in csv.DictReader(open(files[0])):
-        if 'k_ntt_' not in row['Kernel_Name'] or row['Counter_Name'] != counter:
+        if 'k_ntt_' not in row['Kernel_Name'] or row['Counter_Name'] not in GROUPS[counter]:
             continue
         name = row['Kernel_Name'].split('(')[0].replace('void ', '')
-        per_kernel.setdefault(name, {}).setdefault(counter, []).append(float(row['Counter_Value']))
+        per_kernel.setdefault(name, {}).setdefault(row['Counter_Name'], []).append(float(row['Counter_Value']))
     if keep:
         os.makedirs(keep, exist_ok=True)
         shutil.copy(files[0], os.path.join(keep, f'pmc_{counter.lower()}_ntt_2p{logn}.csv'))
@@ -45,6 +48,11 @@ for name, c in per_kernel.items():
     v = c.get('SQ_INSTS_VALU', [])
     kernels[name] = {'launches_sampled': len(c.get('FETCH_SIZE', [])), 'FETCH_SIZE_kib_avg': f, 'WRITE_SIZE_kib_avg': w,
                      'hbm_bytes_per_launch': (2 * f + w) * 1024, 'SQ_INSTS_VALU_avg': (sum(v) / len(v)) if v else None}
+    act, gui = c.get('SQ_ACTIVE_INST_VALU', []), c.get('GRBM_GUI_ACTIVE', [])
+    if act and gui:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, GRBM_GUI_ACTIVE cycles summed over the 8 XCDs
+        kernels[name]['valu_issue_utilisation'] = round((sum(act) / len(act)) * 4 / 1024 / ((sum(gui) / len(gui)) / 8), 4)
+        kernels[name]['kernel_cycles'] = round((sum(gui) / len(gui)) / 8)
 out['kernels'] = kernels
 out['correction'] = 'bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes)'
 if kernels:
