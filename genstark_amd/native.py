@@ -123,6 +123,7 @@ class NativeProver:
         if self.field.modulus != MODULUS:
             raise GstarkError('the native driver is built for the 128-bit field; use Stark.prove() on the small-field builds')
         self.lib = _driver(self.backend)
+        self._static_pack = None
         self._keep = []
         self._out = C.create_string_buffer(1 << 22)
         # AIR-instance constants the device routines need, computed once (they depend on the AIR only, like the static register
@@ -215,9 +216,12 @@ class NativeProver:
                 ja.secret_traces, ja.nsecret = straces, air.secretInputCount
                 keep += [ctx, straces]
             else:
+                # public static registers are constants of the AIR: packed once per prover, not per proof (~500 values for Poseidon)
+                if self._static_pack is None:
+                    self._static_pack = (b''.join(_le(v % f.modulus) for values in air.staticRegisters for v in values) or bytes(16),
+                                         [len(v) for v in air.staticRegisters])
                 tables, table_lens = self._tables, self._lens
-                svals = b''.join(_le(v % f.modulus) for values in air.staticRegisters for v in values) or bytes(16)
-                plist = [len(v) for v in air.staticRegisters]
+                svals, plist = self._static_pack
             periods = (C.c_uint32 * max(len(plist), 1))(*plist)
             lens = (C.c_uint64 * max(len(table_lens), 1))(*table_lens)
             ja.static_values, ja.static_periods, ja.nstatic = svals, periods, len(plist)
