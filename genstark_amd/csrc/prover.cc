@@ -744,7 +744,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     cEval.release();
     psbPowers.release();
 
-    clock.mark("composition + linear combination issued (evaluation root read inside)");
+    clock.mark("composition + LC issued (root read inside)");
     // 7 ----- low-degree proof (LowDegreeProver.ts:39-68, 176-221)
     if (N < 128) fail(GS_ERR_ARG, "Invalid array length");
     // transposeVector(v, 4) is never materialised: row r of it is v[r], v[r + rows], v[r + 2 rows], v[r + 3 rows], which the hashing,
@@ -823,6 +823,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     for (size_t d = 0; d < layers.size(); d++) {
         Layer &L = layers[d];
         await_root(tickets[d + 1], L.cTree);
+        if (d + 1 == layers.size()) clock.mark("roots awaited; queries planned meanwhile");
         std::vector<uint64_t> positions = query_indexes(L.cTree.root, job.fri_query_count, L.column_length, (uint32_t)E);
         std::vector<uint64_t> rows_wanted;
         for (uint64_t p : positions) rows_wanted.push_back(p % (L.column_length / 4));
@@ -834,7 +835,8 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         rb.prove_batch(x, *L.pTree, positions, &c.polyProof);
         rb.gather_rows4(x, L.column, L.rows, positions, &c.polyProof);
     }
-    clock.mark("roots awaited one by one; query positions + batch-proof plans (while the device folds)");
+    if (layers.empty()) clock.mark("roots awaited; queries planned meanwhile");
+    clock.mark("last root here: the last layer's plan");
     std::vector<F> remainder(len);
     Bytes remainder_raw(len * ELEM);
     {
@@ -843,7 +845,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         x.check(A.gs_gather(x.c, column_src, ELEM, all.data(), len, remainder_raw.data()), "gs_gather(remainder)");
     }
     win.end();
-    clock.mark("remainder + query answers fetched (one synchronisation)");
+    clock.mark("remainder + answers fetched (one sync)");
     {
         Bytes &raw = remainder_raw;
         for (uint64_t i = 0; i < len; i++) remainder[i] = from16(raw.data() + 16 * i);
