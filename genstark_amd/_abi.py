@@ -86,6 +86,8 @@ _SIGNATURES = {
     'gs_fri_fold': (_int, [_vp, _bytes, _u64, _u64, _vp, _u64, _bytes, _vp]),
     'gs_fri_fold_seeded': (_int, [_vp, _bytes, _u64, _u64, _vp, _u64, _vp, _vp]),
     'gs_fri_fold_seeded_scaled': (_int, [_vp, _bytes, _u64, _u64, _vp, _u64, _vp, _bytes, _vp]),
+    'gs_merkle_commit_rows_seed': (_int, [_vp, _int, _pvp, _u32, _u64, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
+    'gs_fri_fold_at': (_int, [_vp, _bytes, _u64, _u64, _vp, _u64, _vp, _vp]),
     'gs_eval_quartic_batch': (_int, [_vp, _vp, _u64, _bytes, _vp]),
     'gs_hash_digest': (_int, [_vp, _int, _bytes, _u64, _vp]),
     'gs_hash_merge_rows': (_int, [_vp, _int, _pvp, _u32, _u64, _vp]),

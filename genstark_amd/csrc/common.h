@@ -114,6 +114,9 @@ int gs_defer_flush(gs_ctx *c);                                    // fetch and d
 int gs_push_reserve(gs_ctx *c, uint64_t bytes, void **host);
 int gs_push_commit(gs_ctx *c, void *dst, const void *host, uint64_t bytes);
 int gs_push(gs_ctx *c, void *dst, const void *host_src, uint64_t bytes);     // both steps for one source; blocking copy when too large
+// a slot of the posted-read-back ring for a kernel that delivers the bytes ITSELF (writes `bytes` to *slot_dev, fences, then stores
+// `value` to *flag_dev at system scope — what k_post_words does for gs_readback_post); *ticket is what gs_readback_wait takes
+int gs_readback_reserve(gs_ctx *c, uint32_t bytes, void **slot_dev, unsigned long long **flag_dev, unsigned long long *value, uint64_t *ticket);
 int gs_trace_begin(gs_ctx *c, uint64_t bytes);   // h_trace has >= bytes and no upload of it is in flight
 int gs_trace_end(gs_ctx *c);                     // call after the last hipMemcpyAsync out of h_trace
 // temp device block from the cache (same lifetime rules as gs_alloc/gs_free)

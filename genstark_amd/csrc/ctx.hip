@@ -227,8 +227,7 @@ __global__ void k_post_words(const uint4 *__restrict__ src, uint32_t words, uint
     if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-extern "C" int gs_readback_post(gs_ctx *c, const void *src, uint32_t bytes, uint64_t *ticket) {
-    if (!c || !src || !ticket) return GS_ERR_ARG;
+int gs_readback_reserve(gs_ctx *c, uint32_t bytes, void **slot_dev, unsigned long long **flag_dev, unsigned long long *value, uint64_t *ticket) {
     if (!bytes || bytes > gs_ctx::RB_SLOT_BYTES || (bytes & 15)) return gs_fail(c, GS_ERR_ARG, "readback_post: 16..%u bytes, a multiple of 16", gs_ctx::RB_SLOT_BYTES);
     const size_t data_bytes = (size_t)gs_ctx::RB_SLOTS * gs_ctx::RB_SLOT_BYTES;
     if (!c->h_rb) {
@@ -238,12 +237,22 @@ extern "C" int gs_readback_post(gs_ctx *c, const void *src, uint32_t bytes, uint
     }
     // a slot is reused 64 posts later; its older copy precedes this one on the stream, and flags are ticket numbers: no wait here
     const uint32_t slot = (uint32_t)(c->rb_next % gs_ctx::RB_SLOTS);
-    hipLaunchKernelGGL(k_post_words, dim3(1), dim3(64), 0, c->stream, (const uint4 *)src, bytes / 16,
-                       (uint4 *)((uint8_t *)c->h_rb_dev + (size_t)slot * gs_ctx::RB_SLOT_BYTES),
-                       (unsigned long long *)((uint8_t *)c->h_rb_dev + data_bytes) + slot, (unsigned long long)(c->rb_next + 1));
-    GS_LAUNCH_CHECK(c);
+    *slot_dev = (uint8_t *)c->h_rb_dev + (size_t)slot * gs_ctx::RB_SLOT_BYTES;
+    *flag_dev = (unsigned long long *)((uint8_t *)c->h_rb_dev + data_bytes) + slot;
+    *value = (unsigned long long)(c->rb_next + 1);
     c->rb_bytes[slot] = bytes;
     *ticket = c->rb_next++;
+    return GS_OK;
+}
+
+extern "C" int gs_readback_post(gs_ctx *c, const void *src, uint32_t bytes, uint64_t *ticket) {
+    if (!c || !src || !ticket) return GS_ERR_ARG;
+    void *slot;
+    unsigned long long *flag, value;
+    int rc = gs_readback_reserve(c, bytes, &slot, &flag, &value, ticket);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_post_words, dim3(1), dim3(64), 0, c->stream, (const uint4 *)src, bytes / 16, (uint4 *)slot, flag, value);
+    GS_LAUNCH_CHECK(c);
     return GS_OK;
 }
 

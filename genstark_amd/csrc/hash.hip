@@ -174,11 +174,22 @@ __global__ __launch_bounds__(256) void k_merkle_fused(HashPtrArgs va, uint32_t c
     }
 }
 
+// What the launch that produces a tree's ROOT can do on the side (gs_merkle_commit_rows_seed): hand the root to the host — 32 bytes
+// into a slot of the posted-read-back ring, then the slot's flag (common.h: gs_readback_reserve) — and derive the FRI evaluation
+// point prng(root) (LowDegreeProver.ts:194) where the next fold will read it.  Two launches fewer per FRI layer.
+struct RootTail {
+    uint4 *slot;
+    unsigned long long *flag;
+    unsigned long long value;
+    fe *point;
+};
+__device__ __forceinline__ fe prng_point(const uint32_t *seed);
+
 #define GS_MERKLE_CHUNK 1024
 #define GS_MERKLE_SUBTREE_THREADS 1024      // one first-layer digest per thread, the 512-node level in one step, quads from 256 nodes down
 template <int ALG, int SRC>
 __global__ __launch_bounds__(GS_MERKLE_SUBTREE_THREADS) void k_merkle_subtree(HashPtrArgs va, uint32_t count, const uint4 *__restrict__ layerA, uint4 *__restrict__ outA,
-                                                        uint4 *__restrict__ nodes, uint64_t wA, uint32_t chunk) {
+                                                        uint4 *__restrict__ nodes, uint64_t wA, uint32_t chunk, RootTail tail) {
     __shared__ uint4 sh[4 * GS_MERKLE_CHUNK];   // digest of subtree-heap node s at sh[2s], sh[2s + 1]; the first layer is s in [chunk, 2 chunk)
     const uint64_t base = (uint64_t)blockIdx.x * chunk;
     for (uint32_t i = threadIdx.x; i < chunk; i += GS_MERKLE_SUBTREE_THREADS) {
@@ -227,13 +238,31 @@ __global__ __launch_bounds__(GS_MERKLE_SUBTREE_THREADS) void k_merkle_subtree(Ha
         }
         __syncthreads();
     }
-    if (chunk == wA && threadIdx.x == 0) { nodes[0] = make_uint4(0, 0, 0, 0); nodes[1] = make_uint4(0, 0, 0, 0); }
+    if (chunk == wA && threadIdx.x == 0) {
+        nodes[0] = make_uint4(0, 0, 0, 0);
+        nodes[1] = make_uint4(0, 0, 0, 0);
+        // the root is heap node 1: sh[2], sh[3] (the last level's barrier has passed)
+        if (tail.slot) {
+            tail.slot[0] = sh[2];
+            tail.slot[1] = sh[3];
+            __threadfence_system();
+            __hip_atomic_store(tail.flag, tail.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (tail.point) {
+            const uint4 r0 = sh[2], r1 = sh[3];
+            const uint32_t seed[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            *tail.point = prng_point(seed);
+        }
+    }
 }
 
 #define GS_MERKLE_SUBW (1ull << 15)   // layers at most this wide go to k_merkle_subtree (below it a streaming launch is latency-bound)
 // leaves (n digests, given or hashed from `count` columns when src != 0) -> nodes (heap order).  src as SRC above.
 template <int ALG>
-static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count, const void *leaves_in, void *leaves_out, uint64_t n, uint4 *nd) {
+static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count, const void *leaves_in, void *leaves_out, uint64_t n, uint4 *nd,
+                      const RootTail *root_tail = nullptr) {
+    const RootTail none = {nullptr, nullptr, 0, nullptr};
+    auto tail_for = [&](uint64_t width, uint32_t chunk) { return root_tail && width == chunk ? *root_tail : none; };      // the launch that ends at the root
     const dim3 blk(256), sub_blk(GS_MERKLE_SUBTREE_THREADS);
     uint64_t w = n;                              // the widest complete layer and where its digests are
     const uint4 *cur = (const uint4 *)leaves_in;
@@ -253,8 +282,8 @@ static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count,
             cur = lv == 1 ? lo : nd + 2 * w;
         } else {
             const uint32_t chunk = (uint32_t)(n < GS_MERKLE_CHUNK ? n : GS_MERKLE_CHUNK);
-            if (src == 1) hipLaunchKernelGGL((k_merkle_subtree<ALG, 1>), dim3((unsigned)(n / chunk)), sub_blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk);
-            else hipLaunchKernelGGL((k_merkle_subtree<ALG, 2>), dim3((unsigned)(n / chunk)), sub_blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk);
+            if (src == 1) hipLaunchKernelGGL((k_merkle_subtree<ALG, 1>), dim3((unsigned)(n / chunk)), sub_blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk, tail_for(n, chunk));
+            else hipLaunchKernelGGL((k_merkle_subtree<ALG, 2>), dim3((unsigned)(n / chunk)), sub_blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk, tail_for(n, chunk));
             w = n / chunk;
             cur = nd + 2 * w;
             if (w == 1) { GS_LAUNCH_CHECK(c); return GS_OK; }
@@ -270,7 +299,7 @@ static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count,
     }
     while (w > 1) {                               // subtrees of <= 1024 digests, then the subtree over their roots
         const uint32_t chunk = (uint32_t)(w < GS_MERKLE_CHUNK ? w : GS_MERKLE_CHUNK);
-        hipLaunchKernelGGL((k_merkle_subtree<ALG, 0>), dim3((unsigned)(w / chunk)), sub_blk, 0, c->stream, va, 0u, cur, nullptr, nd, w, chunk);
+        hipLaunchKernelGGL((k_merkle_subtree<ALG, 0>), dim3((unsigned)(w / chunk)), sub_blk, 0, c->stream, va, 0u, cur, nullptr, nd, w, chunk, tail_for(w, chunk));
         w /= chunk;
         cur = nd + 2 * w;
     }
@@ -297,8 +326,12 @@ static int check_alg(gs_ctx *c, gs_hash_alg alg) {
 
 // field.prng(seed) for a 32-byte seed already on the device: sha256(seed) as a big-endian integer, mod p (byte-wise Horner: the same
 // code serves every field flavour).  One lane; the point of it is that the host does not have to see the seed.
+__device__ __forceinline__ fe prng_point(const uint32_t *seed);
 __global__ void k_prng_point(const uint32_t *__restrict__ seed, fe *__restrict__ out) {
     if (threadIdx.x || blockIdx.x) return;
+    *out = prng_point(seed);
+}
+__device__ __forceinline__ fe prng_point(const uint32_t *seed) {
     uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
     uint32_t w[16];
 #pragma unroll
@@ -313,13 +346,13 @@ __global__ void k_prng_point(const uint32_t *__restrict__ seed, fe *__restrict__
     // (2^128 == 9 * 2^32 - 1 mod p) — no multiplication at all, instead of the 32 dependent byte-wise Horner steps of the generic
     // form below (15 -> 4 us on the critical path of every FRI layer)
     const uint32_t r[8] = {h[7], h[6], h[5], h[4], h[3], h[2], h[1], h[0]};
-    *out = fe_reduce_wide(r);
+    return fe_reduce_wide(r);
 #else
     fe x = fe_zero();
     const fe b = fe_make(256u, 0u, 0u, 0u);
     for (int i = 0; i < 8; i++)
         for (int k = 3; k >= 0; k--) x = fe_add(fe_mul(x, b), fe_make((h[i] >> (8 * k)) & 0xFFu, 0u, 0u, 0u));
-    *out = x;
+    return x;
 #endif
 }
 int gs_prng_point_dev(gs_ctx *c, const void *seed32_dev, fe *out_dev) {
@@ -389,21 +422,40 @@ int gs_merkle_build(gs_ctx *c, gs_hash_alg alg, const void *leaves, uint64_t n, 
     return alg == GS_HASH_SHA256 ? merkle_run<0>(c, 0, va, 0, leaves, nullptr, n, (uint4 *)nodes) : merkle_run<1>(c, 0, va, 0, leaves, nullptr, n, (uint4 *)nodes);
 }
 
+static int commit_rows(gs_ctx *c, gs_hash_alg alg, const void *const *vecs_host, uint32_t count, uint64_t n, void *leaves, void *nodes, const RootTail *tail);
 int gs_merkle_commit_rows(gs_ctx *c, gs_hash_alg alg, const void *const *vecs_host, uint32_t count, uint64_t n, void *leaves, void *nodes) {
+    return commit_rows(c, alg, vecs_host, count, n, leaves, nodes, nullptr);
+}
+int gs_merkle_commit_rows_seed(gs_ctx *c, gs_hash_alg alg, const void *const *vecs_host, uint32_t count, uint64_t n, void *leaves, void *nodes,
+                               void *point_out, uint64_t *ticket) {
+    if (!c || (!point_out && !ticket)) return GS_ERR_ARG;
+    if (point_out && ((uintptr_t)point_out & 15)) return gs_fail(c, GS_ERR_ARG, "merkle_commit_rows_seed: point_out must be 16-byte aligned");
+    RootTail tail = {nullptr, nullptr, 0, (fe *)point_out};
+    if (ticket) {
+        void *slot;
+        int rc = gs_readback_reserve(c, 32, &slot, &tail.flag, &tail.value, ticket);
+        if (rc) return rc;
+        tail.slot = (uint4 *)slot;
+    }
+    return commit_rows(c, alg, vecs_host, count, n, leaves, nodes, &tail);
+}
+static int commit_rows(gs_ctx *c, gs_hash_alg alg, const void *const *vecs_host, uint32_t count, uint64_t n, void *leaves, void *nodes, const RootTail *tail) {
     if (!c || !vecs_host || !leaves || !nodes) return GS_ERR_ARG;
     int rc = check_alg(c, alg);
     if (rc) return rc;
     if (count == 0) return gs_fail(c, GS_ERR_ARG, "merkle_commit_rows: no vectors");
     if (!gs_is_pow2(n) || n < 2) return gs_fail(c, GS_ERR_ARG, "merkle_commit_rows: n must be a power of two >= 2");
     if (((uintptr_t)leaves | (uintptr_t)nodes) & 15) return gs_fail(c, GS_ERR_ARG, "merkle_commit_rows: buffers must be 16-byte aligned");
+    HashPtrArgs va;
     if (count > GS_MAX_COMBINE) {      // more columns than fit the kernel-argument table: the two members one after the other
         if ((rc = gs_hash_merge_rows(c, alg, vecs_host, count, n, leaves))) return rc;
-        return gs_merkle_build(c, alg, leaves, n, nodes);
+        for (uint32_t j = 0; j < GS_MAX_COMBINE; j++) va.v[j] = nullptr;
+        return alg == GS_HASH_SHA256 ? merkle_run<0>(c, 0, va, 0, leaves, nullptr, n, (uint4 *)nodes, tail) : merkle_run<1>(c, 0, va, 0, leaves, nullptr, n, (uint4 *)nodes, tail);
     }
-    HashPtrArgs va;
     for (uint32_t j = 0; j < GS_MAX_COMBINE; j++) va.v[j] = (const uint4 *)vecs_host[j < count ? j : 0];
     const int src = count == 1 ? 1 : 2;
-    return alg == GS_HASH_SHA256 ? merkle_run<0>(c, src, va, count, nullptr, leaves, n, (uint4 *)nodes) : merkle_run<1>(c, src, va, count, nullptr, leaves, n, (uint4 *)nodes);
+    return alg == GS_HASH_SHA256 ? merkle_run<0>(c, src, va, count, nullptr, leaves, n, (uint4 *)nodes, tail)
+                                 : merkle_run<1>(c, src, va, count, nullptr, leaves, n, (uint4 *)nodes, tail);
 }
 
 int gs_hash_digest(gs_ctx *c, gs_hash_alg alg, const uint8_t *msg_host, uint64_t len, uint8_t out_host[32]) {

@@ -737,6 +737,12 @@ int gs_fri_fold_seeded_scaled(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64
     return fri_fold_launch(c, omega, n, step, column, m, fe_from_bytes(scale), (const fe *)c->fri_x, out);
 }
 
+int gs_fri_fold_at(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const void *x_dev, void *out) {
+    if (!c || !omega || !column || !x_dev || !out) return GS_ERR_ARG;
+    if ((uintptr_t)x_dev & 15) return gs_fail(c, GS_ERR_ARG, "fri_fold_at: the point must be 16-byte aligned");
+    return fri_fold_launch(c, omega, n, step, column, m, fe_one(), (const fe *)x_dev, out);
+}
+
 int gs_eval_quartic_batch(gs_ctx *c, const void *polys, uint64_t rows, const gs_elt *x, void *out) {
     CHECK3(c, polys, x, out);
     if (!rows) return GS_OK;

@@ -37,7 +37,7 @@ namespace {
     X(gs_eval_polys_at_roots) X(gs_interpolate_roots) X(gs_interpolate_quartic_domain) X(gs_eval_quartic_batch)                \
     X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_commit_rows) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
     X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
-    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end) X(gs_readback_post) X(gs_readback_wait) \
+    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end) X(gs_readback_post) X(gs_readback_wait) X(gs_merkle_commit_rows_seed) X(gs_fri_fold_at) \
     X(gs_vec_mul_scalar) X(gs_copy) X(gs_gather_words) X(gs_transpose_records) X(gs_fri_fold_seeded_scaled)
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
@@ -157,6 +157,8 @@ struct Tree {
     Buf leaves, nodes;   // digests; nodes in heap order
     uint64_t n = 0;
     Bytes root;
+    Buf point;           // FRI trees: prng(root), derived by the launch that produced the root (gs_merkle_commit_rows_seed)
+    uint64_t ticket = 0; // ... which also posted the root to the host
 };
 // Hash.mergeVectorRows(vectors) + MerkleTree.create (lib/Stark.ts:115-118; LowDegreeProver.ts:45-46, 201-202) as one ABI call.
 // read_root = false leaves the root on the device (nodes + DIGEST): the FRI layers derive their evaluation points from it there
@@ -234,10 +236,19 @@ void gather_rows4(Ctx &x, const void *column, uint64_t rows, const std::vector<u
 }
 // tree over the rows of transposeVector(column, 4) (Hash.digestValues of the transposed matrix + MerkleTree.create, LowDegreeProver.ts:45-46,
 // 201-202): the row digests are mergeVectorRows of the four quarters of the column (the same 64-byte messages)
-Tree commit_rows4(Ctx &x, int alg, const void *column, uint64_t rows) {
+// want_point: a layer will be folded at prng(this tree's root); the root is posted to the host either way (t.ticket)
+Tree commit_rows4(Ctx &x, int alg, const void *column, uint64_t rows, bool want_point) {
     const void *quarters[4];
     for (uint64_t c = 0; c < 4; c++) quarters[c] = (const uint8_t *)column + c * rows * ELEM;
-    return commit_rows(x, alg, quarters, 4, rows, false);
+    Tree t;
+    t.n = rows;
+    t.leaves = Buf(x, rows * DIGEST);
+    t.nodes = Buf(x, rows * DIGEST);
+    if (want_point) t.point = Buf(x, ELEM);
+    x.check(A.gs_merkle_commit_rows_seed(x.c, (gs_hash_alg)alg, quarters, 4, rows, t.leaves.p, t.nodes.p, want_point ? t.point.p : nullptr, &t.ticket),
+            "gs_merkle_commit_rows_seed");
+    t.root.resize(DIGEST);
+    return t;
 }
 std::vector<uint64_t> unique_in_order(const std::vector<uint64_t> &v) {
     std::vector<uint64_t> out;
@@ -749,20 +760,16 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     if (N < 128) fail(GS_ERR_ARG, "Invalid array length");
     // transposeVector(v, 4) is never materialised: row r of it is v[r], v[r + rows], v[r + 2 rows], v[r + 3 rows], which the hashing,
     // folding and gathering below read in place
-    Tree pTree0 = commit_rows4(x, alg, lEval.p, N / 4);                                               // :45-46
+    Tree pTree0 = commit_rows4(x, alg, lEval.p, N / 4, N > 256);                                      // :45-46
 
     // layers (:176-221): the loop below is the recursion unrolled.  No root is read back inside it: the point every layer folds at,
-    // prng(root of the tree above) (:194), is derived on the device from the root where it lies (gs_fri_fold_seeded), so all layers
-    // are enqueued without a round trip.  Every tree's root is POSTED behind it (gs_readback_post): the host picks each one up as
-    // soon as that tree exists and derives the layer's query positions and batch-proof plans while the device folds the layers below
-    auto post_root = [&](const Tree &t) {
-        uint64_t ticket = 0;
-        x.check(A.gs_readback_post(x.c, t.nodes.at(DIGEST), (uint32_t)DIGEST, &ticket), "gs_readback_post(root)");
-        return ticket;
-    };
+    // prng(root of the tree above) (:194), is derived on the device from the root where it lies, so all layers
+    // are enqueued without a round trip.  The launch that produces a tree's root also POSTS it to the host and derives that point
+    // (gs_merkle_commit_rows_seed): the host picks each root up as soon as its tree exists and derives the layer's query positions and
+    // batch-proof plans while the device folds the layers below
     auto await_root = [&](uint64_t ticket, Tree &t) { x.check(A.gs_readback_wait(x.c, ticket, t.root.data()), "gs_readback_wait(root)"); };
     std::vector<uint64_t> tickets;
-    tickets.push_back(post_root(pTree0));
+    tickets.push_back(pTree0.ticket);
     std::vector<Layer> layers;
     Tree *pTree = &pTree0;
     const void *column_src = lEval.p;   // the current layer's values in natural order (the remainder at the end)
@@ -782,9 +789,9 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         L.column_length = rows;
         L.next = Buf(x, rows * ELEM);
         le16(omega, s16);
-        x.check(A.gs_fri_fold_seeded(x.c, s16, N, step, column_src, len, pTree->nodes.at(DIGEST), L.next.p), "gs_fri_fold_seeded");   // :189-198
-        L.cTree = commit_rows4(x, alg, L.next.p, rows / 4);                                           // :201-202
-        tickets.push_back(post_root(L.cTree));
+        x.check(A.gs_fri_fold_at(x.c, s16, N, step, column_src, len, pTree->point.p, L.next.p), "gs_fri_fold_at");   // :189-198
+        L.cTree = commit_rows4(x, alg, L.next.p, rows / 4, rows > 256);                               // :201-202 (no layer below the last tree)
+        tickets.push_back(L.cTree.ticket);
         column_src = L.next.p;
         pTree = &L.cTree;
         len = rows;

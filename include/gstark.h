@@ -211,6 +211,15 @@ int gs_fri_fold_seeded(gs_ctx *ctx, const gs_elt *omega, uint64_t n, uint64_t st
  * scaled by shift^-step (csrc/prover_dist.h), and asks for the same point in its own coordinates. */
 int gs_fri_fold_seeded_scaled(gs_ctx *ctx, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m,
                               const void *seed32_dev, const gs_elt *scale, void *out);
+/* The same with less latency per layer (a small layer is a handful of dependent launches, each ~4 us of dispatch):
+ *   gs_merkle_commit_rows_seed: gs_merkle_commit_rows whose LAST launch — the one that produces the root — also (a) posts the
+ *     root to the host exactly like gs_readback_post(nodes + 32, 32) (*ticket for gs_readback_wait; ticket may be NULL) and
+ *     (b) derives field.prng(root) into point_out (16 bytes of device memory; may be NULL): LowDegreeProver.ts:194 and :201-202
+ *     in the launch that already holds the root;
+ *   gs_fri_fold_at: gs_fri_fold at the point stored at x_dev (device memory). */
+int gs_merkle_commit_rows_seed(gs_ctx *ctx, gs_hash_alg alg, const void *const *vecs_host, uint32_t count, uint64_t n, void *leaves, void *nodes,
+                               void *point_out, uint64_t *ticket);
+int gs_fri_fold_at(gs_ctx *ctx, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t len, const void *x_dev, void *out);
 
 /* ---- hashing / Merkle (merkle package) --------------------------------------------------------- */
 /* Hash.digest(Buffer) on host bytes (verifier side; lib/utils/index.ts:37) — runs on the device

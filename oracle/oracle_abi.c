@@ -548,6 +548,31 @@ int gs_merkle_commit_rows(gs_ctx *c, gs_hash_alg alg, const void *const *vecs, u
     return gs_merkle_build(c, alg, leaves, n, nodes);
 }
 
+/* the members one after the other: the tree, its root posted, prng(root) */
+int gs_merkle_commit_rows_seed(gs_ctx *c, gs_hash_alg alg, const void *const *vecs, uint32_t count, uint64_t n, void *leaves, void *nodes,
+                               void *point_out, uint64_t *ticket) {
+    if (!c || (!point_out && !ticket)) return GS_ERR_ARG;
+    int rc = gs_merkle_commit_rows(c, alg, vecs, count, n, leaves, nodes);
+    if (rc) return rc;
+    const uint8_t *root = (const uint8_t *)nodes + 32;
+    if (ticket && (rc = gs_readback_post(c, root, 32, ticket))) return rc;
+    if (point_out) {
+        uint8_t d[32];
+        orc_sha256(root, 32, d);
+        fe x = 0;
+        for (int i = 0; i < 32; i++) x = fe_add(fe_mul(x, (fe)256), (fe)d[i]);
+        fe_store((uint8_t *)point_out, x);
+    }
+    return GS_OK;
+}
+int gs_fri_fold_at(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t m, const void *x_dev, void *out) {
+    if (!x_dev) return GS_ERR_ARG;
+    uint8_t xb[64];
+    memset(xb, 0, sizeof xb);
+    memcpy(xb, x_dev, FE_BYTES);
+    return gs_fri_fold(c, omega, n, step, column, m, (const gs_elt *)xb, out);
+}
+
 int gs_mimc_trace(gs_ctx *c, const gs_elt *seed, const uint8_t *rc, uint32_t nrc, uint64_t steps, void *out) {
     if (!nrc || !steps) return fail(c, GS_ERR_ARG, "mimc_trace: empty");
     fe x = fe_load(seed);

@@ -405,7 +405,28 @@ def merkle_commit_bytes(backend, alg, cols_raw, n, fused=True):
     leaves, nodes = be.alloc(32 * n), be.alloc(32 * n)
     arr = (C.c_void_p * len(ptrs))(*ptrs)
     a = HASH_ALGS[alg]
-    if fused:
+    if fused == 'seed':
+        # gs_merkle_commit_rows_seed: the same tree; its last launch posts the root and derives prng(root) (LowDegreeProver.ts:194)
+        import hashlib
+        point, ticket = be.alloc(16), C.c_uint64()
+        be.call('gs_merkle_commit_rows_seed', a, arr, len(ptrs), n, C.c_void_p(leaves), C.c_void_p(nodes), C.c_void_p(point), C.byref(ticket))
+        root = C.create_string_buffer(32)
+        be.call('gs_readback_wait', ticket.value, root)
+        assert root.raw == be.download(nodes + 32, 32)
+        if es == 16:
+            from genstark_amd.field import MODULUS
+            assert int.from_bytes(be.download(point, 16), 'little') == int.from_bytes(hashlib.sha256(root.raw).digest(), 'big') % MODULUS
+        # either half alone
+        t2 = C.c_uint64()
+        be.call('gs_merkle_commit_rows_seed', a, arr, len(ptrs), n, C.c_void_p(leaves), C.c_void_p(nodes), None, C.byref(t2))
+        r2 = C.create_string_buffer(32)
+        be.call('gs_readback_wait', t2.value, r2)
+        assert r2.raw == root.raw
+        p2 = be.alloc(16)
+        be.call('gs_merkle_commit_rows_seed', a, arr, len(ptrs), n, C.c_void_p(leaves), C.c_void_p(nodes), C.c_void_p(p2), None)
+        assert be.download(p2, 16) == be.download(point, 16)
+        be.free(point); be.free(p2)
+    elif fused:
         be.call('gs_merkle_commit_rows', a, arr, len(ptrs), n, C.c_void_p(leaves), C.c_void_p(nodes))
     else:
         be.call('gs_hash_merge_rows', a, arr, len(ptrs), n, C.c_void_p(leaves))
@@ -429,6 +450,7 @@ def check_merkle_commit(backend, rng, alg, logn, count):
     assert nodes[:32] == b'\0' * 32
     assert [nodes[32 * i:32 * i + 32] for i in range(1, n)] == ref.nodes[1:]
     assert merkle_commit_bytes(backend, alg, cols, n, fused=False) == (leaves, nodes)
+    assert merkle_commit_bytes(backend, alg, cols, n, fused='seed') == (leaves, nodes)
 
 
 def check_device_record_ops(backend, rng):
@@ -517,6 +539,11 @@ def check_device_record_ops(backend, rng):
     be.call('gs_fri_fold_seeded_scaled', f.le(w), n, step, C.c_void_p(column.ptr), m, C.c_void_p(sv.ptr), f.le(scale), C.c_void_p(got.ptr))
     be.call('gs_fri_fold', f.le(w), n, step, C.c_void_p(column.ptr), m, f.le(x), C.c_void_p(want2.ptr))
     assert got.toBuffer() == want2.toBuffer()
+    # gs_fri_fold_at: the fold at a point that lies in device memory
+    xv = f.newVectorFrom([x])
+    got3 = f.newVector(m // 4)
+    be.call('gs_fri_fold_at', f.le(w), n, step, C.c_void_p(column.ptr), m, C.c_void_p(xv.ptr), C.c_void_p(got3.ptr))
+    assert got3.toBuffer() == want2.toBuffer()
     for p_ in (src, dst, addrs):
         be.free(p_)
 
