@@ -57,12 +57,13 @@ def assertions_for(stark, steps, seed):
             {'step': steps - 1, 'register': 0, 'value': trace.getValue(0, steps - 1)}]
 
 
-def cpu_prove(ga, lib, log_steps, ef, exe, fri, threads):
+def cpu_prove(ga, lib, log_steps, ef, exe, fri, threads, timeout=120):
     """one prove() through the native driver on the CPU oracle's implementation of the C ABI, in a child process pinned to
-    `threads` OpenMP threads; returns (seconds, ntt_points)"""
+    `threads` OpenMP threads; returns (seconds, ntt_points, sha256 hex of the serialized proof, its length) — seed 3, assertions at
+    the first and the last step, like the timed GPU proof of rank 0"""
     import subprocess
     code = (
-        'import sys, time, json; sys.path.insert(0, %r)\n'
+        'import sys, time, json, hashlib; sys.path.insert(0, %r)\n'
         'import genstark_amd as ga\n'
         'from genstark_amd._abi import Backend\n'
         'from genstark_amd.native import NativeProver\n'
@@ -74,16 +75,16 @@ def cpu_prove(ga, lib, log_steps, ef, exe, fri, threads):
         'p = NativeProver(st)\n'
         't0 = time.perf_counter(); d = p.prove_bytes(a, [], [3]); dt = time.perf_counter() - t0\n'
         'assert st.verify(a, st.parse(d))\n'
-        'print(json.dumps({"s": dt, "points": p.last_stats()["ntt_points"]}))\n') % (ROOT, lib, log_steps, ef, exe, fri)
+        'print(json.dumps({"s": dt, "points": p.last_stats()["ntt_points"], "sha256": hashlib.sha256(d).hexdigest(), "bytes": len(d)}))\n') % (ROOT, lib, log_steps, ef, exe, fri)
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND='false', OMP_WAIT_POLICY='passive')
-    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=timeout)
     if r.returncode:
         raise RuntimeError(r.stderr[-400:])
     j = json.loads(r.stdout.strip().splitlines()[-1])
-    return j['s'], j['points']
+    return j['s'], j['points'], j['sha256'], j['bytes']
 
 
-def cpu_baseline(ga, ef, fri):
+def cpu_baseline(ga, ef, fri, gpu_digest=None):
     """the CPU path timed on this box's host cores, single-threaded AND on all cores, core count stated, for C2
     (2^13 steps, E=16, exe 48, fri 24) and for the largest trace that stays within the time budget.  "port": the oracle's plain-C
     implementation of the same C ABI under the same native driver (oracle/liboracle_omp.so = oracle_abi.c built with -fopenmp)."""
@@ -94,14 +95,24 @@ def cpu_baseline(ga, ef, fri):
     visible = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     rows = []
     budget = time.perf_counter() + 50.0
+    compared = []
+
+    def same(log_steps, ef_, exe, fri_, sha):
+        # the proof the CPU run produced against the GPU's for the same statement (gpu_digest proves it on the HIP library): bytes, via sha256
+        if gpu_digest is None:
+            return None
+        ok = gpu_digest(log_steps, ef_, exe, fri_) == sha
+        compared.append((log_steps, ef_, fri_, ok))
+        return ok
     # C2 first: one thread, then a sweep of thread counts up to every visible CPU — a container may see more CPUs than its quota
     # lets it run (the first all-256 attempt on the GPU box was 100x slower than one thread); `cores` = the count that won
-    s_, pts = cpu_prove(ga, lib, 13, 16, 48, 24, 1)
-    rows.append({'config': 'C2: 2^13 steps, E=16, exe 48, fri 24', 'threads': 1, 'prove_ms': round(s_ * 1e3, 1), 'elements_per_s': pts / s_})
+    s_, pts, sha, _ = cpu_prove(ga, lib, 13, 16, 48, 24, 1)
+    rows.append({'config': 'C2: 2^13 steps, E=16, exe 48, fri 24', 'threads': 1, 'prove_ms': round(s_ * 1e3, 1), 'elements_per_s': pts / s_,
+                 'same_bytes_as_gpu': same(13, 16, 48, 24, sha)})
     cores, best_c2 = 1, s_
     for threads in [t for t in (4, 8, 16, 32, 64, 128) if t < visible] + [visible]:
         try:
-            s_, pts = cpu_prove(ga, lib, 13, 16, 48, 24, threads)
+            s_, pts, sha, _ = cpu_prove(ga, lib, 13, 16, 48, 24, threads)
         except Exception:   # noqa: BLE001  (timeout: oversubscribed)
             break
         rows.append({'config': 'C2: 2^13 steps, E=16, exe 48, fri 24', 'threads': threads, 'prove_ms': round(s_ * 1e3, 1), 'elements_per_s': pts / s_})
@@ -115,19 +126,23 @@ def cpu_baseline(ga, ef, fri):
     for log_steps in (14, 16, 18, 20):
         if best is not None and best['s'] * 4.5 > budget - time.perf_counter():
             break
-        s_, pts = cpu_prove(ga, lib, log_steps, ef, 48, fri, cores)
-        best = {'log': log_steps, 's': s_, 'points': pts}
-        rows.append({'config': f'2^{log_steps} steps, E={ef}, exe 48, fri {fri}', 'threads': cores, 'prove_ms': round(s_ * 1e3, 1), 'elements_per_s': pts / s_})
+        s_, pts, sha, nbytes = cpu_prove(ga, lib, log_steps, ef, 48, fri, cores)
+        best = {'log': log_steps, 's': s_, 'points': pts, 'same': same(log_steps, ef, 48, fri, sha), 'bytes': nbytes}
+        rows.append({'config': f'2^{log_steps} steps, E={ef}, exe 48, fri {fri}', 'threads': cores, 'prove_ms': round(s_ * 1e3, 1), 'elements_per_s': pts / s_,
+                     'same_bytes_as_gpu': best['same'], 'proof_bytes': nbytes})
     for log_steps in (14, 16, 18):
         if one is not None and one['s'] * 4.5 > budget + 25.0 - time.perf_counter():
             break
-        s_, pts = cpu_prove(ga, lib, log_steps, ef, 48, fri, 1)
+        s_, pts, sha, _ = cpu_prove(ga, lib, log_steps, ef, 48, fri, 1)
         one = {'log': log_steps, 's': s_, 'points': pts}
         rows.append({'config': f'2^{log_steps} steps, E={ef}, exe 48, fri {fri}', 'threads': 1, 'prove_ms': round(s_ * 1e3, 1), 'elements_per_s': pts / s_})
     return {'value': best['points'] / best['s'], 'unit': 'elements/s', 'cores': cores, 'kind': 'port',
             'sample': f'one prove() of MiMC-128 2^{best["log"]} steps, E={ef}, friQueryCount={fri} through the native driver on the CPU oracle '
                       f'(oracle_abi.c, OpenMP, {cores} threads): {best["s"]:.2f} s; NTT points launched / wall time',
             'prove_ms': round(best['s'] * 1e3, 1),
+            # every CPU proof of this leg is compared with the GPU's proof of the same statement (sha256 of the serialized bytes)
+            'same_bytes_as_gpu': (all(ok for *_, ok in compared) if compared else None), 'proof_bytes': best['bytes'],
+            'bytes_compared_for': [f'2^{l} steps, E={e}, fri {q}' for l, e, q, _ in compared],
             'single_thread': {'value': one['points'] / one['s'], 'unit': 'elements/s', 'cores': 1, 'prove_ms': round(one['s'] * 1e3, 1),
                               'sample': f'the same at 2^{one["log"]} steps on one thread'},
             'all_runs': rows, 'host_cpus_visible': visible,
@@ -229,6 +244,38 @@ def pmc_traffic(logn):
         return None, {'error': repr(e)[:200]}
 
 
+def comm_selftest(backend, comm, rank, world):
+    """Both collectives of a gs_comm (include/gstark_comm.h) on rank-stamped patterns in device buffers of `backend`; returns None or
+    what went wrong.  Piece h of rank r's send buffer is the byte (16 * r + h) & 255 repeated (+ the offset inside the piece)."""
+    import ctypes as C
+    piece = 4096
+    ag = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+    pat = lambda r, h: bytes(((16 * r + h + 7 * i) & 255) for i in range(piece))
+    send, recv = backend.alloc(piece * world), backend.alloc(piece * world)
+    try:
+        backend.upload(send, b''.join(pat(rank, h) for h in range(world)))
+        rc = ag(comm.all_gather)(comm.self, backend.ctx, send, recv, piece)          # contributes piece 0 of the send buffer
+        backend.sync()
+        if rc:
+            return f'all_gather returned {rc}'
+        if backend.download(recv, piece * world) != b''.join(pat(r, 0) for r in range(world)):
+            return 'all_gather delivered wrong bytes'
+        backend.upload(recv, bytes(piece * world))
+        rc = ag(comm.all_to_all)(comm.self, backend.ctx, send, recv, piece)
+        backend.sync()
+        if rc:
+            return f'all_to_all returned {rc}'
+        if backend.download(recv, piece * world) != b''.join(pat(r, rank) for r in range(world)):
+            return 'all_to_all delivered wrong bytes'
+        if comm.take_timings:
+            tt = C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.POINTER(C.c_double), C.c_uint32)
+            tt(comm.take_timings)(comm.self, (C.c_double * 8)(), 8)                   # drain the two event pairs
+        return None
+    finally:
+        backend.free(send)
+        backend.free(recv)
+
+
 def self_launch(n):
     """Re-execute this command line under torch.distributed.run with n ranks on this node (127.0.0.1, a free port); returns the
     launcher's exit code.  (The N > 1 form `python -m torch.distributed.run ... bench.py --gpus N` sets WORLD_SIZE and never gets here.)"""
@@ -276,18 +323,27 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    # more ranks than GPUs on this box (a dry run of the N > 1 path on a one-GPU machine): ranks share devices round-robin; RCCL
+    # cannot form a communicator over duplicate devices, so the control path is gloo and the one-proof collectives are staged
+    # through the host (genstark_amd/comm.py: TorchComm) — reported as `gpu_sharing`, rccl_ranks 0
+    ndev = 0 if cpu_mode else torch.cuda.device_count()
+    shared_gpus = (not cpu_mode) and world > ndev >= 1
+    device_index = local_rank % ndev if shared_gpus else local_rank
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if cpu_mode:
+        if cpu_mode or shared_gpus:
             dist.init_process_group('gloo')
+            if not cpu_mode:
+                torch.cuda.set_device(device_index)
         else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))   # nccl == RCCL on ROCm
+            torch.cuda.set_device(device_index)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device_index))   # nccl == RCCL on ROCm
     else:
         dist = None
         if not cpu_mode:
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(device_index)
+    host_collectives = cpu_mode or shared_gpus          # torch.distributed tensors live on the host (gloo)
     launcher_note = None
     if args.gpus != world:
         # a launcher started a different number of ranks than --gpus says: the ranks that exist are what is measured and reported
@@ -303,7 +359,7 @@ def main():
         stream = torch.cuda.Stream()
         torch.cuda.set_stream(stream)
         assert stream.cuda_stream != 0
-        backend = Backend(device=local_rank, stream=stream.cuda_stream)
+        backend = Backend(device=device_index, stream=stream.cuda_stream)
     steps, ef, fri = 1 << args.log_trace, args.extension_factor, args.fri_queries
     n = steps * ef
     seed = 3 + rank
@@ -345,7 +401,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device='cpu' if cpu_mode else 'cuda', dtype=torch.float64)
+        t = torch.tensor([elapsed], device='cpu' if host_collectives else 'cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -420,7 +476,20 @@ def main():
                     'second_roof': second_roof(n, transform_ms, npass, traffic_detail)}
         del src, dst
 
-        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(ga, ef, fri)
+        def gpu_digest(log_steps, ef_, exe, fri_, _cache={}):
+            key = (log_steps, ef_, exe, fri_)
+            if key not in _cache:
+                import hashlib
+                if key == (args.log_trace, ef, 48, fri) and seed == 3:
+                    blob = data                                    # the timed proof itself
+                else:
+                    st_ = ga.instantiateMimc(1 << log_steps, {'hashAlgorithm': 'blake2s256', 'extensionFactor': ef_, 'exeQueryCount': exe, 'friQueryCount': fri_}, backend=backend)
+                    blob = Prover(st_.air, {'hashAlgorithm': 'blake2s256', 'extensionFactor': ef_, 'exeQueryCount': exe, 'friQueryCount': fri_}).prove_bytes(
+                        assertions_for(st_, 1 << log_steps, 3), [], [3])
+                _cache[key] = hashlib.sha256(blob).hexdigest()
+            return _cache[key]
+
+        cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(ga, ef, fri, gpu_digest)
 
         # ---- extra leg (reported beside `value`, never as `value`): throughput of a proving service that keeps several
         # independent proofs in flight on this GPU (genstark_amd/pipeline.py); every proof runs the unmodified prove()
@@ -429,7 +498,7 @@ def main():
             from genstark_amd.pipeline import ProverPool
             job = (a, [], [seed])
             with ProverPool(lambda be: ga.mimcProver(steps, {'hashAlgorithm': 'blake2s256', 'extensionFactor': ef, 'exeQueryCount': 48, 'friQueryCount': fri}, backend=be), lanes=args.lanes,
-                            backend_factory=lambda: Backend(device=local_rank), native=True) as pool:
+                            backend_factory=lambda: Backend(device=device_index), native=True) as pool:
                 for _ in range(max(args.warmup, 1)):
                     pool.on_every_lane(lambda s: s.prove_bytes(*job))
                 tp = time.perf_counter()
@@ -481,7 +550,7 @@ def main():
             ms = (time.perf_counter() - ts) / reps * 1e3
             if hasattr(comm_obj, 'timings'):
                 comm_obj.timings(True)
-            t = torch.tensor([ms], device='cpu' if cpu_mode else 'cuda', dtype=torch.float64)
+            t = torch.tensor([ms], device='cpu' if host_collectives else 'cuda', dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             digests = [None] * world
             dist.all_gather_object(digests, hashlib.sha256(blob).hexdigest())          # verification only, not on the data path
@@ -490,17 +559,40 @@ def main():
         def leg():
             try:
                 if not cpu_mode:
-                    torch.cuda.set_device(local_rank)      # the HIP current device is per-thread state
+                    torch.cuda.set_device(device_index)      # the HIP current device is per-thread state
                     torch.cuda.set_stream(stream)
                 from genstark_amd.comm import RcclComm, TorchComm
-                if cpu_mode:
-                    comm = TorchComm(backend)
-                else:
-                    uid = [RcclComm.unique_id() if rank == 0 else None]
-                    dist.broadcast_object_list(uid, src=0)                              # control path: 128 bytes, once
-                    comm = RcclComm(backend, rank, world, uid[0])
-                result['comm'] = {'name': 'rccl' if not cpu_mode else 'torch.distributed (test double run)', 'ranks': world}
-                result['rccl_ranks'] = world if not cpu_mode else 0
+                comm = None
+                if not host_collectives:
+                    # the product communicator: RCCL on the library's device buffers.  It is checked with known patterns first (both
+                    # collectives, every rank); if any rank cannot create it or sees wrong bytes, ALL ranks fall back to collectives
+                    # staged through the host over a gloo group, so that the strong-scaling figures still exist — and say so
+                    rccl_error = None
+                    try:
+                        uid = [RcclComm.unique_id() if rank == 0 else None]
+                        dist.broadcast_object_list(uid, src=0)                          # control path: 128 bytes, once
+                        comm = RcclComm(backend, rank, world, uid[0])
+                        rccl_error = comm_selftest(backend, comm.comm, rank, world)
+                    except Exception as e:   # noqa: BLE001
+                        rccl_error = repr(e)[:200]
+                    errs = [None] * world
+                    dist.all_gather_object(errs, rccl_error)
+                    if any(errs):
+                        result['rccl_error'] = next(e for e in errs if e)
+                        comm = None
+                if comm is None:
+                    group = dist.new_group(backend='gloo') if not host_collectives else None
+                    comm = TorchComm(backend, group=group)
+                    err = comm_selftest(backend, comm.comm, rank, world)
+                    if err:
+                        raise RuntimeError('host-staged collectives failed their self-test: ' + err)
+                is_rccl = isinstance(comm, RcclComm)
+                result['comm'] = {'name': 'rccl' if is_rccl else ('torch.distributed (test double run)' if cpu_mode else
+                                                                   'torch.distributed gloo, device buffers staged through the host'), 'ranks': world,
+                                  'selftest': 'all_gather + all_to_all of rank-stamped patterns: ok'}
+                if shared_gpus:
+                    result['gpu_sharing'] = f'{world} ranks on {ndev} GPU(s): a dry run of the N > 1 path, not a scaling measurement'
+                result['rccl_ranks'] = world if is_rccl else 0
                 # C4 (BASELINE configs[3]): Poseidon 6x128, 2^16 steps as 1 024 independent 64-step hash chains, E = 16 — and the same AIR
                 # at 2^20 steps (16 384 chains): the 2^16-step statement is latency-bound on ONE GPU already (2.1 ms inside the driver), the
                 # long one is where the shards have work to do.  First rows are packed before the timed region (inputs resident).

@@ -55,8 +55,20 @@ struct JitKernel {
     bool compiling = false;          // a background thread is building the code object (auto mode)
     std::vector<char> code;          // built (or read from the disk cache) but not loaded yet: the next launch loads it
 };
-static std::mutex g_jit_mutex;
-static std::map<std::string, JitKernel> g_jit_cache;   // per process: the lanes of a pool share the compiled programs
+// Process-wide state of the compiled programs.  Heap-allocated and never destroyed: a background builder (auto mode) may still be
+// inside hiprtc when the process reaches exit(), and function-/namespace-scope statics would be destroyed under it.  The builders
+// themselves are joined before the HIP / comgr libraries are torn down (jit_join_builders: atexit + library destructor).
+static std::mutex &g_jit_mutex = *new std::mutex;
+static std::map<std::string, JitKernel> &g_jit_cache = *new std::map<std::string, JitKernel>;   // per process: the lanes of a pool share the compiled programs
+static std::vector<std::thread> &g_jit_builders = *new std::vector<std::thread>;                // guarded by g_jit_mutex
+static std::atomic<bool> g_jit_shutdown{false};
+static void jit_join_builders() {
+    g_jit_shutdown.store(true);
+    std::vector<std::thread> mine;
+    { std::lock_guard<std::mutex> g(g_jit_mutex); mine.swap(g_jit_builders); }
+    for (auto &t : mine) if (t.joinable()) t.join();          // a build takes about a second; its result still reaches the disk cache
+}
+__attribute__((destructor)) static void jit_library_unload() { jit_join_builders(); }          // dlclose, or exit before the dependencies' finalisers
 
 static std::string jit_preamble() {
     std::string s;
@@ -566,18 +578,35 @@ static bool jit_compile(const std::string &source, const char *entry, std::vecto
 // ---- code objects on disk: <dir>/<sha256 of the generated source>.hsaco.  A compiled program outlives the process that built it, so
 // "compile when an AIR is instantiated" costs its seconds once per machine, and the default mode (auto) can use compiled programs
 // whenever they already exist without ever making a proof wait for the compiler.
+// The directory is PRIVATE to the user: created 0700, and used only if it is a real directory (no symlink) owned by the effective
+// user with no group / other write permission — a code object found there is loaded into the proving path, so nobody else may be
+// able to plant one.  Without GSTARK_JIT_CACHE_DIR and without HOME (daemons, bare containers) there is no safe default: no cache.
+// Files are opened without following symlinks and must be regular files of the same owner.
+static bool jit_dir_is_private(const std::string &dir) {
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0) return false;
+    return S_ISDIR(st.st_mode) && st.st_uid == geteuid() && !(st.st_mode & (S_IWGRP | S_IWOTH));
+}
 static std::string jit_cache_path(const std::string &source, const char *entry) {
     const char *dir = getenv("GSTARK_JIT_CACHE_DIR");
     std::string base;
     if (dir && dir[0]) base = dir;
     else {
         const char *home = getenv("HOME");
-        base = std::string(home && home[0] ? home : "/tmp") + "/.cache/gstark_jit";
+        if (!home || !home[0]) return "";
+        base = std::string(home) + "/.cache/gstark_jit";
     }
     if (base == "0" || base == "off") return "";
+    while (base.size() > 1 && base.back() == '/') base.pop_back();
     std::string acc;
-    for (size_t i = 1; i <= base.size(); i++)          // mkdir -p
-        if (i == base.size() || base[i] == '/') { acc = base.substr(0, i); mkdir(acc.c_str(), 0755); }
+    for (size_t i = 1; i <= base.size(); i++)          // mkdir -p: parents with the usual mode, the cache directory itself private
+        if (i == base.size() || base[i] == '/') { acc = base.substr(0, i); (void)mkdir(acc.c_str(), i == base.size() ? 0700 : 0755); }
+    if (!jit_dir_is_private(base)) {
+        static std::atomic<bool> warned{false};
+        if (!warned.exchange(true) && getenv("GSTARK_AIR_JIT_VERBOSE"))
+            fprintf(stderr, "[gstark] code-object cache %s is not a private directory of this user (owner, mode, symlink): not used\n", base.c_str());
+        return "";
+    }
     // the key covers everything the code object depends on: the generated source AND the field headers it is compiled against
     std::string keyed = std::string(entry) + "|gfx950|v2|" + kFieldHeader;
 #ifdef GS_JIT_LAZY
@@ -592,14 +621,22 @@ static std::string jit_cache_path(const std::string &source, const char *entry) 
 }
 static bool jit_disk_read(const std::string &path, std::vector<char> &code) {
     if (path.empty()) return false;
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    fseek(f, 0, SEEK_END);
-    long n = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    bool ok = n > 0;
-    if (ok) { code.resize((size_t)n); ok = fread(code.data(), 1, (size_t)n, f) == (size_t)n; }
-    fclose(f);
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return false;
+    struct stat st;
+    bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() && !(st.st_mode & (S_IWGRP | S_IWOTH)) && st.st_size > 0;
+    if (ok) {
+        code.resize((size_t)st.st_size);
+        size_t got = 0;
+        while (got < code.size()) {
+            const ssize_t r = read(fd, code.data() + got, code.size() - got);
+            if (r <= 0) break;
+            got += (size_t)r;
+        }
+        ok = got == code.size();
+    }
+    close(fd);
+    if (!ok) code.clear();
     return ok;
 }
 static void jit_disk_write(const std::string &path, const std::vector<char> &code) {
@@ -607,11 +644,16 @@ static void jit_disk_write(const std::string &path, const std::vector<char> &cod
     char tmp[32];
     snprintf(tmp, sizeof tmp, ".%d.tmp", (int)getpid());
     const std::string t = path + tmp;
-    FILE *f = fopen(t.c_str(), "wb");
-    if (!f) return;
-    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
-    fclose(f);
-    if (ok) rename(t.c_str(), path.c_str()); else remove(t.c_str());
+    const int fd = open(t.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return;
+    size_t put = 0;
+    while (put < code.size()) {
+        const ssize_t r = write(fd, code.data() + put, code.size() - put);
+        if (r <= 0) break;
+        put += (size_t)r;
+    }
+    close(fd);
+    if (put == code.size()) rename(t.c_str(), path.c_str()); else remove(t.c_str());
 }
 static bool jit_load(JitKernel &k, const char *entry) {
     if (hipModuleLoadData(&k.module, k.code.data()) != hipSuccess) return false;
@@ -656,20 +698,26 @@ static JitKernel *jit_get(gs_ctx *c, const std::string &source, const char *entr
         k.failed = false;
         return &k;
     }
+    if (g_jit_shutdown.load()) return nullptr;                        // the process is on its way out: interpret, start nothing
     k.compiling = true;
-    std::thread([source, path, entry]() {
-        static std::mutex one_at_a_time;          // hiprtc builds one program at a time (two concurrent builds: the second came back empty)
+    static std::once_flag at_exit_once;
+    std::call_once(at_exit_once, [] { atexit(jit_join_builders); });   // registered after HIP / hiprtc initialised: runs before their teardown
+    g_jit_builders.emplace_back([source, path, entry]() {
+        static std::mutex &one_at_a_time = *new std::mutex;   // hiprtc builds one program at a time (two concurrent builds: the second came back empty)
         std::vector<char> code;
         std::string log;
-        bool ok;
-        { std::lock_guard<std::mutex> b(one_at_a_time); ok = jit_compile(source, entry, code, log); }
+        bool ok = false;
+        {
+            std::lock_guard<std::mutex> b(one_at_a_time);
+            if (!g_jit_shutdown.load()) ok = jit_compile(source, entry, code, log);          // queued behind another build at exit: skip
+        }
         if (!ok && getenv("GSTARK_AIR_JIT_VERBOSE")) fprintf(stderr, "[gstark] background build of %s failed: %.600s\n", entry, log.c_str());
         if (ok) jit_disk_write(path, code);
         std::lock_guard<std::mutex> g(g_jit_mutex);
         JitKernel &kk = g_jit_cache[source];
         if (ok) kk.code.swap(code); else kk.failed = true;
         kk.compiling = false;
-    }).detach();
+    });
     return nullptr;
 }
 

@@ -127,6 +127,29 @@ def test_native_prover_2p20_config(hip_backend):
     assert stark.verify(assertions, stark.parse(data))
 
 
+@pytest.mark.gpu
+def test_headline_proof_bytes_hip_equals_oracle():
+    """BASELINE configs[4] (C5: MiMC-128, 2^20 steps, E = 16, friQueryCount 64, blake2s256) END TO END: the serialized proof the
+    product entry (genstark_amd.prover.Prover on the HIP library) produces against the proof of the same statement on the CPU
+    oracle's implementation of the C ABI (OpenMP build, its own process) — every byte, via sha256 + length (lib/Stark.ts:81-163)."""
+    import bench
+    from conftest import ROOT
+    from genstark_amd._abi import Backend
+    from genstark_amd.prover import Prover
+    import subprocess
+    lib = os.path.join(ROOT, 'oracle', 'liboracle_omp.so')
+    if not os.path.exists(lib):
+        subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), '-s', 'liboracle_omp.so'])
+    threads = min(16, len(os.sched_getaffinity(0)))
+    _, _, sha, nbytes = bench.cpu_prove(ga, lib, 20, 16, 48, 64, threads, timeout=600)        # asserts verify() in the child
+    opts = {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 48, 'friQueryCount': 64}
+    be = Backend(device=0)
+    stark = ga.instantiateMimc(1 << 20, opts, None, backend=be)
+    data = Prover(stark.air, opts).prove_bytes(bench.assertions_for(stark, 1 << 20, 3), [], [3])
+    assert len(data) == nbytes and hashlib.sha256(data).hexdigest() == sha
+    assert len(data) == stark.sizeOf(stark.parse(data))
+
+
 def test_product_prover_entry(oracle_backend):
     """genstark_amd.prover.Prover: an AIR + options straight into the native driver (no mirror object), the reference's option rules
     (lib/Stark.ts:318-344), bytes of the mirror, and the CPU verifier behind verify()."""
