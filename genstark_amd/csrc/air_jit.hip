@@ -13,6 +13,7 @@
 // Same arithmetic (the field header the library itself is built from is embedded in the source), same values; any failure to
 // compile falls back to the interpreter.  gs_air_jit_check generates + compiles without a device (CPU test tier).
 #include <hip/hiprtc.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -843,6 +844,15 @@ int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const u
 
 // Compile-only check (no device, no context): does the generated source for this program build for gfx950?  kind 0: trace segments
 // (code + optional init program), kind 1: constraints.  The "does it build" tier of the tests runs it on machines without a GPU.
+// Test hook (not part of include/gstark.h): where the code object of `source` would be cached under the current environment — the
+// empty string when the cache is disabled or the directory is not private to this user.  Creates the directory like a real build.
+extern "C" int gs_jit_cache_path_probe(const char *source, char *out, uint64_t cap) {
+    if (!source || !out || !cap) return GS_ERR_ARG;
+    const std::string path = jit_cache_path(source, "gs_jit_probe");
+    snprintf(out, (size_t)cap, "%s", path.c_str());
+    return GS_OK;
+}
+
 extern "C" int gs_air_jit_check(int kind, const uint32_t *code, uint32_t ninstr, const uint32_t *init_code, uint32_t init_ninstr,
                                 const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs, uint32_t registers, const uint64_t *static_lens,
                                 uint32_t nstatic, char *log_out, uint64_t log_cap) {

@@ -31,7 +31,10 @@ bool begin(RcclState *s, hipStream_t st) {
     if (!s->timings) return true;
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (!s->spare.empty()) { ev = s->spare.back(); s->spare.pop_back(); }
-    else if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) return false;
+    else {
+        if (hipEventCreate(&ev.first) != hipSuccess) return false;
+        if (hipEventCreate(&ev.second) != hipSuccess) { (void)hipEventDestroy(ev.first); return false; }
+    }
     s->timed.push_back(ev);
     return hipEventRecord(ev.first, st) == hipSuccess;
 }

@@ -431,6 +431,12 @@ int gs_merkle_commit_rows_seed(gs_ctx *c, gs_hash_alg alg, const void *const *ve
     if (!c || (!point_out && !ticket)) return GS_ERR_ARG;
     if (point_out && ((uintptr_t)point_out & 15)) return gs_fail(c, GS_ERR_ARG, "merkle_commit_rows_seed: point_out must be 16-byte aligned");
     RootTail tail = {nullptr, nullptr, 0, (fe *)point_out};
+    // every argument is checked BEFORE a read-back slot is reserved: a rejected call must not leave a ticket nobody will ever deliver
+    if (!vecs_host || !leaves || !nodes) return GS_ERR_ARG;
+    if (int rc0 = check_alg(c, alg)) return rc0;
+    if (count == 0) return gs_fail(c, GS_ERR_ARG, "merkle_commit_rows: no vectors");
+    if (!gs_is_pow2(n) || n < 2) return gs_fail(c, GS_ERR_ARG, "merkle_commit_rows: n must be a power of two >= 2");
+    if (((uintptr_t)leaves | (uintptr_t)nodes) & 15) return gs_fail(c, GS_ERR_ARG, "merkle_commit_rows: buffers must be 16-byte aligned");
     if (ticket) {
         void *slot;
         int rc = gs_readback_reserve(c, 32, &slot, &tail.flag, &tail.value, ticket);

@@ -102,11 +102,13 @@ static inline hfe hf_canon(hfe x) {
 // products inside a long chain whose end is canonicalised once (host_pow in air_vm.hip)
 #define HF_CHAIN_MUL hf_mul_weak
 #define HF_CHAIN_END hf_canon
-// sum of two weak values (any 128-bit representatives), weak again: a wrap past 2^128 comes back as + C (2^128 == C mod p), branch-free;
-// the wrapped sum is at most 2^128 - 2, so adding C cannot wrap a second time
+// sum of two weak values (any 128-bit representatives), weak again: a wrap past 2^128 comes back as + C (2^128 == C mod p), branch-free.
+// The wrapped sum can be as large as 2^128 - 2, so adding C may wrap ONCE more (when both operands are within ~2^36 of 2^128); that
+// second wrap leaves a value below C and is paid back the same way — a third is impossible.
 static inline hfe hf_add_weak(hfe a, hfe b) {
-    hfe s = a + b;
-    return s + (((hfe)0 - (hfe)(s < a)) & HF_C);
+    const hfe s = a + b;
+    const hfe t = s + (((hfe)0 - (hfe)(s < a)) & HF_C);
+    return t + (((hfe)0 - (hfe)(t < s)) & HF_C);
 }
 #define HF_CHAIN_ADD hf_add_weak
 static inline hfe hf_add(hfe a, hfe b) {

@@ -487,8 +487,12 @@ __global__ __launch_bounds__(64, 4) void k_ntt_wave(const fe *__restrict__ in, f
     kseg_t kp = (kseg_t)__builtin_amdgcn_kernarg_segment_ptr();
     int t2 = threadIdx.x;
     asm volatile("" : "+s"(kp), "+v"(t2) : : "memory");
-    fe *const out2 = *(fe *const __attribute__((address_space(4))) *)(kp + 8);
-    const kargs_t b = (kargs_t)(kp + 16);
+    // the kernel-argument segment is the argument list laid out like a struct: (const fe *in, fe *out, LzPassArgs a)
+    struct KernargMirror { const fe *in; fe *out; LzPassArgs a; };
+    static_assert(offsetof(KernargMirror, out) == 8 && offsetof(KernargMirror, a) == 16 && alignof(LzPassArgs) <= 16 &&
+                  sizeof(KernargMirror) == 16 + sizeof(LzPassArgs), "k_ntt_wave re-reads its arguments at these offsets: keep them in step with the signature");
+    fe *const out2 = *(fe *const __attribute__((address_space(4))) *)(kp + offsetof(KernargMirror, out));
+    const kargs_t b = (kargs_t)(kp + offsetof(KernargMirror, a));
     fe *const dst = out2 + (uint64_t)blockIdx.y * b->out_stride;
     const uint64_t Ns2 = 1ull << b->logNs;
     const int weak = b->weak;

@@ -10,8 +10,9 @@ import pytest
 # compiled programs (Backend.jit(True) / .jit('auto')), code objects in a directory of their own.
 import os as _os
 import tempfile as _tempfile
-_os.environ.setdefault('GSTARK_AIR_JIT', '0')
-_os.environ.setdefault('GSTARK_JIT_CACHE_DIR', _os.path.join(_tempfile.gettempdir(), 'gstark_jit_tests'))
+if not _os.environ.get('GSTARK_TEST_AUTO_CHILD'):      # tests/test_generic_air.py::test_generic_suite_in_default_auto_mode runs a child suite in the product default
+    _os.environ.setdefault('GSTARK_AIR_JIT', '0')
+_os.environ.setdefault('GSTARK_JIT_CACHE_DIR', _os.path.join(_tempfile.gettempdir(), f'gstark_jit_tests_{_os.getuid()}'))
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

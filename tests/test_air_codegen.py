@@ -3,6 +3,7 @@ runs the compiler (hiprtc cross-compiles gfx950 without a device) — the "does 
 run time.  The values the compiled programs compute are compared with the interpreter's in the gpu tier
 (test_generic_air.py::test_compiled_air_programs_equal_interpreted, test_pipeline.py)."""
 import ctypes as C
+import os
 
 import pytest
 
@@ -97,3 +98,43 @@ def test_small_field_constraint_program_builds_for_gfx950():
     _build_oracle()
     f = PrimeField(backend=Backend(lib_path=os.path.join(ROOT, 'oracle', 'liboracle_q64.so'), allow_test_double=True))
     builds(rescue2x64_air(32, 16, f), load_library(HIP_LIB_PATHS[MODULUS_64]))
+
+
+def _probe(env_extra, drop=()):
+    """genstark_amd/csrc/air_jit.hip: gs_jit_cache_path_probe in a child process with a controlled environment."""
+    import subprocess
+    import sys
+    from genstark_amd import _abi
+    code = ('import ctypes, sys\nlib = ctypes.CDLL(%r)\nbuf = ctypes.create_string_buffer(4096)\n'
+            'assert lib.gs_jit_cache_path_probe(b"source", buf, ctypes.c_uint64(4096)) == 0\nprint("PATH=" + buf.value.decode())\n') % _abi.HIP_LIB_PATH
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return [l for l in r.stdout.splitlines() if l.startswith('PATH=')][0][5:]
+
+
+def test_code_object_cache_directory_must_be_private(tmp_path):
+    """a code object found in the cache is loaded into the proving path, so the cache directory must belong to the user:
+    created 0700; a directory writable by group / others, a symlink, or no HOME and no GSTARK_JIT_CACHE_DIR -> no cache at all."""
+    import stat
+    fresh = tmp_path / 'fresh' / 'cache'
+    path = _probe({'GSTARK_JIT_CACHE_DIR': str(fresh)})
+    assert path.startswith(str(fresh) + '/') and path.endswith('.hsaco')
+    assert stat.S_IMODE(os.stat(fresh).st_mode) == 0o700
+    shared = tmp_path / 'shared'
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    assert _probe({'GSTARK_JIT_CACHE_DIR': str(shared)}) == ''
+    os.chmod(shared, 0o775)
+    assert _probe({'GSTARK_JIT_CACHE_DIR': str(shared)}) == ''
+    os.chmod(shared, 0o755)
+    assert _probe({'GSTARK_JIT_CACHE_DIR': str(shared)}) != ''
+    link = tmp_path / 'link'
+    os.symlink(fresh, link)
+    assert _probe({'GSTARK_JIT_CACHE_DIR': str(link)}) == ''
+    assert _probe({}, drop=('HOME', 'GSTARK_JIT_CACHE_DIR')) == ''
+    home = tmp_path / 'home'
+    home.mkdir()
+    assert _probe({'HOME': str(home)}, drop=('GSTARK_JIT_CACHE_DIR',)).startswith(str(home) + '/.cache/gstark_jit/')
+    assert _probe({'GSTARK_JIT_CACHE_DIR': 'off'}) == ''

@@ -338,6 +338,39 @@ def test_air_programs_auto_mode(hip_backend, tmp_path):
 
 
 @pytest.mark.gpu
+def test_exit_during_first_background_build(tmp_path):
+    """a short-lived process in the default (auto) mode reaches exit() while the background builder is still inside hiprtc.
+    The builder is joined before the HIP / comgr libraries are torn down: the process must end cleanly (exit code 0, no signal)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSTARK_JIT_CACHE_DIR=str(tmp_path / 'cache'))
+    env.pop('GSTARK_AIR_JIT', None)
+    script = ('import os, sys\nROOT = %r\nsys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)\n'
+              'import test_generic_air as t\nfrom genstark_amd._abi import Backend\nb = Backend(device=0)\n'
+              't.check_segmented(b, "poseidon", 1024)\nprint("PROVED", b.jit_launches)\n') % root      # ... and straight to exit()
+    for _ in range(2):           # second round: one program may already be cached, the other still building
+        r = subprocess.run([sys.executable, '-c', script], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and 'PROVED' in r.stdout, (r.returncode, r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_generic_suite_in_default_auto_mode(tmp_path):
+    """The rest of this suite pins GSTARK_AIR_JIT=0 so that its results do not depend on what earlier processes left in the disk cache;
+    the PRODUCT default is auto.  This runs the generic-AIR GPU tests once more in a child pytest with the variable unset (programs
+    interpreted at first, compiled as the background builds land) and a cache directory of its own."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSTARK_JIT_CACHE_DIR=str(tmp_path / 'cache'), GSTARK_TEST_AUTO_CHILD='1')
+    env.pop('GSTARK_AIR_JIT', None)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_generic_air.py'), os.path.join(root, 'tests', 'test_lib128.py'),
+                        '-m', 'gpu', '-q', '-x', '-k', 'not auto_mode and not background_build and not compiled_air_programs_equal_interpreted', '-p', 'no:cacheprovider'],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('kind', ['rescue', 'poseidon'])
 def test_segmented_2p16_configs_verify(hip_backend, kind):
     """BASELINE configs[2] / configs[3] in the reference's sense: 2^16 steps = 2048 Rescue hashes / 1024 Poseidon hashes."""
