@@ -27,6 +27,12 @@ HIP_LIB_PATHS = {MODULUS_128: HIP_LIB_PATH, MODULUS_64: os.path.join(_HERE, 'csr
                  MODULUS_224: os.path.join(_HERE, 'csrc', 'libgstark_hip_p224.so')}
 
 GS_OK = 0
+
+
+class FriLayer(C.Structure):
+    """struct gs_fri_layer of include/gstark.h (gs_fri_layers): one layer's outputs."""
+    _fields_ = [('next', C.c_void_p), ('leaves', C.c_void_p), ('nodes', C.c_void_p), ('point_out', C.c_void_p), ('ticket', C.c_uint64)]
+
 HASH_ALGS = {'sha256': 0, 'blake2s256': 1}  # gs_hash_alg; lib/Stark.ts:19
 
 _vp, _u64, _u32, _int = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
@@ -88,6 +94,7 @@ _SIGNATURES = {
     'gs_fri_fold_seeded_scaled': (_int, [_vp, _bytes, _u64, _u64, _vp, _u64, _vp, _bytes, _vp]),
     'gs_merkle_commit_rows_seed': (_int, [_vp, _int, _pvp, _u32, _u64, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
     'gs_fri_fold_at': (_int, [_vp, _bytes, _u64, _u64, _vp, _u64, _vp, _vp]),
+    'gs_fri_layers': (_int, [_vp, _int, _bytes, _u64, _u64, _vp, _u64, _vp, _u32, _vp]),
     'gs_eval_quartic_batch': (_int, [_vp, _vp, _u64, _bytes, _vp]),
     'gs_hash_digest': (_int, [_vp, _int, _bytes, _u64, _vp]),
     'gs_hash_merge_rows': (_int, [_vp, _int, _pvp, _u32, _u64, _vp]),

@@ -56,6 +56,7 @@ struct gs_ctx {
     void *d_stage = nullptr;
     uint64_t stage_bytes = 0;
     void *fri_x = nullptr;        // the evaluation point gs_fri_fold_seeded derives on the device
+    void *fri_points = nullptr;   // gs_fri_layers: points between layers the caller did not ask for + the arrival counter of its multi-workgroup launches
     uint64_t jit_launches = 0;    // compiled-program launches so far (gs_air_jit_launches)
     uint64_t host_trace_segments = GS_HOST_TRACE_MAX_SEGMENTS;   // traces of at most this many segments run on a host core (GSTARK_HOST_TRACE_SEGMENTS; air_vm.hip)
     int air_jit = 2;              // AIR programs: 0 interpreted, 1 compiled on first use (hiprtc), 2 auto = compiled when the code object already exists (gs_air_jit / GSTARK_AIR_JIT)

@@ -184,6 +184,59 @@ GF_HD lz lz_fold9(int64_t c[9], const lzk &K) {
     return lz_fold_columns(c, K);
 }
 
+// x * w * B^-5 (mod p) — Montgomery's REDC on the nine columns of the product, from the BOTTOM.  In this radix
+//     p = 1 - 576*B + 2^24*B^4   (9*2^32 = 576*B, 2^128 = 2^24*B^4),   p == 1 (mod B),
+// so the multiple of p that clears the low limb of column i is q = -(c_i mod B) — no multiplication to find it — and adding q*p*B^i
+// leaves c_i - lo = carry*B, c_{i+1} += 576*lo, c_{i+4} -= 2^24*lo: two v_mad per step instead of the four a HIGH column costs in
+// lz_fold9 (35 + 5 carry v_mad per product instead of 46).  After five steps columns 5..8 hold the result; the common carry tail
+// brings it to NN limbs.  The multiplier is stored premultiplied by R = B^5 = 2^130 (twiddle tables: x * (w R) / R = x * w), so the
+// DATA never leaves the ordinary domain and every other routine of this file applies to it unchanged.
+// Bounds: |c_k| < 2^57 - 2^51 on entry (every input class of the pass kernels: tests/test_lazy_field.py) — a step adds less than
+// 2^50 + 2^36 + 2^31 to a column; the result is within (x w / R - p, x w / R], a few units of 2^128: t below is a handful of bits.
+GF_HD lz lz_mul_vm(const lz &x, const lz &wR, const lzk &K) {
+    int64_t c[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        int64_t s = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < 5) s += (int64_t)x.l[i] * wR.l[j];
+        }
+        c[k] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int32_t lo = lz_low(c[i]);
+        const int32_t k = lz_carry(c[i]);
+        c[i + 1] = lz_mad_ik(lo, 576, c[i + 1]);
+        c[i + 1] = lz_mad_ik(k, 1, c[i + 1]);
+        c[i + 4] = lz_mad_ik(lo, -(1 << 24), c[i + 4]);
+    }
+    lz y;
+    int32_t k = lz_carry(c[5]);
+    y.l[0] = lz_low(c[5]);
+    c[6] = lz_mad_ik(k, 1, c[6]);
+    k = lz_carry(c[6]);
+    y.l[1] = lz_low(c[6]);
+    c[7] = lz_mad_ik(k, 1, c[7]);
+    k = lz_carry(c[7]);
+    y.l[2] = lz_low(c[7]);
+    c[8] = lz_mad_ik(k, 1, c[8]);
+    k = lz_carry(c[8]);               // limb 4 of the result, signed, a few bits above 2^24 at most
+    y.l[3] = lz_low(c[8]);
+    const int32_t t = k >> 24;        // the part at 2^128 == 576*B - 1
+    y.l[4] = k & 0xffffff;
+    y.l[1] += t * 576;
+    y.l[0] -= t;
+    return y;
+}
+// R^2 mod p and R mod p (R = 2^130) as canonical elements: x * R = lz_mul_vm(x, R^2)
+//   R  = 2^130 mod p = 4 * (9 * 2^32 - 1) = 36 * 2^32 - 4
+//   R2 = R^2 mod p   = 1296 * 2^64 - 288 * 2^32 + 16
+GF_HD fe lz_mont_r() { return fe_make(0xFFFFFFFCu, 35u, 0u, 0u); }
+GF_HD fe lz_mont_r2() { return fe_make(16u, 0xFFFFFEE0u, 1295u, 0u); }
+
 // carry propagation without a product (elements that skip a twiddle): any limbs |l_i| < 2^31 - 2^6 -> NN
 GF_HD lz lz_norm(const lz &x) {
     lz y;

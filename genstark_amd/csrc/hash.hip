@@ -362,6 +362,161 @@ int gs_prng_point_dev(gs_ctx *c, const void *seed32_dev, fe *out_dev) {
     return GS_OK;
 }
 
+
+// ---- a RUN of FRI layers (gs_fri_layers; LowDegreeProver.ts:176-221) ------------------------------------------------------------------
+// One launch per layer, and ONE launch for all layers from the first that fits a single workgroup.  A workgroup owns GS_FRI_CH
+// consecutive leaves of the layer's tree: 4 * GS_FRI_CH threads fold the rows those leaves hash (leaf i = the folded values at i,
+// i + L, i + 2L, i + 3L: each thread one row of transposeVector(column, 4), exactly k_fri_fold's arithmetic), the values go to the
+// next column in memory and to LDS, GS_FRI_CH threads hash the leaves from LDS, the subtree above them is built in LDS (the levels of
+// k_merkle_subtree).  With several workgroups, each counts itself done on a device counter after an agent-scope release fence; the one
+// that arrives LAST reads the subtree roots of all (acquire fence first: the L2s of the eight XCDs are not coherent with each other
+// without it) and builds the tree over them.  The workgroup that holds the root posts it to the host, derives prng(root) — the point
+// of the next layer — and, when it is the only workgroup, goes on with the next layer itself: its inputs are what it has just written.
+#define GS_FRI_CH 256
+#define GS_FRI_THREADS (4 * GS_FRI_CH)
+#define GS_FRI_MAX_LAYERS 16
+#define GS_FRI_ONE_LAUNCH_LEAVES (1ull << 15)      // wider layers: the streaming fold + the fused tree launches (throughput-bound)
+struct FriLayerDesc {
+    const fe *column;          // 4 * rows values
+    fe *next;                  // rows values
+    uint4 *leaves, *nodes;     // rows / 4 digests each
+    fe *point_out;             // may be null
+    uint4 *slot;               // posted root
+    unsigned long long *flag;
+    unsigned long long value;
+    uint64_t rows, step;
+};
+struct FriLayersArgs {
+    FriLayerDesc layer[GS_FRI_MAX_LAYERS];
+    uint32_t first, count;
+    const fe *point_in;
+    const fe *tw_lo, *tw_hi;
+    int log_lo, logn;
+    uint64_t n;
+    fe zeta_inv, inv4;
+    unsigned int *counter;
+};
+
+// the levels m = first_m, first_m / 2, ..., 1 of a subtree whose first layer lies in the LDS heap `sh` (node s at sh[2s], sh[2s + 1]);
+// level of width m is stored to nodes[wl + offset * m + i], wl halving with m.  blockDim.x threads, one barrier per level.
+template <int ALG>
+__device__ __forceinline__ void fri_subtree_levels(uint4 *sh, uint32_t first_m, uint64_t wl, uint64_t offset, uint4 *__restrict__ nodes) {
+    for (uint32_t m = first_m; m >= 1; m >>= 1, wl >>= 1) {
+        bool done = false;
+        if constexpr (ALG == 1) {
+            if (m <= GS_FRI_THREADS / 4) {                      // four lanes per node (hash_core.h: b2s_node_quad), as in k_merkle_subtree
+                if (threadIdx.x < 4 * m) {
+                    const uint32_t i = threadIdx.x >> 2, l = threadIdx.x & 3u, s = m + i;
+                    uint32_t *w = reinterpret_cast<uint32_t *>(sh);
+                    uint32_t lo, hi;
+                    b2s_node_quad(w + 16 * s, (int)l, lo, hi);
+                    w[8 * s + l] = lo;
+                    w[8 * s + 4 + l] = hi;
+                    uint32_t *g = reinterpret_cast<uint32_t *>(nodes) + 8 * (wl + offset * m + i);
+                    g[l] = lo;
+                    g[4 + l] = hi;
+                }
+                done = true;
+            }
+        }
+        if (!done) {
+            for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+                const uint32_t s = m + i;
+                const uint4 x0 = sh[4 * s], x1 = sh[4 * s + 1], x2 = sh[4 * s + 2], x3 = sh[4 * s + 3];
+                uint32_t d[8];
+                digest_words16<ALG>([&](uint32_t k) { return k == 0 ? x0 : (k == 1 ? x1 : (k == 2 ? x2 : x3)); }, 4, d);
+                sh[2 * s] = make_uint4(d[0], d[1], d[2], d[3]);
+                sh[2 * s + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+                store_digest(nodes, wl + offset * m + i, d);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int ALG>
+__global__ __launch_bounds__(GS_FRI_THREADS) void k_fri_layers(FriLayersArgs a) {
+    __shared__ fe colbuf[4 * GS_FRI_CH];           // this workgroup's folded values: quarter q of leaf i at [q * CH + i]
+    __shared__ uint4 sh[4 * GS_FRI_CH];            // digest heap of the subtree (and, in the last workgroup, of the tree over the subtree roots)
+    __shared__ fe point_sh;
+    __shared__ int last_sh;
+    const uint32_t tid = threadIdx.x, G = gridDim.x;
+    fe t = *a.point_in;
+    for (uint32_t li = a.first; li < a.first + a.count; li++) {
+        const FriLayerDesc &D = a.layer[li];
+        const uint64_t rows = D.rows, L = rows >> 2;
+        const uint32_t CH = L < GS_FRI_CH ? (uint32_t)L : (uint32_t)GS_FRI_CH;
+        const uint64_t base = (uint64_t)blockIdx.x * CH;
+        if (tid < 4 * CH) {                          // one row of transposeVector(column, 4) per thread (k_fri_fold)
+            const uint32_t q = tid / CH, i = tid - q * CH;
+            const uint64_t r = base + i + (uint64_t)q * L;
+            const fe *col = D.column;
+            const fe y0 = col[r], y1 = col[r + rows], y2 = col[r + 2 * rows], y3 = col[r + 3 * rows];
+            const fe s0 = fe_add(y0, y2), s1 = fe_sub(y0, y2), s2 = fe_add(y1, y3);
+            const fe s3 = fe_mul(fe_sub(y1, y3), a.zeta_inv);
+            const fe u0 = fe_add(s0, s2), u2 = fe_sub(s0, s2), u1 = fe_add(s1, s3), u3 = fe_sub(s1, s3);
+            uint64_t e = (r * D.step) & (a.n - 1);
+            e = e ? a.n - e : 0;
+            fe tx = t;                               // X * x_r^-1
+            if (e) {
+                fe xi = a.tw_lo[e & ((1ull << a.log_lo) - 1)];
+                if (a.logn > a.log_lo) xi = fe_mul(xi, a.tw_hi[e >> a.log_lo]);
+                tx = fe_mul(t, xi);
+            }
+            fe v = fe_add(fe_mul(u3, tx), u2);
+            v = fe_add(fe_mul(v, tx), u1);
+            v = fe_add(fe_mul(v, tx), u0);
+            v = fe_mul(v, a.inv4);
+            D.next[r] = v;
+            colbuf[q * CH + i] = v;
+        }
+        __syncthreads();
+        if (tid < CH) {                              // leaf = H(next[i] || next[i + L] || next[i + 2L] || next[i + 3L])
+            const uint4 *cb = reinterpret_cast<const uint4 *>(colbuf);
+            uint32_t d[8];
+            digest_words16<ALG>([&](uint32_t w) { return cb[(uint64_t)((w / GS_EW) * CH + tid) * GS_EW + w % GS_EW]; }, 4 * GS_EW, d);
+            store_digest(D.leaves, base + tid, d);
+            sh[2 * (CH + tid)] = make_uint4(d[0], d[1], d[2], d[3]);
+            sh[2 * (CH + tid) + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+        }
+        __syncthreads();
+        fri_subtree_levels<ALG>(sh, CH / 2, L >> 1, blockIdx.x, D.nodes);
+        if (G > 1) {
+            __threadfence();                         // release: this workgroup's nodes (its subtree root among them) reach memory
+            __syncthreads();
+            if (tid == 0) last_sh = atomicAdd(a.counter, 1u) == G - 1;
+            __syncthreads();
+            if (!last_sh) return;
+            __threadfence();                         // acquire: the other workgroups' subtree roots, not a stale line of this XCD's L2
+            for (uint32_t i = tid; i < G; i += GS_FRI_THREADS) {        // heap nodes G .. 2G - 1 of the layer's tree
+                sh[2 * (G + i)] = D.nodes[2 * (G + (uint64_t)i)];
+                sh[2 * (G + i) + 1] = D.nodes[2 * (G + (uint64_t)i) + 1];
+            }
+            if (tid == 0) atomicExch(a.counter, 0u);                    // ready for the next launch on this context's stream
+            __syncthreads();
+            fri_subtree_levels<ALG>(sh, G / 2, G >> 1, 0, D.nodes);
+        }
+        if (tid == 0) {                              // the root is heap node 1: sh[2], sh[3]
+            D.nodes[0] = make_uint4(0, 0, 0, 0);
+            D.nodes[1] = make_uint4(0, 0, 0, 0);
+            const uint4 r0 = sh[2], r1 = sh[3];
+            if (D.slot) {
+                D.slot[0] = r0;
+                D.slot[1] = r1;
+                __threadfence_system();
+                __hip_atomic_store(D.flag, D.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            const uint32_t seed[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            const fe x = prng_point(seed);
+            if (D.point_out) *D.point_out = x;
+            point_sh = x;
+        }
+        if (G > 1) return;                           // a launch of several workgroups is one layer
+        __syncthreads();                             // the next layer's column is what this workgroup has just stored (D.next)
+        t = point_sh;
+    }
+}
+
 extern "C" {
 
 int gs_hash_digest_values(gs_ctx *c, gs_hash_alg alg, const void *buf, uint64_t value_size, uint64_t count, void *out) {
@@ -462,6 +617,87 @@ static int commit_rows(gs_ctx *c, gs_hash_alg alg, const void *const *vecs_host,
     const int src = count == 1 ? 1 : 2;
     return alg == GS_HASH_SHA256 ? merkle_run<0>(c, src, va, count, nullptr, leaves, n, (uint4 *)nodes, tail)
                                  : merkle_run<1>(c, src, va, count, nullptr, leaves, n, (uint4 *)nodes, tail);
+}
+
+int gs_fri_layers(gs_ctx *c, gs_hash_alg alg, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t len, const void *x_dev,
+                  uint32_t nlayers, struct gs_fri_layer *layers) {
+    if (!c || !omega || !column || !x_dev || !layers || !nlayers) return GS_ERR_ARG;
+    int rc = check_alg(c, alg);
+    if (rc) return rc;
+    if (!gs_is_pow2(n) || len < 32 || !gs_is_pow2(len) || len * step != n) return gs_fail(c, GS_ERR_ARG, "fri_layers: len must be a power of two >= 32 with len * step == n");
+    if (nlayers > GS_FRI_MAX_LAYERS || (len >> (2 * nlayers)) < 8) return gs_fail(c, GS_ERR_ARG, "fri_layers: too many layers for this column");
+    if (((uintptr_t)column | (uintptr_t)x_dev) & 15) return gs_fail(c, GS_ERR_ARG, "fri_layers: buffers must be 16-byte aligned");
+    for (uint32_t i = 0; i < nlayers; i++) {
+        const gs_fri_layer &L = layers[i];
+        if (!L.next || !L.leaves || !L.nodes) return GS_ERR_ARG;
+        if (((uintptr_t)L.next | (uintptr_t)L.leaves | (uintptr_t)L.nodes | (uintptr_t)L.point_out) & 15)
+            return gs_fail(c, GS_ERR_ARG, "fri_layers: buffers must be 16-byte aligned");
+        if (L.next == (i ? layers[i - 1].next : column)) return gs_fail(c, GS_ERR_ARG, "fri_layers: a layer's output must not alias its column");
+    }
+    // points between layers that the caller does not ask for live in a per-context scratch (ordered on the context's stream)
+    if (!c->fri_points) {
+        if ((rc = gs_alloc(c, (GS_FRI_MAX_LAYERS + 1) * GS_ELT + 64, &c->fri_points))) return rc;
+        GS_HIP(c, hipMemsetAsync((uint8_t *)c->fri_points + (GS_FRI_MAX_LAYERS + 1) * GS_ELT, 0, 64, c->stream));       // the arrival counter
+    }
+    fe *scratch = (fe *)c->fri_points;
+    unsigned int *counter = (unsigned int *)((uint8_t *)c->fri_points + (GS_FRI_MAX_LAYERS + 1) * GS_ELT);
+    const fe w = fe_from_bytes(omega);
+    const fe *lo, *hi;
+    int log_lo;
+    if ((rc = gs_plan_pow_tables(c, w, n, &lo, &hi, &log_lo))) return rc;
+    const fe zeta = fe_pow_u64(w, n / 4);
+    FriLayersArgs a;
+    memset(&a, 0, sizeof a);
+    a.tw_lo = lo; a.tw_hi = hi; a.log_lo = log_lo; a.logn = gs_log2(n); a.n = n;
+    a.zeta_inv = fe_mul(fe_mul(zeta, zeta), zeta);
+    a.inv4 = fe_inv(fe_from_u64(4));
+    a.counter = counter;
+    const void *col = column;
+    const void *point = x_dev;
+    uint64_t m = len, st = step;
+    for (uint32_t i = 0; i < nlayers; i++, m >>= 2, st <<= 2) {
+        gs_fri_layer &L = layers[i];
+        FriLayerDesc &D = a.layer[i];
+        fe *pout = L.point_out ? (fe *)L.point_out : scratch + i;
+        D.column = (const fe *)col; D.next = (fe *)L.next; D.leaves = (uint4 *)L.leaves; D.nodes = (uint4 *)L.nodes; D.point_out = pout;
+        D.rows = m / 4; D.step = st;
+        void *slot;
+        if ((rc = gs_readback_reserve(c, 32, &slot, &D.flag, &D.value, &L.ticket))) return rc;
+        D.slot = (uint4 *)slot;
+        const uint64_t leaves = m / 16;
+        if (leaves > GS_FRI_ONE_LAUNCH_LEAVES) {
+            // throughput-bound layer: the streaming fold, then the tree launches (root posted and point derived by the last of them)
+            if ((rc = gs_fri_fold_at(c, omega, n, st, col, m, point, L.next))) return rc;
+            const void *quarters[4];
+            for (uint64_t k = 0; k < 4; k++) quarters[k] = (const uint8_t *)L.next + k * leaves * GS_ELT;
+            const RootTail tail = {D.slot, D.flag, D.value, pout};
+            if ((rc = commit_rows(c, alg, quarters, 4, leaves, L.leaves, L.nodes, &tail))) return rc;
+        } else {
+            const uint32_t grid = (uint32_t)(leaves <= GS_FRI_CH ? 1 : leaves / GS_FRI_CH);
+            a.first = i;
+            a.count = grid == 1 ? nlayers - i : 1;
+            a.point_in = (const fe *)point;
+            if (grid == 1)         // every remaining layer in this launch: their descriptors first
+                for (uint32_t j = i + 1; j < nlayers; j++) {
+                    gs_fri_layer &Lj = layers[j];
+                    FriLayerDesc &Dj = a.layer[j];
+                    const uint64_t mj = len >> (2 * j);
+                    Dj.column = (const fe *)layers[j - 1].next; Dj.next = (fe *)Lj.next; Dj.leaves = (uint4 *)Lj.leaves; Dj.nodes = (uint4 *)Lj.nodes;
+                    Dj.point_out = Lj.point_out ? (fe *)Lj.point_out : scratch + j;
+                    Dj.rows = mj / 4; Dj.step = step << (2 * j);
+                    void *sj;
+                    if ((rc = gs_readback_reserve(c, 32, &sj, &Dj.flag, &Dj.value, &Lj.ticket))) return rc;
+                    Dj.slot = (uint4 *)sj;
+                }
+            if (alg == GS_HASH_SHA256) hipLaunchKernelGGL(k_fri_layers<0>, dim3(grid), dim3(GS_FRI_THREADS), 0, c->stream, a);
+            else hipLaunchKernelGGL(k_fri_layers<1>, dim3(grid), dim3(GS_FRI_THREADS), 0, c->stream, a);
+            GS_LAUNCH_CHECK(c);
+            if (grid == 1) break;
+        }
+        col = L.next;
+        point = pout;
+    }
+    return GS_OK;
 }
 
 int gs_hash_digest(gs_ctx *c, gs_hash_alg alg, const uint8_t *msg_host, uint64_t len, uint8_t out_host[32]) {

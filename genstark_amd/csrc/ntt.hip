@@ -44,7 +44,9 @@ struct NttPlan {
     fe *inv_table = nullptr;                           // 1 / (omega^j - 1), j < n, [0] = 0 (built on first use: gs_plan_inverse_table)
 #ifdef GS_NTT_LAZY
     lzw *wtab = nullptr;                               // device: W-forms of omega_16^1..7 and of 1/n (read with scalar loads)
-    lz8 *wRz[4] = {nullptr, nullptr, nullptr, nullptr};   // wR[i] as NN limbs
+    lz8 *wRz[4] = {nullptr, nullptr, nullptr, nullptr};   // wR[i] * 2^130 as NN limbs (signed digits): the multipliers of lz_mul_vm
+    fe *twpR[4] = {nullptr, nullptr, nullptr, nullptr};   // twp[i] * 2^130: per-lane twiddles go through the Montgomery product (gf128_lazy.h)
+    fe *tw_loR = nullptr;                                 // tw_lo * 2^130 (start value of the running-product twiddles)
     lz8 *wRz_scaled = nullptr;                         // the last pass's table times 1/n (inverse transforms: the scale rides on the exchange twiddle)
 #ifdef GS_NTT_EXPERIMENTS
     int4 *mf_tab = nullptr;                            // matrix-core passes (tools/ntt_mfma.h): the 4 KB operand table of omega_16
@@ -119,8 +121,9 @@ struct LzPassArgs {
     int scale;      // multiply every output by ninv (inverse transform, passes without an exchange stage)
     int exq0;       // the exchange table carries a common factor (1/n): output qa = 0 takes wR[0] as well
     int weak;       // not the last pass: store any representative below 2^128 (lz_pack_weak), the next pass unpacks it
-    const fe *tw_lo, *tw_hi, *twp;
-    const lz8 *wR;
+    const fe *tw_lo, *tw_hi, *twp;      // twp: the [k][jq] table times 2^130 (lz_mul_vm)
+    const fe *tw_loR;                   // tw_lo times 2^130
+    const lz8 *wR;                      // exchange twiddles times 2^130 (times 1/n on the last pass of an inverse transform)
     const lzw *wtab;   // W-forms: [0..6] omega_16^1..7, [7] 1/n.  Read with scalar loads right before each use (see LZ_FENCE)
 };
 
@@ -161,6 +164,13 @@ __device__ __forceinline__ lz lz_load8(const lz8 *__restrict__ p) {
 
 __device__ __forceinline__ lz lz_pow_lookup(const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn, uint64_t e, const lzk &K) {
     lz x = lz_unpack(tw_lo[e & ((1ull << log_lo) - 1)]);
+    if (logn > log_lo) x = lz_mul_v(x, lz_unpack(tw_hi[e >> log_lo]), K);  // wave-uniform
+    return x;
+}
+
+// the same power times 2^130 (a multiplier of lz_mul_vm): the low table is stored premultiplied, the ordinary product keeps the factor
+__device__ __forceinline__ lz lz_pow_lookup_r(const fe *__restrict__ tw_loR, const fe *__restrict__ tw_hi, int log_lo, int logn, uint64_t e, const lzk &K) {
+    lz x = lz_unpack(tw_loR[e & ((1ull << log_lo) - 1)]);
     if (logn > log_lo) x = lz_mul_v(x, lz_unpack(tw_hi[e >> log_lo]), K);  // wave-uniform
     return x;
 }
@@ -284,12 +294,12 @@ __global__ __launch_bounds__(128, 2) void k_ntt_pass_lz(const fe *__restrict__ i
 #pragma unroll
             for (int m = 0; m < 16; m++) {
                 if ((m & 3) == 0) { LZ_FENCE(); __builtin_amdgcn_sched_barrier(0); }   // four twiddle loads and four products at a time: the 16 data loads above already hold 64 VGPRs
-                v[m] = lz_mul_v(lz_unpack(raw[m]), lz_unpack(a.twp[((uint64_t)(kk + RB * m) << a.logNs) + jq]), K);
+                v[m] = lz_mul_vm(lz_unpack(raw[m]), lz_unpack(a.twp[((uint64_t)(kk + RB * m) << a.logNs) + jq]), K);
             }
         } else if constexpr (TW == 2) {
             // v[m] *= omega_{Ns*R}^(jq * (kk + RB*m)): start value + running product; the step is put in W-form once
             const uint64_t eu = a.n >> (a.logNs + 4 + LB);
-            lz cur = lz_pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * kk * eu, K);
+            lz cur = lz_pow_lookup_r(a.tw_loR, a.tw_hi, a.log_lo, a.logn, jq * kk * eu, K);        // times 2^130, and stays so: the step is an ordinary multiplier
             lz row = lz_pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * RB * eu, K);
             lzw step;
 #pragma unroll
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(128, 2) void k_ntt_pass_lz(const fe *__restrict__ i
             }
 #pragma unroll
             for (int m = 0; m < 16; m++) {
-                v[m] = lz_mul_v(lz_unpack(raw[m]), cur, K);
+                v[m] = lz_mul_vm(lz_unpack(raw[m]), cur, K);
                 if (m < 15) cur = lz_mul_u(cur, step, K);
             }
         } else {
@@ -340,8 +350,8 @@ __global__ __launch_bounds__(128, 2) void k_ntt_pass_lz(const fe *__restrict__ i
             // the other fourteen are at most 9 NN values apart, which the signed-digit table entries absorb
             lz x = v[brev(qa, 4)];
             if (qa == 0 || qa == 8) x = lz_norm(x);
-            if (qa != 0) x = lz_mul_v(x, lz_load8(a.wR + ((kk * qa) & (R - 1))), K);
-            else if (a.exq0) x = lz_mul_v(x, lz_load8(a.wR), K);
+            if (qa != 0) x = lz_mul_vm(x, lz_load8(a.wR + ((kk * qa) & (R - 1))), K);
+            else if (a.exq0) x = lz_mul_vm(x, lz_load8(a.wR), K);
             const int slot = lz_slot((qa * RB + kk) * Wj + jj, a.logWj);
 #pragma unroll
             for (int l = 0; l < 5; l++) lds[l * plane + slot] = x.l[l];
@@ -453,7 +463,7 @@ __global__ __launch_bounds__(64, 4) void k_ntt_wave(const fe *__restrict__ in, f
                     for (int u = 0; u < 4; u++) { tws[u] = *tp; tp += tstep; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                v[m] = lz_mul_v(lz_unpack(raw[m]), lz_unpack(tws[m & 3]), K);
+                v[m] = lz_mul_vm(lz_unpack(raw[m]), lz_unpack(tws[m & 3]), K);
             }
             __builtin_amdgcn_sched_barrier(0);
         } else if constexpr (TW == 2) {
@@ -461,13 +471,14 @@ __global__ __launch_bounds__(64, 4) void k_ntt_wave(const fe *__restrict__ in, f
             // the lanes of a tile), and its W-form would be 25 VGPRs: a plain five-limb multiplier and lz_mul_v keep the pass at four
             // waves per SIMD with nothing in scratch
             const uint64_t eu = a.n >> (a.logNs + 4 + LB);
-            lz cur = lz_pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * kk * eu, K);
-            const lz step = lz_pow_lookup(a.tw_lo, a.tw_hi, a.log_lo, a.logn, jq * RB * eu, K);
+            // (both times 2^130: multipliers of the Montgomery product, whose result is the ordinary product — the running value keeps its factor)
+            lz cur = lz_pow_lookup_r(a.tw_loR, a.tw_hi, a.log_lo, a.logn, jq * kk * eu, K);
+            const lz step = lz_pow_lookup_r(a.tw_loR, a.tw_hi, a.log_lo, a.logn, jq * RB * eu, K);
 #pragma unroll
             for (int m = 0; m < 16; m++) {
                 __builtin_amdgcn_sched_barrier(0);
-                v[m] = lz_mul_v(lz_unpack(raw[m]), cur, K);
-                if (m < 15) cur = lz_mul_v(cur, step, K);
+                v[m] = lz_mul_vm(lz_unpack(raw[m]), cur, K);
+                if (m < 15) cur = lz_mul_vm(cur, step, K);
             }
             __builtin_amdgcn_sched_barrier(0);
         } else {
@@ -521,8 +532,8 @@ __global__ __launch_bounds__(64, 4) void k_ntt_wave(const fe *__restrict__ in, f
             if ((qa & 1) == 0) { LZ_FENCE(); __builtin_amdgcn_sched_barrier(0); }
             lz x = v[brev(qa, 4)];
             if (qa == 0 || qa == 8) x = lz_norm(x);
-            if (qa != 0) x = lz_mul_v(x, lz_load8(wR + ((kk2 * qa) & (R - 1))), K);
-            else if (exq0) x = lz_mul_v(x, lz_load8(wR), K);
+            if (qa != 0) x = lz_mul_vm(x, lz_load8(wR + ((kk2 * qa) & (R - 1))), K);
+            else if (exq0) x = lz_mul_vm(x, lz_load8(wR), K);
             v[brev(qa, 4)] = x;
         }
         lz xb[GB][RB];
@@ -700,12 +711,17 @@ __global__ void k_eval_horner(const fe *__restrict__ in, fe *__restrict__ out, u
 
 // twp[k * Ns + jq] = omega^(jq * k * eu), eu = n / (Ns * R)
 __global__ void k_build_pass_twiddles(fe *__restrict__ out, uint64_t Ns, uint64_t R, uint64_t eu, const fe *__restrict__ tw_lo,
-                                      const fe *__restrict__ tw_hi, int log_lo, int logn) {
+                                      const fe *__restrict__ tw_hi, int log_lo, int logn, fe scale, int use_scale) {
     const uint64_t total = Ns * R;
     for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t k = t / Ns, jq = t % Ns;
-        out[t] = pow_lookup(tw_lo, tw_hi, log_lo, logn, jq * k * eu);
+        fe x = pow_lookup(tw_lo, tw_hi, log_lo, logn, jq * k * eu);
+        if (use_scale) x = fe_mul(x, scale);
+        out[t] = x;
     }
+}
+__global__ void k_scale_table(const fe *__restrict__ in, fe *__restrict__ out, uint64_t count, fe scale) {
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < count; t += (uint64_t)gridDim.x * blockDim.x) out[t] = fe_mul(in[t], scale);
 }
 
 // inter-pass twiddle tables of up to 2^20 entries (16 MiB, L2 resident); larger passes keep the running product.  A [k][jq] table of
@@ -776,15 +792,29 @@ static int plan_get(gs_ctx *c, const fe &omega, uint64_t n, NttPlan **out) {
             }
         }
 #endif
+#ifdef GS_NTT_LAZY
+        if ((rc = gs_alloc(c, (1ull << p->log_lo) * GS_ELT, &q))) { delete p; return rc; }
+        p->tw_loR = (fe *)q;
+        hipLaunchKernelGGL(k_scale_table, dim3(gs_grid(1ull << p->log_lo)), dim3(256), 0, c->stream, p->tw_lo, p->tw_loR, 1ull << p->log_lo, lz_mont_r());
+#endif
         uint64_t Ns_acc = 1;
         for (int i = 0; i < np; i++) {
             p->L[i] = base + (i < extra ? 1 : 0);
             uint64_t R = 1ull << p->L[i];
             if (i > 0 && Ns_acc * R <= max_pass_twiddle_entries()) {
+#if !defined(GS_NTT_LAZY) || defined(GS_NTT_EXPERIMENTS)
                 if ((rc = gs_alloc(c, Ns_acc * R * GS_ELT, &q))) { delete p; return rc; }
                 p->twp[i] = (fe *)q;
                 hipLaunchKernelGGL(k_build_pass_twiddles, dim3(gs_grid(Ns_acc * R)), dim3(256), 0, c->stream, p->twp[i], Ns_acc, R,
-                                   n / (Ns_acc * R), p->tw_lo, p->tw_hi, p->log_lo, p->logn);
+                                   n / (Ns_acc * R), p->tw_lo, p->tw_hi, p->log_lo, p->logn, fe_one(), 0);
+#endif
+#ifdef GS_NTT_LAZY
+                // the lazy kernels multiply by these through lz_mul_vm (x * w * 2^-130): the table holds w * 2^130
+                if ((rc = gs_alloc(c, Ns_acc * R * GS_ELT, &q))) { delete p; return rc; }
+                p->twpR[i] = (fe *)q;
+                hipLaunchKernelGGL(k_build_pass_twiddles, dim3(gs_grid(Ns_acc * R)), dim3(256), 0, c->stream, p->twpR[i], Ns_acc, R,
+                                   n / (Ns_acc * R), p->tw_lo, p->tw_hi, p->log_lo, p->logn, lz_mont_r(), 1);
+#endif
             }
             Ns_acc *= R;
             if (R > 16) {
@@ -802,7 +832,7 @@ static int plan_get(gs_ctx *c, const fe &omega, uint64_t n, NttPlan **out) {
                 if (!p->wRz[i]) {
                     if ((rc = gs_alloc(c, R * sizeof(lz8), &q))) { delete p; return rc; }
                     p->wRz[i] = (lz8 *)q;
-                    hipLaunchKernelGGL(k_build_lz_table, dim3(gs_grid(R)), dim3(256), 0, c->stream, p->wR[i], p->wRz[i], R, fe_one(), 0);
+                    hipLaunchKernelGGL(k_build_lz_table, dim3(gs_grid(R)), dim3(256), 0, c->stream, p->wR[i], p->wRz[i], R, lz_mont_r(), 1);
                 }
 #endif
             }
@@ -987,7 +1017,8 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
             a.log_lo = p->log_lo;
             a.tw_lo = p->tw_lo;
             a.tw_hi = p->tw_hi;
-            a.twp = p->twp[i];
+            a.twp = p->twpR[i];
+            a.tw_loR = p->tw_loR;
             a.wR = p->wRz[i];
             a.scale = 0;
             a.exq0 = 0;
@@ -998,7 +1029,7 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
                         void *q;
                         if ((rc = gs_alloc(c, R * sizeof(lz8), &q))) { if (tmp) gs_tmp_free(c, tmp); return rc; }
                         p->wRz_scaled = (lz8 *)q;
-                        hipLaunchKernelGGL(k_build_lz_table, dim3(gs_grid(R)), dim3(256), 0, c->stream, p->wR[i], p->wRz_scaled, R, ninv, 1);
+                        hipLaunchKernelGGL(k_build_lz_table, dim3(gs_grid(R)), dim3(256), 0, c->stream, p->wR[i], p->wRz_scaled, R, fe_mul(ninv, lz_mont_r()), 1);
                     }
                     a.wR = p->wRz_scaled;
                     a.exq0 = 1;

@@ -38,7 +38,7 @@ namespace {
     X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_commit_rows) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
     X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
     X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end) X(gs_readback_post) X(gs_readback_wait) X(gs_merkle_commit_rows_seed) X(gs_fri_fold_at) \
-    X(gs_vec_mul_scalar) X(gs_copy) X(gs_gather_words) X(gs_transpose_records) X(gs_fri_fold_seeded_scaled)
+    X(gs_vec_mul_scalar) X(gs_copy) X(gs_gather_words) X(gs_transpose_records) X(gs_fri_fold_seeded_scaled) X(gs_fri_layers)
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
     GS_API_LIST(X)
@@ -366,6 +366,23 @@ struct PhaseClock {
         }
         g_stats.total_ms = total;
         if (on) fprintf(stderr, "[prover] %-44s %8.3f ms  (+%.3f)\n", what, total, delta);
+        last = now;
+    }
+    // the interval since the last mark as TWO entries: `first_ms` of it under `a` (time the host spent blocked, measured by the caller),
+    // the rest under `b`
+    void mark_split(const char *a, double first_ms, const char *b) {
+        auto now = std::chrono::steady_clock::now();
+        const double delta = std::chrono::duration<double, std::milli>(now - last).count();
+        const double total = std::chrono::duration<double, std::milli>(now - t0).count();
+        const char *labels[2] = {a, b};
+        const double parts[2] = {std::min(first_ms, delta), delta - std::min(first_ms, delta)};
+        for (int k = 0; k < 2; k++)
+            if (g_stats.nphases < GS_PROVER_MAX_PHASES) {
+                snprintf(g_stats.phase_label[g_stats.nphases], sizeof g_stats.phase_label[0], "%s", labels[k]);
+                g_stats.phase_ms[g_stats.nphases++] = parts[k];
+            }
+        g_stats.total_ms = total;
+        if (on) fprintf(stderr, "[prover] %-44s %8.3f ms  (+%.3f)\n[prover] %-44s %8.3f ms  (+%.3f)\n", a, total - parts[1], parts[0], b, total, parts[1]);
         last = now;
     }
 };
@@ -767,7 +784,12 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     // are enqueued without a round trip.  The launch that produces a tree's root also POSTS it to the host and derives that point
     // (gs_merkle_commit_rows_seed): the host picks each root up as soon as its tree exists and derives the layer's query positions and
     // batch-proof plans while the device folds the layers below
-    auto await_root = [&](uint64_t ticket, Tree &t) { x.check(A.gs_readback_wait(x.c, ticket, t.root.data()), "gs_readback_wait(root)"); };
+    double waited_ms = 0;          // host time blocked on roots that had not arrived yet (the device was the slower side)
+    auto await_root = [&](uint64_t ticket, Tree &t) {
+        const auto w0 = std::chrono::steady_clock::now();
+        x.check(A.gs_readback_wait(x.c, ticket, t.root.data()), "gs_readback_wait(root)");
+        waited_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    };
     std::vector<uint64_t> tickets;
     tickets.push_back(pTree0.ticket);
     std::vector<Layer> layers;
@@ -777,10 +799,10 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     uint64_t max_degree_plus1 = composition_degree;
     uint32_t depth = 0;
     layers.reserve(32);
+    // every layer's buffers first, then ONE call for the whole recursion (gs_fri_layers = per layer gs_fri_fold_at :189-198 +
+    // gs_merkle_commit_rows_seed :201-202, with as few dependent launches as the sizes allow)
     while (len > 256) {
         const uint64_t rows = len / 4;
-        uint64_t step = 1;
-        for (uint32_t d = 0; d < depth; d++) step *= 4;
         layers.emplace_back();
         Layer &L = layers.back();
         L.pTree = pTree;
@@ -788,15 +810,24 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         L.rows = rows;
         L.column_length = rows;
         L.next = Buf(x, rows * ELEM);
-        le16(omega, s16);
-        x.check(A.gs_fri_fold_at(x.c, s16, N, step, column_src, len, pTree->point.p, L.next.p), "gs_fri_fold_at");   // :189-198
-        L.cTree = commit_rows4(x, alg, L.next.p, rows / 4, rows > 256);                               // :201-202 (no layer below the last tree)
-        tickets.push_back(L.cTree.ticket);
+        L.cTree.n = rows / 4;
+        L.cTree.leaves = Buf(x, rows / 4 * DIGEST);
+        L.cTree.nodes = Buf(x, rows / 4 * DIGEST);
+        if (rows > 256) L.cTree.point = Buf(x, ELEM);                                                 // (no layer below the last tree)
+        L.cTree.root.resize(DIGEST);
         column_src = L.next.p;
         pTree = &L.cTree;
         len = rows;
         max_degree_plus1 /= 4;
         depth++;
+    }
+    if (!layers.empty()) {
+        std::vector<gs_fri_layer> outs(layers.size());
+        for (size_t d = 0; d < layers.size(); d++)
+            outs[d] = gs_fri_layer{layers[d].next.p, layers[d].cTree.leaves.p, layers[d].cTree.nodes.p, layers[d].cTree.point.p, 0};
+        le16(omega, s16);
+        x.check(A.gs_fri_layers(x.c, (gs_hash_alg)alg, s16, N, 1, lEval.p, N, pTree0.point.p, (uint32_t)outs.size(), outs.data()), "gs_fri_layers");
+        for (size_t d = 0; d < layers.size(); d++) { layers[d].cTree.ticket = outs[d].ticket; tickets.push_back(outs[d].ticket); }
     }
     if (layers.size() > 60) fail(GS_ERR_ARG, "too many FRI components");
     clock.mark("FRI layers issued");
@@ -830,7 +861,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     for (size_t d = 0; d < layers.size(); d++) {
         Layer &L = layers[d];
         await_root(tickets[d + 1], L.cTree);
-        if (d + 1 == layers.size()) clock.mark("roots awaited; queries planned meanwhile");
+        if (d + 1 == layers.size()) clock.mark_split("waiting for FRI roots (device busy)", waited_ms, "query plans while the device folds");
         std::vector<uint64_t> positions = query_indexes(L.cTree.root, job.fri_query_count, L.column_length, (uint32_t)E);
         std::vector<uint64_t> rows_wanted;
         for (uint64_t p : positions) rows_wanted.push_back(p % (L.column_length / 4));
@@ -842,7 +873,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         rb.prove_batch(x, *L.pTree, positions, &c.polyProof);
         rb.gather_rows4(x, L.column, L.rows, positions, &c.polyProof);
     }
-    if (layers.empty()) clock.mark("roots awaited; queries planned meanwhile");
+    if (layers.empty()) clock.mark_split("waiting for FRI roots (device busy)", waited_ms, "query plans while the device folds");
     clock.mark("last root here: the last layer's plan");
     std::vector<F> remainder(len);
     Bytes remainder_raw(len * ELEM);

@@ -220,6 +220,26 @@ int gs_fri_fold_seeded_scaled(gs_ctx *ctx, const gs_elt *omega, uint64_t n, uint
 int gs_merkle_commit_rows_seed(gs_ctx *ctx, gs_hash_alg alg, const void *const *vecs_host, uint32_t count, uint64_t n, void *leaves, void *nodes,
                                void *point_out, uint64_t *ticket);
 int gs_fri_fold_at(gs_ctx *ctx, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t len, const void *x_dev, void *out);
+/* A RUN of FRI layers in one call (LowDegreeProver.ts:176-221, the recursion from one column down): for i < nlayers, with
+ * column_0 = column (len values), len_i = len / 4^i, step_i = step * 4^i and x_0 the point stored at x_dev,
+ *     layers[i].next   = gs_fri_fold_at(column_i, len_i, step_i, x_i)                      (len_i / 4 values; column_{i+1})
+ *     layers[i].leaves, .nodes, .ticket, .point_out = gs_merkle_commit_rows_seed over the four quarters of layers[i].next
+ *                                                                                           (len_i / 16 leaves; :201-202)
+ *     x_{i+1} = field.prng(root_i)                                                          (:194; also stored at point_out if non-NULL)
+ * — byte for byte what those two calls per layer give, with as few dependent launches as the sizes allow: a layer of at most 2^15
+ * leaves is ONE launch (every workgroup folds the rows of its own 256 leaves, hashes them and builds the subtree above them; the
+ * workgroup that finishes last builds the tree over the subtree roots, posts the root and derives the next point), and from the
+ * first layer that fits one workgroup on, ALL remaining layers run in that same launch.  Every root is posted (layers[i].ticket
+ * for gs_readback_wait).  Requirements: len a power of two >= 32, len * step == n, len / 4^nlayers >= 8. */
+struct gs_fri_layer {
+    void *next;          /* out: len_i / 4 elements */
+    void *leaves;        /* out: len_i / 16 digests */
+    void *nodes;         /* out: len_i / 16 digests, heap order (nodes + 32 = the root) */
+    void *point_out;     /* out, may be NULL: field.prng(root_i), one element */
+    uint64_t ticket;     /* out: posted root */
+};
+int gs_fri_layers(gs_ctx *ctx, gs_hash_alg alg, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t len,
+                  const void *x_dev, uint32_t nlayers, struct gs_fri_layer *layers);
 
 /* ---- hashing / Merkle (merkle package) --------------------------------------------------------- */
 /* Hash.digest(Buffer) on host bytes (verifier side; lib/utils/index.ts:37) — runs on the device

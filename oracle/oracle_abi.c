@@ -573,6 +573,36 @@ int gs_fri_fold_at(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t step, co
     return gs_fri_fold(c, omega, n, step, column, m, (const gs_elt *)xb, out);
 }
 
+/* gs_fri_layers restated as what its contract says it equals: per layer, gs_fri_fold_at then gs_merkle_commit_rows_seed over the four
+ * quarters of the folded column (LowDegreeProver.ts:189-202), the next point taken from the tree just built. */
+int gs_fri_layers(gs_ctx *c, gs_hash_alg alg, const gs_elt *omega, uint64_t n, uint64_t step, const void *column, uint64_t len, const void *x_dev,
+                  uint32_t nlayers, struct gs_fri_layer *layers) {
+    if (!c || !omega || !column || !x_dev || !layers || !nlayers) return GS_ERR_ARG;
+    if (len < 32 || (len & (len - 1)) || len * step != n) return fail(c, GS_ERR_ARG, "fri_layers: len must be a power of two >= 32 with len * step == n");
+    if (2 * (uint64_t)nlayers > 62 || (len >> (2 * nlayers)) < 8) return fail(c, GS_ERR_ARG, "fri_layers: too many layers for this column");
+    uint8_t point[64];
+    memset(point, 0, sizeof point);
+    memcpy(point, x_dev, FE_BYTES);
+    for (uint32_t i = 0; i < nlayers; i++) {
+        struct gs_fri_layer *L = &layers[i];
+        if (!L->next || !L->leaves || !L->nodes) return GS_ERR_ARG;
+        int rc = gs_fri_fold_at(c, omega, n, step, column, len, point, L->next);
+        if (rc) return rc;
+        const uint64_t rows = len / 4, q = rows / 4;
+        const void *quarters[4];
+        for (int k = 0; k < 4; k++) quarters[k] = (const uint8_t *)L->next + (uint64_t)k * q * FE_BYTES;
+        uint8_t next_point[64];
+        memset(next_point, 0, sizeof next_point);
+        if ((rc = gs_merkle_commit_rows_seed(c, alg, quarters, 4, q, L->leaves, L->nodes, next_point, &L->ticket))) return rc;
+        if (L->point_out) memcpy(L->point_out, next_point, FE_BYTES);
+        memcpy(point, next_point, FE_BYTES);
+        column = L->next;
+        len = rows;
+        step *= 4;
+    }
+    return GS_OK;
+}
+
 int gs_mimc_trace(gs_ctx *c, const gs_elt *seed, const uint8_t *rc, uint32_t nrc, uint64_t steps, void *out) {
     if (!nrc || !steps) return fail(c, GS_ERR_ARG, "mimc_trace: empty");
     fe x = fe_load(seed);

@@ -548,6 +548,63 @@ def check_device_record_ops(backend, rng):
         be.free(p_)
 
 
+def check_fri_layers(backend, rng, logm, depth, nlayers, alg='blake2s256'):
+    """gs_fri_layers — a run of FRI layers in one call (LowDegreeProver.ts:176-221) — against what its contract says it equals, layer by
+    layer on the same backend: gs_fri_fold_at at the running point, gs_merkle_commit_rows_seed over the four quarters of the folded
+    column; the posted roots; the points (sha256 of the root as a big-endian integer mod p).  Returns every output byte (for
+    backend-vs-backend comparison)."""
+    import hashlib
+    from genstark_amd._abi import FriLayer
+    be = backend
+    f = field_for(be)
+    es = be.element_size
+    m, step = 1 << logm, 4 ** depth
+    n = m * step
+    w = f.getRootOfUnity(n)
+    column = f.newVectorFrom([rng.randrange(f.modulus) for _ in range(m)]) if m <= 4096 else f.getPowerSeries(rng.randrange(2, f.modulus), m)
+    x0 = rng.randrange(f.modulus)
+    xv = f.newVectorFrom([x0])
+    a = HASH_ALGS[alg]
+    layers = (FriLayer * nlayers)()
+    keep = []
+    for i in range(nlayers):
+        rows = m >> (2 * i + 2)
+        nxt, leaves, nodes = f.newVector(rows), be.alloc(32 * (rows // 4)), be.alloc(32 * (rows // 4))
+        point = f.newVector(1) if i % 2 == 0 else None                  # every other layer asks for its point
+        keep.append((nxt, leaves, nodes, point))
+        layers[i].next, layers[i].leaves, layers[i].nodes = nxt.ptr, leaves, nodes
+        layers[i].point_out = point.ptr if point is not None else None
+    be.call('gs_fri_layers', a, f.le(w), n, step, C.c_void_p(column.ptr), m, C.c_void_p(xv.ptr), nlayers, C.cast(layers, C.c_void_p))
+    out = []
+    col, cur_m, cur_step, cur_x = column, m, step, xv
+    for i in range(nlayers):
+        nxt, leaves, nodes, point = keep[i]
+        rows = cur_m // 4
+        q = rows // 4
+        want_next = f.newVector(rows)
+        be.call('gs_fri_fold_at', f.le(w), n, cur_step, C.c_void_p(col.ptr), cur_m, C.c_void_p(cur_x.ptr), C.c_void_p(want_next.ptr))
+        assert nxt.toBuffer() == want_next.toBuffer(), ('next', i)
+        wl, wn, wp = be.alloc(32 * q), be.alloc(32 * q), f.newVector(1)
+        quarters = (C.c_void_p * 4)(*[want_next.ptr + k * q * es for k in range(4)])
+        t = C.c_uint64()
+        be.call('gs_merkle_commit_rows_seed', a, quarters, 4, q, C.c_void_p(wl), C.c_void_p(wn), C.c_void_p(wp.ptr), C.byref(t))
+        assert be.download(leaves, 32 * q) == be.download(wl, 32 * q), ('leaves', i)
+        assert be.download(nodes, 32 * q) == be.download(wn, 32 * q), ('nodes', i)
+        root = C.create_string_buffer(32)
+        be.call('gs_readback_wait', layers[i].ticket, root)
+        assert root.raw == be.download(wn + 32, 32), ('posted root', i)
+        assert wp.toValues()[0] == int.from_bytes(hashlib.sha256(root.raw).digest(), 'big') % f.modulus
+        if point is not None:
+            assert point.toBuffer() == wp.toBuffer(), ('point', i)
+        out += [nxt.toBuffer(), be.download(leaves, 32 * q), be.download(nodes, 32 * q), root.raw]
+        be.free(wl); be.free(wn)
+        col, cur_m, cur_step, cur_x = nxt, rows, cur_step * 4, wp
+        keep[i] = (nxt, leaves, nodes, point, wp)
+    for k in keep:
+        be.free(k[1]); be.free(k[2])
+    return hashlib.sha256(b''.join(out)).hexdigest()
+
+
 def check_mimc_air(backend, rng, steps):
     from genstark_amd.air import MimcAir, runMimc
     f = field_for(backend)

@@ -18,6 +18,8 @@ void z_sqr(const int32_t *x, int32_t *o, int n) { for (int i = 0; i < n; i++) st
 void z_sqr_chain(const int32_t *x, int k, int32_t *o, int n) {
     for (int i = 0; i < n; i++) { const lz a = ldl(x + 5 * i); lz c = a; for (int q = 0; q < k; q++) c = lz_sqr(c, K); stl(o + 5 * i, lz_mul_v(c, a, K)); }
 }
+void z_mul_vm(const int32_t *x, const int32_t *w, int32_t *o, int n) { for (int i = 0; i < n; i++) stl(o + 5 * i, lz_mul_vm(ldl(x + 5 * i), ldl(w + 5 * i), K)); }
+void z_mont_consts(uint8_t *o) { st(o, lz_mont_r()); st(o + 16, lz_mont_r2()); }
 void z_mul_v(const int32_t *x, const int32_t *w, int32_t *o, int n) { for (int i = 0; i < n; i++) stl(o + 5 * i, lz_mul_v(ldl(x + 5 * i), ldl(w + 5 * i), K)); }
 // multiplier given as a canonical element: its W-form is built the way the plan builds the radix-16 twiddles
 void z_mul_u(const int32_t *x, const uint8_t *w, int32_t *o, int n) {

@@ -55,6 +55,32 @@ def test_fri_fold(hip_backend, oracle_backend, rng, logn, depth):
         assert got == cases.check_fri_fold(oracle_backend, random.Random(seed), logn, depth)
 
 
+@pytest.mark.parametrize('logm,depth,nlayers,alg', [
+    (5, 0, 1, 'blake2s256'),       # the smallest layer: 2 leaves... (32 values -> 8, a tree of 2 leaves)
+    (9, 0, 1, 'blake2s256'),       # 32 leaves, one workgroup, one layer
+    (13, 1, 3, 'blake2s256'),      # one workgroup from the first layer on: three layers in ONE launch
+    (14, 0, 4, 'sha256'),          # the same through the SHA-256 instantiation
+    (17, 1, 5, 'blake2s256'),      # 8192 leaves = 32 workgroups + last-arrival top, 2048 = 8, then the single-workgroup run
+    (19, 0, 6, 'blake2s256'),      # 2^15 leaves: 128 workgroups, the widest one-launch layer
+    (20, 0, 2, 'blake2s256'),      # 2^16 leaves: the streaming fold + fused tree launches, then one-launch layers
+    (18, 0, 5, 'sha256'),
+])
+def test_fri_layers(hip_backend, oracle_backend, rng, logm, depth, nlayers, alg):
+    """gs_fri_layers: a run of FRI layers in as few launches as the sizes allow == the member sequence on the same device (every next
+    column, leaf, node, posted root and point), and every output byte == the oracle's."""
+    import random
+    seed = rng.randrange(1 << 30)
+    got = cases.check_fri_layers(hip_backend, random.Random(seed), logm, depth, nlayers, alg)
+    assert got == cases.check_fri_layers(oracle_backend, random.Random(seed), logm, depth, nlayers, alg)
+
+
+def test_fri_layers_repeated_launches_keep_the_arrival_counter_clean(hip_backend, rng):
+    """Back-to-back multi-workgroup launches on one context: the workgroup that arrives last resets the counter for the next."""
+    import random
+    for k in range(6):
+        cases.check_fri_layers(hip_backend, random.Random(k), 16 + k % 3, 0, 3)
+
+
 @pytest.mark.parametrize('n', [64, 1 << 16])
 def test_deferred_readbacks(hip_backend, rng, n):
     cases.check_deferred_readbacks(hip_backend, rng, n)

@@ -195,6 +195,54 @@ def test_product_of_unnormalised_sums_by_signed_digit_multiplier(lib):
     assert max(cols) + 2 * (2304 * (1 << 31) + 147456 * (1 << 25) + (1 << 40)) < (1 << 57) - (1 << 44)
 
 
+def test_montgomery_product(lib):
+    """lz_mul_vm: x * w * B^-5 by REDC from the bottom (p == 1 mod B: the quotient digit is -(c_i mod B)); with the multiplier stored
+    premultiplied by R = 2^130 the result is x * w.  Every input class the pass kernels feed it: exact NN data times NN multipliers,
+    sums of up to 9 NN values times signed-digit table entries (the exchange stage), extreme limbs; result NN, value exact."""
+    rng = random.Random(4242)
+    R = pow(2, 130, P)
+    Rinv = pow(R, -1, P)
+    buf = ctypes.create_string_buffer(32)
+    lib.z_mont_consts(buf)
+    assert int.from_bytes(buf.raw[:16], 'little') == R and int.from_bytes(buf.raw[16:], 'little') == R * R % P
+    n = 6000
+    o = out_limbs(n)
+    for terms in (1, 2, 4, 9):
+        xs = [lazy_combo(rng, terms, extreme=(i % 2 == 0)) for i in range(n)]
+        wl = [rand_nn(rng, extreme=(i % 2 == 1)) for i in range(n)]
+        if terms == 9:           # signed-digit multipliers, |limb| <= 2^25, as k_build_lz_table stores the exchange twiddles
+            wl = []
+            for i in range(n):
+                w = rng.randrange(P) if i % 5 else rng.choice([P - 1, (1 << 128) - (1 << 103), sum(((1 << 25) - 1) << (26 * k) for k in range(5)) % P])
+                l = [w % B, (w >> 26) % B, (w >> 52) % B, (w >> 78) % B, w >> 104]
+                for k in range(4):
+                    if l[k] >= 1 << 25:
+                        l[k] -= 1 << 26
+                        l[k + 1] += 1
+                wl.append(l)
+        lib.z_mul_vm(limbs_buf(xs), limbs_buf(wl), o, n)
+        for x, w, y in zip(xs, wl, rows_of(o, n)):
+            assert value(y) % P == value(x) * value(w) * Rinv % P and is_nn(y), ('mul_vm', terms, x, w, y)
+    # premultiplied multiplier: the ordinary product comes out
+    ws = elements(rng, n)
+    xs = [lazy_combo(rng, 2, extreme=False) for _ in range(n)]
+    wl = []
+    for w in ws:
+        v = w * R % P
+        wl.append([v % B, (v >> 26) % B, (v >> 52) % B, (v >> 78) % B, v >> 104])
+    lib.z_mul_vm(limbs_buf(xs), limbs_buf(wl), o, n)
+    for x, w, y in zip(xs, ws, rows_of(o, n)):
+        assert value(y) % P == value(x) * w % P
+    # column interval: the widest input class (9 NN values x signed digits) leaves the 2^51 of slack the REDC steps need
+    nn_hi = [B + (1 << 8), B + (1 << 17), B, B, 1 << 24]
+    x9 = [9 * h for h in nn_hi]
+    cols = [sum(x9[i] * (1 << 25) for i in range(5) if 0 <= k - i < 5) for k in range(9)]
+    assert max(cols) < (1 << 57) - (1 << 51)
+    x4 = [4 * h for h in nn_hi]
+    cols = [sum(x4[i] * nn_hi[k - i] for i in range(5) if 0 <= k - i < 5) for k in range(9)]
+    assert max(cols) < (1 << 57) - (1 << 51)
+
+
 def test_shift_limb(lib):
     rng = random.Random(3)
     n = 4000

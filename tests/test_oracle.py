@@ -27,6 +27,11 @@ def test_fri_fold(oracle_backend, rng, logn, depth):
     cases.check_fri_fold(oracle_backend, rng, logn, depth)
 
 
+@pytest.mark.parametrize('logm,depth,nlayers,alg', [(5, 0, 1, 'blake2s256'), (9, 1, 3, 'blake2s256'), (12, 0, 4, 'sha256')])
+def test_fri_layers(oracle_backend, rng, logm, depth, nlayers, alg):
+    cases.check_fri_layers(oracle_backend, rng, logm, depth, nlayers, alg)
+
+
 def test_deferred_readbacks(oracle_backend, rng):
     cases.check_deferred_readbacks(oracle_backend, rng, 256)
 

@@ -60,6 +60,19 @@ __global__ __launch_bounds__(128) void k_mulv(const fe *in, fe *out, const lzw *
 #pragma unroll
     for (int m = 0; m < 16; m++) out[blockIdx.x * 2048 + threadIdx.x + 128 * m] = lz_pack(v[m]);
 }
+// (b') the same through the Montgomery form (REDC from the bottom: lz_mul_vm; multipliers premultiplied by 2^130)
+__global__ __launch_bounds__(128) void k_mulvm(const fe *in, fe *out, const lzw *w) {
+    const lzk K = lzk_make();
+    lz v[16], t[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) { v[m] = lz_unpack(in[threadIdx.x + 128 * m]); t[m] = lz_unpack(in[threadIdx.x + 128 * m + 64]); }
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) v[m] = lz_mul_vm(v[m], t[m], K);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) out[blockIdx.x * 2048 + threadIdx.x + 128 * m] = lz_pack(v[m]);
+}
 // (c) 16 packs + unpacks per round
 __global__ __launch_bounds__(128) void k_pack(const fe *in, fe *out, const lzw *w) {
     lz v[16];
@@ -100,10 +113,11 @@ int main(int argc, char **argv) {
         {"lz_mul_v", k_mulv, 16, "per product"},
         {"lz_pack + lz_unpack + add", k_pack, 16, "per element"},
         {"fe_mul (canonical limbs)", k_femul, 16, "per product"},
+        {"lz_mul_vm (Montgomery REDC, radix 2^26)", k_mulvm, 16, "per product"},
     };
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     if (!json) printf("%-50s %10s %10s %10s %10s   ns per wave per SIMD (wall clock; k waves per SIMD forced by LDS size, 128-thread blocks)\n", "core", "1 w/SIMD", "2 w/SIMD", "3 w/SIMD", "4 w/SIMD");
-    double res[4][4];
+    double res[5][4];
     int ei = 0;
     for (auto &e : es) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(e.k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -126,9 +140,9 @@ int main(int argc, char **argv) {
         ei++;
     }
     if (json) {
-        const char *keys[4] = {"dif16_network_ns", "mul_v_ns", "pack_unpack_add_ns", "fe_mul_ns"};
+        const char *keys[5] = {"dif16_network_ns", "mul_v_ns", "pack_unpack_add_ns", "fe_mul_ns", "mul_vm_ns"};
         printf("{\"cus\": %d, \"unit\": \"ns per wave per SIMD at 1,2,3,4 waves per SIMD\"", cus);
-        for (int k = 0; k < 4; k++) printf(", \"%s\": [%.2f, %.2f, %.2f, %.2f]", keys[k], res[k][0], res[k][1], res[k][2], res[k][3]);
+        for (int k = 0; k < 5; k++) printf(", \"%s\": [%.2f, %.2f, %.2f, %.2f]", keys[k], res[k][0], res[k][1], res[k][2], res[k][3]);
         printf("}\n");
     }
     return 0;
