@@ -41,10 +41,23 @@ wait
 if [ ! -f ntt_isa_mix.json ] || [ ntt.hip -nt ntt_isa_mix.json ] || [ gf128_lazy.h -nt ntt_isa_mix.json ]; then
   $HIPCC $FLAGS -S --cuda-device-only ntt.hip -o build/ntt.s 2>/dev/null && python3 ../../tools/valu_mix.py build/ntt.s > ntt_isa_mix.json.tmp && mv ntt_isa_mix.json.tmp ntt_isa_mix.json
 fi
-# the native prove() driver: plain C++ above the C ABI (binds to whichever implementation of it the caller loaded)
-if [ ! -f libgstark_prover.so ] || [ prover.cc -nt libgstark_prover.so ] || [ prover_dist.h -nt libgstark_prover.so ] || [ ../../include/gstark_comm.h -nt libgstark_prover.so ] || [ ../../include/gstark.h -nt libgstark_prover.so ]; then
-  g++ -O2 -std=c++17 -shared -fPIC -Wall -Wno-unused-function prover.cc -ldl -o libgstark_prover.so
-fi
+# the native prove() driver: plain C++ above the C ABI (binds to whichever implementation of it the caller loaded).  One build per
+# field flavour, like the ABI library: its host-side scalars (domain roots, Fiat-Shamir coefficients, interpolants, the remainder check)
+# are computed in that flavour's host arithmetic, elements are gs_element_size() bytes
+build_driver() {   # <output> <extra flags>
+  local out=$1 extra=$2
+  if [ ! -f $out ] || [ prover.cc -nt $out ] || [ prover_dist.h -nt $out ] || [ ../../include/gstark_comm.h -nt $out ] || [ ../../include/gstark.h -nt $out ] \
+     || [ ../../include/gstark_prover.h -nt $out ] || [ host_field.h -nt $out ] || [ host_field_small.h -nt $out ] || [ host_field_wide.h -nt $out ] || [ gf_wide.h -nt $out ]; then
+    g++ -O2 -std=c++17 -shared -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas $extra prover.cc -ldl -o $out
+  fi
+}
+build_driver libgstark_prover.so "" &
+build_driver libgstark_prover_q64.so "-DGS_SMALL_Q=18446744051160973313ull" &
+build_driver libgstark_prover_q32.so "-DGS_SMALL_Q=4194304001ull" &
+build_driver libgstark_prover_q17.so "-DGS_SMALL_Q=96769ull" &
+build_driver libgstark_prover_p256.so "-DGS_WIDE_BITS=256" &
+build_driver libgstark_prover_p224.so "-DGS_WIDE_BITS=224" &
+wait
 echo built $(pwd)/libgstark_prover.so
 # the communicator of a distributed proof over RCCL / xGMI (include/gstark_comm.h): host code against librccl + the HIP runtime
 if [ ! -f libgstark_rccl.so ] || [ comm_rccl.cc -nt libgstark_rccl.so ] || [ ../../include/gstark_comm.h -nt libgstark_rccl.so ]; then

@@ -25,6 +25,12 @@
 #include "../../include/gstark.h"
 #include "../../include/gstark_prover.h"
 #include "../../include/gstark_comm.h"
+// One build of this file per field flavour of the ABI library (csrc/build.sh: the same -DGS_SMALL_Q / -DGS_WIDE_BITS): the host-side
+// scalars (domain roots, Fiat-Shamir coefficients, boundary interpolants, the remainder check) use the flavour's host arithmetic,
+// elements are gs_element_size() bytes on the ABI and in the proof.
+#if defined(GS_WIDE_BITS)
+#include "gf_wide.h"
+#endif
 #include "host_field.h"
 #include "host_sha256.h"
 
@@ -43,8 +49,18 @@ struct Api {
 #define X(name) decltype(&::name) name = nullptr;
     GS_API_LIST(X)
 #undef X
-} A;
+};
+// The driver is written against `A.gs_xxx(...)`: A is the binding of the CURRENT call on this thread — the process-wide default
+// (gs_prover_bind) unless the entry point was handed a binding of its own (gs_prover_open, the `_on` entry points).
+Api g_default_api;
 bool g_bound = false;
+thread_local const Api *g_api = &g_default_api;
+#define A (*g_api)
+struct UseApi {          // scope of one entry point
+    const Api *saved;
+    explicit UseApi(const Api *a) : saved(g_api) { g_api = a; }
+    ~UseApi() { g_api = saved; }
+};
 
 struct Fail {
     int code;
@@ -60,7 +76,16 @@ struct Fail {
 }
 
 typedef hfe F;
-const uint64_t DIGEST = 32, ELEM = 16, MAX_ARRAY = 256;
+#if defined(GS_WIDE_BITS)
+const uint64_t ELEM = sizeof(fe);               // 32: the 256- / 224-bit fields
+inline bool operator==(const F &a, const F &b) { return fe_eq(a.v, b.v); }
+inline bool operator!=(const F &a, const F &b) { return !fe_eq(a.v, b.v); }
+#else
+const uint64_t ELEM = 16;
+#endif
+const uint64_t DIGEST = 32, MAX_ARRAY = 256;
+const uint64_t WORD = 16, EW = ELEM / WORD;     // gs_gather_words / gs_defer_* move 16-byte words
+static_assert(ELEM <= GS_PROVER_ELT_MAX, "element wider than the job's scalar fields");
 typedef std::vector<uint8_t> Bytes;
 
 struct Ctx {
@@ -88,15 +113,22 @@ struct Buf {
     uint8_t *at(uint64_t byte_offset) const { return (uint8_t *)p + byte_offset; }
 };
 
-void le16(F v, uint8_t out[16]) { memcpy(out, &v, 16); }
-F from16(const uint8_t *b) { F v; memcpy(&v, b, 16); return v; }
+void le16(F v, uint8_t *out) { hf_store(out, v); }          // ELEM bytes, little-endian (the names date from the 128-bit-only driver)
+F from16(const uint8_t *b) { return hf_load(b); }
 
 // ---- galois prng (genstark_amd/field.py: prng — restated) and the index generator -----------------
 F digest_mod_p(const uint8_t d[32]) {          // 256-bit big-endian integer mod p
+#if !defined(GS_WIDE_BITS) && !defined(GS_SMALL_Q)
     F hi = 0, lo = 0;
     for (int i = 0; i < 16; i++) hi = (hi << 8) | d[i];
     for (int i = 16; i < 32; i++) lo = (lo << 8) | d[i];
     return hf_reduce(hi, lo);
+#else
+    F x = 0;                                    // byte-wise Horner: the same code for every other modulus
+    const F b = 256;
+    for (int i = 0; i < 32; i++) x = hf_add(hf_mul(x, b), (F)(uint64_t)d[i]);
+    return x;
+#endif
 }
 std::vector<F> prng_many(const Bytes &seed, size_t count) {
     std::vector<F> out(count);
@@ -279,23 +311,59 @@ static int counted_eval_polys_at_roots(gs_ctx *c, const void *polys, uint32_t ro
 
 extern "C" {
 
-int gs_prover_bind(void *dl_handle) {
+static int bind_api(Api &api, void *dl_handle) {
     if (!dl_handle) return GS_ERR_ARG;
-#define X(name)                                             \
-    A.name = (decltype(A.name))dlsym(dl_handle, #name);     \
-    if (!A.name) return GS_ERR_UNSUPPORTED;
+#define X(name)                                                 \
+    api.name = (decltype(api.name))dlsym(dl_handle, #name);     \
+    if (!api.name) return GS_ERR_UNSUPPORTED;
     GS_API_LIST(X)
 #undef X
-    g_bound = true;
+    // the library must compute in the field this build of the driver does its host-side scalars in
+    auto esize = (int (*)())dlsym(dl_handle, "gs_element_size");
+    auto modulus = (int (*)(uint8_t *))dlsym(dl_handle, "gs_field_modulus");
+    if (!esize || !modulus || (uint64_t)esize() != ELEM) return GS_ERR_UNSUPPORTED;
+    uint8_t m[GS_PROVER_ELT_MAX] = {0}, want[GS_PROVER_ELT_MAX] = {0};
+    if (modulus(m)) return GS_ERR_UNSUPPORTED;
+#if defined(GS_WIDE_BITS)
+    for (int i = 0; i < GF_LIMBS; i++) { const uint32_t w = gf_p_limb(i); memcpy(want + 4 * i, &w, 4); }
+#else
+    { const hfe pp = hf_p(); memcpy(want, &pp, 16); }
+#endif
+    return memcmp(m, want, ELEM) ? GS_ERR_UNSUPPORTED : GS_OK;
+}
+int gs_prover_bind(void *dl_handle) {
+    const int rc = bind_api(g_default_api, dl_handle);
+    if (rc == GS_OK) g_bound = true;
+    return rc;
+}
+int gs_prover_open(void *dl_handle, gs_prover_binding **out) {
+    if (!out) return GS_ERR_ARG;
+    Api *api = new Api();
+    const int rc = bind_api(*api, dl_handle);
+    if (rc) { delete api; return rc; }
+    *out = reinterpret_cast<gs_prover_binding *>(api);
     return GS_OK;
 }
+void gs_prover_close(gs_prover_binding *b) { delete reinterpret_cast<Api *>(b); }
+int gs_prover_element_size(void) { return (int)ELEM; }
 
 static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out);
+static int prove_entry(gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, uint64_t cap, uint64_t *len, char *err, uint64_t errcap);
 static bool remainder_is_low_degree(const std::vector<F> &remainder, uint64_t E, uint64_t m, F rou, int method);
 
 // Serialized proof into out[0..cap); *len receives the size (also when cap is too small: GS_ERR_ARG then).
+int gs_prover_prove_on(const gs_prover_binding *b, gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, uint64_t cap, uint64_t *len, char *err,
+                       uint64_t errcap) {
+    if (!b) return GS_ERR_ARG;
+    UseApi use(reinterpret_cast<const Api *>(b));
+    return prove_entry(ctx, job, out, cap, len, err, errcap);
+}
 int gs_prover_prove(gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, uint64_t cap, uint64_t *len, char *err, uint64_t errcap) {
     if (!g_bound) return GS_ERR_UNSUPPORTED;
+    UseApi use(&g_default_api);
+    return prove_entry(ctx, job, out, cap, len, err, errcap);
+}
+static int prove_entry(gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, uint64_t cap, uint64_t *len, char *err, uint64_t errcap) {
     if (!ctx || !job || !len) return GS_ERR_ARG;
     try {
         Ctx x{ctx};
@@ -314,13 +382,24 @@ int gs_prover_prove(gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, 
     }
 }
 
+static int remainder_check_entry(const uint8_t *values, uint64_t len, uint32_t extension_factor, uint64_t max_degree_plus1, const uint8_t *root_of_unity, int method);
 int gs_prover_remainder_check(const uint8_t *values, uint64_t len, uint32_t extension_factor, uint64_t max_degree_plus1, const uint8_t *root_of_unity,
                               int method) {
-    if (!values || !root_of_unity || !len || (method != 0 && method != 1)) return GS_ERR_ARG;
     if (!g_bound) return GS_ERR_UNSUPPORTED;
+    UseApi use(&g_default_api);
+    return remainder_check_entry(values, len, extension_factor, max_degree_plus1, root_of_unity, method);
+}
+int gs_prover_remainder_check_on(const gs_prover_binding *b, const uint8_t *values, uint64_t len, uint32_t extension_factor, uint64_t max_degree_plus1,
+                                 const uint8_t *root_of_unity, int method) {
+    if (!b) return GS_ERR_ARG;
+    UseApi use(reinterpret_cast<const Api *>(b));
+    return remainder_check_entry(values, len, extension_factor, max_degree_plus1, root_of_unity, method);
+}
+static int remainder_check_entry(const uint8_t *values, uint64_t len, uint32_t extension_factor, uint64_t max_degree_plus1, const uint8_t *root_of_unity, int method) {
+    if (!values || !root_of_unity || !len || (method != 0 && method != 1)) return GS_ERR_ARG;
     try {
         std::vector<F> v(len);
-        for (uint64_t i = 0; i < len; i++) v[i] = from16(values + 16 * i);
+        for (uint64_t i = 0; i < len; i++) v[i] = from16(values + ELEM * i);
         return remainder_is_low_degree(v, extension_factor, max_degree_plus1, from16(root_of_unity), method) ? 1 : 0;
     } catch (const Fail &f) {
         return f.code ? f.code : GS_ERR_ARG;
@@ -432,15 +511,15 @@ static bool remainder_is_low_degree(const std::vector<F> &remainder, uint64_t E,
     std::vector<F> domain(len);
     F cur = 1;
     for (uint64_t i = 0; i < len; i++) { domain[i] = cur; cur = hf_mul(cur, rou); }
-    Bytes xs(m * 16), ys(m * 16), poly(m * 16);
-    for (uint64_t i = 0; i < m; i++) { le16(domain[positions[i]], xs.data() + 16 * i); le16(remainder[positions[i]], ys.data() + 16 * i); }
+    Bytes xs(m * ELEM), ys(m * ELEM), poly(m * ELEM);
+    for (uint64_t i = 0; i < m; i++) { le16(domain[positions[i]], xs.data() + ELEM * i); le16(remainder[positions[i]], ys.data() + ELEM * i); }
     if (A.gs_small_interpolate(xs.data(), ys.data(), (uint32_t)m, poly.data())) fail(GS_ERR_ARG, "gs_small_interpolate failed");
     const uint32_t rest = (uint32_t)(positions.size() - m);
-    Bytes rx(rest * 16), rv(rest * 16);
-    for (uint32_t i = 0; i < rest; i++) le16(domain[positions[m + i]], rx.data() + 16 * i);
+    Bytes rx(rest * ELEM), rv(rest * ELEM);
+    for (uint32_t i = 0; i < rest; i++) le16(domain[positions[m + i]], rx.data() + ELEM * i);
     if (A.gs_small_eval_poly(poly.data(), (uint32_t)m, rx.data(), rest, rv.data())) fail(GS_ERR_ARG, "gs_small_eval_poly failed");
     for (uint32_t i = 0; i < rest; i++)
-        if (from16(rv.data() + 16 * i) != remainder[positions[m + i]]) return false;
+        if (from16(rv.data() + ELEM * i) != remainder[positions[m + i]]) return false;
     return true;
 }
 
@@ -459,7 +538,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     if (E < 2 * cf) fail(GS_ERR_ARG, "extension factor must be at least 2x the composition factor");
     const F omega = from16(job.root_of_unity);
     const F comp_rou = hf_pow(omega, (hfe)(N / Nc)), exec_rou = hf_pow(omega, (hfe)E);
-    uint8_t s16[16], s16b[16];
+    uint8_t s16[ELEM], s16b[ELEM];
 
     // 1 ----- evaluation context (lib/Stark.ts:92-94): the kernels below derive domain points from omega; the evaluation domain is
     // materialised only by the general Z(x) sequence
@@ -589,15 +668,15 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         x.check(A.gs_gather(x.c, eTree.nodes.p, DIGEST, &one, 1, eTree.root.data()), "gs_gather(root)");
         win.end();
         for (uint32_t i = 0; i < job.nassertions; i++)
-            if (memcmp(got.data() + i * ELEM, job.assertions[i].value, 16))
+            if (memcmp(got.data() + i * ELEM, job.assertions[i].value, ELEM))
                 fail(GS_ERR_ARG, "Assertion at step %llu, register %u conflicts with execution trace", (unsigned long long)job.assertions[i].step,
                      job.assertions[i].reg);
         trace.release();
         coefficients = prng_many(eTree.root, dcount + bcoef);
     };
     auto coeff_bytes = [&](size_t from, size_t count) {
-        Bytes b(count * 16);
-        for (size_t i = 0; i < count; i++) le16(coefficients[from + i], b.data() + 16 * i);
+        Bytes b(count * ELEM);
+        for (size_t i = 0; i < count; i++) le16(coefficients[from + i], b.data() + ELEM * i);
         return b;
     };
 
@@ -608,22 +687,22 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         read_evaluation_root();
         const RegData &d = rdata[0];
         const uint32_t m = (uint32_t)d.xs.size();
-        Bytes xs(m * 16), ys(m * 16), ipoly(m * 16);
-        for (uint32_t i = 0; i < m; i++) { le16(d.xs[i], xs.data() + 16 * i); le16(d.ys[i], ys.data() + 16 * i); }
+        Bytes xs(m * ELEM), ys(m * ELEM), ipoly(m * ELEM);
+        for (uint32_t i = 0; i < m; i++) { le16(d.xs[i], xs.data() + ELEM * i); le16(d.ys[i], ys.data() + ELEM * i); }
         if (A.gs_small_interpolate(xs.data(), ys.data(), m, ipoly.data())) fail(GS_ERR_ARG, "gs_small_interpolate failed");    // BoundaryConstraints.ts:42
         const bool q_adjusted = groups[0].first < combination_degree;
-        Bytes co(4 * 16, 0);
+        Bytes co(4 * ELEM, 0);
         le16(coefficients[0], co.data());
-        if (q_adjusted) le16(coefficients[1], co.data() + 16);
-        le16(coefficients[dcount], co.data() + 32);
-        if (b_inc > 0) le16(coefficients[dcount + 1], co.data() + 48);
+        if (q_adjusted) le16(coefficients[1], co.data() + ELEM);
+        le16(coefficients[dcount], co.data() + 2 * ELEM);
+        if (b_inc > 0) le16(coefficients[dcount + 1], co.data() + 3 * ELEM);
         // ... and, with one committed vector, LinearCombination.computeMany (:36-64) on top: the same prng stream continues
         const bool with_lc = lc_folds;
-        Bytes lc(2 * 16, 0);
+        Bytes lc(2 * ELEM, 0);
         if (with_lc) {
             std::vector<F> all = prng_many(eTree.root, dcount + bcoef + (b_inc > 0 ? 2 : 1));
             le16(all[dcount + bcoef], lc.data());
-            if (b_inc > 0) le16(all[dcount + bcoef + 1], lc.data() + 16);
+            if (b_inc > 0) le16(all[dcount + bcoef + 1], lc.data() + ELEM);
         }
         lc_fused = with_lc;
         le16(omega, s16);
@@ -666,13 +745,13 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
                 le16(hf_pow(q_rou, (hfe)(combination_degree - g.first)), s16);
                 x.check(A.gs_power_series(x.c, s16, Nq, powers.p), "gs_power_series(q powers)");
                 if (first) {                                         // every constraint's plain term + this group's adjusted terms
-                    Bytes adj(air.nconstraints * 16, 0);
-                    for (uint32_t i : g.second) le16(coefficients[next++], adj.data() + 16 * i);
+                    Bytes adj(air.nconstraints * ELEM, 0);
+                    for (uint32_t i : g.second) le16(coefficients[next++], adj.data() + ELEM * i);
                     x.check(A.gs_combine_adjusted(x.c, qa.data(), plain.data(), adj.data(), air.nconstraints, powers.p, nullptr, Nq, merged), "gs_combine_adjusted(Q)");
                 } else {
                     std::vector<const void *> members;
-                    Bytes adj(g.second.size() * 16);
-                    for (size_t k = 0; k < g.second.size(); k++) { members.push_back(qa[g.second[k]]); le16(coefficients[next++], adj.data() + 16 * k); }
+                    Bytes adj(g.second.size() * ELEM);
+                    for (size_t k = 0; k < g.second.size(); k++) { members.push_back(qa[g.second[k]]); le16(coefficients[next++], adj.data() + ELEM * k); }
                     x.check(A.gs_combine_adjusted(x.c, members.data(), nullptr, adj.data(), (uint32_t)members.size(), powers.p, merged, Nq, merged), "gs_combine_adjusted(Q)");
                 }
                 first = false;
@@ -694,11 +773,11 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         std::vector<std::vector<F>> ipolys, zpolys;
         for (auto &d : rdata) {
             const uint32_t m = (uint32_t)d.xs.size();
-            Bytes xs(m * 16), ys(m * 16), co(m * 16);
-            for (uint32_t i = 0; i < m; i++) { le16(d.xs[i], xs.data() + 16 * i); le16(d.ys[i], ys.data() + 16 * i); }
+            Bytes xs(m * ELEM), ys(m * ELEM), co(m * ELEM);
+            for (uint32_t i = 0; i < m; i++) { le16(d.xs[i], xs.data() + ELEM * i); le16(d.ys[i], ys.data() + ELEM * i); }
             if (A.gs_small_interpolate(xs.data(), ys.data(), m, co.data())) fail(GS_ERR_ARG, "gs_small_interpolate failed");
             std::vector<F> ip(m), zp{1};
-            for (uint32_t i = 0; i < m; i++) ip[i] = from16(co.data() + 16 * i);
+            for (uint32_t i = 0; i < m; i++) ip[i] = from16(co.data() + ELEM * i);
             for (uint32_t i = 0; i < m; i++) {          // zPoly *= (x - xs[i]), BoundaryConstraints.ts:24-30
                 std::vector<F> nz(zp.size() + 1, 0);
                 const F nx = hf_sub(0, d.xs[i]);
@@ -714,9 +793,9 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
             zpolys.push_back(zp);
         }
         auto upload_rows = [&](const std::vector<std::vector<F>> &rows, size_t len) {
-            Bytes host(rows.size() * len * 16, 0);                    // shorter rows are zero-extended (newMatrixFromVectors)
+            Bytes host(rows.size() * len * ELEM, 0);                    // shorter rows are zero-extended (newMatrixFromVectors)
             for (size_t r = 0; r < rows.size(); r++)
-                for (size_t k = 0; k < rows[r].size(); k++) le16(rows[r][k], host.data() + (r * len + k) * 16);
+                for (size_t k = 0; k < rows[r].size(); k++) le16(rows[r][k], host.data() + (r * len + k) * ELEM);
             Buf b(x, host.size());
             x.check(A.gs_upload(x.c, b.p, host.data(), host.size()), "gs_upload(boundary polynomials)");
             return b;
@@ -750,7 +829,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         std::vector<const void *> ba;
         for (uint32_t i = 0; i < bcount; i++) ba.push_back(bEval.at((uint64_t)i * N * ELEM));
         Bytes bco = coeff_bytes(dcount, bcoef);
-        x.check(A.gs_combine_adjusted(x.c, ba.data(), bco.data(), b_inc > 0 ? bco.data() + 16 * bcount : nullptr, bcount, b_inc > 0 ? psbPowers.p : nullptr,
+        x.check(A.gs_combine_adjusted(x.c, ba.data(), bco.data(), b_inc > 0 ? bco.data() + ELEM * bcount : nullptr, bcount, b_inc > 0 ? psbPowers.p : nullptr,
                                       dEval.p, N, cEval.p), "gs_combine_adjusted(B + D)");
     }
     if (!fused) zInverses.release();
@@ -764,9 +843,9 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         // psIncrementalDegree = compositionDegree - T: the same powers as B's; P_r o powers is not materialised, C is added in the pass
         const uint32_t offset = dcount + bcoef, cnt = b_inc > 0 ? 2 * V : V;
         std::vector<F> co = prng_many(eTree.root, offset + cnt);
-        Bytes cb(cnt * 16);
-        for (uint32_t i = 0; i < cnt; i++) le16(co[offset + i], cb.data() + 16 * i);
-        x.check(A.gs_combine_adjusted(x.c, eVectors.data(), cb.data(), b_inc > 0 ? cb.data() + 16 * V : nullptr, V, b_inc > 0 ? psbPowers.p : nullptr, cEval.p, N,
+        Bytes cb(cnt * ELEM);
+        for (uint32_t i = 0; i < cnt; i++) le16(co[offset + i], cb.data() + ELEM * i);
+        x.check(A.gs_combine_adjusted(x.c, eVectors.data(), cb.data(), b_inc > 0 ? cb.data() + ELEM * V : nullptr, V, b_inc > 0 ? psbPowers.p : nullptr, cEval.p, N,
                                       lEval.p), "gs_combine_adjusted(L)");
     }
     cEval.release();
@@ -886,7 +965,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     clock.mark("remainder + answers fetched (one sync)");
     {
         Bytes &raw = remainder_raw;
-        for (uint64_t i = 0; i < len; i++) remainder[i] = from16(raw.data() + 16 * i);
+        for (uint64_t i = 0; i < len; i++) remainder[i] = from16(raw.data() + ELEM * i);
         // verifyRemainder (:223-252)
         F rou = omega;
         for (uint32_t d = 0; d < depth; d++) { rou = hf_mul(rou, rou); rou = hf_mul(rou, rou); }      // omega^(4^depth)
@@ -918,7 +997,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     }
     if (remainder.size() > MAX_ARRAY) fail(GS_ERR_ARG, "remainder too long");
     out.push_back(remainder.size() == MAX_ARRAY ? 0 : (uint8_t)remainder.size());
-    for (F v : remainder) { uint8_t b[16]; le16(v, b); out.insert(out.end(), b, b + 16); }
+    for (F v : remainder) { uint8_t b[ELEM]; le16(v, b); out.insert(out.end(), b, b + ELEM); }
     out.push_back(0);    // no input shapes (iShapes = [])
     clock.mark("serialized");
 }

@@ -17,15 +17,21 @@ from .field import _le
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PROVER_LIB_PATH = os.path.join(_HERE, 'csrc', 'libgstark_prover.so')
+# one build of the driver per field flavour, like the ABI library (csrc/build.sh): its host-side scalars are computed in that field
+from ._abi import MODULUS_17, MODULUS_32, MODULUS_64, MODULUS_128, MODULUS_224, MODULUS_256   # noqa: E402
+PROVER_LIB_PATHS = {MODULUS_128: PROVER_LIB_PATH, MODULUS_64: os.path.join(_HERE, 'csrc', 'libgstark_prover_q64.so'),
+                    MODULUS_32: os.path.join(_HERE, 'csrc', 'libgstark_prover_q32.so'), MODULUS_17: os.path.join(_HERE, 'csrc', 'libgstark_prover_q17.so'),
+                    MODULUS_256: os.path.join(_HERE, 'csrc', 'libgstark_prover_p256.so'), MODULUS_224: os.path.join(_HERE, 'csrc', 'libgstark_prover_p224.so')}
+ELT_MAX = 32          # GS_PROVER_ELT_MAX: the job's scalar fields (include/gstark_prover.h)
 
 
 class _Assertion(C.Structure):
-    _fields_ = [('step', C.c_uint64), ('reg', C.c_uint32), ('value', C.c_uint8 * 16)]
+    _fields_ = [('step', C.c_uint64), ('reg', C.c_uint32), ('value', C.c_uint8 * ELT_MAX)]
 
 
 class _Air(C.Structure):
     _fields_ = [('kind', C.c_uint32), ('registers', C.c_uint32), ('nconstraints', C.c_uint32), ('degrees', C.POINTER(C.c_uint32)),
-                ('seed', C.c_uint8 * 16), ('round_constants', C.c_char_p), ('nrc', C.c_uint32), ('k_table', C.c_void_p), ('k_len', C.c_uint64),
+                ('seed', C.c_uint8 * ELT_MAX), ('round_constants', C.c_char_p), ('nrc', C.c_uint32), ('k_table', C.c_void_p), ('k_len', C.c_uint64),
                 ('t_code', C.POINTER(C.c_uint32)), ('t_ninstr', C.c_uint32), ('i_code', C.POINTER(C.c_uint32)), ('i_ninstr', C.c_uint32),
                 ('e_code', C.POINTER(C.c_uint32)), ('e_ninstr', C.c_uint32), ('consts', C.c_char_p), ('nconsts', C.c_uint32),
                 ('vm_regs', C.c_uint32), ('static_values', C.c_char_p), ('static_periods', C.POINTER(C.c_uint32)), ('nstatic', C.c_uint32),
@@ -35,7 +41,7 @@ class _Air(C.Structure):
 
 class _Job(C.Structure):
     _fields_ = [('steps', C.c_uint64), ('extension_factor', C.c_uint32), ('exe_query_count', C.c_uint32), ('fri_query_count', C.c_uint32),
-                ('hash_alg', C.c_int32), ('root_of_unity', C.c_uint8 * 16), ('assertions', C.POINTER(_Assertion)), ('nassertions', C.c_uint32),
+                ('hash_alg', C.c_int32), ('root_of_unity', C.c_uint8 * ELT_MAX), ('assertions', C.POINTER(_Assertion)), ('nassertions', C.c_uint32),
                 ('air', _Air)]
 
 
@@ -55,47 +61,49 @@ class _Collective(C.Structure):
     _fields_ = [('label', C.c_char * 40), ('kind', C.c_uint32), ('bytes', C.c_uint64), ('ms', C.c_double)]
 
 
-_bound = {}
+_libs = {}           # driver library path -> CDLL (one image per field flavour)
+_bindings = {}       # (driver path, ABI library handle) -> gs_prover_binding*
 _bound_lock = threading.Lock()      # ProverPool lanes construct their NativeProver concurrently
 
 
 def _driver(backend):
-    """libgstark_prover.so bound to the ABI library of `backend` (one private copy of the driver per ABI library)."""
-    key = backend.lib._name
+    """(driver library, binding) for the ABI library of `backend`: the build of libgstark_prover*.so for the backend's field, and a
+    binding of its own for that ABI library (gs_prover_open) — any number of ABI libraries (the HIP library, a test double) share one
+    driver image."""
+    path = PROVER_LIB_PATHS.get(backend.modulus)
+    if path is None:
+        raise GstarkError(f'no build of the native driver for the field of {backend.modulus} elements')
     with _bound_lock:
-        return _driver_locked(backend, key)
-
-
-def _driver_locked(backend, key):
-    if key not in _bound:
-        if not os.path.exists(PROVER_LIB_PATH):
-            raise GstarkError(f'{PROVER_LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"`')
-        mode = getattr(os, 'RTLD_LOCAL', 0) | getattr(os, 'RTLD_NOW', 2)
-        if len(_bound):
-            # a second ABI library in the same process (tests: oracle double + HIP): the driver keeps its binding in static
-            # storage, so give it its own image
-            import shutil
-            import tempfile
-            tmp = os.path.join(tempfile.mkdtemp(prefix='gstark_prover_'), f'libgstark_prover_{len(_bound)}.so')
-            shutil.copy(PROVER_LIB_PATH, tmp)
-            lib = C.CDLL(tmp, mode=mode)
-        else:
-            lib = C.CDLL(PROVER_LIB_PATH, mode=mode)
-        lib.gs_prover_bind.argtypes = [C.c_void_p]
-        lib.gs_prover_bind.restype = C.c_int
-        lib.gs_prover_prove.argtypes = [C.c_void_p, C.POINTER(_Job), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
-        lib.gs_prover_prove.restype = C.c_int
-        lib.gs_prover_last_stats.argtypes = [C.POINTER(_Stats)]
-        lib.gs_prover_last_stats.restype = C.c_int
-        lib.gs_prover_prove_dist.argtypes = [C.c_void_p, C.POINTER(_Job), C.POINTER(GsComm), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
-        lib.gs_prover_prove_dist.restype = C.c_int
-        lib.gs_prover_last_collectives.argtypes = [C.POINTER(_Collective), C.c_uint32, C.POINTER(C.c_uint32)]
-        lib.gs_prover_last_collectives.restype = C.c_int
-        rc = lib.gs_prover_bind(C.c_void_p(backend.lib._handle))
-        if rc:
-            raise GstarkError(f'gs_prover_bind failed ({rc}): the ABI library lacks an entry point the driver needs')
-        _bound[key] = lib
-    return _bound[key]
+        lib = _libs.get(path)
+        if lib is None:
+            if not os.path.exists(path):
+                raise GstarkError(f'{path} is missing: run `python -c "import __graft_entry__ as g; g.build()"`')
+            lib = C.CDLL(path, mode=getattr(os, 'RTLD_LOCAL', 0) | getattr(os, 'RTLD_NOW', 2))
+            lib.gs_prover_open.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+            lib.gs_prover_open.restype = C.c_int
+            lib.gs_prover_element_size.argtypes = []
+            lib.gs_prover_element_size.restype = C.c_int
+            lib.gs_prover_prove_on.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Job), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
+            lib.gs_prover_prove_on.restype = C.c_int
+            lib.gs_prover_last_stats.argtypes = [C.POINTER(_Stats)]
+            lib.gs_prover_last_stats.restype = C.c_int
+            lib.gs_prover_prove_dist_on.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Job), C.POINTER(GsComm), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
+            lib.gs_prover_prove_dist_on.restype = C.c_int
+            lib.gs_prover_last_collectives.argtypes = [C.POINTER(_Collective), C.c_uint32, C.POINTER(C.c_uint32)]
+            lib.gs_prover_last_collectives.restype = C.c_int
+            lib.gs_prover_remainder_check_on.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_char_p, C.c_int]
+            lib.gs_prover_remainder_check_on.restype = C.c_int
+            if lib.gs_prover_element_size() != backend.element_size:
+                raise GstarkError(f'{path} is built for {lib.gs_prover_element_size()}-byte elements')
+            _libs[path] = lib
+        key = (path, backend.lib._handle)
+        if key not in _bindings:
+            b = C.c_void_p()
+            rc = lib.gs_prover_open(C.c_void_p(backend.lib._handle), C.byref(b))
+            if rc:
+                raise GstarkError(f'gs_prover_open failed ({rc}): the ABI library lacks an entry point the driver needs, or computes in another field')
+            _bindings[key] = b
+        return lib, _bindings[key]
 
 
 class PackedSeed:
@@ -119,10 +127,7 @@ class NativeProver:
             self._exe, self._fri, self._alg = stark.exeQueryCount, stark.friQueryCount, stark.hashAlg
         self.field = air.field
         self.backend = self.field.backend
-        from .field import MODULUS
-        if self.field.modulus != MODULUS:
-            raise GstarkError('the native driver is built for the 128-bit field; use Stark.prove() on the small-field builds')
-        self.lib = _driver(self.backend)
+        self.lib, self.binding = _driver(self.backend)       # the driver build for this field, bound to this backend's ABI library
         self._static_pack = None
         self._keep = []
         self._out = C.create_string_buffer(1 << 22)
@@ -132,7 +137,7 @@ class NativeProver:
             ctx = air.initProvingContext([], [0])
             self.kind, self.degrees = 0, [3]
             self._kTable = ctx._kTable
-            self._rc = b''.join(_le(k) for k in air.roundConstants)
+            self._rc = b''.join(self.field.le(k) for k in air.roundConstants)
             self.rootOfUnity = ctx.rootOfUnity
         elif isinstance(air, GenericAir):
             rows = [[0] * air.traceRegisterCount]
@@ -158,13 +163,14 @@ class NativeProver:
         job.steps, job.extension_factor = air.steps, air.extensionFactor
         job.exe_query_count, job.fri_query_count = self._exe, self._fri
         job.hash_alg = self._alg
-        job.root_of_unity[:] = _le(self.rootOfUnity)
+        es = f.elementSize
+        job.root_of_unity[:es] = f.le(self.rootOfUnity)
         arr = (_Assertion * len(assertions))()
         for i, a in enumerate(assertions):
             if a['register'] < 0 or a['step'] < 0:
                 raise ValueError('Invalid assertion')
             arr[i].step, arr[i].reg = a['step'], a['register']
-            arr[i].value[:] = _le(a['value'] % f.modulus)
+            arr[i].value[:es] = f.le(a['value'] % f.modulus)
         job.assertions, job.nassertions = arr, len(assertions)
         ja = job.air
         ja.kind, ja.registers, ja.nconstraints = self.kind, air.traceRegisterCount, len(self.degrees)
@@ -172,12 +178,12 @@ class NativeProver:
         ja.degrees = degrees
         keep = [arr, degrees]
         if self.kind == 0:
-            ja.seed[:] = _le((seed or [0])[0] % f.modulus)
+            ja.seed[:es] = f.le((seed or [0])[0] % f.modulus)
             ja.round_constants, ja.nrc = self._rc, len(air.roundConstants)
             ja.k_table, ja.k_len = self._kTable.ptr, self._kTable.length
         else:
-            t_code, t_n, consts, nconsts, nregs = air.transitionProgram.abi_args()
-            e_code, e_n, consts, nconsts, _ = air.evaluationProgram.abi_args() if air.evaluationProgram.consts is air.transitionProgram.consts \
+            t_code, t_n, consts, nconsts, nregs = air.transitionProgram.abi_args(es)
+            e_code, e_n, consts, nconsts, _ = air.evaluationProgram.abi_args(es) if air.evaluationProgram.consts is air.transitionProgram.consts \
                 else (None, 0, None, 0, 0)
             if e_code is None:
                 # transition and evaluator have separate constant pools: concatenate and rebase the evaluator's constant indexes
@@ -193,12 +199,12 @@ class NativeProver:
                     code.extend((op, d, a, b))
                 e_code, e_n = (C.c_uint32 * len(code))(*code), len(e_prog.code)
                 pool = list(t_prog.consts) + list(e_prog.consts)
-                consts, nconsts = b''.join(int(v).to_bytes(16, 'little') for v in pool), len(pool)
+                consts, nconsts = b''.join(int(v).to_bytes(es, 'little') for v in pool), len(pool)
                 nregs = max(t_prog.nregs, e_prog.nregs)
             ja.t_code, ja.t_ninstr, ja.e_code, ja.e_ninstr = t_code, t_n, e_code, e_n
             ja.consts, ja.nconsts, ja.vm_regs = consts, nconsts, nregs
             if air.initProgram is not None:
-                i_code, i_n = air.initProgram.abi_args()[:2]
+                i_code, i_n = air.initProgram.abi_args(es)[:2]
                 ja.i_code, ja.i_ninstr = i_code, i_n
                 keep.append(i_code)
                 ja.vm_regs = max(ja.vm_regs, air.initProgram.nregs)
@@ -218,7 +224,7 @@ class NativeProver:
             else:
                 # public static registers are constants of the AIR: packed once per prover, not per proof (~500 values for Poseidon)
                 if self._static_pack is None:
-                    self._static_pack = (b''.join(_le(v % f.modulus) for values in air.staticRegisters for v in values) or bytes(16),
+                    self._static_pack = (b''.join(f.le(v % f.modulus) for values in air.staticRegisters for v in values) or bytes(es),
                                          [len(v) for v in air.staticRegisters])
                 tables, table_lens = self._tables, self._lens
                 svals, plist = self._static_pack
@@ -237,9 +243,9 @@ class NativeProver:
         n = C.c_uint64()
         err = C.create_string_buffer(512)
         if comm is None:
-            rc = self.lib.gs_prover_prove(self.backend.ctx, C.byref(job), C.cast(out, C.c_void_p), cap, C.byref(n), err, 512)
+            rc = self.lib.gs_prover_prove_on(self.binding, self.backend.ctx, C.byref(job), C.cast(out, C.c_void_p), cap, C.byref(n), err, 512)
         else:
-            rc = self.lib.gs_prover_prove_dist(self.backend.ctx, C.byref(job), C.byref(comm), C.cast(out, C.c_void_p), cap, C.byref(n), err, 512)
+            rc = self.lib.gs_prover_prove_dist_on(self.binding, self.backend.ctx, C.byref(job), C.byref(comm), C.cast(out, C.c_void_p), cap, C.byref(n), err, 512)
         if rc:
             raise StarkError(f'native prove() failed ({rc}): {err.value.decode(errors="replace")}')
         return C.string_at(out, n.value)

@@ -39,6 +39,9 @@ struct gs_comm {
 int gs_prover_prove_dist(gs_ctx *ctx, const struct gs_prover_job *job, const gs_comm *comm, uint8_t *out, uint64_t cap, uint64_t *len,
                          char *err, uint64_t errcap);
 
+int gs_prover_prove_dist_on(const gs_prover_binding *b, gs_ctx *ctx, const struct gs_prover_job *job, const gs_comm *comm, uint8_t *out, uint64_t cap,
+                            uint64_t *len, char *err, uint64_t errcap);
+
 /* The collectives the last gs_prover_prove_dist on the calling thread issued, in order. */
 struct gs_prover_collective {
     char label[40];

@@ -14,11 +14,15 @@
 extern "C" {
 #endif
 
+/* Scalars of a job (assertion values, the MiMC seed, the root of unity) are field elements of gs_element_size() bytes, little-endian,
+ * in fields of GS_PROVER_ELT_MAX bytes (the bytes above the element size are ignored): one job layout for every field flavour. */
+#define GS_PROVER_ELT_MAX 32
+
 typedef struct gs_assertion gs_assertion;
 struct gs_assertion {          /* lib/Stark.ts:356-375: register `reg` holds `value` at `step` */
     uint64_t step;
     uint32_t reg;
-    uint8_t value[16];
+    uint8_t value[GS_PROVER_ELT_MAX];
 };
 
 /* What the AIR module contributes (lib/Stark.ts:35-58: `air`): counts, degrees and the two device routines. */
@@ -28,8 +32,8 @@ struct gs_prover_air {
     uint32_t nconstraints;
     const uint32_t *degrees;     /* constraint degrees */
     /* kind 0 */
-    uint8_t seed[16];
-    const uint8_t *round_constants;   /* host, nrc * 16 */
+    uint8_t seed[GS_PROVER_ELT_MAX];
+    const uint8_t *round_constants;   /* host, nrc elements */
     uint32_t nrc;
     const void *k_table;         /* device: the cyclic register over the composition domain */
     uint64_t k_len;
@@ -50,7 +54,7 @@ struct gs_prover_job {
     uint64_t steps;
     uint32_t extension_factor, exe_query_count, fri_query_count;
     int32_t hash_alg;
-    uint8_t root_of_unity[16];   /* primitive (steps*extension_factor)-th root: galois getRootOfUnity, computed by the caller */
+    uint8_t root_of_unity[GS_PROVER_ELT_MAX];   /* primitive (steps*extension_factor)-th root: galois getRootOfUnity, computed by the caller */
     const gs_assertion *assertions;
     uint32_t nassertions;
     struct gs_prover_air air;
@@ -70,11 +74,21 @@ struct gs_prover_stats {
 };
 
 /* Resolves the gs_* entry points from `dl_handle` (the handle dlopen() returned for the ABI library).  GS_ERR_UNSUPPORTED if one
- * is missing. */
+ * is missing, or if the library computes in another field / element size than this build of the driver (one driver library per
+ * field flavour: libgstark_prover.so, libgstark_prover_q64.so, ... — csrc/build.sh).  This is the process-wide DEFAULT binding, used
+ * by the entry points that take no binding. */
 int gs_prover_bind(void *dl_handle);
+/* A binding of its own (several ABI libraries of one flavour in a process: the HIP library and a test double): every entry point
+ * below has an `_on` form that takes it.  Bindings are immutable and may be shared between threads. */
+typedef struct gs_prover_binding gs_prover_binding;
+int gs_prover_open(void *dl_handle, gs_prover_binding **out);
+void gs_prover_close(gs_prover_binding *b);
+int gs_prover_element_size(void);      /* of this build of the driver */
 /* The serialized proof into out[0..cap); *len receives its size (GS_ERR_ARG with *len set when cap is too small).  On failure
  * err[0..errcap) holds the reference's message where there is one ("Assertion at step ... conflicts with execution trace"). */
 int gs_prover_prove(gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, uint64_t cap, uint64_t *len, char *err, uint64_t errcap);
+int gs_prover_prove_on(const gs_prover_binding *b, gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, uint64_t cap, uint64_t *len, char *err,
+                       uint64_t errcap);
 int gs_prover_last_stats(struct gs_prover_stats *out);
 /* LowDegreeProver.verifyRemainder (LowDegreeProver.ts:223-252) on its own, for tests: `len` values on the powers of root_of_unity
  * (order len); 1 = the values at the positions that are not multiples of extension_factor lie on a polynomial of degree
@@ -82,6 +96,8 @@ int gs_prover_last_stats(struct gs_prover_stats *out);
  * positions, evaluate at the rest); method 1: the coefficient form the driver uses — same verdict on every input. */
 int gs_prover_remainder_check(const uint8_t *values, uint64_t len, uint32_t extension_factor, uint64_t max_degree_plus1, const uint8_t *root_of_unity,
                               int method);
+int gs_prover_remainder_check_on(const gs_prover_binding *b, const uint8_t *values, uint64_t len, uint32_t extension_factor, uint64_t max_degree_plus1,
+                                 const uint8_t *root_of_unity, int method);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,17 @@ const path = require('path');
 const { native, le } = require('./galois');
 
 const HASH_ALG = { sha256: 0, blake2s256: 1 };
+// one build of the driver per field flavour, like the ABI library (genstark_amd/csrc/build.sh)
+const DRIVERS = new Map([
+    [2n ** 128n - 9n * 2n ** 32n + 1n, 'libgstark_prover.so'], [2n ** 64n - 21n * 2n ** 30n + 1n, 'libgstark_prover_q64.so'],
+    [2n ** 32n - 3n * 2n ** 25n + 1n, 'libgstark_prover_q32.so'], [96769n, 'libgstark_prover_q17.so'],
+    [2n ** 256n - 351n * 2n ** 32n + 1n, 'libgstark_prover_p256.so'], [2n ** 224n - 2n ** 96n + 1n, 'libgstark_prover_p224.so'],
+]);
+function driverPath(field) {
+    if (process.env.GSTARK_PROVER_LIB) return process.env.GSTARK_PROVER_LIB;
+    if (!DRIVERS.has(field.modulus)) throw new TypeError(`no build of the native driver for the field of ${field.modulus} elements`);
+    return path.join(__dirname, '..', 'genstark_amd', 'csrc', DRIVERS.get(field.modulus));
+}
 
 function proveMimcSerialized(air, options, assertions, seed) {
     if (!(options.hashAlgorithm in HASH_ALG)) throw new TypeError(`Hash algorithm ${options.hashAlgorithm} is not supported`);
@@ -17,8 +28,7 @@ function proveMimcSerialized(air, options, assertions, seed) {
         roundConstants: Buffer.concat(air.roundConstants.map(le)), kTable: context.kTable.ptr, kLen: context.kTable.length,
         assertions: assertions.map(a => ({ step: a.step, register: a.register, value: le(f.mod(a.value)) })),
     };
-    const lib = process.env.GSTARK_PROVER_LIB || path.join(__dirname, '..', 'genstark_amd', 'csrc', 'libgstark_prover.so');
-    return native().proveMimcSerialized(f.ctx, lib, job);
+    return native().proveMimcSerialized(f.ctx, driverPath(f), job);
 }
 
 // ... and for an AIR given as register-machine programs (js/air_generic.js: the reference's Rescue / Poseidon examples): kind 1 of
@@ -44,8 +54,7 @@ function proveGenericSerialized(air, options, assertions, seed) {
         staticLens: context.staticLens, firstRows: Buffer.concat(context.firstRows.map(row => Buffer.concat(row.map(le)))),
         segments: air.segmentLength === null ? 0 : context.firstRows.length, segmentLen: air.segmentLength === null ? 0 : air.segmentLength,
     };
-    const lib = process.env.GSTARK_PROVER_LIB || path.join(__dirname, '..', 'genstark_amd', 'csrc', 'libgstark_prover.so');
-    return native().proveGenericSerialized(f.ctx, lib, job);
+    return native().proveGenericSerialized(f.ctx, driverPath(f), job);
 }
 
 module.exports = { proveMimcSerialized, proveGenericSerialized };

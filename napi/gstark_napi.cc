@@ -348,9 +348,35 @@ napi_value MerkleProveBatch(napi_env env, napi_callback_info info) {
 
 // proveMimcSerialized(ctx, proverLibPath, job) -> Buffer: ONE call = Stark.prove() + Serializer.serializeProof() of the MiMC AIR through
 // the native driver (include/gstark_prover.h; the driver is bound to the ABI library load() opened).
-//   job = { steps, extensionFactor, exeQueryCount, friQueryCount, hashAlg, rootOfUnity: Buffer(16), seed: Buffer(16),
-//           roundConstants: Buffer(16*n), kTable: BigInt (device pointer), kLen, assertions: [{step, register, value: Buffer(16)}] }
+//   job = { steps, extensionFactor, exeQueryCount, friQueryCount, hashAlg, rootOfUnity: Buffer(es), seed: Buffer(es),
+//           roundConstants: Buffer(es*n), kTable: BigInt (device pointer), kLen, assertions: [{step, register, value: Buffer(es)}] }   (es = gs_element_size() of the loaded library)
+// The driver library is the build for the loaded ABI library's field (js/prover.js picks libgstark_prover*.so by modulus); the addon
+// holds ONE binding of it to that ABI library (gs_prover_open: nothing process-wide is written).  Scalars of a job are gs_element_size()
+// bytes each.
 void *g_prover = nullptr;
+gs_prover_binding *g_binding = nullptr;
+size_t g_es = 16;
+typedef int (*prove_on_fn)(const gs_prover_binding *, gs_ctx *, const gs_prover_job *, uint8_t *, uint64_t, uint64_t *, char *, uint64_t);
+bool open_driver(napi_env env, napi_value path_value) {
+    if (g_prover) return true;
+    char path[1024];
+    size_t len;
+    if (napi_get_value_string_utf8(env, path_value, path, sizeof path, &len) != napi_ok) { napi_throw_type_error(env, nullptr, "driver library path expected"); return false; }
+    void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) { napi_throw_error(env, nullptr, (std::string("cannot load ") + path + ": " + dlerror()).c_str()); return false; }
+    typedef int (*openfn)(void *, gs_prover_binding **);
+    typedef int (*sizefn)();
+    openfn of = (openfn)dlsym(lib, "gs_prover_open");
+    sizefn sf = (sizefn)dlsym(g_lib, "gs_element_size");
+    if (!of || !sf || of(g_lib, &g_binding) != GS_OK) {
+        napi_throw_error(env, nullptr, "gs_prover_open failed: the driver library is not the build for the loaded library's field");
+        dlclose(lib);
+        return false;
+    }
+    g_es = (size_t)sf();
+    g_prover = lib;
+    return true;
+}
 napi_value ProveMimcSerialized(napi_env env, napi_callback_info info) {
     size_t argc = 3;
     napi_value argv[3];
@@ -358,18 +384,8 @@ napi_value ProveMimcSerialized(napi_env env, napi_callback_info info) {
     void *ctx;
     NAPI_OK(env, napi_get_value_external(env, argv[0], &ctx));
     if (!g_lib) { napi_throw_error(env, nullptr, "call load(path) first"); return nullptr; }
-    typedef int (*bindfn)(void *);
-    typedef int (*provefn)(gs_ctx *, const gs_prover_job *, uint8_t *, uint64_t, uint64_t *, char *, uint64_t);
-    if (!g_prover) {
-        char path[1024];
-        size_t len;
-        NAPI_OK(env, napi_get_value_string_utf8(env, argv[1], path, sizeof path, &len));
-        void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
-        if (!lib) { napi_throw_error(env, nullptr, (std::string("cannot load ") + path + ": " + dlerror()).c_str()); return nullptr; }
-        bindfn bf = (bindfn)dlsym(lib, "gs_prover_bind");
-        if (!bf || bf(g_lib) != GS_OK) { napi_throw_error(env, nullptr, "gs_prover_bind failed"); return nullptr; }
-        g_prover = lib;
-    }
+    if (!open_driver(env, argv[1])) return nullptr;
+    const size_t es = g_es;
     auto prop = [&](const char *name) { napi_value v; napi_get_named_property(env, argv[2], name, &v); return v; };
     auto u64 = [&](const char *name, uint64_t *out) { return get_u64(env, prop(name), out); };
     auto bytes = [&](napi_value v, const uint8_t **data, size_t *len) { void *d; bool ok = napi_get_buffer_info(env, v, &d, len) == napi_ok; *data = (const uint8_t *)d; return ok; };
@@ -379,17 +395,17 @@ napi_value ProveMimcSerialized(napi_env env, napi_callback_info info) {
     const uint8_t *rou, *seed, *rc;
     size_t nrou, nseed, nrc;
     if (!u64("steps", &t) || !u64("extensionFactor", &ef) || !u64("exeQueryCount", &exe) || !u64("friQueryCount", &fri) || !u64("hashAlg", &alg) ||
-        !u64("kLen", &klen) || !u64("kTable", &ktab) || !bytes(prop("rootOfUnity"), &rou, &nrou) || nrou != 16 || !bytes(prop("seed"), &seed, &nseed) ||
-        nseed != 16 || !bytes(prop("roundConstants"), &rc, &nrc) || nrc % 16) {
+        !u64("kLen", &klen) || !u64("kTable", &ktab) || !bytes(prop("rootOfUnity"), &rou, &nrou) || nrou != es || !bytes(prop("seed"), &seed, &nseed) ||
+        nseed != es || !bytes(prop("roundConstants"), &rc, &nrc) || nrc % es) {
         napi_throw_type_error(env, nullptr, "proveMimcSerialized: malformed job");
         return nullptr;
     }
     job.steps = t; job.extension_factor = (uint32_t)ef; job.exe_query_count = (uint32_t)exe; job.fri_query_count = (uint32_t)fri; job.hash_alg = (int32_t)alg;
-    memcpy(job.root_of_unity, rou, 16);
+    memcpy(job.root_of_unity, rou, es);
     const uint32_t degree = 3;
     job.air.kind = 0; job.air.registers = 1; job.air.nconstraints = 1; job.air.degrees = &degree;
-    memcpy(job.air.seed, seed, 16);
-    job.air.round_constants = rc; job.air.nrc = (uint32_t)(nrc / 16);
+    memcpy(job.air.seed, seed, es);
+    job.air.round_constants = rc; job.air.nrc = (uint32_t)(nrc / es);
     job.air.k_table = (const void *)(uintptr_t)ktab; job.air.k_len = klen;
     napi_value arr = prop("assertions");
     uint32_t na = 0;
@@ -405,15 +421,15 @@ napi_value ProveMimcSerialized(napi_env env, napi_callback_info info) {
         napi_get_named_property(env, e, "register", &v);
         ok = ok && get_u64(env, v, &reg);
         napi_get_named_property(env, e, "value", &v);
-        ok = ok && bytes(v, &val, &nval) && nval == 16;
+        ok = ok && bytes(v, &val, &nval) && nval == es;
         if (!ok) { napi_throw_type_error(env, nullptr, "proveMimcSerialized: malformed assertion"); return nullptr; }
-        as[i].step = step; as[i].reg = (uint32_t)reg; memcpy(as[i].value, val, 16);
+        as[i].step = step; as[i].reg = (uint32_t)reg; memcpy(as[i].value, val, es);
     }
     job.assertions = as.data(); job.nassertions = na;
     std::vector<uint8_t> out(1 << 22);
     uint64_t n = 0;
     char err[512] = {0};
-    int rcode = ((provefn)dlsym(g_prover, "gs_prover_prove"))((gs_ctx *)ctx, &job, out.data(), out.size(), &n, err, sizeof err);
+    int rcode = ((prove_on_fn)dlsym(g_prover, "gs_prover_prove_on"))(g_binding, (gs_ctx *)ctx, &job, out.data(), out.size(), &n, err, sizeof err);
     if (rcode != GS_OK) { napi_throw_error(env, nullptr, (std::string("native prove() failed: ") + err).c_str()); return nullptr; }
     napi_value buf;
     NAPI_OK(env, napi_create_buffer_copy(env, (size_t)n, out.data(), nullptr, &buf));
@@ -432,18 +448,8 @@ napi_value ProveGenericSerialized(napi_env env, napi_callback_info info) {
     void *ctx;
     NAPI_OK(env, napi_get_value_external(env, argv[0], &ctx));
     if (!g_lib) { napi_throw_error(env, nullptr, "call load(path) first"); return nullptr; }
-    typedef int (*bindfn)(void *);
-    typedef int (*provefn)(gs_ctx *, const gs_prover_job *, uint8_t *, uint64_t, uint64_t *, char *, uint64_t);
-    if (!g_prover) {
-        char path[1024];
-        size_t len;
-        NAPI_OK(env, napi_get_value_string_utf8(env, argv[1], path, sizeof path, &len));
-        void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
-        if (!lib) { napi_throw_error(env, nullptr, (std::string("cannot load ") + path + ": " + dlerror()).c_str()); return nullptr; }
-        bindfn bf = (bindfn)dlsym(lib, "gs_prover_bind");
-        if (!bf || bf(g_lib) != GS_OK) { napi_throw_error(env, nullptr, "gs_prover_bind failed"); return nullptr; }
-        g_prover = lib;
-    }
+    if (!open_driver(env, argv[1])) return nullptr;
+    const size_t es = g_es;
     auto prop = [&](const char *name) { napi_value v; napi_get_named_property(env, argv[2], name, &v); return v; };
     auto u64 = [&](const char *name, uint64_t *out) { return get_u64(env, prop(name), out); };
     auto bytes = [&](napi_value v, const uint8_t **data, size_t *len) { void *d; bool ok = napi_get_buffer_info(env, v, &d, len) == napi_ok; *data = (const uint8_t *)d; return ok; };
@@ -468,22 +474,22 @@ napi_value ProveGenericSerialized(napi_env env, napi_callback_info info) {
     std::vector<uint32_t> degrees, tcode, icode, ecode, periods, lens32;
     if (!u64("steps", &t) || !u64("extensionFactor", &ef) || !u64("exeQueryCount", &exe) || !u64("friQueryCount", &fri) || !u64("hashAlg", &alg) ||
         !u64("registers", &regs) || !u64("vmRegs", &vmregs) || !u64("staticTables", &tables) || !u64("segments", &segments) || !u64("segmentLen", &seglen) ||
-        !bytes(prop("rootOfUnity"), &rou, &nrou) || nrou != 16 || !bytes(prop("consts"), &consts, &nconsts) || nconsts % 16 ||
+        !bytes(prop("rootOfUnity"), &rou, &nrou) || nrou != es || !bytes(prop("consts"), &consts, &nconsts) || nconsts % es ||
         !bytes(prop("staticValues"), &svals, &nsvals) || !bytes(prop("firstRows"), &first, &nfirst) || !words("degrees", degrees) || !words("tCode", tcode) ||
         !words("iCode", icode) || !words("eCode", ecode) || !words("staticPeriods", periods) || !words("staticLens", lens32) || tcode.size() % 4 || icode.size() % 4 ||
-        ecode.size() % 4 || lens32.size() != periods.size() || nfirst != (segments ? segments : 1) * regs * 16) {
+        ecode.size() % 4 || lens32.size() != periods.size() || nfirst != (segments ? segments : 1) * regs * es) {
         napi_throw_type_error(env, nullptr, "proveGenericSerialized: malformed job");
         return nullptr;
     }
     std::vector<uint64_t> lens(lens32.begin(), lens32.end());
     job.steps = t; job.extension_factor = (uint32_t)ef; job.exe_query_count = (uint32_t)exe; job.fri_query_count = (uint32_t)fri; job.hash_alg = (int32_t)alg;
-    memcpy(job.root_of_unity, rou, 16);
+    memcpy(job.root_of_unity, rou, es);
     gs_prover_air &a = job.air;
     a.kind = 1; a.registers = (uint32_t)regs; a.nconstraints = (uint32_t)degrees.size(); a.degrees = degrees.data();
     a.t_code = tcode.data(); a.t_ninstr = (uint32_t)(tcode.size() / 4);
     a.i_code = icode.empty() ? nullptr : icode.data(); a.i_ninstr = (uint32_t)(icode.size() / 4);
     a.e_code = ecode.data(); a.e_ninstr = (uint32_t)(ecode.size() / 4);
-    a.consts = consts; a.nconsts = (uint32_t)(nconsts / 16); a.vm_regs = (uint32_t)vmregs;
+    a.consts = consts; a.nconsts = (uint32_t)(nconsts / es); a.vm_regs = (uint32_t)vmregs;
     a.static_values = svals; a.static_periods = periods.data(); a.nstatic = (uint32_t)periods.size();
     a.static_tables = (const void *)(uintptr_t)tables; a.static_lens = lens.data();
     a.first_rows = first; a.segments = segments; a.segment_len = seglen;
@@ -501,15 +507,15 @@ napi_value ProveGenericSerialized(napi_env env, napi_callback_info info) {
         napi_get_named_property(env, e, "register", &v);
         ok = ok && get_u64(env, v, &reg);
         napi_get_named_property(env, e, "value", &v);
-        ok = ok && bytes(v, &val, &nval) && nval == 16;
+        ok = ok && bytes(v, &val, &nval) && nval == es;
         if (!ok) { napi_throw_type_error(env, nullptr, "proveGenericSerialized: malformed assertion"); return nullptr; }
-        as[i].step = step; as[i].reg = (uint32_t)reg; memcpy(as[i].value, val, 16);
+        as[i].step = step; as[i].reg = (uint32_t)reg; memcpy(as[i].value, val, es);
     }
     job.assertions = as.data(); job.nassertions = na;
     std::vector<uint8_t> out(1 << 22);
     uint64_t n = 0;
     char err[512] = {0};
-    int rcode = ((provefn)dlsym(g_prover, "gs_prover_prove"))((gs_ctx *)ctx, &job, out.data(), out.size(), &n, err, sizeof err);
+    int rcode = ((prove_on_fn)dlsym(g_prover, "gs_prover_prove_on"))(g_binding, (gs_ctx *)ctx, &job, out.data(), out.size(), &n, err, sizeof err);
     if (rcode != GS_OK) { napi_throw_error(env, nullptr, (std::string("native prove() failed: ") + err).c_str()); return nullptr; }
     napi_value buf;
     NAPI_OK(env, napi_create_buffer_copy(env, (size_t)n, out.data(), nullptr, &buf));

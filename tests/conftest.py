@@ -66,3 +66,12 @@ def from_bytes(raw):
 @pytest.fixture
 def rng():
     return random.Random(0x4d694d43)
+
+
+def native_same_bytes(stark, assertions, inputs, seed, data):
+    """The product's native driver (csrc/prover.cc, the build for this field flavour, bound to this backend's ABI library) on the
+    statement a mirror Stark has just proved: the same serialized bytes."""
+    from genstark_amd.native import NativeProver
+    got = NativeProver(stark).prove_bytes(assertions, inputs, seed)
+    assert got == data, 'native driver and mirror disagree'
+    return got

@@ -33,8 +33,9 @@ for (const c of cases) {
     try { const bad = Buffer.from(bytes); bad[40] ^= 1; stark.verify(assertions, stark.parse(bad)); } catch (e) { tamperRejected = true; }
     // (init programs extend the transition program's pool in place: pools of a descriptor with an init program cannot be concatenated blindly,
     //  proveGenericSerialized checks)
-    const nativeBytes = wide ? null : generic ? proveGenericSerialized(stark.air, options, assertions, big(c.seed)) : proveMimcSerialized(new MimcAir(c.steps, c.extension_factor), options, assertions, BigInt(c.seed));   // the native driver is 128-bit only
-    out.push({ name: c.name, nativeDriverEqualsReference: wide ? null : Buffer.from(bytes).equals(nativeBytes), proofHex: bytes.toString('hex'), evRoot: proof.evRoot.toString('hex'), lcRoot: proof.ldProof.lcRoot.toString('hex'),
+    // ONE call of the native driver through the same addon: the build of libgstark_prover*.so for the loaded library's field (js/prover.js)
+    const nativeBytes = generic ? proveGenericSerialized(stark.air, options, assertions, big(c.seed)) : proveMimcSerialized(wide ? stark.air : new MimcAir(c.steps, c.extension_factor), options, assertions, BigInt(c.seed));
+    out.push({ name: c.name, nativeDriverEqualsReference: Buffer.from(bytes).equals(nativeBytes), proofHex: bytes.toString('hex'), evRoot: proof.evRoot.toString('hex'), lcRoot: proof.ldProof.lcRoot.toString('hex'),
                friLayers: proof.ldProof.components.length, remainderLength: proof.ldProof.remainder.length, verified: ok === true,
                tamperRejected, securityLevel: stark.securityLevel });
     console.log(c.name, bytes.byteLength, 'verified', ok, 'security', stark.securityLevel);

@@ -148,7 +148,8 @@ def test_prover_library_exports_its_header():
     header = os.path.join(ROOT, 'include', 'gstark_prover.h')
     subprocess.check_call(['gcc', '-fsyntax-only', '-x', 'c', '-std=c11', header])
     names = set(re.findall(r'^int\s+(gs_prover_\w+)\s*\(', open(header).read(), flags=re.M))
-    assert names == {'gs_prover_bind', 'gs_prover_prove', 'gs_prover_last_stats', 'gs_prover_remainder_check'}
+    assert names == {'gs_prover_bind', 'gs_prover_open', 'gs_prover_element_size', 'gs_prover_prove', 'gs_prover_prove_on', 'gs_prover_last_stats',
+                     'gs_prover_remainder_check', 'gs_prover_remainder_check_on'}
     if not os.path.exists(PROVER_LIB_PATH):
         pytest.skip('libgstark_prover.so not built')
     import shutil
@@ -162,3 +163,15 @@ def test_prover_library_exports_its_header():
     n = C.c_uint64()
     assert lib.gs_prover_prove(None, None, None, C.c_uint64(0), C.byref(n), None, C.c_uint64(0)) != 0
     assert lib.gs_prover_bind(None) != 0
+    assert lib.gs_prover_element_size() == 16
+    # one build of the driver per field flavour; each refuses an ABI library of another field (here: the 128-bit oracle)
+    from genstark_amd.native import PROVER_LIB_PATHS
+    from conftest import ORACLE_LIB
+    oracle = C.CDLL(ORACLE_LIB)
+    for modulus, path in PROVER_LIB_PATHS.items():
+        assert os.path.exists(path), f'{path}: run __graft_entry__.build() first'
+        drv = C.CDLL(path)
+        assert drv.gs_prover_element_size() == (16 if modulus < 2**128 else 32)
+        b = C.c_void_p()
+        rc = drv.gs_prover_open(C.c_void_p(oracle._handle), C.byref(b))
+        assert (rc == 0) == (modulus == P), (modulus, rc)

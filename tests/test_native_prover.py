@@ -199,16 +199,14 @@ def test_remainder_check_forms_agree(oracle_backend):
     from genstark_amd._mirror.components.low_degree_prover import LowDegreeProver
     from genstark_amd.errors import StarkError
     f = PrimeField(backend=oracle_backend)
-    lib = _driver(oracle_backend)
-    lib.gs_prover_remainder_check.restype = C.c_int
-    lib.gs_prover_remainder_check.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_char_p, C.c_int]
+    lib, binding = _driver(oracle_backend)
     rng = random.Random(20260927)
     p = f.modulus
 
     def verdicts(values, ef, m, rou):
         raw = b''.join(v.to_bytes(16, 'little') for v in values)
         r = rou.to_bytes(16, 'little')
-        return [lib.gs_prover_remainder_check(raw, len(values), ef, m, r, method) for method in (0, 1)]
+        return [lib.gs_prover_remainder_check_on(binding, raw, len(values), ef, m, r, method) for method in (0, 1)]
 
     def mirror(values, ef, m, rou):
         ldp = LowDegreeProver.__new__(LowDegreeProver)

@@ -105,6 +105,7 @@ def test_reference_stark_js_runs_live_over_another_field(name, tmp_path):
     rec = json.loads(cout.read_text())[0]
     assert rec['verified'] and rec['tamperRejected']
     assert rec['proofHex'] == want.hex()
+    assert rec['nativeDriverEqualsReference'] is True       # the native driver's build for this field, one N-API call (js/prover.js)
 
 
 # ---- AIRs given as register-machine programs: Rescue 4x128 / Poseidon 6x128 through instantiate({generic: descriptor}) ----------

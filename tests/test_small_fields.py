@@ -8,7 +8,7 @@ import random
 
 import pytest
 
-from conftest import ROOT, _build_oracle
+from conftest import ROOT, _build_oracle, native_same_bytes
 from genstark_amd._abi import HIP_LIB_PATHS, MODULUS_17, MODULUS_32, MODULUS_64, Backend
 from genstark_amd.air_generic import GenericAir
 from genstark_amd.errors import StarkError
@@ -112,6 +112,7 @@ def check_starks(backend, name):
         assert hv.verify(assertions, hv.parse(data))
         with pytest.raises(StarkError):
             stark.verify([assertions[0], dict(assertions[1], value=781)], stark.parse(data))
+        native_same_bytes(stark, assertions, [], [1], data)
         out.append(data)
     elif name == 'q32':
         air = foo_air(f)                                                     # README.md:17-60, its own field
@@ -123,6 +124,7 @@ def check_starks(backend, name):
         assert len(data) == stark.sizeOf(proof) and stark.verify(assertions, stark.parse(data))
         hv = Stark(foo_air(HostField(q)), None)
         assert hv.verify(assertions, hv.parse(data))
+        native_same_bytes(stark, assertions, [], [1], data)                  # BASELINE configs[0] (Foo) through the native driver's q32 build
         out.append(data)
         steps = 2**6
         air = fibonacci_air(f, steps)
@@ -139,6 +141,7 @@ def check_starks(backend, name):
         assert stark.verify(assertions, stark.parse(data))
         with pytest.raises(StarkError):
             stark.verify(assertions[:2] + [dict(assertions[2], value=FIBONACCI[steps] - 1)], stark.parse(data))
+        native_same_bytes(stark, assertions, [], [1, 1], data)
         out.append(data)
     else:
         air = rescue2x64_air(32, 16, f)
@@ -156,6 +159,7 @@ def check_starks(backend, name):
         assert hv.verify(assertions, hv.parse(data))
         with pytest.raises(StarkError):
             stark.prove([{'step': 31, 'register': 0, 'value': RESCUE_2X64_DIGEST - 1}], [], [42])
+        native_same_bytes(stark, assertions, [], [42], data)                 # hash2x64.ts through the native driver's q64 build
         out.append(data)
         air = rescue2x64_air(256, 16, f)                                     # longer chain: more FRI layers
         full = air.hostTrace([42])
@@ -163,6 +167,7 @@ def check_starks(backend, name):
         assertions = [{'step': 31, 'register': 0, 'value': RESCUE_2X64_DIGEST}, {'step': 255, 'register': 1, 'value': full[255][1]}]
         data = stark.serialize(stark.prove(assertions, [], [42]))
         assert stark.verify(assertions, stark.parse(data))
+        native_same_bytes(stark, assertions, [], [42], data)
         out.append(data)
     return out
 

@@ -8,7 +8,7 @@ import os
 
 import pytest
 
-from conftest import ROOT, _build_oracle
+from conftest import ROOT, _build_oracle, native_same_bytes
 from genstark_amd._abi import MODULUS_224, MODULUS_256, Backend
 from genstark_amd.air import MimcAir, runMimc
 from genstark_amd.air_generic import GenericAir
@@ -57,6 +57,7 @@ def check_point_mul(backend):
     assert len(data) == stark.sizeOf(proof) and stark.verify(assertions, stark.parse(data))
     hv = Stark(point_mul_air(HostField(MODULUS_224)), EC_OPTIONS)
     assert hv.verify(assertions, hv.parse(data))
+    native_same_bytes(stark, assertions, inputs, seeds, data)
     with pytest.raises(StarkError):
         stark.verify([assertions[0], dict(assertions[1], value=EC_PRODUCT[1] ^ 1)], stark.parse(data))
     # two multiplications in one trace (two device threads), the second by another scalar
@@ -111,6 +112,7 @@ def check_starks(backend, name, steps=2**7):
         stark.verify([assertions[0], dict(assertions[1], value=(control[-1] + 1) % q)], stark.parse(data))
     with pytest.raises(StarkError):
         stark.prove([assertions[0], dict(assertions[1], value=(control[-1] + 1) % q)], [], [3])
+    native_same_bytes(stark, assertions, [], [3], data)                      # the native driver's build for this field (README.md:213-214 rows)
     out.append(data)
     # generic AIR (register machine) over the wide field, sha256 leaves
     air = quintic_air(f, 64)
@@ -123,6 +125,7 @@ def check_starks(backend, name, steps=2**7):
     assert stark.verify(assertions, stark.parse(data))
     hv = Stark(quintic_air(HostField(q), 64), {'hashAlgorithm': 'sha256', 'extensionFactor': 16, 'exeQueryCount': 30, 'friQueryCount': 16})
     assert hv.verify(assertions, hv.parse(data))
+    native_same_bytes(stark, assertions, [], [5, 9], data)
     out.append(data)
     return out
 
@@ -160,6 +163,31 @@ def test_wide_field_hip(name):
     # a size where the NTT runs its multi-pass radix-256 path and the Merkle tree its streaming levels
     big = check_starks(hip, name, steps=2**12)
     assert len(big) == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('log_steps', [13, 17])
+def test_native_driver_mimc256_at_the_readme_sizes(log_steps):
+    """MiMC over the 256-bit field at the two sizes the reference's README publishes for it (README.md:213-214; mimc256.ts options)
+    through the PRODUCT entry — genstark_amd.prover.Prover = the native driver's p256 build on the HIP p256 library: bytes of the mirror
+    on the same device, of the oracle flavour at 2^13 steps, and the GPU-free verifier accepts them."""
+    from genstark_amd.prover import Prover
+    steps = 1 << log_steps
+    hip = hip_for('p256')
+    f = PrimeField(backend=hip)
+    air = MimcAir(steps, 16, f)
+    last = air.initProvingContext([], [3]).generateExecutionTrace().getValue(0, steps - 1)
+    assertions = [{'step': 0, 'register': 0, 'value': 3}, {'step': steps - 1, 'register': 0, 'value': last}]
+    data = Prover(air, MIMC256_OPTIONS).prove_bytes(assertions, [], [3])
+    mirror = Stark(air, MIMC256_OPTIONS)
+    assert data == mirror.serialize(mirror.prove(assertions, [], [3]))
+    if log_steps == 13:
+        fo = PrimeField(backend=oracle_for('p256'))
+        assert data == Prover(MimcAir(steps, 16, fo), MIMC256_OPTIONS).prove_bytes(assertions, [], [3])
+        hv = Stark(MimcAir(steps, 16, HostField(MODULUS_256)), MIMC256_OPTIONS)
+        assert hv.verify(assertions, hv.parse(data))
+    else:
+        assert mirror.verify(assertions, mirror.parse(data))
 
 
 @pytest.mark.gpu
