@@ -301,6 +301,7 @@ def main():
     ap.add_argument('--fri-queries', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-pmc', action='store_true', help='skip the rocprofv3 child process that measures roofline.traffic')
+    ap.add_argument('--no-configs', action='store_true', help='skip the per-configuration runs (tools/config_runs.py: every BASELINE.json config, N = 1 only)')
     ap.add_argument('--sharded-leg-timeout', type=float, default=150.0,
                     help='N > 1 only: seconds allowed for the one-proof-across-all-ranks measurements (0 = skip them: replicas only)')
     ap.add_argument('--c4-log-trace', type=int, default=16, help='N > 1 only: log2 steps of the Poseidon 6-register proof across the ranks (0 = skip)')
@@ -491,6 +492,38 @@ def main():
 
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(ga, ef, fri, gpu_digest)
 
+        # ---- every BASELINE.json configuration through the product entry (compiled programs, packed seeds), driver-run: wall-clock per
+        # proof, device-busy time and launches per proof (rocprofv3 --kernel-trace of a second child), the reference's own phase log
+        # with device-synchronised times.  Child processes of this run (tools/config_runs.py); N = 1 only
+        configs = None
+        if not args.no_configs and world == 1:
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'config_runs.py')], capture_output=True, text=True, timeout=600)
+                configs = json.loads([l for l in r.stdout.splitlines() if l.startswith('[')][-1])
+            except Exception as e:   # noqa: BLE001
+                configs = [{'error': repr(e)[:300]}]
+        # the kernel that dominates the PROOF (the NTT pass above dominates the transform metric, not the proof): from the C5 run
+        c5 = next((c for c in (configs or []) if c.get('name') == 'C5' and c.get('dominant_kernel')), None)
+        if c5 is not None:
+            ms_k = c5['dominant_kernel_ms_per_proof']
+            fused_leaves = 'k_merkle_fused<1, 1>' in c5['dominant_kernel']
+            comp = n * 1.875 if fused_leaves else None        # 2^24 leaf hashes + the three node layers above them in the same launch
+            roofline['proof_dominant_kernel'] = {
+                'kernel': c5['dominant_kernel'], 'ms_per_proof': ms_k, 'share_of_device_busy_time': c5['dominant_share'],
+                'device_busy_ms_per_proof': c5['device_busy_ms'],
+                'what': 'evaluation-tree commitment: mergeVectorRows + the first three node layers in one launch (lib/Stark.ts:113-118)' if fused_leaves else None,
+                'bound': 'blake2s compression issue rate (39.5 G compressions/s chip-wide, tools/microbench_hash.hip), not HBM',
+                'compressions_per_sec': None if comp is None else round(comp / (ms_k * 1e-3), 1),
+                'frac_of_compression_roof': None if comp is None else round(comp / (ms_k * 1e-3) / 39.5e9, 4),
+                'algorithmic_GBs': None if comp is None else round(n * (16 + 32 + 28) / (ms_k * 1e-3) / 1e9, 1),
+                'frac_of_hbm_peak': None if comp is None else round(n * (16 + 32 + 28) / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # the reference's phase vocabulary for the headline proof (README.md:62-73; lib/Stark.ts:92-152), device-synchronised
+        prover.sync_phases(True)
+        prover.prove_bytes(a, [], [seed])
+        phases_readme = prover.last_stats().get('phases_readme')
+        prover.sync_phases(False)
+
         # ---- extra leg (reported beside `value`, never as `value`): throughput of a proving service that keeps several
         # independent proofs in flight on this GPU (genstark_amd/pipeline.py); every proof runs the unmodified prove()
         pipelined = None
@@ -521,6 +554,11 @@ def main():
                        'ntt_points_source': 'gs_prover_last_stats: rows * n of every transform the timed driver launched', 'proof_bytes': len(data)},
             'prove_ms': ms_per_step, 'per_step_ms': step_ms, 'python_mirror_prove_ms': mirror_ms, 'phases_ms': phases, 'phases_source': 'native driver clock, last timed step', 'driver_total_ms': driver_total_ms, 'roofline': roofline, 'cpu_baseline': cpu,
             'pipelined': pipelined,
+            'phases_readme': {'ms': phases_readme, 'total_ms': None if not phases_readme else round(sum(m for _, m in phases_readme), 4),
+                              'note': 'the reference\'s own log points (README.md:62-73, lib/Stark.ts:92-152) on ONE extra proof of the headline statement '
+                                      'with the device synchronised at each of them (gs_prover_sync_phases): each entry is that phase alone; the timed '
+                                      'proofs above run asynchronously and overlap them (phases_ms)'},
+            'configs': configs,
         }
     # ---- N > 1.  `value` stays the BASELINE metric on the BASELINE workload with one independent MiMC-128 proof per GPU (weak
     # scaling, no data-path collective: a single MiMC proof is bounded by the serial trace recurrence of its one register, SURVEY 8e

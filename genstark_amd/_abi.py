@@ -81,6 +81,8 @@ _SIGNATURES = {
     'gs_pluck': (_int, [_vp, _vp, _u64, _u64, _u64, _vp]),
     'gs_zero_poly_inverses': (_int, [_vp, _bytes, _u64, _u64, _bytes, _vp]),
     'gs_div_by_domain_roots': (_int, [_vp, _vp, _u32, _u64, _bytes, C.POINTER(_u64), C.POINTER(_u32), _u32, _vp]),
+    'gs_zero_poly_inverses_coset': (_int, [_vp, _bytes, _u64, _bytes, _u64, _bytes, _vp]),
+    'gs_div_by_domain_roots_coset': (_int, [_vp, _vp, _u32, _u64, _bytes, _bytes, C.POINTER(_u64), C.POINTER(_u32), _u32, _vp]),
     'gs_transpose_vector': (_int, [_vp, _vp, _u64, _u32, _u64, _vp]),
     'gs_transpose_matrix': (_int, [_vp, _vp, _u64, _u64, _vp]),
     'gs_sub_matrix_from_vectors': (_int, [_vp, _pvp, _vp, _u32, _u64, _vp]),

@@ -144,3 +144,4 @@ int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const u
 void gs_plans_destroy(gs_ctx *c);
 int gs_plan_pow_tables(gs_ctx *c, const fe &omega, uint64_t n, const fe **tw_lo, const fe **tw_hi, int *log_lo);
 int gs_plan_inverse_table(gs_ctx *c, const fe &omega, uint64_t n, const fe **u);   // 1 / (omega^j - 1), cached with the plan
+int gs_plan_inverse_table_shifted(gs_ctx *c, const fe &omega, uint64_t n, const fe &shift, const fe **u);   // 1 / (shift * omega^j - 1)

@@ -42,6 +42,7 @@ struct NttPlan {
     fe *twp[4] = {nullptr, nullptr, nullptr, nullptr}; // inter-pass twiddles omega_{Ns*R}^(jq*k) as a [k][jq] table (passes >= 1, when small)
     fe w16[8];                                         // omega_16^i
     fe *inv_table = nullptr;                           // 1 / (omega^j - 1), j < n, [0] = 0 (built on first use: gs_plan_inverse_table)
+    std::map<std::string, fe *> inv_table_shifted;     // 1 / (shift * omega^j - 1) per shift != 1 (gs_plan_inverse_table_shifted: a rank's coset)
 #ifdef GS_NTT_LAZY
     lzw *wtab = nullptr;                               // device: W-forms of omega_16^1..7 and of 1/n (read with scalar loads)
     lz8 *wRz[4] = {nullptr, nullptr, nullptr, nullptr};   // wR[i] * 2^130 as NN limbs (signed digits): the multipliers of lz_mul_vm
@@ -859,9 +860,12 @@ int gs_plan_pow_tables(gs_ctx *c, const fe &omega, uint64_t n, const fe **tw_lo,
 }
 
 __global__ void k_omega_minus_one(const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn, uint64_t n,
-                                  fe *__restrict__ out) {
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        out[i] = fe_sub(pow_lookup(tw_lo, tw_hi, log_lo, logn, i), fe_one());
+                                  fe shift, int has_shift, fe *__restrict__ out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        fe x = pow_lookup(tw_lo, tw_hi, log_lo, logn, i);
+        if (has_shift) x = fe_mul(x, shift);
+        out[i] = fe_sub(x, fe_one());
+    }
 }
 
 int gs_vec_inv_dev(gs_ctx *c, const fe *a, uint64_t n, fe *out);   // pointwise.hip
@@ -877,13 +881,35 @@ int gs_plan_inverse_table(gs_ctx *c, const fe &omega, uint64_t n, const fe **u) 
         void *q = nullptr, *t = nullptr;
         if ((rc = gs_alloc(c, n * GS_ELT, &q))) return rc;
         if ((rc = gs_tmp_alloc(c, n * GS_ELT, &t))) { gs_free(c, q); return rc; }
-        hipLaunchKernelGGL(k_omega_minus_one, dim3(gs_grid(n)), dim3(256), 0, c->stream, p->tw_lo, p->tw_hi, p->log_lo, p->logn, n, (fe *)t);
+        hipLaunchKernelGGL(k_omega_minus_one, dim3(gs_grid(n)), dim3(256), 0, c->stream, p->tw_lo, p->tw_hi, p->log_lo, p->logn, n, fe_one(), 0, (fe *)t);
         rc = gs_vec_inv_dev(c, (const fe *)t, n, (fe *)q);
         gs_tmp_free(c, t);
         if (rc) { gs_free(c, q); return rc; }
         p->inv_table = (fe *)q;
     }
     *u = p->inv_table;
+    return GS_OK;
+}
+// u_s[j] = 1 / (shift * omega^j - 1): the same table for the coset {shift * omega^j} (one rank's share of a larger domain; shift != 1
+// is not a power of omega there, so no entry is zero); cached per shift with the plan of (omega, n)
+int gs_plan_inverse_table_shifted(gs_ctx *c, const fe &omega, uint64_t n, const fe &shift, const fe **u) {
+    if (fe_eq(shift, fe_one())) return gs_plan_inverse_table(c, omega, n, u);
+    NttPlan *p;
+    int rc = plan_get(c, omega, n, &p);
+    if (rc) return rc;
+    const std::string key = plan_key(shift, 0);
+    auto it = p->inv_table_shifted.find(key);
+    if (it == p->inv_table_shifted.end()) {
+        void *q = nullptr, *t = nullptr;
+        if ((rc = gs_alloc(c, n * GS_ELT, &q))) return rc;
+        if ((rc = gs_tmp_alloc(c, n * GS_ELT, &t))) { gs_free(c, q); return rc; }
+        hipLaunchKernelGGL(k_omega_minus_one, dim3(gs_grid(n)), dim3(256), 0, c->stream, p->tw_lo, p->tw_hi, p->log_lo, p->logn, n, shift, 1, (fe *)t);
+        rc = gs_vec_inv_dev(c, (const fe *)t, n, (fe *)q);
+        gs_tmp_free(c, t);
+        if (rc) { gs_free(c, q); return rc; }
+        it = p->inv_table_shifted.emplace(key, (fe *)q).first;
+    }
+    *u = it->second;
     return GS_OK;
 }
 

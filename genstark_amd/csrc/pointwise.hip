@@ -196,13 +196,14 @@ int gs_vec_inv_dev(gs_ctx *c, const fe *a, uint64_t n, fe *out) { return launch_
 #define GS_ZPOLY_MAX_PERIOD 32
 struct ZTable { fe c[GS_ZPOLY_MAX_PERIOD]; };
 __global__ void k_zero_poly_inverses(const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn, uint64_t n, ZTable tab,
-                                     uint32_t period, fe x_last, fe *__restrict__ out) {
+                                     uint32_t period, fe x_last, fe shift, int has_shift, fe *__restrict__ out) {
     __shared__ fe c[GS_ZPOLY_MAX_PERIOD];
     if (threadIdx.x < period) c[threadIdx.x] = tab.c[threadIdx.x];
     __syncthreads();
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         fe x = tw_lo[i & ((1ull << log_lo) - 1)];
         if (logn > log_lo) x = fe_mul(x, tw_hi[i >> log_lo]);
+        if (has_shift) x = fe_mul(x, shift);                       // a coset of the domain (wave-uniform flag)
         out[i] = fe_mul(fe_sub(x, x_last), c[i & (period - 1)]);
     }
 }
@@ -562,8 +563,15 @@ int gs_combine(gs_ctx *c, const void *a, const void *b, uint64_t n, gs_elt *out_
 }
 
 int gs_zero_poly_inverses(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t steps, const gs_elt *x_last, void *out) {
-    if (!c || !omega || !x_last || !out) return GS_ERR_ARG;
+    uint8_t one[sizeof(fe)];
+    fe_to_bytes(one, fe_one());
+    return gs_zero_poly_inverses_coset(c, omega, n, one, steps, x_last, out);
+}
+int gs_zero_poly_inverses_coset(gs_ctx *c, const gs_elt *omega, uint64_t n, const gs_elt *shift_bytes, uint64_t steps, const gs_elt *x_last, void *out) {
+    if (!c || !omega || !shift_bytes || !x_last || !out) return GS_ERR_ARG;
     if (!gs_is_pow2(n) || !gs_is_pow2(steps) || steps > n) return gs_fail(c, GS_ERR_ARG, "zero_poly_inverses: n and steps must be powers of two, steps <= n");
+    const fe shift = fe_from_bytes(shift_bytes);
+    const int has_shift = fe_eq(shift, fe_one()) ? 0 : 1;
     const uint64_t period = n / steps;
     if (period > GS_ZPOLY_MAX_PERIOD) return gs_fail(c, GS_ERR_UNSUPPORTED, "zero_poly_inverses: n / steps above %d", GS_ZPOLY_MAX_PERIOD);
     const fe w = fe_from_bytes(omega);
@@ -572,21 +580,27 @@ int gs_zero_poly_inverses(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t s
     int rc = gs_plan_pow_tables(c, w, n, &lo, &hi, &log_lo);      // also checks that omega is a primitive n-th root of unity
     if (rc) return rc;
     ZTable tab;
-    const fe g = fe_pow_u64(w, steps);                            // omega^(i*steps) = g^(i mod period)
-    fe cur = fe_one();
+    const fe g = fe_pow_u64(w, steps);                            // x_i^steps = shift^steps * g^(i mod period)
+    fe cur = fe_pow_u64(shift, steps);
     for (uint64_t j = 0; j < GS_ZPOLY_MAX_PERIOD; j++) {
         tab.c[j] = j < period ? fe_inv(fe_sub(cur, fe_one())) : fe_zero();     // j = 0: 0^-1 = 0
         cur = fe_mul(cur, g);
     }
     hipLaunchKernelGGL(k_zero_poly_inverses, dim3(gs_grid(n)), dim3(256), 0, c->stream, lo, hi, log_lo, gs_log2(n), n, tab, (uint32_t)period,
-                       fe_from_bytes(x_last), (fe *)out);
+                       fe_from_bytes(x_last), shift, has_shift, (fe *)out);
     GS_LAUNCH_CHECK(c);
     return GS_OK;
 }
 
 int gs_div_by_domain_roots(gs_ctx *c, const void *num, uint32_t rows, uint64_t n, const gs_elt *omega, const uint64_t *root_index_host,
                            const uint32_t *roots_per_row_host, uint32_t max_roots, void *out) {
-    if (!c || !num || !omega || !out || !roots_per_row_host || (max_roots && !root_index_host)) return GS_ERR_ARG;
+    uint8_t one[sizeof(fe)];
+    fe_to_bytes(one, fe_one());
+    return gs_div_by_domain_roots_coset(c, num, rows, n, omega, one, root_index_host, roots_per_row_host, max_roots, out);
+}
+int gs_div_by_domain_roots_coset(gs_ctx *c, const void *num, uint32_t rows, uint64_t n, const gs_elt *omega, const gs_elt *shift_bytes,
+                                 const uint64_t *root_index_host, const uint32_t *roots_per_row_host, uint32_t max_roots, void *out) {
+    if (!c || !num || !omega || !shift_bytes || !out || !roots_per_row_host || (max_roots && !root_index_host)) return GS_ERR_ARG;
     if (!gs_is_pow2(n)) return gs_fail(c, GS_ERR_ARG, "div_by_domain_roots: n must be a power of two");
     if (!rows) return GS_OK;
     for (uint32_t r = 0; r < rows; r++)
@@ -594,7 +608,7 @@ int gs_div_by_domain_roots(gs_ctx *c, const void *num, uint32_t rows, uint64_t n
             return gs_fail(c, GS_ERR_UNSUPPORTED, "div_by_domain_roots: at most %d roots per row", GS_DOMAIN_ROOTS_MAX);
     const fe w = fe_from_bytes(omega);
     const fe *u;
-    int rc = gs_plan_inverse_table(c, w, n, &u);
+    int rc = gs_plan_inverse_table_shifted(c, w, n, fe_from_bytes(shift_bytes), &u);      // (the unshifted table when shift = 1)
     if (rc) return rc;
     for (uint32_t r = 0; r < rows; r++) {
         RootArgs ra;

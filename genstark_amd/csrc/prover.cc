@@ -44,7 +44,7 @@ namespace {
     X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_commit_rows) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
     X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
     X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end) X(gs_readback_post) X(gs_readback_wait) X(gs_merkle_commit_rows_seed) X(gs_fri_fold_at) \
-    X(gs_vec_mul_scalar) X(gs_copy) X(gs_gather_words) X(gs_transpose_records) X(gs_fri_fold_seeded_scaled) X(gs_fri_layers)
+    X(gs_vec_mul_scalar) X(gs_copy) X(gs_gather_words) X(gs_transpose_records) X(gs_fri_fold_seeded_scaled) X(gs_fri_layers) X(gs_sync) X(gs_zero_poly_inverses_coset) X(gs_div_by_domain_roots_coset)
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
     GS_API_LIST(X)
@@ -295,6 +295,7 @@ std::vector<uint64_t> unique_in_order(const std::vector<uint64_t> &v) {
 // What the last prove() on this thread did: wall-clock of the phases (host clock at the phase boundaries; no device
 // synchronisation is added, so a phase lasts until its last BLOCKING call returned) and the transform work it launched.
 static thread_local gs_prover_stats g_stats;
+static thread_local bool g_sync_phases = false;      // gs_prover_sync_phases
 
 // the two transform entry points, counted: rows * n points per call.  The library serves a transform of fewer than 256 points
 // or of a polynomial of at most 8 coefficients with a Horner kernel (ntt.hip: ntt_run), which is not an NTT: counted apart.
@@ -408,6 +409,8 @@ static int remainder_check_entry(const uint8_t *values, uint64_t len, uint32_t e
     }
 }
 
+void gs_prover_sync_phases(int on) { g_sync_phases = on != 0; }
+
 int gs_prover_last_stats(struct gs_prover_stats *out) {
     if (!out) return GS_ERR_ARG;
     *out = g_stats;
@@ -433,8 +436,24 @@ struct Layer {           // one FRI layer: the tree / rows it queries and the ch
 // shows the time until its last BLOCKING call returned)
 struct PhaseClock {
     bool on = getenv("GSTARK_PROVER_TIMING") != nullptr;      // also echo the marks on stderr
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    const bool sync = g_sync_phases;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0, last_readme = t0;
     PhaseClock() { memset(&g_stats, 0, sizeof g_stats); }
+    // one of the reference's log points (lib/Stark.ts:92-152; README.md:62-73).  Measuring mode only (gs_prover_sync_phases): the
+    // device is drained here, so the entry is this phase's own wall-clock
+    void readme(Ctx &x, const char *fmt, ...) {
+        if (!sync) return;
+        x.check(A.gs_sync(x.c), "gs_sync");
+        auto now = std::chrono::steady_clock::now();
+        if (g_stats.nreadme < GS_PROVER_MAX_PHASES) {
+            va_list ap;
+            va_start(ap, fmt);
+            vsnprintf(g_stats.readme_label[g_stats.nreadme], sizeof g_stats.readme_label[0], fmt, ap);
+            va_end(ap);
+            g_stats.readme_ms[g_stats.nreadme++] = std::chrono::duration<double, std::milli>(now - last_readme).count();
+        }
+        last_readme = now;
+    }
     void mark(const char *what) {
         auto now = std::chrono::steady_clock::now();
         const double total = std::chrono::duration<double, std::milli>(now - t0).count();
@@ -595,6 +614,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     }
 
     clock.mark("context + trace-independent work issued");
+    clock.readme(x, "Set up evaluation context");
     // 2 ----- execution trace (:97) and the assertions it must satisfy (:356-375)
     Buf trace(x, (uint64_t)R * T * ELEM);
     if (air.kind == 0)
@@ -616,12 +636,15 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     }
 
     clock.mark("execution trace (host recurrence)");
+    clock.readme(x, "Generated execution trace");
     // 3 ----- P(x) and its low-degree extension (:106-109)
     Buf pPolys(x, (uint64_t)R * T * ELEM), pEval(x, (uint64_t)R * N * ELEM);
     le16(exec_rou, s16);
     x.check(counted_interpolate_roots(x.c, trace.p, R, s16, T, pPolys.p), "gs_interpolate_roots(trace)");
+    clock.readme(x, "Computed execution trace polynomials P(x)");
     le16(omega, s16);
     x.check(counted_eval_polys_at_roots(x.c, pPolys.p, R, T, s16, N, pEval.p), "gs_eval_polys_at_roots(P)");
+    clock.readme(x, "Low-degree extended P(x) polynomials over evaluation domain");
     std::vector<const void *> pRows(R);
     for (uint32_t r = 0; r < R; r++) pRows[r] = pEval.at((uint64_t)r * N * ELEM);
     std::vector<const void *> eVectors(pRows);                    // [P_0.., S_0..] (lib/Stark.ts:113-114)
@@ -632,6 +655,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     Tree eTree = commit_rows(x, alg, eVectors.data(), V, N, false);
 
     clock.mark("P(x), extension, evaluation tree issued");
+    clock.readme(x, "Serialized evaluations of P(x) and S(x) polynomials + Built evaluation merkle tree (one fused call)");
     // 5 ----- composition polynomial (CompositionPolynomial.ts:29-146)
     // boundary constraints per asserted register, in order of first appearance (BoundaryConstraints.ts:15-45)
     struct RegData { uint32_t reg; std::vector<F> xs, ys; std::vector<uint64_t> at; };   // at: positions of the xs in the evaluation domain
@@ -834,6 +858,8 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     }
     if (!fused) zInverses.release();
 
+    clock.readme(x, lc_fused ? "Computed composition polynomial C(x) + Combined P(x) and S(x) evaluations with C(x) evaluations (one kernel)"
+                            : "Computed composition polynomial C(x)");
     // 6 ----- random linear combination (LinearCombination.ts:36-64)
     Buf lEval;
     if (lc_fused) {
@@ -851,6 +877,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     cEval.release();
     psbPowers.release();
 
+    if (!lc_fused) clock.readme(x, "Combined P(x) and S(x) evaluations with C(x) evaluations");
     clock.mark("composition + LC issued (root read inside)");
     // 7 ----- low-degree proof (LowDegreeProver.ts:39-68, 176-221)
     if (N < 128) fail(GS_ERR_ARG, "Invalid array length");
@@ -910,6 +937,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     }
     if (layers.size() > 60) fail(GS_ERR_ARG, "too many FRI components");
     clock.mark("FRI layers issued");
+    clock.readme(x, "Computed low-degree proof: %zu FRI layers folded and committed", layers.size());
     // Everything the proof reads back — the queried rows and their batch proofs of every tree, the remainder (:179-187: the natural-
     // order vector the last polyValues came from) — is requested in ONE deferral window; the requests are planned root by root as
     // the roots arrive, the window closes with the single synchronisation of the proof
@@ -973,6 +1001,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
             fail(GS_ERR_ARG, "Low degree proof failed: Remainder is not a valid degree %llu polynomial", (unsigned long long)(max_degree_plus1 - 1));
     }
     clock.mark("remainder checked");
+    clock.readme(x, "Computed low-degree proof: query answers + Computed %zu evaluation spot checks (one read-back), remainder verified", exe_positions.size());
     if (V > 1) {
         evProof.value_size = (uint64_t)V * ELEM;
         evProof.nvalues = (uint32_t)aug.size();
@@ -1000,6 +1029,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     for (F v : remainder) { uint8_t b[ELEM]; le16(v, b); out.insert(out.end(), b, b + ELEM); }
     out.push_back(0);    // no input shapes (iShapes = [])
     clock.mark("serialized");
+    clock.readme(x, "Proof serialized");
 }
 
 // ---- one proof across several GPUs (same helpers, same coefficient streams, same wire format)

@@ -47,7 +47,8 @@ class _Job(C.Structure):
 
 class _Stats(C.Structure):
     _fields_ = [('ntt_points', C.c_uint64), ('ntt_transforms', C.c_uint64), ('horner_points', C.c_uint64), ('nphases', C.c_uint32),
-                ('total_ms', C.c_double), ('phase_ms', C.c_double * 16), ('phase_label', (C.c_char * 48) * 16)]
+                ('total_ms', C.c_double), ('phase_ms', C.c_double * 16), ('phase_label', (C.c_char * 48) * 16),
+                ('nreadme', C.c_uint32), ('readme_ms', C.c_double * 16), ('readme_label', (C.c_char * 160) * 16)]
 
 
 class GsComm(C.Structure):
@@ -87,6 +88,8 @@ def _driver(backend):
             lib.gs_prover_prove_on.restype = C.c_int
             lib.gs_prover_last_stats.argtypes = [C.POINTER(_Stats)]
             lib.gs_prover_last_stats.restype = C.c_int
+            lib.gs_prover_sync_phases.argtypes = [C.c_int]
+            lib.gs_prover_sync_phases.restype = None
             lib.gs_prover_prove_dist_on.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Job), C.POINTER(GsComm), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
             lib.gs_prover_prove_dist_on.restype = C.c_int
             lib.gs_prover_last_collectives.argtypes = [C.POINTER(_Collective), C.c_uint32, C.POINTER(C.c_uint32)]
@@ -270,8 +273,17 @@ class NativeProver:
         phases = {}
         for i in range(st.nphases):
             phases[bytes(st.phase_label[i]).split(b'\0', 1)[0].decode()] = round(st.phase_ms[i], 4)
-        return {'total_ms': round(st.total_ms, 4), 'phases_ms': phases, 'ntt_points': int(st.ntt_points),
-                'ntt_transforms': int(st.ntt_transforms), 'horner_points': int(st.horner_points)}
+        out = {'total_ms': round(st.total_ms, 4), 'phases_ms': phases, 'ntt_points': int(st.ntt_points),
+               'ntt_transforms': int(st.ntt_transforms), 'horner_points': int(st.horner_points)}
+        if st.nreadme:       # a proof that ran under sync_phases(True): the reference's own phase log (lib/Stark.ts:92-152; README.md:62-73)
+            out['phases_readme'] = [(bytes(st.readme_label[i]).split(b'\0', 1)[0].decode(), round(st.readme_ms[i], 4)) for i in range(st.nreadme)]
+        return out
+
+    def sync_phases(self, on=True):
+        """Measuring mode for the proofs this THREAD issues next: the device is synchronised at each of the reference's log points, so
+        last_stats()['phases_readme'] lists every phase of README.md:62-73 with its own wall-clock.  Same proof bytes."""
+        self.lib.gs_prover_sync_phases(1 if on else 0)
+        return self
 
     def last_collectives(self):
         """The collectives the last distributed prove_bytes() on this thread issued: [{'label', 'kind', 'bytes', 'ms'}] (ms: device

@@ -62,6 +62,11 @@ class Prover:
     def last_stats(self):
         return self._native.last_stats()
 
+    def sync_phases(self, on=True):
+        """Measuring mode (this thread's next proofs): last_stats()['phases_readme'] = the reference's own phase log with device-synchronised times."""
+        self._native.sync_phases(on)
+        return self
+
     def last_collectives(self):
         return self._native.last_collectives()
 

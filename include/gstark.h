@@ -166,6 +166,15 @@ int gs_zero_poly_inverses(gs_ctx *ctx, const gs_elt *omega, uint64_t n, uint64_t
  * use the general members).  The library keeps the table 1/(omega^j - 1) of the domain with its transform plan. */
 int gs_div_by_domain_roots(gs_ctx *ctx, const void *num, uint32_t rows, uint64_t n, const gs_elt *omega,
                            const uint64_t *root_index_host, const uint32_t *roots_per_row_host, uint32_t max_roots, void *out);
+/* The same two over a COSET of a domain: point i is shift * w^i, i < m, w a primitive m-th root of unity — what ONE RANK of a proof
+ * spread over several GPUs holds of the evaluation domain (csrc/prover_dist.h: w = omega^ranks, shift = omega^rank).  At shift = 1
+ * they are the two functions above.
+ *   gs_zero_poly_inverses_coset:  out[i] = (x_i - x_last) / (x_i^steps - 1),  x_i^steps takes m / steps (<= 32) values: a table again
+ *   gs_div_by_domain_roots_coset: out[r][i] = num[r][i] / prod_a (x_i - w^k_a): the roots are powers of w (NOT shifted), so each factor
+ *     is w^-k * u_s[(i - k) mod m] with u_s[j] = 1 / (shift * w^j - 1) — one table per (w, m, shift), cached with the transform plan */
+int gs_zero_poly_inverses_coset(gs_ctx *ctx, const gs_elt *w, uint64_t m, const gs_elt *shift, uint64_t steps, const gs_elt *x_last, void *out);
+int gs_div_by_domain_roots_coset(gs_ctx *ctx, const void *num, uint32_t rows, uint64_t m, const gs_elt *w, const gs_elt *shift,
+                                 const uint64_t *root_index_host, const uint32_t *roots_per_row_host, uint32_t max_roots, void *out);
 /* transposeVector(v, cols, step): rows = n/(cols*step); out[r*cols+c] = v[(r + c*rows)*step].
  * LowDegreeProver.ts:42,162,190,198 */
 int gs_transpose_vector(gs_ctx *ctx, const void *v, uint64_t n, uint32_t cols, uint64_t step, void *out);

@@ -35,7 +35,8 @@ struct gs_comm {
 
 /* One proof of `job` across the comm->size ranks (every rank calls this with the same job; SPMD).  Every rank receives the same
  * serialized proof — byte for byte what gs_prover_prove gives on one device.  Requirements: steps * extension_factor divisible by
- * 4 * size^2, extension_factor divisible by size, no secret registers. */
+ * 4 * size^2, extension_factor divisible by size.  Secret input registers (job->air.secret_traces: their extensions over the whole
+ * evaluation domain, the same on every rank) are committed and combined share by share like the trace registers. */
 int gs_prover_prove_dist(gs_ctx *ctx, const struct gs_prover_job *job, const gs_comm *comm, uint8_t *out, uint64_t cap, uint64_t *len,
                          char *err, uint64_t errcap);
 

@@ -71,7 +71,16 @@ struct gs_prover_stats {
     double total_ms;             /* host wall-clock of the whole call */
     double phase_ms[GS_PROVER_MAX_PHASES];       /* host wall-clock between phase boundaries; no device synchronisation is added */
     char phase_label[GS_PROVER_MAX_PHASES][48];
+    /* the reference's own phase log (lib/Stark.ts:92-152, lib/utils/Logger.ts; README.md:62-73), filled only by a proof that ran with
+     * gs_prover_sync_phases(1): the device is synchronised at each of the reference's log points, so every entry is the wall-clock
+     * of that phase alone (the default, asynchronous proof overlaps them: phase_ms above) */
+    uint32_t nreadme;
+    double readme_ms[GS_PROVER_MAX_PHASES];
+    char readme_label[GS_PROVER_MAX_PHASES][160];
 };
+/* per calling thread: the next proofs synchronise the device at the reference's log points and fill readme_ms (a measuring mode:
+ * a proof takes a little longer; its bytes are the same) */
+void gs_prover_sync_phases(int on);
 
 /* Resolves the gs_* entry points from `dl_handle` (the handle dlopen() returned for the ABI library).  GS_ERR_UNSUPPORTED if one
  * is missing, or if the library computes in another field / element size than this build of the driver (one driver library per

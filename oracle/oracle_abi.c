@@ -246,22 +246,30 @@ int gs_pluck(gs_ctx *c, const void *v, uint64_t vlen, uint64_t skip, uint64_t ti
     return GS_OK;
 }
 /* the definitions, term by term: denominators materialised, inverted with the serial Montgomery trick, multiplied */
+/* the point list of a coset: x_i = shift * w^i.  The plain entries are the coset forms at shift = 1. */
 int gs_zero_poly_inverses(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t steps, const gs_elt *x_last, void *o) {
+    uint8_t one[64];
+    memset(one, 0, sizeof one);
+    one[0] = 1;
+    return gs_zero_poly_inverses_coset(c, omega, n, (const gs_elt *)one, steps, x_last, o);
+}
+int gs_zero_poly_inverses_coset(gs_ctx *c, const gs_elt *omega, uint64_t n, const gs_elt *shift, uint64_t steps, const gs_elt *x_last, void *o) {
     if (!is_pow2(n) || !is_pow2(steps) || steps > n) return fail(c, GS_ERR_ARG, "zero_poly_inverses: bad sizes");
     if (n / steps > 32) return fail(c, GS_ERR_UNSUPPORTED, "zero_poly_inverses: n / steps above 32");
+    const fe sh = fe_load(shift), shs = fe_exp(sh, (fexp)steps);
     fe w = fe_load(omega), xl = fe_load(x_last), ws = fe_exp(w, (fexp)steps);
     uint8_t *den = (uint8_t *)malloc((n ? n : 1) * FE_BYTES);
     fe *inv = (fe *)malloc((n ? n : 1) * sizeof(fe));
     if (!den || !inv) { free(den); free(inv); return fail(c, GS_ERR_OOM, "malloc failed"); }
     PAR_FOR
     for (uint64_t s0 = 0; s0 < n; s0 += BLOCK) {
-        fe d = fe_exp(ws, (fexp)s0);
-        for (uint64_t i = s0; i < n && i < s0 + BLOCK; i++) { ST(den, i, fe_sub(d, 1)); d = fe_mul(d, ws); }      /* omega^(i*steps) - 1 */
+        fe d = fe_mul(shs, fe_exp(ws, (fexp)s0));
+        for (uint64_t i = s0; i < n && i < s0 + BLOCK; i++) { ST(den, i, fe_sub(d, 1)); d = fe_mul(d, ws); }      /* x_i^steps - 1 */
     }
     batch_inv(den, n, inv);
     PAR_FOR
     for (uint64_t s0 = 0; s0 < n; s0 += BLOCK) {
-        fe x = fe_exp(w, (fexp)s0);
+        fe x = fe_mul(sh, fe_exp(w, (fexp)s0));
         for (uint64_t i = s0; i < n && i < s0 + BLOCK; i++) { ST(o, i, fe_mul(fe_sub(x, xl), inv[i])); x = fe_mul(x, w); }
     }
     free(den); free(inv);
@@ -269,8 +277,16 @@ int gs_zero_poly_inverses(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t s
 }
 int gs_div_by_domain_roots(gs_ctx *c, const void *num, uint32_t rows, uint64_t n, const gs_elt *omega, const uint64_t *root_index,
                            const uint32_t *roots_per_row, uint32_t max_roots, void *o) {
+    uint8_t one[64];
+    memset(one, 0, sizeof one);
+    one[0] = 1;
+    return gs_div_by_domain_roots_coset(c, num, rows, n, omega, (const gs_elt *)one, root_index, roots_per_row, max_roots, o);
+}
+int gs_div_by_domain_roots_coset(gs_ctx *c, const void *num, uint32_t rows, uint64_t n, const gs_elt *omega, const gs_elt *shift, const uint64_t *root_index,
+                                 const uint32_t *roots_per_row, uint32_t max_roots, void *o) {
     if (!is_pow2(n)) return fail(c, GS_ERR_ARG, "div_by_domain_roots: n must be a power of two");
     fe w = fe_load(omega);
+    const fe sh = fe_load(shift);
     uint8_t *den = (uint8_t *)malloc((n ? n : 1) * FE_BYTES);
     fe *inv = (fe *)malloc((n ? n : 1) * sizeof(fe));
     if (!den || !inv) { free(den); free(inv); return fail(c, GS_ERR_OOM, "malloc failed"); }
@@ -280,7 +296,7 @@ int gs_div_by_domain_roots(gs_ctx *c, const void *num, uint32_t rows, uint64_t n
         for (uint32_t a = 0; a < roots_per_row[r]; a++) root[a] = fe_exp(w, (fexp)(root_index[(uint64_t)r * max_roots + a] % n));
         PAR_FOR
         for (uint64_t s0 = 0; s0 < n; s0 += BLOCK) {
-            fe x = fe_exp(w, (fexp)s0);
+            fe x = fe_mul(sh, fe_exp(w, (fexp)s0));
             for (uint64_t i = s0; i < n && i < s0 + BLOCK; i++) {
                 fe z = 1;
                 for (uint32_t a = 0; a < roots_per_row[r]; a++) z = fe_mul(z, fe_sub(x, root[a]));

@@ -548,6 +548,61 @@ def check_device_record_ops(backend, rng):
         be.free(p_)
 
 
+def check_coset_divisions(backend, rng, logn, logsteps, ranks):
+    """gs_zero_poly_inverses_coset / gs_div_by_domain_roots_coset — the two table-driven divisions over ONE RANK'S COSET of a domain
+    (point i = shift * w^i, w = omega^ranks, shift = omega^rank): every rank's output must be the strided share of what the plain entry
+    computes over the whole domain, and equal its definition on Python integers (sampled)."""
+    be = backend
+    f = field_for(be)
+    p = f.modulus
+    n, steps = 1 << logn, 1 << logsteps
+    omega = f.getRootOfUnity(n)
+    x_last = pow(omega, (steps - 1) * (n // steps), p)
+    full_z = f.newVector(n)
+    be.call('gs_zero_poly_inverses', f.le(omega), n, steps, f.le(x_last), C.c_void_p(full_z.ptr))
+    full_z = full_z.toValues()
+    rows, max_roots = 2, 3
+    num = [[rng.randrange(p) for _ in range(n)] for _ in range(rows)]
+    e = n // steps
+    roots = [[0, (steps - 1) * e, (steps // 2) * e], [(steps // 4) * e, 0, 0]]
+    per_row = [3, 1]
+    numv = f.newMatrixFrom(num)
+    full_b = f.newMatrix(rows, n)
+    ri = (C.c_uint64 * (rows * max_roots))(*[k for r in roots for k in r])
+    pr = (C.c_uint32 * rows)(*per_row)
+    be.call('gs_div_by_domain_roots', C.c_void_p(numv.ptr), rows, n, f.le(omega), ri, pr, max_roots, C.c_void_p(full_b.ptr))
+    full_b = full_b.toValues()
+    m = n // ranks
+    w = pow(omega, ranks, p)
+    out = []
+    for g in range(ranks):
+        shift = pow(omega, g, p)
+        z = f.newVector(m)
+        be.call('gs_zero_poly_inverses_coset', f.le(w), m, f.le(shift), steps, f.le(x_last), C.c_void_p(z.ptr))
+        got = z.toValues()
+        assert got == full_z[g::ranks], ('1/Z', g)
+        for k in sorted({0, 1, m - 1, rng.randrange(m), rng.randrange(m)}):
+            x = shift * pow(w, k, p) % p
+            den = (pow(x, steps, p) - 1) % p
+            assert got[k] == ((x - x_last) * pow(den, p - 2, p) % p if den else 0)
+        share = f.newMatrixFrom([row[g::ranks] for row in num])
+        b = f.newMatrix(rows, m)
+        ri2 = (C.c_uint64 * (rows * max_roots))(*[k // ranks for r in roots for k in r])         # in units of w = omega^ranks
+        be.call('gs_div_by_domain_roots_coset', C.c_void_p(share.ptr), rows, m, f.le(w), f.le(shift), ri2, pr, max_roots, C.c_void_p(b.ptr))
+        gotb = b.toValues()
+        if g:                    # (on the domain itself a point may coincide with a root: 0^-1 = 0 by convention, same in both entries)
+            for r in range(rows):
+                k = rng.randrange(m)
+                x = shift * pow(w, k, p) % p
+                den = 1
+                for a in roots[r][:per_row[r]]:
+                    den = den * (x - pow(omega, a, p)) % p
+                assert gotb[r][k] == num[r][g + ranks * k] * pow(den, p - 2, p) % p
+        assert gotb == [row[g::ranks] for row in full_b], ('B', g)
+        out.append((got, gotb))
+    return out
+
+
 def check_fri_layers(backend, rng, logm, depth, nlayers, alg='blake2s256'):
     """gs_fri_layers — a run of FRI layers in one call (LowDegreeProver.ts:176-221) — against what its contract says it equals, layer by
     layer on the same backend: gs_fri_fold_at at the running point, gs_merkle_commit_rows_seed over the four quarters of the folded

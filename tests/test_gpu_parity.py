@@ -74,6 +74,17 @@ def test_fri_layers(hip_backend, oracle_backend, rng, logm, depth, nlayers, alg)
     assert got == cases.check_fri_layers(oracle_backend, random.Random(seed), logm, depth, nlayers, alg)
 
 
+@pytest.mark.parametrize('logn,logsteps,ranks', [(8, 4, 1), (10, 6, 8), (16, 12, 4), (20, 16, 2), (20, 15, 8)])
+def test_coset_divisions(hip_backend, oracle_backend, rng, logn, logsteps, ranks):
+    """gs_zero_poly_inverses_coset / gs_div_by_domain_roots_coset: a rank's coset of the domain == the strided share of the whole-domain
+    entries on the same device, == the oracle's values."""
+    import random
+    seed = rng.randrange(1 << 30)
+    got = cases.check_coset_divisions(hip_backend, random.Random(seed), logn, logsteps, ranks)
+    if logn <= 16:
+        assert got == cases.check_coset_divisions(oracle_backend, random.Random(seed), logn, logsteps, ranks)
+
+
 def test_fri_layers_repeated_launches_keep_the_arrival_counter_clean(hip_backend, rng):
     """Back-to-back multi-workgroup launches on one context: the workgroup that arrives last resets the counter for the next."""
     import random

@@ -32,6 +32,11 @@ def test_fri_layers(oracle_backend, rng, logm, depth, nlayers, alg):
     cases.check_fri_layers(oracle_backend, rng, logm, depth, nlayers, alg)
 
 
+@pytest.mark.parametrize('logn,logsteps,ranks', [(8, 4, 1), (8, 4, 4), (10, 6, 8), (9, 4, 2)])
+def test_coset_divisions(oracle_backend, rng, logn, logsteps, ranks):
+    cases.check_coset_divisions(oracle_backend, rng, logn, logsteps, ranks)
+
+
 def test_deferred_readbacks(oracle_backend, rng):
     cases.check_deferred_readbacks(oracle_backend, rng, 256)
 

@@ -1,0 +1,135 @@
+"""tools/config_runs.py — prove() of every BASELINE.json configuration on the HIP backend through the product entry (native driver,
+compiled AIR programs, packed seeds): wall-clock per proof, device-busy time per proof (sum of kernel durations, rocprofv3
+--kernel-trace of a second run of the same child), launches per proof, proof size.  bench.py embeds the JSON (`configs`).
+
+    python tools/config_runs.py                 -> one JSON list on stdout (parent: runs the children below)
+    python tools/config_runs.py --child NAME N  -> N timed proofs of one configuration, one JSON object on stdout
+"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {   # name -> (what BASELINE.json calls it, timed proofs)
+    'C1_foo': ('configs[0]: Foo (x <- x + 2), 64 steps over 2^32 - 3*2^25 + 1, 1 register, defaults (sha256, 80 / 40 queries): the q32 build of library and driver', 20),
+    'C2_E8': ('configs[1]: MiMC-128, 2^13 steps, extensionFactor 8, exe 48, fri 24, blake2s256', 30),
+    'C2_E16': ('configs[1] as the README log runs it: MiMC-128, 2^13 steps, extensionFactor 16, exe 48, fri 24, blake2s256', 30),
+    'C3': ('configs[2]: Rescue 4x128, 2^16 steps = 2048 hash chains, E = 16, exe 68, fri 24, blake2s256', 20),
+    'C4': ('configs[3]: Poseidon 6x128, 2^16 steps = 1024 hash chains, E = 16, exe 48, fri 24, blake2s256', 20),
+    'C4_long': ('configs[3] at 2^20 steps = 16384 hash chains (the strong-scaling statement of --gpus N)', 5),
+    'C5': ('configs[4]: MiMC-128, 2^20 steps, extensionFactor 16, exe 48, fri 64, blake2s256 (the headline)', 5),
+}
+
+
+def child(name, reps):
+    from genstark_amd._abi import MODULUS_32, Backend
+    from genstark_amd.field import PrimeField
+    from genstark_amd.prover import Prover
+    opts = lambda ef, exe, fri: {'hashAlgorithm': 'blake2s256', 'extensionFactor': ef, 'exeQueryCount': exe, 'friQueryCount': fri}
+    inputs = []
+    if name == 'C1_foo':
+        from genstark_amd.air_generic import GenericAir
+        be = Backend(device=0, modulus=MODULUS_32).jit()
+        f = PrimeField(backend=be)
+        air = GenericAir(64, 1, [1], [], lambda r, k: [r[0] + 2], lambda r, n, k: [n[0] - (r[0] + 2)], lambda seed: [seed[0]], None, f)
+        p = Prover(air, {'hashAlgorithm': 'sha256', 'extensionFactor': air.extensionFactor})      # README.md:17-60: defaults (sha256, 80 / 40 queries)
+        a, seed = [{'step': 0, 'register': 0, 'value': 1}, {'step': 63, 'register': 0, 'value': 127}], [1]
+    elif name in ('C2_E8', 'C2_E16', 'C5'):
+        import genstark_amd as ga
+        be = Backend(device=0)
+        steps, ef, fri = {'C2_E8': (1 << 13, 8, 24), 'C2_E16': (1 << 13, 16, 24), 'C5': (1 << 20, 16, 64)}[name]
+        st = ga.instantiateMimc(steps, opts(ef, 48, fri), backend=be)
+        p = Prover(st.air, opts(ef, 48, fri))
+        a, seed = [{'step': 0, 'register': 0, 'value': 3}], [3]
+    else:
+        be = Backend(device=0).jit()
+        f = PrimeField(backend=be)
+        t = 1 << (20 if name == 'C4_long' else 16)
+        if name == 'C3':
+            from genstark_amd.rescue import rescue4x128_air
+            air, seeds = rescue4x128_air(t, 16, f, segmented=True), [[42 + s, 43 + 2 * s] for s in range(t // 32)]
+            tr = air.initProvingContext([], seeds).generateExecutionTrace()
+            a = [{'step': 31, 'register': 0, 'value': tr.getValue(0, 31)}, {'step': t - 1, 'register': 1, 'value': tr.getValue(1, t - 1)}]
+            p = Prover(air, opts(16, 68, 24))
+        else:
+            from genstark_amd.poseidon import poseidon6x128_air
+            air, seeds = poseidon6x128_air(t, 16, f, segmented=True), [[1 + s, 2, 3 + s, 4] for s in range(t // 64)]
+            a = [{'step': 0, 'register': 0, 'value': 1}, {'step': t - 64, 'register': 2, 'value': 3 + t // 64 - 1}]
+            p = Prover(air, opts(16, 48, 24))
+        seed = p.pack_seed(seeds)
+    for _ in range(3):
+        data = p.prove_bytes(a, inputs, seed)       # plans, block cache, compiled programs (hiprtc or the disk cache)
+    be.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        data = p.prove_bytes(a, inputs, seed)
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    st = p.last_stats()
+    p.sync_phases(True)
+    p.prove_bytes(a, inputs, seed)
+    readme = p.last_stats().get('phases_readme')
+    print(json.dumps({'name': name, 'prove_ms': round(ms, 4), 'driver_ms': st['total_ms'], 'proof_bytes': len(data), 'proofs_timed': reps,
+                      'compiled_program_launches': int(getattr(be, 'jit_launches', 0)), 'phases_readme_ms': readme}), flush=True)
+
+
+def busy_from_db(db_path):
+    """(kernel time of the last proof in ms, its launches, the kernel with the largest share and that share) from a rocprofv3 rocpd db:
+    proofs of one statement issue the same launch sequence; the last period of the sequence of kernel names is one proof."""
+    import sqlite3
+    rows = list(sqlite3.connect(db_path).execute('select name, start, end from kernels order by start'))
+    names = [r[0] for r in rows]
+    per = next((q for q in range(3, len(names) // 2 + 1) if names[-q:] == names[-2 * q:-q]), None)
+    if per is None:
+        return None
+    # the synchronised measuring proof is the LAST one in the child: step back over it, then average over up to three plain proofs
+    k = 0
+    while k < 3 and len(names) >= (k + 3) * per and names[-(k + 2) * per:-(k + 1) * per] == names[-(k + 3) * per:-(k + 2) * per]:
+        k += 1
+    k = max(k, 1)
+    sel = rows[-(k + 1) * per:-per]
+    busy = sum(e - s for _, s, e in sel) / k / 1e6
+    by = {}
+    for n, s, e in sel:
+        by[n] = by.get(n, 0) + (e - s)
+    top = max(by, key=by.get)
+    return {'device_busy_ms': round(busy, 4), 'launches_per_proof': per, 'dominant_kernel': top[:80], 'dominant_share': round(by[top] / sum(by.values()), 3),
+            'dominant_kernel_ms_per_proof': round(by[top] / k / 1e6, 4)}
+
+
+def parent(names, rocprof=True):
+    out = []
+    env = dict(os.environ, TMPDIR='/tmp')
+    for name in names:
+        what, reps = CONFIGS[name]
+        rec = {'name': name, 'config': what}
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--child', name, str(reps)], capture_output=True, text=True, timeout=180, env=env)
+            rec.update(json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1]))
+        except Exception as e:   # noqa: BLE001
+            rec['error'] = repr(e)[:200]
+            out.append(rec)
+            continue
+        if rocprof:
+            d = f'/tmp/gs_cfg_{os.getpid()}_{name}'
+            try:
+                subprocess.run(['rocprofv3', '--kernel-trace', '-d', d, '-o', 'c', '--', sys.executable, os.path.abspath(__file__), '--child', name, str(min(reps, 4))],
+                               capture_output=True, text=True, timeout=240, env=env, cwd='/tmp')
+                db = next((os.path.join(dp, fn) for dp, _, fns in os.walk(d) for fn in fns if fn.endswith('_results.db')), None)
+                rec.update(busy_from_db(db) or {'device_busy_ms': None})
+            except Exception as e:   # noqa: BLE001
+                rec['rocprof_error'] = repr(e)[:200]
+            subprocess.run(['rm', '-rf', d])
+        out.append(rec)
+    return out
+
+
+if __name__ == '__main__':
+    if len(sys.argv) >= 4 and sys.argv[1] == '--child':
+        child(sys.argv[2], int(sys.argv[3]))
+    else:
+        names = [a for a in sys.argv[1:] if a in CONFIGS] or list(CONFIGS)
+        print(json.dumps(parent(names, rocprof='--no-rocprof' not in sys.argv)))

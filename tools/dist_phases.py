@@ -1,7 +1,7 @@
 """tools/dist_phases.py — the native distributed driver with G ranks SHARING the box's one GPU (ranks = threads, thread communicator of
 the tests): wall time per proof, rank 0's phase clock and the collectives of one proof, for C4 (Poseidon 2^16 steps as 1 024 chains)
 and C5 (MiMC 2^20).  On one GPU the ranks' kernels serialise, so the wall time is the SUM of the ranks' device work + exchanges: it
-shows how much total work the distributed form adds, not a speed-up.  usage: python tools/dist_phases.py [c4|c5] [G ...]"""
+shows how much total work the distributed form adds, not a speed-up.  usage: python tools/dist_phases.py [c4|c4long|c5] [G ...]   (c4long: the same AIR at 2^20 steps; programs compiled)"""
 import os, sys, time, threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -22,15 +22,15 @@ def statement(be):
         return p, [{'step': 0, 'register': 0, 'value': 3}], [], [3]
     from genstark_amd.poseidon import poseidon6x128_air
     from genstark_amd.field import PrimeField
-    t4 = 1 << 16
+    t4 = 1 << (20 if which == 'c4long' else 16)
     air = poseidon6x128_air(t4, 16, PrimeField(backend=be), segmented=True)
     seed = [[1 + s, 2, 3 + s, 4] for s in range(t4 // 64)]
     p = Prover(air, {'hashAlgorithm': 'blake2s256', 'extensionFactor': 16, 'exeQueryCount': 48, 'friQueryCount': 24})
-    return p, [{'step': 0, 'register': 0, 'value': 1}], [], seed
+    return p, [{'step': 0, 'register': 0, 'value': 1}], [], p.pack_seed(seed)
 
 
 for G in Gs:
-    bes = [Backend(device=0) for _ in range(G)]
+    bes = [Backend(device=0).jit() for _ in range(G)]
     sts = [statement(be) for be in bes]
     comms, keep = thread_comms(bes[0], G)
     single = sts[0][0].prove_bytes(*sts[0][1:])
