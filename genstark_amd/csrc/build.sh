@@ -48,7 +48,7 @@ build_driver() {   # <output> <extra flags>
   local out=$1 extra=$2
   if [ ! -f $out ] || [ prover.cc -nt $out ] || [ prover_dist.h -nt $out ] || [ ../../include/gstark_comm.h -nt $out ] || [ ../../include/gstark.h -nt $out ] \
      || [ ../../include/gstark_prover.h -nt $out ] || [ host_field.h -nt $out ] || [ host_field_small.h -nt $out ] || [ host_field_wide.h -nt $out ] || [ gf_wide.h -nt $out ]; then
-    g++ -O2 -std=c++17 -shared -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas $extra prover.cc -ldl -o $out
+    g++ -O3 -std=c++17 -shared -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas $extra prover.cc -ldl -o $out
   fi
 }
 build_driver libgstark_prover.so "" &

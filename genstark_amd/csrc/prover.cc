@@ -1034,3 +1034,6 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
 
 // ---- one proof across several GPUs (same helpers, same coefficient streams, same wire format)
 #include "prover_dist.h"
+
+// ---- Stark.verify(): the CPU-side half of the acceptance loop, native
+#include "verifier.h"

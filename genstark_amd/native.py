@@ -86,6 +86,8 @@ def _driver(backend):
             lib.gs_prover_element_size.restype = C.c_int
             lib.gs_prover_prove_on.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Job), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
             lib.gs_prover_prove_on.restype = C.c_int
+            lib.gs_prover_verify_on.argtypes = [C.c_void_p, C.POINTER(_Job), C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]
+            lib.gs_prover_verify_on.restype = C.c_int
             lib.gs_prover_last_stats.argtypes = [C.POINTER(_Stats)]
             lib.gs_prover_last_stats.restype = C.c_int
             lib.gs_prover_sync_phases.argtypes = [C.c_int]
@@ -252,6 +254,50 @@ class NativeProver:
         if rc:
             raise StarkError(f'native prove() failed ({rc}): {err.value.decode(errors="replace")}')
         return C.string_at(out, n.value)
+
+    def verify_bytes(self, assertions, data):
+        """Stark.verify(assertions, stark.parse(data)) natively (csrc/verifier.h: lib/Stark.ts:167-248 + LowDegreeProver.ts:70-172 on host
+        scalars, no device work): True, or StarkError with the reference's message.  AIRs whose proofs carry input shapes (AssemblyAir
+        with input registers) are verified by the Python verifier instead (GstarkError here)."""
+        air, f = self.stark.air, self.field
+        if not isinstance(assertions, list) or len(assertions) == 0:
+            raise TypeError('At least one assertion must be provided')
+        es = f.elementSize
+        job = _Job()
+        job.steps, job.extension_factor = air.steps, air.extensionFactor
+        job.exe_query_count, job.fri_query_count, job.hash_alg = self._exe, self._fri, self._alg
+        job.root_of_unity[:es] = f.le(self.rootOfUnity)
+        arr = (_Assertion * len(assertions))()
+        for i, a in enumerate(assertions):
+            if a['register'] < 0 or a['step'] < 0:
+                raise ValueError('Invalid assertion')
+            arr[i].step, arr[i].reg = a['step'], a['register']
+            arr[i].value[:es] = f.le(a['value'] % f.modulus)
+        job.assertions, job.nassertions = arr, len(assertions)
+        ja = job.air
+        ja.kind, ja.registers, ja.nconstraints = self.kind, air.traceRegisterCount, len(self.degrees)
+        degrees = (C.c_uint32 * len(self.degrees))(*self.degrees)
+        ja.degrees = degrees
+        keep = [arr, degrees]
+        if self.kind == 0:
+            ja.round_constants, ja.nrc = self._rc, len(air.roundConstants)
+        else:
+            nsec = air.secretInputCount
+            e_code, e_n, consts, nconsts, nregs = air.evaluationProgram.abi_args(es)
+            pub = b''.join(f.le(v % f.modulus) for values in air.staticRegisters for v in values) or bytes(es)
+            plist = [len(v) for v in air.staticRegisters] + [1] * nsec          # the secret registers' values come with the proof's leaves
+            periods = (C.c_uint32 * max(len(plist), 1))(*plist)
+            ja.e_code, ja.e_ninstr, ja.consts, ja.nconsts, ja.vm_regs = e_code, e_n, consts, nconsts, nregs
+            ja.static_values, ja.static_periods, ja.nstatic, ja.nsecret = pub, periods, len(plist), nsec
+            keep += [e_code, consts, pub, periods]
+        err = C.create_string_buffer(512)
+        data = bytes(data)
+        rc = self.lib.gs_prover_verify_on(self.binding, C.byref(job), data, len(data), err, 512)
+        if rc == -3:      # GS_ERR_UNSUPPORTED
+            raise GstarkError(err.value.decode(errors='replace') or 'unsupported by the native verifier')
+        if rc:
+            raise StarkError(err.value.decode(errors='replace') or f'verification failed ({rc})')
+        return True
 
     def _pack_rows(self, rows):
         f = self.field

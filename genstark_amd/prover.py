@@ -70,6 +70,11 @@ class Prover:
     def last_collectives(self):
         return self._native.last_collectives()
 
+    def verify_native(self, assertions, data):
+        """Stark.verify of serialized proof bytes by the NATIVE verifier (csrc/verifier.h; CPU only, ~100x the Python verifier's speed):
+        True or StarkError with the reference's message."""
+        return self._native.verify_bytes(assertions, data)
+
     def verify(self, assertions, proof, publicInputs=None):
         """lib/Stark.ts:167-248 on the CPU side of the same backend (the restated caller in genstark_amd/_mirror; a verifier that
         needs no device at all is Stark(air over HostField(), options).verify, tests/test_host_verifier.py)."""

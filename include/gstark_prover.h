@@ -98,6 +98,16 @@ int gs_prover_element_size(void);      /* of this build of the driver */
 int gs_prover_prove(gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, uint64_t cap, uint64_t *len, char *err, uint64_t errcap);
 int gs_prover_prove_on(const gs_prover_binding *b, gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, uint64_t cap, uint64_t *len, char *err,
                        uint64_t errcap);
+/* Stark.verify() (lib/Stark.ts:167-248; LowDegreeProver.ts:70-172) of a serialized proof, native and CPU-only like the reference's:
+ * GS_OK = the proof is valid for the statement; otherwise the reference's message in err ("Verification of evaluation Merkle proof
+ * failed", "Degree 4 polynomial didn't evaluate to column value at depth 2", ...).  The job is the one prove() takes; the verifier
+ * reads of it the sizes, query counts, hash, root of unity, assertions and, of the AIR, kind / registers / nsecret / degrees and
+ * (kind 0) round_constants or (kind 1) e_code, consts, vm_regs, static_values / static_periods / nstatic (public registers first;
+ * the trailing nsecret entries are the secret ones, whose values come with the proof).  No gs_ctx: nothing touches a device; the
+ * binding supplies the library's host-side helpers (index generator, small interpolation).  Input shapes at the end of a proof are
+ * parsed and not interpreted: the job states the trace length. */
+int gs_prover_verify(const struct gs_prover_job *job, const uint8_t *proof, uint64_t len, char *err, uint64_t errcap);
+int gs_prover_verify_on(const gs_prover_binding *b, const struct gs_prover_job *job, const uint8_t *proof, uint64_t len, char *err, uint64_t errcap);
 int gs_prover_last_stats(struct gs_prover_stats *out);
 /* LowDegreeProver.verifyRemainder (LowDegreeProver.ts:223-252) on its own, for tests: `len` values on the powers of root_of_unity
  * (order len); 1 = the values at the positions that are not multiples of extension_factor lie on a polynomial of degree

@@ -150,6 +150,69 @@ def test_headline_proof_bytes_hip_equals_oracle():
     assert len(data) == stark.sizeOf(stark.parse(data))
 
 
+def check_native_verifier(backend):
+    """csrc/verifier.h — Stark.verify (lib/Stark.ts:167-248) + LowDegreeProver.verify (LowDegreeProver.ts:70-172) natively: accepts what
+    the mirror's verifier accepts (golden MiMC proofs, sha256 and blake2s256; every generic AIR case incl. secret registers), and on a
+    sweep of single-bit corruptions over the whole proof gives the mirror's verdict AND the mirror's message every time."""
+    import random
+    for case in GOLDEN:
+        options = {'hashAlgorithm': case['hash_algorithm'], 'extensionFactor': case['extension_factor'],
+                   'exeQueryCount': case['exe_query_count'], 'friQueryCount': case['fri_query_count']}
+        stark = ga.instantiateMimc(case['steps'], options, None, backend=backend)
+        assertions = [{'step': a['step'], 'register': a['register'], 'value': int(a['value'])} for a in case['assertions']]
+        nat = NativeProver(stark)
+        data = nat.prove_bytes(assertions, [], [case['seed']])
+        assert nat.verify_bytes(assertions, data) is True
+        with pytest.raises(StarkError, match='linear combination correctness'):
+            nat.verify_bytes([dict(assertions[0], value=assertions[0]['value'] + 1)] + assertions[1:], data)
+    # the verdicts and messages of the two verifiers on corrupted proofs (one statement: the sweep is ~150 verifications)
+    case = GOLDEN[0]
+    options = {'hashAlgorithm': case['hash_algorithm'], 'extensionFactor': case['extension_factor'], 'exeQueryCount': case['exe_query_count'],
+               'friQueryCount': case['fri_query_count']}
+    stark = ga.instantiateMimc(case['steps'], options, None, backend=backend)
+    assertions = [{'step': a['step'], 'register': a['register'], 'value': int(a['value'])} for a in case['assertions']]
+    nat = NativeProver(stark)
+    data = nat.prove_bytes(assertions, [], [case['seed']])
+    rng = random.Random(2026)
+    offsets = sorted(set([0, 31, 32, 33, len(data) - 1, len(data) - 2, len(data) - 20] + [rng.randrange(len(data)) for _ in range(140)]))
+    agree = 0
+    for off in offsets:
+        bad = bytearray(data)
+        bad[off] ^= 1 << rng.randrange(8)
+        verdicts = []
+        for verify in (lambda b: stark.verify(assertions, stark.parse(b)), lambda b: nat.verify_bytes(assertions, b)):
+            try:
+                verdicts.append(('ok', '') if verify(bytes(bad)) else ('false', ''))
+            except StarkError as e:
+                verdicts.append(('rejected', str(e).split(':')[0]))
+        assert verdicts[0][0] == verdicts[1][0], (off, verdicts)
+        agree += verdicts[0][1] == verdicts[1][1] or verdicts[0][1].startswith('Verification of low degree failed') or 'malformed' in verdicts[0][1] + verdicts[1][1]
+    assert agree == len(offsets)
+    # truncated and empty proofs are StarkErrors, not crashes
+    for cut in (0, 1, 31, 40, len(data) // 2, len(data) - 1):
+        with pytest.raises(StarkError):
+            nat.verify_bytes(assertions, data[:cut])
+    for name, stark, seed, trace, points, *rest in generic_cases(backend):
+        inputs = rest[0] if rest else []
+        assertions = [{'step': s, 'register': r, 'value': trace[s][r]} for s, r in points]
+        nat = NativeProver(stark)
+        data = nat.prove_bytes(assertions, inputs, seed)
+        assert nat.verify_bytes(assertions, data) is True, name
+        bad = bytearray(data)
+        bad[len(bad) // 3] ^= 4
+        with pytest.raises(StarkError):
+            nat.verify_bytes(assertions, bytes(bad))
+
+
+def test_native_verifier_oracle(oracle_backend):
+    check_native_verifier(oracle_backend)
+
+
+@pytest.mark.gpu
+def test_native_verifier_hip(hip_backend):
+    check_native_verifier(hip_backend)
+
+
 def test_product_prover_entry(oracle_backend):
     """genstark_amd.prover.Prover: an AIR + options straight into the native driver (no mirror object), the reference's option rules
     (lib/Stark.ts:318-344), bytes of the mirror, and the CPU verifier behind verify()."""
