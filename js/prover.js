@@ -57,4 +57,32 @@ function proveGenericSerialized(air, options, assertions, seed) {
     return native().proveGenericSerialized(f.ctx, driverPath(f), job);
 }
 
-module.exports = { proveMimcSerialized, proveGenericSerialized };
+// Stark.verify() of serialized proof bytes by the NATIVE verifier (genstark_amd/csrc/verifier.h; CPU only, no device work): true, or throws
+// the reference's message.  The job carries what a verifier needs of the statement: no trace tables, no first rows.
+function verifyMimcSerialized(air, options, assertions, proof) {
+    const f = air.field, root = air._root !== undefined ? air._root : f.getRootOfUnity(air.steps * air.extensionFactor);
+    const job = {
+        steps: air.steps, extensionFactor: air.extensionFactor, exeQueryCount: options.exeQueryCount, friQueryCount: options.friQueryCount,
+        hashAlg: HASH_ALG[options.hashAlgorithm], rootOfUnity: le(root), seed: le(0n),
+        roundConstants: Buffer.concat(air.roundConstants.map(le)), kTable: 0n, kLen: 0,
+        assertions: assertions.map(a => ({ step: a.step, register: a.register, value: le(f.mod(a.value)) })),
+    };
+    return native().proveMimcSerialized(f.ctx, driverPath(f), job, Buffer.from(proof));
+}
+function verifyGenericSerialized(air, options, assertions, proof) {
+    const f = air.field, e = air.evaluationProgram;
+    const statics = [].concat(...air.staticRegisters);
+    const job = {
+        steps: air.steps, extensionFactor: air.extensionFactor, exeQueryCount: options.exeQueryCount, friQueryCount: options.friQueryCount,
+        hashAlg: HASH_ALG[options.hashAlgorithm], rootOfUnity: le(air.rootOfUnity),
+        assertions: assertions.map(a => ({ step: a.step, register: a.register, value: le(f.mod(a.value)) })),
+        registers: air.traceRegisterCount, degrees: air.constraintDegrees, tCode: [], iCode: [], eCode: e.code,
+        consts: e.consts.length ? Buffer.concat(e.consts.map(le)) : Buffer.alloc(0), vmRegs: e.nregs,
+        staticValues: statics.length ? Buffer.concat(statics.map(v => le(f.mod(v)))) : le(0n), staticPeriods: air.staticRegisters.map(v => v.length),
+        staticTables: 0n, staticLens: air.staticRegisters.map(() => 0), firstRows: Buffer.alloc(air.traceRegisterCount * f.elementSize),
+        segments: 0, segmentLen: 0,
+    };
+    return native().proveGenericSerialized(f.ctx, driverPath(f), job, Buffer.from(proof));
+}
+
+module.exports = { proveMimcSerialized, proveGenericSerialized, verifyMimcSerialized, verifyGenericSerialized };

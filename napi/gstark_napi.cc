@@ -377,9 +377,23 @@ bool open_driver(napi_env env, napi_value path_value) {
     g_prover = lib;
     return true;
 }
+typedef int (*verify_on_fn)(const gs_prover_binding *, const gs_prover_job *, const uint8_t *, uint64_t, char *, uint64_t);
+// a 4th argument (a Buffer holding a serialized proof) turns either call below into Stark.verify() of that proof for the statement the job
+// describes (include/gstark_prover.h: gs_prover_verify_on — native, CPU only): returns true or throws the reference's message
+napi_value verify_instead(napi_env env, napi_value proof_value, const gs_prover_job &job) {
+    void *d;
+    size_t len;
+    if (napi_get_buffer_info(env, proof_value, &d, &len) != napi_ok) { napi_throw_type_error(env, nullptr, "the proof must be a Buffer"); return nullptr; }
+    char err[512] = {0};
+    const int rc = ((verify_on_fn)dlsym(g_prover, "gs_prover_verify_on"))(g_binding, &job, (const uint8_t *)d, len, err, sizeof err);
+    if (rc != GS_OK) { napi_throw_error(env, nullptr, err[0] ? err : "verification failed"); return nullptr; }
+    napi_value t;
+    NAPI_OK(env, napi_get_boolean(env, true, &t));
+    return t;
+}
 napi_value ProveMimcSerialized(napi_env env, napi_callback_info info) {
-    size_t argc = 3;
-    napi_value argv[3];
+    size_t argc = 4;
+    napi_value argv[4];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     void *ctx;
     NAPI_OK(env, napi_get_value_external(env, argv[0], &ctx));
@@ -426,6 +440,7 @@ napi_value ProveMimcSerialized(napi_env env, napi_callback_info info) {
         as[i].step = step; as[i].reg = (uint32_t)reg; memcpy(as[i].value, val, es);
     }
     job.assertions = as.data(); job.nassertions = na;
+    if (argc >= 4) return verify_instead(env, argv[3], job);
     std::vector<uint8_t> out(1 << 22);
     uint64_t n = 0;
     char err[512] = {0};
@@ -442,8 +457,8 @@ napi_value ProveMimcSerialized(napi_env env, napi_callback_info info) {
 //           tCode / iCode / eCode: number[] (4 words per instruction), consts: Buffer(16 * nconsts), vmRegs, staticValues: Buffer, staticPeriods: number[],
 //           staticTables: BigInt (device pointer), staticLens: number[], firstRows: Buffer, segments, segmentLen }
 napi_value ProveGenericSerialized(napi_env env, napi_callback_info info) {
-    size_t argc = 3;
-    napi_value argv[3];
+    size_t argc = 4;
+    napi_value argv[4];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     void *ctx;
     NAPI_OK(env, napi_get_value_external(env, argv[0], &ctx));
@@ -512,6 +527,7 @@ napi_value ProveGenericSerialized(napi_env env, napi_callback_info info) {
         as[i].step = step; as[i].reg = (uint32_t)reg; memcpy(as[i].value, val, es);
     }
     job.assertions = as.data(); job.nassertions = na;
+    if (argc >= 4) return verify_instead(env, argv[3], job);
     std::vector<uint8_t> out(1 << 22);
     uint64_t n = 0;
     char err[512] = {0};

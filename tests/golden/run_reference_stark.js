@@ -12,7 +12,7 @@ const cases = JSON.parse(fs.readFileSync(process.argv[3], 'utf8'));
 // the native driver (C++ above the C ABI) behind the same addon: its bytes must equal what the reference's Stark.js produces
 const repoJs = path.join(__dirname, '..', '..', 'js');
 const { MimcAir } = require(path.join(repoJs, 'air_mimc.js'));
-const { proveMimcSerialized, proveGenericSerialized } = require(path.join(repoJs, 'prover.js'));
+const { proveMimcSerialized, proveGenericSerialized, verifyMimcSerialized, verifyGenericSerialized } = require(path.join(repoJs, 'prover.js'));
 const out = [];
 const noopLogger = { start() { return () => {}; }, sub() { return () => {}; }, done() {} };
 for (const c of cases) {
@@ -35,7 +35,13 @@ for (const c of cases) {
     //  proveGenericSerialized checks)
     // ONE call of the native driver through the same addon: the build of libgstark_prover*.so for the loaded library's field (js/prover.js)
     const nativeBytes = generic ? proveGenericSerialized(stark.air, options, assertions, big(c.seed)) : proveMimcSerialized(wide ? stark.air : new MimcAir(c.steps, c.extension_factor), options, assertions, BigInt(c.seed));
-    out.push({ name: c.name, nativeDriverEqualsReference: Buffer.from(bytes).equals(nativeBytes), proofHex: bytes.toString('hex'), evRoot: proof.evRoot.toString('hex'), lcRoot: proof.ldProof.lcRoot.toString('hex'),
+    // ... and the native verifier through the same addon: accepts the reference's bytes, rejects the tampered ones with a message
+    const vAir = generic ? stark.air : (wide ? stark.air : new MimcAir(c.steps, c.extension_factor));
+    const nativeVerify = generic ? verifyGenericSerialized : verifyMimcSerialized;
+    const nativeVerified = nativeVerify(vAir, options, assertions, bytes) === true;
+    let nativeTamperRejected = false;
+    try { const bad = Buffer.from(bytes); bad[40] ^= 1; nativeVerify(vAir, options, assertions, bad); } catch (e) { nativeTamperRejected = true; }
+    out.push({ name: c.name, nativeVerified, nativeTamperRejected, nativeDriverEqualsReference: Buffer.from(bytes).equals(nativeBytes), proofHex: bytes.toString('hex'), evRoot: proof.evRoot.toString('hex'), lcRoot: proof.ldProof.lcRoot.toString('hex'),
                friLayers: proof.ldProof.components.length, remainderLength: proof.ldProof.remainder.length, verified: ok === true,
                tamperRejected, securityLevel: stark.securityLevel });
     console.log(c.name, bytes.byteLength, 'verified', ok, 'security', stark.securityLevel);

@@ -69,6 +69,7 @@ def test_reference_stark_js_runs_live_on_the_drop_in_modules(oracle_backend, tmp
         # the native driver (csrc/prover.cc), called through the same N-API addon in the same process, gives the bytes the
         # reference's own Stark.js produced
         assert rec['nativeDriverEqualsReference'] is True
+        assert rec['nativeVerified'] is True and rec['nativeTamperRejected'] is True
 
 
 @pytest.mark.skipif(not (os.path.isdir(REF_LIB) and shutil.which('node') and os.path.exists('/usr/include/node/node_api.h')),
@@ -106,6 +107,7 @@ def test_reference_stark_js_runs_live_over_another_field(name, tmp_path):
     assert rec['verified'] and rec['tamperRejected']
     assert rec['proofHex'] == want.hex()
     assert rec['nativeDriverEqualsReference'] is True       # the native driver's build for this field, one N-API call (js/prover.js)
+    assert rec['nativeVerified'] is True and rec['nativeTamperRejected'] is True       # ... and the native verifier through the same addon
 
 
 # ---- AIRs given as register-machine programs: Rescue 4x128 / Poseidon 6x128 through instantiate({generic: descriptor}) ----------
@@ -162,3 +164,4 @@ def test_reference_stark_js_proves_generic_airs_live(oracle_backend, tmp_path):
         assert (len(data), hashlib.sha256(data).hexdigest()) == (DRIVER_GENERIC[rec['name']]['proofSize'], DRIVER_GENERIC[rec['name']]['proofSha256'])
         # ... and ONE call of the native driver through the same addon (js/prover.js proveGenericSerialized -> csrc/prover.cc) gives these bytes
         assert rec['nativeDriverEqualsReference'] is True
+        assert rec['nativeVerified'] is True and rec['nativeTamperRejected'] is True

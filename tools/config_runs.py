@@ -72,7 +72,11 @@ def child(name, reps):
     p.sync_phases(True)
     p.prove_bytes(a, inputs, seed)
     readme = p.last_stats().get('phases_readme')
-    print(json.dumps({'name': name, 'prove_ms': round(ms, 4), 'driver_ms': st['total_ms'], 'proof_bytes': len(data), 'proofs_timed': reps,
+    tv = time.perf_counter()
+    for _ in range(5):
+        assert p.verify_native(a, data) is True        # Stark.verify natively (csrc/verifier.h): CPU only
+    verify_ms = (time.perf_counter() - tv) / 5 * 1e3
+    print(json.dumps({'name': name, 'prove_ms': round(ms, 4), 'verify_native_ms': round(verify_ms, 4), 'driver_ms': st['total_ms'], 'proof_bytes': len(data), 'proofs_timed': reps,
                       'compiled_program_launches': int(getattr(be, 'jit_launches', 0)), 'phases_readme_ms': readme}), flush=True)
 
 
