@@ -104,6 +104,53 @@ static std::string jit_preamble() {
          "    for (int i = 0; i < (int)(sizeof(fe) / 4); i++) pa[i] = c ? pa[i] : pb[i];\n"
          "    return a;\n"
          "}\n";
+    // sum_k x_k * c_k on ONE lane (a fused row of a linear layer, ssa_fuse_dots)
+#ifdef GS_JIT_LAZY
+    // 128-bit field: the constants in W-form (five pre-shifted copies: no high columns), every term 25 v_mad into five shared 64-bit
+    // columns, ONE fold for up to six terms (columns stay below 2^57: 6 * 5 * 2^52).  The rows of a W-form built in registers are
+    // laundered through an empty asm: with their value ranges visible hipcc (ROCm 7.2) miscompiles the products (ntt.hip has the same note)
+    s += "typedef lzw gs_dotk;\n"
+         "__device__ __forceinline__ void gs_dotk_make(lzw &W, const fe c) {\n"
+         "    lz_wform(c, W);\n"
+         "#pragma unroll\n"
+         "    for (int i = 0; i < 5; i++)\n"
+         "#pragma unroll\n"
+         "        for (int j = 0; j < 5; j++) asm volatile(\"\" : \"+v\"(W.w[i][j]));\n"
+         "}\n"
+         "struct gs_dot_t { long long c[5]; fe partial; bool has; };\n"
+         "__device__ __forceinline__ void gs_dot_begin(gs_dot_t &a) { for (int j = 0; j < 5; j++) a.c[j] = 0; a.has = false; }\n"
+         "__device__ __forceinline__ void gs_dot_acc(gs_dot_t &a, const fe x, const lzw &W) {\n"
+         "    const lz u = lz_unpack(x);\n"
+         "#pragma unroll\n"
+         "    for (int j = 0; j < 5; j++) {\n"
+         "        long long t = a.c[j];\n"
+         "#pragma unroll\n"
+         "        for (int i = 0; i < 5; i++) t += (long long)u.l[i] * W.w[i][j];\n"
+         "        a.c[j] = t;\n"
+         "    }\n"
+         "}\n"
+         "__device__ __forceinline__ fe gs_dot_fold(gs_dot_t &a) {\n"
+         "    const lzk K = lzk_make();\n"
+         "    int64_t c[5];\n"
+         "    for (int j = 0; j < 5; j++) c[j] = a.c[j];\n"
+         "    return lz_pack(lz_fold_columns(c, K));\n"
+         "}\n"
+         "__device__ __forceinline__ void gs_dot_flush(gs_dot_t &a) {\n"
+         "    const fe v = gs_dot_fold(a);\n"
+         "    a.partial = a.has ? fe_add(a.partial, v) : v;\n"
+         "    a.has = true;\n"
+         "    for (int j = 0; j < 5; j++) a.c[j] = 0;\n"
+         "}\n"
+         "__device__ __forceinline__ fe gs_dot_end(gs_dot_t &a) { const fe v = gs_dot_fold(a); return a.has ? fe_add(a.partial, v) : v; }\n";
+#else
+    s += "typedef fe gs_dotk;\n"
+         "__device__ __forceinline__ void gs_dotk_make(fe &k, const fe c) { k = c; }\n"
+         "struct gs_dot_t { fe acc; };\n"
+         "__device__ __forceinline__ void gs_dot_begin(gs_dot_t &a) { a.acc = fe_zero(); }\n"
+         "__device__ __forceinline__ void gs_dot_acc(gs_dot_t &a, const fe x, const fe &k) { a.acc = fe_add(a.acc, gs_mul(x, k)); }\n"
+         "__device__ __forceinline__ void gs_dot_flush(gs_dot_t &) {}\n"
+         "__device__ __forceinline__ fe gs_dot_end(gs_dot_t &a) { return a.acc; }\n";
+#endif
     return s;
 }
 
@@ -268,11 +315,81 @@ static bool jit_body(std::string &s, const JitGen &gen, const uint32_t *code, ui
 // Cheap operations run redundantly on all lanes.  Long exponentiations of one depth and exponent are rounds of their own (one
 // member per lane).  L = 1, 2, 4 or 8 by the widest depth.
 struct SsaNode {
-    enum Kind { ZERO, CONSTV, ROW, STATICV, ADD, SUB, MUL, POWLONG, POWSHORT, OUT } kind = ZERO;
+    enum Kind { ZERO, CONSTV, ROW, STATICV, ADD, SUB, MUL, POWLONG, POWSHORT, OUT, DOT, DEAD } kind = ZERO;
     int a = -1, b = -1;        // operand nodes (MUL/ADD/SUB/POWLONG/OUT: a; b for binary) or the index of a constant/register/static
     uint32_t aux = 0;          // POWLONG: constant index of the exponent; POWSHORT: the exponent; OUT: destination register
     int depth = 0;
+    // DOT: sum_k value(tx[k]) * consts[tc[k]]  (tc[k] = -1: the literal one) — a linear layer's row (an MDS matrix times the state) fused
+    // into ONE unit of work for ONE lane (ssa_fuse_dots)
+    std::vector<int> tx, tc;
 };
+static void ssa_operands(const SsaNode &x, std::vector<int> &out) {
+    out.clear();
+    switch (x.kind) {
+        case SsaNode::ADD: case SsaNode::SUB: case SsaNode::MUL: out.push_back(x.a); out.push_back(x.b); break;
+        case SsaNode::POWLONG: case SsaNode::POWSHORT: case SsaNode::OUT: out.push_back(x.a); break;
+        case SsaNode::DOT: out = x.tx; break;
+        default: break;
+    }
+}
+static void ssa_recompute_depths(std::vector<SsaNode> &nodes) {
+    std::vector<int> ops;
+    for (SsaNode &n : nodes) {
+        ssa_operands(n, ops);
+        int d = 0;
+        for (int o : ops) d = std::max(d, nodes[o].depth);
+        if (n.kind == SsaNode::MUL || n.kind == SsaNode::POWLONG || n.kind == SsaNode::POWSHORT || n.kind == SsaNode::DOT) d++;
+        n.depth = d;
+    }
+}
+// Sums of products by constants — the rows of a linear layer, y_j = sum_k m_jk x_k: an ADD tree whose leaves are MUL(value, constant)
+// nodes used nowhere else — become ONE node each.  Spread over the lanes product by product such a layer costs a round per L products,
+// a select chain per operand, an LDS read-back per product and, on every lane, the whole tree of additions (a Poseidon step: 36
+// products in 2.25 rounds + 30 additions x 16 lanes); as a DOT node a row is one lane's work — in the 128-bit field K x 25 v_mad into
+// five shared 64-bit columns and ONE fold (gf128_lazy.h: the W-forms of the row's constants are built before the step loop), the rows
+// of a layer side by side on K lanes, one exchange for the whole layer.  Leaves that are not products by constants ride along with the
+// constant one.  Trees with fewer than two genuine products are left alone.
+static void ssa_fuse_dots(std::vector<SsaNode> &nodes) {
+    const int n = (int)nodes.size();
+    std::vector<int> uses(n, 0), ops;
+    for (const SsaNode &x : nodes) { ssa_operands(x, ops); for (int o : ops) uses[o]++; }
+    auto is_const = [&](int id) { return nodes[id].kind == SsaNode::CONSTV && nodes[id].a >= 0; };
+    std::vector<bool> absorbed(n, false);
+    for (int id = n - 1; id >= 0; id--) {
+        if (nodes[id].kind != SsaNode::ADD || absorbed[id]) continue;
+        // leaves of the maximal ADD tree rooted here (inner ADDs must have no other user)
+        std::vector<int> leaves, inner, stack = {nodes[id].a, nodes[id].b};
+        while (!stack.empty()) {
+            const int v = stack.back();
+            stack.pop_back();
+            if (nodes[v].kind == SsaNode::ADD && uses[v] == 1 && !absorbed[v]) { inner.push_back(v); stack.push_back(nodes[v].a); stack.push_back(nodes[v].b); }
+            else leaves.push_back(v);
+        }
+        std::vector<int> tx, tc, dead;
+        int products = 0;
+        for (int v : leaves) {
+            const SsaNode &m = nodes[v];
+            if (m.kind == SsaNode::MUL && uses[v] == 1 && (is_const(m.a) != is_const(m.b))) {
+                tx.push_back(is_const(m.a) ? m.b : m.a);
+                tc.push_back(nodes[is_const(m.a) ? m.a : m.b].a);
+                dead.push_back(v);
+                products++;
+            } else { tx.push_back(v); tc.push_back(-1); }
+        }
+        if (products < 2 || tx.size() > 64) continue;
+        // operands in a canonical order: the rows of one layer then line up position by position (shared operands need no selects)
+        std::vector<size_t> order(tx.size());
+        for (size_t k = 0; k < order.size(); k++) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return tx[x] < tx[y]; });
+        SsaNode &r = nodes[id];
+        r.kind = SsaNode::DOT;
+        r.a = r.b = -1;
+        for (size_t k : order) { r.tx.push_back(tx[k]); r.tc.push_back(tc[k]); }
+        for (int v : dead) { nodes[v].kind = SsaNode::DEAD; absorbed[v] = true; }
+        for (int v : inner) { nodes[v].kind = SsaNode::DEAD; absorbed[v] = true; }
+    }
+    ssa_recompute_depths(nodes);
+}
 
 static bool ssa_build(std::vector<SsaNode> &nodes, const JitGen &gen, const uint32_t *code, uint32_t ninstr, uint32_t vm_regs, bool allow_statics) {
     std::vector<int> cur(vm_regs, -1);
@@ -349,21 +466,12 @@ static void ssa_align_pows(std::vector<SsaNode> &nodes) {
     for (int id = 0; id < n; id++)
         if (nodes[id].kind == SsaNode::POWLONG) pows.push_back(id);
     if (pows.size() < 2) return;
-    auto operands = [&](int id, int out[2]) {
-        const SsaNode &x = nodes[id];
-        out[0] = out[1] = -1;
-        switch (x.kind) {
-            case SsaNode::ADD: case SsaNode::SUB: case SsaNode::MUL: out[0] = x.a; out[1] = x.b; break;
-            case SsaNode::POWLONG: case SsaNode::POWSHORT: case SsaNode::OUT: out[0] = x.a; break;
-            default: break;
-        }
-    };
+    std::vector<int> op;
     // reach[k][id]: node id depends on pows[k]
     std::vector<std::vector<bool>> reach(pows.size(), std::vector<bool>(n, false));
     for (size_t k = 0; k < pows.size(); k++)
         for (int id = pows[k] + 1; id < n; id++) {
-            int op[2];
-            operands(id, op);
+            ssa_operands(nodes[id], op);
             for (int o : op)
                 if (o >= 0 && (o == pows[k] || reach[k][o])) reach[k][id] = true;
         }
@@ -384,11 +492,11 @@ static void ssa_align_pows(std::vector<SsaNode> &nodes) {
         for (size_t g : group) forced[pows[g]] = depth;
         // the delay moves everything behind the group: recompute before the next group is formed
         for (int id = 0; id < n; id++) {
-            int op[2], d = 0;
-            operands(id, op);
+            int d = 0;
+            ssa_operands(nodes[id], op);
             for (int o : op)
                 if (o >= 0) d = std::max(d, nodes[o].depth);
-            if (nodes[id].kind == SsaNode::MUL || nodes[id].kind == SsaNode::POWLONG || nodes[id].kind == SsaNode::POWSHORT) d++;
+            if (nodes[id].kind == SsaNode::MUL || nodes[id].kind == SsaNode::POWLONG || nodes[id].kind == SsaNode::POWSHORT || nodes[id].kind == SsaNode::DOT) d++;
             nodes[id].depth = std::max(d, forced[id]);
         }
     }
@@ -403,8 +511,8 @@ static uint32_t ssa_lanes(const std::vector<SsaNode> &nodes) {
         // more lanes for the sake of the few single products changes nothing: point multiplication 79.5 vs 79.7 ms)
         if (n.kind == SsaNode::MUL || n.kind == SsaNode::POWSHORT) continue;
 #endif
-        if (n.kind == SsaNode::MUL || n.kind == SsaNode::POWLONG || n.kind == SsaNode::POWSHORT)
-            widest = std::max(widest, ++per_depth[n.depth * 3 + (n.kind == SsaNode::POWLONG ? 1 : (n.kind == SsaNode::POWSHORT ? 2 : 0))]);
+        if (n.kind == SsaNode::MUL || n.kind == SsaNode::POWLONG || n.kind == SsaNode::POWSHORT || n.kind == SsaNode::DOT)
+            widest = std::max(widest, ++per_depth[n.depth * 4 + (n.kind == SsaNode::POWLONG ? 1 : (n.kind == SsaNode::POWSHORT ? 2 : (n.kind == SsaNode::DOT ? 3 : 0)))]);
     }
     return widest >= 12 ? 16 : (widest >= 5 ? 8 : (widest >= 3 ? 4 : widest));
 }
@@ -440,11 +548,12 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
     const bool spread = L > 1;
     for (int depth = 0; depth <= max_depth; depth++) {
         // the products of this depth, L per round
-        std::vector<int> muls, pows;
+        std::vector<int> muls, pows, dots;
         for (int id = 0; id < (int)nodes.size(); id++) {
             if (nodes[id].depth != depth) continue;
             if (nodes[id].kind == SsaNode::MUL) muls.push_back(id);
             if (nodes[id].kind == SsaNode::POWLONG || nodes[id].kind == SsaNode::POWSHORT) pows.push_back(id);
+            if (nodes[id].kind == SsaNode::DOT) dots.push_back(id);
         }
         if (spread) {   // products by constants first, so that rounds are all-constant where they can be
             std::stable_partition(muls.begin(), muls.end(), [&](int id) { return is_const(nodes[id].a) || is_const(nodes[id].b); });
@@ -468,7 +577,10 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
             }
             for (size_t i = 0; i < m; i++) s += "        fe " + name(muls[base + i]) + ";\n";
             s += "        {\n            fe xa = " + name(xa[0]) + ";\n";
-            for (size_t i = 1; i < m; i++) { snprintf(buf, sizeof buf, "            xa = gs_pick(sub == %zuu, ", i); s += buf + name(xa[i]) + ", xa);\n"; }
+            for (size_t i = 1; i < m; i++) {
+                if (xa[i] == xa[0]) continue;                      // (the lanes that keep the default need no select)
+                snprintf(buf, sizeof buf, "            xa = gs_pick(sub == %zuu, ", i); s += buf + name(xa[i]) + ", xa);\n";
+            }
             if (squares) s += "            const fe xr = gs_sqr(xa);\n";
             else if (by_consts) {
                 snprintf(buf, sizeof buf, "    const fe %sk%d = consts[", tag, round_no); hoisted += buf;
@@ -477,7 +589,10 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
                 snprintf(buf, sizeof buf, "            const fe xr = gs_mul(xa, %sk%d);\n", tag, round_no); s += buf;
             } else {
                 s += "            fe xb = " + name(xb[0]) + ";\n";
-                for (size_t i = 1; i < m; i++) { snprintf(buf, sizeof buf, "            xb = gs_pick(sub == %zuu, ", i); s += buf + name(xb[i]) + ", xb);\n"; }
+                for (size_t i = 1; i < m; i++) {
+                    if (xb[i] == xb[0]) continue;
+                    snprintf(buf, sizeof buf, "            xb = gs_pick(sub == %zuu, ", i); s += buf + name(xb[i]) + ", xb);\n";
+                }
                 s += "            const fe xr = gs_mul(xa, xb);\n";
             }
             s += "            gs_swap[threadIdx.x] = xr;\n            __syncthreads();\n";
@@ -506,6 +621,50 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
             }
             if (L > 1) s += "            __syncthreads();\n";
             s += "        }\n";
+        }
+        // the fused rows of this depth (ssa_fuse_dots): one row per lane, rows with the same number of terms side by side
+        std::vector<bool> dot_done(dots.size(), false);
+        for (size_t first = 0; first < dots.size(); first++) {
+            if (dot_done[first]) continue;
+            std::vector<int> members;
+            const size_t K = nodes[dots[first]].tx.size();
+            for (size_t k = first; k < dots.size() && members.size() < (spread ? L : 1); k++)
+                if (!dot_done[k] && nodes[dots[k]].tx.size() == K) { members.push_back(dots[k]); dot_done[k] = true; }
+            const size_t m = members.size();
+            for (int id : members) s += "        fe " + name(id) + ";\n";
+            // the constants of position k, one per lane, in the form the accumulation wants (before the step loop)
+            for (size_t k = 0; k < K; k++) {
+                snprintf(buf, sizeof buf, "    gs_dotk %sd%d_%zu; gs_dotk_make(%sd%d_%zu, ", tag, round_no, k, tag, round_no, k); hoisted += buf;
+                std::string sel;
+                for (size_t i = m - 1; i >= 1; i--) {
+                    const int c = nodes[members[i]].tc[k];
+                    if (c < 0) snprintf(buf, sizeof buf, "sub == %zuu ? fe_one() : ", i); else snprintf(buf, sizeof buf, "sub == %zuu ? consts[%d] : ", i, c);
+                    sel += buf;
+                }
+                const int c0 = nodes[members[0]].tc[k];
+                if (c0 < 0) sel += "fe_one()"; else { snprintf(buf, sizeof buf, "consts[%d]", c0); sel += buf; }
+                hoisted += sel + ");\n";
+            }
+            s += "        {\n            gs_dot_t acc;\n            gs_dot_begin(acc);\n";
+            for (size_t k = 0; k < K; k++) {
+                if (k && k % 6 == 0) s += "            gs_dot_flush(acc);\n";      // (128-bit field: six terms per fold keep the 64-bit columns below 2^57)
+                bool shared = true;
+                for (size_t i = 1; i < m; i++) shared &= nodes[members[i]].tx[k] == nodes[members[0]].tx[k];
+                if (shared) { snprintf(buf, sizeof buf, ", %sd%d_%zu);\n", tag, round_no, k); s += "            gs_dot_acc(acc, " + name(nodes[members[0]].tx[k]) + buf; }
+                else {
+                    s += "            {\n                fe xo = " + name(nodes[members[0]].tx[k]) + ";\n";
+                    for (size_t i = 1; i < m; i++) { snprintf(buf, sizeof buf, "                xo = gs_pick(sub == %zuu, ", i); s += buf + name(nodes[members[i]].tx[k]) + ", xo);\n"; }
+                    snprintf(buf, sizeof buf, "                gs_dot_acc(acc, xo, %sd%d_%zu);\n            }\n", tag, round_no, k); s += buf;
+                }
+            }
+            s += "            const fe xr = gs_dot_end(acc);\n";
+            if (spread) {
+                s += "            gs_swap[threadIdx.x] = xr;\n            __syncthreads();\n";
+                for (size_t i = 0; i < m; i++) { snprintf(buf, sizeof buf, " = gs_swap[gs_group + %zu];\n", i); s += "            " + name(members[i]) + buf; }
+                s += "            __syncthreads();\n";
+            } else s += "            " + name(members[0]) + " = xr;\n";
+            s += "        }\n";
+            round_no++;
         }
         // everything cheap of this depth, in program order
         for (int id = 0; id < (int)nodes.size(); id++) {
@@ -731,6 +890,8 @@ static bool jit_trace_source(std::string &s, JitGen &gen, const uint32_t *code, 
     std::vector<SsaNode> main_nodes, init_nodes;
     if (!ssa_build(main_nodes, gen, code, ninstr, vm_regs, true)) return false;
     if (init_ninstr && !ssa_build(init_nodes, gen, icode, init_ninstr, vm_regs, false)) return false;
+    ssa_fuse_dots(main_nodes);
+    ssa_fuse_dots(init_nodes);
     ssa_align_pows(main_nodes);
     ssa_align_pows(init_nodes);
     gen.lanes = std::max(ssa_lanes(main_nodes), ssa_lanes(init_nodes));

@@ -66,18 +66,23 @@ def test_trace_kernels_spread_products_over_lanes(oracle_backend, hip_libs, tmp_
     compiler turns into scratch traffic); the lanes exchange results through LDS."""
     f = PrimeField(backend=oracle_backend)
     src = generated_trace_source(poseidon.poseidon6x128_air(2048, 16, f, segmented=True), hip_libs[MODULUS_128], tmp_path / 'p', monkeypatch)
-    assert '#define GS_LANES 16u' in src                        # 36 MDS products of one depth -> 16 lanes, 3 rounds
+    # the 6 x 6 MDS layer is SIX fused rows (ssa_fuse_dots: a row = one lane's 6 x 25 v_mad + one fold), not 36 products over 16 lanes
+    assert '#define GS_LANES 8u' in src
     body = src[src.index('for (unsigned long long k = 0'):]
-    assert body.count('gs_mul(') + body.count('gs_sqr(') <= 8   # per lane and step: the x^5 chain + 3 MDS rounds (+ leftovers), not 54
+    assert body.count('gs_mul(') + body.count('gs_sqr(') <= 5   # per lane and step: the x^5 chain + the blend product; the MDS is a dot
+    assert body.count('gs_dot_acc(') == 6 and body.count('gs_dot_end(') == 1 and 'gs_pick' not in body[body.index('gs_dot_begin'):body.index('gs_dot_end')]
     assert 'gs_pick(sub ==' in body and 'gs_swap[threadIdx.x]' in body
     assert [line for line in body.split('\n') if 'if (sub ==' in line and 'out[' not in line] == []
-    assert 'consts[sub ==' in src[:src.index('for (unsigned long long k = 0')]      # per-lane MDS constants, loaded before the step loop
+    head = src[:src.index('for (unsigned long long k = 0')]
+    assert head.count('gs_dotk_make(vd') == 6 and 'sub == 5u ? consts[' in head          # per-lane MDS constants in W-form, built before the step loop
+    assert body.count('fe_add(') <= 14                          # the row sums are inside the dots: no tree of 30 additions on every lane
 
     src = generated_trace_source(rescue4x128_air(1024, 16, f, segmented=True), hip_libs[MODULUS_128], tmp_path / 'r', monkeypatch)
-    assert '#define GS_LANES 16u' in src                        # two 4x4 MDS products per step: 16 products of one depth
+    assert '#define GS_LANES 4u' in src or '#define GS_LANES 8u' in src      # 4 x 4 MDS layers as four fused rows each; four S-box members
     body = src[src.index('for (unsigned long long k = 0'):]
     assert body.count('#pragma nounroll') >= 1                  # the inverse S-box: squaring runs of the fixed addition chain
     assert body.count('gs_swap[threadIdx.x] = x;') >= 2         # S-box layers (x^3 and x^(1/3)): one member per lane
+    assert body.count('gs_dot_end(') == 2 and body.count('gs_dot_acc(') >= 8      # two MDS layers per step (the rows' additive constants ride along as terms by one)
 
 
 def test_point_multiplication_inversions_share_a_round(hip_libs, tmp_path, monkeypatch):
