@@ -63,11 +63,18 @@ static std::mutex &g_jit_mutex = *new std::mutex;
 static std::map<std::string, JitKernel> &g_jit_cache = *new std::map<std::string, JitKernel>;   // per process: the lanes of a pool share the compiled programs
 static std::vector<std::thread> &g_jit_builders = *new std::vector<std::thread>;                // guarded by g_jit_mutex
 static std::atomic<bool> g_jit_shutdown{false};
+static std::atomic<int> g_jit_running{0};                   // builders that have not finished yet
 static void jit_join_builders() {
     g_jit_shutdown.store(true);
     std::vector<std::thread> mine;
     { std::lock_guard<std::mutex> g(g_jit_mutex); mine.swap(g_jit_builders); }
-    for (auto &t : mine) if (t.joinable()) t.join();          // a build takes about a second; its result still reaches the disk cache
+    // a build takes a second to a minute and a half (the largest programs of the examples); its result still reaches the disk cache.
+    // Bounded: should a builder ever be stuck (a compiler that died under it), the process still ends — the threads are let go
+    for (int waited = 0; g_jit_running.load() > 0 && waited < 200 * 100; waited++) usleep(10000);
+    for (auto &t : mine) {
+        if (!t.joinable()) continue;
+        if (g_jit_running.load() > 0) t.detach(); else t.join();
+    }
 }
 __attribute__((destructor)) static void jit_library_unload() { jit_join_builders(); }          // dlclose, or exit before the dependencies' finalisers
 
@@ -141,7 +148,34 @@ static std::string jit_preamble() {
          "    a.has = true;\n"
          "    for (int j = 0; j < 5; j++) a.c[j] = 0;\n"
          "}\n"
-         "__device__ __forceinline__ fe gs_dot_end(gs_dot_t &a) { const fe v = gs_dot_fold(a); return a.has ? fe_add(a.partial, v) : v; }\n";
+         "__device__ __forceinline__ fe gs_dot_end(gs_dot_t &a) { const fe v = gs_dot_fold(a); return a.has ? fe_add(a.partial, v) : v; }\n"
+         // the same with the constant as an ordinary element (lane-uniform in the constraint kernels: its limbs are scalar values):
+         // nine shared columns, the four high ones folded once (lz_fold9)
+         "struct gs_dot9_t { long long c[9]; fe partial; bool has; };\n"
+         "__device__ __forceinline__ void gs_dot9_begin(gs_dot9_t &a) { for (int k = 0; k < 9; k++) a.c[k] = 0; a.has = false; }\n"
+         "__device__ __forceinline__ void gs_dot9_acc(gs_dot9_t &a, const fe x, const fe w) {\n"
+         "    const lz u = lz_unpack(x), v = lz_unpack(w);\n"
+         "#pragma unroll\n"
+         "    for (int k = 0; k < 9; k++) {\n"
+         "        long long t = a.c[k];\n"
+         "#pragma unroll\n"
+         "        for (int i = 0; i < 5; i++) { const int j = k - i; if (j >= 0 && j < 5) t += (long long)u.l[i] * v.l[j]; }\n"
+         "        a.c[k] = t;\n"
+         "    }\n"
+         "}\n"
+         "__device__ __forceinline__ fe gs_dot9_fold(gs_dot9_t &a) {\n"
+         "    const lzk K = lzk_make();\n"
+         "    int64_t c[9];\n"
+         "    for (int k = 0; k < 9; k++) c[k] = a.c[k];\n"
+         "    return lz_pack(lz_fold9(c, K));\n"
+         "}\n"
+         "__device__ __forceinline__ void gs_dot9_flush(gs_dot9_t &a) {\n"
+         "    const fe v = gs_dot9_fold(a);\n"
+         "    a.partial = a.has ? fe_add(a.partial, v) : v;\n"
+         "    a.has = true;\n"
+         "    for (int k = 0; k < 9; k++) a.c[k] = 0;\n"
+         "}\n"
+         "__device__ __forceinline__ fe gs_dot9_end(gs_dot9_t &a) { const fe v = gs_dot9_fold(a); return a.has ? fe_add(a.partial, v) : v; }\n";
 #else
     s += "typedef fe gs_dotk;\n"
          "__device__ __forceinline__ void gs_dotk_make(fe &k, const fe c) { k = c; }\n"
@@ -149,7 +183,12 @@ static std::string jit_preamble() {
          "__device__ __forceinline__ void gs_dot_begin(gs_dot_t &a) { a.acc = fe_zero(); }\n"
          "__device__ __forceinline__ void gs_dot_acc(gs_dot_t &a, const fe x, const fe &k) { a.acc = fe_add(a.acc, gs_mul(x, k)); }\n"
          "__device__ __forceinline__ void gs_dot_flush(gs_dot_t &) {}\n"
-         "__device__ __forceinline__ fe gs_dot_end(gs_dot_t &a) { return a.acc; }\n";
+         "__device__ __forceinline__ fe gs_dot_end(gs_dot_t &a) { return a.acc; }\n"
+         "typedef gs_dot_t gs_dot9_t;\n"
+         "__device__ __forceinline__ void gs_dot9_begin(gs_dot_t &a) { a.acc = fe_zero(); }\n"
+         "__device__ __forceinline__ void gs_dot9_acc(gs_dot_t &a, const fe x, const fe k) { a.acc = fe_add(a.acc, gs_mul(x, k)); }\n"
+         "__device__ __forceinline__ void gs_dot9_flush(gs_dot_t &) {}\n"
+         "__device__ __forceinline__ fe gs_dot9_end(gs_dot_t &a) { return a.acc; }\n";
 #endif
     return s;
 }
@@ -315,7 +354,7 @@ static bool jit_body(std::string &s, const JitGen &gen, const uint32_t *code, ui
 // Cheap operations run redundantly on all lanes.  Long exponentiations of one depth and exponent are rounds of their own (one
 // member per lane).  L = 1, 2, 4 or 8 by the widest depth.
 struct SsaNode {
-    enum Kind { ZERO, CONSTV, ROW, STATICV, ADD, SUB, MUL, POWLONG, POWSHORT, OUT, DOT, DEAD } kind = ZERO;
+    enum Kind { ZERO, CONSTV, ROW, ROWN, STATICV, ADD, SUB, MUL, POWLONG, POWSHORT, OUT, DOT, DEAD } kind = ZERO;
     int a = -1, b = -1;        // operand nodes (MUL/ADD/SUB/POWLONG/OUT: a; b for binary) or the index of a constant/register/static
     uint32_t aux = 0;          // POWLONG: constant index of the exponent; POWSHORT: the exponent; OUT: destination register
     int depth = 0;
@@ -350,6 +389,7 @@ static void ssa_recompute_depths(std::vector<SsaNode> &nodes) {
 // of a layer side by side on K lanes, one exchange for the whole layer.  Leaves that are not products by constants ride along with the
 // constant one.  Trees with fewer than two genuine products are left alone.
 static void ssa_fuse_dots(std::vector<SsaNode> &nodes) {
+    if (const char *e = getenv("GSTARK_AIR_JIT_FUSE")) if (e[0] == '0') return;       // diagnostic: the unfused programs (A/B of the generator)
     const int n = (int)nodes.size();
     std::vector<int> uses(n, 0), ops;
     for (const SsaNode &x : nodes) { ssa_operands(x, ops); for (int o : ops) uses[o]++; }
@@ -391,7 +431,8 @@ static void ssa_fuse_dots(std::vector<SsaNode> &nodes) {
     ssa_recompute_depths(nodes);
 }
 
-static bool ssa_build(std::vector<SsaNode> &nodes, const JitGen &gen, const uint32_t *code, uint32_t ninstr, uint32_t vm_regs, bool allow_statics) {
+static bool ssa_build(std::vector<SsaNode> &nodes, const JitGen &gen, const uint32_t *code, uint32_t ninstr, uint32_t vm_regs, bool allow_statics,
+                      bool allow_next = false) {
     std::vector<int> cur(vm_regs, -1);
     auto add = [&](SsaNode n) { nodes.push_back(n); return (int)nodes.size() - 1; };
     auto use = [&](uint32_t r) {
@@ -411,6 +452,10 @@ static bool ssa_build(std::vector<SsaNode> &nodes, const JitGen &gen, const uint
         switch (op) {
             case J_LOADC: n.kind = SsaNode::CONSTV; n.a = (int)a; cur[d] = add(n); break;
             case J_LOADR: n.kind = SsaNode::ROW; n.a = (int)a; cur[d] = add(n); break;
+            case J_LOADN:
+                if (!allow_next) return false;       // (does not occur in trace programs)
+                n.kind = SsaNode::ROWN; n.a = (int)a; cur[d] = add(n);
+                break;
             case J_LOADS:
                 if (!allow_statics) return false;
                 n.kind = SsaNode::STATICV; n.a = (int)a; cur[d] = add(n);
@@ -860,9 +905,24 @@ static JitKernel *jit_get(gs_ctx *c, const std::string &source, const char *entr
     }
     if (g_jit_shutdown.load()) return nullptr;                        // the process is on its way out: interpret, start nothing
     k.compiling = true;
+    // The builders must be joined BEFORE the compiler's libraries are torn down at exit.  hiprtc loads comgr (LLVM) lazily, on its first
+    // compilation, and that library's finalisers are registered THEN: an atexit handler registered earlier would run AFTER them, with a
+    // builder still inside a compiler that no longer exists (seen once on the GPU box: a process that never ended).  So the first
+    // background build of a process is preceded by ONE tiny synchronous compilation on the calling thread (~0.1 s, once per process and
+    // only when something has to be built at all), and the handler is registered after it: LIFO order then runs the join first.
     static std::once_flag at_exit_once;
-    std::call_once(at_exit_once, [] { atexit(jit_join_builders); });   // registered after HIP / hiprtc initialised: runs before their teardown
+    std::call_once(at_exit_once, [] {
+        hiprtcProgram warm;
+        if (hiprtcCreateProgram(&warm, "extern \"C\" __global__ void gs_jit_warm() {}\n", "gs_jit_warm.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS) {
+            const char *opts[] = {"--offload-arch=gfx950"};
+            (void)hiprtcCompileProgram(warm, 1, opts);
+            hiprtcDestroyProgram(&warm);
+        }
+        atexit(jit_join_builders);
+    });
+    g_jit_running.fetch_add(1);
     g_jit_builders.emplace_back([source, path, entry]() {
+        struct Done { ~Done() { g_jit_running.fetch_sub(1); } } done;
         static std::mutex &one_at_a_time = *new std::mutex;   // hiprtc builds one program at a time (two concurrent builds: the second came back empty)
         std::vector<char> code;
         std::string log;
@@ -953,6 +1013,62 @@ int gs_jit_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t ninstr, cons
 }
 
 // ---- constraints -----------------------------------------------------------------------------------------------------------------
+// A constraint program whose linear layers fuse (ssa_fuse_dots) is emitted from its SSA form, node by node: one thread per domain
+// point, no lanes.  A fused row is K x 25 v_mad into nine shared columns and ONE fold (gs_dot9: the constants are lane-uniform, their
+// limbs come out of scalar loads) instead of K products of 84 instructions and K - 1 additions: the 36 MDS products of a Poseidon
+// round are 6 x ~300 instructions instead of 36 x 84 + 30 x 12.
+static bool ssa_emit_flat(std::string &s, const std::vector<SsaNode> &nodes, const JitGen &gen, const uint64_t *soff, const uint64_t *slen) {
+    char buf[256];
+    auto name = [&](int id) {
+        const SsaNode &n = nodes[id];
+        char t[48];
+        if (n.kind == SsaNode::ZERO) return std::string("fe_zero()");
+        if (n.kind == SsaNode::CONSTV) {
+            if (n.a < 0) return std::string("fe_one()");
+            snprintf(t, sizeof t, "consts[%d]", n.a);
+            return std::string(t);
+        }
+        snprintf(t, sizeof t, "v%d", id);
+        return std::string(t);
+    };
+    for (int id = 0; id < (int)nodes.size(); id++) {
+        const SsaNode &n = nodes[id];
+        switch (n.kind) {
+            case SsaNode::ROW: snprintf(buf, sizeof buf, "        const fe v%d = p[%dull * nc + j];\n", id, n.a); s += buf; break;
+            case SsaNode::ROWN: snprintf(buf, sizeof buf, "        const fe v%d = p[%dull * nc + jn];\n", id, n.a); s += buf; break;
+            case SsaNode::STATICV:
+                if (slen[n.a] & (slen[n.a] - 1)) snprintf(buf, sizeof buf, "        const fe v%d = statics[%lluull + j %% %lluull];\n", id, (unsigned long long)soff[n.a], (unsigned long long)slen[n.a]);
+                else snprintf(buf, sizeof buf, "        const fe v%d = statics[%lluull + (j & %lluull)];\n", id, (unsigned long long)soff[n.a], (unsigned long long)(slen[n.a] - 1));
+                s += buf;
+                break;
+            case SsaNode::ADD: s += "        const fe " + name(id) + " = fe_add(" + name(n.a) + ", " + name(n.b) + ");\n"; break;
+            case SsaNode::SUB: s += "        const fe " + name(id) + " = fe_sub(" + name(n.a) + ", " + name(n.b) + ");\n"; break;
+            case SsaNode::MUL: s += "        const fe " + name(id) + " = gs_mul(" + name(n.a) + ", " + name(n.b) + ");\n"; break;
+            case SsaNode::POWSHORT: case SsaNode::POWLONG: {
+                std::vector<uint32_t> e(GS_ELT / 4, 0u);
+                if (n.kind == SsaNode::POWSHORT) e[0] = n.aux;
+                else memcpy(e.data(), gen.consts + (size_t)n.aux * GS_ELT, GS_ELT);
+                s += "        fe " + name(id) + " = " + name(n.a) + ";\n        {\n";
+                emit_pow(s, name(id).c_str(), e);
+                s += "        }\n";
+                break;
+            }
+            case SsaNode::DOT:
+                s += "        fe " + name(id) + ";\n        {\n            gs_dot9_t acc;\n            gs_dot9_begin(acc);\n";
+                for (size_t k = 0; k < n.tx.size(); k++) {
+                    if (k && k % 6 == 0) s += "            gs_dot9_flush(acc);\n";
+                    if (n.tc[k] < 0) s += "            gs_dot9_acc(acc, " + name(n.tx[k]) + ", fe_one());\n";
+                    else { snprintf(buf, sizeof buf, ", consts[%d]);\n", n.tc[k]); s += "            gs_dot9_acc(acc, " + name(n.tx[k]) + buf; }
+                }
+                s += "            " + name(id) + " = gs_dot9_end(acc);\n        }\n";
+                break;
+            case SsaNode::OUT: snprintf(buf, sizeof buf, "        out[%uull * nc + j] = ", n.aux); s += buf + name(n.a) + ";\n"; break;
+            default: break;      // CONSTV / ZERO are named in place, DEAD nodes were absorbed
+        }
+    }
+    return true;
+}
+
 static bool jit_constraints_source(std::string &s, const JitGen &gen, const uint32_t *code, uint32_t ninstr, uint32_t vm_regs, const uint64_t *soff,
                                    const uint64_t *slen) {
     s = jit_preamble();
@@ -963,6 +1079,19 @@ static bool jit_constraints_source(std::string &s, const JitGen &gen, const uint
     s += "    for (unsigned long long j = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; j < nc; j += (unsigned long long)gridDim.x * blockDim.x) {\n"
          "        unsigned long long jn = j + shift;\n"
          "        if (jn >= nc) jn -= nc;\n";
+    {   // linear layers present: the SSA route with fused rows (everything else: the register-by-register generator below)
+        std::vector<SsaNode> nodes;
+        if (ssa_build(nodes, gen, code, ninstr, vm_regs, true, true)) {
+            ssa_fuse_dots(nodes);
+            bool any = false;
+            for (const SsaNode &n : nodes) any |= n.kind == SsaNode::DOT;
+            std::string body;
+            if (any && ssa_emit_flat(body, nodes, gen, soff, slen)) {
+                s += body + "    }\n}\n";
+                return true;
+            }
+        }
+    }
     // loads of trace registers and outputs are memory operations here: rewrite them on the fly
     std::vector<uint32_t> tmp(code, code + 4 * (size_t)ninstr);
     std::string body;

@@ -366,7 +366,7 @@ def test_generic_suite_in_default_auto_mode(tmp_path):
     env.pop('GSTARK_AIR_JIT', None)
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_generic_air.py'), os.path.join(root, 'tests', 'test_lib128.py'),
                         '-m', 'gpu', '-q', '-x', '-k', 'not auto_mode and not background_build and not compiled_air_programs_equal_interpreted', '-p', 'no:cacheprovider'],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 

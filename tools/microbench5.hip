@@ -73,6 +73,17 @@ __global__ __launch_bounds__(128) void k_mulvm(const fe *in, fe *out, const lzw 
 #pragma unroll
     for (int m = 0; m < 16; m++) out[blockIdx.x * 2048 + threadIdx.x + 128 * m] = lz_pack(v[m]);
 }
+// (e) ONE dependent chain of squarings per lane (Rescue's inverse S-box: 127 squarings + 32 products that wait for each other): what a
+// trace kernel with a single wave per SIMD pays per squaring — the floor of the compiled Rescue trace kernel
+__global__ __launch_bounds__(128) void k_sqrchain(const fe *in, fe *out, const lzw *w) {
+    const lzk K = lzk_make();
+    lz v = lz_unpack(in[threadIdx.x]);
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) v = lz_sqr(v, K);
+    }
+    out[blockIdx.x * 2048 + threadIdx.x] = lz_pack(v);
+}
 // (c) 16 packs + unpacks per round
 __global__ __launch_bounds__(128) void k_pack(const fe *in, fe *out, const lzw *w) {
     lz v[16];
@@ -114,10 +125,11 @@ int main(int argc, char **argv) {
         {"lz_pack + lz_unpack + add", k_pack, 16, "per element"},
         {"fe_mul (canonical limbs)", k_femul, 16, "per product"},
         {"lz_mul_vm (Montgomery REDC, radix 2^26)", k_mulvm, 16, "per product"},
+        {"lz_sqr, ONE dependent chain per lane", k_sqrchain, 16, "per squaring"},
     };
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     if (!json) printf("%-50s %10s %10s %10s %10s   ns per wave per SIMD (wall clock; k waves per SIMD forced by LDS size, 128-thread blocks)\n", "core", "1 w/SIMD", "2 w/SIMD", "3 w/SIMD", "4 w/SIMD");
-    double res[5][4];
+    double res[6][4];
     int ei = 0;
     for (auto &e : es) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(e.k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -140,9 +152,9 @@ int main(int argc, char **argv) {
         ei++;
     }
     if (json) {
-        const char *keys[5] = {"dif16_network_ns", "mul_v_ns", "pack_unpack_add_ns", "fe_mul_ns", "mul_vm_ns"};
+        const char *keys[6] = {"dif16_network_ns", "mul_v_ns", "pack_unpack_add_ns", "fe_mul_ns", "mul_vm_ns", "sqr_chain_ns"};
         printf("{\"cus\": %d, \"unit\": \"ns per wave per SIMD at 1,2,3,4 waves per SIMD\"", cus);
-        for (int k = 0; k < 5; k++) printf(", \"%s\": [%.2f, %.2f, %.2f, %.2f]", keys[k], res[k][0], res[k][1], res[k][2], res[k][3]);
+        for (int k = 0; k < 6; k++) printf(", \"%s\": [%.2f, %.2f, %.2f, %.2f]", keys[k], res[k][0], res[k][1], res[k][2], res[k][3]);
         printf("}\n");
     }
     return 0;
