@@ -13,8 +13,12 @@
 // Same arithmetic (the field header the library itself is built from is embedded in the source), same values; any failure to
 // compile falls back to the interpreter.  gs_air_jit_check generates + compiles without a device (CPU test tier).
 #include <hip/hiprtc.h>
+#include <dlfcn.h>
 #include <fcntl.h>
+#include <spawn.h>
+#include <sys/socket.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <thread>
@@ -56,20 +60,26 @@ struct JitKernel {
     bool compiling = false;          // a background thread is building the code object (auto mode)
     std::vector<char> code;          // built (or read from the disk cache) but not loaded yet: the next launch loads it
 };
-// Process-wide state of the compiled programs.  Heap-allocated and never destroyed: a background builder (auto mode) may still be
-// inside hiprtc when the process reaches exit(), and function-/namespace-scope statics would be destroyed under it.  The builders
-// themselves are joined before the HIP / comgr libraries are torn down (jit_join_builders: atexit + library destructor).
+// Process-wide state of the compiled programs.  Heap-allocated and never destroyed: a builder thread may still be running when the
+// process reaches exit(), and function-/namespace-scope statics would be destroyed under it.  Background builds run in a helper
+// process (jit_compile_helper); at exit / dlclose the threads waiting for one are released (their sockets shut down — the helper
+// still finishes and fills the disk cache) and joined; a build running inside this process (no helper installed) is waited for.
 static std::mutex &g_jit_mutex = *new std::mutex;
 static std::map<std::string, JitKernel> &g_jit_cache = *new std::map<std::string, JitKernel>;   // per process: the lanes of a pool share the compiled programs
 static std::vector<std::thread> &g_jit_builders = *new std::vector<std::thread>;                // guarded by g_jit_mutex
+static std::vector<int> &g_jit_helper_fds = *new std::vector<int>;                              // sockets of the helpers being waited for; guarded by g_jit_mutex
 static std::atomic<bool> g_jit_shutdown{false};
-static std::atomic<int> g_jit_running{0};                   // builders that have not finished yet
+static std::atomic<int> g_jit_running{0};                   // builds inside this process that have not finished yet
 static void jit_join_builders() {
     g_jit_shutdown.store(true);
     std::vector<std::thread> mine;
-    { std::lock_guard<std::mutex> g(g_jit_mutex); mine.swap(g_jit_builders); }
-    // a build takes a second to a minute and a half (the largest programs of the examples); its result still reaches the disk cache.
-    // Bounded: should a builder ever be stuck (a compiler that died under it), the process still ends — the threads are let go
+    {
+        std::lock_guard<std::mutex> g(g_jit_mutex);
+        mine.swap(g_jit_builders);
+        for (int fd : g_jit_helper_fds) shutdown(fd, SHUT_RDWR);
+    }
+    // an in-process build takes a second to a minute and a half (the largest programs of the examples); its result still reaches the
+    // disk cache.  Bounded: should a builder ever be stuck (a compiler that died under it), the process still ends — the thread is let go
     for (int waited = 0; g_jit_running.load() > 0 && waited < 200 * 100; waited++) usleep(10000);
     for (auto &t : mine) {
         if (!t.joinable()) continue;
@@ -780,6 +790,96 @@ static bool jit_compile(const std::string &source, const char *entry, std::vecto
     return true;
 }
 
+// ---- background builds run in a helper process (jitc.cc explains why): <directory of this library>/gstark_jitc, or $GSTARK_JITC.
+// 1 = built (code filled; the helper has written the cache file too), 0 = the compiler refused the source (log filled),
+// -1 = no helper / could not be started (the caller compiles in-process, as gs_air_jit(ctx, 1) does)
+extern char **environ;
+static std::string jit_helper_path() {
+    if (const char *e = getenv("GSTARK_JITC")) return e;
+    Dl_info info;
+    if (!dladdr((const void *)&jit_helper_path, &info) || !info.dli_fname) return "";
+    std::string lib = info.dli_fname;
+    const size_t slash = lib.rfind('/');
+    return (slash == std::string::npos ? std::string(".") : lib.substr(0, slash)) + "/gstark_jitc";
+}
+static bool sock_send(int fd, const void *src, size_t n) {
+    const char *p = (const char *)src;
+    while (n) {
+        const ssize_t r = send(fd, p, n, MSG_NOSIGNAL);
+        if (r <= 0) return false;
+        p += r;
+        n -= (size_t)r;
+    }
+    return true;
+}
+static bool sock_recv(int fd, void *dst, size_t n) {
+    char *p = (char *)dst;
+    while (n) {
+        const ssize_t r = recv(fd, p, n, 0);
+        if (r <= 0) return false;
+        p += r;
+        n -= (size_t)r;
+    }
+    return true;
+}
+static int jit_compile_helper(const std::string &source, const char *entry, const std::string &cache_path, std::vector<char> &code, std::string &log) {
+    const std::string helper = jit_helper_path();
+    if (helper.empty() || access(helper.c_str(), X_OK) != 0) return -1;
+    int sv[2];
+    if (socketpair(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0, sv) != 0) return -1;
+    {
+        std::lock_guard<std::mutex> g(g_jit_mutex);
+        if (g_jit_shutdown.load()) { close(sv[0]); close(sv[1]); return 0; }
+        g_jit_helper_fds.push_back(sv[0]);
+    }
+    auto forget = [&] { std::lock_guard<std::mutex> g(g_jit_mutex); g_jit_helper_fds.erase(std::find(g_jit_helper_fds.begin(), g_jit_helper_fds.end(), sv[0])); close(sv[0]); };
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_adddup2(&fa, sv[1], 0);                 // dup2 clears close-on-exec on the copies
+    posix_spawn_file_actions_adddup2(&fa, sv[1], 1);
+    if (!getenv("GSTARK_AIR_JIT_VERBOSE")) posix_spawn_file_actions_addopen(&fa, 2, "/dev/null", O_WRONLY, 0);
+    char *const argv[] = {const_cast<char *>(helper.c_str()), nullptr};
+    pid_t pid = 0;
+    const int rc = posix_spawn(&pid, helper.c_str(), &fa, nullptr, argv, environ);
+    posix_spawn_file_actions_destroy(&fa);
+    close(sv[1]);
+    if (rc != 0) { forget(); return -1; }
+    if (getenv("GSTARK_AIR_JIT_VERBOSE")) fprintf(stderr, "[gstark] %s: built by %s (pid %d), %zu bytes of source\n", entry, helper.c_str(), (int)pid, source.size());
+    const int fd = sv[0];
+    std::vector<std::pair<std::string, const char *>> items;
+    items.push_back({entry, source.c_str()});
+#ifdef GS_JIT_LAZY
+    items.push_back({"gf128.h", kFieldHeader});
+    items.push_back({"gf128_lazy.h", kLazyHeader});
+#else
+    items.push_back({"gs_field.h", kFieldHeader});
+#endif
+    const uint32_t nitems = (uint32_t)items.size();
+    bool ok = sock_send(fd, "GSJ1", 4) && sock_send(fd, &nitems, 4);
+    for (size_t i = 0; ok && i < items.size(); i++) {
+        const uint32_t nl = (uint32_t)items[i].first.size();
+        const uint64_t dl = strlen(items[i].second);
+        ok = sock_send(fd, &nl, 4) && sock_send(fd, items[i].first.data(), nl) && sock_send(fd, &dl, 8) && sock_send(fd, items[i].second, dl);
+    }
+    const uint32_t pl = (uint32_t)cache_path.size();
+    ok = ok && sock_send(fd, &pl, 4) && sock_send(fd, cache_path.data(), pl);
+    char tag[4];
+    uint64_t len = 0;
+    int result = -1;
+    if (ok && sock_recv(fd, tag, 4) && sock_recv(fd, &len, 8) && len <= (256ull << 20)) {
+        std::vector<char> body(len);
+        if (sock_recv(fd, body.data(), len)) {
+            if (memcmp(tag, "GSOK", 4) == 0 && len > 0) { code.swap(body); result = 1; }
+            else if (memcmp(tag, "GSER", 4) == 0) { log.assign(body.begin(), body.end()); result = 0; }
+        }
+    }
+    forget();
+    int status = 0;
+    (void)waitpid(pid, &status, g_jit_shutdown.load() ? WNOHANG : 0);          // reap; the verdict is what came over the socket
+    if (result < 0 && g_jit_shutdown.load()) result = 0;            // released at exit: nothing to fall back to
+    return result;
+}
+
 // ---- code objects on disk: <dir>/<sha256 of the generated source>.hsaco.  A compiled program outlives the process that built it, so
 // "compile when an AIR is instantiated" costs its seconds once per machine, and the default mode (auto) can use compiled programs
 // whenever they already exist without ever making a proof wait for the compiler.
@@ -905,37 +1005,29 @@ static JitKernel *jit_get(gs_ctx *c, const std::string &source, const char *entr
     }
     if (g_jit_shutdown.load()) return nullptr;                        // the process is on its way out: interpret, start nothing
     k.compiling = true;
-    // The builders must be joined BEFORE the compiler's libraries are torn down at exit.  hiprtc loads comgr (LLVM) lazily, on its first
-    // compilation, and that library's finalisers are registered THEN: an atexit handler registered earlier would run AFTER them, with a
-    // builder still inside a compiler that no longer exists (seen once on the GPU box: a process that never ended).  So the first
-    // background build of a process is preceded by ONE tiny synchronous compilation on the calling thread (~0.1 s, once per process and
-    // only when something has to be built at all), and the handler is registered after it: LIFO order then runs the join first.
+    // Background builds run in the helper process: a host that exits meanwhile leaves nothing of the compiler inside THIS process to be
+    // torn down under a running thread.  Only without the helper (not installed next to the library) does the builder compile here, and
+    // then exit waits for it (jit_join_builders, bounded).
     static std::once_flag at_exit_once;
-    std::call_once(at_exit_once, [] {
-        hiprtcProgram warm;
-        if (hiprtcCreateProgram(&warm, "extern \"C\" __global__ void gs_jit_warm() {}\n", "gs_jit_warm.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS) {
-            const char *opts[] = {"--offload-arch=gfx950"};
-            (void)hiprtcCompileProgram(warm, 1, opts);
-            hiprtcDestroyProgram(&warm);
-        }
-        atexit(jit_join_builders);
-    });
-    g_jit_running.fetch_add(1);
+    std::call_once(at_exit_once, [] { atexit(jit_join_builders); });
     g_jit_builders.emplace_back([source, path, entry]() {
-        struct Done { ~Done() { g_jit_running.fetch_sub(1); } } done;
-        static std::mutex &one_at_a_time = *new std::mutex;   // hiprtc builds one program at a time (two concurrent builds: the second came back empty)
         std::vector<char> code;
         std::string log;
-        bool ok = false;
-        {
+        int built = g_jit_shutdown.load() ? 0 : jit_compile_helper(source, entry, path, code, log);
+        if (built < 0) {
+            static std::atomic<bool> told{false};
+            if (!told.exchange(true)) fprintf(stderr, "[gstark] gstark_jitc not found next to the library (%s): AIR programs are compiled inside this process\n", jit_helper_path().c_str());
+            g_jit_running.fetch_add(1);
+            struct Done { ~Done() { g_jit_running.fetch_sub(1); } } done;
+            static std::mutex &one_at_a_time = *new std::mutex;   // hiprtc builds one program at a time (two concurrent builds: the second came back empty)
             std::lock_guard<std::mutex> b(one_at_a_time);
-            if (!g_jit_shutdown.load()) ok = jit_compile(source, entry, code, log);          // queued behind another build at exit: skip
+            built = !g_jit_shutdown.load() && jit_compile(source, entry, code, log) ? 1 : 0;          // queued behind another build at exit: skip
+            if (built == 1) jit_disk_write(path, code);
         }
-        if (!ok && getenv("GSTARK_AIR_JIT_VERBOSE")) fprintf(stderr, "[gstark] background build of %s failed: %.600s\n", entry, log.c_str());
-        if (ok) jit_disk_write(path, code);
+        if (built != 1 && getenv("GSTARK_AIR_JIT_VERBOSE")) fprintf(stderr, "[gstark] background build of %s failed: %.600s\n", entry, log.c_str());
         std::lock_guard<std::mutex> g(g_jit_mutex);
         JitKernel &kk = g_jit_cache[source];
-        if (ok) kk.code.swap(code); else kk.failed = true;
+        if (built == 1) kk.code.swap(code); else kk.failed = true;
         kk.compiling = false;
     });
     return nullptr;
@@ -1136,6 +1228,18 @@ int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const u
 // (code + optional init program), kind 1: constraints.  The "does it build" tier of the tests runs it on machines without a GPU.
 // Test hook (not part of include/gstark.h): where the code object of `source` would be cached under the current environment — the
 // empty string when the cache is disabled or the directory is not private to this user.  Creates the directory like a real build.
+// test hook: one program through the helper process, synchronously.  Returns jit_compile_helper's verdict; *size = bytes of code object
+// (or of the compiler's log), the first min(cap, *size) of which are copied to out
+extern "C" int gs_jit_helper_probe(const char *source, const char *entry, const char *cache_path, char *out, uint64_t cap, uint64_t *size) {
+    std::vector<char> code;
+    std::string log;
+    const int r = jit_compile_helper(source, entry, cache_path ? cache_path : "", code, log);
+    const char *src = r == 1 ? code.data() : log.data();
+    const uint64_t n = r == 1 ? code.size() : log.size();
+    if (size) *size = n;
+    if (out && cap) memcpy(out, src, n < cap ? n : cap);
+    return r;
+}
 extern "C" int gs_jit_cache_path_probe(const char *source, char *out, uint64_t cap) {
     if (!source || !out || !cap) return GS_ERR_ARG;
     const std::string path = jit_cache_path(source, "gs_jit_probe");

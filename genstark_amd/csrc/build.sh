@@ -25,10 +25,14 @@ build_flavour() {   # <object dir> <output> <extra flags>
   for p in "${pids[@]}"; do wait $p; done
   for f in $UNITS; do [ $dir/$f.o -nt $out ] && stale=1; done      # an object compiled by hand is newer than the library too
   if [ $stale = 1 ] || [ ! -f $out ]; then
-    $HIPCC --offload-arch=gfx950 -shared -fPIC -o $out $(for f in $UNITS; do echo $dir/$f.o; done) -lhiprtc
+    $HIPCC --offload-arch=gfx950 -shared -fPIC -o $out $(for f in $UNITS; do echo $dir/$f.o; done) -lhiprtc -ldl
   fi
   echo built $(pwd)/$out
 }
+# the compiler of AIR programs as a process of its own (jitc.cc): background builds of every flavour go through it
+if [ ! -f gstark_jitc ] || [ jitc.cc -nt gstark_jitc ]; then
+  g++ -O2 -std=c++17 -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include jitc.cc -o gstark_jitc -L/opt/rocm/lib -lhiprtc -Wl,-rpath,/opt/rocm/lib
+fi
 build_flavour build libgstark_hip.so "" &
 build_flavour build_q64 libgstark_hip_q64.so "-DGS_SMALL_Q=18446744051160973313ull" &
 build_flavour build_q32 libgstark_hip_q32.so "-DGS_SMALL_Q=4194304001ull" &

@@ -143,3 +143,40 @@ def test_code_object_cache_directory_must_be_private(tmp_path):
     home.mkdir()
     assert _probe({'HOME': str(home)}, drop=('GSTARK_JIT_CACHE_DIR',)).startswith(str(home) + '/.cache/gstark_jit/')
     assert _probe({'GSTARK_JIT_CACHE_DIR': 'off'}) == ''
+
+
+HELPER_SCRIPT = r'''
+import ctypes, os, sys
+lib = ctypes.CDLL(sys.argv[1])
+lib.gs_jit_helper_probe.restype = ctypes.c_int
+good = b'#define GS_SMALL_Q 18446744051160973313ull\n#include "gs_field.h"\nextern "C" __global__ void gs_probe(fe *o) { o[0] = fe_add(o[1], o[2]); }\n' if sys.argv[3] == 'plain' else \
+       b'#include "gf128_lazy.h"\nextern "C" __global__ void gs_probe(fe *o) { o[0] = fe_add(o[1], o[2]); }\n'
+out = ctypes.create_string_buffer(1 << 20)
+size = ctypes.c_uint64(0)
+r = lib.gs_jit_helper_probe(good, b'gs_probe', sys.argv[2].encode(), out, ctypes.c_uint64(len(out)), ctypes.byref(size))
+print('GOOD', r, size.value, out.raw[:4] == b'\x7fELF', os.path.exists(sys.argv[2]) and os.path.getsize(sys.argv[2]) == size.value)
+r = lib.gs_jit_helper_probe(b'this is not HIP\n', b'gs_probe', b'', out, ctypes.c_uint64(len(out)), ctypes.byref(size))
+print('BAD', r, b'error' in out.raw[:size.value])
+'''
+
+
+def test_background_builds_run_in_the_helper_process(tmp_path):
+    """genstark_amd/csrc/jitc.cc: the default (auto) mode never compiles inside the proving process — a host that exits during a
+    build would have the compiler's statics destroyed under the builder thread (seen on the GPU box: 'LLVM ERROR' + abort at exit).
+    One program through gstark_jitc: a gfx950 code object comes back AND is in the cache; a source the compiler refuses comes back
+    as a log; a missing helper is reported as such (-1: the caller then compiles in-process)."""
+    import subprocess
+    import sys
+    from genstark_amd import _abi
+    helper = os.path.join(os.path.dirname(_abi.HIP_LIB_PATH), 'gstark_jitc')
+    assert os.access(helper, os.X_OK), 'genstark_amd/csrc/build.sh builds gstark_jitc next to the libraries'
+    for lib_path, kind in ((_abi.HIP_LIB_PATH, 'lazy'), (HIP_LIB_PATHS[_abi.MODULUS_64], 'plain')):
+        cache = tmp_path / ('probe_%s.hsaco' % kind)
+        r = subprocess.run([sys.executable, '-c', HELPER_SCRIPT, lib_path, str(cache), kind], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = dict((l.split()[0], l.split()[1:]) for l in r.stdout.splitlines() if l.split() and l.split()[0] in ('GOOD', 'BAD'))
+        assert lines['GOOD'][0] == '1' and int(lines['GOOD'][1]) > 1000 and lines['GOOD'][2:] == ['True', 'True'], r.stdout
+        assert lines['BAD'] == ['0', 'True'], r.stdout
+    r = subprocess.run([sys.executable, '-c', HELPER_SCRIPT, _abi.HIP_LIB_PATH, str(tmp_path / 'none.hsaco'), 'lazy'],
+                       env=dict(os.environ, GSTARK_JITC=str(tmp_path / 'no_such_helper')), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'GOOD -1' in r.stdout, r.stdout + r.stderr[-1000:]
