@@ -508,7 +508,16 @@ class GenericAir:
         def check(name, kind, prog, init):
             code, ninstr, consts, nconsts, nregs = prog.abi_args(self.field.elementSize)
             icode, ininstr = init.abi_args(self.field.elementSize)[:2] if init is not None else (None, 0)
-            rc = lib.gs_air_jit_check(kind, code, ninstr, icode, ininstr, consts, nconsts, nregs, self.traceRegisterCount, lens, len(periods), log, len(log))
+            hook = getattr(lib, 'gs_air_jit_check_statics', None) if kind == 0 and not self.secretInputCount else None
+            if hook is not None:
+                # the trace program's source depends on the static tables (0/1 selectors become selects): check what a prover compiles
+                hook.restype = C.c_int
+                hook.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                 C.c_uint32, C.c_char_p, C.c_void_p, C.c_uint64]
+                packed = b''.join(self.field.le(v % self.field.modulus) for values in self.staticRegisters for v in values)
+                rc = hook(kind, code, ninstr, icode, ininstr, consts, nconsts, nregs, self.traceRegisterCount, lens, len(periods), packed or None, log, len(log))
+            else:
+                rc = lib.gs_air_jit_check(kind, code, ninstr, icode, ininstr, consts, nconsts, nregs, self.traceRegisterCount, lens, len(periods), log, len(log))
             out.append((name, rc == GS_OK, log.value.decode(errors='replace')))
         if self.segmentLength is not None:
             check('trace', 0, self.transitionProgram, self.initProgram)

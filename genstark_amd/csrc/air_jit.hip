@@ -27,6 +27,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <memory>
 #include <mutex>
 
 #include "common.h"
@@ -121,6 +123,14 @@ static std::string jit_preamble() {
          "    for (int i = 0; i < (int)(sizeof(fe) / 4); i++) pa[i] = c ? pa[i] : pb[i];\n"
          "    return a;\n"
          "}\n";
+#ifdef GS_JIT_LAZY
+    // f * x for a selector f (a static register whose table is all 0 / 1 when the source is generated): a select; any other value of
+    // f — the table is data, it may change without the program changing — takes the product, so the result never depends on the guess
+    s += "__device__ __forceinline__ fe gs_blend(const fe f, const fe x) {\n"
+         "    if (__builtin_expect((f.w1 | f.w2 | f.w3) != 0u || f.w0 > 1u, 0)) return gs_mul(f, x);\n"
+         "    return gs_pick(f.w0 == 1u, x, fe_zero());\n"
+         "}\n";
+#endif
     // sum_k x_k * c_k on ONE lane (a fused row of a linear layer, ssa_fuse_dots)
 #ifdef GS_JIT_LAZY
     // 128-bit field: the constants in W-form (five pre-shifted copies: no high columns), every term 25 v_mad into five shared 64-bit
@@ -209,6 +219,25 @@ struct JitGen {
     const uint8_t *consts = nullptr;   // host copy, nconsts x GS_ELT bytes
     uint32_t nconsts = 0;
     uint32_t lanes = 1;                // 1, 2 or 4 consecutive lanes per segment (trace kernel only)
+    // trace programs: host copy of the static registers' tables (element soff[s] + i), or null.  A static register whose table holds
+    // only 0 and 1 is a SELECTOR (Poseidon's full / partial round flag): products by it are emitted as selects (SsaNode::BLEND)
+    const uint8_t *statics = nullptr;
+    const uint64_t *soff = nullptr, *slen = nullptr;
+    uint32_t nstatic = 0;
+    bool static_is_binary(uint32_t reg) const {
+#ifdef GS_JIT_LAZY
+        if (!statics || !soff || !slen || reg >= nstatic) return false;
+        for (uint64_t i = 0; i < slen[reg]; i++) {
+            const uint8_t *v = statics + (soff[reg] + i) * GS_ELT;
+            if (v[0] > 1) return false;
+            for (int b = 1; b < GS_ELT; b++) if (v[b]) return false;
+        }
+        return slen[reg] > 0;
+#else
+        (void)reg;
+        return false;
+#endif
+    }
 };
 
 // x <- x^e as a fixed addition chain: left-to-right sliding windows over the bits of e (little-endian 32-bit limbs), the window
@@ -364,8 +393,8 @@ static bool jit_body(std::string &s, const JitGen &gen, const uint32_t *code, ui
 // Cheap operations run redundantly on all lanes.  Long exponentiations of one depth and exponent are rounds of their own (one
 // member per lane).  L = 1, 2, 4 or 8 by the widest depth.
 struct SsaNode {
-    enum Kind { ZERO, CONSTV, ROW, ROWN, STATICV, ADD, SUB, MUL, POWLONG, POWSHORT, OUT, DOT, DEAD } kind = ZERO;
-    int a = -1, b = -1;        // operand nodes (MUL/ADD/SUB/POWLONG/OUT: a; b for binary) or the index of a constant/register/static
+    enum Kind { ZERO, CONSTV, ROW, ROWN, STATICV, ADD, SUB, MUL, POWLONG, POWSHORT, OUT, DOT, DEAD, BLEND } kind = ZERO;
+    int a = -1, b = -1;        // operand nodes (MUL/ADD/SUB/POWLONG/OUT: a; b for binary; BLEND: a = the selector, b = the value) or the index of a constant/register/static
     uint32_t aux = 0;          // POWLONG: constant index of the exponent; POWSHORT: the exponent; OUT: destination register
     int depth = 0;
     // DOT: sum_k value(tx[k]) * consts[tc[k]]  (tc[k] = -1: the literal one) — a linear layer's row (an MDS matrix times the state) fused
@@ -375,7 +404,7 @@ struct SsaNode {
 static void ssa_operands(const SsaNode &x, std::vector<int> &out) {
     out.clear();
     switch (x.kind) {
-        case SsaNode::ADD: case SsaNode::SUB: case SsaNode::MUL: out.push_back(x.a); out.push_back(x.b); break;
+        case SsaNode::ADD: case SsaNode::SUB: case SsaNode::MUL: case SsaNode::BLEND: out.push_back(x.a); out.push_back(x.b); break;
         case SsaNode::POWLONG: case SsaNode::POWSHORT: case SsaNode::OUT: out.push_back(x.a); break;
         case SsaNode::DOT: out = x.tx; break;
         default: break;
@@ -473,6 +502,19 @@ static bool ssa_build(std::vector<SsaNode> &nodes, const JitGen &gen, const uint
             case J_ADDV: case J_SUBV: case J_MULV: {
                 if (a >= vm_regs || b >= vm_regs) return false;
                 const int x = use(a), y = use(b);
+                if (op == J_MULV) {
+                    // a product by a 0/1 selector is a select: cheap, on every lane, no round of its own (gs_blend still multiplies
+                    // should the table ever hold anything else)
+                    const bool fx = nodes[x].kind == SsaNode::STATICV && gen.static_is_binary((uint32_t)nodes[x].a);
+                    const bool fy = nodes[y].kind == SsaNode::STATICV && gen.static_is_binary((uint32_t)nodes[y].a);
+                    if (fx || fy) {
+                        SsaNode bl;
+                        bl.kind = SsaNode::BLEND; bl.a = fx ? x : y; bl.b = fx ? y : x;
+                        bl.depth = std::max(nodes[x].depth, nodes[y].depth);
+                        cur[d] = add(bl);
+                        break;
+                    }
+                }
                 cur[d] = binary(op == J_ADDV ? SsaNode::ADD : (op == J_SUBV ? SsaNode::SUB : SsaNode::MUL), x, y);
                 break;
             }
@@ -743,6 +785,7 @@ static void ssa_emit(std::string &s, std::string &hoisted, std::vector<bool> &co
                 }
                 case SsaNode::ADD: s += "        const fe " + name(id) + " = fe_add(" + name(n.a) + ", " + name(n.b) + ");\n"; break;
                 case SsaNode::SUB: s += "        const fe " + name(id) + " = fe_sub(" + name(n.a) + ", " + name(n.b) + ");\n"; break;
+                case SsaNode::BLEND: s += "        const fe " + name(id) + " = gs_blend(" + name(n.a) + ", " + name(n.b) + ");\n"; break;
                 case SsaNode::OUT: snprintf(buf, sizeof buf, "        %s%u = ", sink, n.aux); s += buf + name(n.a) + ";\n"; break;
                 default: break;
             }
@@ -1033,6 +1076,26 @@ static JitKernel *jit_get(gs_ctx *c, const std::string &source, const char *entr
     return nullptr;
 }
 
+// ---- generated sources, remembered.  Turning a program into source (SSA, scheduling, ~10 KB of text) costs ~0.1 ms of host time — per
+// proof, if done per call, and a Poseidon proof is 1.5 ms.  The inputs of the generator — program(s), constants, static layout and,
+// for trace programs, which static registers are 0/1 selectors — are concatenated into a key (a ~10 KB memcpy + one map lookup);
+// the source (itself the key of the code-object cache) and the lane count are generated once per key and process.
+struct JitSource { std::string source; uint32_t lanes = 1; bool ok = false; };
+static std::mutex &g_src_mutex = *new std::mutex;
+static std::map<std::string, std::shared_ptr<JitSource>> &g_src_memo = *new std::map<std::string, std::shared_ptr<JitSource>>;
+static void key_add(std::string &k, const void *p, size_t n) { const uint64_t len = n; k.append((const char *)&len, 8); if (n) k.append((const char *)p, n); }
+template <class Make>
+static std::shared_ptr<const JitSource> jit_source_memo(const std::string &key, Make make) {
+    std::lock_guard<std::mutex> g(g_src_mutex);
+    auto it = g_src_memo.find(key);
+    if (it == g_src_memo.end()) {
+        if (g_src_memo.size() > 256) g_src_memo.clear();          // a host cycling through hundreds of AIRs: start over rather than grow (callers hold their entry)
+        it = g_src_memo.emplace(key, std::make_shared<JitSource>()).first;
+        make(*it->second);
+    }
+    return it->second;
+}
+
 // ---- trace segments --------------------------------------------------------------------------------------------------------------
 // returns GS_OK when the compiled kernel was launched, GS_ERR_UNSUPPORTED when the caller should interpret instead
 static bool jit_trace_source(std::string &s, JitGen &gen, const uint32_t *code, uint32_t ninstr, const uint32_t *icode, uint32_t init_ninstr,
@@ -1085,13 +1148,31 @@ static bool jit_trace_source(std::string &s, JitGen &gen, const uint32_t *code, 
 }
 
 int gs_jit_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const uint32_t *icode, uint32_t init_ninstr, const uint8_t *consts_host,
-                          uint32_t nconsts, uint32_t vm_regs, uint32_t registers, const uint64_t *soff, const uint64_t *slen, const fe *dconst,
-                          const fe *dstat, const fe *drows, uint64_t segments, uint64_t seglen, fe *out) {
-    std::string s;
+                          uint32_t nconsts, uint32_t vm_regs, uint32_t registers, const uint64_t *soff, const uint64_t *slen, const uint8_t *statics_host,
+                          uint32_t nstatic, const fe *dconst, const fe *dstat, const fe *drows, uint64_t segments, uint64_t seglen, fe *out) {
     JitGen gen;
     gen.consts = consts_host;
     gen.nconsts = nconsts;
-    if (!jit_trace_source(s, gen, code, ninstr, icode, init_ninstr, vm_regs, registers, soff, slen)) return GS_ERR_UNSUPPORTED;
+    gen.statics = statics_host;
+    gen.soff = soff;
+    gen.slen = slen;
+    gen.nstatic = nstatic;
+    std::string key("T");
+    key_add(key, code, (size_t)ninstr * 16);
+    key_add(key, icode, (size_t)init_ninstr * 16);
+    key_add(key, consts_host, (size_t)nconsts * GS_ELT);
+    key_add(key, soff, sizeof(uint64_t) * GS_AIR_MAX_REGISTERS);
+    key_add(key, slen, sizeof(uint64_t) * GS_AIR_MAX_REGISTERS);
+    const uint32_t shape[3] = {vm_regs, registers, nstatic};
+    key_add(key, shape, sizeof shape);
+    for (uint32_t r = 0; r < nstatic; r++) key.push_back(gen.static_is_binary(r) ? '1' : '0');
+    const std::shared_ptr<const JitSource> src = jit_source_memo(key, [&](JitSource &js) {
+        js.ok = jit_trace_source(js.source, gen, code, ninstr, icode, init_ninstr, vm_regs, registers, soff, slen);
+        js.lanes = gen.lanes;
+    });
+    if (!src->ok) return GS_ERR_UNSUPPORTED;
+    gen.lanes = src->lanes;
+    const std::string &s = src->source;
     JitKernel *k = jit_get(c, s, "gs_jit_trace");
     if (!k) return GS_ERR_UNSUPPORTED;
     unsigned long long a_segments = segments, a_seglen = seglen;
@@ -1208,12 +1289,19 @@ static bool jit_constraints_source(std::string &s, const JitGen &gen, const uint
 int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs,
                        uint32_t registers, const uint64_t *soff, const uint64_t *slen, const fe *dconst, const fe *p, uint64_t nc, uint64_t shift,
                        const fe *statics, fe *out) {
-    (void)registers;
-    std::string s;
     JitGen gen;
     gen.consts = consts_host;
     gen.nconsts = nconsts;
-    if (!jit_constraints_source(s, gen, code, ninstr, vm_regs, soff, slen)) return GS_ERR_UNSUPPORTED;
+    std::string key("C");
+    key_add(key, code, (size_t)ninstr * 16);
+    key_add(key, consts_host, (size_t)nconsts * GS_ELT);
+    key_add(key, soff, sizeof(uint64_t) * GS_AIR_MAX_REGISTERS);
+    key_add(key, slen, sizeof(uint64_t) * GS_AIR_MAX_REGISTERS);
+    const uint32_t shape[2] = {vm_regs, registers};
+    key_add(key, shape, sizeof shape);
+    const std::shared_ptr<const JitSource> src = jit_source_memo(key, [&](JitSource &js) { js.ok = jit_constraints_source(js.source, gen, code, ninstr, vm_regs, soff, slen); });
+    if (!src->ok) return GS_ERR_UNSUPPORTED;
+    const std::string &s = src->source;
     JitKernel *k = jit_get(c, s, "gs_jit_constraints");
     if (!k) return GS_ERR_UNSUPPORTED;
     unsigned long long a_nc = nc, a_shift = shift;
@@ -1247,9 +1335,11 @@ extern "C" int gs_jit_cache_path_probe(const char *source, char *out, uint64_t c
     return GS_OK;
 }
 
-extern "C" int gs_air_jit_check(int kind, const uint32_t *code, uint32_t ninstr, const uint32_t *init_code, uint32_t init_ninstr,
-                                const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs, uint32_t registers, const uint64_t *static_lens,
-                                uint32_t nstatic, char *log_out, uint64_t log_cap) {
+// gs_air_jit_check with the tables of the static registers (trace programs: products by 0/1 selectors become selects, so the source
+// a prover compiles depends on them); not part of the ABI — a hook of this library for AirObject.compileCheck and the CPU test tier
+extern "C" int gs_air_jit_check_statics(int kind, const uint32_t *code, uint32_t ninstr, const uint32_t *init_code, uint32_t init_ninstr,
+                                        const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs, uint32_t registers, const uint64_t *static_lens,
+                                        uint32_t nstatic, const uint8_t *static_values_host, char *log_out, uint64_t log_cap) {
     if (!code || !ninstr || nstatic > GS_AIR_MAX_REGISTERS || (nstatic && !static_lens) || (nconsts && !consts_host)) return GS_ERR_ARG;
     JitGen gen;
     gen.consts = consts_host;
@@ -1260,11 +1350,21 @@ extern "C" int gs_air_jit_check(int kind, const uint32_t *code, uint32_t ninstr,
         slen[s] = s < nstatic ? static_lens[s] : 1;
         if (s < nstatic) off += static_lens[s];
     }
+    if (kind == 0 && static_values_host) { gen.statics = static_values_host; gen.soff = soff; gen.slen = slen; gen.nstatic = nstatic; }
     std::string src, log;
+    const auto t0 = std::chrono::steady_clock::now();
     const bool ok = kind == 0 ? jit_trace_source(src, gen, code, ninstr, init_code, init_ninstr, vm_regs, registers, soff, slen)
                               : jit_constraints_source(src, gen, code, ninstr, vm_regs, soff, slen);
+    if (getenv("GSTARK_AIR_JIT_VERBOSE"))
+        fprintf(stderr, "[gstark] source of the %s program generated in %.1f us (%zu bytes)\n", kind == 0 ? "trace" : "constraint",
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), src.size());
     std::vector<char> obj;
     const bool built = ok && jit_compile(src, kind == 0 ? "gs_jit_trace" : "gs_jit_constraints", obj, log);
     if (log_out && log_cap) snprintf(log_out, log_cap, "%s", !ok ? "the program has an instruction the generator does not know" : log.c_str());
     return built ? GS_OK : GS_ERR_UNSUPPORTED;
+}
+extern "C" int gs_air_jit_check(int kind, const uint32_t *code, uint32_t ninstr, const uint32_t *init_code, uint32_t init_ninstr,
+                                const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs, uint32_t registers, const uint64_t *static_lens,
+                                uint32_t nstatic, char *log_out, uint64_t log_cap) {
+    return gs_air_jit_check_statics(kind, code, ninstr, init_code, init_ninstr, consts_host, nconsts, vm_regs, registers, static_lens, nstatic, nullptr, log_out, log_cap);
 }

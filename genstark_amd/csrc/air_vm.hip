@@ -485,7 +485,7 @@ int gs_air_trace_segments(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr,
     const uint4 *dcode = (const uint4 *)p, *dinit = (const uint4 *)(p + main_b);
     const fe *dconst = (const fe *)(p + code_b), *dstat = (const fe *)(p + code_b + const_b), *drows = (const fe *)(p + code_b + const_b + stat_b);
     if (c->air_jit) {   // compiled form of the program (air_jit.hip); the interpreter below is the fallback
-        int jrc = gs_jit_trace_segments(c, code_host, ninstr, init_code_host, init_ninstr, consts_host, nconsts, vm_regs, registers, sd.offset, sd.len, dconst, dstat, drows,
+        int jrc = gs_jit_trace_segments(c, code_host, ninstr, init_code_host, init_ninstr, consts_host, nconsts, vm_regs, registers, sd.offset, sd.len, nstat ? static_values_host : nullptr, nstatic, dconst, dstat, drows,
                                         segments, segment_len, (fe *)out);
         if (jrc == GS_OK) { gs_tmp_free(c, d); return GS_OK; }
     }

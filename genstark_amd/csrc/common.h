@@ -134,8 +134,8 @@ static inline unsigned gs_grid(uint64_t work_items, unsigned block = 256, unsign
 
 // air_jit.hip: GS_OK = the compiled kernel was launched, GS_ERR_UNSUPPORTED = interpret instead
 int gs_jit_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const uint32_t *icode, uint32_t init_ninstr, const uint8_t *consts_host,
-                          uint32_t nconsts, uint32_t vm_regs, uint32_t registers, const uint64_t *soff, const uint64_t *slen, const fe *dconst,
-                          const fe *dstat, const fe *drows, uint64_t segments, uint64_t seglen, fe *out);
+                          uint32_t nconsts, uint32_t vm_regs, uint32_t registers, const uint64_t *soff, const uint64_t *slen, const uint8_t *statics_host,
+                          uint32_t nstatic, const fe *dconst, const fe *dstat, const fe *drows, uint64_t segments, uint64_t seglen, fe *out);
 int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs,
                        uint32_t registers, const uint64_t *soff, const uint64_t *slen, const fe *dconst, const fe *p, uint64_t nc, uint64_t shift,
                        const fe *statics, fe *out);

@@ -69,7 +69,10 @@ def test_trace_kernels_spread_products_over_lanes(oracle_backend, hip_libs, tmp_
     # the 6 x 6 MDS layer is SIX fused rows (ssa_fuse_dots: a row = one lane's 6 x 25 v_mad + one fold), not 36 products over 16 lanes
     assert '#define GS_LANES 8u' in src
     body = src[src.index('for (unsigned long long k = 0'):]
-    assert body.count('gs_mul(') + body.count('gs_sqr(') <= 5   # per lane and step: the x^5 chain + the blend product; the MDS is a dot
+    assert body.count('gs_mul(') + body.count('gs_sqr(') == 3   # per lane and step: the x^5 chain; the MDS is a dot, and ...
+    # ... the full / partial round flag (a static register of zeros and ones) selects instead of multiplying, on every lane, between
+    # the two rounds: a step is TWO exchanges (S-box layer, MDS rows)
+    assert body.count('gs_blend(v') == 5 and body.count('gs_swap[threadIdx.x] =') == 2
     assert body.count('gs_dot_acc(') == 6 and body.count('gs_dot_end(') == 1 and 'gs_pick' not in body[body.index('gs_dot_begin'):body.index('gs_dot_end')]
     assert 'gs_pick(sub ==' in body and 'gs_swap[threadIdx.x]' in body
     assert [line for line in body.split('\n') if 'if (sub ==' in line and 'out[' not in line] == []
