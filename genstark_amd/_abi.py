@@ -114,6 +114,8 @@ _SIGNATURES = {
     'gs_air_trace': (_int, [_vp, C.POINTER(_u32), _u32, _bytes, _u32, _u32, _u32, _bytes, C.POINTER(_u32), _u32, _bytes, _u64, _vp]),
     'gs_air_constraints': (_int, [_vp, C.POINTER(_u32), _u32, _bytes, _u32, _u32, _u32, _u32, _vp, _u64, _u64, _vp,
                                   C.POINTER(_u64), _u32, _vp]),
+    'gs_air_constraints_strided': (_int, [_vp, C.POINTER(_u32), _u32, _bytes, _u32, _u32, _u32, _u32, _vp, _u64, _u64, _u64, _u64, _vp,
+                                          C.POINTER(_u64), _u32, _vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

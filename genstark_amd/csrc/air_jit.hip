@@ -1207,8 +1207,8 @@ static bool ssa_emit_flat(std::string &s, const std::vector<SsaNode> &nodes, con
     for (int id = 0; id < (int)nodes.size(); id++) {
         const SsaNode &n = nodes[id];
         switch (n.kind) {
-            case SsaNode::ROW: snprintf(buf, sizeof buf, "        const fe v%d = p[%dull * nc + j];\n", id, n.a); s += buf; break;
-            case SsaNode::ROWN: snprintf(buf, sizeof buf, "        const fe v%d = p[%dull * nc + jn];\n", id, n.a); s += buf; break;
+            case SsaNode::ROW: snprintf(buf, sizeof buf, "        const fe v%d = p[%dull * prow + jp];\n", id, n.a); s += buf; break;
+            case SsaNode::ROWN: snprintf(buf, sizeof buf, "        const fe v%d = p[%dull * prow + jnp];\n", id, n.a); s += buf; break;
             case SsaNode::STATICV:
                 if (slen[n.a] & (slen[n.a] - 1)) snprintf(buf, sizeof buf, "        const fe v%d = statics[%lluull + j %% %lluull];\n", id, (unsigned long long)soff[n.a], (unsigned long long)slen[n.a]);
                 else snprintf(buf, sizeof buf, "        const fe v%d = statics[%lluull + (j & %lluull)];\n", id, (unsigned long long)soff[n.a], (unsigned long long)(slen[n.a] - 1));
@@ -1246,12 +1246,16 @@ static bool jit_constraints_source(std::string &s, const JitGen &gen, const uint
                                    const uint64_t *slen) {
     s = jit_preamble();
     char buf[256];
+    // register r at point j is p[r * prow + j * pstride]: the columns may be those of a larger domain read with a stride (the composition
+    // domain inside the evaluation domain: gs_air_constraints_strided) — no plucked copy of the trace extension
     s += "extern \"C\" __global__ __launch_bounds__(128) void gs_jit_constraints(const fe *__restrict__ consts, const fe *__restrict__ p, unsigned long long nc,\n"
-         "                                               unsigned long long shift, const fe *__restrict__ statics, fe *__restrict__ out) {\n";
+         "                                               unsigned long long shift, const fe *__restrict__ statics, fe *__restrict__ out,\n"
+         "                                               unsigned long long prow, unsigned long long pstride) {\n";
     for (uint32_t t = 0; t < vm_regs; t++) { snprintf(buf, sizeof buf, "    fe t%u;\n", t); s += buf; }
     s += "    for (unsigned long long j = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; j < nc; j += (unsigned long long)gridDim.x * blockDim.x) {\n"
          "        unsigned long long jn = j + shift;\n"
-         "        if (jn >= nc) jn -= nc;\n";
+         "        if (jn >= nc) jn -= nc;\n"
+         "        const unsigned long long jp = j * pstride, jnp = jn * pstride;\n";
     {   // linear layers present: the SSA route with fused rows (everything else: the register-by-register generator below)
         std::vector<SsaNode> nodes;
         if (ssa_build(nodes, gen, code, ninstr, vm_regs, true, true)) {
@@ -1270,8 +1274,8 @@ static bool jit_constraints_source(std::string &s, const JitGen &gen, const uint
     std::string body;
     for (uint32_t pc = 0; pc < ninstr; pc++) {
         const uint32_t op = tmp[4 * pc], d = tmp[4 * pc + 1], a = tmp[4 * pc + 2];
-        if (op == J_LOADR) { snprintf(buf, sizeof buf, "        t%u = p[%uull * nc + j];\n", d, a); body += buf; }
-        else if (op == J_LOADN) { snprintf(buf, sizeof buf, "        t%u = p[%uull * nc + jn];\n", d, a); body += buf; }
+        if (op == J_LOADR) { snprintf(buf, sizeof buf, "        t%u = p[%uull * prow + jp];\n", d, a); body += buf; }
+        else if (op == J_LOADN) { snprintf(buf, sizeof buf, "        t%u = p[%uull * prow + jnp];\n", d, a); body += buf; }
         else if (op == J_OUT) { snprintf(buf, sizeof buf, "        out[%uull * nc + j] = t%u;\n", d, a); body += buf; }
         else {
             // runs of arithmetic go through the common generator (so that exponentiation groups are found)
@@ -1288,7 +1292,7 @@ static bool jit_constraints_source(std::string &s, const JitGen &gen, const uint
 
 int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs,
                        uint32_t registers, const uint64_t *soff, const uint64_t *slen, const fe *dconst, const fe *p, uint64_t nc, uint64_t shift,
-                       const fe *statics, fe *out) {
+                       const fe *statics, fe *out, uint64_t prow, uint64_t pstride) {
     JitGen gen;
     gen.consts = consts_host;
     gen.nconsts = nconsts;
@@ -1304,8 +1308,8 @@ int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const u
     const std::string &s = src->source;
     JitKernel *k = jit_get(c, s, "gs_jit_constraints");
     if (!k) return GS_ERR_UNSUPPORTED;
-    unsigned long long a_nc = nc, a_shift = shift;
-    void *args[] = {(void *)&dconst, (void *)&p, (void *)&a_nc, (void *)&a_shift, (void *)&statics, (void *)&out};
+    unsigned long long a_nc = nc, a_shift = shift, a_prow = prow, a_pstride = pstride;
+    void *args[] = {(void *)&dconst, (void *)&p, (void *)&a_nc, (void *)&a_shift, (void *)&statics, (void *)&out, (void *)&a_prow, (void *)&a_pstride};
     const unsigned block = 128, grid = gs_grid(nc, block, 256 * 16);
     if (hipModuleLaunchKernel(k->fn, grid, 1, 1, block, 1, 1, 0, c->stream, args, nullptr) != hipSuccess) return GS_ERR_UNSUPPORTED;
     c->jit_launches++;

@@ -24,18 +24,19 @@ struct StaticDesc {
 template <int NREG>
 __global__ void k_air_constraints(const uint4 *__restrict__ code, uint32_t ninstr, const fe *__restrict__ consts,
                                   const fe *__restrict__ p, uint64_t nc, uint64_t shift, const fe *__restrict__ statics, StaticDesc sd,
-                                  fe *__restrict__ out) {
+                                  fe *__restrict__ out, uint64_t prow, uint64_t pstride) {
     for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < nc; j += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t jn = j + shift;
         if (jn >= nc) jn -= nc;
+        const uint64_t jp = j * pstride, jnp = jn * pstride;      // register a at point j: p[a * prow + j * pstride]
         fe vm[NREG];
         for (uint32_t pc = 0; pc < ninstr; pc++) {
             const uint4 ins = code[pc];
             const uint32_t dst = ins.y, a = ins.z, b = ins.w;
             switch (ins.x) {
                 case OP_LOADC: vm[dst] = consts[a]; break;
-                case OP_LOADR: vm[dst] = p[(uint64_t)a * nc + j]; break;
-                case OP_LOADN: vm[dst] = p[(uint64_t)a * nc + jn]; break;
+                case OP_LOADR: vm[dst] = p[(uint64_t)a * prow + jp]; break;
+                case OP_LOADN: vm[dst] = p[(uint64_t)a * prow + jnp]; break;
                 case OP_LOADS: vm[dst] = statics[sd.offset[a] + j % sd.len[a]]; break;
                 case OP_ADDV: vm[dst] = fe_add(vm[a], vm[b]); break;
                 case OP_SUBV: vm[dst] = fe_sub(vm[a], vm[b]); break;
@@ -383,10 +384,20 @@ extern "C" {
 int gs_air_constraints(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs,
                        uint32_t registers, uint32_t constraints, const void *p_comp, uint64_t nc, uint64_t shift, const void *static_tables,
                        const uint64_t *static_lens_host, uint32_t nstatic, void *out) {
+    return gs_air_constraints_strided(c, code_host, ninstr, consts_host, nconsts, vm_regs, registers, constraints, p_comp, nc, 1, nc, shift, static_tables,
+                                      static_lens_host, nstatic, out);
+}
+
+int gs_air_constraints_strided(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs,
+                               uint32_t registers, uint32_t constraints, const void *p_comp, uint64_t prow, uint64_t pstride, uint64_t nc, uint64_t shift,
+                               const void *static_tables, const uint64_t *static_lens_host, uint32_t nstatic, void *out) {
     if (!c || !p_comp || !out || (!consts_host && nconsts) || (nstatic && (!static_tables || !static_lens_host))) return GS_ERR_ARG;
     int rc = check_program(c, code_host, ninstr, nconsts, vm_regs, registers, nstatic, constraints, true);
     if (rc) return rc;
     if (!nc) return gs_fail(c, GS_ERR_ARG, "air_constraints: empty domain");
+    if (!pstride || (nc - 1) > (UINT64_MAX / pstride) || (nc - 1) * pstride >= prow)
+        return gs_fail(c, GS_ERR_ARG, "air_constraints: %llu points at stride %llu do not fit rows of %llu elements", (unsigned long long)nc,
+                       (unsigned long long)pstride, (unsigned long long)prow);
     StaticDesc sd;
     uint64_t off = 0;
     for (uint32_t s = 0; s < GS_AIR_MAX_REGISTERS; s++) {
@@ -415,18 +426,18 @@ int gs_air_constraints(gs_ctx *c, const uint32_t *code_host, uint32_t ninstr, co
     }
     if (c->air_jit) {   // compiled form of the program (air_jit.hip); the interpreter below is the fallback
         int jrc = gs_jit_constraints(c, code_host, ninstr, consts_host, nconsts, vm_regs, registers, sd.offset, sd.len, (const fe *)((uint8_t *)dprog + code_bytes),
-                                     (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, (fe *)out);
+                                     (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, (fe *)out, prow, pstride);
         if (jrc == GS_OK) { gs_tmp_free(c, dprog); return GS_OK; }
     }
     const uint4 *dcode = (const uint4 *)dprog;
     const fe *dconst = (const fe *)((uint8_t *)dprog + code_bytes);
     dim3 grid(gs_grid(nc)), block(256);
     if (vm_regs <= 16)
-        hipLaunchKernelGGL(k_air_constraints<16>, grid, block, 0, c->stream, dcode, ninstr, dconst, (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, sd, (fe *)out);
+        hipLaunchKernelGGL(k_air_constraints<16>, grid, block, 0, c->stream, dcode, ninstr, dconst, (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, sd, (fe *)out, prow, pstride);
     else if (vm_regs <= 32)
-        hipLaunchKernelGGL(k_air_constraints<32>, grid, block, 0, c->stream, dcode, ninstr, dconst, (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, sd, (fe *)out);
+        hipLaunchKernelGGL(k_air_constraints<32>, grid, block, 0, c->stream, dcode, ninstr, dconst, (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, sd, (fe *)out, prow, pstride);
     else
-        hipLaunchKernelGGL(k_air_constraints<64>, grid, block, 0, c->stream, dcode, ninstr, dconst, (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, sd, (fe *)out);
+        hipLaunchKernelGGL(k_air_constraints<64>, grid, block, 0, c->stream, dcode, ninstr, dconst, (const fe *)p_comp, nc, shift % nc, (const fe *)static_tables, sd, (fe *)out, prow, pstride);
     hipError_t e = hipGetLastError();
     gs_tmp_free(c, dprog);  // stream-ordered reuse: later users of the block are queued behind this kernel
     if (e != hipSuccess) return gs_fail(c, GS_ERR_DEVICE, "air_constraints launch: %s", hipGetErrorString(e));

@@ -138,7 +138,7 @@ int gs_jit_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t ninstr, cons
                           uint32_t nstatic, const fe *dconst, const fe *dstat, const fe *drows, uint64_t segments, uint64_t seglen, fe *out);
 int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts, uint32_t vm_regs,
                        uint32_t registers, const uint64_t *soff, const uint64_t *slen, const fe *dconst, const fe *p, uint64_t nc, uint64_t shift,
-                       const fe *statics, fe *out);
+                       const fe *statics, fe *out, uint64_t prow, uint64_t pstride);
 
 // NTT entry points implemented in ntt.hip and used by other units
 void gs_plans_destroy(gs_ctx *c);

@@ -43,7 +43,7 @@ namespace {
     X(gs_eval_polys_at_roots) X(gs_interpolate_roots) X(gs_interpolate_quartic_domain) X(gs_eval_quartic_batch)                \
     X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_commit_rows) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
     X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
-    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end) X(gs_readback_post) X(gs_readback_wait) X(gs_merkle_commit_rows_seed) X(gs_fri_fold_at) \
+    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_air_constraints_strided) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end) X(gs_readback_post) X(gs_readback_wait) X(gs_merkle_commit_rows_seed) X(gs_fri_fold_at) \
     X(gs_vec_mul_scalar) X(gs_copy) X(gs_gather_words) X(gs_transpose_records) X(gs_fri_fold_seeded_scaled) X(gs_fri_layers) X(gs_sync) X(gs_zero_poly_inverses_coset) X(gs_div_by_domain_roots_coset)
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
@@ -745,10 +745,9 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         } else {
             // P over the composition domain is every (N/Nc)-th element of the extension just computed (:76)
             // (the R rows are one contiguous R x N matrix and N / Nc divides N: ONE strided pick over the whole matrix gives R x Nc)
-            Buf pComp(x, (uint64_t)R * Nc * ELEM);
-            x.check(A.gs_pluck(x.c, pEval.p, (uint64_t)R * N, N / Nc, (uint64_t)R * Nc, pComp.p), "gs_pluck(P over the composition domain)");
-            x.check(A.gs_air_constraints(x.c, air.e_code, air.e_ninstr, air.consts, air.nconsts, air.vm_regs, R, air.nconstraints, pComp.p, Nc,
-                                         Nc / T, air.static_tables, air.static_lens, air.nstatic, q.p), "gs_air_constraints");
+            // — read in place, with that stride: no plucked copy (R x Nc elements written and read again)
+            x.check(A.gs_air_constraints_strided(x.c, air.e_code, air.e_ninstr, air.consts, air.nconsts, air.vm_regs, R, air.nconstraints, pEval.p, N, N / Nc,
+                                                 Nc, Nc / T, air.static_tables, air.static_lens, air.nstatic, q.p), "gs_air_constraints_strided");
         }
         // 5.2 degree adjustment (:83-101) and 5.3 merge + extension (:103-111): the adjusted vectors q_i o powers are not
         // materialised — gs_combine_adjusted merges sum k_i q_i + powers o sum k'_i q_i in one pass (one further pass per additional

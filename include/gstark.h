@@ -374,6 +374,15 @@ int gs_air_constraints(gs_ctx *ctx, const uint32_t *code_host, uint32_t ninstr, 
                        uint32_t vm_regs, uint32_t registers, uint32_t constraints, const void *p_comp /* registers x nc */,
                        uint64_t nc, uint64_t shift, const void *static_tables /* device, concatenated */,
                        const uint64_t *static_lens_host, uint32_t nstatic, void *out /* constraints x nc */);
+/* The same evaluation with the registers read IN PLACE from columns of a larger domain: register r at point j is
+ * p[r * prow + j * pstride] (next row: point (j + shift) mod nc).  CompositionPolynomial.ts:76 evaluates the constraints over the
+ * composition domain, whose points are every (N / nc)-th point of the evaluation domain the trace polynomials were just extended
+ * over (lib/Stark.ts:109): with prow = N and pstride = N / nc the extension is read directly and the plucked copy (registers x nc
+ * elements written and read again) is never made.  gs_air_constraints is prow = nc, pstride = 1.  (nc - 1) * pstride < prow. */
+int gs_air_constraints_strided(gs_ctx *ctx, const uint32_t *code_host, uint32_t ninstr, const uint8_t *consts_host, uint32_t nconsts,
+                               uint32_t vm_regs, uint32_t registers, uint32_t constraints, const void *p /* registers x prow */,
+                               uint64_t prow, uint64_t pstride, uint64_t nc, uint64_t shift, const void *static_tables,
+                               const uint64_t *static_lens_host, uint32_t nstatic, void *out /* constraints x nc */);
 
 #ifdef __cplusplus
 }

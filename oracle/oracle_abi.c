@@ -894,10 +894,13 @@ int gs_air_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t n, const uin
     }
     return GS_OK;
 }
-int gs_air_constraints(gs_ctx *c, const uint32_t *code, uint32_t n, const uint8_t *consts, uint32_t nconsts, uint32_t vmn, uint32_t regs,
-                       uint32_t ncons, const void *p, uint64_t nc, uint64_t shift, const void *stab, const uint64_t *slens, uint32_t nstatic, void *out) {
+/* registers read in place from the columns of a larger domain (include/gstark.h): register a at point j is p[a * prow + j * pstride] */
+int gs_air_constraints_strided(gs_ctx *c, const uint32_t *code, uint32_t n, const uint8_t *consts, uint32_t nconsts, uint32_t vmn, uint32_t regs,
+                               uint32_t ncons, const void *p, uint64_t prow, uint64_t pstride, uint64_t nc, uint64_t shift, const void *stab,
+                               const uint64_t *slens, uint32_t nstatic, void *out) {
     if (air_check(c, code, n, nconsts, vmn, regs, nstatic, ncons, 1)) return GS_ERR_ARG;
     if (!nc) return fail(c, GS_ERR_ARG, "air_constraints: empty domain");
+    if (!pstride || (nc - 1) > UINT64_MAX / pstride || (nc - 1) * pstride >= prow) return fail(c, GS_ERR_ARG, "air_constraints: points at this stride do not fit the rows");
     fe vm[GS_AIR_MAX_VM_REGS];
     uint64_t soff[GS_AIR_MAX_REGISTERS], o = 0;
     for (uint32_t s = 0; s < nstatic; s++) { if (!slens[s]) return fail(c, GS_ERR_ARG, "air_constraints: empty static table"); soff[s] = o; o += slens[s]; }
@@ -907,8 +910,8 @@ int gs_air_constraints(gs_ctx *c, const uint32_t *code, uint32_t n, const uint8_
             uint32_t op = code[4 * pc], d = code[4 * pc + 1], a = code[4 * pc + 2], b = code[4 * pc + 3];
             switch (op) {
                 case 0: vm[d] = fe_load(consts + FE_BYTES * a); break;
-                case 1: vm[d] = EL(p, (uint64_t)a * nc + j); break;
-                case 2: vm[d] = EL(p, (uint64_t)a * nc + jn); break;
+                case 1: vm[d] = EL(p, (uint64_t)a * prow + j * pstride); break;
+                case 2: vm[d] = EL(p, (uint64_t)a * prow + jn * pstride); break;
                 case 3: vm[d] = EL(stab, soff[a] + j % slens[a]); break;
                 case 4: vm[d] = fe_add(vm[a], vm[b]); break;
                 case 5: vm[d] = fe_sub(vm[a], vm[b]); break;
@@ -920,6 +923,10 @@ int gs_air_constraints(gs_ctx *c, const uint32_t *code, uint32_t n, const uint8_
         }
     }
     return GS_OK;
+}
+int gs_air_constraints(gs_ctx *c, const uint32_t *code, uint32_t n, const uint8_t *consts, uint32_t nconsts, uint32_t vmn, uint32_t regs,
+                       uint32_t ncons, const void *p, uint64_t nc, uint64_t shift, const void *stab, const uint64_t *slens, uint32_t nstatic, void *out) {
+    return gs_air_constraints_strided(c, code, n, consts, nconsts, vmn, regs, ncons, p, nc, 1, nc, shift, stab, slens, nstatic, out);
 }
 
 /* include/gstark.h gs_pseudorandom_indexes — QueryIndexGenerator.ts:39-67 on the host */

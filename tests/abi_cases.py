@@ -761,3 +761,28 @@ def check_combine_adjusted(backend, rng, n=300):
             raise
         except Exception:      # noqa: BLE001
             pass
+
+
+def check_constraints_strided(backend, air, inputs):
+    """gs_air_constraints_strided (include/gstark.h): the constraint program over the composition domain with the registers read in
+    place from the extension over the EVALUATION domain (every (N / Nc)-th point) equals gs_air_constraints on the plucked copy —
+    compiled or interpreted, whichever the backend runs; strides that do not fit the rows are refused.  Returns the values."""
+    import ctypes as C
+    from genstark_amd.field import Matrix
+    f = air.field
+    ctx = air.initProvingContext([], inputs)
+    p_polys = f.interpolateRoots(ctx.executionDomain, ctx.generateExecutionTrace())
+    want = ctx.evaluateTransitionConstraints(p_polys).toValues()
+    p_eval = f.evalPolysAtRoots(p_polys, ctx.evaluationDomain)
+    n, nc = ctx.evaluationDomain.length, ctx.compositionDomain.length
+    code, ninstr, consts, nconsts, nregs = air.evaluationProgram.abi_args(f.elementSize)
+    q = Matrix(f.backend, len(air.constraintDegrees), nc)
+    lens = (C.c_uint64 * max(len(ctx._staticLens), 1))(*ctx._staticLens)
+    args = [code, ninstr, consts, nconsts, nregs, air.traceRegisterCount, len(air.constraintDegrees), C.c_void_p(p_eval.ptr)]
+    tail = [nc, nc // ctx.traceLength, C.c_void_p(ctx._staticTables.ptr), lens, len(ctx._staticLens), C.c_void_p(q.ptr)]
+    f.backend.call('gs_air_constraints_strided', *args, n, n // nc, *tail)
+    got = q.toValues()
+    assert got == want
+    for prow, pstride in ((n, 0), (n, n // nc + 1), (nc, n // nc)):
+        assert f.backend.lib.gs_air_constraints_strided(f.backend.ctx, *args, prow, pstride, *tail) != 0
+    return got

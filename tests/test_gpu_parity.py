@@ -177,6 +177,21 @@ def test_mimc_air(hip_backend, rng):
     cases.check_mimc_air(hip_backend, rng, 128)
 
 
+@pytest.mark.parametrize('jit', [0, 1])
+def test_constraints_read_in_place_from_the_evaluation_domain(hip_backend, oracle_backend, jit):
+    """gs_air_constraints_strided, interpreted and compiled, against the oracle's (Poseidon and Rescue segments)."""
+    from genstark_amd.poseidon import poseidon6x128_air
+    from genstark_amd.rescue import rescue4x128_air
+    hip_backend.call('gs_air_jit', jit)
+    try:
+        for make, inputs in ((lambda f: poseidon6x128_air(256, 16, f, segmented=True), [[1, 2, 3, 4], [5, 6, 7, 8], [9, 9, 9, 9], [0, 1, 0, 1]]),
+                             (lambda f: rescue4x128_air(128, 16, f, segmented=True), [[42, 43], [1, 2], [3, 4], [5, 6]])):
+            got = cases.check_constraints_strided(hip_backend, make(PrimeField(backend=hip_backend)), inputs)
+            assert got == cases.check_constraints_strided(oracle_backend, make(PrimeField(backend=oracle_backend)), inputs)
+    finally:
+        hip_backend.call('gs_air_jit', 0)
+
+
 def test_kat_rescue_4x128_through_hip_kernels(hip_backend):
     cases.check_rescue_kat(hip_backend)
 

@@ -97,6 +97,13 @@ def test_mimc_air(oracle_backend, rng):
     cases.check_mimc_air(oracle_backend, rng, 128)
 
 
+def test_constraints_read_in_place_from_the_evaluation_domain(oracle_backend):
+    from genstark_amd.field import PrimeField
+    from genstark_amd.poseidon import poseidon6x128_air
+    f = PrimeField(backend=oracle_backend)
+    cases.check_constraints_strided(oracle_backend, poseidon6x128_air(128, 16, f, segmented=True), [[1, 2, 3, 4], [5, 6, 7, 8]])
+
+
 # ---- known-answer values held by the reference's own example programs --------------------------------
 def test_kat_foo_and_fibonacci():
     """README.md:23,42-45 (Foo: 1 -> 127 after 64 steps of +2) and examples/demo/fibonacci.ts:9-11
