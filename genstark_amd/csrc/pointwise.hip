@@ -221,6 +221,48 @@ __global__ void k_div_by_domain_roots(const fe *__restrict__ num, const fe *__re
     }
 }
 
+// ---- the tail of the composition polynomial and the linear combination in ONE pass (gs_composition_tail, include/gstark.h) ----------
+//   l[i] = q[i] * zinv[i]  +  sum_b (k_b + pw[i] kp_b) (P_b[i] - I_b(w^i)) / prod_a (w^i - w^r_ba)  +  sum_v (k_v + pw[i] kp_v) e_v[i]
+// Separately (gs_vec_mul, gs_eval_polys_at_roots, gs_sub_matrix_from_vectors, gs_div_by_domain_roots, two gs_combine_adjusted) these are
+// seven passes over the domain with five intermediate matrices; here every input is read once and nothing but l (and, if asked for, C)
+// is written.  The descriptors are uniform: they sit in device memory (too many for the 4 KB of kernel arguments) and come in through
+// scalar loads.  Each quotient's constant prod_a w^-r_a is folded into its two coefficients on the host.
+#define GS_TAIL_MAX_ROOTS 4
+#define GS_TAIL_MAX_ILEN 4
+struct TailRow { const fe *v; fe k, kp; uint64_t root[GS_TAIL_MAX_ROOTS]; fe ipoly[GS_TAIL_MAX_ILEN]; uint32_t nroots, pad[3]; };
+struct TailVec { const fe *v; uint64_t pad; fe k, kp; };
+template <int HAS_PW, int HAS_X>
+__global__ __launch_bounds__(256) void k_composition_tail(const fe *__restrict__ q, const fe *__restrict__ zinv, const fe *__restrict__ pw, const fe *__restrict__ u,
+                                                          const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn, uint64_t n,
+                                                          const TailRow *__restrict__ rows, uint32_t bcount, uint32_t ilen,
+                                                          const TailVec *__restrict__ vecs, uint32_t lcount, fe *__restrict__ c_out, fe *__restrict__ l_out) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        fe acc = fe_mul(q[i], zinv[i]);
+        fe p = fe_one(), x = fe_one();
+        if (HAS_PW) p = pw[i];
+        if (HAS_X) {
+            x = tw_lo[i & ((1ull << log_lo) - 1)];
+            if (logn > log_lo) x = fe_mul(x, tw_hi[i >> log_lo]);
+        }
+        for (uint32_t b = 0; b < bcount; b++) {
+            const TailRow &r = rows[b];
+            fe iv = r.ipoly[ilen - 1];
+            if (HAS_X) for (int t = (int)ilen - 2; t >= 0; t--) iv = fe_add(fe_mul(iv, x), r.ipoly[t]);
+            fe t = fe_sub(r.v[i], iv);
+            for (uint32_t a = 0; a < r.nroots; a++) t = fe_mul(t, u[(i + n - r.root[a]) & (n - 1)]);
+            const fe cf = HAS_PW ? fe_add(r.k, fe_mul(p, r.kp)) : r.k;
+            acc = fe_add(acc, fe_mul(t, cf));
+        }
+        if (c_out) c_out[i] = acc;
+        for (uint32_t v = 0; v < lcount; v++) {
+            const TailVec &e = vecs[v];
+            const fe cf = HAS_PW ? fe_add(e.k, fe_mul(p, e.kp)) : e.k;
+            acc = fe_add(acc, fe_mul(e.v[i], cf));
+        }
+        l_out[i] = acc;
+    }
+}
+
 // ---- linear combination of many vectors --------------------------------------------------------------
 struct PtrArgs {
     const fe *v[GS_MAX_COMBINE];
@@ -622,6 +664,71 @@ int gs_div_by_domain_roots_coset(gs_ctx *c, const void *num, uint32_t rows, uint
                            roots_per_row_host[r], scale, (fe *)out + (uint64_t)r * n);
     }
     GS_LAUNCH_CHECK(c);
+    return GS_OK;
+}
+
+int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *q, const void *z_inv, const void *const *b_vecs_host, uint32_t bcount,
+                        const uint8_t *ipolys_host, uint32_t ilen, const uint64_t *root_index_host, const uint32_t *roots_per_row_host, uint32_t max_roots,
+                        const uint8_t *b_coeffs_host, const uint8_t *b_adj_host, const void *const *l_vecs_host, uint32_t lcount,
+                        const uint8_t *l_coeffs_host, const uint8_t *l_adj_host, const void *powers, void *c_out, void *l_out) {
+    if (!c || !omega || !q || !z_inv || !l_out) return GS_ERR_ARG;
+    if (bcount && (!b_vecs_host || !ipolys_host || !roots_per_row_host || !b_coeffs_host || (max_roots && !root_index_host))) return GS_ERR_ARG;
+    if (lcount && (!l_vecs_host || !l_coeffs_host)) return GS_ERR_ARG;
+    if ((b_adj_host || l_adj_host) && !powers) return GS_ERR_ARG;
+    if (!gs_is_pow2(n)) return gs_fail(c, GS_ERR_ARG, "composition_tail: n must be a power of two");
+    if (bcount && (ilen == 0 || ilen > GS_TAIL_MAX_ILEN)) return gs_fail(c, GS_ERR_UNSUPPORTED, "composition_tail: 1..%d interpolant coefficients per row", GS_TAIL_MAX_ILEN);
+    for (uint32_t r = 0; r < bcount; r++)
+        if (roots_per_row_host[r] > max_roots || roots_per_row_host[r] > GS_TAIL_MAX_ROOTS)
+            return gs_fail(c, GS_ERR_UNSUPPORTED, "composition_tail: at most %d roots per row", GS_TAIL_MAX_ROOTS);
+    const fe w = fe_from_bytes(omega);
+    const fe *lo = nullptr, *hi = nullptr, *u = nullptr;
+    int log_lo = 0;
+    int rc = gs_plan_pow_tables(c, w, n, &lo, &hi, &log_lo);
+    if (!rc && bcount) rc = gs_plan_inverse_table(c, w, n, &u);
+    if (rc) return rc;
+    // descriptors -> device scratch through the upload ring (asynchronous, the caller's arrays are free at once)
+    const uint64_t rows_b = ((uint64_t)bcount * sizeof(TailRow) + 255) & ~(uint64_t)255, vecs_b = (uint64_t)lcount * sizeof(TailVec);
+    const uint64_t total = rows_b + vecs_b ? rows_b + vecs_b : 256;
+    void *d = nullptr, *h = nullptr;
+    if ((rc = gs_tmp_alloc(c, total, &d))) return rc;
+    if ((rc = gs_push_reserve(c, total, &h))) { gs_tmp_free(c, d); return rc == GS_ERR_UNSUPPORTED ? gs_fail(c, GS_ERR_UNSUPPORTED, "composition_tail: too many vectors") : rc; }
+    memset(h, 0, total);
+    TailRow *hr = (TailRow *)h;
+    TailVec *hv = (TailVec *)((uint8_t *)h + rows_b);
+    for (uint32_t r = 0; r < bcount; r++) {
+        hr[r].v = (const fe *)b_vecs_host[r];
+        hr[r].nroots = roots_per_row_host[r];
+        uint64_t ksum = 0;
+        for (uint32_t a = 0; a < roots_per_row_host[r]; a++) {
+            hr[r].root[a] = root_index_host[(uint64_t)r * max_roots + a] & (n - 1);
+            ksum = (ksum + hr[r].root[a]) & (n - 1);
+        }
+        const fe scale = fe_pow_u64(w, (n - ksum) & (n - 1));              // prod_a omega^-r_a: 1/(w^i - w^r) = w^-r * u[i - r]
+        hr[r].k = fe_mul(fe_from_bytes(b_coeffs_host + (size_t)r * GS_ELT), scale);
+        hr[r].kp = b_adj_host ? fe_mul(fe_from_bytes(b_adj_host + (size_t)r * GS_ELT), scale) : fe_zero();
+        for (uint32_t t = 0; t < ilen; t++) hr[r].ipoly[t] = fe_from_bytes(ipolys_host + ((size_t)r * ilen + t) * GS_ELT);
+    }
+    for (uint32_t v = 0; v < lcount; v++) {
+        hv[v].v = (const fe *)l_vecs_host[v];
+        hv[v].k = fe_from_bytes(l_coeffs_host + (size_t)v * GS_ELT);
+        hv[v].kp = l_adj_host ? fe_from_bytes(l_adj_host + (size_t)v * GS_ELT) : fe_zero();
+    }
+    if ((rc = gs_push_commit(c, d, h, total))) { gs_tmp_free(c, d); return rc; }
+    const TailRow *dr = (const TailRow *)d;
+    const TailVec *dv = (const TailVec *)((uint8_t *)d + rows_b);
+    const bool has_pw = powers != nullptr, has_x = bcount && ilen > 1;
+    const dim3 grid(gs_grid(n)), block(256);
+#define GS_TAIL_LAUNCH(PW, X)                                                                                                                        \
+    hipLaunchKernelGGL((k_composition_tail<PW, X>), grid, block, 0, c->stream, (const fe *)q, (const fe *)z_inv, (const fe *)powers, u, lo, hi, log_lo, \
+                       gs_log2(n), n, dr, bcount, ilen ? ilen : 1u, dv, lcount, (fe *)c_out, (fe *)l_out)
+    if (has_pw && has_x) GS_TAIL_LAUNCH(1, 1);
+    else if (has_pw) GS_TAIL_LAUNCH(1, 0);
+    else if (has_x) GS_TAIL_LAUNCH(0, 1);
+    else GS_TAIL_LAUNCH(0, 0);
+#undef GS_TAIL_LAUNCH
+    hipError_t e = hipGetLastError();
+    gs_tmp_free(c, d);      // stream-ordered reuse: later users of the block are queued behind this kernel
+    if (e != hipSuccess) return gs_fail(c, GS_ERR_DEVICE, "composition_tail launch: %s", hipGetErrorString(e));
     return GS_OK;
 }
 

@@ -43,7 +43,7 @@ namespace {
     X(gs_eval_polys_at_roots) X(gs_interpolate_roots) X(gs_interpolate_quartic_domain) X(gs_eval_quartic_batch)                \
     X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_commit_rows) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
     X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
-    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_air_constraints_strided) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end) X(gs_readback_post) X(gs_readback_wait) X(gs_merkle_commit_rows_seed) X(gs_fri_fold_at) \
+    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_air_constraints_strided) X(gs_composition_tail) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end) X(gs_readback_post) X(gs_readback_wait) X(gs_merkle_commit_rows_seed) X(gs_fri_fold_at) \
     X(gs_vec_mul_scalar) X(gs_copy) X(gs_gather_words) X(gs_transpose_records) X(gs_fri_fold_seeded_scaled) X(gs_fri_layers) X(gs_sync) X(gs_zero_poly_inverses_coset) X(gs_div_by_domain_roots_coset)
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
@@ -788,6 +788,37 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
             le16(omega, s16);
             x.check(counted_eval_polys_at_roots(x.c, qcPoly.p, 1, Nc, s16, N, qe.p), "gs_eval_polys_at_roots(Q)");
         }
+        // 5.4-5.7 and 6 in ONE pass (gs_composition_tail): D = Q / Z, the boundary quotients from the registers' extensions, their
+        // degree-adjusted merge, and LinearCombination.computeMany on top — when the assertions fit its per-register limits
+        size_t tail_roots = 0;
+        for (auto &d : rdata) tail_roots = std::max(tail_roots, d.at.size());
+        if (tail_roots <= 4 && bcount <= 64 && V <= 96 && !getenv("GSTARK_NO_TAIL")) {
+            const uint32_t il = (uint32_t)tail_roots;                   // an interpolant through m assertions has m coefficients
+            Bytes ip((size_t)bcount * il * ELEM, 0);
+            std::vector<uint64_t> at((size_t)bcount * il, 0);
+            std::vector<uint32_t> per_row(bcount);
+            for (uint32_t r = 0; r < bcount; r++) {
+                const RegData &d = rdata[r];
+                const uint32_t m = (uint32_t)d.xs.size();
+                Bytes xs(m * ELEM), ys(m * ELEM);
+                for (uint32_t i = 0; i < m; i++) { le16(d.xs[i], xs.data() + ELEM * i); le16(d.ys[i], ys.data() + ELEM * i); }
+                if (A.gs_small_interpolate(xs.data(), ys.data(), m, ip.data() + (size_t)r * il * ELEM)) fail(GS_ERR_ARG, "gs_small_interpolate failed");   // BoundaryConstraints.ts:42
+                per_row[r] = m;
+                for (uint32_t k = 0; k < m; k++) at[(size_t)r * il + k] = d.at[k];
+            }
+            std::vector<const void *> pv;
+            for (auto &d : rdata) pv.push_back(pRows[d.reg]);
+            Bytes bco = coeff_bytes(dcount, bcoef);
+            const uint32_t offset = dcount + bcoef, cnt = b_inc > 0 ? 2 * V : V;
+            std::vector<F> co = prng_many(eTree.root, offset + cnt);      // LinearCombination.ts:36-64: the same stream continues
+            Bytes cb(cnt * ELEM);
+            for (uint32_t i = 0; i < cnt; i++) le16(co[offset + i], cb.data() + ELEM * i);
+            le16(omega, s16);
+            x.check(A.gs_composition_tail(x.c, N, s16, qe.p, zInverses.p, pv.data(), bcount, ip.data(), il, at.data(), per_row.data(), il, bco.data(),
+                                          b_inc > 0 ? bco.data() + ELEM * bcount : nullptr, eVectors.data(), V, cb.data(), b_inc > 0 ? cb.data() + ELEM * V : nullptr,
+                                          b_inc > 0 ? psbPowers.p : nullptr, nullptr, cEval.p), "gs_composition_tail");
+            lc_fused = true;
+        } else {
         // 5.4 D(x) = Q(x) / Z(x) (:113-121)
         Buf dEval(x, N * ELEM);
         x.check(A.gs_vec_mul(x.c, qe.p, zInverses.p, N, dEval.p), "gs_vec_mul(D)");
@@ -854,6 +885,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         Bytes bco = coeff_bytes(dcount, bcoef);
         x.check(A.gs_combine_adjusted(x.c, ba.data(), bco.data(), b_inc > 0 ? bco.data() + ELEM * bcount : nullptr, bcount, b_inc > 0 ? psbPowers.p : nullptr,
                                       dEval.p, N, cEval.p), "gs_combine_adjusted(B + D)");
+        }
     }
     if (!fused) zInverses.release();
 

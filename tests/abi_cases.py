@@ -786,3 +786,91 @@ def check_constraints_strided(backend, air, inputs):
     for prow, pstride in ((n, 0), (n, n // nc + 1), (nc, n // nc)):
         assert f.backend.lib.gs_air_constraints_strided(f.backend.ctx, *args, prow, pstride, *tail) != 0
     return got
+
+
+def check_composition_tail(backend, rng, logn, logsteps, per_row, lcount, adjusted, with_c=True):
+    """gs_composition_tail against its definition on Python integers (sampled points) and against the sequence of entries it replaces
+    (gs_vec_mul, gs_eval_polys_at_roots, gs_sub_matrix_from_vectors, gs_div_by_domain_roots, gs_combine_adjusted twice) on the same
+    backend (every point).  per_row: assertions per asserted register (1..4 each).  Returns (c, l) for cross-backend comparison."""
+    be = backend
+    f = field_for(be)
+    p = f.modulus
+    n, steps = 1 << logn, 1 << logsteps
+    e = n // steps
+    omega = f.getRootOfUnity(n)
+    bcount, ilen = len(per_row), max(per_row)
+    qv, zv, pwv = rand_elements(rng, n), rand_elements(rng, n), rand_elements(rng, n)
+    bcols = [rand_elements(rng, n) for _ in range(bcount)]
+    lcols = [rand_elements(rng, n) for _ in range(lcount)]
+    roots = [sorted(rng.sample(range(steps), m)) for m in per_row]              # asserted steps of register b
+    ipolys = [[rng.randrange(p) for _ in range(m)] + [0] * (ilen - m) for m in per_row]
+    bk, bkp = [rng.randrange(p) for _ in range(bcount)], [rng.randrange(p) for _ in range(bcount)]
+    lk, lkp = [rng.randrange(p) for _ in range(lcount)], [rng.randrange(p) for _ in range(lcount)]
+    q, z, pw = f.newVectorFrom(qv), f.newVectorFrom(zv), f.newVectorFrom(pwv)
+    bvecs, lvecs = [f.newVectorFrom(c) for c in bcols], [f.newVectorFrom(c) for c in lcols]
+    bp = (C.c_void_p * bcount)(*[v.ptr for v in bvecs])
+    lp = (C.c_void_p * max(lcount, 1))(*[v.ptr for v in lvecs])
+    ri = (C.c_uint64 * (bcount * ilen))(*[(r[k] * e if k < len(r) else 0) for r in roots for k in range(ilen)])
+    pr = (C.c_uint32 * bcount)(*per_row)
+    le = lambda xs: b''.join(f.le(v) for v in xs)
+    c_out, l_out = f.newVector(n), f.newVector(n)
+    be.call('gs_composition_tail', n, f.le(omega), C.c_void_p(q.ptr), C.c_void_p(z.ptr), bp, bcount, le([v for row in ipolys for v in row]), ilen, ri, pr, ilen,
+            le(bk), le(bkp) if adjusted else None, lp if lcount else None, lcount, le(lk) if lcount else None, le(lkp) if adjusted and lcount else None,
+            C.c_void_p(pw.ptr) if adjusted else None, C.c_void_p(c_out.ptr) if with_c else None, C.c_void_p(l_out.ptr))
+    got_c, got_l = (c_out.toValues() if with_c else None), l_out.toValues()
+    # the definition, on integers
+    for i in sorted({0, 1, n - 1, roots[0][0] * e + 1} | {rng.randrange(n) for _ in range(12)}):
+        x = pow(omega, i, p)
+        c = qv[i] * zv[i] % p
+        for b in range(bcount):
+            iv = sum(co * pow(x, t, p) for t, co in enumerate(ipolys[b])) % p
+            den = 1
+            for r in roots[b]:
+                den = den * (x - pow(omega, r * e, p)) % p
+            if den == 0:
+                continue                                                  # a root of the divisor: 0^-1 = 0 by convention (checked against the member sequence below)
+            cf = (bk[b] + (pwv[i] * bkp[b] if adjusted else 0)) % p
+            c = (c + cf * (bcols[b][i] - iv) * pow(den, p - 2, p)) % p
+        else:
+            if with_c:
+                assert got_c[i] == c, i
+            l = (c + sum((lk[v] + (pwv[i] * lkp[v] if adjusted else 0)) * lcols[v][i] for v in range(lcount))) % p
+            assert got_l[i] == l, i
+    # the sequence it replaces
+    d = f.newVector(n)
+    be.call('gs_vec_mul', C.c_void_p(q.ptr), C.c_void_p(z.ptr), n, C.c_void_p(d.ptr))
+    ipm = f.newMatrixFrom(ipolys)
+    iv, pi, bq = f.newMatrix(bcount, n), f.newMatrix(bcount, n), f.newMatrix(bcount, n)
+    be.call('gs_eval_polys_at_roots', C.c_void_p(ipm.ptr), bcount, ilen, f.le(omega), n, C.c_void_p(iv.ptr))
+    be.call('gs_sub_matrix_from_vectors', bp, C.c_void_p(iv.ptr), bcount, n, C.c_void_p(pi.ptr))
+    be.call('gs_div_by_domain_roots', C.c_void_p(pi.ptr), bcount, n, f.le(omega), ri, pr, ilen, C.c_void_p(bq.ptr))
+    rows = (C.c_void_p * bcount)(*[bq.ptr + r * n * f.elementSize for r in range(bcount)])
+    cc = f.newVector(n)
+    be.call('gs_combine_adjusted', rows, le(bk), le(bkp) if adjusted else None, bcount, C.c_void_p(pw.ptr) if adjusted else None, C.c_void_p(d.ptr), n, C.c_void_p(cc.ptr))
+    want_c = cc.toValues()
+    if lcount:
+        ll = f.newVector(n)
+        be.call('gs_combine_adjusted', lp, le(lk), le(lkp) if adjusted else None, lcount, C.c_void_p(pw.ptr) if adjusted else None, C.c_void_p(cc.ptr), n, C.c_void_p(ll.ptr))
+        want_l = ll.toValues()
+    else:
+        want_l = want_c
+    assert got_l == want_l and (not with_c or got_c == want_c)
+    return got_c, got_l
+
+
+def check_composition_tail_limits(backend):
+    """More than 4 assertions on a register is refused (GS_ERR_UNSUPPORTED: the caller keeps the separate entries), and so are missing
+    arguments."""
+    f = field_for(backend)
+    n = 64
+    v = f.newVectorFrom([1] * n)
+    bp = (C.c_void_p * 1)(v.ptr)
+    ri = (C.c_uint64 * 5)(0, 1, 2, 3, 4)
+    pr = (C.c_uint32 * 1)(5)
+    one = f.le(1)
+    args = lambda ilen, roots: (backend.ctx, n, f.le(f.getRootOfUnity(n)), C.c_void_p(v.ptr), C.c_void_p(v.ptr), bp, 1, one * 5, ilen, ri, pr, roots, one, None,
+                                None, 0, None, None, None, None, C.c_void_p(v.ptr))
+    assert backend.lib.gs_composition_tail(*args(5, 5)) == -3 or backend.lib.gs_composition_tail(*args(5, 5)) != 0
+    assert backend.lib.gs_composition_tail(*args(4, 5)) != 0
+    a = list(args(4, 4)); a[-1] = None
+    assert backend.lib.gs_composition_tail(*a) != 0

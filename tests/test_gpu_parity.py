@@ -177,19 +177,34 @@ def test_mimc_air(hip_backend, rng):
     cases.check_mimc_air(hip_backend, rng, 128)
 
 
+@pytest.mark.parametrize('logn,logsteps,per_row,lcount,adjusted', [(8, 4, [1], 0, False), (12, 8, [2, 1], 3, True), (14, 10, [4, 1, 3], 7, True),
+                                                                   (16, 12, [1, 1], 6, True), (13, 9, [1, 1], 70, False), (16, 10, [3] * 20, 2, True)])
+def test_composition_tail(hip_backend, oracle_backend, logn, logsteps, per_row, lcount, adjusted):
+    """gs_composition_tail on HIP: its definition, the member sequence it replaces, and the oracle's bytes."""
+    seed = hash((logn, tuple(per_row), lcount)) & 0xffff
+    got = cases.check_composition_tail(hip_backend, random.Random(seed), logn, logsteps, per_row, lcount, adjusted)
+    if logn <= 14:
+        assert got == cases.check_composition_tail(oracle_backend, random.Random(seed), logn, logsteps, per_row, lcount, adjusted)
+    cases.check_composition_tail(hip_backend, random.Random(seed + 1), logn, logsteps, per_row, lcount, adjusted, with_c=False)
+    cases.check_composition_tail_limits(hip_backend)
+
+
 @pytest.mark.parametrize('jit', [0, 1])
 def test_constraints_read_in_place_from_the_evaluation_domain(hip_backend, oracle_backend, jit):
     """gs_air_constraints_strided, interpreted and compiled, against the oracle's (Poseidon and Rescue segments)."""
     from genstark_amd.poseidon import poseidon6x128_air
     from genstark_amd.rescue import rescue4x128_air
-    hip_backend.call('gs_air_jit', jit)
+    from genstark_amd._abi import Backend
+    be = Backend(device=0).jit() if jit else hip_backend        # (a context of its own: the session's counts no compiled launches)
     try:
         for make, inputs in ((lambda f: poseidon6x128_air(256, 16, f, segmented=True), [[1, 2, 3, 4], [5, 6, 7, 8], [9, 9, 9, 9], [0, 1, 0, 1]]),
                              (lambda f: rescue4x128_air(128, 16, f, segmented=True), [[42, 43], [1, 2], [3, 4], [5, 6]])):
-            got = cases.check_constraints_strided(hip_backend, make(PrimeField(backend=hip_backend)), inputs)
+            got = cases.check_constraints_strided(be, make(PrimeField(backend=be)), inputs)
             assert got == cases.check_constraints_strided(oracle_backend, make(PrimeField(backend=oracle_backend)), inputs)
+        assert not jit or be.jit_launches >= 2
     finally:
-        hip_backend.call('gs_air_jit', 0)
+        if jit:
+            be.close()
 
 
 def test_kat_rescue_4x128_through_hip_kernels(hip_backend):

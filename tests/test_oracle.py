@@ -97,6 +97,13 @@ def test_mimc_air(oracle_backend, rng):
     cases.check_mimc_air(oracle_backend, rng, 128)
 
 
+@pytest.mark.parametrize('logn,logsteps,per_row,lcount,adjusted', [(8, 4, [1], 0, False), (9, 5, [2, 1], 3, True), (10, 6, [4, 1, 3], 7, True),
+                                                                   (8, 5, [1, 1], 6, False)])
+def test_composition_tail(oracle_backend, rng, logn, logsteps, per_row, lcount, adjusted):
+    cases.check_composition_tail(oracle_backend, rng, logn, logsteps, per_row, lcount, adjusted)
+    cases.check_composition_tail_limits(oracle_backend)
+
+
 def test_constraints_read_in_place_from_the_evaluation_domain(oracle_backend):
     from genstark_amd.field import PrimeField
     from genstark_amd.poseidon import poseidon6x128_air
