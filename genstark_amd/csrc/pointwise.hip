@@ -229,37 +229,142 @@ __global__ void k_div_by_domain_roots(const fe *__restrict__ num, const fe *__re
 // scalar loads.  Each quotient's constant prod_a w^-r_a is folded into its two coefficients on the host.
 #define GS_TAIL_MAX_ROOTS 4
 #define GS_TAIL_MAX_ILEN 4
-struct TailRow { const fe *v; fe k, kp; uint64_t root[GS_TAIL_MAX_ROOTS]; fe ipoly[GS_TAIL_MAX_ILEN]; uint32_t nroots, pad[3]; };
-struct TailVec { const fe *v; uint64_t pad; fe k, kp; };
-template <int HAS_PW, int HAS_X>
+#if !defined(GS_SMALL_Q) && !defined(GS_WIDE_BITS)
+#define GS_TAIL_LAZY 1
+// 128-bit field: both sums are dot products with UNIFORM constants — sum_t k_t x_t and sum_t k'_t x_t over the boundary quotients and
+// the committed vectors alike, l = D + S + pw * S'.  A term is one lz_unpack of x_t and 2 x 25 v_mad into two sets of nine 64-bit
+// columns (the constants' limbs, unpacked on the host, arrive through scalar loads); a set is folded every six terms (columns below
+// 2^57).  ~60 instructions per term against two canonical products and two additions (2 x 84 + 2 x 12).
+struct TailK { int32_t k[5], kp[5], pad[2]; };
+#else
+struct TailK { fe k, kp; };
+#endif
+struct TailRow { const fe *v; uint64_t root[GS_TAIL_MAX_ROOTS]; fe ipoly[GS_TAIL_MAX_ILEN]; TailK c; uint32_t nroots, pad[3]; };
+struct TailVec { const fe *v; uint64_t pad; TailK c; };
+#ifdef GS_TAIL_LAZY
+struct TailSums {
+    int64_t a[9], b[9];
+    fe pa, pb;
+    int terms;
+};
+template <int HAS_PW>
+__device__ __forceinline__ void tail_flush(TailSums &s, const lzk &K) {
+    s.pa = fe_add(s.pa, lz_pack(lz_fold9(s.a, K)));
+    if (HAS_PW) s.pb = fe_add(s.pb, lz_pack(lz_fold9(s.b, K)));
+#pragma unroll
+    for (int k = 0; k < 9; k++) { s.a[k] = 0; s.b[k] = 0; }
+    s.terms = 0;
+}
+template <int HAS_PW>
+__device__ __forceinline__ void tail_term(TailSums &s, const fe &x, const TailK &c, const lzk &K) {
+    const lz u = lz_unpack(x);
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        int64_t ta = s.a[k], tb = s.b[k];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < 5) {
+                ta += (int64_t)u.l[i] * c.k[j];
+                if (HAS_PW) tb += (int64_t)u.l[i] * c.kp[j];
+            }
+        }
+        s.a[k] = ta;
+        s.b[k] = tb;
+    }
+    if (++s.terms == 6) tail_flush<HAS_PW>(s, K);
+}
+#endif
+// HAS_PW: 0 no degree adjustment, 1 pw[i] read from a vector, 2 pw[i] = omega^(i * pw_exp) from the domain's power tables.
+// ZC: 1/Z(x_i) = (x_i - x_last) * ztab[i mod period] computed here (k_zero_poly_inverses' formula) instead of read.  Both vectors are
+// written once and read once otherwise — the kernel is bound by its ~12 HBM streams, and its VALU has room for the three products.
+template <int HAS_PW, int HAS_X, int ZC>
 __global__ __launch_bounds__(256) void k_composition_tail(const fe *__restrict__ q, const fe *__restrict__ zinv, const fe *__restrict__ pw, const fe *__restrict__ u,
                                                           const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn, uint64_t n,
                                                           const TailRow *__restrict__ rows, uint32_t bcount, uint32_t ilen,
-                                                          const TailVec *__restrict__ vecs, uint32_t lcount, fe *__restrict__ c_out, fe *__restrict__ l_out) {
+                                                          const TailVec *__restrict__ vecs, uint32_t lcount, ZTable ztab, uint32_t period, fe x_last,
+                                                          uint64_t pw_exp, fe pw_step, fe *__restrict__ c_out, fe *__restrict__ l_out) {
+    static_assert(!ZC || HAS_X, "1/Z(x) needs x");
+#ifdef GS_TAIL_LAZY
+    const lzk K = lzk_make();
+#endif
+    __shared__ fe zc[GS_ZPOLY_MAX_PERIOD];
+    if (ZC) {
+        if (threadIdx.x < period) zc[threadIdx.x] = ztab.c[threadIdx.x];
+        __syncthreads();
+    }
+    // HAS_PW == 2: the power of this thread's first point from the tables (scattered reads, once), then a running product by
+    // pw_step = omega^(pw_exp * stride of the loop) — a look-up per point would be two uncoalesced 16-byte gathers per lane
+    fe prun = fe_one();
+    if (HAS_PW == 2) {
+        const uint64_t e = ((blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) * pw_exp) & (n - 1);
+        prun = tw_lo[e & ((1ull << log_lo) - 1)];
+        if (logn > log_lo) prun = fe_mul(prun, tw_hi[e >> log_lo]);
+    }
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        fe acc = fe_mul(q[i], zinv[i]);
         fe p = fe_one(), x = fe_one();
-        if (HAS_PW) p = pw[i];
+        if (HAS_PW == 1) p = pw[i];
+        if (HAS_PW == 2) { p = prun; prun = fe_mul(prun, pw_step); }
         if (HAS_X) {
             x = tw_lo[i & ((1ull << log_lo) - 1)];
             if (logn > log_lo) x = fe_mul(x, tw_hi[i >> log_lo]);
         }
+        const fe d = fe_mul(q[i], ZC ? fe_mul(fe_sub(x, x_last), zc[i & (period - 1)]) : zinv[i]);
+#ifdef GS_TAIL_LAZY
+        TailSums s;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { s.a[k] = 0; s.b[k] = 0; }
+        s.pa = d;
+        s.pb = fe_zero();
+        s.terms = 0;
+#else
+        fe acc = d;
+#endif
         for (uint32_t b = 0; b < bcount; b++) {
             const TailRow &r = rows[b];
             fe iv = r.ipoly[ilen - 1];
             if (HAS_X) for (int t = (int)ilen - 2; t >= 0; t--) iv = fe_add(fe_mul(iv, x), r.ipoly[t]);
             fe t = fe_sub(r.v[i], iv);
             for (uint32_t a = 0; a < r.nroots; a++) t = fe_mul(t, u[(i + n - r.root[a]) & (n - 1)]);
-            const fe cf = HAS_PW ? fe_add(r.k, fe_mul(p, r.kp)) : r.k;
+#ifdef GS_TAIL_LAZY
+            tail_term<HAS_PW>(s, t, r.c, K);
+#else
+            const fe cf = HAS_PW ? fe_add(r.c.k, fe_mul(p, r.c.kp)) : r.c.k;
             acc = fe_add(acc, fe_mul(t, cf));
+#endif
         }
+#ifdef GS_TAIL_LAZY
+        if (c_out) {
+            if (s.terms) tail_flush<HAS_PW>(s, K);
+            c_out[i] = HAS_PW ? fe_add(s.pa, fe_mul(p, s.pb)) : s.pa;
+        }
+#else
         if (c_out) c_out[i] = acc;
-        for (uint32_t v = 0; v < lcount; v++) {
-            const TailVec &e = vecs[v];
-            const fe cf = HAS_PW ? fe_add(e.k, fe_mul(p, e.kp)) : e.k;
-            acc = fe_add(acc, fe_mul(e.v[i], cf));
+#endif
+        // six vectors at a time: their loads are issued together (one at a time behind a run-time trip count, every load's latency would
+        // be paid separately: 0.96 ms against 0.7x for six registers at N = 2^24)
+        for (uint32_t v0 = 0; v0 < lcount; v0 += 6) {
+            fe xs[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) xs[k] = v0 + k < lcount ? vecs[v0 + k].v[i] : fe_zero();
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                if (v0 + k >= lcount) break;
+                const TailVec &e = vecs[v0 + k];
+#ifdef GS_TAIL_LAZY
+                tail_term<HAS_PW>(s, xs[k], e.c, K);
+#else
+                const fe cf = HAS_PW ? fe_add(e.c.k, fe_mul(p, e.c.kp)) : e.c.k;
+                acc = fe_add(acc, fe_mul(xs[k], cf));
+#endif
+            }
         }
+#ifdef GS_TAIL_LAZY
+        if (s.terms) tail_flush<HAS_PW>(s, K);
+        l_out[i] = HAS_PW ? fe_add(s.pa, fe_mul(p, s.pb)) : s.pa;
+#else
         l_out[i] = acc;
+#endif
     }
 }
 
@@ -667,15 +772,32 @@ int gs_div_by_domain_roots_coset(gs_ctx *c, const void *num, uint32_t rows, uint
     return GS_OK;
 }
 
-int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *q, const void *z_inv, const void *const *b_vecs_host, uint32_t bcount,
-                        const uint8_t *ipolys_host, uint32_t ilen, const uint64_t *root_index_host, const uint32_t *roots_per_row_host, uint32_t max_roots,
-                        const uint8_t *b_coeffs_host, const uint8_t *b_adj_host, const void *const *l_vecs_host, uint32_t lcount,
-                        const uint8_t *l_coeffs_host, const uint8_t *l_adj_host, const void *powers, void *c_out, void *l_out) {
-    if (!c || !omega || !q || !z_inv || !l_out) return GS_ERR_ARG;
+static void tail_coeffs(TailK &c, const fe &k, const fe &kp) {
+#ifdef GS_TAIL_LAZY
+    const lz a = lz_unpack(k), b = lz_unpack(kp);
+    for (int i = 0; i < 5; i++) { c.k[i] = a.l[i]; c.kp[i] = b.l[i]; }
+#else
+    c.k = k;
+    c.kp = kp;
+#endif
+}
+int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *q, const void *z_inv, uint64_t z_steps, const gs_elt *x_last,
+                        const void *const *b_vecs_host, uint32_t bcount, const uint8_t *ipolys_host, uint32_t ilen, const uint64_t *root_index_host,
+                        const uint32_t *roots_per_row_host, uint32_t max_roots, const uint8_t *b_coeffs_host, const uint8_t *b_adj_host,
+                        const void *const *l_vecs_host, uint32_t lcount, const uint8_t *l_coeffs_host, const uint8_t *l_adj_host, const void *powers,
+                        uint64_t powers_exponent, void *c_out, void *l_out) {
+    if (!c || !omega || !q || (!z_inv && !x_last) || !l_out) return GS_ERR_ARG;
     if (bcount && (!b_vecs_host || !ipolys_host || !roots_per_row_host || !b_coeffs_host || (max_roots && !root_index_host))) return GS_ERR_ARG;
     if (lcount && (!l_vecs_host || !l_coeffs_host)) return GS_ERR_ARG;
-    if ((b_adj_host || l_adj_host) && !powers) return GS_ERR_ARG;
+    if ((b_adj_host || l_adj_host) && !powers && !powers_exponent) return GS_ERR_ARG;
     if (!gs_is_pow2(n)) return gs_fail(c, GS_ERR_ARG, "composition_tail: n must be a power of two");
+    ZTable ztab;
+    uint64_t period = 1;
+    if (!z_inv) {
+        if (!gs_is_pow2(z_steps) || z_steps > n) return gs_fail(c, GS_ERR_ARG, "composition_tail: steps must be a power of two <= n");
+        period = n / z_steps;
+        if (period > GS_ZPOLY_MAX_PERIOD) return gs_fail(c, GS_ERR_UNSUPPORTED, "composition_tail: n / steps above %d (pass 1/Z as a vector)", GS_ZPOLY_MAX_PERIOD);
+    }
     if (bcount && (ilen == 0 || ilen > GS_TAIL_MAX_ILEN)) return gs_fail(c, GS_ERR_UNSUPPORTED, "composition_tail: 1..%d interpolant coefficients per row", GS_TAIL_MAX_ILEN);
     for (uint32_t r = 0; r < bcount; r++)
         if (roots_per_row_host[r] > max_roots || roots_per_row_host[r] > GS_TAIL_MAX_ROOTS)
@@ -686,6 +808,16 @@ int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *
     int rc = gs_plan_pow_tables(c, w, n, &lo, &hi, &log_lo);
     if (!rc && bcount) rc = gs_plan_inverse_table(c, w, n, &u);
     if (rc) return rc;
+    if (!z_inv) {                                                  // gs_zero_poly_inverses' table: 1 / (g^j - 1), g = omega^steps, 0^-1 = 0
+        const fe g = fe_pow_u64(w, z_steps);
+        fe cur = fe_one();
+        for (uint64_t j = 0; j < GS_ZPOLY_MAX_PERIOD; j++) {
+            ztab.c[j] = j < period ? fe_inv(fe_sub(cur, fe_one())) : fe_zero();
+            cur = fe_mul(cur, g);
+        }
+    } else {
+        for (uint64_t j = 0; j < GS_ZPOLY_MAX_PERIOD; j++) ztab.c[j] = fe_zero();
+    }
     // descriptors -> device scratch through the upload ring (asynchronous, the caller's arrays are free at once)
     const uint64_t rows_b = ((uint64_t)bcount * sizeof(TailRow) + 255) & ~(uint64_t)255, vecs_b = (uint64_t)lcount * sizeof(TailVec);
     const uint64_t total = rows_b + vecs_b ? rows_b + vecs_b : 256;
@@ -704,27 +836,33 @@ int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *
             ksum = (ksum + hr[r].root[a]) & (n - 1);
         }
         const fe scale = fe_pow_u64(w, (n - ksum) & (n - 1));              // prod_a omega^-r_a: 1/(w^i - w^r) = w^-r * u[i - r]
-        hr[r].k = fe_mul(fe_from_bytes(b_coeffs_host + (size_t)r * GS_ELT), scale);
-        hr[r].kp = b_adj_host ? fe_mul(fe_from_bytes(b_adj_host + (size_t)r * GS_ELT), scale) : fe_zero();
+        tail_coeffs(hr[r].c, fe_mul(fe_from_bytes(b_coeffs_host + (size_t)r * GS_ELT), scale),
+                    b_adj_host ? fe_mul(fe_from_bytes(b_adj_host + (size_t)r * GS_ELT), scale) : fe_zero());
         for (uint32_t t = 0; t < ilen; t++) hr[r].ipoly[t] = fe_from_bytes(ipolys_host + ((size_t)r * ilen + t) * GS_ELT);
     }
     for (uint32_t v = 0; v < lcount; v++) {
         hv[v].v = (const fe *)l_vecs_host[v];
-        hv[v].k = fe_from_bytes(l_coeffs_host + (size_t)v * GS_ELT);
-        hv[v].kp = l_adj_host ? fe_from_bytes(l_adj_host + (size_t)v * GS_ELT) : fe_zero();
+        tail_coeffs(hv[v].c, fe_from_bytes(l_coeffs_host + (size_t)v * GS_ELT), l_adj_host ? fe_from_bytes(l_adj_host + (size_t)v * GS_ELT) : fe_zero());
     }
     if ((rc = gs_push_commit(c, d, h, total))) { gs_tmp_free(c, d); return rc; }
     const TailRow *dr = (const TailRow *)d;
     const TailVec *dv = (const TailVec *)((uint8_t *)d + rows_b);
-    const bool has_pw = powers != nullptr, has_x = bcount && ilen > 1;
+    const bool adjusted = b_adj_host || l_adj_host;
+    const int pwk = !adjusted ? 0 : (powers ? 1 : 2);
+    const bool zc = !z_inv, has_x = zc || (bcount && ilen > 1);
+    const fe xl = x_last ? fe_from_bytes(x_last) : fe_zero();
     const dim3 grid(gs_grid(n)), block(256);
-#define GS_TAIL_LAUNCH(PW, X)                                                                                                                        \
-    hipLaunchKernelGGL((k_composition_tail<PW, X>), grid, block, 0, c->stream, (const fe *)q, (const fe *)z_inv, (const fe *)powers, u, lo, hi, log_lo, \
-                       gs_log2(n), n, dr, bcount, ilen ? ilen : 1u, dv, lcount, (fe *)c_out, (fe *)l_out)
-    if (has_pw && has_x) GS_TAIL_LAUNCH(1, 1);
-    else if (has_pw) GS_TAIL_LAUNCH(1, 0);
-    else if (has_x) GS_TAIL_LAUNCH(0, 1);
-    else GS_TAIL_LAUNCH(0, 0);
+    const fe pw_step = fe_pow_u64(w, (((powers_exponent & (n - 1)) * ((uint64_t)grid.x * block.x)) & (n - 1)));      // n <= 2^32: no overflow
+#define GS_TAIL_LAUNCH(PW, X, ZC)                                                                                                                    \
+    hipLaunchKernelGGL((k_composition_tail<PW, X, ZC>), grid, block, 0, c->stream, (const fe *)q, (const fe *)z_inv, (const fe *)powers, u, lo, hi,   \
+                       log_lo, gs_log2(n), n, dr, bcount, ilen ? ilen : 1u, dv, lcount, ztab, (uint32_t)period, xl, powers_exponent & (n - 1),         \
+                       pw_step, (fe *)c_out, (fe *)l_out)
+#define GS_TAIL_PW(X, ZC)                                                                                                                              \
+    do { if (pwk == 0) GS_TAIL_LAUNCH(0, X, ZC); else if (pwk == 1) GS_TAIL_LAUNCH(1, X, ZC); else GS_TAIL_LAUNCH(2, X, ZC); } while (0)
+    if (zc) GS_TAIL_PW(1, 1);
+    else if (has_x) GS_TAIL_PW(1, 0);
+    else GS_TAIL_PW(0, 0);
+#undef GS_TAIL_PW
 #undef GS_TAIL_LAUNCH
     hipError_t e = hipGetLastError();
     gs_tmp_free(c, d);      // stream-ordered reuse: later users of the block are queued behind this kernel

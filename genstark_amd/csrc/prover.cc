@@ -571,8 +571,21 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     uint32_t assertions_on_r0 = 0;
     for (uint32_t i = 0; i < job.nassertions; i++) assertions_on_r0 += job.assertions[i].reg == 0;
     const bool fused = air.kind == 0 && E <= 32 && air.nconstraints == 1 && assertions_on_r0 == job.nassertions && job.nassertions <= 4;
+    // the generic sequence's tail in one pass (gs_composition_tail) when the assertions fit its per-register limits: neither 1/Z(x) nor
+    // the power series of the degree adjustment is materialised then
+    bool tail = !fused && R + air.nsecret <= 96 && !getenv("GSTARK_NO_TAIL");
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> per_reg;
+        for (uint32_t i = 0; i < job.nassertions && tail; i++) {
+            bool found = false;
+            for (auto &e : per_reg) if (e.first == job.assertions[i].reg) { found = true; if (++e.second > 4) tail = false; }
+            if (!found) per_reg.push_back({job.assertions[i].reg, 1u});
+        }
+        if (per_reg.size() > 64) tail = false;
+    }
+    const bool tail_makes_z = tail && E <= 32;
     Buf zInverses;
-    if (!fused) {
+    if (!fused && !tail_makes_z) {
         zInverses = Buf(x, N * ELEM);
         // ZeroPolynomial.ts:36-44 and the division of CompositionPolynomial.ts:117 in one kernel: x^T - 1 takes only E distinct values
         le16(omega, s16);
@@ -593,7 +606,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     Buf psbPowers;                                                 // x^(compositionDegree - T) over the evaluation domain
     const uint64_t b_inc = composition_degree - T;
     const bool lc_folds = fused && R + air.nsecret == 1;           // LinearCombination folded into the composition kernel too
-    if (b_inc > 0 && !lc_folds) {                                  // also what LinearCombination.ts:44-52 multiplies by
+    if (b_inc > 0 && !lc_folds && !tail) {                         // also what LinearCombination.ts:44-52 multiplies by
         psbPowers = Buf(x, N * ELEM);
         le16(hf_pow(omega, (hfe)b_inc), s16);
         x.check(A.gs_power_series(x.c, s16, N, psbPowers.p), "gs_power_series(psb)");
@@ -792,7 +805,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
         // degree-adjusted merge, and LinearCombination.computeMany on top — when the assertions fit its per-register limits
         size_t tail_roots = 0;
         for (auto &d : rdata) tail_roots = std::max(tail_roots, d.at.size());
-        if (tail_roots <= 4 && bcount <= 64 && V <= 96 && !getenv("GSTARK_NO_TAIL")) {
+        if (tail) {
             const uint32_t il = (uint32_t)tail_roots;                   // an interpolant through m assertions has m coefficients
             Bytes ip((size_t)bcount * il * ELEM, 0);
             std::vector<uint64_t> at((size_t)bcount * il, 0);
@@ -814,9 +827,10 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
             Bytes cb(cnt * ELEM);
             for (uint32_t i = 0; i < cnt; i++) le16(co[offset + i], cb.data() + ELEM * i);
             le16(omega, s16);
-            x.check(A.gs_composition_tail(x.c, N, s16, qe.p, zInverses.p, pv.data(), bcount, ip.data(), il, at.data(), per_row.data(), il, bco.data(),
-                                          b_inc > 0 ? bco.data() + ELEM * bcount : nullptr, eVectors.data(), V, cb.data(), b_inc > 0 ? cb.data() + ELEM * V : nullptr,
-                                          b_inc > 0 ? psbPowers.p : nullptr, nullptr, cEval.p), "gs_composition_tail");
+            le16(hf_pow(omega, (hfe)((T - 1) * E)), s16b);                                           // ZeroPolynomial.ts:21-23: the last step's point
+            x.check(A.gs_composition_tail(x.c, N, s16, qe.p, tail_makes_z ? nullptr : zInverses.p, T, s16b, pv.data(), bcount, ip.data(), il, at.data(),
+                                          per_row.data(), il, bco.data(), b_inc > 0 ? bco.data() + ELEM * bcount : nullptr, eVectors.data(), V, cb.data(),
+                                          b_inc > 0 ? cb.data() + ELEM * V : nullptr, nullptr, b_inc, nullptr, cEval.p), "gs_composition_tail");
             lc_fused = true;
         } else {
         // 5.4 D(x) = Q(x) / Z(x) (:113-121)

@@ -380,16 +380,19 @@ int gs_air_constraints(gs_ctx *ctx, const uint32_t *code_host, uint32_t ninstr, 
  *        + sum_b (b_coeffs[b] + powers[i] * b_adj[b]) * (b_vecs[b][i] - I_b(x_i)) / prod_a (x_i - omega^root[b][a])
  *   l[i] = c[i] + sum_v (l_coeffs[v] + powers[i] * l_adj[v]) * l_vecs[v][i]
  * I_b: row b of ipolys_host (ilen coefficients, zero-extended: the interpolant through register b's assertions); the divisor's roots
- * are domain points, given by their positions (as gs_div_by_domain_roots).  b_adj / l_adj NULL: no degree adjustment of that sum
- * (powers may then be NULL too).  c_out NULL: C is not stored.  lcount = 0: l = c.  Replaces gs_vec_mul + gs_eval_polys_at_roots +
- * gs_sub_matrix_from_vectors + gs_div_by_domain_roots + two gs_combine_adjusted: seven passes and five intermediate matrices.
+ * are domain points, given by their positions (as gs_div_by_domain_roots).  b_adj / l_adj NULL: no degree adjustment of that sum.
+ * The two vectors that depend on the domain alone need not exist: z_inv NULL -> 1/Z(x_i) as gs_zero_poly_inverses(omega, n, z_steps,
+ * x_last) defines it, computed per point (n / z_steps <= 32); powers NULL (with an adjusted sum) -> powers[i] = omega^(i *
+ * powers_exponent), i.e. gs_power_series of omega^powers_exponent, from the domain's power tables.  c_out NULL: C is not stored.
+ * lcount = 0: l = c.  Replaces gs_zero_poly_inverses + gs_power_series + gs_vec_mul + gs_eval_polys_at_roots +
+ * gs_sub_matrix_from_vectors + gs_div_by_domain_roots + two gs_combine_adjusted: nine passes and seven intermediate vectors / matrices.
  * GS_ERR_UNSUPPORTED beyond 4 roots / 4 coefficients per row (callers then use the separate entries). */
-int gs_composition_tail(gs_ctx *ctx, uint64_t n, const gs_elt *omega, const void *q, const void *z_inv,
-                        const void *const *b_vecs_host, uint32_t bcount, const uint8_t *ipolys_host /* bcount x ilen */, uint32_t ilen,
-                        const uint64_t *root_index_host /* bcount x max_roots */, const uint32_t *roots_per_row_host, uint32_t max_roots,
-                        const uint8_t *b_coeffs_host, const uint8_t *b_adj_host /* or NULL */,
+int gs_composition_tail(gs_ctx *ctx, uint64_t n, const gs_elt *omega, const void *q, const void *z_inv /* or NULL: */, uint64_t z_steps,
+                        const gs_elt *x_last, const void *const *b_vecs_host, uint32_t bcount, const uint8_t *ipolys_host /* bcount x ilen */,
+                        uint32_t ilen, const uint64_t *root_index_host /* bcount x max_roots */, const uint32_t *roots_per_row_host,
+                        uint32_t max_roots, const uint8_t *b_coeffs_host, const uint8_t *b_adj_host /* or NULL */,
                         const void *const *l_vecs_host, uint32_t lcount, const uint8_t *l_coeffs_host, const uint8_t *l_adj_host /* or NULL */,
-                        const void *powers /* n elements, or NULL */, void *c_out /* or NULL */, void *l_out);
+                        const void *powers /* n elements, or NULL: */, uint64_t powers_exponent, void *c_out /* or NULL */, void *l_out);
 /* gs_air_constraints with the registers read IN PLACE from columns of a larger domain: register r at point j is
  * p[r * prow + j * pstride] (next row: point (j + shift) mod nc).  CompositionPolynomial.ts:76 evaluates the constraints over the
  * composition domain, whose points are every (N / nc)-th point of the evaluation domain the trace polynomials were just extended

@@ -315,25 +315,48 @@ int gs_div_by_domain_roots_coset(gs_ctx *c, const void *num, uint32_t rows, uint
  * steps it replaces — each one this file's own entry: D = Q / Z (CompositionPolynomial.ts:113-121), I_b over the domain, P_b - I_b,
  * / Z_b (BoundaryConstraints.ts:71-95), the degree-adjusted merge with D (CompositionPolynomial.ts:124-146), then
  * LinearCombination.computeMany with C added (LinearCombination.ts:36-64). */
-int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *q, const void *z_inv, const void *const *b_vecs, uint32_t bcount,
-                        const uint8_t *ipolys, uint32_t ilen, const uint64_t *root_index, const uint32_t *roots_per_row, uint32_t max_roots,
-                        const uint8_t *b_coeffs, const uint8_t *b_adj, const void *const *l_vecs, uint32_t lcount, const uint8_t *l_coeffs,
-                        const uint8_t *l_adj, const void *powers, void *c_out, void *l_out) {
-    if (!c || !omega || !q || !z_inv || !l_out) return GS_ERR_ARG;
+int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *q, const void *z_inv_in, uint64_t z_steps, const gs_elt *x_last,
+                        const void *const *b_vecs, uint32_t bcount, const uint8_t *ipolys, uint32_t ilen, const uint64_t *root_index,
+                        const uint32_t *roots_per_row, uint32_t max_roots, const uint8_t *b_coeffs, const uint8_t *b_adj, const void *const *l_vecs,
+                        uint32_t lcount, const uint8_t *l_coeffs, const uint8_t *l_adj, const void *powers_in, uint64_t powers_exponent, void *c_out,
+                        void *l_out) {
+    if (!c || !omega || !q || (!z_inv_in && !x_last) || !l_out) return GS_ERR_ARG;
     if (bcount && (!b_vecs || !ipolys || !roots_per_row || !b_coeffs || (max_roots && !root_index))) return GS_ERR_ARG;
     if (lcount && (!l_vecs || !l_coeffs)) return GS_ERR_ARG;
-    if ((b_adj || l_adj) && !powers) return GS_ERR_ARG;
-    if (!is_pow2(n)) return fail(c, GS_ERR_ARG, "composition_tail: n must be a power of two");
-    if (bcount && (ilen == 0 || ilen > 4)) return fail(c, GS_ERR_UNSUPPORTED, "composition_tail: 1..4 interpolant coefficients per row");
+    if ((b_adj || l_adj) && !powers_in && !powers_exponent) return GS_ERR_ARG;
+    /* the two domain-only vectors, when the caller did not make them: ZeroPolynomial.ts:36-44 + CompositionPolynomial.ts:117, and the
+     * power series of the degree adjustment (CompositionPolynomial.ts:124-138) */
+    const void *z_inv = z_inv_in, *powers = powers_in;
+    uint8_t *zmade = NULL, *pmade = NULL;
+    if (!z_inv) {
+        if (!is_pow2(n) || !is_pow2(z_steps) || z_steps > n) return fail(c, GS_ERR_ARG, "composition_tail: steps must be a power of two <= n");
+        if (n / z_steps > 32) return fail(c, GS_ERR_UNSUPPORTED, "composition_tail: n / steps above 32 (pass 1/Z as a vector)");
+        zmade = (uint8_t *)malloc((n ? n : 1) * FE_BYTES);
+        if (!zmade) return fail(c, GS_ERR_OOM, "malloc failed");
+        int zr = gs_zero_poly_inverses(c, omega, n, z_steps, x_last, zmade);
+        if (zr) { free(zmade); return zr; }
+        z_inv = zmade;
+    }
+    if ((b_adj || l_adj) && !powers) {
+        pmade = (uint8_t *)malloc((n ? n : 1) * FE_BYTES);
+        if (!pmade) { free(zmade); return fail(c, GS_ERR_OOM, "malloc failed"); }
+        uint8_t base[FE_BYTES];
+        fe_store(base, fe_exp(fe_load(omega), (fexp)(powers_exponent % n)));
+        int pr = gs_power_series(c, (const gs_elt *)base, n, pmade);
+        if (pr) { free(zmade); free(pmade); return pr; }
+        powers = pmade;
+    }
+    if (!is_pow2(n)) { free(zmade); free(pmade); return fail(c, GS_ERR_ARG, "composition_tail: n must be a power of two"); }
+    if (bcount && (ilen == 0 || ilen > 4)) { free(zmade); free(pmade); return fail(c, GS_ERR_UNSUPPORTED, "composition_tail: 1..4 interpolant coefficients per row"); }
     for (uint32_t r = 0; r < bcount; r++)
-        if (roots_per_row[r] > max_roots || roots_per_row[r] > 4) return fail(c, GS_ERR_UNSUPPORTED, "composition_tail: at most 4 roots per row");
+        if (roots_per_row[r] > max_roots || roots_per_row[r] > 4) { free(zmade); free(pmade); return fail(c, GS_ERR_UNSUPPORTED, "composition_tail: at most 4 roots per row"); }
     int rc = GS_OK;
     uint8_t *cbuf = (uint8_t *)malloc((n ? n : 1) * FE_BYTES), *mat = NULL;
-    if (!cbuf) return fail(c, GS_ERR_OOM, "malloc failed");
+    if (!cbuf) { free(zmade); free(pmade); return fail(c, GS_ERR_OOM, "malloc failed"); }
     rc = gs_vec_mul(c, q, z_inv, n, cbuf);
     if (!rc && bcount) {
         mat = (uint8_t *)malloc((size_t)3 * bcount * n * FE_BYTES);
-        if (!mat) { free(cbuf); return fail(c, GS_ERR_OOM, "malloc failed"); }
+        if (!mat) { free(cbuf); free(zmade); free(pmade); return fail(c, GS_ERR_OOM, "malloc failed"); }
         uint8_t *iv = mat, *pi = mat + (size_t)bcount * n * FE_BYTES, *bq = pi + (size_t)bcount * n * FE_BYTES;
         rc = gs_eval_polys_at_roots(c, ipolys, bcount, ilen, omega, n, iv);
         if (!rc) rc = gs_sub_matrix_from_vectors(c, b_vecs, iv, bcount, n, pi);
@@ -350,7 +373,7 @@ int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *
         if (lcount) rc = gs_combine_adjusted(c, l_vecs, l_coeffs, l_adj, lcount, l_adj ? powers : NULL, cbuf, n, l_out);
         else memcpy(l_out, cbuf, n * FE_BYTES);
     }
-    free(mat); free(cbuf);
+    free(mat); free(cbuf); free(zmade); free(pmade);
     return rc;
 }
 int gs_transpose_vector(gs_ctx *c, const void *v, uint64_t n, uint32_t cols, uint64_t step, void *o) {

@@ -788,10 +788,12 @@ def check_constraints_strided(backend, air, inputs):
     return got
 
 
-def check_composition_tail(backend, rng, logn, logsteps, per_row, lcount, adjusted, with_c=True):
+def check_composition_tail(backend, rng, logn, logsteps, per_row, lcount, adjusted, with_c=True, made=False):
     """gs_composition_tail against its definition on Python integers (sampled points) and against the sequence of entries it replaces
     (gs_vec_mul, gs_eval_polys_at_roots, gs_sub_matrix_from_vectors, gs_div_by_domain_roots, gs_combine_adjusted twice) on the same
-    backend (every point).  per_row: assertions per asserted register (1..4 each).  Returns (c, l) for cross-backend comparison."""
+    backend (every point).  per_row: assertions per asserted register (1..4 each).  made: 1/Z(x) and the power series are not passed as
+    vectors but as what defines them (steps + the last step's point; the exponent) — the entry computes them per point.  Returns (c, l)
+    for cross-backend comparison."""
     be = backend
     f = field_for(be)
     p = f.modulus
@@ -800,6 +802,13 @@ def check_composition_tail(backend, rng, logn, logsteps, per_row, lcount, adjust
     omega = f.getRootOfUnity(n)
     bcount, ilen = len(per_row), max(per_row)
     qv, zv, pwv = rand_elements(rng, n), rand_elements(rng, n), rand_elements(rng, n)
+    x_last = pow(omega, (steps - 1) * e, p)
+    pw_exp = rng.randrange(1, n)
+    if made:                                     # what gs_zero_poly_inverses / gs_power_series would have produced
+        zvec = f.newVector(n)
+        be.call('gs_zero_poly_inverses', f.le(omega), n, steps, f.le(x_last), C.c_void_p(zvec.ptr))
+        zv = zvec.toValues()
+        pwv = [pow(omega, i * pw_exp % n, p) for i in range(n)]
     bcols = [rand_elements(rng, n) for _ in range(bcount)]
     lcols = [rand_elements(rng, n) for _ in range(lcount)]
     roots = [sorted(rng.sample(range(steps), m)) for m in per_row]              # asserted steps of register b
@@ -814,9 +823,10 @@ def check_composition_tail(backend, rng, logn, logsteps, per_row, lcount, adjust
     pr = (C.c_uint32 * bcount)(*per_row)
     le = lambda xs: b''.join(f.le(v) for v in xs)
     c_out, l_out = f.newVector(n), f.newVector(n)
-    be.call('gs_composition_tail', n, f.le(omega), C.c_void_p(q.ptr), C.c_void_p(z.ptr), bp, bcount, le([v for row in ipolys for v in row]), ilen, ri, pr, ilen,
+    be.call('gs_composition_tail', n, f.le(omega), C.c_void_p(q.ptr), None if made else C.c_void_p(z.ptr), steps, f.le(x_last), bp, bcount,
+            le([v for row in ipolys for v in row]), ilen, ri, pr, ilen,
             le(bk), le(bkp) if adjusted else None, lp if lcount else None, lcount, le(lk) if lcount else None, le(lkp) if adjusted and lcount else None,
-            C.c_void_p(pw.ptr) if adjusted else None, C.c_void_p(c_out.ptr) if with_c else None, C.c_void_p(l_out.ptr))
+            C.c_void_p(pw.ptr) if adjusted and not made else None, pw_exp if made else 0, C.c_void_p(c_out.ptr) if with_c else None, C.c_void_p(l_out.ptr))
     got_c, got_l = (c_out.toValues() if with_c else None), l_out.toValues()
     # the definition, on integers
     for i in sorted({0, 1, n - 1, roots[0][0] * e + 1} | {rng.randrange(n) for _ in range(12)}):
@@ -868,9 +878,13 @@ def check_composition_tail_limits(backend):
     ri = (C.c_uint64 * 5)(0, 1, 2, 3, 4)
     pr = (C.c_uint32 * 1)(5)
     one = f.le(1)
-    args = lambda ilen, roots: (backend.ctx, n, f.le(f.getRootOfUnity(n)), C.c_void_p(v.ptr), C.c_void_p(v.ptr), bp, 1, one * 5, ilen, ri, pr, roots, one, None,
-                                None, 0, None, None, None, None, C.c_void_p(v.ptr))
+    args = lambda ilen, roots: (backend.ctx, n, f.le(f.getRootOfUnity(n)), C.c_void_p(v.ptr), C.c_void_p(v.ptr), 0, None, bp, 1, one * 5, ilen, ri, pr, roots, one, None,
+                                None, 0, None, None, None, 0, None, C.c_void_p(v.ptr))
     assert backend.lib.gs_composition_tail(*args(5, 5)) == -3 or backend.lib.gs_composition_tail(*args(5, 5)) != 0
     assert backend.lib.gs_composition_tail(*args(4, 5)) != 0
     a = list(args(4, 4)); a[-1] = None
+    assert backend.lib.gs_composition_tail(*a) != 0
+    a = list(args(4, 4)); a[4] = None                       # no 1/Z vector and nothing to compute it from
+    assert backend.lib.gs_composition_tail(*a) != 0
+    a = list(args(4, 4)); a[4] = None; a[5] = 1; a[6] = one   # n / steps = 64 > 32: the vector form is the one to use
     assert backend.lib.gs_composition_tail(*a) != 0

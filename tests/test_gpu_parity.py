@@ -178,7 +178,7 @@ def test_mimc_air(hip_backend, rng):
 
 
 @pytest.mark.parametrize('logn,logsteps,per_row,lcount,adjusted', [(8, 4, [1], 0, False), (12, 8, [2, 1], 3, True), (14, 10, [4, 1, 3], 7, True),
-                                                                   (16, 12, [1, 1], 6, True), (13, 9, [1, 1], 70, False), (16, 10, [3] * 20, 2, True)])
+                                                                   (16, 12, [1, 1], 6, True), (13, 9, [1, 1], 70, False), (16, 11, [3] * 20, 2, True)])
 def test_composition_tail(hip_backend, oracle_backend, logn, logsteps, per_row, lcount, adjusted):
     """gs_composition_tail on HIP: its definition, the member sequence it replaces, and the oracle's bytes."""
     seed = hash((logn, tuple(per_row), lcount)) & 0xffff
@@ -186,6 +186,9 @@ def test_composition_tail(hip_backend, oracle_backend, logn, logsteps, per_row, 
     if logn <= 14:
         assert got == cases.check_composition_tail(oracle_backend, random.Random(seed), logn, logsteps, per_row, lcount, adjusted)
     cases.check_composition_tail(hip_backend, random.Random(seed + 1), logn, logsteps, per_row, lcount, adjusted, with_c=False)
+    got = cases.check_composition_tail(hip_backend, random.Random(seed + 2), logn, logsteps, per_row, lcount, adjusted, made=True)
+    if logn <= 14:
+        assert got == cases.check_composition_tail(oracle_backend, random.Random(seed + 2), logn, logsteps, per_row, lcount, adjusted, made=True)
     cases.check_composition_tail_limits(hip_backend)
 
 

@@ -101,6 +101,7 @@ def test_mimc_air(oracle_backend, rng):
                                                                    (8, 5, [1, 1], 6, False)])
 def test_composition_tail(oracle_backend, rng, logn, logsteps, per_row, lcount, adjusted):
     cases.check_composition_tail(oracle_backend, rng, logn, logsteps, per_row, lcount, adjusted)
+    cases.check_composition_tail(oracle_backend, rng, logn, logsteps, per_row, lcount, adjusted, made=True)
     cases.check_composition_tail_limits(oracle_backend)
 
 
