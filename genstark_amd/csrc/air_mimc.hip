@@ -115,21 +115,32 @@ int gs_mimc_composition(gs_ctx *c, const void *p_eval, uint64_t n, uint64_t step
         a.ipoly[r] = r < nroots ? fe_from_bytes(ipoly_host + GS_ELT * r) : fe_zero();
         if (r < nroots) ksum = (ksum + a.root[r]) & (n - 1);
     }
-    const fe scale = fe_pow_u64(w, (n - ksum) & (n - 1));                    // prod omega^-k_a
-    const fe g = fe_pow_u64(w, steps);                                       // x^steps = g^(i mod period)
-    const fe gq = fe_pow_u64(g, (q_inc / steps) % period), gb = fe_pow_u64(g, (b_inc / steps) % period);
-    fe gj = fe_one(), gqj = fe_one(), gbj = fe_one();
+    const fe scale = gs_memo_pow(c, w, (n - ksum) & (n - 1));                // prod omega^-k_a
+    // what depends on the domain and the degrees alone, remembered per context: [3j] 1/(g^j - 1) (j = 0: 0^-1 = 0), [3j+1] g^(j*qm),
+    // [3j+2] g^(j*bm) for g = omega^steps (x^steps = g^(i mod period)), then x_last — sixteen inversions of 4 us each otherwise, on the
+    // host between the arrival of the evaluation root and this launch
+    const std::vector<fe> &tab = gs_memo(c, gs_memo_key("mimc_comp").add(w).add(n).add(steps).add(q_inc).add(b_inc), [&](std::vector<fe> &t) {
+        const fe g = fe_pow_u64(w, steps);
+        const fe gq = fe_pow_u64(g, (q_inc / steps) % period), gb = fe_pow_u64(g, (b_inc / steps) % period);
+        fe gj = fe_one(), gqj = fe_one(), gbj = fe_one();
+        for (uint64_t j = 0; j < period; j++) {
+            t.push_back(fe_inv(fe_sub(gj, fe_one())));
+            t.push_back(gqj);
+            t.push_back(gbj);
+            gj = fe_mul(gj, g); gqj = fe_mul(gqj, gq); gbj = fe_mul(gbj, gb);
+        }
+        t.push_back(fe_pow_u64(w, (steps - 1) * period));
+    });
     for (uint64_t j = 0; j < GS_MIMC_COMP_MAX_PERIOD; j++) {
         if (j < period) {
-            a.qz[j] = fe_mul(fe_add(d0, fe_mul(d1, gqj)), fe_inv(fe_sub(gj, fe_one())));      // j = 0: 0^-1 = 0
-            a.bt[j] = fe_mul(fe_add(b0, fe_mul(b1, gbj)), scale);
-            a.lt[j] = fe_add(l0, fe_mul(l1, gbj));
+            a.qz[j] = fe_mul(fe_add(d0, fe_mul(d1, tab[3 * j + 1])), tab[3 * j]);
+            a.bt[j] = fe_mul(fe_add(b0, fe_mul(b1, tab[3 * j + 2])), scale);
+            a.lt[j] = fe_add(l0, fe_mul(l1, tab[3 * j + 2]));
         } else {
             a.qz[j] = a.bt[j] = a.lt[j] = fe_zero();
         }
-        gj = fe_mul(gj, g); gqj = fe_mul(gqj, gq); gbj = fe_mul(gbj, gb);
     }
-    a.x_last = fe_pow_u64(w, (steps - 1) * period);
+    a.x_last = tab[3 * period];
     hipLaunchKernelGGL(k_mimc_composition, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const fe *)p_eval, n, period, (const fe *)k_table, klen, lo, hi,
                        log_lo, gs_log2(n), u, a, (uint32_t)period, nroots, lc_coeffs_host ? 1 : 0, (fe *)out);
     GS_LAUNCH_CHECK(c);

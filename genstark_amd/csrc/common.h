@@ -57,6 +57,9 @@ struct gs_ctx {
     uint64_t stage_bytes = 0;
     void *fri_x = nullptr;        // the evaluation point gs_fri_fold_seeded derives on the device
     void *fri_points = nullptr;   // gs_fri_layers: points between layers the caller did not ask for + the arrival counter of its multi-workgroup launches
+    // host-side scalar tables that depend on the domain alone (1 / (g^j - 1), powers of omega by fixed exponents): a proof server asks
+    // for the same ones with every proof, and an inversion is 4 us of host time on the critical path of a 0.5 ms proof (gs_memo)
+    std::map<std::string, std::vector<fe>> scalar_memo;
     uint64_t jit_launches = 0;    // compiled-program launches so far (gs_air_jit_launches)
     uint64_t host_trace_segments = GS_HOST_TRACE_MAX_SEGMENTS;   // traces of at most this many segments run on a host core (GSTARK_HOST_TRACE_SEGMENTS; air_vm.hip)
     int air_jit = 2;              // AIR programs: 0 interpreted, 1 compiled on first use (hiprtc), 2 auto = compiled when the code object already exists (gs_air_jit / GSTARK_AIR_JIT)
@@ -91,6 +94,29 @@ struct gs_ctx {
 };
 
 int gs_fail(gs_ctx *c, int code, const char *fmt, ...);
+
+// key: a tag + the bytes of whatever the table depends on
+struct gs_memo_key {
+    std::string k;
+    explicit gs_memo_key(const char *tag) : k(tag) {}
+    gs_memo_key &add(const void *p, size_t n) { k.append((const char *)p, n); return *this; }
+    gs_memo_key &add(uint64_t v) { return add(&v, sizeof v); }
+    gs_memo_key &add(const fe &v) { return add(&v, sizeof v); }
+};
+template <class Build>
+static inline const std::vector<fe> &gs_memo(gs_ctx *c, const gs_memo_key &key, Build build) {
+    auto it = c->scalar_memo.find(key.k);
+    if (it == c->scalar_memo.end()) {
+        if (c->scalar_memo.size() > 1024) c->scalar_memo.clear();
+        it = c->scalar_memo.emplace(key.k, std::vector<fe>()).first;
+        build(it->second);
+    }
+    return it->second;
+}
+// omega^e for an exponent that recurs from proof to proof
+static inline fe gs_memo_pow(gs_ctx *c, const fe &w, uint64_t e) {
+    return gs_memo(c, gs_memo_key("pow").add(w).add(e), [&](std::vector<fe> &t) { t.push_back(fe_pow_u64(w, e)); })[0];
+}
 
 #define GS_HIP(c, call)                                                                              \
     do {                                                                                             \

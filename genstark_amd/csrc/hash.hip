@@ -645,12 +645,13 @@ int gs_fri_layers(gs_ctx *c, gs_hash_alg alg, const gs_elt *omega, uint64_t n, u
     const fe *lo, *hi;
     int log_lo;
     if ((rc = gs_plan_pow_tables(c, w, n, &lo, &hi, &log_lo))) return rc;
-    const fe zeta = fe_pow_u64(w, n / 4);
+    const fe zeta = gs_memo_pow(c, w, n / 4);
     FriLayersArgs a;
     memset(&a, 0, sizeof a);
     a.tw_lo = lo; a.tw_hi = hi; a.log_lo = log_lo; a.logn = gs_log2(n); a.n = n;
     a.zeta_inv = fe_mul(fe_mul(zeta, zeta), zeta);
-    a.inv4 = fe_inv(fe_from_u64(4));
+    static const fe inv4_const = fe_inv(fe_from_u64(4));  // (a constant of the field: computed once)
+    a.inv4 = inv4_const;
     a.counter = counter;
     const void *col = column;
     const void *point = x_dev;

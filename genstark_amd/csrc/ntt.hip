@@ -999,11 +999,12 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
         const uint8_t *o0 = (const uint8_t *)out, *o1 = o0 + total * GS_ELT;
         if (i0 < o1 && o0 < i1) return gs_fail(c, GS_ERR_ARG, "ntt: output overlaps input");
     }
-    fe w = inverse ? fe_inv(omega) : omega;
+    // (inversions are 4 us of host time each: remembered per context, a prover asks for the same ones with every proof)
+    fe w = inverse ? gs_memo(c, gs_memo_key("inv").add(omega), [&](std::vector<fe> &t) { t.push_back(fe_inv(omega)); })[0] : omega;
     NttPlan *p;
     int rc = plan_get(c, w, n, &p);
     if (rc) return rc;
-    fe ninv = inverse ? fe_inv(fe_from_u64(n)) : fe_one();
+    fe ninv = inverse ? gs_memo(c, gs_memo_key("inv").add(fe_from_u64(n)), [&](std::vector<fe> &t) { t.push_back(fe_inv(fe_from_u64(n))); })[0] : fe_one();
 
     if (n < 256 || in_len <= 8) {
         dim3 grid(gs_grid(n, 256, 1024), rows);

@@ -727,12 +727,15 @@ int gs_zero_poly_inverses_coset(gs_ctx *c, const gs_elt *omega, uint64_t n, cons
     int rc = gs_plan_pow_tables(c, w, n, &lo, &hi, &log_lo);      // also checks that omega is a primitive n-th root of unity
     if (rc) return rc;
     ZTable tab;
-    const fe g = fe_pow_u64(w, steps);                            // x_i^steps = shift^steps * g^(i mod period)
-    fe cur = fe_pow_u64(shift, steps);
-    for (uint64_t j = 0; j < GS_ZPOLY_MAX_PERIOD; j++) {
-        tab.c[j] = j < period ? fe_inv(fe_sub(cur, fe_one())) : fe_zero();     // j = 0: 0^-1 = 0
-        cur = fe_mul(cur, g);
-    }
+    const std::vector<fe> &inv = gs_memo(c, gs_memo_key("zpoly").add(w).add(n).add(steps).add(shift), [&](std::vector<fe> &t) {
+        const fe g = fe_pow_u64(w, steps);                        // x_i^steps = shift^steps * g^(i mod period)
+        fe cur = fe_pow_u64(shift, steps);
+        for (uint64_t j = 0; j < period; j++) {
+            t.push_back(fe_inv(fe_sub(cur, fe_one())));           // j = 0: 0^-1 = 0
+            cur = fe_mul(cur, g);
+        }
+    });
+    for (uint64_t j = 0; j < GS_ZPOLY_MAX_PERIOD; j++) tab.c[j] = j < period ? inv[j] : fe_zero();
     hipLaunchKernelGGL(k_zero_poly_inverses, dim3(gs_grid(n)), dim3(256), 0, c->stream, lo, hi, log_lo, gs_log2(n), n, tab, (uint32_t)period,
                        fe_from_bytes(x_last), shift, has_shift, (fe *)out);
     GS_LAUNCH_CHECK(c);
@@ -764,7 +767,7 @@ int gs_div_by_domain_roots_coset(gs_ctx *c, const void *num, uint32_t rows, uint
             ra.k[a] = a < roots_per_row_host[r] ? root_index_host[(uint64_t)r * max_roots + a] & (n - 1) : 0;
             if (a < roots_per_row_host[r]) ksum = (ksum + ra.k[a]) & (n - 1);
         }
-        const fe scale = fe_pow_u64(w, (n - ksum) & (n - 1));     // prod omega^-k_a
+        const fe scale = gs_memo_pow(c, w, (n - ksum) & (n - 1));     // prod omega^-k_a
         hipLaunchKernelGGL(k_div_by_domain_roots, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const fe *)num + (uint64_t)r * n, u, n, ra,
                            roots_per_row_host[r], scale, (fe *)out + (uint64_t)r * n);
     }
@@ -809,12 +812,15 @@ int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *
     if (!rc && bcount) rc = gs_plan_inverse_table(c, w, n, &u);
     if (rc) return rc;
     if (!z_inv) {                                                  // gs_zero_poly_inverses' table: 1 / (g^j - 1), g = omega^steps, 0^-1 = 0
-        const fe g = fe_pow_u64(w, z_steps);
-        fe cur = fe_one();
-        for (uint64_t j = 0; j < GS_ZPOLY_MAX_PERIOD; j++) {
-            ztab.c[j] = j < period ? fe_inv(fe_sub(cur, fe_one())) : fe_zero();
-            cur = fe_mul(cur, g);
-        }
+        const std::vector<fe> &inv = gs_memo(c, gs_memo_key("zpoly").add(w).add(n).add(z_steps).add(fe_one()), [&](std::vector<fe> &t) {
+            const fe g = fe_pow_u64(w, z_steps);
+            fe cur = fe_one();
+            for (uint64_t j = 0; j < period; j++) {
+                t.push_back(fe_inv(fe_sub(cur, fe_one())));
+                cur = fe_mul(cur, g);
+            }
+        });
+        for (uint64_t j = 0; j < GS_ZPOLY_MAX_PERIOD; j++) ztab.c[j] = j < period ? inv[j] : fe_zero();
     } else {
         for (uint64_t j = 0; j < GS_ZPOLY_MAX_PERIOD; j++) ztab.c[j] = fe_zero();
     }
@@ -835,7 +841,7 @@ int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *
             hr[r].root[a] = root_index_host[(uint64_t)r * max_roots + a] & (n - 1);
             ksum = (ksum + hr[r].root[a]) & (n - 1);
         }
-        const fe scale = fe_pow_u64(w, (n - ksum) & (n - 1));              // prod_a omega^-r_a: 1/(w^i - w^r) = w^-r * u[i - r]
+        const fe scale = gs_memo_pow(c, w, (n - ksum) & (n - 1));          // prod_a omega^-r_a: 1/(w^i - w^r) = w^-r * u[i - r]
         tail_coeffs(hr[r].c, fe_mul(fe_from_bytes(b_coeffs_host + (size_t)r * GS_ELT), scale),
                     b_adj_host ? fe_mul(fe_from_bytes(b_adj_host + (size_t)r * GS_ELT), scale) : fe_zero());
         for (uint32_t t = 0; t < ilen; t++) hr[r].ipoly[t] = fe_from_bytes(ipolys_host + ((size_t)r * ilen + t) * GS_ELT);
@@ -852,7 +858,7 @@ int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *
     const bool zc = !z_inv, has_x = zc || (bcount && ilen > 1);
     const fe xl = x_last ? fe_from_bytes(x_last) : fe_zero();
     const dim3 grid(gs_grid(n)), block(256);
-    const fe pw_step = fe_pow_u64(w, (((powers_exponent & (n - 1)) * ((uint64_t)grid.x * block.x)) & (n - 1)));      // n <= 2^32: no overflow
+    const fe pw_step = gs_memo_pow(c, w, (((powers_exponent & (n - 1)) * ((uint64_t)grid.x * block.x)) & (n - 1)));      // n <= 2^32: no overflow
 #define GS_TAIL_LAUNCH(PW, X, ZC)                                                                                                                    \
     hipLaunchKernelGGL((k_composition_tail<PW, X, ZC>), grid, block, 0, c->stream, (const fe *)q, (const fe *)z_inv, (const fe *)powers, u, lo, hi,   \
                        log_lo, gs_log2(n), n, dr, bcount, ilen ? ilen : 1u, dv, lcount, ztab, (uint32_t)period, xl, powers_exponent & (n - 1),         \
@@ -947,9 +953,9 @@ int gs_interpolate_quartic_domain(gs_ctx *c, const gs_elt *omega, uint64_t n, ui
     int log_lo;
     int rc = gs_plan_pow_tables(c, w, n, &lo, &hi, &log_lo);
     if (rc) return rc;
-    fe zeta = fe_pow_u64(w, n / 4);
+    fe zeta = gs_memo_pow(c, w, n / 4);
     fe zeta_inv = fe_mul(fe_mul(zeta, zeta), zeta);  // zeta^3 = zeta^-1
-    fe inv4 = fe_inv(fe_from_u64(4));
+    static const fe inv4 = fe_inv(fe_from_u64(4));      // (a constant of the field: computed once)
     hipLaunchKernelGGL(k_quartic_interp_domain, dim3(gs_grid(rows)), dim3(256), 0, c->stream, (const fe *)ys, rows, step, n, lo, hi,
                        log_lo, gs_log2(n), zeta_inv, inv4, (fe *)out);
     GS_LAUNCH_CHECK(c);
@@ -964,9 +970,9 @@ static int fri_fold_launch(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t 
     int log_lo;
     int rc = gs_plan_pow_tables(c, w, n, &lo, &hi, &log_lo);
     if (rc) return rc;
-    fe zeta = fe_pow_u64(w, n / 4);
+    fe zeta = gs_memo_pow(c, w, n / 4);
     fe zeta_inv = fe_mul(fe_mul(zeta, zeta), zeta);  // zeta^3 = zeta^-1
-    fe inv4 = fe_inv(fe_from_u64(4));
+    static const fe inv4 = fe_inv(fe_from_u64(4));      // (a constant of the field: computed once)
     hipLaunchKernelGGL(k_fri_fold, dim3(gs_grid(m / 4)), dim3(256), 0, c->stream, (const fe *)column, m / 4, step, n, lo, hi, log_lo, gs_log2(n),
                        zeta_inv, inv4, x, x_dev, (fe *)out);
     GS_LAUNCH_CHECK(c);
