@@ -72,8 +72,8 @@ int gs_mimc_trace(gs_ctx *c, const gs_elt *seed, const uint8_t *rc_host, uint32_
     for (uint64_t base = 0; base < steps; base += CHUNK) {
         const uint64_t end = base + CHUNK < steps ? base + CHUNK : steps;
         for (uint64_t i = base; i < end; i++) {
-            t[i] = x;
-            x = hf_mimc_step(x, rc[ri]);
+            t[i] = hf_mimc_out(x);                // the canonical value, beside the chain
+            x = hf_mimc_step_weak(x, rc[ri]);     // the chain itself stays weak (host_field.h)
             if (++ri == nrc) ri = 0;
         }
         GS_HIP(c, hipMemcpyAsync((uint8_t *)out + base * GS_ELT, t + base, (end - base) * GS_ELT, hipMemcpyHostToDevice, c->stream));

@@ -130,6 +130,46 @@ static inline hfe hf_inv(hfe a) { return a ? hf_pow(a, hf_p() - 2) : 0; }
 static inline bool hf_is_zero(hfe a) { return a == 0; }
 static inline hfe hf_load(const uint8_t *b) { hfe v; memcpy(&v, b, 16); return v; }
 static inline void hf_store(uint8_t *b, hfe v) { memcpy(b, &v, 16); }
+// x^3 + k in one go, weak in and weak out (any 128-bit representatives; k < 2^128): hf_cube_weak with k's two limbs joining the limb sums
+// of the first fold.  A separate "+ k" after the cube wraps past 2^128 every other step (k is a uniform residue) — a select or a
+// mispredicted branch on the chain — and a canonical chain adds its compare-and-subtract to every step; here the constant costs no
+// step of the dependency chain at all (the sums it joins have other terms arriving later), the only fix-up left is the one-in-2^55
+// wrap of R + T*C, and the canonical value the trace stores is computed beside the chain (hf_mimc_out), not on it.
+static inline hfe hf_cube_add_weak(hfe x, hfe k) {
+    typedef uint64_t u64;
+    const u64 C = (u64)HF_C, C20 = 0xFFFFFFEE00000001ull, C21 = 80;   // C^2 = 81*2^64 - 18*2^32 + 1 = C21*2^64 + C20
+    u64 x0 = (u64)x, x1 = (u64)(x >> 64);
+    hfe p00 = (hfe)x0 * x0, p01 = (hfe)x0 * x1, p11 = (hfe)x1 * x1;
+    u64 s0 = (u64)p00;
+    hfe mid = (p00 >> 64) + ((hfe)(u64)p01 << 1);
+    u64 s1 = (u64)mid;
+    hfe up = (mid >> 64) + ((p01 >> 64) << 1) + (u64)p11;
+    u64 s2 = (u64)up;
+    u64 s3 = (u64)(up >> 64) + (u64)(p11 >> 64);
+    hfe q00 = (hfe)s0 * x0, q10 = (hfe)s1 * x0, q20 = (hfe)s2 * x0, q30 = (hfe)s3 * x0;
+    hfe q01 = (hfe)s0 * x1, q11 = (hfe)s1 * x1, q21 = (hfe)s2 * x1, q31 = (hfe)s3 * x1;
+    u64 y0 = (u64)q00;
+    hfe c1 = (q00 >> 64) + (u64)q10 + (u64)q01;
+    u64 y1 = (u64)c1;
+    hfe c2 = (c1 >> 64) + (q10 >> 64) + (q01 >> 64) + (u64)q20 + (u64)q11;
+    u64 y2 = (u64)c2;
+    hfe c3 = (c2 >> 64) + (q20 >> 64) + (q11 >> 64) + (u64)q30 + (u64)q21;
+    u64 y3 = (u64)c3;
+    hfe c4 = (c3 >> 64) + (q30 >> 64) + (q21 >> 64) + (u64)q31;
+    u64 y4 = (u64)c4;
+    u64 y5 = (u64)(c4 >> 64) + (u64)(q31 >> 64);
+    hfe A = (hfe)y2 * C, B = (hfe)y3 * C, D = (hfe)y4 * C20, E = (hfe)y4 * C21, G = (hfe)y5 * C20, H = (hfe)y5 * C21;
+    hfe a0 = (hfe)y0 + (u64)k + (u64)A + (u64)D;                                                       // (four 64-bit terms: < 2^66)
+    hfe a1 = (hfe)y1 + (u64)(k >> 64) + (u64)(A >> 64) + (u64)(D >> 64) + (u64)B + (u64)E + (u64)G + (u64)(a0 >> 64);
+    hfe T = (B >> 64) + (E >> 64) + (G >> 64) + H + (a1 >> 64);          // < 2^73
+    hfe R = ((hfe)(u64)a1 << 64) | (u64)a0;
+    hfe TC = (hfe)(u64)T * C + (((hfe)(u64)(T >> 64) * C) << 64);
+    hfe r = R + TC;
+    if (__builtin_expect(r < R, 0)) r += HF_C;
+    return r;
+}
+static inline hfe hf_mimc_step_weak(hfe xw, hfe k) { return hf_cube_add_weak(xw, k); }
+static inline hfe hf_mimc_out(hfe xw) { return xw >= hf_p() ? xw - hf_p() : xw; }      // a weak value is below 2^128 < 2p
 // one step of the MiMC recurrence x <- x^3 + k (examples/mimc/utils.ts:7-15) on the weak cube
 static inline hfe hf_mimc_step(hfe x, hfe k) {
     hfe y = hf_cube_weak(x);                           // any representative of x^3

@@ -33,6 +33,9 @@ static inline hfe hf_pow(hfe b, hfe e) {
 }
 static inline hfe hf_inv(hfe a) { return a % HF_Q ? hf_pow(a, HF_Q - 2) : 0; }
 static inline hfe hf_mimc_step(hfe x, hfe k) { return hf_add(hf_cube_weak(x), k % HF_Q); }
+// (the 128-bit flavour keeps the chain weak and canonicalises beside it: host_field.h)
+static inline hfe hf_mimc_step_weak(hfe x, hfe k) { return hf_mimc_step(x, k); }
+static inline hfe hf_mimc_out(hfe x) { return x; }
 static inline bool hf_is_zero(hfe a) { return a % HF_Q == 0; }
 static inline hfe hf_load(const uint8_t *b) { hfe v; memcpy(&v, b, 16); return v; }
 static inline void hf_store(uint8_t *b, hfe v) { memcpy(b, &v, 16); }

@@ -128,6 +128,9 @@ static inline hfe hf_inv(hfe a) {                      // Fermat, 0 -> 0 (as fe_
     return hf_pow(a, e);
 }
 static inline hfe hf_mimc_step(hfe x, hfe k) { return hf_add(hf_mul(hf_mul(x, x), x), k); }   // examples/mimc/utils.ts:7-15
+// (the 128-bit flavour keeps the chain weak and canonicalises beside it: host_field.h)
+static inline hfe hf_mimc_step_weak(hfe x, hfe k) { return hf_mimc_step(x, k); }
+static inline hfe hf_mimc_out(hfe x) { return x; }
 static inline bool hf_is_zero(hfe a) { return fe_is_zero(a.v); }
 static inline hfe hf_load(const uint8_t *b) { hfe r; memcpy(&r.v, b, sizeof(fe)); return r; }
 static inline void hf_store(uint8_t *b, hfe x) { memcpy(b, &x.v, sizeof(fe)); }

@@ -1,7 +1,9 @@
 // host_field_check.cpp — the host-side field arithmetic of the library (csrc/host_field*.h, csrc/host_pow.h: what the host trace
 // interpreter of air_vm.hip computes with) as a filter, so that tests/test_host_field.py can compare it with Python integers on
 // machines without a GPU.  Build: g++ -O2 [-DGS_WIDE_BITS=224|256 | -DGS_SMALL_Q=<q>ull] tools/host_field_check.cpp
-// stdin: lines "a b e" (hex, big endian); stdout: "a*b  a^-1  a^e  b^e" computed by hf_mul, hf_inv and host_pow_group (g = 2).
+// stdin: lines "a b e" (hex, big endian); stdout: "a*b  a^-1  a^e  b^e  m1  m2" computed by hf_mul, hf_inv and host_pow_group (g = 2);
+// m1 = two steps of the MiMC recurrence as gs_mimc_trace runs it (weak chain, canonical value taken beside it): ((a^3 + b)^3 + b);
+// m2 (128-bit flavour: the same from the NON-canonical 128-bit value ~a — the chain accepts any representative; others: = m1).
 #include <stdio.h>
 #include <stdint.h>
 #include <string.h>
@@ -37,7 +39,13 @@ int main() {
         show(hf_mul(x, y)); printf(" ");
         show(hf_inv(x)); printf(" ");
         show(g[0]); printf(" ");
-        show(g[1]); printf("\n");
+        show(g[1]); printf(" ");
+        show(hf_mimc_out(hf_mimc_step_weak(hf_mimc_step_weak(x, y), y))); printf(" ");
+#if !defined(GS_WIDE_BITS) && !defined(GS_SMALL_Q)
+        show(hf_mimc_out(hf_mimc_step_weak(hf_mimc_step_weak(~x, y), y))); printf("\n");
+#else
+        show(hf_mimc_out(hf_mimc_step_weak(hf_mimc_step_weak(x, y), y))); printf("\n");
+#endif
     }
     return 0;
 }

@@ -44,12 +44,60 @@ static inline hfe hf_cube_direct(hfe x) {
 #undef HI
 }
 
+// ---- experiment: hf_cube_add_weak with the second fold started early: the part of T that does not wait for a1's carry is multiplied by C
+// beside the limb sums; the carry (< 16) joins as carry * C
+static inline hfe hf_cube_add_early(hfe x, hfe k) {
+    typedef uint64_t u64;
+    const u64 C = (u64)HF_C, C20 = 0xFFFFFFEE00000001ull, C21 = 80;
+    u64 x0 = (u64)x, x1 = (u64)(x >> 64);
+    hfe p00 = (hfe)x0 * x0, p01 = (hfe)x0 * x1, p11 = (hfe)x1 * x1;
+    u64 s0 = (u64)p00;
+    hfe mid = (p00 >> 64) + ((hfe)(u64)p01 << 1);
+    u64 s1 = (u64)mid;
+    hfe up = (mid >> 64) + ((p01 >> 64) << 1) + (u64)p11;
+    u64 s2 = (u64)up;
+    u64 s3 = (u64)(up >> 64) + (u64)(p11 >> 64);
+    hfe q00 = (hfe)s0 * x0, q10 = (hfe)s1 * x0, q20 = (hfe)s2 * x0, q30 = (hfe)s3 * x0;
+    hfe q01 = (hfe)s0 * x1, q11 = (hfe)s1 * x1, q21 = (hfe)s2 * x1, q31 = (hfe)s3 * x1;
+    u64 y0 = (u64)q00;
+    hfe c1 = (q00 >> 64) + (u64)q10 + (u64)q01;
+    u64 y1 = (u64)c1;
+    hfe c2 = (c1 >> 64) + (q10 >> 64) + (q01 >> 64) + (u64)q20 + (u64)q11;
+    u64 y2 = (u64)c2;
+    hfe c3 = (c2 >> 64) + (q20 >> 64) + (q11 >> 64) + (u64)q30 + (u64)q21;
+    u64 y3 = (u64)c3;
+    hfe c4 = (c3 >> 64) + (q30 >> 64) + (q21 >> 64) + (u64)q31;
+    u64 y4 = (u64)c4;
+    u64 y5 = (u64)(c4 >> 64) + (u64)(q31 >> 64);
+    hfe A = (hfe)y2 * C, B = (hfe)y3 * C, D = (hfe)y4 * C20, E = (hfe)y4 * C21, G = (hfe)y5 * C20, H = (hfe)y5 * C21;
+    hfe T0 = (B >> 64) + (E >> 64) + (G >> 64) + H;                       // < 2^73, ready with the fold products
+    hfe TC0 = (hfe)(u64)T0 * C + (((hfe)(u64)(T0 >> 64) * C) << 64);       // beside the limb sums below
+    hfe a0 = (hfe)y0 + (u64)k + (u64)A + (u64)D;
+    hfe a1 = (hfe)y1 + (u64)(k >> 64) + (u64)(A >> 64) + (u64)(D >> 64) + (u64)B + (u64)E + (u64)G + (u64)(a0 >> 64);
+    hfe R = ((hfe)(u64)a1 << 64) | (u64)a0;
+    hfe r = R + TC0;
+    u64 wrap = r < R;                                                      // (probability 2^-18)
+    hfe r2 = r + (hfe)((u64)(a1 >> 64) + 0) * C;                           // the carry of the limb sums: < 16
+    const u64 wrap2 = r2 < r;
+    if (__builtin_expect(wrap | wrap2, 0)) {                               // every wrap past 2^128 comes back as + C
+        const hfe r3 = r2 + (hfe)(wrap + wrap2) * HF_C;
+        r2 = r3 < r2 ? r3 + HF_C : r3;
+    }
+    return r2;
+}
+
 template <int V>
 static double run(uint64_t steps, const std::vector<hfe> &rc, hfe seed, std::vector<hfe> &t) {
     auto t0 = std::chrono::steady_clock::now();
     hfe x = seed;
     uint32_t ri = 0, nrc = (uint32_t)rc.size();
     for (uint64_t i = 0; i < steps; i++) {
+        if (V & 8) {          // the product's chain since round 4: k joins the cube's first fold, weak chain, canonical value beside it
+            t[i] = hf_mimc_out(x);
+            x = (V & 16) ? hf_cube_add_early(x, rc[ri]) : hf_mimc_step_weak(x, rc[ri]);
+            if (++ri == nrc) ri = 0;
+            continue;
+        }
         hfe y = (V & 4) ? hf_cube_direct(x) : (V & 2) ? hf_cube_weak(x) : hf_mul_weak(hf_mul_weak(x, x), x);
         hfe sum = y + rc[ri];
         if (V & 1) {          // weak chain, canonicalisation off the critical path
@@ -78,6 +126,11 @@ int main() {
         for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t1[i] && t0[i] == t2[i] && t0[i] == t3[i];
         double e = run<4>(steps, rc, seed, t1), f = run<5>(steps, rc, seed, t3);
         for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t1[i] && t0[i] == t3[i];
+        double g8 = run<8>(steps, rc, seed, t2);
+        for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
+        double g24 = run<24>(steps, rc, seed, t2);
+        for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
+        printf("2^20 steps: cube + k in one fold, weak chain %.2f ms | + second fold started early %.2f ms\n", g8, g24);
         printf("2^20 steps: A/canon-chain %.2f ms | A/weak-chain %.2f ms | cube/canon-chain %.2f ms | cube/weak-chain %.2f ms | direct/canon %.2f ms | direct/weak %.2f ms  (%s)\n", a, b, c, d, e, f,
                ok ? "all equal" : "DIFF");
     }
