@@ -187,9 +187,48 @@ __device__ __forceinline__ fe prng_point(const uint32_t *seed);
 
 #define GS_MERKLE_CHUNK 1024
 #define GS_MERKLE_SUBTREE_THREADS 1024      // one first-layer digest per thread, the 512-node level in one step, quads from 256 nodes down
+// The levels of a subtree whose first layer (2 * first_m digests) sits in LDS at heap slots [2 first_m, 4 first_m): one barrier per level,
+// nodes stored at nodes[wl + offset * m + i] (wl: width of the layer being produced, halving; offset: this workgroup's subtree).  Levels
+// no wider than a quarter of the workgroup are bound by the latency of ONE compression per level: four lanes per node (hash_core.h:
+// b2s_node_quad) cut it 2.3x; quads are wholly active or wholly idle (4 m threads), as the lane rotations need.
+template <int ALG>
+__device__ __forceinline__ void subtree_levels(uint4 *sh, uint32_t first_m, uint64_t wl, uint64_t offset, uint4 *__restrict__ nodes) {
+    for (uint32_t m = first_m; m >= 1; m >>= 1, wl >>= 1) {
+        bool done = false;
+        if constexpr (ALG == 1) {
+            if (m <= GS_MERKLE_SUBTREE_THREADS / 4) {
+                if (threadIdx.x < 4 * m) {
+                    const uint32_t i = threadIdx.x >> 2, l = threadIdx.x & 3u, s = m + i;
+                    uint32_t *w = reinterpret_cast<uint32_t *>(sh);
+                    uint32_t lo, hi;
+                    b2s_node_quad(w + 16 * s, (int)l, lo, hi);
+                    w[8 * s + l] = lo;
+                    w[8 * s + 4 + l] = hi;
+                    uint32_t *g = reinterpret_cast<uint32_t *>(nodes) + 8 * (wl + offset * m + i);
+                    g[l] = lo;
+                    g[4 + l] = hi;
+                }
+                done = true;
+            }
+        }
+        if (!done) {
+            for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
+                const uint32_t s = m + i;
+                const uint4 x0 = sh[4 * s], x1 = sh[4 * s + 1], x2 = sh[4 * s + 2], x3 = sh[4 * s + 3];
+                uint32_t d[8];
+                digest_words16<ALG>([&](uint32_t k) { return k == 0 ? x0 : (k == 1 ? x1 : (k == 2 ? x2 : x3)); }, 4, d);
+                sh[2 * s] = make_uint4(d[0], d[1], d[2], d[3]);
+                sh[2 * s + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+                store_digest(nodes, wl + offset * m + i, d);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <int ALG, int SRC>
 __global__ __launch_bounds__(GS_MERKLE_SUBTREE_THREADS) void k_merkle_subtree(HashPtrArgs va, uint32_t count, const uint4 *__restrict__ layerA, uint4 *__restrict__ outA,
-                                                        uint4 *__restrict__ nodes, uint64_t wA, uint32_t chunk, RootTail tail) {
+                                                        uint4 *__restrict__ nodes, uint64_t wA, uint32_t chunk, RootTail tail, unsigned int *counter) {
     __shared__ uint4 sh[4 * GS_MERKLE_CHUNK];   // digest of subtree-heap node s at sh[2s], sh[2s + 1]; the first layer is s in [chunk, 2 chunk)
     const uint64_t base = (uint64_t)blockIdx.x * chunk;
     for (uint32_t i = threadIdx.x; i < chunk; i += GS_MERKLE_SUBTREE_THREADS) {
@@ -205,40 +244,30 @@ __global__ __launch_bounds__(GS_MERKLE_SUBTREE_THREADS) void k_merkle_subtree(Ha
         }
     }
     __syncthreads();
-    uint64_t wl = wA >> 1;       // width of the layer being produced: it lives at nodes[wl .. 2 wl)
-    for (uint32_t m = chunk / 2; m >= 1; m >>= 1, wl >>= 1) {
-        if constexpr (ALG == 1) {
-            // levels no wider than a quarter of the workgroup are bound by the latency of ONE compression per level: four lanes per
-            // node (hash_core.h: b2s_node_quad) cut it 2.3x.  Quads are wholly active or wholly idle (4 m threads), as the lane
-            // rotations need.
-            if (m <= GS_MERKLE_SUBTREE_THREADS / 4) {
-                if (threadIdx.x < 4 * m) {
-                    const uint32_t i = threadIdx.x >> 2, l = threadIdx.x & 3u, s = m + i;
-                    uint32_t *w = reinterpret_cast<uint32_t *>(sh);
-                    uint32_t lo, hi;
-                    b2s_node_quad(w + 16 * s, (int)l, lo, hi);
-                    w[8 * s + l] = lo;                       // digest of node s at words 8 s .. 8 s + 7; its children's were at 16 s .. 16 s + 15
-                    w[8 * s + 4 + l] = hi;
-                    uint32_t *g = reinterpret_cast<uint32_t *>(nodes) + 8 * (wl + (uint64_t)blockIdx.x * m + i);
-                    g[l] = lo;
-                    g[4 + l] = hi;
-                }
-                __syncthreads();
-                continue;
-            }
-        }
-        for (uint32_t i = threadIdx.x; i < m; i += GS_MERKLE_SUBTREE_THREADS) {
-            const uint32_t s = m + i;
-            const uint4 x0 = sh[4 * s], x1 = sh[4 * s + 1], x2 = sh[4 * s + 2], x3 = sh[4 * s + 3];
-            uint32_t d[8];
-            digest_words16<ALG>([&](uint32_t k) { return k == 0 ? x0 : (k == 1 ? x1 : (k == 2 ? x2 : x3)); }, 4, d);
-            sh[2 * s] = make_uint4(d[0], d[1], d[2], d[3]);
-            sh[2 * s + 1] = make_uint4(d[4], d[5], d[6], d[7]);
-            store_digest(nodes, wl + (uint64_t)blockIdx.x * m + i, d);
-        }
+    subtree_levels<ALG>(sh, chunk / 2, wA >> 1, blockIdx.x, nodes);
+    bool at_root = chunk == wA;
+    if (counter && gridDim.x > 1) {
+        // Several workgroups and a counter: the tree over their subtree roots is built HERE, by the workgroup that arrives last (k_fri_layers'
+        // pattern: agent-scope release, count, acquire — the eight XCD L2s are not coherent with each other; nobody waits for anybody).
+        // One launch per tree of <= 2^15 first-layer digests instead of two.
+        __shared__ int last_sh;
+        const uint32_t G = gridDim.x;                 // a power of two <= 1024
+        __threadfence();
         __syncthreads();
+        if (threadIdx.x == 0) last_sh = atomicAdd(counter, 1u) == G - 1;
+        __syncthreads();
+        if (!last_sh) return;
+        __threadfence();
+        for (uint32_t i = threadIdx.x; i < G; i += GS_MERKLE_SUBTREE_THREADS) {      // heap nodes G .. 2G - 1 of the tree: the subtree roots
+            sh[2 * (G + i)] = nodes[2 * (G + (uint64_t)i)];
+            sh[2 * (G + i) + 1] = nodes[2 * (G + (uint64_t)i) + 1];
+        }
+        if (threadIdx.x == 0) atomicExch(counter, 0u);                               // ready for the next launch on this context's stream
+        __syncthreads();
+        subtree_levels<ALG>(sh, G / 2, G >> 1, 0, nodes);
+        at_root = true;
     }
-    if (chunk == wA && threadIdx.x == 0) {
+    if (at_root && threadIdx.x == 0) {
         nodes[0] = make_uint4(0, 0, 0, 0);
         nodes[1] = make_uint4(0, 0, 0, 0);
         // the root is heap node 1: sh[2], sh[3] (the last level's barrier has passed)
@@ -256,13 +285,33 @@ __global__ __launch_bounds__(GS_MERKLE_SUBTREE_THREADS) void k_merkle_subtree(Ha
     }
 }
 
+#define GS_FRI_MAX_LAYERS 16
+// per-context device scratch of the launches whose workgroups count themselves done (k_fri_layers, k_merkle_subtree): the points between
+// FRI layers, then 64 zeroed bytes — word 0: gs_fri_layers' arrival counter, word 1: k_merkle_subtree's
+static int arrival_counters(gs_ctx *c, unsigned int **counters) {
+    if (!c->fri_points) {
+        int rc = gs_alloc(c, (GS_FRI_MAX_LAYERS + 1) * GS_ELT + 64, &c->fri_points);
+        if (rc) return rc;
+        GS_HIP(c, hipMemsetAsync((uint8_t *)c->fri_points + (GS_FRI_MAX_LAYERS + 1) * GS_ELT, 0, 64, c->stream));
+    }
+    *counters = (unsigned int *)((uint8_t *)c->fri_points + (GS_FRI_MAX_LAYERS + 1) * GS_ELT);
+    return GS_OK;
+}
+
 #define GS_MERKLE_SUBW (1ull << 15)   // layers at most this wide go to k_merkle_subtree (below it a streaming launch is latency-bound)
 // leaves (n digests, given or hashed from `count` columns when src != 0) -> nodes (heap order).  src as SRC above.
 template <int ALG>
 static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count, const void *leaves_in, void *leaves_out, uint64_t n, uint4 *nd,
                       const RootTail *root_tail = nullptr) {
     const RootTail none = {nullptr, nullptr, 0, nullptr};
-    auto tail_for = [&](uint64_t width, uint32_t chunk) { return root_tail && width == chunk ? *root_tail : none; };      // the launch that ends at the root
+    // the launch that ends at the root: a subtree launch of one workgroup, or of several that finish the tree themselves (arrival counter)
+    auto tail_for = [&](uint64_t width, uint32_t chunk) { return root_tail && (width == chunk || width / chunk <= GS_MERKLE_CHUNK) ? *root_tail : none; };
+    unsigned int *counters = nullptr;
+    if (n > GS_MERKLE_CHUNK) {
+        int rc = arrival_counters(c, &counters);
+        if (rc) return rc;
+        counters += 1;                           // (word 0 is gs_fri_layers')
+    }
     const dim3 blk(256), sub_blk(GS_MERKLE_SUBTREE_THREADS);
     uint64_t w = n;                              // the widest complete layer and where its digests are
     const uint4 *cur = (const uint4 *)leaves_in;
@@ -282,11 +331,10 @@ static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count,
             cur = lv == 1 ? lo : nd + 2 * w;
         } else {
             const uint32_t chunk = (uint32_t)(n < GS_MERKLE_CHUNK ? n : GS_MERKLE_CHUNK);
-            if (src == 1) hipLaunchKernelGGL((k_merkle_subtree<ALG, 1>), dim3((unsigned)(n / chunk)), sub_blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk, tail_for(n, chunk));
-            else hipLaunchKernelGGL((k_merkle_subtree<ALG, 2>), dim3((unsigned)(n / chunk)), sub_blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk, tail_for(n, chunk));
-            w = n / chunk;
-            cur = nd + 2 * w;
-            if (w == 1) { GS_LAUNCH_CHECK(c); return GS_OK; }
+            if (src == 1) hipLaunchKernelGGL((k_merkle_subtree<ALG, 1>), dim3((unsigned)(n / chunk)), sub_blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk, tail_for(n, chunk), counters);
+            else hipLaunchKernelGGL((k_merkle_subtree<ALG, 2>), dim3((unsigned)(n / chunk)), sub_blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk, tail_for(n, chunk), counters);
+            GS_LAUNCH_CHECK(c);                  // (n <= 2^15: at most 32 subtrees, whose roots the last workgroup finishes)
+            return GS_OK;
         }
     }
     while (w > GS_MERKLE_SUBW) {                  // node layers w/2, ..., w >> lv from the digests of layer w
@@ -299,9 +347,10 @@ static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count,
     }
     while (w > 1) {                               // subtrees of <= 1024 digests, then the subtree over their roots
         const uint32_t chunk = (uint32_t)(w < GS_MERKLE_CHUNK ? w : GS_MERKLE_CHUNK);
-        hipLaunchKernelGGL((k_merkle_subtree<ALG, 0>), dim3((unsigned)(w / chunk)), sub_blk, 0, c->stream, va, 0u, cur, nullptr, nd, w, chunk, tail_for(w, chunk));
+        hipLaunchKernelGGL((k_merkle_subtree<ALG, 0>), dim3((unsigned)(w / chunk)), sub_blk, 0, c->stream, va, 0u, cur, nullptr, nd, w, chunk, tail_for(w, chunk), counters);
         w /= chunk;
         cur = nd + 2 * w;
+        if (counters && w <= GS_MERKLE_CHUNK) break;       // the last workgroup of that launch has built the tree over the subtree roots
     }
     GS_LAUNCH_CHECK(c);
     return GS_OK;
@@ -374,7 +423,6 @@ int gs_prng_point_dev(gs_ctx *c, const void *seed32_dev, fe *out_dev) {
 // of the next layer — and, when it is the only workgroup, goes on with the next layer itself: its inputs are what it has just written.
 #define GS_FRI_CH 256
 #define GS_FRI_THREADS (4 * GS_FRI_CH)
-#define GS_FRI_MAX_LAYERS 16
 #define GS_FRI_ONE_LAUNCH_LEAVES (1ull << 15)      // wider layers: the streaming fold + the fused tree launches (throughput-bound)
 struct FriLayerDesc {
     const fe *column;          // 4 * rows values
@@ -399,41 +447,6 @@ struct FriLayersArgs {
 
 // the levels m = first_m, first_m / 2, ..., 1 of a subtree whose first layer lies in the LDS heap `sh` (node s at sh[2s], sh[2s + 1]);
 // level of width m is stored to nodes[wl + offset * m + i], wl halving with m.  blockDim.x threads, one barrier per level.
-template <int ALG>
-__device__ __forceinline__ void fri_subtree_levels(uint4 *sh, uint32_t first_m, uint64_t wl, uint64_t offset, uint4 *__restrict__ nodes) {
-    for (uint32_t m = first_m; m >= 1; m >>= 1, wl >>= 1) {
-        bool done = false;
-        if constexpr (ALG == 1) {
-            if (m <= GS_FRI_THREADS / 4) {                      // four lanes per node (hash_core.h: b2s_node_quad), as in k_merkle_subtree
-                if (threadIdx.x < 4 * m) {
-                    const uint32_t i = threadIdx.x >> 2, l = threadIdx.x & 3u, s = m + i;
-                    uint32_t *w = reinterpret_cast<uint32_t *>(sh);
-                    uint32_t lo, hi;
-                    b2s_node_quad(w + 16 * s, (int)l, lo, hi);
-                    w[8 * s + l] = lo;
-                    w[8 * s + 4 + l] = hi;
-                    uint32_t *g = reinterpret_cast<uint32_t *>(nodes) + 8 * (wl + offset * m + i);
-                    g[l] = lo;
-                    g[4 + l] = hi;
-                }
-                done = true;
-            }
-        }
-        if (!done) {
-            for (uint32_t i = threadIdx.x; i < m; i += blockDim.x) {
-                const uint32_t s = m + i;
-                const uint4 x0 = sh[4 * s], x1 = sh[4 * s + 1], x2 = sh[4 * s + 2], x3 = sh[4 * s + 3];
-                uint32_t d[8];
-                digest_words16<ALG>([&](uint32_t k) { return k == 0 ? x0 : (k == 1 ? x1 : (k == 2 ? x2 : x3)); }, 4, d);
-                sh[2 * s] = make_uint4(d[0], d[1], d[2], d[3]);
-                sh[2 * s + 1] = make_uint4(d[4], d[5], d[6], d[7]);
-                store_digest(nodes, wl + offset * m + i, d);
-            }
-        }
-        __syncthreads();
-    }
-}
-
 template <int ALG>
 __global__ __launch_bounds__(GS_FRI_THREADS) void k_fri_layers(FriLayersArgs a) {
     __shared__ fe colbuf[4 * GS_FRI_CH];           // this workgroup's folded values: quarter q of leaf i at [q * CH + i]
@@ -480,7 +493,7 @@ __global__ __launch_bounds__(GS_FRI_THREADS) void k_fri_layers(FriLayersArgs a) 
             sh[2 * (CH + tid) + 1] = make_uint4(d[4], d[5], d[6], d[7]);
         }
         __syncthreads();
-        fri_subtree_levels<ALG>(sh, CH / 2, L >> 1, blockIdx.x, D.nodes);
+        subtree_levels<ALG>(sh, CH / 2, L >> 1, blockIdx.x, D.nodes);
         if (G > 1) {
             __threadfence();                         // release: this workgroup's nodes (its subtree root among them) reach memory
             __syncthreads();
@@ -494,7 +507,7 @@ __global__ __launch_bounds__(GS_FRI_THREADS) void k_fri_layers(FriLayersArgs a) 
             }
             if (tid == 0) atomicExch(a.counter, 0u);                    // ready for the next launch on this context's stream
             __syncthreads();
-            fri_subtree_levels<ALG>(sh, G / 2, G >> 1, 0, D.nodes);
+            subtree_levels<ALG>(sh, G / 2, G >> 1, 0, D.nodes);
         }
         if (tid == 0) {                              // the root is heap node 1: sh[2], sh[3]
             D.nodes[0] = make_uint4(0, 0, 0, 0);
@@ -635,12 +648,9 @@ int gs_fri_layers(gs_ctx *c, gs_hash_alg alg, const gs_elt *omega, uint64_t n, u
         if (L.next == (i ? layers[i - 1].next : column)) return gs_fail(c, GS_ERR_ARG, "fri_layers: a layer's output must not alias its column");
     }
     // points between layers that the caller does not ask for live in a per-context scratch (ordered on the context's stream)
-    if (!c->fri_points) {
-        if ((rc = gs_alloc(c, (GS_FRI_MAX_LAYERS + 1) * GS_ELT + 64, &c->fri_points))) return rc;
-        GS_HIP(c, hipMemsetAsync((uint8_t *)c->fri_points + (GS_FRI_MAX_LAYERS + 1) * GS_ELT, 0, 64, c->stream));       // the arrival counter
-    }
+    unsigned int *counter = nullptr;
+    if ((rc = arrival_counters(c, &counter))) return rc;
     fe *scratch = (fe *)c->fri_points;
-    unsigned int *counter = (unsigned int *)((uint8_t *)c->fri_points + (GS_FRI_MAX_LAYERS + 1) * GS_ELT);
     const fe w = fe_from_bytes(omega);
     const fe *lo, *hi;
     int log_lo;
