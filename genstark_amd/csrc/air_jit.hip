@@ -881,6 +881,9 @@ static int jit_compile_helper(const std::string &source, const char *entry, cons
     posix_spawn_file_actions_adddup2(&fa, sv[1], 0);                 // dup2 clears close-on-exec on the copies
     posix_spawn_file_actions_adddup2(&fa, sv[1], 1);
     if (!getenv("GSTARK_AIR_JIT_VERBOSE")) posix_spawn_file_actions_addopen(&fa, 2, "/dev/null", O_WRONLY, 0);
+#if defined(__GLIBC__) && (__GLIBC__ > 2 || (__GLIBC__ == 2 && __GLIBC_MINOR__ >= 34))
+    posix_spawn_file_actions_addclosefrom_np(&fa, 3);                // nothing else of the host (device nodes, sockets) reaches the helper
+#endif
     char *const argv[] = {const_cast<char *>(helper.c_str()), nullptr};
     pid_t pid = 0;
     const int rc = posix_spawn(&pid, helper.c_str(), &fa, nullptr, argv, environ);

@@ -801,6 +801,7 @@ int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *
         period = n / z_steps;
         if (period > GS_ZPOLY_MAX_PERIOD) return gs_fail(c, GS_ERR_UNSUPPORTED, "composition_tail: n / steps above %d (pass 1/Z as a vector)", GS_ZPOLY_MAX_PERIOD);
     }
+    if (bcount > 64) return gs_fail(c, GS_ERR_UNSUPPORTED, "composition_tail: at most 64 boundary rows");
     if (bcount && (ilen == 0 || ilen > GS_TAIL_MAX_ILEN)) return gs_fail(c, GS_ERR_UNSUPPORTED, "composition_tail: 1..%d interpolant coefficients per row", GS_TAIL_MAX_ILEN);
     for (uint32_t r = 0; r < bcount; r++)
         if (roots_per_row_host[r] > max_roots || roots_per_row_host[r] > GS_TAIL_MAX_ROOTS)

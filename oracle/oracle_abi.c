@@ -347,6 +347,7 @@ int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *
         powers = pmade;
     }
     if (!is_pow2(n)) { free(zmade); free(pmade); return fail(c, GS_ERR_ARG, "composition_tail: n must be a power of two"); }
+    if (bcount > 64) { free(zmade); free(pmade); return fail(c, GS_ERR_UNSUPPORTED, "composition_tail: at most 64 boundary rows"); }
     if (bcount && (ilen == 0 || ilen > 4)) { free(zmade); free(pmade); return fail(c, GS_ERR_UNSUPPORTED, "composition_tail: 1..4 interpolant coefficients per row"); }
     for (uint32_t r = 0; r < bcount; r++)
         if (roots_per_row[r] > max_roots || roots_per_row[r] > 4) { free(zmade); free(pmade); return fail(c, GS_ERR_UNSUPPORTED, "composition_tail: at most 4 roots per row"); }
