@@ -721,12 +721,13 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     bool lc_fused = false;                     // cEval already holds L (LinearCombination folded into the composition kernel)
     if (fused) {
         // K over the evaluation domain (issued before the trace), the interpolant through the assertions, then one kernel for :71-146
-        read_evaluation_root();
+        // (what needs no coefficient first: the device is idle while the root travels)
         const RegData &d = rdata[0];
         const uint32_t m = (uint32_t)d.xs.size();
         Bytes xs(m * ELEM), ys(m * ELEM), ipoly(m * ELEM);
         for (uint32_t i = 0; i < m; i++) { le16(d.xs[i], xs.data() + ELEM * i); le16(d.ys[i], ys.data() + ELEM * i); }
         if (A.gs_small_interpolate(xs.data(), ys.data(), m, ipoly.data())) fail(GS_ERR_ARG, "gs_small_interpolate failed");    // BoundaryConstraints.ts:42
+        read_evaluation_root();
         const bool q_adjusted = groups[0].first < combination_degree;
         Bytes co(4 * ELEM, 0);
         le16(coefficients[0], co.data());
