@@ -107,6 +107,35 @@ def test_native_prover_generic_airs_oracle(oracle_backend):
     check_generic(oracle_backend)
 
 
+def check_without_the_fused_tail(backend, monkeypatch):
+    """The driver's composition tail in its two forms: gs_composition_tail (default, when every asserted register has at most four
+    assertions) and the member sequence it replaces — forced with GSTARK_NO_TAIL=1, and taken on its own when a register has five
+    assertions.  Same bytes as the mirror either way."""
+    fused = check_generic(backend)
+    monkeypatch.setenv('GSTARK_NO_TAIL', '1')
+    assert check_generic(backend) == fused
+    monkeypatch.delenv('GSTARK_NO_TAIL')
+    from genstark_amd import poseidon
+    from test_generic_air import POSEIDON_OPTS
+    f = PrimeField(backend=backend)
+    air = poseidon.poseidon6x128_air(128, 16, f)
+    stark = Stark(air, POSEIDON_OPTS)
+    trace = air.hostTrace([1, 2, 3, 4])
+    assertions = [{'step': s, 'register': r, 'value': trace[s][r]} for s, r in [(0, 0), (7, 0), (63, 0), (64, 0), (127, 0), (127, 5)]]
+    want = stark.serialize(stark.prove(assertions, [], [1, 2, 3, 4]))
+    assert NativeProver(stark).prove_bytes(assertions, [], [1, 2, 3, 4]) == want
+    return fused
+
+
+def test_native_prover_with_and_without_the_fused_tail_oracle(oracle_backend, monkeypatch):
+    check_without_the_fused_tail(oracle_backend, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_native_prover_with_and_without_the_fused_tail_hip(hip_backend, monkeypatch):
+    check_without_the_fused_tail(hip_backend, monkeypatch)
+
+
 @pytest.mark.gpu
 def test_native_prover_hip(hip_backend, oracle_backend):
     for case in GOLDEN:
