@@ -407,6 +407,18 @@ __global__ __launch_bounds__(128, 2) void k_ntt_pass_lz(const fe *__restrict__ i
 // the dispatcher places on the same XCD one after the other, so the two halves of a 128-byte line meet in that XCD's L2.
 // The first pass writes its tile (contiguous in q for RB = 16) straight from registers; first passes of other radices keep the
 // workgroup kernel (their stores would be 16-byte pieces).
+// the conversions between the 16-byte elements of a pass's input / output and the five-limb form it computes in.  The experiments build
+// can replace them by register moves (-DGS_EXP_NO_FORMAT: results are garbage, TIMINGS are what a pass costs without them — the part
+// a plan with fewer passes would save one third of; tools/ntt_noformat.sh)
+#ifdef GS_EXP_NO_FORMAT
+__device__ __forceinline__ lz lz_unpack_fake(const fe &r) { lz x; x.l[0] = (int32_t)(r.w0 & LZ_M); x.l[1] = (int32_t)(r.w1 & LZ_M); x.l[2] = (int32_t)(r.w2 & LZ_M); x.l[3] = (int32_t)(r.w3 & LZ_M); x.l[4] = (int32_t)(r.w3 >> 26); return x; }
+__device__ __forceinline__ fe lz_pack_fake(const lz &x) { return fe_make((uint32_t)x.l[0], (uint32_t)x.l[1], (uint32_t)x.l[2], (uint32_t)(x.l[3] ^ (x.l[4] << 26))); }
+#define LZ_DATA_UNPACK(r) lz_unpack_fake(r)
+#define LZ_DATA_PACK(x, w) lz_pack_fake(x)
+#else
+#define LZ_DATA_UNPACK(r) lz_unpack(r)
+#define LZ_DATA_PACK(x, w) lz_pack_flag(x, w)
+#endif
 template <int LB, int TW>
 __global__ __launch_bounds__(64, 4) void k_ntt_wave(const fe *__restrict__ in, fe *__restrict__ out, LzPassArgs a) {
     constexpr int RB = 1 << LB, R = 16 * RB, GB = 16 / RB, LOGWJ = 6 - LB, Wj = 64 >> LB;
@@ -464,7 +476,7 @@ __global__ __launch_bounds__(64, 4) void k_ntt_wave(const fe *__restrict__ in, f
                     for (int u = 0; u < 4; u++) { tws[u] = *tp; tp += tstep; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                v[m] = lz_mul_vm(lz_unpack(raw[m]), lz_unpack(tws[m & 3]), K);
+                v[m] = lz_mul_vm(LZ_DATA_UNPACK(raw[m]), lz_unpack(tws[m & 3]), K);
             }
             __builtin_amdgcn_sched_barrier(0);
         } else if constexpr (TW == 2) {
@@ -478,13 +490,13 @@ __global__ __launch_bounds__(64, 4) void k_ntt_wave(const fe *__restrict__ in, f
 #pragma unroll
             for (int m = 0; m < 16; m++) {
                 __builtin_amdgcn_sched_barrier(0);
-                v[m] = lz_mul_vm(lz_unpack(raw[m]), cur, K);
+                v[m] = lz_mul_vm(LZ_DATA_UNPACK(raw[m]), cur, K);
                 if (m < 15) cur = lz_mul_vm(cur, step, K);
             }
             __builtin_amdgcn_sched_barrier(0);
         } else {
 #pragma unroll
-            for (int m = 0; m < 16; m++) v[m] = lz_unpack(raw[m]);
+            for (int m = 0; m < 16; m++) v[m] = LZ_DATA_UNPACK(raw[m]);
         }
         ntt_dif_lz<4>(v, (lzw_cptr)a.wtab, K);
     }
@@ -522,7 +534,7 @@ __global__ __launch_bounds__(64, 4) void k_ntt_wave(const fe *__restrict__ in, f
         for (int q = 0; q < 16; q++) {
             lz x = v[brev(q, 4)];
             if (scale) { LZ_FENCE(); const lzw W = lz_load_w(wt + 7); x = lz_mul_u(lz_norm(x), W, K); }
-            dst[jbase + (uint64_t)q * Ns2] = lz_pack_flag(x, weak);
+            dst[jbase + (uint64_t)q * Ns2] = LZ_DATA_PACK(x, weak);
         }
     } else {
         // ---- exchange twiddles in place, then the exchange itself, limb plane by limb plane
@@ -559,7 +571,7 @@ __global__ __launch_bounds__(64, 4) void k_ntt_wave(const fe *__restrict__ in, f
             const uint64_t ostep = FIRST ? 16 : (Ns2 << 4);
 #pragma unroll
             for (int qb = 0; qb < RB; qb++) {
-                *o = lz_pack_flag(xb[u][brev(qb, LB)], weak);
+                *o = LZ_DATA_PACK(xb[u][brev(qb, LB)], weak);
                 o += ostep;
                 if ((qb & 3) == 3 || qb == RB - 1) __builtin_amdgcn_sched_barrier(0);
             }

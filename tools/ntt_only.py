@@ -1,4 +1,4 @@
-"""tools/ntt_only.py — a few 2^24-point NTTs and nothing else (target for rocprofv3 --pmc passes)."""
+"""tools/ntt_only.py [log n = 24] [library = the product one] — a few 2^24-point NTTs and nothing else (target for rocprofv3 passes)."""
 import ctypes as C
 import os
 import sys
@@ -8,7 +8,7 @@ from genstark_amd._abi import Backend  # noqa: E402
 from genstark_amd.field import PrimeField  # noqa: E402
 
 logn = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-be = Backend()
+be = Backend(lib_path=sys.argv[2]) if len(sys.argv) > 2 else Backend()
 f = PrimeField(backend=be)
 n = 1 << logn
 w = f.getRootOfUnity(n)
