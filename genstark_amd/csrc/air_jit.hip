@@ -428,7 +428,9 @@ static void ssa_recompute_depths(std::vector<SsaNode> &nodes) {
 // of a layer side by side on K lanes, one exchange for the whole layer.  Leaves that are not products by constants ride along with the
 // constant one.  Trees with fewer than two genuine products are left alone.
 static void ssa_fuse_dots(std::vector<SsaNode> &nodes) {
-    if (const char *e = getenv("GSTARK_AIR_JIT_FUSE")) if (e[0] == '0') return;       // diagnostic: the unfused programs (A/B of the generator)
+#ifdef GS_NTT_EXPERIMENTS
+    if (const char *e = getenv("GSTARK_AIR_JIT_FUSE")) if (e[0] == '0') return;       // experiments build only: the unfused programs (A/B of the generator)
+#endif
     const int n = (int)nodes.size();
     std::vector<int> uses(n, 0), ops;
     for (const SsaNode &x : nodes) { ssa_operands(x, ops); for (int o : ops) uses[o]++; }

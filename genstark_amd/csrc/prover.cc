@@ -296,6 +296,7 @@ std::vector<uint64_t> unique_in_order(const std::vector<uint64_t> &v) {
 // synchronisation is added, so a phase lasts until its last BLOCKING call returned) and the transform work it launched.
 static thread_local gs_prover_stats g_stats;
 static thread_local bool g_sync_phases = false;      // gs_prover_sync_phases
+static thread_local bool g_member_sequence = false;  // gs_prover_member_sequence
 
 // the two transform entry points, counted: rows * n points per call.  The library serves a transform of fewer than 256 points
 // or of a polynomial of at most 8 coefficients with a Horner kernel (ntt.hip: ntt_run), which is not an NTT: counted apart.
@@ -410,6 +411,7 @@ static int remainder_check_entry(const uint8_t *values, uint64_t len, uint32_t e
 }
 
 void gs_prover_sync_phases(int on) { g_sync_phases = on != 0; }
+void gs_prover_member_sequence(int on) { g_member_sequence = on != 0; }
 
 int gs_prover_last_stats(struct gs_prover_stats *out) {
     if (!out) return GS_ERR_ARG;
@@ -573,7 +575,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     const bool fused = air.kind == 0 && E <= 32 && air.nconstraints == 1 && assertions_on_r0 == job.nassertions && job.nassertions <= 4;
     // the generic sequence's tail in one pass (gs_composition_tail) when the assertions fit its per-register limits: neither 1/Z(x) nor
     // the power series of the degree adjustment is materialised then
-    bool tail = !fused && R + air.nsecret <= 96 && !getenv("GSTARK_NO_TAIL");
+    bool tail = !fused && R + air.nsecret <= 96 && !g_member_sequence;
     {
         std::vector<std::pair<uint32_t, uint32_t>> per_reg;
         for (uint32_t i = 0; i < job.nassertions && tail; i++) {

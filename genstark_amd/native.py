@@ -92,6 +92,8 @@ def _driver(backend):
             lib.gs_prover_last_stats.restype = C.c_int
             lib.gs_prover_sync_phases.argtypes = [C.c_int]
             lib.gs_prover_sync_phases.restype = None
+            lib.gs_prover_member_sequence.argtypes = [C.c_int]
+            lib.gs_prover_member_sequence.restype = None
             lib.gs_prover_prove_dist_on.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(_Job), C.POINTER(GsComm), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.c_uint64]
             lib.gs_prover_prove_dist_on.restype = C.c_int
             lib.gs_prover_last_collectives.argtypes = [C.POINTER(_Collective), C.c_uint32, C.POINTER(C.c_uint32)]
@@ -324,6 +326,11 @@ class NativeProver:
         if st.nreadme:       # a proof that ran under sync_phases(True): the reference's own phase log (lib/Stark.ts:92-152; README.md:62-73)
             out['phases_readme'] = [(bytes(st.readme_label[i]).split(b'\0', 1)[0].decode(), round(st.readme_ms[i], 4)) for i in range(st.nreadme)]
         return out
+
+    def member_sequence(self, on=True):
+        """Checking mode of the calling thread's next proofs: the composition tail as the member-by-member sequence of entries instead of
+        gs_composition_tail (gs_prover_member_sequence); same bytes."""
+        self.lib.gs_prover_member_sequence(1 if on else 0)
 
     def sync_phases(self, on=True):
         """Measuring mode for the proofs this THREAD issues next: the device is synchronised at each of the reference's log points, so

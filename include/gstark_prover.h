@@ -81,6 +81,11 @@ struct gs_prover_stats {
 /* per calling thread: the next proofs synchronise the device at the reference's log points and fill readme_ms (a measuring mode:
  * a proof takes a little longer; its bytes are the same) */
 void gs_prover_sync_phases(int on);
+/* per calling thread: the next proofs of generic AIRs run the tail of the composition polynomial and the linear combination as the
+ * member-by-member sequence of entries (gs_zero_poly_inverses, gs_power_series, gs_vec_mul, gs_eval_polys_at_roots,
+ * gs_sub_matrix_from_vectors, gs_div_by_domain_roots, gs_combine_adjusted twice) instead of the one pass of gs_composition_tail —
+ * a checking mode (the tests compare the two): same bytes, a few passes more */
+void gs_prover_member_sequence(int on);
 
 /* Resolves the gs_* entry points from `dl_handle` (the handle dlopen() returned for the ABI library).  GS_ERR_UNSUPPORTED if one
  * is missing, or if the library computes in another field / element size than this build of the driver (one driver library per

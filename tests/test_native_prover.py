@@ -109,12 +109,15 @@ def test_native_prover_generic_airs_oracle(oracle_backend):
 
 def check_without_the_fused_tail(backend, monkeypatch):
     """The driver's composition tail in its two forms: gs_composition_tail (default, when every asserted register has at most four
-    assertions) and the member sequence it replaces — forced with GSTARK_NO_TAIL=1, and taken on its own when a register has five
+    assertions) and the member sequence it replaces — asked for with gs_prover_member_sequence, and taken on its own when a register has five
     assertions.  Same bytes as the mirror either way."""
     fused = check_generic(backend)
-    monkeypatch.setenv('GSTARK_NO_TAIL', '1')
-    assert check_generic(backend) == fused
-    monkeypatch.delenv('GSTARK_NO_TAIL')
+    some = NativeProver(generic_cases(backend)[0][1])
+    some.member_sequence(True)                    # (a mode of the calling thread, like sync_phases)
+    try:
+        assert check_generic(backend) == fused
+    finally:
+        some.member_sequence(False)
     from genstark_amd import poseidon
     from test_generic_air import POSEIDON_OPTS
     f = PrimeField(backend=backend)
