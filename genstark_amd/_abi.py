@@ -116,6 +116,8 @@ _SIGNATURES = {
                                   C.POINTER(_u64), _u32, _vp]),
     'gs_composition_tail': (_int, [_vp, _u64, _bytes, _vp, _vp, _u64, _bytes, _vp, _u32, _bytes, _u32, C.POINTER(_u64), C.POINTER(_u32), _u32, _bytes, _bytes,
                                    _vp, _u32, _bytes, _bytes, _vp, _u64, _vp, _vp]),
+    'gs_composition_tail_coset': (_int, [_vp, _u64, _bytes, _bytes, _vp, _vp, _u64, _bytes, _vp, _u32, _bytes, _u32, C.POINTER(_u64), C.POINTER(_u32), _u32, _bytes,
+                                         _bytes, _vp, _u32, _bytes, _bytes, _vp, _u64, _vp, _vp]),
     'gs_air_constraints_strided': (_int, [_vp, C.POINTER(_u32), _u32, _bytes, _u32, _u32, _u32, _u32, _vp, _u64, _u64, _u64, _u64, _vp,
                                           C.POINTER(_u64), _u32, _vp]),
 }

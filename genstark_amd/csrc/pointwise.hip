@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256) void k_composition_tail(const fe *__restrict__
                                                           const fe *__restrict__ tw_lo, const fe *__restrict__ tw_hi, int log_lo, int logn, uint64_t n,
                                                           const TailRow *__restrict__ rows, uint32_t bcount, uint32_t ilen,
                                                           const TailVec *__restrict__ vecs, uint32_t lcount, ZTable ztab, uint32_t period, fe x_last,
-                                                          uint64_t pw_exp, fe pw_step, fe *__restrict__ c_out, fe *__restrict__ l_out) {
+                                                          uint64_t pw_exp, fe pw_step, fe shift, fe pw_scale, int has_shift, fe *__restrict__ c_out,
+                                                          fe *__restrict__ l_out) {
     static_assert(!ZC || HAS_X, "1/Z(x) needs x");
 #ifdef GS_TAIL_LAZY
     const lzk K = lzk_make();
@@ -300,6 +301,7 @@ __global__ __launch_bounds__(256) void k_composition_tail(const fe *__restrict__
         const uint64_t e = ((blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) * pw_exp) & (n - 1);
         prun = tw_lo[e & ((1ull << log_lo) - 1)];
         if (logn > log_lo) prun = fe_mul(prun, tw_hi[e >> log_lo]);
+        if (has_shift) prun = fe_mul(prun, pw_scale);               // a coset: x_i = shift * omega^i, so x_i^e = shift^e * omega^(i e)
     }
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         fe p = fe_one(), x = fe_one();
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(256) void k_composition_tail(const fe *__restrict__
         if (HAS_X) {
             x = tw_lo[i & ((1ull << log_lo) - 1)];
             if (logn > log_lo) x = fe_mul(x, tw_hi[i >> log_lo]);
+            if (has_shift) x = fe_mul(x, shift);                     // (wave-uniform flag)
         }
         const fe d = fe_mul(q[i], ZC ? fe_mul(fe_sub(x, x_last), zc[i & (period - 1)]) : zinv[i]);
 #ifdef GS_TAIL_LAZY
@@ -789,7 +792,19 @@ int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *
                         const uint32_t *roots_per_row_host, uint32_t max_roots, const uint8_t *b_coeffs_host, const uint8_t *b_adj_host,
                         const void *const *l_vecs_host, uint32_t lcount, const uint8_t *l_coeffs_host, const uint8_t *l_adj_host, const void *powers,
                         uint64_t powers_exponent, void *c_out, void *l_out) {
-    if (!c || !omega || !q || (!z_inv && !x_last) || !l_out) return GS_ERR_ARG;
+    uint8_t one[sizeof(fe)];
+    fe_to_bytes(one, fe_one());
+    return gs_composition_tail_coset(c, n, omega, one, q, z_inv, z_steps, x_last, b_vecs_host, bcount, ipolys_host, ilen, root_index_host, roots_per_row_host,
+                                     max_roots, b_coeffs_host, b_adj_host, l_vecs_host, lcount, l_coeffs_host, l_adj_host, powers, powers_exponent, c_out, l_out);
+}
+int gs_composition_tail_coset(gs_ctx *c, uint64_t n, const gs_elt *omega, const gs_elt *shift_bytes, const void *q, const void *z_inv, uint64_t z_steps,
+                              const gs_elt *x_last, const void *const *b_vecs_host, uint32_t bcount, const uint8_t *ipolys_host, uint32_t ilen,
+                              const uint64_t *root_index_host, const uint32_t *roots_per_row_host, uint32_t max_roots, const uint8_t *b_coeffs_host,
+                              const uint8_t *b_adj_host, const void *const *l_vecs_host, uint32_t lcount, const uint8_t *l_coeffs_host,
+                              const uint8_t *l_adj_host, const void *powers, uint64_t powers_exponent, void *c_out, void *l_out) {
+    if (!c || !omega || !shift_bytes || !q || (!z_inv && !x_last) || !l_out) return GS_ERR_ARG;
+    const fe shift = fe_from_bytes(shift_bytes);
+    const int has_shift = fe_eq(shift, fe_one()) ? 0 : 1;
     if (bcount && (!b_vecs_host || !ipolys_host || !roots_per_row_host || !b_coeffs_host || (max_roots && !root_index_host))) return GS_ERR_ARG;
     if (lcount && (!l_vecs_host || !l_coeffs_host)) return GS_ERR_ARG;
     if ((b_adj_host || l_adj_host) && !powers && !powers_exponent) return GS_ERR_ARG;
@@ -810,12 +825,12 @@ int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *
     const fe *lo = nullptr, *hi = nullptr, *u = nullptr;
     int log_lo = 0;
     int rc = gs_plan_pow_tables(c, w, n, &lo, &hi, &log_lo);
-    if (!rc && bcount) rc = gs_plan_inverse_table(c, w, n, &u);
+    if (!rc && bcount) rc = gs_plan_inverse_table_shifted(c, w, n, shift, &u);        // 1 / (shift * omega^j - 1): the unshifted table when shift = 1
     if (rc) return rc;
-    if (!z_inv) {                                                  // gs_zero_poly_inverses' table: 1 / (g^j - 1), g = omega^steps, 0^-1 = 0
-        const std::vector<fe> &inv = gs_memo(c, gs_memo_key("zpoly").add(w).add(n).add(z_steps).add(fe_one()), [&](std::vector<fe> &t) {
+    if (!z_inv) {                                                  // gs_zero_poly_inverses[_coset]' table: 1 / (shift^steps g^j - 1), g = omega^steps, 0^-1 = 0
+        const std::vector<fe> &inv = gs_memo(c, gs_memo_key("zpoly").add(w).add(n).add(z_steps).add(shift), [&](std::vector<fe> &t) {
             const fe g = fe_pow_u64(w, z_steps);
-            fe cur = fe_one();
+            fe cur = fe_pow_u64(shift, z_steps);
             for (uint64_t j = 0; j < period; j++) {
                 t.push_back(fe_inv(fe_sub(cur, fe_one())));
                 cur = fe_mul(cur, g);
@@ -857,13 +872,15 @@ int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *
     const bool adjusted = b_adj_host || l_adj_host;
     const int pwk = !adjusted ? 0 : (powers ? 1 : 2);
     const bool zc = !z_inv, has_x = zc || (bcount && ilen > 1);
+    // x_i^e = shift^e * omega^(i e): omega's exponent reduces mod n, the shift's does NOT (shift is a root of unity of a larger order)
+    const fe pw_scale = has_shift && pwk == 2 ? gs_memo_pow(c, shift, powers_exponent) : fe_one();
     const fe xl = x_last ? fe_from_bytes(x_last) : fe_zero();
     const dim3 grid(gs_grid(n)), block(256);
     const fe pw_step = gs_memo_pow(c, w, (((powers_exponent & (n - 1)) * ((uint64_t)grid.x * block.x)) & (n - 1)));      // n <= 2^32: no overflow
 #define GS_TAIL_LAUNCH(PW, X, ZC)                                                                                                                    \
     hipLaunchKernelGGL((k_composition_tail<PW, X, ZC>), grid, block, 0, c->stream, (const fe *)q, (const fe *)z_inv, (const fe *)powers, u, lo, hi,   \
                        log_lo, gs_log2(n), n, dr, bcount, ilen ? ilen : 1u, dv, lcount, ztab, (uint32_t)period, xl, powers_exponent & (n - 1),         \
-                       pw_step, (fe *)c_out, (fe *)l_out)
+                       pw_step, shift, pw_scale, has_shift, (fe *)c_out, (fe *)l_out)
 #define GS_TAIL_PW(X, ZC)                                                                                                                              \
     do { if (pwk == 0) GS_TAIL_LAUNCH(0, X, ZC); else if (pwk == 1) GS_TAIL_LAUNCH(1, X, ZC); else GS_TAIL_LAUNCH(2, X, ZC); } while (0)
     if (zc) GS_TAIL_PW(1, 1);

@@ -43,7 +43,7 @@ namespace {
     X(gs_eval_polys_at_roots) X(gs_interpolate_roots) X(gs_interpolate_quartic_domain) X(gs_eval_quartic_batch)                \
     X(gs_hash_merge_rows) X(gs_hash_digest_values) X(gs_merkle_build) X(gs_merkle_commit_rows) X(gs_merkle_prove_batch) X(gs_small_interpolate)          \
     X(gs_small_eval_poly) X(gs_pseudorandom_indexes) X(gs_mimc_trace) X(gs_mimc_constraints) X(gs_air_trace)                    \
-    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_air_constraints_strided) X(gs_composition_tail) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end) X(gs_readback_post) X(gs_readback_wait) X(gs_merkle_commit_rows_seed) X(gs_fri_fold_at) \
+    X(gs_air_trace_segments) X(gs_air_constraints) X(gs_air_constraints_strided) X(gs_composition_tail) X(gs_composition_tail_coset) X(gs_zero_poly_inverses) X(gs_div_by_domain_roots) X(gs_mimc_composition) X(gs_fri_fold) X(gs_fri_fold_seeded) X(gs_defer_begin) X(gs_defer_end) X(gs_readback_post) X(gs_readback_wait) X(gs_merkle_commit_rows_seed) X(gs_fri_fold_at) \
     X(gs_vec_mul_scalar) X(gs_copy) X(gs_gather_words) X(gs_transpose_records) X(gs_fri_fold_seeded_scaled) X(gs_fri_layers) X(gs_sync) X(gs_zero_poly_inverses_coset) X(gs_div_by_domain_roots_coset)
 struct Api {
 #define X(name) decltype(&::name) name = nullptr;
@@ -297,6 +297,18 @@ std::vector<uint64_t> unique_in_order(const std::vector<uint64_t> &v) {
 static thread_local gs_prover_stats g_stats;
 static thread_local bool g_sync_phases = false;      // gs_prover_sync_phases
 static thread_local bool g_member_sequence = false;  // gs_prover_member_sequence
+// gs_composition_tail[_coset] takes up to four assertions per register, 64 asserted registers, 96 committed vectors
+static bool tail_fits(const gs_prover_job &job, uint32_t vectors) {
+    if (g_member_sequence || vectors > 96) return false;
+    std::vector<std::pair<uint32_t, uint32_t>> per_reg;
+    for (uint32_t i = 0; i < job.nassertions; i++) {
+        bool found = false;
+        for (auto &e : per_reg)
+            if (e.first == job.assertions[i].reg) { found = true; if (++e.second > 4) return false; }
+        if (!found) per_reg.push_back({job.assertions[i].reg, 1u});
+    }
+    return per_reg.size() <= 64;
+}
 
 // the two transform entry points, counted: rows * n points per call.  The library serves a transform of fewer than 256 points
 // or of a polynomial of at most 8 coefficients with a Horner kernel (ntt.hip: ntt_run), which is not an NTT: counted apart.
@@ -575,16 +587,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     const bool fused = air.kind == 0 && E <= 32 && air.nconstraints == 1 && assertions_on_r0 == job.nassertions && job.nassertions <= 4;
     // the generic sequence's tail in one pass (gs_composition_tail) when the assertions fit its per-register limits: neither 1/Z(x) nor
     // the power series of the degree adjustment is materialised then
-    bool tail = !fused && R + air.nsecret <= 96 && !g_member_sequence;
-    {
-        std::vector<std::pair<uint32_t, uint32_t>> per_reg;
-        for (uint32_t i = 0; i < job.nassertions && tail; i++) {
-            bool found = false;
-            for (auto &e : per_reg) if (e.first == job.assertions[i].reg) { found = true; if (++e.second > 4) tail = false; }
-            if (!found) per_reg.push_back({job.assertions[i].reg, 1u});
-        }
-        if (per_reg.size() > 64) tail = false;
-    }
+    const bool tail = !fused && tail_fits(job, R + air.nsecret);
     const bool tail_makes_z = tail && E <= 32;
     Buf zInverses;
     if (!fused && !tail_makes_z) {

@@ -393,6 +393,16 @@ int gs_composition_tail(gs_ctx *ctx, uint64_t n, const gs_elt *omega, const void
                         uint32_t max_roots, const uint8_t *b_coeffs_host, const uint8_t *b_adj_host /* or NULL */,
                         const void *const *l_vecs_host, uint32_t lcount, const uint8_t *l_coeffs_host, const uint8_t *l_adj_host /* or NULL */,
                         const void *powers /* n elements, or NULL: */, uint64_t powers_exponent, void *c_out /* or NULL */, void *l_out);
+/* The same over ONE RANK'S COSET of the evaluation domain (a proof spread over several GPUs: point i is shift * omega^i, omega = the
+ * n-th root w^ranks, shift = w^rank; q, the vectors and the outputs are the rank's strided shares): I_b is evaluated at the coset's
+ * points, the divisors' roots are still given as positions in units of omega (domain points w^(ranks * position)), 1/Z and the
+ * powers are those of gs_zero_poly_inverses_coset and of the strided share of the power series (x_i^powers_exponent, full exponent). */
+int gs_composition_tail_coset(gs_ctx *ctx, uint64_t n, const gs_elt *omega, const gs_elt *shift, const void *q, const void *z_inv, uint64_t z_steps,
+                              const gs_elt *x_last, const void *const *b_vecs_host, uint32_t bcount, const uint8_t *ipolys_host, uint32_t ilen,
+                              const uint64_t *root_index_host, const uint32_t *roots_per_row_host, uint32_t max_roots,
+                              const uint8_t *b_coeffs_host, const uint8_t *b_adj_host, const void *const *l_vecs_host, uint32_t lcount,
+                              const uint8_t *l_coeffs_host, const uint8_t *l_adj_host, const void *powers, uint64_t powers_exponent,
+                              void *c_out, void *l_out);
 /* gs_air_constraints with the registers read IN PLACE from columns of a larger domain: register r at point j is
  * p[r * prow + j * pstride] (next row: point (j + shift) mod nc).  CompositionPolynomial.ts:76 evaluates the constraints over the
  * composition domain, whose points are every (N / nc)-th point of the evaluation domain the trace polynomials were just extended

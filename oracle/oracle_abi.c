@@ -315,12 +315,13 @@ int gs_div_by_domain_roots_coset(gs_ctx *c, const void *num, uint32_t rows, uint
  * steps it replaces — each one this file's own entry: D = Q / Z (CompositionPolynomial.ts:113-121), I_b over the domain, P_b - I_b,
  * / Z_b (BoundaryConstraints.ts:71-95), the degree-adjusted merge with D (CompositionPolynomial.ts:124-146), then
  * LinearCombination.computeMany with C added (LinearCombination.ts:36-64). */
-int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *q, const void *z_inv_in, uint64_t z_steps, const gs_elt *x_last,
+int gs_composition_tail_coset(gs_ctx *c, uint64_t n, const gs_elt *omega, const gs_elt *shift, const void *q, const void *z_inv_in, uint64_t z_steps,
+                              const gs_elt *x_last,
                         const void *const *b_vecs, uint32_t bcount, const uint8_t *ipolys, uint32_t ilen, const uint64_t *root_index,
                         const uint32_t *roots_per_row, uint32_t max_roots, const uint8_t *b_coeffs, const uint8_t *b_adj, const void *const *l_vecs,
                         uint32_t lcount, const uint8_t *l_coeffs, const uint8_t *l_adj, const void *powers_in, uint64_t powers_exponent, void *c_out,
                         void *l_out) {
-    if (!c || !omega || !q || (!z_inv_in && !x_last) || !l_out) return GS_ERR_ARG;
+    if (!c || !omega || !shift || !q || (!z_inv_in && !x_last) || !l_out) return GS_ERR_ARG;
     if (bcount && (!b_vecs || !ipolys || !roots_per_row || !b_coeffs || (max_roots && !root_index))) return GS_ERR_ARG;
     if (lcount && (!l_vecs || !l_coeffs)) return GS_ERR_ARG;
     if ((b_adj || l_adj) && !powers_in && !powers_exponent) return GS_ERR_ARG;
@@ -333,16 +334,19 @@ int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *
         if (n / z_steps > 32) return fail(c, GS_ERR_UNSUPPORTED, "composition_tail: n / steps above 32 (pass 1/Z as a vector)");
         zmade = (uint8_t *)malloc((n ? n : 1) * FE_BYTES);
         if (!zmade) return fail(c, GS_ERR_OOM, "malloc failed");
-        int zr = gs_zero_poly_inverses(c, omega, n, z_steps, x_last, zmade);
+        int zr = gs_zero_poly_inverses_coset(c, omega, n, shift, z_steps, x_last, zmade);
         if (zr) { free(zmade); return zr; }
         z_inv = zmade;
     }
     if ((b_adj || l_adj) && !powers) {
         pmade = (uint8_t *)malloc((n ? n : 1) * FE_BYTES);
         if (!pmade) { free(zmade); return fail(c, GS_ERR_OOM, "malloc failed"); }
-        uint8_t base[FE_BYTES];
+        /* x_i^e for x_i = shift * omega^i: the power series of omega^e, times shift^e (the strided share of the domain-wide series) */
+        uint8_t base[FE_BYTES], se[FE_BYTES];
         fe_store(base, fe_exp(fe_load(omega), (fexp)(powers_exponent % n)));
+        fe_store(se, fe_exp(fe_load(shift), (fexp)powers_exponent));
         int pr = gs_power_series(c, (const gs_elt *)base, n, pmade);
+        if (!pr) pr = gs_vec_mul_scalar(c, pmade, (const gs_elt *)se, n, pmade);
         if (pr) { free(zmade); free(pmade); return pr; }
         powers = pmade;
     }
@@ -359,9 +363,17 @@ int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *
         mat = (uint8_t *)malloc((size_t)3 * bcount * n * FE_BYTES);
         if (!mat) { free(cbuf); free(zmade); free(pmade); return fail(c, GS_ERR_OOM, "malloc failed"); }
         uint8_t *iv = mat, *pi = mat + (size_t)bcount * n * FE_BYTES, *bq = pi + (size_t)bcount * n * FE_BYTES;
-        rc = gs_eval_polys_at_roots(c, ipolys, bcount, ilen, omega, n, iv);
+        /* I_b over the coset: its coefficients scaled by shift^k, then the values at the powers of omega */
+        uint8_t *isc = (uint8_t *)malloc((size_t)bcount * ilen * FE_BYTES);
+        if (!isc) { free(mat); free(cbuf); free(zmade); free(pmade); return fail(c, GS_ERR_OOM, "malloc failed"); }
+        for (uint32_t r = 0; r < bcount; r++) {
+            fe sk = 1;
+            for (uint32_t k = 0; k < ilen; k++) { ST(isc, (size_t)r * ilen + k, fe_mul(EL(ipolys, (size_t)r * ilen + k), sk)); sk = fe_mul(sk, fe_load(shift)); }
+        }
+        rc = gs_eval_polys_at_roots(c, isc, bcount, ilen, omega, n, iv);
+        free(isc);
         if (!rc) rc = gs_sub_matrix_from_vectors(c, b_vecs, iv, bcount, n, pi);
-        if (!rc) rc = gs_div_by_domain_roots(c, pi, bcount, n, omega, root_index, roots_per_row, max_roots, bq);
+        if (!rc) rc = gs_div_by_domain_roots_coset(c, pi, bcount, n, omega, shift, root_index, roots_per_row, max_roots, bq);
         if (!rc) {
             const void *rows[64];
             if (bcount > 64) rc = fail(c, GS_ERR_UNSUPPORTED, "composition_tail: at most 64 boundary rows");
@@ -376,6 +388,17 @@ int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *
     }
     free(mat); free(cbuf); free(zmade); free(pmade);
     return rc;
+}
+int gs_composition_tail(gs_ctx *c, uint64_t n, const gs_elt *omega, const void *q, const void *z_inv, uint64_t z_steps, const gs_elt *x_last,
+                        const void *const *b_vecs, uint32_t bcount, const uint8_t *ipolys, uint32_t ilen, const uint64_t *root_index,
+                        const uint32_t *roots_per_row, uint32_t max_roots, const uint8_t *b_coeffs, const uint8_t *b_adj, const void *const *l_vecs,
+                        uint32_t lcount, const uint8_t *l_coeffs, const uint8_t *l_adj, const void *powers, uint64_t powers_exponent, void *c_out,
+                        void *l_out) {
+    uint8_t one[64];
+    memset(one, 0, sizeof one);
+    one[0] = 1;
+    return gs_composition_tail_coset(c, n, omega, (const gs_elt *)one, q, z_inv, z_steps, x_last, b_vecs, bcount, ipolys, ilen, root_index, roots_per_row, max_roots,
+                                     b_coeffs, b_adj, l_vecs, lcount, l_coeffs, l_adj, powers, powers_exponent, c_out, l_out);
 }
 int gs_transpose_vector(gs_ctx *c, const void *v, uint64_t n, uint32_t cols, uint64_t step, void *o) {
     if (!cols || !step || n % ((uint64_t)cols * step)) return fail(c, GS_ERR_ARG, "transpose_vector: n %% (cols*step) != 0");

@@ -888,3 +888,59 @@ def check_composition_tail_limits(backend):
     assert backend.lib.gs_composition_tail(*a) != 0
     a = list(args(4, 4)); a[4] = None; a[5] = 1; a[6] = one   # n / steps = 64 > 32: the vector form is the one to use
     assert backend.lib.gs_composition_tail(*a) != 0
+
+
+def check_composition_tail_coset(backend, rng, logn, logsteps, per_row, lcount, ranks):
+    """gs_composition_tail_coset: every rank's output over its coset (point i = omega^rank * (omega^ranks)^i, strided shares of the inputs)
+    must be the strided share of what gs_composition_tail computes over the whole domain — with 1/Z and the powers passed as the
+    shares of the domain-wide vectors, and computed in place from (steps, x_last) / the exponent."""
+    be = backend
+    f = field_for(be)
+    p = f.modulus
+    n, steps = 1 << logn, 1 << logsteps
+    e = n // steps
+    assert e % ranks == 0 and e // ranks <= 32
+    omega = f.getRootOfUnity(n)
+    bcount, ilen = len(per_row), max(per_row)
+    x_last = pow(omega, (steps - 1) * e, p)
+    pw_exp = rng.randrange(1, 4 * n)                 # (the degree adjustment's exponent may exceed a rank's domain)
+    qv = rand_elements(rng, n)
+    zvec = f.newVector(n)
+    be.call('gs_zero_poly_inverses', f.le(omega), n, steps, f.le(x_last), C.c_void_p(zvec.ptr))
+    zv = zvec.toValues()
+    pwv = [pow(omega, i * pw_exp % n, p) for i in range(n)]
+    bcols = [rand_elements(rng, n) for _ in range(bcount)]
+    lcols = [rand_elements(rng, n) for _ in range(lcount)]
+    roots = [sorted(rng.sample(range(steps), m)) for m in per_row]
+    ipolys = [[rng.randrange(p) for _ in range(m)] + [0] * (ilen - m) for m in per_row]
+    bk, bkp = [rng.randrange(p) for _ in range(bcount)], [rng.randrange(p) for _ in range(bcount)]
+    lk, lkp = [rng.randrange(p) for _ in range(lcount)], [rng.randrange(p) for _ in range(lcount)]
+    le = lambda xs: b''.join(f.le(v) for v in xs)
+    pr = (C.c_uint32 * bcount)(*per_row)
+
+    def run(name, m, w, shift, q_, z_, pw_, b_, l_, unit, made):
+        q, z, pw = f.newVectorFrom(q_), f.newVectorFrom(z_), f.newVectorFrom(pw_)
+        bvecs, lvecs = [f.newVectorFrom(c) for c in b_], [f.newVectorFrom(c) for c in l_]
+        bp = (C.c_void_p * bcount)(*[v.ptr for v in bvecs])
+        lp = (C.c_void_p * max(lcount, 1))(*[v.ptr for v in lvecs])
+        ri = (C.c_uint64 * (bcount * ilen))(*[(r[k] * e // unit if k < len(r) else 0) for r in roots for k in range(ilen)])
+        c_out, l_out = f.newVector(m), f.newVector(m)
+        head = [m, f.le(w)] + ([f.le(shift)] if name.endswith('coset') else [])
+        be.call(name, *head, C.c_void_p(q.ptr), None if made else C.c_void_p(z.ptr), steps, f.le(x_last), bp, bcount,
+                le([v for row in ipolys for v in row]), ilen, ri, pr, ilen, le(bk), le(bkp), lp if lcount else None, lcount,
+                le(lk) if lcount else None, le(lkp) if lcount else None, None if made else C.c_void_p(pw.ptr), pw_exp if made else 0,
+                C.c_void_p(c_out.ptr), C.c_void_p(l_out.ptr))
+        return c_out.toValues(), l_out.toValues()
+
+    full = run('gs_composition_tail', n, omega, 1, qv, zv, pwv, bcols, lcols, 1, False)
+    assert full == run('gs_composition_tail', n, omega, 1, qv, zv, pwv, bcols, lcols, 1, True)
+    w = pow(omega, ranks, p)
+    out = []
+    for g in range(ranks):
+        share = lambda col: col[g::ranks]
+        args = (n // ranks, w, pow(omega, g, p), share(qv), share(zv), share(pwv), [share(c) for c in bcols], [share(c) for c in lcols], ranks)
+        for made in (False, True):
+            got = run('gs_composition_tail_coset', *args, made)
+            assert got == (share(full[0]), share(full[1])), (g, made)
+        out.append(got)
+    return out

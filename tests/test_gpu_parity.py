@@ -192,6 +192,14 @@ def test_composition_tail(hip_backend, oracle_backend, logn, logsteps, per_row, 
     cases.check_composition_tail_limits(hip_backend)
 
 
+@pytest.mark.parametrize('logn,logsteps,per_row,lcount,ranks', [(8, 4, [1], 2, 2), (12, 7, [2, 1], 3, 4), (16, 11, [4, 1, 3], 7, 8), (15, 11, [1, 1], 6, 2)])
+def test_composition_tail_over_a_rank_s_coset(hip_backend, oracle_backend, logn, logsteps, per_row, lcount, ranks):
+    seed = logn * 100 + ranks
+    got = cases.check_composition_tail_coset(hip_backend, random.Random(seed), logn, logsteps, per_row, lcount, ranks)
+    if logn <= 12:
+        assert got == cases.check_composition_tail_coset(oracle_backend, random.Random(seed), logn, logsteps, per_row, lcount, ranks)
+
+
 @pytest.mark.parametrize('jit', [0, 1])
 def test_constraints_read_in_place_from_the_evaluation_domain(hip_backend, oracle_backend, jit):
     """gs_air_constraints_strided, interpreted and compiled, against the oracle's (Poseidon and Rescue segments)."""

@@ -105,6 +105,11 @@ def test_composition_tail(oracle_backend, rng, logn, logsteps, per_row, lcount, 
     cases.check_composition_tail_limits(oracle_backend)
 
 
+@pytest.mark.parametrize('logn,logsteps,per_row,lcount,ranks', [(8, 4, [1], 2, 2), (10, 5, [2, 1], 3, 4), (11, 6, [4, 1, 3], 7, 8)])
+def test_composition_tail_over_a_rank_s_coset(oracle_backend, rng, logn, logsteps, per_row, lcount, ranks):
+    cases.check_composition_tail_coset(oracle_backend, rng, logn, logsteps, per_row, lcount, ranks)
+
+
 def test_constraints_read_in_place_from_the_evaluation_domain(oracle_backend):
     from genstark_amd.field import PrimeField
     from genstark_amd.poseidon import poseidon6x128_air
