@@ -990,10 +990,11 @@ int gs_air_constraints_strided(gs_ctx *c, const uint32_t *code, uint32_t n, cons
     if (air_check(c, code, n, nconsts, vmn, regs, nstatic, ncons, 1)) return GS_ERR_ARG;
     if (!nc) return fail(c, GS_ERR_ARG, "air_constraints: empty domain");
     if (!pstride || (nc - 1) > UINT64_MAX / pstride || (nc - 1) * pstride >= prow) return fail(c, GS_ERR_ARG, "air_constraints: points at this stride do not fit the rows");
-    fe vm[GS_AIR_MAX_VM_REGS];
     uint64_t soff[GS_AIR_MAX_REGISTERS], o = 0;
     for (uint32_t s = 0; s < nstatic; s++) { if (!slens[s]) return fail(c, GS_ERR_ARG, "air_constraints: empty static table"); soff[s] = o; o += slens[s]; }
+    PAR_FOR
     for (uint64_t j = 0; j < nc; j++) {
+        fe vm[GS_AIR_MAX_VM_REGS];       /* (the points are independent: a scratch file per iteration) */
         uint64_t jn = (j + shift) % nc;
         for (uint32_t pc = 0; pc < n; pc++) {
             uint32_t op = code[4 * pc], d = code[4 * pc + 1], a = code[4 * pc + 2], b = code[4 * pc + 3];

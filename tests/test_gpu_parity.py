@@ -572,3 +572,63 @@ def test_lazy_field_arithmetic_on_the_device():
         pytest.fail('tools/lazy_device_check is missing: run __graft_entry__.build()')
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and ' 0 mismatching' in r.stdout, r.stdout + r.stderr
+
+
+def test_composition_tail_bytes_equal_oracle_at_2p24(hip_backend, oracle_omp_backend):
+    """gs_composition_tail over the evaluation domain of the 2^20-step Poseidon statement (N = 2^24, six committed vectors, two asserted
+    registers, degree adjustment; 1/Z and the powers computed in place): every byte of L against the oracle's member sequence."""
+    n, steps = 1 << 24, 1 << 20
+    rng = random.Random(424)
+    fh, fo = PrimeField(backend=hip_backend), PrimeField(backend=oracle_omp_backend)
+    w = fh.getRootOfUnity(n)
+    cols = [_dense_input(fh, n, 0x1234567890abcdef1234567 + 977 * k).toBuffer() for k in range(7)]
+    x_last = pow(w, (steps - 1) * 16, P)
+    roots = (C.c_uint64 * 2)(0, (steps - 64) * 16)
+    per_row = (C.c_uint32 * 2)(1, 1)
+    ip, bk, bkp = to_bytes(rng.randrange(P) for _ in range(2)), to_bytes(rng.randrange(P) for _ in range(2)), to_bytes(rng.randrange(P) for _ in range(2))
+    lk, lkp = to_bytes(rng.randrange(P) for _ in range(6)), to_bytes(rng.randrange(P) for _ in range(6))
+    outs = []
+    for be, f in ((hip_backend, fh), (oracle_omp_backend, fo)):
+        vecs = [f.newVector(n) for _ in range(7)]
+        for v, raw in zip(vecs, cols):
+            be.upload(v.ptr, raw)
+        bp = (C.c_void_p * 2)(vecs[1].ptr, vecs[3].ptr)
+        lp = (C.c_void_p * 6)(*[v.ptr for v in vecs[1:]])
+        out = f.newVector(n)
+        be.call('gs_composition_tail', n, w.to_bytes(16, 'little'), C.c_void_p(vecs[0].ptr), None, steps, x_last.to_bytes(16, 'little'), bp, 2, ip, 1, roots, per_row, 1,
+                bk, bkp, lp, 6, lk, lkp, None, 6 * steps, None, C.c_void_p(out.ptr))
+        outs.append(out.toBuffer())
+        del vecs
+    assert outs[0] == outs[1]
+
+
+def test_constraints_in_place_bytes_equal_oracle_at_2p22(hip_backend, oracle_omp_backend):
+    """gs_air_constraints_strided, compiled, with the Poseidon 6x128 constraint program over 2^22 composition-domain points read in
+    place from six columns of 2^23 elements: every byte of the six constraint columns against the oracle's interpreter."""
+    from genstark_amd._abi import Backend
+    from genstark_amd.poseidon import poseidon6x128_air
+    from genstark_amd.field import Matrix
+    nc, n, steps = 1 << 22, 1 << 23, 1 << 19
+    compiled = Backend(device=0).jit()
+    outs = []
+    try:
+        raw = None
+        for be in (compiled, oracle_omp_backend):
+            f = PrimeField(backend=be)
+            air = poseidon6x128_air(steps, 16, f, segmented=True)
+            ctx = air.initProvingContext([], [[1 + s, 2, 3 + s, 4] for s in range(steps // 64)])
+            if raw is None:
+                raw = [_dense_input(f, n, 0xabcdef1234567 + 131 * r).toBuffer() for r in range(6)]
+            p = Matrix(be, 6, n)
+            for r in range(6):
+                be.upload(p.ptr + r * n * 16, raw[r])
+            code, ninstr, consts, nconsts, nregs = air.evaluationProgram.abi_args(16)
+            q = Matrix(be, len(air.constraintDegrees), nc)
+            lens = (C.c_uint64 * len(ctx._staticLens))(*ctx._staticLens)
+            be.call('gs_air_constraints_strided', code, ninstr, consts, nconsts, nregs, 6, len(air.constraintDegrees), C.c_void_p(p.ptr), n, 2, nc,
+                    nc // steps, C.c_void_p(ctx._staticTables.ptr), lens, len(ctx._staticLens), C.c_void_p(q.ptr))
+            outs.append(be.download(q.ptr, len(air.constraintDegrees) * nc * 16))
+        assert compiled.jit_launches >= 1
+    finally:
+        compiled.close()
+    assert outs[0] == outs[1]
