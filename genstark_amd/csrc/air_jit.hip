@@ -273,6 +273,61 @@ static PowPlan pow_plan(const std::vector<uint32_t> &e, int nbits, int w) {
     if (pl.table_max > 1) pl.cost += 1 + (pl.table_max - 1) / 2;
     return pl;
 }
+// Exponents whose top bits repeat "10" — (2p - 1)/3, the inverse of the cube, is 1010...10 over its top 92 bits in the 128-bit field —
+// have a much shorter chain than windows give: with r_k = x^("10" k times), r_{a+b} = r_a^(4^b) * r_b, so r_k costs 2k - 1 squarings and
+// about log2 k + popcount k products (k = 46: 91 + 8, where five-bit windows spend 23 products on the same 92 bits), and the r_j met on
+// the way are dictionary words for the remaining low bits (greedy longest match among them, x and x^3).  ops: (squarings, word to
+// multiply by; "" = none); words are variable names: "p1", "p3", "g<j>" = r_j.  Returns false when the exponent has no such run.
+struct PatOp { uint32_t sq; std::string word; };
+struct PatPlan {
+    uint32_t k = 0;                                            // pairs of the leading run
+    std::vector<std::pair<uint32_t, uint32_t>> doubling;       // (j, 0): g_{2j} = g_j^(4^j) g_j;  (j, 1): g_{j+1} = g_j^4 g_1
+    std::vector<PatOp> ops;                                    // after acc = g_k
+    bool needs_p3 = false;
+    uint32_t cost = 0;
+};
+static bool pattern_plan(const std::vector<uint32_t> &e, int nbits, PatPlan &pl) {
+    auto bit = [&](int i) { return i >= 0 ? (e[i / 32] >> (i % 32)) & 1u : 0u; };
+    int i = nbits - 1;
+    while (i >= 1 && bit(i) && !bit(i - 1)) { pl.k++; i -= 2; }
+    if (pl.k < 8) return false;
+    std::vector<uint32_t> have = {1};                          // the r_j that exist, ascending
+    pl.cost = 1;                                               // g1 = x^2
+    {
+        int top = 31;
+        while (!((pl.k >> top) & 1u)) top--;
+        uint32_t j = 1;
+        for (int b = top - 1; b >= 0; b--) {
+            pl.doubling.push_back({j, 0}); pl.cost += 2 * j + 1; j *= 2; have.push_back(j);
+            if ((pl.k >> b) & 1u) { pl.doubling.push_back({j, 1}); pl.cost += 3; j += 1; have.push_back(j); }
+        }
+    }
+    uint32_t pending = 0;
+    while (i >= 0) {
+        if (!bit(i)) { pending++; i--; continue; }
+        // longest dictionary word that matches the bits from i down: "10" x j (needs 2j bits), "11" (x^3), "1" (x)
+        uint32_t best_j = 0;
+        for (uint32_t j : have) {
+            if ((int)(2 * j) > i + 1) continue;
+            bool ok = true;
+            for (uint32_t t = 0; ok && t < j; t++) ok = bit(i - 2 * (int)t) && !bit(i - 2 * (int)t - 1);
+            if (ok) best_j = j;
+        }
+        char w[16];
+        uint32_t len;
+        if (best_j) { snprintf(w, sizeof w, "g%u", best_j); len = 2 * best_j; }
+        else if (i >= 1 && bit(i - 1)) { snprintf(w, sizeof w, "p3"); len = 2; pl.needs_p3 = true; }
+        else { snprintf(w, sizeof w, "p1"); len = 1; }
+        pl.ops.push_back({pending + len, w});
+        pl.cost += pending + len + 1;
+        pending = 0;
+        i -= (int)len;
+    }
+    if (pending) { pl.ops.push_back({pending, ""}); pl.cost += pending; }
+    if (pl.needs_p3) pl.cost += 1;
+    return true;
+}
+
 static void emit_pow(std::string &s, const char *x, const std::vector<uint32_t> &e) {
     char buf[160];
     int nbits = 0;
@@ -289,6 +344,33 @@ static void emit_pow(std::string &s, const char *x, const std::vector<uint32_t> 
     // A long chain (Rescue's inverse S-box: 127 squarings + 32 products) runs in the lazy five-limb form from end to end: one unpack,
     // lz_sqr (15 products + fold: ~53 instructions against the 84 of a canonical fe_mul) and lz_mul_v, one pack.  On a single wave per
     // SIMD a chain of dependent products costs its instruction count, so this is the length of the trace kernel's critical path.
+    PatPlan pat;
+    if (pattern_plan(e, nbits, pat) && pat.cost < best.cost) {
+        auto sqr_run = [&](const char *v, uint32_t n) {
+            if (n >= 4) { snprintf(buf, sizeof buf, "#pragma nounroll\n                for (int q = 0; q < %u; q++) %s = lz_sqr(%s, K);\n", n, v, v); s += buf; }
+            else for (uint32_t q = 0; q < n; q++) { snprintf(buf, sizeof buf, "                %s = lz_sqr(%s, K);\n", v, v); s += buf; }
+        };
+        s += "            {\n                const lzk K = lzk_make();\n";
+        snprintf(buf, sizeof buf, "                const lz p1 = lz_unpack(%s);\n", x); s += buf;
+        s += "                const lz g1 = lz_sqr(p1, K);\n";
+        if (pat.needs_p3) s += "                const lz p3 = lz_mul_v(g1, p1, K);\n";
+        s += "                lz acc;\n";
+        for (auto &d : pat.doubling) {
+            const uint32_t j = d.first;
+            snprintf(buf, sizeof buf, "                acc = g%u;\n", j); s += buf;
+            sqr_run("acc", d.second ? 2 : 2 * j);
+            if (d.second) snprintf(buf, sizeof buf, "                const lz g%u = lz_mul_v(acc, g1, K);\n", j + 1);
+            else snprintf(buf, sizeof buf, "                const lz g%u = lz_mul_v(acc, g%u, K);\n", 2 * j, j);
+            s += buf;
+        }
+        snprintf(buf, sizeof buf, "                acc = g%u;\n", pat.k); s += buf;
+        for (auto &o : pat.ops) {
+            sqr_run("acc", o.sq);
+            if (!o.word.empty()) { snprintf(buf, sizeof buf, "                acc = lz_mul_v(acc, %s, K);\n", o.word.c_str()); s += buf; }
+        }
+        snprintf(buf, sizeof buf, "                %s = lz_pack(acc);\n            }\n", x); s += buf;
+        return;
+    }
     if (best.cost >= 8) {
         s += "            {\n                const lzk K = lzk_make();\n";
         snprintf(buf, sizeof buf, "                const lz p1 = lz_unpack(%s);\n", x); s += buf;

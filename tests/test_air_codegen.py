@@ -183,3 +183,47 @@ def test_background_builds_run_in_the_helper_process(tmp_path):
     r = subprocess.run([sys.executable, '-c', HELPER_SCRIPT, _abi.HIP_LIB_PATH, str(tmp_path / 'none.hsaco'), 'lazy'],
                        env=dict(os.environ, GSTARK_JITC=str(tmp_path / 'no_such_helper')), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'GOOD -1' in r.stdout, r.stdout + r.stderr[-1000:]
+
+
+def chain_exponent(block):
+    """The exponent a generated lazy-form chain computes, by following its statements with integers (x = p1 has exponent 1)."""
+    import re
+    val = {'p1': 1}
+    lines = block.split('\n')
+    i = 0
+    while i < len(lines):
+        ln = lines[i].strip()
+        i += 1
+        m = re.match(r'for \(int q = 0; q < (\d+); q\+\+\) (\w+) = lz_sqr\((\w+), K\);', ln)
+        if m:
+            assert m.group(2) == m.group(3)
+            val[m.group(2)] <<= int(m.group(1))
+            continue
+        m = re.match(r'(?:const lz |lz )?(\w+) = lz_sqr\((\w+), K\);', ln)
+        if m:
+            val[m.group(1)] = 2 * val[m.group(2)]
+            continue
+        m = re.match(r'(?:const lz |lz )?(\w+) = lz_mul_v\((\w+), (\w+), K\);', ln)
+        if m:
+            val[m.group(1)] = val[m.group(2)] + val[m.group(3)]
+            continue
+        m = re.match(r'(?:const lz |lz )?(\w+) = (\w+);$', ln)
+        if m and m.group(2) in val:
+            val[m.group(1)] = val[m.group(2)]
+    return val['acc'], sum(1 for l in lines if 'lz_mul_v(' in l), val
+
+
+def test_inverse_sbox_chain_uses_the_periodic_pattern(oracle_backend, hip_libs, tmp_path, monkeypatch):
+    """Rescue's inverse S-box exponent (2p - 1)/3 = 0xaaaa...a4aaaaaaab: its top 92 bits repeat "10", so r_k = x^("10" k times) by
+    doubling (r_{a+b} = r_a^(4^b) r_b) replaces five-bit windows there, and the r_j on the way serve the low bits: the generated chain
+    must compute exactly that exponent, with 127 + 1 squarings and a dozen products instead of 32."""
+    f = PrimeField(backend=oracle_backend)
+    src = generated_trace_source(rescue4x128_air(1024, 16, f, segmented=True), hip_libs[MODULUS_128], tmp_path / 'r', monkeypatch)
+    body = src[src.index('for (unsigned long long k = 0'):]
+    start = body.index('const lz p1 = lz_unpack(')
+    block = body[start:body.index('lz_pack(acc)', start)]
+    e = (2 * MODULUS_128 - 1) // 3
+    got, products, val = chain_exponent(block)
+    assert got == e, hex(got)
+    assert 'g46' in val and val['g46'] == int('10' * 46, 2)
+    assert products <= 14 and block.count('lz_sqr(') <= 20          # (squaring runs are loops: few call sites, 128 squarings executed)
