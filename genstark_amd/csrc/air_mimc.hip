@@ -54,6 +54,28 @@ __global__ void k_mimc_composition(const fe *__restrict__ p, uint64_t n, uint64_
 // The MiMC recurrence x <- x^3 + k is a serial dependency chain (examples/mimc/utils.ts:7-15): like
 // the reference (generated JS over one input) it runs on one host core, here on native 64-bit limbs
 // (host_field.h), written straight into a pinned staging buffer that is then copied to the device.
+// One chunk of the chain.  The same source twice: for any x86-64, and for cores with BMI2 / AVX2 scheduled for Zen 5 (what MI355X hosts
+// are: EPYC 9005) — 2 % on the chain there (tools/trace_bench.cpp, profiles/r04_k_*); picked at run time, never assumed.
+#define GS_MIMC_CHUNK_BODY                                                                                      \
+    for (uint64_t i = base; i < end; i++) {                                                                    \
+        t[i] = hf_mimc_out(x);                /* the canonical value, beside the chain */                      \
+        x = hf_mimc_step_weak(x, rc[ri]);     /* the chain itself stays weak (host_field.h) */                 \
+        if (++ri == nrc) ri = 0;                                                                               \
+    }                                                                                                          \
+    *ri_io = ri;                                                                                               \
+    return x;
+static hfe mimc_chunk_generic(hfe *t, hfe x, const hfe *rc, uint32_t nrc, uint32_t *ri_io, uint64_t base, uint64_t end) {
+    uint32_t ri = *ri_io;
+    GS_MIMC_CHUNK_BODY
+}
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__) && !defined(GS_SMALL_Q) && !defined(GS_WIDE_BITS)
+#define GS_MIMC_CHUNK_V3 1
+__attribute__((target("arch=x86-64-v3,tune=znver5"))) static hfe mimc_chunk_v3(hfe *t, hfe x, const hfe *rc, uint32_t nrc, uint32_t *ri_io, uint64_t base,
+                                                                               uint64_t end) {
+    uint32_t ri = *ri_io;
+    GS_MIMC_CHUNK_BODY
+}
+#endif
 extern "C" {
 
 int gs_mimc_trace(gs_ctx *c, const gs_elt *seed, const uint8_t *rc_host, uint32_t nrc, uint64_t steps, void *out) {
@@ -69,13 +91,19 @@ int gs_mimc_trace(gs_ctx *c, const gs_elt *seed, const uint8_t *rc_host, uint32_
     hfe x = hf_load(seed);
     uint32_t ri = 0;
     const uint64_t CHUNK = 1ull << 16;            // copy finished chunks while the next one is being generated
+#ifdef GS_MIMC_CHUNK_V3
+    static const bool v3 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("fma");
+#else
+    const bool v3 = false;
+#endif
     for (uint64_t base = 0; base < steps; base += CHUNK) {
         const uint64_t end = base + CHUNK < steps ? base + CHUNK : steps;
-        for (uint64_t i = base; i < end; i++) {
-            t[i] = hf_mimc_out(x);                // the canonical value, beside the chain
-            x = hf_mimc_step_weak(x, rc[ri]);     // the chain itself stays weak (host_field.h)
-            if (++ri == nrc) ri = 0;
-        }
+#ifdef GS_MIMC_CHUNK_V3
+        if (v3) x = mimc_chunk_v3(t, x, rc.data(), nrc, &ri, base, end);
+        else
+#endif
+            x = mimc_chunk_generic(t, x, rc.data(), nrc, &ri, base, end);
+        (void)v3;
         GS_HIP(c, hipMemcpyAsync((uint8_t *)out + base * GS_ELT, t + base, (end - base) * GS_ELT, hipMemcpyHostToDevice, c->stream));
     }
     return gs_trace_end(c);   // no synchronisation: consumers are ordered on the stream

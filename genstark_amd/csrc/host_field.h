@@ -135,7 +135,8 @@ static inline void hf_store(uint8_t *b, hfe v) { memcpy(b, &v, 16); }
 // mispredicted branch on the chain — and a canonical chain adds its compare-and-subtract to every step; here the constant costs no
 // step of the dependency chain at all (the sums it joins have other terms arriving later), the only fix-up left is the one-in-2^55
 // wrap of R + T*C, and the canonical value the trace stores is computed beside the chain (hf_mimc_out), not on it.
-static inline hfe hf_cube_add_weak(hfe x, hfe k) {
+// (always_inline: gs_mimc_trace compiles its loop a second time for BMI2 cores — a function with other target attributes inlines this only when told to)
+__attribute__((always_inline)) static inline hfe hf_cube_add_weak(hfe x, hfe k) {
     typedef uint64_t u64;
     const u64 C = (u64)HF_C, C20 = 0xFFFFFFEE00000001ull, C21 = 80;   // C^2 = 81*2^64 - 18*2^32 + 1 = C21*2^64 + C20
     u64 x0 = (u64)x, x1 = (u64)(x >> 64);
@@ -168,8 +169,8 @@ static inline hfe hf_cube_add_weak(hfe x, hfe k) {
     if (__builtin_expect(r < R, 0)) r += HF_C;
     return r;
 }
-static inline hfe hf_mimc_step_weak(hfe xw, hfe k) { return hf_cube_add_weak(xw, k); }
-static inline hfe hf_mimc_out(hfe xw) { return xw >= hf_p() ? xw - hf_p() : xw; }      // a weak value is below 2^128 < 2p
+__attribute__((always_inline)) static inline hfe hf_mimc_step_weak(hfe xw, hfe k) { return hf_cube_add_weak(xw, k); }
+__attribute__((always_inline)) static inline hfe hf_mimc_out(hfe xw) { return xw >= hf_p() ? xw - hf_p() : xw; }      // a weak value is below 2^128 < 2p
 // one step of the MiMC recurrence x <- x^3 + k (examples/mimc/utils.ts:7-15) on the weak cube
 static inline hfe hf_mimc_step(hfe x, hfe k) {
     hfe y = hf_cube_weak(x);                           // any representative of x^3

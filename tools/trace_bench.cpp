@@ -86,6 +86,81 @@ static inline hfe hf_cube_add_early(hfe x, hfe k) {
     return r2;
 }
 
+// ---- experiment: the last-arriving limb of the cube, y5 = hi(c4) + hi(q31), folded in two pieces: hi(q31) * C^2 starts as soon as the
+// product q31 exists, the (tiny: < 16) carry hi(c4) joins y4's high side as carry * 2^64 * C^2 = carry * C^2 << 64 ... kept simple: the
+// carry is multiplied too, but off the path of the big product
+static inline hfe hf_cube_add_v2(hfe x, hfe k) {
+    typedef uint64_t u64;
+    const u64 C = (u64)HF_C, C20 = 0xFFFFFFEE00000001ull, C21 = 80;
+    u64 x0 = (u64)x, x1 = (u64)(x >> 64);
+    hfe p00 = (hfe)x0 * x0, p01 = (hfe)x0 * x1, p11 = (hfe)x1 * x1;
+    u64 s0 = (u64)p00;
+    hfe mid = (p00 >> 64) + ((hfe)(u64)p01 << 1);
+    u64 s1 = (u64)mid;
+    hfe up = (mid >> 64) + ((p01 >> 64) << 1) + (u64)p11;
+    u64 s2 = (u64)up;
+    u64 s3 = (u64)(up >> 64) + (u64)(p11 >> 64);
+    hfe q00 = (hfe)s0 * x0, q10 = (hfe)s1 * x0, q20 = (hfe)s2 * x0, q30 = (hfe)s3 * x0;
+    hfe q01 = (hfe)s0 * x1, q11 = (hfe)s1 * x1, q21 = (hfe)s2 * x1, q31 = (hfe)s3 * x1;
+    u64 y0 = (u64)q00;
+    hfe c1 = (q00 >> 64) + (u64)q10 + (u64)q01;
+    u64 y1 = (u64)c1;
+    hfe c2 = (c1 >> 64) + (q10 >> 64) + (q01 >> 64) + (u64)q20 + (u64)q11;
+    u64 y2 = (u64)c2;
+    hfe c3 = (c2 >> 64) + (q20 >> 64) + (q11 >> 64) + (u64)q30 + (u64)q21;
+    u64 y3 = (u64)c3;
+    hfe c4 = (c3 >> 64) + (q30 >> 64) + (q21 >> 64) + (u64)q31;
+    u64 y4 = (u64)c4;
+    const u64 y5a = (u64)(q31 >> 64), y5b = (u64)(c4 >> 64);          // y5 = y5a + y5b, y5b < 16
+    hfe A = (hfe)y2 * C, B = (hfe)y3 * C, D = (hfe)y4 * C20, E = (hfe)y4 * C21;
+    hfe G = (hfe)y5a * C20, H = (hfe)y5a * C21;                          // (start with q31, not with the column sum)
+    hfe Gb = (hfe)y5b * C20, Hb = (hfe)y5b * C21;
+    hfe a0 = (hfe)y0 + (u64)k + (u64)A + (u64)D;
+    hfe a1 = (hfe)y1 + (u64)(k >> 64) + (u64)(A >> 64) + (u64)(D >> 64) + (u64)B + (u64)E + (u64)G + (u64)Gb + (u64)(a0 >> 64);
+    hfe T = (B >> 64) + (E >> 64) + (G >> 64) + (Gb >> 64) + H + Hb + (a1 >> 64);
+    hfe R = ((hfe)(u64)a1 << 64) | (u64)a0;
+    hfe TC = (hfe)(u64)T * C + (((hfe)(u64)(T >> 64) * C) << 64);
+    hfe r = R + TC;
+    if (__builtin_expect(r < R, 0)) r += HF_C;
+    return r;
+}
+// ---- experiment: the doubled cross product from a doubled limb (2 x1 mod 2^64, the lost top bit paid back as x0 << 64): no 128-bit
+// shifts between the square and the cube
+static inline hfe hf_cube_add_v3(hfe x, hfe k) {
+    typedef uint64_t u64;
+    const u64 C = (u64)HF_C, C20 = 0xFFFFFFEE00000001ull, C21 = 80;
+    u64 x0 = (u64)x, x1 = (u64)(x >> 64);
+    const u64 x1d = x1 << 1, top = x1 >> 63;
+    hfe p00 = (hfe)x0 * x0, p01d = (hfe)x0 * x1d, p11 = (hfe)x1 * x1;   // 2 x0 x1 = p01d + top * x0 * 2^64
+    u64 s0 = (u64)p00;
+    hfe mid = (p00 >> 64) + (u64)p01d;
+    u64 s1 = (u64)mid;
+    hfe up = (mid >> 64) + (p01d >> 64) + (u64)p11 + ((0 - top) & x0);
+    u64 s2 = (u64)up;
+    u64 s3 = (u64)(up >> 64) + (u64)(p11 >> 64);
+    hfe q00 = (hfe)s0 * x0, q10 = (hfe)s1 * x0, q20 = (hfe)s2 * x0, q30 = (hfe)s3 * x0;
+    hfe q01 = (hfe)s0 * x1, q11 = (hfe)s1 * x1, q21 = (hfe)s2 * x1, q31 = (hfe)s3 * x1;
+    u64 y0 = (u64)q00;
+    hfe c1 = (q00 >> 64) + (u64)q10 + (u64)q01;
+    u64 y1 = (u64)c1;
+    hfe c2 = (c1 >> 64) + (q10 >> 64) + (q01 >> 64) + (u64)q20 + (u64)q11;
+    u64 y2 = (u64)c2;
+    hfe c3 = (c2 >> 64) + (q20 >> 64) + (q11 >> 64) + (u64)q30 + (u64)q21;
+    u64 y3 = (u64)c3;
+    hfe c4 = (c3 >> 64) + (q30 >> 64) + (q21 >> 64) + (u64)q31;
+    u64 y4 = (u64)c4;
+    u64 y5 = (u64)(c4 >> 64) + (u64)(q31 >> 64);
+    hfe A = (hfe)y2 * C, B = (hfe)y3 * C, D = (hfe)y4 * C20, E = (hfe)y4 * C21, G = (hfe)y5 * C20, H = (hfe)y5 * C21;
+    hfe a0 = (hfe)y0 + (u64)k + (u64)A + (u64)D;
+    hfe a1 = (hfe)y1 + (u64)(k >> 64) + (u64)(A >> 64) + (u64)(D >> 64) + (u64)B + (u64)E + (u64)G + (u64)(a0 >> 64);
+    hfe T = (B >> 64) + (E >> 64) + (G >> 64) + H + (a1 >> 64);
+    hfe R = ((hfe)(u64)a1 << 64) | (u64)a0;
+    hfe TC = (hfe)(u64)T * C + (((hfe)(u64)(T >> 64) * C) << 64);
+    hfe r = R + TC;
+    if (__builtin_expect(r < R, 0)) r += HF_C;
+    return r;
+}
+
 template <int V>
 static double run(uint64_t steps, const std::vector<hfe> &rc, hfe seed, std::vector<hfe> &t) {
     auto t0 = std::chrono::steady_clock::now();
@@ -94,7 +169,7 @@ static double run(uint64_t steps, const std::vector<hfe> &rc, hfe seed, std::vec
     for (uint64_t i = 0; i < steps; i++) {
         if (V & 8) {          // the product's chain since round 4: k joins the cube's first fold, weak chain, canonical value beside it
             t[i] = hf_mimc_out(x);
-            x = (V & 16) ? hf_cube_add_early(x, rc[ri]) : hf_mimc_step_weak(x, rc[ri]);
+            x = (V & 64) ? hf_cube_add_v3(x, rc[ri]) : (V & 32) ? hf_cube_add_v2(x, rc[ri]) : (V & 16) ? hf_cube_add_early(x, rc[ri]) : hf_mimc_step_weak(x, rc[ri]);
             if (++ri == nrc) ri = 0;
             continue;
         }
@@ -130,7 +205,11 @@ int main() {
         for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
         double g24 = run<24>(steps, rc, seed, t2);
         for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
-        printf("2^20 steps: cube + k in one fold, weak chain %.2f ms | + second fold started early %.2f ms\n", g8, g24);
+        double g40 = run<40>(steps, rc, seed, t2);
+        for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
+        double g72 = run<72>(steps, rc, seed, t2);
+        for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
+        printf("2^20 steps: cube + k in one fold, weak chain %.2f ms | + second fold started early %.2f ms | y5 in two pieces %.2f ms | doubled limb %.2f ms\n", g8, g24, g40, g72);
         printf("2^20 steps: A/canon-chain %.2f ms | A/weak-chain %.2f ms | cube/canon-chain %.2f ms | cube/weak-chain %.2f ms | direct/canon %.2f ms | direct/weak %.2f ms  (%s)\n", a, b, c, d, e, f,
                ok ? "all equal" : "DIFF");
     }

@@ -3,7 +3,7 @@
 # compilers / flags the library could be built with.  Output: stdout.
 cd "$(dirname "$0")/.."
 lscpu | grep -E "Model name|MHz" | head -3
-for cc in "g++ -O3" "g++ -O3 -march=native" "/opt/rocm/lib/llvm/bin/clang++ -O3" "/opt/rocm/lib/llvm/bin/clang++ -O3 -mbmi2 -madx" "/opt/rocm/lib/llvm/bin/clang++ -O3 -march=native"; do
+for cc in "/opt/rocm/lib/llvm/bin/clang++ -O3" "/opt/rocm/lib/llvm/bin/clang++ -O3 -mtune=znver5" "/opt/rocm/lib/llvm/bin/clang++ -O3 -mtune=znver4" "/opt/rocm/lib/llvm/bin/clang++ -O3 -march=x86-64-v3" "/opt/rocm/lib/llvm/bin/clang++ -O3 -march=x86-64-v3 -mtune=znver5" "/opt/rocm/lib/llvm/bin/clang++ -O3 -march=native"; do
   $cc tools/trace_bench.cpp -o /tmp/trace_bench_x 2>/dev/null || { echo "$cc: build failed"; continue; }
   echo "== $cc"
   /tmp/trace_bench_x | tail -4
