@@ -50,8 +50,13 @@ fi
 # are computed in that flavour's host arithmetic, elements are gs_element_size() bytes
 build_driver() {   # <output> <extra flags>
   local out=$1 extra=$2
-  if [ ! -f $out ] || [ prover.cc -nt $out ] || [ prover_dist.h -nt $out ] || [ ../../include/gstark_comm.h -nt $out ] || [ ../../include/gstark.h -nt $out ] \
-     || [ ../../include/gstark_prover.h -nt $out ] || [ host_field.h -nt $out ] || [ host_field_small.h -nt $out ] || [ host_field_wide.h -nt $out ] || [ gf_wide.h -nt $out ]; then
+  local stale=0 d
+  # everything prover.cc includes, directly or through prover_dist.h / verifier.h (g++ -MM prover.cc lists the same files)
+  for d in prover.cc prover_dist.h verifier.h host_sha256.h host_field.h host_field_small.h host_field_wide.h host_pow.h gf_wide.h \
+           ../../include/gstark.h ../../include/gstark_comm.h ../../include/gstark_prover.h; do
+    [ $d -nt $out ] && stale=1
+  done
+  if [ ! -f $out ] || [ $stale = 1 ]; then
     g++ -O3 -std=c++17 -shared -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas $extra prover.cc -ldl -o $out
   fi
 }

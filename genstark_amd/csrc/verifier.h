@@ -279,9 +279,24 @@ void verify_impl(const gs_prover_job &job, const uint8_t *proof, uint64_t proof_
     if (!rlen) rlen = (uint32_t)MAX_ARRAY;
     std::vector<F> remainder(rlen);
     for (uint32_t i = 0; i < rlen; i++) remainder[i] = from16(r.take(ELEM));
-    // input shapes (lib/Serializer.ts:127-141): read (bounds-checked) and not interpreted — the job states the trace length, and the
-    // AIRs this verifier takes have no input registers whose shape could change it (the reference's contexts ignore them too then)
-    for (uint32_t shapes = r.byte(); shapes > 0; shapes--) r.take(4ull * r.byte());
+    // input shapes (lib/Serializer.ts:127-141).  The reference sizes the trace from them (initVerificationContext(proof.iShapes, ...),
+    // lib/Stark.ts:180); here the JOB states the trace length and the AIRs this verifier takes have no input registers, so a proof
+    // that carries shapes describes something this entry cannot check: refused, never verified against job.steps alone
+    {
+        const uint32_t nshapes = r.byte();
+        for (uint32_t i = 0; i < nshapes; i++) r.take(4ull * r.byte());      // (bounds-checked either way)
+        if (nshapes) fail(GS_ERR_UNSUPPORTED, "proofs that carry input shapes (%u) are verified by the Python verifier", nshapes);
+    }
+    // the number of FRI layers is a function of the domain size alone (LowDegreeProver.ts:179: fold while more than 256 values are
+    // left); a proof with any other count is malformed — in particular one with extra layers, which would floor the degree bound of
+    // the remainder to zero and leave the low-degree test with nothing to check
+    {
+        uint32_t want = 0;
+        for (uint64_t len = N; len > MAX_ARRAY; len /= 4) want++;
+        if (ncomp != want) fail(GS_ERR_ARG, "malformed proof: %u FRI components, %u expected for a domain of %llu", ncomp, want, (unsigned long long)N);
+        const uint64_t rem_want = N >> (2 * want);
+        if (rlen != rem_want) fail(GS_ERR_ARG, "malformed proof: remainder of %u values, %llu expected", rlen, (unsigned long long)rem_want);
+    }
 
     // ----- composition polynomial set-up (CompositionPolynomial.ts:29-69): the same coefficient stream as the prover's
     struct RegData { uint32_t reg; std::vector<F> xs, ys, ipoly, zpoly; };
@@ -326,6 +341,7 @@ void verify_impl(const gs_prover_job &job, const uint8_t *proof, uint64_t proof_
     std::vector<uint64_t> static_periods;
     if (air.kind == 0) {
         if (!air.nrc || !air.round_constants) fail(GS_ERR_ARG, "the MiMC AIR needs its round constants");
+        if ((air.nrc & (air.nrc - 1)) || T % air.nrc) fail(GS_ERR_ARG, "invalid job: the number of round constants must be a power of two dividing the trace length");
         std::vector<F> rc(air.nrc);
         for (uint32_t i = 0; i < air.nrc; i++) rc[i] = from16(air.round_constants + ELEM * i);
         static_polys.push_back(cyclic_poly(rc, hf_pow(omega, (hfe)(E * (T / air.nrc)))));
@@ -475,6 +491,10 @@ void verify_impl(const gs_prover_job &job, const uint8_t *proof, uint64_t proof_
     }
     // ----- remainder (:155-171)
     if (max_degree_plus1 > remainder.size()) fail(GS_ERR_ARG, "Remainder degree is greater than number of remainder values");
+    // the bound is floor(floor(d / 4) / 4 ...): with a tiny trace under a large extension factor it floors to 0 although a fold never
+    // takes a polynomial below a constant.  Untrusted input never gets the prover's `m == 0: nothing to check` shortcut: the remainder
+    // must then be a constant (the ceiling of the same divisions)
+    if (!max_degree_plus1) max_degree_plus1 = 1;
     if (remainder.size() < 4 || (remainder.size() & 3)) fail(GS_ERR_ARG, "malformed proof: remainder length");
     {
         // the tree over the rows of transposeVector(remainder, 4) must be the last column's tree

@@ -357,11 +357,20 @@ void *g_prover = nullptr;
 gs_prover_binding *g_binding = nullptr;
 size_t g_es = 16;
 typedef int (*prove_on_fn)(const gs_prover_binding *, gs_ctx *, const gs_prover_job *, uint8_t *, uint64_t, uint64_t *, char *, uint64_t);
+std::string g_prover_path;          // the driver build g_binding belongs to ...
+void *g_prover_for_lib = nullptr;   // ... and the ABI library it is bound to: load() may have replaced g_lib by another field's since
 bool open_driver(napi_env env, napi_value path_value) {
-    if (g_prover) return true;
     char path[1024];
     size_t len;
     if (napi_get_value_string_utf8(env, path_value, path, sizeof path, &len) != napi_ok) { napi_throw_type_error(env, nullptr, "driver library path expected"); return false; }
+    if (g_prover && g_prover_for_lib == g_lib && g_prover_path == path) return true;
+    if (g_prover) {      // a binding of another driver flavour, or to a library that is no longer the loaded one: never reused
+        typedef void (*closefn)(gs_prover_binding *);
+        closefn cf = (closefn)dlsym(g_prover, "gs_prover_close");
+        if (cf && g_binding) cf(g_binding);
+        dlclose(g_prover);
+        g_prover = nullptr; g_binding = nullptr; g_prover_for_lib = nullptr; g_prover_path.clear();
+    }
     void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
     if (!lib) { napi_throw_error(env, nullptr, (std::string("cannot load ") + path + ": " + dlerror()).c_str()); return false; }
     typedef int (*openfn)(void *, gs_prover_binding **);
@@ -375,6 +384,8 @@ bool open_driver(napi_env env, napi_value path_value) {
     }
     g_es = (size_t)sf();
     g_prover = lib;
+    g_prover_path = path;
+    g_prover_for_lib = g_lib;
     return true;
 }
 typedef int (*verify_on_fn)(const gs_prover_binding *, const gs_prover_job *, const uint8_t *, uint64_t, char *, uint64_t);

@@ -245,6 +245,50 @@ def test_native_verifier_hip(hip_backend):
     check_native_verifier(hip_backend)
 
 
+def test_native_verifier_refuses_structures_the_prover_never_emits(oracle_backend):
+    """the number of FRI layers and the remainder length are functions of the domain (LowDegreeProver.ts:179) — a proof
+    with appended layers (which would floor the remainder's degree bound to zero) is malformed; a proof carrying input shapes is
+    UNSUPPORTED (never checked against job.steps alone); a MiMC job whose round-constant count does not divide the trace is invalid."""
+    import copy
+    from genstark_amd._abi import GstarkError
+    case = GOLDEN[0]
+    options = {'hashAlgorithm': case['hash_algorithm'], 'extensionFactor': case['extension_factor'], 'exeQueryCount': case['exe_query_count'],
+               'friQueryCount': case['fri_query_count']}
+    stark = ga.instantiateMimc(case['steps'], options, None, backend=oracle_backend)
+    assertions = [{'step': a['step'], 'register': a['register'], 'value': int(a['value'])} for a in case['assertions']]
+    nat = NativeProver(stark)
+    data = nat.prove_bytes(assertions, [], [case['seed']])
+    assert nat.verify_bytes(assertions, data) is True
+    proof = stark.parse(data)
+    assert stark.serialize(proof) == data
+    comps = proof['ldProof']['components']
+    more = copy.deepcopy(proof)
+    more['ldProof']['components'] = comps + [copy.deepcopy(comps[-1])]
+    with pytest.raises(StarkError, match='FRI components'):
+        nat.verify_bytes(assertions, stark.serialize(more))
+    if comps:
+        fewer = copy.deepcopy(proof)
+        fewer['ldProof']['components'] = comps[:-1]
+        with pytest.raises(StarkError, match='FRI components'):
+            nat.verify_bytes(assertions, stark.serialize(fewer))
+    short = copy.deepcopy(proof)
+    short['ldProof']['remainder'] = proof['ldProof']['remainder'][:len(proof['ldProof']['remainder']) // 4]
+    with pytest.raises(StarkError, match='remainder of'):
+        nat.verify_bytes(assertions, stark.serialize(short))
+    shaped = copy.deepcopy(proof)
+    shaped['iShapes'] = [[4]]
+    with pytest.raises(GstarkError, match='input shapes'):
+        nat.verify_bytes(assertions, stark.serialize(shaped))
+    # a MiMC statement whose round constants cannot be a cyclic register of this trace
+    keep = stark.air.roundConstants
+    try:
+        stark.air.roundConstants = keep[:3]           # (the Python front end refuses to BUILD such an AIR; the job struct can still say it)
+        with pytest.raises(StarkError, match='round constants'):
+            nat.verify_bytes(assertions, data)
+    finally:
+        stark.air.roundConstants = keep
+
+
 def test_product_prover_entry(oracle_backend):
     """genstark_amd.prover.Prover: an AIR + options straight into the native driver (no mirror object), the reference's option rules
     (lib/Stark.ts:318-344), bytes of the mirror, and the CPU verifier behind verify()."""
