@@ -592,7 +592,16 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             digests = [None] * world
             dist.all_gather_object(digests, hashlib.sha256(blob).hexdigest())          # verification only, not on the data path
+            for c in colls:
+                # xGMI is point to point: in an all-gather every peer's piece (`bytes`) arrives over its own link, in an all-to-all every
+                # pair exchanges `bytes` over its own link — so bytes / device time is the rate PER LINK (peak ~64 GB/s per direction)
+                c['GBs_per_link'] = None if not c.get('ms') else round(c['bytes'] / (c['ms'] * 1e-3) / 1e9, 2)
             return float(t[0]), blob, len(set(digests)) == 1, colls, nat.last_stats()
+
+        def mode_of(colls):
+            # what the distributed driver did with the statement (gs_comm::solo_below, include/gstark_comm.h)
+            return 'rank 0 alone, bytes delivered to every rank (fewer than 2^20 evaluation-domain points per rank: not worth a collective)' \
+                if colls and colls[0]['label'].startswith('solo') else 'sharded over the ranks'
 
         def leg():
             try:
@@ -609,8 +618,12 @@ def main():
                     try:
                         uid = [RcclComm.unique_id() if rank == 0 else None]
                         dist.broadcast_object_list(uid, src=0)                          # control path: 128 bytes, once
+                        t_rccl = time.perf_counter()
                         comm = RcclComm(backend, rank, world, uid[0])
+                        result['rccl_create_ms'] = round((time.perf_counter() - t_rccl) * 1e3, 1)
+                        t_rccl = time.perf_counter()
                         rccl_error = comm_selftest(backend, comm.comm, rank, world)
+                        result['rccl_selftest_ms'] = round((time.perf_counter() - t_rccl) * 1e3, 1)
                     except Exception as e:   # noqa: BLE001
                         rccl_error = repr(e)[:200]
                     errs = [None] * world
@@ -631,6 +644,19 @@ def main():
                 if shared_gpus:
                     result['gpu_sharing'] = f'{world} ranks on {ndev} GPU(s): a dry run of the N > 1 path, not a scaling measurement'
                 result['rccl_ranks'] = world if is_rccl else 0
+                result['HSA_ENABLE_IPC_MODE_LEGACY'] = os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')
+
+                def sharded_anyway(nat, a0, inputs, sd, reps, single_blob):
+                    # the same statement with the bar off (solo_below = 1): what sharding a proof this small costs — reported beside the
+                    # driver's own choice, never instead of it
+                    comm.comm.solo_below = 1
+                    try:
+                        ms_f, blob_f, same_f, colls_f, st_f = timed_dist(nat, a0, inputs, sd, comm, reps)
+                    finally:
+                        comm.comm.solo_below = 0
+                    return {'ms_per_proof': round(ms_f, 3), 'same_bytes_as_the_single_gpu_proof_on_every_rank': bool(same_f and blob_f == single_blob),
+                            'phases_ms': st_f['phases_ms'], 'collectives': colls_f,
+                            'collective_bytes_per_rank': sum(c['bytes'] * (world if c['kind'] == 'all_to_all' else 1) for c in colls_f)}
                 # C4 (BASELINE configs[3]): Poseidon 6x128, 2^16 steps as 1 024 independent 64-step hash chains, E = 16 — and the same AIR
                 # at 2^20 steps (16 384 chains): the 2^16-step statement is latency-bound on ONE GPU already (2.1 ms inside the driver), the
                 # long one is where the shards have work to do.  First rows are packed before the timed region (inputs resident).
@@ -656,7 +682,9 @@ def main():
                     ms4, blob4, same4, colls4, st4 = timed_dist(p4, a4, [], seed4, comm, reps4)
                     verified4 = None if t4 > (1 << 16) else (rank != 0 or bool(p4.verify(a4, blob4)))   # the long statement is not verified here (host verifier: seconds)
                     ok4 = same4 and blob4 == single and verified4 is not False
+                    forced4 = sharded_anyway(p4, a4, [], seed4, reps4, single) if colls4 and colls4[0]['label'].startswith('solo') else None
                     result[key] = {'workload': f'Poseidon 6x128, 2^{log_t4} steps = {t4 // 64} hash chains, E=16, exe 48, fri 24, blake2s256',
+                                   'mode': mode_of(colls4), 'sharded_anyway': forced4,
                                    'ms_per_proof': round(ms4, 3), 'single_gpu_ms_per_proof': round(single_ms, 3),
                                    'speedup_vs_one_gpu': round(single_ms / ms4, 3), 'ranks': world, 'proofs_timed': reps4, 'proof_bytes': len(blob4),
                                    'scaling': 'strong', 'air_programs': 'compiled (gs_air_jit)' if not cpu_mode else 'interpreted', 'phases_ms': st4['phases_ms'], 'collectives': colls4,
@@ -668,7 +696,9 @@ def main():
                 want = prover.prove_bytes(a0, [], [3])
                 ms, blob, same, colls, st5 = timed_dist(prover, a0, [], [3], comm, args.steps)
                 ok = same and blob == want and (rank != 0 or stark.verify(a0, stark.parse(blob)))
+                forced5 = sharded_anyway(prover, a0, [], [3], args.steps, want) if colls and colls[0]['label'].startswith('solo') else None
                 result['c5'] = {'workload': f'MiMC-128 2^{args.log_trace} steps, E={ef}: ONE proof across {world} ranks', 'ms_per_proof': round(ms, 3),
+                                'mode': mode_of(colls), 'sharded_anyway': forced5,
                                 'ranks': world, 'proofs_timed': args.steps, 'proof_bytes': len(blob), 'scaling': 'strong',
                                 'phases_ms': st5['phases_ms'], 'collectives': colls,
                                 'note': 'bounded from below by the serial x^3 + k recurrence of the one trace register (replicated on every rank)',
@@ -693,7 +723,15 @@ def main():
             out['rccl_ranks'] = snap.get('rccl_ranks')
             # strong scaling in one object: the longest statement that ran as ONE proof across the ranks, beside the same proof on one GPU
             sk = next((k for k in ('c4_long', 'c4') if k in snap), None)
-            out['strong'] = None if sk is None else {
+            # ... and ONLY when the collectives were RCCL over as many ranks as GPUs: with the host-staged fallback (or ranks sharing a GPU)
+            # one_proof.*.ms_per_proof stay as a record of what ran, but they are not a scaling measurement and must not read as one
+            strong_ok = sk is not None and snap.get('rccl_ranks') == world and not shared_gpus
+            out['strong_unavailable'] = None if strong_ok else (
+                'no one-proof statement ran' if sk is None else
+                f'rccl_ranks = {snap.get("rccl_ranks")} of {world} ranks' + (f' ({snap["rccl_error"]})' if snap.get('rccl_error') else '') +
+                (f'; {snap["gpu_sharing"]}' if snap.get('gpu_sharing') else '') +
+                ': the collectives were staged through the host, so the one-proof times are a dry run, not strong scaling')
+            out['strong'] = None if not strong_ok else {
                 'workload': snap[sk]['workload'], 'key': sk, 'ms_1gpu': snap[sk]['single_gpu_ms_per_proof'], 'ms_Ngpu': snap[sk]['ms_per_proof'],
                 'speedup': snap[sk]['speedup_vs_one_gpu'], 'ranks': world, 'same_bytes': snap[sk]['same_bytes_as_the_single_gpu_proof_on_every_rank'],
                 'note': 'ONE proof across all ranks (csrc/prover_dist.h over RCCL) against the same proof on one GPU, both timed in this run; '

@@ -31,6 +31,11 @@ struct gs_comm {
     /* tuning: a FRI layer (after the first) with fewer values than this is all-gathered once and finished on every rank instead of
      * being folded on shares (two collectives per layer are not worth a latency-bound layer).  0 = the default (2^22 values). */
     uint64_t fri_gather_below;
+    /* tuning: a statement with fewer evaluation-domain points PER RANK than this is not sharded at all — rank 0 proves it with the
+     * single-device sequence and the serialized proof is delivered to every rank (two small all-gathers): a proof of a millisecond
+     * is a chain of dependent launches that more devices cannot shorten, and every collective of the sharded form costs more than
+     * the work it would spread.  0 = the default (2^20 points per rank); 1 = always shard (tests). */
+    uint64_t solo_below;
 };
 
 /* One proof of `job` across the comm->size ranks (every rank calls this with the same job; SPMD).  Every rank receives the same

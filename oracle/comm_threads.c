@@ -24,6 +24,14 @@ struct group {
     copy_fn copy;
     sync_fn sync;
     volatile int failed;
+    /* measuring mode (GSTARK_COMM_TAKE_TURNS=1; tools/dist_only.py): between two collectives only ONE rank at a time has work on the
+     * device — rank r starts its stretch when rank r - 1 has drained its own.  With the ranks sharing one GPU every kernel then runs
+     * alone, so a kernel trace shows each rank's work at its uncontended duration and the wall time is the plain sum of the ranks'
+     * stretches.  Same bytes, same collectives. */
+    int take_turns;
+    int turn;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
 };
 struct rank_state {
     struct group *grp;
@@ -35,20 +43,67 @@ static int meet(struct group *g) {
     return g->failed ? GS_ERR_DEVICE : GS_OK;
 }
 
+static void wait_turn(struct group *g, int rank) {
+    if (!g->take_turns) return;
+    pthread_mutex_lock(&g->mu);
+    while (g->turn != rank && !g->failed) pthread_cond_wait(&g->cv, &g->mu);
+    pthread_mutex_unlock(&g->mu);
+}
+static void pass_turn(struct group *g, int rank) {
+    if (!g->take_turns) return;
+    pthread_mutex_lock(&g->mu);
+    g->turn = rank + 1;
+    pthread_cond_broadcast(&g->cv);
+    pthread_mutex_unlock(&g->mu);
+}
+
 static int exchange(struct rank_state *st, gs_ctx *ctx, const void *send, void *recv, uint64_t bytes, int all_to_all) {
     struct group *g = st->grp;
     int rc = g->sync(ctx);
     if (rc) g->failed = 1;
+    pass_turn(g, st->rank);                      /* my stretch of work is done: the next rank may start its own */
     g->send[st->rank] = send;
     if ((rc = meet(g))) return rc;
+    if (g->take_turns && st->rank == 0) { pthread_mutex_lock(&g->mu); g->turn = 0; pthread_mutex_unlock(&g->mu); }    /* everyone has passed; nobody waits before the second meeting */
+    wait_turn(g, st->rank);                      /* (the copies of a collective take turns as well) */
     for (int h = 0; h < g->size && !rc; h++) {
         const uint8_t *src = (const uint8_t *)g->send[h] + (all_to_all ? (uint64_t)st->rank * bytes : 0);
         rc = g->copy(ctx, (uint8_t *)recv + (uint64_t)h * bytes, src, bytes);
     }
     if (!rc) rc = g->sync(ctx);
-    if (rc) g->failed = 1;
+    if (rc) { g->failed = 1; if (g->take_turns) { pthread_mutex_lock(&g->mu); pthread_cond_broadcast(&g->cv); pthread_mutex_unlock(&g->mu); } }
+    pass_turn(g, st->rank);
     int rc2 = meet(g);
+    if (g->take_turns && st->rank == 0) { pthread_mutex_lock(&g->mu); g->turn = 0; pthread_cond_broadcast(&g->cv); pthread_mutex_unlock(&g->mu); }
+    if (!rc && !rc2) {
+        if (g->take_turns && st->rank != 0) {    /* rank 0 has reset the counter when it reads 0 again after everybody's last pass */
+            pthread_mutex_lock(&g->mu);
+            while (g->turn > st->rank && !g->failed) pthread_cond_wait(&g->cv, &g->mu);
+            pthread_mutex_unlock(&g->mu);
+        }
+        wait_turn(g, st->rank);
+    }
     return rc ? rc : rc2;
+}
+/* measuring mode: the stretch before a proof's first collective and after its last one take turns too (tools/dist_only.py calls
+ * these around every proof; no-ops otherwise) */
+int gs_threads_comm_begin(const gs_comm *c) {
+    if (!c || !c->self) return GS_ERR_ARG;
+    struct rank_state *st = (struct rank_state *)c->self;
+    wait_turn(st->grp, st->rank);
+    return GS_OK;
+}
+int gs_threads_comm_end(const gs_comm *c, gs_ctx *ctx) {
+    if (!c || !c->self) return GS_ERR_ARG;
+    struct rank_state *st = (struct rank_state *)c->self;
+    struct group *g = st->grp;
+    if (!g->take_turns) return GS_OK;
+    int rc = g->sync(ctx);
+    pass_turn(g, st->rank);
+    meet(g);
+    if (st->rank == 0) { pthread_mutex_lock(&g->mu); g->turn = 0; pthread_cond_broadcast(&g->cv); pthread_mutex_unlock(&g->mu); }
+    meet(g);
+    return rc;
 }
 static int t_all_gather(void *self, gs_ctx *ctx, const void *send, void *recv, uint64_t bytes) {
     return exchange((struct rank_state *)self, ctx, send, recv, bytes, 0);
@@ -66,6 +121,10 @@ int gs_threads_comm_create(int size, void *abi_dl_handle, gs_comm *out) {
     g->copy = (copy_fn)dlsym(abi_dl_handle, "gs_copy");
     g->sync = (sync_fn)dlsym(abi_dl_handle, "gs_sync");
     if (!g->copy || !g->sync || pthread_barrier_init(&g->bar, NULL, (unsigned)size)) { free(g); return GS_ERR_UNSUPPORTED; }
+    const char *tt = getenv("GSTARK_COMM_TAKE_TURNS");
+    g->take_turns = tt && tt[0] == '1';
+    pthread_mutex_init(&g->mu, NULL);
+    pthread_cond_init(&g->cv, NULL);
     for (int r = 0; r < size; r++) {
         struct rank_state *st = (struct rank_state *)calloc(1, sizeof *st);
         if (!st) return GS_ERR_OOM;

@@ -21,13 +21,16 @@ def thread_comms(backend, size):
     return arr, lib
 
 
-def prove_on_ranks(make_backend, make_stark, size, assertions, inputs, seed, fri_gather_below=0):
-    """-> (list of proof bytes per rank, list of collectives of rank 0).  make_backend() -> Backend; make_stark(backend) -> Stark."""
+def prove_on_ranks(make_backend, make_stark, size, assertions, inputs, seed, fri_gather_below=0, solo_below=1):
+    """-> (list of proof bytes per rank, list of collectives of rank 0).  make_backend() -> Backend; make_stark(backend) -> Stark.
+    solo_below = 1: the statement is sharded whatever its size (the tests' statements are small; the driver's default, 0, hands a
+    statement with fewer than 2^20 points per rank to rank 0 alone)."""
     backends = [make_backend() for _ in range(size)]
     provers = [NativeProver(make_stark(be)) for be in backends]
     comms, keep = thread_comms(backends[0], size)
     for r in range(size):
         comms[r].fri_gather_below = fri_gather_below          # 0: the driver's default; 1: every FRI layer stays on strided shares
+        comms[r].solo_below = solo_below
     out, errs, colls = [None] * size, [None] * size, [None]
 
     def run(r):

@@ -35,6 +35,7 @@ def main():
     nat = NativeProver(stark)
     want = nat.prove_bytes(assertions, [], seed)
     comm = TorchComm(backend)
+    comm.comm.solo_below = int(os.environ.get('GSTARK_TEST_SOLO_BELOW', '1'))      # 1: shard whatever the size; 0: the driver's default
     got = nat.prove_bytes(assertions, [], seed, comm=comm.comm)
     assert comm.error is None, comm.error
     assert got == want, f'rank {rank}: distributed proof differs from the single-device proof'

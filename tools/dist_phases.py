@@ -1,7 +1,7 @@
 """tools/dist_phases.py — the native distributed driver with G ranks SHARING the box's one GPU (ranks = threads, thread communicator of
 the tests): wall time per proof, rank 0's phase clock and the collectives of one proof, for C4 (Poseidon 2^16 steps as 1 024 chains)
 and C5 (MiMC 2^20).  On one GPU the ranks' kernels serialise, so the wall time is the SUM of the ranks' device work + exchanges: it
-shows how much total work the distributed form adds, not a speed-up.  usage: python tools/dist_phases.py [c4|c4long|c5] [G ...]   (c4long: the same AIR at 2^20 steps; programs compiled)"""
+shows how much total work the distributed form adds, not a speed-up.  usage: python tools/dist_phases.py [c4|c4long|c5] [full] [G ...]   (full: shard whatever the size)   (c4long: the same AIR at 2^20 steps; programs compiled)"""
 import os, sys, time, threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -12,7 +12,8 @@ from genstark_amd.prover import Prover
 from dist_helpers import thread_comms
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'c4'
-Gs = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8]
+FULL = 'full' in sys.argv[2:]          # shard whatever the size (gs_comm::solo_below = 1); default: the driver decides (small statements: rank 0 alone)
+Gs = [int(x) for x in sys.argv[2:] if x != 'full'] or [1, 2, 4, 8]
 
 
 def statement(be):
@@ -33,6 +34,8 @@ for G in Gs:
     bes = [Backend(device=0).jit() for _ in range(G)]
     sts = [statement(be) for be in bes]
     comms, keep = thread_comms(bes[0], G)
+    for r in range(G):
+        comms[r].solo_below = 1 if FULL else 0
     single = sts[0][0].prove_bytes(*sts[0][1:])
     outs = [None] * G
 
@@ -53,7 +56,7 @@ for G in Gs:
     one = (time.perf_counter() - t0) / 5 * 1e3
     st = sts[0][0]
     run(0, 0)
-    print(f'== {which} G={G}: {dt:.3f} ms per proof with the ranks sharing one GPU (single-device driver on the same GPU: {one:.3f} ms); bytes equal')
+    print(f'== {which} G={G}{" (sharded whatever the size)" if FULL else ""}: {dt:.3f} ms per proof with the ranks sharing one GPU (single-device driver on the same GPU: {one:.3f} ms); bytes equal')
     ths = [threading.Thread(target=run, args=(r, 1)) for r in range(1, G)]
     for t in ths: t.start()
     run(0, 1)

@@ -72,8 +72,10 @@ while done < cases:
         continue
     comms, keep = thread_comms(bes[0], G)
     gather_below = rng.choice([0, 1, 1 << 10, 1 << 14])          # FRI tail: default threshold, never gathered, gathered at various depths
+    solo_below = rng.choice([1, 1, 1, 0, 1 << 12])               # mostly sharded whatever the size; sometimes the default / a low bar (rank 0 alone)
     for r in range(G):
         comms[r].fri_gather_below = gather_below
+        comms[r].solo_below = solo_below
     outs, errs = [None] * G, [None] * G
 
     def run(r):
