@@ -161,6 +161,68 @@ static inline hfe hf_cube_add_v3(hfe x, hfe k) {
     return r;
 }
 
+// ---- experiment: the recurrence on AVX-512 IFMA (vpmadd52luq / vpmadd52huq).  Radix 2^44, three limbs per element,
+// lane c of a zmm register = column c of a product.  The multiplier side is pre-shifted by 8 bits so that the 52-bit split of the
+// instruction falls on the radix: lo52(a * (b << 8)) = ((a b) mod 2^44) << 8, hi52 = (a b) >> 44.  2^132 = 16 * (9 * 2^32 - 1) mod p is a
+// 40-bit constant K3, so columns 3.. fold down with the same instruction pair (column c -> limbs c - 3, c - 2).  The multiplicand may be
+// lazy (limbs < 2^52); the pre-shifted side must be strict (< 2^44), which is restored once per step through the scalar domain — a
+// sequential carry chain across lanes costs more than the round trip.  What this form can NOT avoid, per step: two products, each
+// broadcast/shift permutes (3 cycles) + a chain of vpmadd52 (4 cycles each, 3-4 deep unless split) + a fold (permute, vpmadd52 pair,
+// permute, adds) — about 75 cycles of dependent latency against the scalar chain's 38: IFMA buys throughput over many independent chains,
+// not latency on one.
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define IFMA_TARGET __attribute__((target("avx512f,avx512ifma,avx512vl,avx512dq")))
+IFMA_TARGET static inline __m512i ifma_bcast(__m512i v, int t) { return _mm512_permutexvar_epi64(_mm512_set1_epi64(t), v); }
+template <int S> IFMA_TARGET static inline __m512i ifma_up(__m512i v) { return _mm512_alignr_epi64(v, _mm512_setzero_si512(), 8 - S); }     // lane i <- lane i - S
+template <int S> IFMA_TARGET static inline __m512i ifma_down(__m512i v) { return _mm512_alignr_epi64(_mm512_setzero_si512(), v, S); }       // lane i <- lane i + S
+// columns of a (NA lazy limbs) times the strict element whose limbs << 8 are x8
+template <int NA> IFMA_TARGET static inline __m512i ifma_mul(__m512i a, __m512i x8) {
+    const __m512i z = _mm512_setzero_si512();
+    __m512i L0 = _mm512_madd52lo_epu64(z, ifma_bcast(a, 0), x8), H0 = _mm512_madd52hi_epu64(z, ifma_bcast(a, 0), ifma_up<1>(x8));
+    __m512i L1 = _mm512_madd52lo_epu64(z, ifma_bcast(a, 1), ifma_up<1>(x8)), H1 = _mm512_madd52hi_epu64(z, ifma_bcast(a, 1), ifma_up<2>(x8));
+    L0 = _mm512_madd52lo_epu64(L0, ifma_bcast(a, 2), ifma_up<2>(x8));
+    H0 = _mm512_madd52hi_epu64(H0, ifma_bcast(a, 2), ifma_up<3>(x8));
+    if (NA > 3) {
+        L1 = _mm512_madd52lo_epu64(L1, ifma_bcast(a, 3), ifma_up<3>(x8));
+        H1 = _mm512_madd52hi_epu64(H1, ifma_bcast(a, 3), ifma_up<4>(x8));
+    }
+    return _mm512_add_epi64(_mm512_srli_epi64(_mm512_add_epi64(L0, L1), 8), _mm512_add_epi64(H0, H1));
+}
+// columns 3.. of P come down as column * K3: low 44 bits to limb c - 3, the rest to limb c - 2
+IFMA_TARGET static inline __m512i ifma_fold(__m512i P) {
+    const __m512i z = _mm512_setzero_si512();
+    const __m512i K8 = _mm512_set1_epi64((long long)(((9ull << 32) - 1) * 16) << 8);
+    const __m512i F = ifma_down<3>(P);
+    const __m512i lo = _mm512_srli_epi64(_mm512_madd52lo_epu64(z, F, K8), 8), hi = ifma_up<1>(_mm512_madd52hi_epu64(z, F, K8));
+    return _mm512_add_epi64(_mm512_add_epi64(_mm512_maskz_mov_epi64(0x07, P), lo), hi);
+}
+IFMA_TARGET static double run_ifma(uint64_t steps, const std::vector<hfe> &rc, hfe seed, std::vector<hfe> &t) {
+    auto t0 = std::chrono::steady_clock::now();
+    const uint64_t M44 = (1ull << 44) - 1;
+    hfe x = seed;
+    uint32_t ri = 0, nrc = (uint32_t)rc.size();
+    for (uint64_t i = 0; i < steps; i++) {
+        t[i] = hf_mimc_out(x);
+        const uint64_t x0 = (uint64_t)x & M44, x1 = (uint64_t)(x >> 44) & M44, x2 = (uint64_t)(x >> 88);          // strict limbs (x2 < 2^40)
+        const __m512i X = _mm512_set_epi64(0, 0, 0, 0, 0, (long long)x2, (long long)x1, (long long)x0), X8 = _mm512_slli_epi64(X, 8);
+        __m512i S = ifma_fold(ifma_mul<3>(X, X8));             // x^2: limbs 0..3 lazy (< 2^48), limb 3 = what column 5 left above 2^132
+        __m512i Y = ifma_fold(ifma_mul<4>(S, X8));             // x^3: limbs 0..4
+        Y = ifma_fold(Y);                                      // limbs 3, 4 once more: limbs 0..2, each < 2^52
+        alignas(64) uint64_t y[8];
+        _mm512_store_si512((__m512i *)y, Y);
+        // back to a weak 128-bit value: y0 + y1 2^44 + y2 2^88, the part of y2 above 2^40 is a multiple of 2^128 == C
+        hfe v = (hfe)y[0] + ((hfe)y[1] << 44);
+        v = hf_add_weak(v, (hfe)(y[2] & ((1ull << 40) - 1)) << 88);
+        v = hf_add_weak(v, (hfe)(y[2] >> 40) * HF_C);
+        x = hf_add_weak(v, rc[ri]);
+        if (++ri == nrc) ri = 0;
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(t1 - t0).count();
+}
+#endif
+
 template <int V>
 static double run(uint64_t steps, const std::vector<hfe> &rc, hfe seed, std::vector<hfe> &t) {
     auto t0 = std::chrono::steady_clock::now();
@@ -210,6 +272,15 @@ int main() {
         double g72 = run<72>(steps, rc, seed, t2);
         for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
         printf("2^20 steps: cube + k in one fold, weak chain %.2f ms | + second fold started early %.2f ms | y5 in two pieces %.2f ms | doubled limb %.2f ms\n", g8, g24, g40, g72);
+#if defined(__x86_64__)
+        if (__builtin_cpu_supports("avx512ifma")) {
+            double gi = run_ifma(steps, rc, seed, t2);
+            for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
+            printf("2^20 steps: AVX-512 IFMA form (radix 2^44, vpmadd52, one chain) %.2f ms\n", gi);
+        } else {
+            printf("2^20 steps: AVX-512 IFMA form: this CPU has no avx512ifma\n");
+        }
+#endif
         printf("2^20 steps: A/canon-chain %.2f ms | A/weak-chain %.2f ms | cube/canon-chain %.2f ms | cube/weak-chain %.2f ms | direct/canon %.2f ms | direct/weak %.2f ms  (%s)\n", a, b, c, d, e, f,
                ok ? "all equal" : "DIFF");
     }
