@@ -518,6 +518,15 @@ def main():
                 'frac_of_compression_roof': None if comp is None else round(comp / (ms_k * 1e-3) / 39.5e9, 4),
                 'algorithmic_GBs': None if comp is None else round(n * (16 + 32 + 28) / (ms_k * 1e-3) / 1e9, 1),
                 'frac_of_hbm_peak': None if comp is None else round(n * (16 + 32 + 28) / (ms_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # every kernel of the headline proof and of the long Poseidon proof against its roof (tools/config_runs.py: kernel_table): the
+        # kernel trace of the configuration's own child run joined with the library's tally of what each launch had to move
+        roofline['kernels'] = {c_['name']: c_.pop('kernels') for c_ in (configs or []) if c_.get('name') in ('C5', 'C4_long') and c_.get('kernels')}
+        roofline['kernels_note'] = ('per proof: calls and ms from rocprofv3 --kernel-trace of the configuration\'s child run; algorithmic_MB = the bytes the launches HAD to '
+                                    'read once and write once (gs_traffic_enable: tallied by the library per launch from its arguments — an NTT pass 16 B in + 16 B out '
+                                    'per element, a Merkle layer 64 B in + 32 B out per node, ...); frac_hbm against 8 TB/s; frac_own_roof where the kernel\'s own roof '
+                                    'is known (BLAKE2s compression issue 39.5 G/s; NTT passes: issue time of their static VALU mix)')
+        for c_ in (configs or []):
+            c_.pop('kernels', None)
         # the reference's phase vocabulary for the headline proof (README.md:62-73; lib/Stark.ts:92-152), device-synchronised
         prover.sync_phases(True)
         prover.prove_bytes(a, [], [seed])

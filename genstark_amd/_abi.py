@@ -57,6 +57,8 @@ _SIGNATURES = {
     'gs_copy': (_int, [_vp, _vp, _vp, _u64]),
     'gs_air_jit': (_int, [_vp, _int]),
     'gs_air_jit_launches': (_u64, [_vp]),
+    'gs_traffic_enable': (_int, [_vp, _int]),
+    'gs_traffic_read': (_int, [_vp, _vp, _u32, _vp]),
     'gs_air_jit_check': (_int, [_int, _vp, _u32, _vp, _u32, _bytes, _u32, _u32, _u32, _vp, _u32, _vp, _u64]),
     'gs_gather_words': (_int, [_vp, _vp, _u64, _vp]),
     'gs_transpose_records': (_int, [_vp, _vp, _u64, _u64, _u64, _vp]),
@@ -178,6 +180,20 @@ class Backend:
     @property
     def jit_launches(self):
         return self.lib.gs_air_jit_launches(self.ctx)
+
+    def traffic(self, on=None):
+        """gs_traffic_enable / gs_traffic_read (a measurement aid): traffic(True) starts a fresh tally, traffic(False) stops it, traffic()
+        returns {kernel name: {'launches', 'bytes', 'units'}} — what every kernel launched since HAD to move (algorithmic bytes)."""
+        if on is not None:
+            self.call('gs_traffic_enable', 1 if on else 0)
+            return self
+
+        class _E(C.Structure):
+            _fields_ = [('kernel', C.c_char * 64), ('launches', C.c_uint64), ('bytes', C.c_uint64), ('units', C.c_uint64)]
+        n = C.c_uint32()
+        arr = (_E * 256)()
+        self.call('gs_traffic_read', arr, 256, C.byref(n))
+        return {arr[i].kernel.decode(): {'launches': int(arr[i].launches), 'bytes': int(arr[i].bytes), 'units': int(arr[i].units)} for i in range(min(n.value, 256))}
 
     def close(self):
         if getattr(self, 'ctx', None):

@@ -1267,6 +1267,7 @@ int gs_jit_trace_segments(gs_ctx *c, const uint32_t *code, uint32_t ninstr, cons
     constexpr unsigned block = 64;
     static_assert(block == 64, "gs_jit_trace: gs_swap[64], __launch_bounds__(64) and the lane groups assume one wave64 per block");
     const unsigned grid = (unsigned)((segments * gen.lanes + block - 1) / block);
+    gs_traffic(c, (uint64_t)registers * segments * (seglen + 1) * GS_ELT, (uint64_t)registers * segments * seglen, "gs_jit_trace");      // first rows in, the trace out
     if (hipModuleLaunchKernel(k->fn, grid, 1, 1, block, 1, 1, 0, c->stream, args, nullptr) != hipSuccess) return GS_ERR_UNSUPPORTED;
     c->jit_launches++;
     return GS_OK;
@@ -1398,6 +1399,11 @@ int gs_jit_constraints(gs_ctx *c, const uint32_t *code, uint32_t ninstr, const u
     unsigned long long a_nc = nc, a_shift = shift, a_prow = prow, a_pstride = pstride;
     void *args[] = {(void *)&dconst, (void *)&p, (void *)&a_nc, (void *)&a_shift, (void *)&statics, (void *)&out, (void *)&a_prow, (void *)&a_pstride};
     const unsigned block = 128, grid = gs_grid(nc, block, 256 * 16);
+    {   // every register read at nc points (the neighbour row is the same vector), one vector per constraint written
+        uint64_t outs = 0;
+        for (uint32_t pc = 0; pc < ninstr; pc++) outs += code[4 * pc] == J_OUT;
+        gs_traffic(c, nc * ((uint64_t)registers + outs) * GS_ELT, nc * outs, "gs_jit_constraints");
+    }
     if (hipModuleLaunchKernel(k->fn, grid, 1, 1, block, 1, 1, 0, c->stream, args, nullptr) != hipSuccess) return GS_ERR_UNSUPPORTED;
     c->jit_launches++;
     return GS_OK;

@@ -169,6 +169,7 @@ int gs_mimc_composition(gs_ctx *c, const void *p_eval, uint64_t n, uint64_t step
         }
     }
     a.x_last = tab[3 * period];
+    gs_traffic(c, 2 * n * GS_ELT, n, "k_mimc_composition");      // P over the evaluation domain in (its neighbour P(x g) is the same vector), L out
     hipLaunchKernelGGL(k_mimc_composition, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const fe *)p_eval, n, period, (const fe *)k_table, klen, lo, hi,
                        log_lo, gs_log2(n), u, a, (uint32_t)period, nroots, lc_coeffs_host ? 1 : 0, (fe *)out);
     GS_LAUNCH_CHECK(c);

@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdarg.h>
 #include <string.h>
+
+#include <array>
 
 #include <map>
 #include <mutex>
@@ -61,6 +64,9 @@ struct gs_ctx {
     // for the same ones with every proof, and an inversion is 4 us of host time on the critical path of a 0.5 ms proof (gs_memo)
     std::map<std::string, std::vector<fe>> scalar_memo;
     uint64_t jit_launches = 0;    // compiled-program launches so far (gs_air_jit_launches)
+    // gs_traffic_enable / gs_traffic_read: per kernel name {launches, algorithmic bytes, work units} of the launches issued while on
+    bool traffic_on = false;
+    std::map<std::string, std::array<uint64_t, 3>> traffic;
     uint64_t host_trace_segments = GS_HOST_TRACE_MAX_SEGMENTS;   // traces of at most this many segments run on a host core (GSTARK_HOST_TRACE_SEGMENTS; air_vm.hip)
     int air_jit = 2;              // AIR programs: 0 interpreted, 1 compiled on first use (hiprtc), 2 auto = compiled when the code object already exists (gs_air_jit / GSTARK_AIR_JIT)
     // deferred read-backs (gs_defer_begin / gs_defer_end): gathers only record the device addresses of the 16-byte words they want;
@@ -94,6 +100,19 @@ struct gs_ctx {
 };
 
 int gs_fail(gs_ctx *c, int code, const char *fmt, ...);
+
+// one launch's entry in the traffic tally (see gs_traffic_enable in gstark.h); `name` may carry printf-style template arguments
+static inline void gs_traffic(gs_ctx *c, uint64_t bytes, uint64_t units, const char *fmt, ...) __attribute__((format(printf, 4, 5)));
+static inline void gs_traffic(gs_ctx *c, uint64_t bytes, uint64_t units, const char *fmt, ...) {
+    if (!c->traffic_on) return;
+    char name[64];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(name, sizeof name, fmt, ap);
+    va_end(ap);
+    auto &e = c->traffic[name];
+    e[0] += 1; e[1] += bytes; e[2] += units;
+}
 
 // key: a tag + the bytes of whatever the table depends on
 struct gs_memo_key {

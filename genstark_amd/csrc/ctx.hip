@@ -65,6 +65,25 @@ int gs_air_jit(gs_ctx *c, int enable) {
     return GS_OK;
 }
 uint64_t gs_air_jit_launches(const gs_ctx *c) { return c ? c->jit_launches : 0; }
+int gs_traffic_enable(gs_ctx *c, int on) {
+    if (!c) return GS_ERR_ARG;
+    c->traffic_on = on != 0;
+    if (on) c->traffic.clear();
+    return GS_OK;
+}
+int gs_traffic_read(gs_ctx *c, struct gs_traffic_entry *out, uint32_t cap, uint32_t *count) {
+    if (!c || !count) return GS_ERR_ARG;
+    *count = (uint32_t)c->traffic.size();
+    uint32_t i = 0;
+    for (auto &kv : c->traffic) {
+        if (i >= cap || !out) break;
+        memset(&out[i], 0, sizeof out[i]);
+        snprintf(out[i].kernel, sizeof out[i].kernel, "%s", kv.first.c_str());
+        out[i].launches = kv.second[0]; out[i].bytes = kv.second[1]; out[i].units = kv.second[2];
+        i++;
+    }
+    return GS_OK;
+}
 
 void gs_ctx_destroy(gs_ctx *c) {
     if (!c) return;
@@ -429,6 +448,7 @@ extern "C" int gs_transpose_records(gs_ctx *c, const void *src, uint64_t rows, u
     if (!rec_bytes || rec_bytes % 16) return gs_fail(c, GS_ERR_ARG, "transpose_records: record size must be a multiple of 16");
     if (!rows || !cols) return GS_OK;
     if (((uintptr_t)src | (uintptr_t)dst) & 15) return gs_fail(c, GS_ERR_ARG, "transpose_records: misaligned buffer");
+    gs_traffic(c, 2 * rows * cols * rec_bytes, rows * cols, "k_transpose_records");
     hipLaunchKernelGGL(k_transpose_records, dim3(gs_grid(rows * cols * (rec_bytes / 16))), dim3(256), 0, c->stream, (const uint4 *)src, rows, cols,
                        (uint32_t)(rec_bytes / 16), (uint4 *)dst);
     GS_LAUNCH_CHECK(c);

@@ -298,6 +298,9 @@ static int arrival_counters(gs_ctx *c, unsigned int **counters) {
     return GS_OK;
 }
 
+// compressions one message of `bytes` bytes costs (gs_traffic: the work unit of the hash kernels): BLAKE2s absorbs 64-byte blocks, the
+// last one together with the finalisation; SHA-256 pads with 0x80 and a 64-bit length
+static inline uint64_t hash_blocks(int alg, uint64_t bytes) { return alg == 1 ? (bytes + 63) / 64 : (bytes + 9 + 63) / 64; }
 #define GS_MERKLE_SUBW (1ull << 15)   // layers at most this wide go to k_merkle_subtree (below it a streaming launch is latency-bound)
 // leaves (n digests, given or hashed from `count` columns when src != 0) -> nodes (heap order).  src as SRC above.
 template <int ALG>
@@ -325,12 +328,17 @@ static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count,
             const int maxlv = src == 2 ? 2 : GS_MERKLE_MAX_LV;
             while (lv < maxlv && (n >> lv) >= GS_MERKLE_SUBW) lv++;         // layers n, n/2, ..., n >> (lv - 1)
             const uint64_t groups = n >> (lv - 1);
+            {   // n leaves hashed from `count` columns (digests written: 32 B each) + the lv - 1 node layers above them (written only)
+                const uint64_t above = n - (n >> (lv - 1));
+                gs_traffic(c, n * ((uint64_t)count * GS_ELT + 32) + above * 32, n * hash_blocks(ALG, (uint64_t)count * GS_ELT) + above, "k_merkle_fused<%d, %d>", ALG, src);
+            }
             if (src == 1) hipLaunchKernelGGL((k_merkle_fused<ALG, 1>), dim3(gs_grid(groups)), blk, 0, c->stream, va, count, nullptr, groups, lv, lo, nd, n);
             else hipLaunchKernelGGL((k_merkle_fused<ALG, 2>), dim3(gs_grid(groups)), blk, 0, c->stream, va, count, nullptr, groups, lv, lo, nd, n);
             w = n >> (lv - 1);
             cur = lv == 1 ? lo : nd + 2 * w;
         } else {
             const uint32_t chunk = (uint32_t)(n < GS_MERKLE_CHUNK ? n : GS_MERKLE_CHUNK);
+            gs_traffic(c, n * ((uint64_t)count * GS_ELT + 32) + n * 32, n * hash_blocks(ALG, (uint64_t)count * GS_ELT) + n - 1, "k_merkle_subtree<%d, %d>", ALG, src);
             if (src == 1) hipLaunchKernelGGL((k_merkle_subtree<ALG, 1>), dim3((unsigned)(n / chunk)), sub_blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk, tail_for(n, chunk), counters);
             else hipLaunchKernelGGL((k_merkle_subtree<ALG, 2>), dim3((unsigned)(n / chunk)), sub_blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk, tail_for(n, chunk), counters);
             GS_LAUNCH_CHECK(c);                  // (n <= 2^15: at most 32 subtrees, whose roots the last workgroup finishes)
@@ -341,12 +349,14 @@ static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count,
         int lv = 1;
         while (lv < GS_MERKLE_MAX_LV && (w >> (lv + 1)) >= GS_MERKLE_SUBW) lv++;
         const uint64_t groups = w >> lv;
+        gs_traffic(c, w * 32 + (w - (w >> lv)) * 32, w - (w >> lv), "k_merkle_fused<%d, 0>", ALG);      // reads layer w, writes layers w/2 .. w >> lv
         hipLaunchKernelGGL((k_merkle_fused<ALG, 0>), dim3(gs_grid(groups)), blk, 0, c->stream, va, 0u, cur, groups, lv, nd + 2 * (w / 2), nd, w / 2);
         w >>= lv;
         cur = nd + 2 * w;
     }
     while (w > 1) {                               // subtrees of <= 1024 digests, then the subtree over their roots
         const uint32_t chunk = (uint32_t)(w < GS_MERKLE_CHUNK ? w : GS_MERKLE_CHUNK);
+        gs_traffic(c, w * 32 + (w - 1) * 32, w - 1, "k_merkle_subtree<%d, 0>", ALG);
         hipLaunchKernelGGL((k_merkle_subtree<ALG, 0>), dim3((unsigned)(w / chunk)), sub_blk, 0, c->stream, va, 0u, cur, nullptr, nd, w, chunk, tail_for(w, chunk), counters);
         w /= chunk;
         cur = nd + 2 * w;
@@ -562,6 +572,8 @@ int gs_hash_merge_rows(gs_ctx *c, gs_hash_alg alg, const void *const *vecs_host,
         GS_LAUNCH_CHECK(c);
         return GS_OK;
     }
+    gs_traffic(c, n * ((uint64_t)count * GS_ELT + 32), n * hash_blocks(alg == GS_HASH_SHA256 ? 0 : 1, (uint64_t)count * GS_ELT),
+               count == 1 ? "k_hash_merge_rows1<%d>" : "k_hash_merge_rows<%d>", alg == GS_HASH_SHA256 ? 0 : 1);
     if (count == 1) {
         if (alg == GS_HASH_SHA256)
             hipLaunchKernelGGL(k_hash_merge_rows1<0>, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const uint4 *)vecs_host[0], n, (uint4 *)out);
@@ -700,6 +712,16 @@ int gs_fri_layers(gs_ctx *c, gs_hash_alg alg, const gs_elt *omega, uint64_t n, u
                     if ((rc = gs_readback_reserve(c, 32, &sj, &Dj.flag, &Dj.value, &Lj.ticket))) return rc;
                     Dj.slot = (uint4 *)sj;
                 }
+            {   // per layer of mj values: the column read, the folded column (mj/4 elements), mj/16 leaf digests and mj/16 - 1 nodes written;
+                // one 64-byte row per leaf = one compression, one per node
+                uint64_t by = 0, un = 0;
+                for (uint32_t j = i; j < i + a.count; j++) {
+                    const uint64_t mj = len >> (2 * j);
+                    by += mj * GS_ELT + mj / 4 * GS_ELT + mj / 16 * 64;
+                    un += mj / 16 * hash_blocks(alg == GS_HASH_SHA256 ? 0 : 1, 4 * GS_ELT) + mj / 16;
+                }
+                gs_traffic(c, by, un, "k_fri_layers<%d>", alg == GS_HASH_SHA256 ? 0 : 1);
+            }
             if (alg == GS_HASH_SHA256) hipLaunchKernelGGL(k_fri_layers<0>, dim3(grid), dim3(GS_FRI_THREADS), 0, c->stream, a);
             else hipLaunchKernelGGL(k_fri_layers<1>, dim3(grid), dim3(GS_FRI_THREADS), 0, c->stream, a);
             GS_LAUNCH_CHECK(c);

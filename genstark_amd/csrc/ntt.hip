@@ -950,6 +950,8 @@ static void launch_pass_lz(gs_ctx *c, const fe *in, fe *out, const LzPassArgs &a
     size_t lds = 0;
     if (RB > 1) lds = (size_t)5 * 4 * R * Wj;
     if (first) { const size_t tr = (size_t)Wj * (R + 1) * sizeof(fe); if (tr > lds) lds = tr; }
+    // a pass reads every element of its input once (a zero-extending first pass: in_len of them) and writes every element once
+    gs_traffic(c, (uint64_t)rows * ((first ? a.in_len : a.n) + a.n) * GS_ELT, (uint64_t)rows * a.n, "k_ntt_pass_lz<%d, %d>", LB, first ? 0 : (a.twp ? 1 : 2));
     if (first) hipLaunchKernelGGL((k_ntt_pass_lz<LB, 0>), dim3((unsigned)tiles, rows), dim3(RB * Wj), lds, c->stream, in, out, a);
     else if (a.twp) hipLaunchKernelGGL((k_ntt_pass_lz<LB, 1>), dim3((unsigned)tiles, rows), dim3(RB * Wj), lds, c->stream, in, out, a);
     else hipLaunchKernelGGL((k_ntt_pass_lz<LB, 2>), dim3((unsigned)tiles, rows), dim3(RB * Wj), lds, c->stream, in, out, a);
@@ -959,6 +961,7 @@ template <int LB>
 static void launch_pass_wave(gs_ctx *c, const fe *in, fe *out, const LzPassArgs &a, uint32_t rows) {
     constexpr int RB = 1 << LB, R = 16 * RB, Wj = 64 >> LB;
     const uint64_t tiles = (a.n / R) / Wj;
+    gs_traffic(c, (uint64_t)rows * ((a.logNs == 0 ? a.in_len : a.n) + a.n) * GS_ELT, (uint64_t)rows * a.n, "k_ntt_wave<%d, %d>", LB, a.logNs == 0 ? 0 : (a.twp ? 1 : 2));
     if (a.logNs == 0) {
         if constexpr (LB == 4) hipLaunchKernelGGL((k_ntt_wave<4, 0>), dim3((unsigned)tiles, rows), dim3(64), 0, c->stream, in, out, a);
     } else if (a.twp) hipLaunchKernelGGL((k_ntt_wave<LB, 1>), dim3((unsigned)tiles, rows), dim3(64), 0, c->stream, in, out, a);
@@ -1020,6 +1023,7 @@ static int ntt_run(gs_ctx *c, const fe *in, uint32_t rows, uint64_t in_len, uint
 
     if (n < 256 || in_len <= 8) {
         dim3 grid(gs_grid(n, 256, 1024), rows);
+        gs_traffic(c, (uint64_t)rows * (in_len + n) * GS_ELT, (uint64_t)rows * n, "k_eval_horner");
         hipLaunchKernelGGL(k_eval_horner, grid, dim3(256), 0, c->stream, in, out, n, in_len, in_stride, p->tw_lo, p->tw_hi, p->log_lo,
                            p->logn, inverse ? 1 : 0, ninv);
         GS_LAUNCH_CHECK(c);

@@ -23,6 +23,7 @@ int gs_power_series_dev(gs_ctx *c, const fe &base, uint64_t n, fe *out) {
     uint64_t tot = n < 65536 ? n : 65536;
     fe step = fe_pow_u64(base, tot);
     unsigned blocks = (unsigned)((tot + 255) / 256);
+    gs_traffic(c, n * GS_ELT, n, "k_power_series");
     hipLaunchKernelGGL(k_power_series, dim3(blocks), dim3(256), 0, c->stream, base, step, n, tot, out);
     GS_LAUNCH_CHECK(c);
     return GS_OK;
@@ -183,6 +184,7 @@ static int launch_batch_inv(gs_ctx *c, const fe *a, const fe *num, uint64_t n, f
     if (tot < 16384) tot = n < 16384 ? n : 16384;
     unsigned threads = tot >= GS_BINV_THREADS ? GS_BINV_THREADS : (unsigned)((tot + 63) / 64 * 64);
     unsigned blocks = (unsigned)((tot + threads - 1) / threads);
+    gs_traffic(c, n * GS_ELT * (num ? 3 : 2), n, "k_batch_inv");
     hipLaunchKernelGGL(k_batch_inv, dim3(blocks), dim3(threads), 0, c->stream, a, num, n, tot, out);
     GS_LAUNCH_CHECK(c);
     return GS_OK;
@@ -624,6 +626,7 @@ int gs_power_series(gs_ctx *c, const gs_elt *base, uint64_t n, void *out) {
     int NAME(gs_ctx *c, const void *a, const void *b, uint64_t n, void *out) {                             \
         CHECK3(c, a, b, out);                                                                              \
         if (!n) return GS_OK;                                                                              \
+        gs_traffic(c, 3 * n * GS_ELT, n, "k_vec_vec<%d>", (int)OP);                                        \
         hipLaunchKernelGGL(k_vec_vec<OP>, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const fe *)a, (const fe *)b, n, (fe *)out); \
         GS_LAUNCH_CHECK(c);                                                                                \
         return GS_OK;                                                                                      \
@@ -632,6 +635,7 @@ int gs_power_series(gs_ctx *c, const gs_elt *base, uint64_t n, void *out) {
     int NAME(gs_ctx *c, const void *a, const gs_elt *s, uint64_t n, void *out) {                       \
         CHECK3(c, a, s, out);                                                                              \
         if (!n) return GS_OK;                                                                              \
+        gs_traffic(c, 2 * n * GS_ELT, n, "k_vec_scalar<%d>", (int)OP);                                     \
         hipLaunchKernelGGL(k_vec_scalar<OP>, dim3(gs_grid(n)), dim3(256), 0, c->stream, (const fe *)a, fe_from_bytes(s), n, (fe *)out); \
         GS_LAUNCH_CHECK(c);                                                                                \
         return GS_OK;                                                                                      \
@@ -673,6 +677,7 @@ int gs_combine_many(gs_ctx *c, const void *const *vecs_host, const uint8_t *coef
             va.v[j] = (const fe *)vecs_host[base + (j < m ? j : 0)];
             va.k[j] = j < m ? fe_from_bytes(coeffs_host + GS_ELT * (base + j)) : fe_zero();
         }
+        gs_traffic(c, n * GS_ELT * (m + 1 + (base ? 1 : 0)), n, "k_combine_many");
         hipLaunchKernelGGL(k_combine_many, dim3(gs_grid(n)), dim3(256), 0, c->stream, va, m, n, base ? 1 : 0, (fe *)out);
         GS_LAUNCH_CHECK(c);
     }
@@ -695,6 +700,8 @@ int gs_combine_adjusted(gs_ctx *c, const void *const *vecs_host, const uint8_t *
         }
         const fe *pl = base ? (const fe *)out : (const fe *)plus;
         const dim3 grid(gs_grid(n)), block(256);
+        // m vectors + the power series (when there are adjusted terms) + the addend read, one vector written
+        gs_traffic(c, n * GS_ELT * (m + (adj_coeffs_host ? 1 : 0) + (pl ? 1 : 0) + 1), n, "k_combine_adjusted<%d, %d>", coeffs_host ? 1 : 0, adj_coeffs_host ? 1 : 0);
         if (coeffs_host && adj_coeffs_host)
             hipLaunchKernelGGL((k_combine_adjusted<1, 1>), grid, block, 0, c->stream, va, m, n, (const fe *)powers, pl, (fe *)out);
         else if (adj_coeffs_host)
@@ -883,6 +890,10 @@ int gs_composition_tail_coset(gs_ctx *c, uint64_t n, const gs_elt *omega, const 
                        pw_step, shift, pw_scale, has_shift, (fe *)c_out, (fe *)l_out)
 #define GS_TAIL_PW(X, ZC)                                                                                                                              \
     do { if (pwk == 0) GS_TAIL_LAUNCH(0, X, ZC); else if (pwk == 1) GS_TAIL_LAUNCH(1, X, ZC); else GS_TAIL_LAUNCH(2, X, ZC); } while (0)
+    // Q + (1/Z when it is not computed per point) + the power series when materialised + the bcount asserted registers' extensions + the
+    // lcount committed vectors read, L (and C when asked for) written.  The asserted registers are among the committed vectors: counted once
+    gs_traffic(c, n * GS_ELT * (1 + (z_inv ? 1 : 0) + (pwk == 1 ? 1 : 0) + (lcount ? lcount : bcount) + (c_out ? 1 : 0) + (l_out ? 1 : 0)), n,
+               "k_composition_tail<%d, %d, %d>", pwk, (zc || has_x) ? 1 : 0, zc ? 1 : 0);
     if (zc) GS_TAIL_PW(1, 1);
     else if (has_x) GS_TAIL_PW(1, 0);
     else GS_TAIL_PW(0, 0);
@@ -991,6 +1002,7 @@ static int fri_fold_launch(gs_ctx *c, const gs_elt *omega, uint64_t n, uint64_t 
     fe zeta = gs_memo_pow(c, w, n / 4);
     fe zeta_inv = fe_mul(fe_mul(zeta, zeta), zeta);  // zeta^3 = zeta^-1
     static const fe inv4 = fe_inv(fe_from_u64(4));      // (a constant of the field: computed once)
+    gs_traffic(c, (m + m / 4) * GS_ELT, m / 4, "k_fri_fold");
     hipLaunchKernelGGL(k_fri_fold, dim3(gs_grid(m / 4)), dim3(256), 0, c->stream, (const fe *)column, m / 4, step, n, lo, hi, log_lo, gs_log2(n),
                        zeta_inv, inv4, x, x_dev, (fe *)out);
     GS_LAUNCH_CHECK(c);

@@ -364,6 +364,17 @@ int gs_air_trace_segments(gs_ctx *ctx, const uint32_t *code_host, uint32_t ninst
  * processes; 1 (GSTARK_AIR_JIT=1): compile on first use; 0 (GSTARK_AIR_JIT=0): always interpret. */
 int gs_air_jit(gs_ctx *ctx, int enable);
 uint64_t gs_air_jit_launches(const gs_ctx *ctx);       /* how many launches ran compiled programs so far (0: everything was interpreted) */
+/* Measurement aid (bench.py: roofline.kernels[]; nothing a proof depends on): while enabled, every kernel launch of the hot path adds
+ * what it MUST move — the bytes it has to read once and write once given its arguments (SURVEY 8d's "algorithmic bytes": an NTT pass
+ * 16 B in + 16 B out per element, a Merkle layer 64 B in + 32 B out per node, ...) — and its work units (hash kernels: compressions;
+ * transforms and pointwise kernels: field elements written) to a per-kernel tally of the context.  Joined with a rocprofv3 kernel
+ * trace of the same run by kernel name this gives every kernel's achieved GB/s against the HBM roof.  enable(1) also clears the tally. */
+struct gs_traffic_entry {
+    char kernel[64];             /* as rocprofv3 prints it up to the parameter list, e.g. "k_merkle_fused<1, 2>" */
+    uint64_t launches, bytes, units;
+};
+int gs_traffic_enable(gs_ctx *ctx, int on);
+int gs_traffic_read(gs_ctx *ctx, struct gs_traffic_entry *out, uint32_t cap, uint32_t *count);
 /* Compile-only check, no context and no device: GS_OK when the source generated for the program builds for gfx950 (kind 0: the
  * trace program with its optional init program, arguments as gs_air_trace_segments; kind 1: the constraint program, arguments as
  * gs_air_constraints).  GS_ERR_UNSUPPORTED otherwise, with the compiler's log (NUL-terminated, truncated) in log_out. */

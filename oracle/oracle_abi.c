@@ -76,6 +76,9 @@ int gs_gather(gs_ctx *c, const void *src, uint64_t rec, const uint64_t *idx, uin
 
 int gs_air_jit(gs_ctx *c, int enable) { (void)c; (void)enable; return GS_OK; }   /* the oracle interprets */
 uint64_t gs_air_jit_launches(const gs_ctx *c) { (void)c; return 0; }
+/* (a measurement aid of the HIP library: the oracle launches no kernels and tallies nothing) */
+int gs_traffic_enable(gs_ctx *c, int on) { (void)c; (void)on; return GS_OK; }
+int gs_traffic_read(gs_ctx *c, struct gs_traffic_entry *out, uint32_t cap, uint32_t *count) { (void)c; (void)out; (void)cap; if (count) *count = 0; return GS_OK; }
 int gs_air_jit_check(int kind, const uint32_t *code, uint32_t ninstr, const uint32_t *icode, uint32_t init_ninstr, const uint8_t *consts,
                      uint32_t nconsts, uint32_t vm_regs, uint32_t registers, const uint64_t *lens, uint32_t nstatic, char *log_out,
                      uint64_t log_cap) {

@@ -266,3 +266,47 @@ def test_column_bounds_of_the_products():
     x4 = [4 * h for h in nn_hi]                                 # what the DIF network really multiplies: 4 values apart
     col_v = [sum(x4[i] * nn_hi[k - i] for i in range(5) if 0 <= k - i < 5) for k in range(9)]
     assert max(col_v) + 2 * fold < (1 << 57) - (1 << 44)
+
+
+def test_fp64_fma_product_experiment(tmp_path):
+    """tools/gf128_f64.h (an experiment beside the library): the radix-2^43 product on fp64 FMAs — values mod p and
+    the normalised-limb bounds, for normalised multipliers and multiplicands as lazy as a radix-16 network leaves them (|limb| < 2^47)."""
+    so = str(tmp_path / 'gf128_f64_host.so')
+    subprocess.check_call(['g++', '-O2', '-ffp-contract=off', '-shared', '-fPIC', '-o', so, os.path.join(ROOT, 'tests', 'host_harness', 'gf128_f64_host.cpp')])
+    lib = ctypes.CDLL(so)
+    R = 1 << 43
+    rng = random.Random(43)
+    D3 = ctypes.c_double * 3
+
+    def val(l):
+        assert all(float(x).is_integer() for x in l)
+        return sum(int(x) * R**i for i, x in enumerate(l))
+
+    def mul(x, w):
+        out = D3()
+        lib.fz_mul_host(D3(*[float(v) for v in x]), D3(*[float(v) for v in w]), out)
+        return list(out)
+
+    for case in range(20000):
+        extreme = case % 4 == 0
+        if extreme:
+            w = [rng.choice([-(R // 2), R // 2, R - 1, 0]) for _ in range(3)]
+            x = [rng.choice([-1, 1]) * ((1 << 47) - 1 - rng.randrange(4)) for _ in range(3)]
+        else:
+            w = [rng.randrange(R) for _ in range(2)] + [rng.randrange(1 << 42)]
+            x = [rng.randrange(-(1 << 47) + 1, 1 << 47) for _ in range(3)]
+        y = mul(x, w)
+        assert val(y) % P == val(x) * val(w) % P, (x, w, y)
+        assert abs(y[0]) < 2 * R and abs(y[1]) <= R // 2 and abs(y[2]) <= R // 2, y
+        z = mul(y, w)                                  # a result is a valid multiplicand AND (signed digits) a valid multiplier
+        assert val(z) % P == val(y) * val(w) % P
+        z2 = mul(x, y)
+        assert val(z2) % P == val(x) * val(y) % P
+    words = (ctypes.c_uint32 * 4)()
+    for _ in range(2000):
+        v = rng.randrange(P)
+        for i in range(4):
+            words[i] = (v >> (32 * i)) & 0xffffffff
+        out = D3()
+        lib.fz_unpack_host(words, out)
+        assert val(list(out)) == v and all(0 <= x < R for x in out)

@@ -44,7 +44,9 @@ def child(name, reps):
         steps, ef, fri = {'C2_E8': (1 << 13, 8, 24), 'C2_E16': (1 << 13, 16, 24), 'C5': (1 << 20, 16, 64)}[name]
         st = ga.instantiateMimc(steps, opts(ef, 48, fri), backend=be)
         p = Prover(st.air, opts(ef, 48, fri))
-        a, seed = [{'step': 0, 'register': 0, 'value': 3}], [3]
+        # the statement bench.py's headline proves: the first and the last step asserted (examples/mimc/mimc128.ts:64-67)
+        tr = st.generateExecutionTrace([], [3])['dTrace']
+        a, seed = [{'step': 0, 'register': 0, 'value': tr.getValue(0, 0)}, {'step': steps - 1, 'register': 0, 'value': tr.getValue(0, steps - 1)}], [3]
     else:
         be = Backend(device=0).jit()
         f = PrimeField(backend=be)
@@ -75,11 +77,22 @@ def child(name, reps):
     p.sync_phases(True)
     p.prove_bytes(a, inputs, seed)
     readme = p.last_stats().get('phases_readme')
+    p.sync_phases(False)
+    # what every kernel of one proof HAD to move (gs_traffic_enable: algorithmic bytes and work units per kernel name; the parent joins
+    # them with the kernel trace of the second child)
+    be.traffic(True)
+    p.prove_bytes(a, inputs, seed)
+    be.sync()
+    be.traffic(False)
+    traffic = be.traffic()
+    p.sync_phases(True)
+    p.prove_bytes(a, inputs, seed)                    # (the measuring proof stays the LAST one of the child: busy_from_db steps back over it)
     tv = time.perf_counter()
     for _ in range(5):
         assert p.verify_native(a, data) is True        # Stark.verify natively (csrc/verifier.h): CPU only
     verify_ms = (time.perf_counter() - tv) / 5 * 1e3
-    print(json.dumps({'name': name, 'prove_ms': round(ms, 4), 'prove_ms_min_max': [round(each[0], 4), round(each[-1], 4)], 'verify_native_ms': round(verify_ms, 4), 'driver_ms': st['total_ms'], 'proof_bytes': len(data), 'proofs_timed': reps,
+    import hashlib
+    print(json.dumps({'name': name, 'proof_sha256': hashlib.sha256(data).hexdigest(), 'assertions': len(a), 'traffic': traffic, 'prove_ms': round(ms, 4), 'prove_ms_min_max': [round(each[0], 4), round(each[-1], 4)], 'verify_native_ms': round(verify_ms, 4), 'driver_ms': st['total_ms'], 'proof_bytes': len(data), 'proofs_timed': reps,
                       'compiled_program_launches': int(getattr(be, 'jit_launches', 0)), 'phases_readme_ms': readme}), flush=True)
 
 
@@ -99,12 +112,58 @@ def busy_from_db(db_path):
     k = max(k, 1)
     sel = rows[-(k + 1) * per:-per]
     busy = sum(e - s for _, s, e in sel) / k / 1e6
-    by = {}
+    by, calls = {}, {}
     for n, s, e in sel:
         by[n] = by.get(n, 0) + (e - s)
+        calls[n] = calls.get(n, 0) + 1
     top = max(by, key=by.get)
     return {'device_busy_ms': round(busy, 4), 'launches_per_proof': per, 'dominant_kernel': top[:80], 'dominant_share': round(by[top] / sum(by.values()), 3),
-            'dominant_kernel_ms_per_proof': round(by[top] / k / 1e6, 4)}
+            'dominant_kernel_ms_per_proof': round(by[top] / k / 1e6, 4),
+            '_per_kernel': {n: (calls[n] / k, by[n] / k / 1e6) for n in by}}
+
+
+HBM_PEAK_GBS = 8000.0
+B2S_COMPRESSIONS_PER_S = 39.5e9          # chip-wide BLAKE2s compression issue roof (tools/microbench_hash.hip, profiles/r03_b_*)
+VALU_CLASS_NS = {'cheap': 1.1, 'vop3': 1.8, 'carry': 1.95, 'mad64': 2.0}      # profiles/r02_a_instruction_costs.txt, 4 waves per SIMD
+
+
+def kernel_table(per_kernel, traffic):
+    """roofline.kernels[]: every kernel of one proof — calls, ms, the bytes it HAD to move (the library's own tally, SURVEY 8d's
+    algorithmic bytes per launch), GB/s and the fraction of the 8 TB/s HBM roof; for the kernels whose own roof is known, that roof and
+    the fraction of it: hash kernels against the chip's BLAKE2s compression issue rate, NTT passes against the issue time of their own
+    static VALU instruction mix (csrc/ntt_isa_mix.json x the measured cost of each instruction class, 1024 SIMDs)."""
+    import re
+    try:
+        mix = json.load(open(os.path.join(ROOT, 'genstark_amd', 'csrc', 'ntt_isa_mix.json')))
+    except Exception:   # noqa: BLE001
+        mix = {}
+    out = []
+    for full, (calls, ms) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
+        base = re.sub(r'^void ', '', full)
+        base = re.sub(r'\(.*$', '', base).strip()
+        t = traffic.get(base)
+        row = {'kernel': base, 'calls': round(calls, 2), 'ms': round(ms, 4)}
+        if t and ms > 0:
+            per = max(t['launches'], 1)                 # the tally is of ONE proof; calls from the trace should agree
+            row['algorithmic_MB'] = round(t['bytes'] / 1e6, 3)
+            row['GBs'] = round(t['bytes'] / (ms * 1e-3) / 1e9, 1)
+            row['frac_hbm'] = round(t['bytes'] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            row['calls_tallied'] = per
+            if ('merkle' in base or 'hash' in base or 'fri_layers' in base) and '<1' in base:
+                row['own_roof'] = 'BLAKE2s compression issue, 39.5 G/s chip-wide'
+                row['compressions'] = t['units']
+                row['frac_own_roof'] = round(t['units'] / (ms * 1e-3) / B2S_COMPRESSIONS_PER_S, 4)
+            m = re.match(r'k_ntt_(wave|pass_lz)<(\d), (\d)>', base)
+            if m:
+                key = next((k for k in mix if f'k_ntt_{m.group(1)}ILi{m.group(2)}ELi{m.group(3)}E' in k), None)
+                if key:
+                    waves = t['units'] / 16 / 64                      # every thread owns 16 elements, whatever the workgroup shape
+                    ns = sum(mix[key][c] * VALU_CLASS_NS[c] for c in VALU_CLASS_NS) * waves / 1024
+                    row['own_roof'] = 'VALU issue of the kernel\'s own instruction mix'
+                    row['valu_per_wave'] = mix[key]['valu']
+                    row['frac_own_roof'] = round(ns * 1e-6 / ms, 4)
+        out.append(row)
+    return out
 
 
 def parent(names, rocprof=True):
@@ -126,10 +185,15 @@ def parent(names, rocprof=True):
                 subprocess.run(['rocprofv3', '--kernel-trace', '-d', d, '-o', 'c', '--', sys.executable, os.path.abspath(__file__), '--child', name, str(min(reps, 4))],
                                capture_output=True, text=True, timeout=240, env=env, cwd='/tmp')
                 db = next((os.path.join(dp, fn) for dp, _, fns in os.walk(d) for fn in fns if fn.endswith('_results.db')), None)
-                rec.update(busy_from_db(db) or {'device_busy_ms': None})
+                got = busy_from_db(db) or {'device_busy_ms': None}
+                per_kernel = got.pop('_per_kernel', None)
+                rec.update(got)
+                if per_kernel and rec.get('traffic') is not None:
+                    rec['kernels'] = kernel_table(per_kernel, rec['traffic'])
             except Exception as e:   # noqa: BLE001
                 rec['rocprof_error'] = repr(e)[:200]
             subprocess.run(['rm', '-rf', d])
+        rec.pop('traffic', None)
         out.append(rec)
     return out
 

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include "../genstark_amd/csrc/gf128_lazy.h"
+#include "gf128_f64.h"
 
 __device__ __forceinline__ lzw load_w(const lzw *p) {
     lzw W;
@@ -109,6 +110,72 @@ __global__ __launch_bounds__(128) void k_femul(const fe *in, fe *out, const lzw 
     for (int m = 0; m < 16; m++) out[blockIdx.x * 2048 + threadIdx.x + 128 * m] = v[m];
 }
 
+// (f) EXPERIMENT: the per-lane product on the fp64 FMA pipe — three limbs of 43 bits, partial products split exactly
+// by two FMAs and a subtraction (tools/gf128_f64.h; 73 fp64 operations per product, 3 x 3 = 6 VGPRs per element instead of 5)
+__global__ __launch_bounds__(128) void k_mulf64(const fe *in, fe *out, const lzw *w) {
+    fz v[16], t[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) { v[m] = fz_unpack(in[threadIdx.x + 128 * m]); t[m] = fz_unpack(in[threadIdx.x + 128 * m + 64]); }
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) v[m] = fz_mul(v[m], t[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < 16; m++) {          // (the limbs as they are: a timing experiment; values are checked on the host, tests/test_lazy_field.py)
+        fe o;
+        o.w0 = (uint32_t)(int64_t)v[m].l[0]; o.w1 = (uint32_t)(int64_t)v[m].l[1]; o.w2 = (uint32_t)(int64_t)v[m].l[2]; o.w3 = 0;
+        out[blockIdx.x * 2048 + threadIdx.x + 128 * m] = o;
+    }
+}
+
+// (g) the two candidates side by side at the pass kernels' REAL occupancy: eight products per round and a register budget of 128
+// (four waves per SIMD); the sixteen-product kernels above need ~210 VGPRs and hold two
+__global__ __launch_bounds__(128, 4) void k_mulvm8(const fe *in, fe *out, const lzw *w) {
+    const lzk K = lzk_make();
+    lz v[8], t[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) { v[m] = lz_unpack(in[threadIdx.x + 128 * m]); t[m] = lz_unpack(in[threadIdx.x + 128 * m + 64]); }
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) v[m] = lz_mul_vm(v[m], t[m], K);
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) out[blockIdx.x * 2048 + threadIdx.x + 128 * m] = lz_pack(v[m]);
+}
+// (h) what a WAVE-UNIFORM exchange twiddle would cost: the same eight products by multipliers in W-form out of
+// scalar registers (lz_mul_u: five columns, no REDC) — the difference to k_mulvm8 is what a pass could save per element IF its exchange
+// twiddles omega_R^(kk * qa) were the same for all lanes of a wave, i.e. if the lanes of a wave were 64 different sub-transforms
+__global__ __launch_bounds__(128, 4) void k_mulu8(const fe *in, fe *out, const lzw *w) {
+    const lzk K = lzk_make();
+    lz v[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) v[m] = lz_unpack(in[threadIdx.x + 128 * m]);
+    // best case for the uniform form: ONE multiplier, its 25 words resident in scalar registers for the whole loop (a real exchange
+    // needs sixteen of them per pass: loads pipelined between the products as in the radix-16 network, ~5 % on top)
+    const lzw W = load_w(w);
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) v[m] = lz_mul_u(v[m], W, K);
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) out[blockIdx.x * 2048 + threadIdx.x + 128 * m] = lz_pack(v[m]);
+}
+__global__ __launch_bounds__(128, 4) void k_mulf64_8(const fe *in, fe *out, const lzw *w) {
+    fz v[8], t[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) { v[m] = fz_unpack(in[threadIdx.x + 128 * m]); t[m] = fz_unpack(in[threadIdx.x + 128 * m + 64]); }
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) v[m] = fz_mul(v[m], t[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        fe o;
+        o.w0 = (uint32_t)(int64_t)v[m].l[0]; o.w1 = (uint32_t)(int64_t)v[m].l[1]; o.w2 = (uint32_t)(int64_t)v[m].l[2]; o.w3 = 0;
+        out[blockIdx.x * 2048 + threadIdx.x + 128 * m] = o;
+    }
+}
+
 typedef void (*kern_t)(const fe *, fe *, const lzw *);
 // `--json`: one JSON object on stdout (bench.py: the second roof of the NTT pass kernel, measured in the same run)
 int main(int argc, char **argv) {
@@ -126,10 +193,14 @@ int main(int argc, char **argv) {
         {"fe_mul (canonical limbs)", k_femul, 16, "per product"},
         {"lz_mul_vm (Montgomery REDC, radix 2^26)", k_mulvm, 16, "per product"},
         {"lz_sqr, ONE dependent chain per lane", k_sqrchain, 16, "per squaring"},
+        {"fz_mul (fp64 FMA, radix 2^43: experiment)", k_mulf64, 16, "per product"},
+        {"lz_mul_vm, 8 per round, <= 128 VGPRs", k_mulvm8, 8, "per product"},
+        {"fz_mul, 8 per round, <= 128 VGPRs", k_mulf64_8, 8, "per product"},
+        {"lz_mul_u (wave-uniform W-form), 8 per round", k_mulu8, 8, "per product"},
     };
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     if (!json) printf("%-50s %10s %10s %10s %10s   ns per wave per SIMD (wall clock; k waves per SIMD forced by LDS size, 128-thread blocks)\n", "core", "1 w/SIMD", "2 w/SIMD", "3 w/SIMD", "4 w/SIMD");
-    double res[6][4];
+    double res[12][4];
     int ei = 0;
     for (auto &e : es) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(e.k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -152,9 +223,9 @@ int main(int argc, char **argv) {
         ei++;
     }
     if (json) {
-        const char *keys[6] = {"dif16_network_ns", "mul_v_ns", "pack_unpack_add_ns", "fe_mul_ns", "mul_vm_ns", "sqr_chain_ns"};
+        const char *keys[10] = {"dif16_network_ns", "mul_v_ns", "pack_unpack_add_ns", "fe_mul_ns", "mul_vm_ns", "sqr_chain_ns", "mul_f64_ns", "mul_vm_128vgpr_ns", "mul_f64_128vgpr_ns", "mul_u_128vgpr_ns"};
         printf("{\"cus\": %d, \"unit\": \"ns per wave per SIMD at 1,2,3,4 waves per SIMD\"", cus);
-        for (int k = 0; k < 6; k++) printf(", \"%s\": [%.2f, %.2f, %.2f, %.2f]", keys[k], res[k][0], res[k][1], res[k][2], res[k][3]);
+        for (int k = 0; k < 10; k++) printf(", \"%s\": [%.2f, %.2f, %.2f, %.2f]", keys[k], res[k][0], res[k][1], res[k][2], res[k][3]);
         printf("}\n");
     }
     return 0;
