@@ -162,6 +162,9 @@ def kernel_table(per_kernel, traffic):
                     row['own_roof'] = 'VALU issue of the kernel\'s own instruction mix'
                     row['valu_per_wave'] = mix[key]['valu']
                     row['frac_own_roof'] = round(ns * 1e-6 / ms, 4)
+                    if row['frac_own_roof'] > 1.0:      # a zero-extending first pass (>= 16x) skips its first network: the static count overstates it
+                        row['frac_own_roof'] = None
+                        row['own_roof'] += ' (not applicable: the pruned first pass of a >= 16x extension skips the first radix-16 network)'
         out.append(row)
     return out
 
