@@ -109,8 +109,9 @@ int gs_prover_prove_on(const gs_prover_binding *b, gs_ctx *ctx, const struct gs_
  * reads of it the sizes, query counts, hash, root of unity, assertions and, of the AIR, kind / registers / nsecret / degrees and
  * (kind 0) round_constants or (kind 1) e_code, consts, vm_regs, static_values / static_periods / nstatic (public registers first;
  * the trailing nsecret entries are the secret ones, whose values come with the proof).  No gs_ctx: nothing touches a device; the
- * binding supplies the library's host-side helpers (index generator, small interpolation).  Input shapes at the end of a proof are
- * parsed and not interpreted: the job states the trace length. */
+ * binding supplies the library's host-side helpers (index generator, small interpolation).  The job states the trace length: a proof that
+ * carries input shapes (the reference sizes the trace from them) is GS_ERR_UNSUPPORTED, and the number of FRI layers and the remainder
+ * length must be the ones the domain implies (fold while more than 256 values are left) — anything else is a malformed proof. */
 int gs_prover_verify(const struct gs_prover_job *job, const uint8_t *proof, uint64_t len, char *err, uint64_t errcap);
 int gs_prover_verify_on(const gs_prover_binding *b, const struct gs_prover_job *job, const uint8_t *proof, uint64_t len, char *err, uint64_t errcap);
 int gs_prover_last_stats(struct gs_prover_stats *out);
