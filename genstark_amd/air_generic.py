@@ -454,12 +454,10 @@ class GenericAir:
         programs in the {op, dst, a, b} encoding of include/gstark.h; integers that may exceed 2^53 travel as decimal strings.
         The node side builds first rows by zero-padding prove()'s seed; an AIR whose init() does anything else must pass the
         `seed` it will be proved with, and the rows init() gives for it are pinned in the descriptor instead."""
-        if self.secretInputCount:
-            raise GstarkError('secret input registers have no node-side twin')
         prog = lambda pr: None if pr is None else {'code': [w for ins in pr.code for w in ins], 'consts': [str(v) for v in pr.consts],
                                                    'nregs': pr.nregs, 'nout': pr.nout}
         d = {'modulus': str(self.field.modulus), 'steps': self.steps, 'registers': self.traceRegisterCount,
-             'constraintDegrees': list(self.constraintDegrees), 'extensionFactor': self.extensionFactor, 'secretInputCount': 0,
+             'constraintDegrees': list(self.constraintDegrees), 'extensionFactor': self.extensionFactor, 'secretInputCount': self.secretInputCount,
              'staticRegisters': [[str(v) for v in values] for values in self.staticRegisters],
              'transition': prog(self.transitionProgram), 'evaluation': prog(self.evaluationProgram), 'init': prog(self.initProgram)}
         if self.segmentLength is not None:

@@ -508,6 +508,15 @@ class AssemblyAir:
 
     # -- AirModule surface (lib/Stark.ts:90,176)
     def initProvingContext(self, inputs=None, seed=None):
+        air, packed, firsts, shapes = self.plan(inputs, seed)
+        context = air.initProvingContext(packed, firsts)
+        context.inputShapes = shapes
+        return context
+
+    def plan(self, inputs=None, seed=None):
+        """What initProvingContext decides before any device work: (the inner GenericAir for these input shapes, the secret registers'
+        packed columns, the first row — or the first row of every independent run —, the input shapes).  Needs no backend: the node-side
+        compile() of js/shims/@guildofweavers/air-assembly asks for exactly this (genstark_amd/aa_json.py)."""
         ex, p = self.export, self.module.modulus
         inputs = list(inputs or [])
         layout = _Layout(ex.statics, [_shape_of(v) for v in inputs])
@@ -526,7 +535,7 @@ class AssemblyAir:
         packed = [PackedColumn(b''.join(v.to_bytes(es, 'little') for v in _shrink(c)), es) for c in secret]
         at = lambda t: [c[t % len(c)] for c in cols]
         if segment is None:
-            context = air.initProvingContext(packed, self._first_row(at(0), seed))
+            firsts = self._first_row(at(0), seed)
         else:
             firsts = [self._first_row(at(s * segment), None) for s in range(runs)]
             # the restart the segmentation relies on: the row the transition produces on the last step of run 0 is run 1's first row
@@ -536,11 +545,8 @@ class AssemblyAir:
                 row = air.transitionProgram.run(row, None, [v[i % len(v)] for v in statics])
             if row != [v % p for v in firsts[1]]:
                 air = self._inner(length, public, None)
-                context = air.initProvingContext(packed, firsts[0])
-            else:
-                context = air.initProvingContext(packed, firsts)
-        context.inputShapes = [list(s) for s in layout.shapes]
-        return context
+                firsts = firsts[0]
+        return air, packed, firsts, [list(s) for s in layout.shapes]
 
     def initVerificationContext(self, inputShapes=None, publicInputs=None):
         ex = self.export

@@ -1,0 +1,75 @@
+'use strict';
+// js/air_assembly.js — compile(source) / AirSchema / instantiate(schema, component, options) of `@guildofweavers/air-assembly` as
+// index.ts:4,18-33 and lib/Stark.ts:40 use them, for AirAssembly SOURCE (the inline module of examples/mimc/mimc128Assembly.ts:28-51,
+// assembly/*.aa).  The loader itself is genstark_amd/airassembly.py; this file asks it for a descriptor through a child process
+// (`python3 -m genstark_amd.aa_json`: one JSON request in, one JSON answer out, no device, no library) and hands the descriptor to the
+// register-machine AIR of js/air_generic.js, whose programs the device runs.  Input registers (secret and public, nested shapes) are laid
+// out by the loader when the inputs arrive: the plan it returns carries the public registers as static registers and the secret ones as
+// this proof's columns.
+const { spawnSync } = require('child_process');
+const path = require('path');
+const { GenericAir } = require('./air_generic');
+const { defaultField } = require('./context');
+
+const REPO = path.resolve(__dirname, '..');
+
+function ask(request) {
+    const r = spawnSync(process.env.GSTARK_PYTHON || 'python3', ['-m', 'genstark_amd.aa_json'], { cwd: REPO, input: JSON.stringify(request), encoding: 'utf8', maxBuffer: 1 << 28 });
+    if (r.error) throw new Error(`AirAssembly loader (python3 -m genstark_amd.aa_json) could not be started: ${r.error.message}`);
+    let out;
+    try { out = JSON.parse(r.stdout.trim().split('\n').pop()); } catch (e) { throw new Error(`AirAssembly loader: ${r.stderr.slice(-400) || 'no answer'}`); }
+    if (out.error) throw new Error(`AirAssembly: ${out.error}`);
+    return out;
+}
+const toStrings = x => Array.isArray(x) ? x.map(toStrings) : String(x);
+
+class AirSchema {
+    /** source: AirAssembly text; parsed (and rejected, if malformed) by the loader at construction */
+    constructor(source) {
+        this.source = Buffer.isBuffer(source) ? source.toString('utf8') : String(source);
+        const info = ask({ op: 'check', source: this.source });
+        this.modulus = BigInt(info.modulus);
+        this.exports = info.exports;
+    }
+}
+
+function compile(source) {          // index.ts:29 — compileAirAssembly(source: Buffer | string): AirSchema
+    if (typeof source === 'string' && !source.includes('(')) source = require('fs').readFileSync(source, 'utf8');      // a path to an .aa file
+    return new AirSchema(source);
+}
+
+// The AirModule of a component.  Without input registers the trace shape is fixed and the inner AIR is built once; with (public) input
+// registers it is sized when the inputs arrive (initProvingContext) or from the proof's shapes (initVerificationContext).
+class AssemblyAir {
+    constructor(schema, component, options) {
+        const ex = schema.exports[component];
+        if (!ex) throw new Error(`component ${component} is not exported (exports: ${Object.keys(schema.exports).sort().join(', ')})`);
+        this.schema = schema; this.component = component;
+        this.field = defaultField(schema.modulus);
+        this._ef = options && options.extensionFactor;
+        // counts, degrees and the extension factor do not depend on the inputs' shape (lib/Stark.ts:40-75 reads them at construction)
+        const info = ask(this._req('info'));
+        this.traceRegisterCount = info.traceRegisterCount; this.secretInputCount = info.secretInputCount;
+        this.constraintDegrees = info.constraintDegrees; this.maxConstraintDegree = info.maxConstraintDegree; this.extensionFactor = info.extensionFactor;
+        this.constraints = info.constraintDegrees.map(degree => ({ degree }));
+        this._inner = info.inputRegisters ? null : this._build(ask(this._req('describe')).descriptor);
+    }
+    _req(op, more) { return Object.assign({ op, source: this.schema.source, component: this.component, extensionFactor: this._ef || null }, more || {}); }
+    _build(desc) { return new GenericAir(desc, this.extensionFactor, this.field); }
+    initProvingContext(inputs, seed) {
+        if (this._inner) return this._inner.initProvingContext(inputs, seed);
+        const plan = ask(this._req('plan', { inputs: toStrings(inputs || []), seed: seed === undefined || seed === null ? null : toStrings(seed) }));
+        const ctx = this._build(plan.descriptor).initProvingContext([], undefined);
+        ctx.inputShapes = plan.inputShapes;
+        return ctx;
+    }
+    initVerificationContext(inputShapes, publicInputs) {
+        if (this._inner) return this._inner.initVerificationContext(inputShapes, publicInputs);
+        const d = ask(this._req('verify', { inputShapes: inputShapes || [], publicInputs: toStrings(publicInputs || []) })).descriptor;
+        const ctx = this._build(d).initVerificationContext(inputShapes, publicInputs);
+        ctx.inputShapes = inputShapes || [];
+        return ctx;
+    }
+}
+
+module.exports = { AirSchema, compile, AssemblyAir };

@@ -69,36 +69,55 @@ class Context {
 }
 
 class ProvingContext extends Context {
-    constructor(air, firstRows) {
+    /** secretColumns: the SECRET registers' values for this proof (one BigInt array per register, length a power of two dividing the
+     *  trace length: the column repeats), as the loader laid them out — they join the static registers of the trace and constraint
+     *  programs after the public ones, their low-degree extensions are committed beside P(x) (lib/Stark.ts:113-114) */
+    constructor(air, firstRows, secretColumns) {
         super(air);
+        this.secretColumns = secretColumns || [];
+        if (this.secretColumns.length !== air.secretInputCount) throw new Error(`the AIR has ${air.secretInputCount} secret input registers`);
         const f = this.field, n = this.traceLength * this.extensionFactor, nc = this.traceLength * this.compositionFactor;
         this.firstRows = firstRows;
         this.evaluationDomain = f.getPowerSeries(this.rootOfUnity, n);
         this.compositionDomain = f.getPowerSeries(f.exp(this.rootOfUnity, BigInt(n / nc)), nc);
         this.executionDomain = f.getPowerSeries(f.exp(this.rootOfUnity, BigInt(this.extensionFactor)), this.traceLength);
-        this.secretRegisterTraces = [];
-        // static registers over the composition domain: K_s at the (period * compositionFactor)-th roots of unity, back to back
-        const polys = this.staticPolys();
-        this.staticLens = air.staticRegisters.map(v => v.length * this.compositionFactor);
+        // secret registers: the polynomial K_s through one period of the column (degree < period m, in the variable x^(T/m)); its values
+        // over the evaluation domain are what is committed — they repeat with period m * E there
+        const secretPolys = this.secretColumns.map(col => {
+            const m = col.length;
+            if (!isPow2(m) || this.traceLength % m) throw new Error('a secret register column must be a power of 2 long and divide the trace length');
+            const g = f.exp(this.rootOfUnity, BigInt(this.extensionFactor * (this.traceLength / m)));
+            return f.interpolateRoots(f.getPowerSeries(g, m), f.newVectorFrom(col));
+        });
+        this.secretRegisterTraces = secretPolys.map((poly, s) => {
+            const m = this.secretColumns[s].length, period = m * this.extensionFactor;
+            const onePeriod = f.evalPolyAtRoots(poly, f.getPowerSeries(f.exp(this.rootOfUnity, BigInt(this.traceLength / m)), period));
+            return period === n ? onePeriod : f.pluckVector(onePeriod, 1, n);            // v[i mod period]
+        });
+        // static registers over the composition domain: K_s at the (period * compositionFactor)-th roots of unity, back to back; public, then secret
+        const all = this.staticPolys().map((poly, s) => ({ m: air.staticRegisters[s].length, poly: f.newVectorFrom(poly) }))
+            .concat(secretPolys.map((poly, s) => ({ m: this.secretColumns[s].length, poly })));
+        this.staticLens = all.map(e => e.m * this.compositionFactor);
         const total = this.staticLens.reduce((a, b) => a + b, 0);
         this.staticTables = new Vector(f, Math.max(total, 1));
         let off = 0;
-        polys.forEach((poly, s) => {
-            const m = air.staticRegisters[s].length, ln = this.staticLens[s];
-            const wk = f.exp(this.compositionDomain.seriesBase, BigInt(this.traceLength / m));
-            const tab = f.evalPolyAtRoots(f.newVectorFrom(poly), f.getPowerSeries(wk, ln));
+        all.forEach((e, s) => {
+            const ln = this.staticLens[s];
+            const wk = f.exp(this.compositionDomain.seriesBase, BigInt(this.traceLength / e.m));
+            const tab = f.evalPolyAtRoots(e.poly, f.getPowerSeries(wk, ln));
             native().call('gs_copy', f.ctx, this.staticTables.ptr + BigInt(off * f.elementSize), tab.ptr, ln * f.elementSize);
             off += ln;
         });
     }
+    allStaticColumns() { return this.air.staticRegisters.concat(this.secretColumns); }
     staticValuesPacked() {
-        const regs = this.air.staticRegisters;
+        const regs = this.allStaticColumns();
         return regs.length ? Buffer.concat(regs.map(v => Buffer.concat(v.map(le)))) : le(0n);
     }
     generateExecutionTrace() {   // lib/Stark.ts:97
         const air = this.air, f = this.field, t = air.transitionProgram;
         const m = new Matrix(f, air.traceRegisterCount, this.traceLength);
-        const periods = air.staticRegisters.map(v => v.length);
+        const periods = this.allStaticColumns().map(v => v.length);
         const first = Buffer.concat(this.firstRows.map(row => Buffer.concat(row.map(le))));
         if (air.segmentLength === null) {
             native().call('gs_air_trace', f.ctx, t.code, t.ninstr, t.constsBuffer(), t.consts.length, t.nregs, air.traceRegisterCount,
@@ -112,7 +131,7 @@ class ProvingContext extends Context {
     }
     generateStaticTrace() {
         const T = this.traceLength;
-        return this.field.newMatrixFrom(this.air.staticRegisters.map(v => { const row = new Array(T); for (let i = 0; i < T; i++) row[i] = v[i % v.length]; return row; }));
+        return this.field.newMatrixFrom(this.allStaticColumns().map(v => { const row = new Array(T); for (let i = 0; i < T; i++) row[i] = v[i % v.length]; return row; }));
     }
     evaluateTransitionConstraints(pPolys) {   // CompositionPolynomial.ts:76
         const air = this.air, f = this.field, e = air.evaluationProgram, nc = this.compositionDomain.length;
@@ -134,7 +153,7 @@ class VerificationContext extends Context {
             for (let i = poly.length - 1; i >= 0; i--) k = f.mod(k * xc + poly[i]);
             return k;
         });
-        return this.air.evaluationProgram.run(f, rValues, nValues, statics);
+        return this.air.evaluationProgram.run(f, rValues, nValues, statics.concat(hValues.map(v => f.mod(BigInt(v)))));      // public registers, then the secret ones (from the proof's leaves)
     }
 }
 
@@ -145,8 +164,9 @@ class GenericAir {
     constructor(desc, extensionFactor, field) {
         this.field = field;
         if (BigInt(desc.modulus) !== field.modulus) throw new TypeError(`the AIR is defined over the field of ${desc.modulus} elements`);
-        if (desc.secretInputCount) throw new Error('secret input registers are not available through this module');
-        this.steps = desc.steps; this.traceRegisterCount = desc.registers; this.secretInputCount = 0;
+        this.steps = desc.steps; this.traceRegisterCount = desc.registers; this.secretInputCount = desc.secretInputCount || 0;
+        // the secret registers' columns for ONE proof, when the descriptor was made for it (js/air_assembly.js: the loader's plan)
+        this.secretColumns = desc.secretRegisters ? desc.secretRegisters.map(col => col.map(v => field.mod(BigInt(v)))) : null;
         if (!isPow2(this.steps) || this.steps < 2) throw new Error('steps must be a power of 2');
         this.constraintDegrees = desc.constraintDegrees.slice();
         this.maxConstraintDegree = Math.max(...this.constraintDegrees);
@@ -180,8 +200,13 @@ class GenericAir {
         return seed.map(pad);
     }
     initProvingContext(inputs, seed) {
-        if (inputs && inputs.length) throw new Error('the AIR has no input registers');
-        return new ProvingContext(this, this.firstRows(seed));
+        // inputs: one column per SECRET register (BigInt arrays), unless the descriptor already carries this proof's columns
+        let cols = this.secretColumns;
+        if (inputs && inputs.length) {
+            if (inputs.length !== this.secretInputCount) throw new Error(`the AIR has ${this.secretInputCount} secret input registers`);
+            cols = inputs.map(col => col.map(v => this.field.mod(BigInt(v))));
+        }
+        return new ProvingContext(this, this.firstRows(seed), cols || []);
     }
     initVerificationContext(inputShapes, publicInputs) { return new VerificationContext(this); }
 }

@@ -218,3 +218,131 @@ def test_reference_224_bit_sources_equal_hand_transcriptions():
     for _ in range(5):
         r, n, k = ([rng.randrange(p) for _ in range(count)] for count in (14, 14, 10))
         assert inner.evaluationProgram.run(r, n, k) == hand.evaluationProgram.run(r, n, k)
+
+
+# ---- the node side: compile(source) / AirSchema of the air-assembly drop-in (js/air_assembly.js -> python -m genstark_amd.aa_json) ------
+import hashlib
+import json
+import shutil
+import subprocess
+
+from conftest import ORACLE_LIB
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+needs_node_and_reference = pytest.mark.skipif(
+    not (os.path.isdir(os.path.join(REF, 'bin', 'lib')) and shutil.which('node') and os.path.exists('/usr/include/node/node_api.h')),
+    reason='needs the genSTARK checkout and node (build container only)')
+with open(os.path.join(HERE, 'golden', 'reference_index_proofs.json')) as _f:
+    INDEX_PROOFS = {r['name']: r for r in json.load(_f)}
+
+
+def index_cases(backend):
+    """Statements proved through the reference's bin/index.js: instantiate(SOURCE, component, options) — this repository's own modules
+    (the reference's inline MiMC module is added by the live test, which reads it from the checkout): the cube chain (no inputs) and the
+    ledger (secret and public input registers, nested shapes: the proof carries iShapes, the verifier supplies the public register)."""
+    f = PrimeField(backend=backend)
+    chain = open(os.path.join(AA, 'cube_chain.aa')).read()
+    rc = ga.instantiateMimc(64, MIMC_OPTS, backend=backend).air.roundConstants
+    out = []
+    for steps in (64, 1024):
+        control = ga.runMimc(f, steps, rc, 3)
+        out.append({'name': f'cube_chain_{steps}', 'source': chain.replace('(steps 64)', f'(steps {steps})'), 'component': 'chain', 'options': MIMC_OPTS, 'seed': ['3'],
+                    'assertions': [{'step': 0, 'register': 0, 'value': '3'}, {'step': steps - 1, 'register': 0, 'value': str(control[-1])}]})
+    runs = 4
+    balances, factors = [100 + 7 * i for i in range(runs)], [3 + i for i in range(runs)]
+    deposits = [[5 + i + 2 * j for j in range(4)] for i in range(runs)]
+    model = ledger_model(f.modulus, balances, factors, deposits)
+    last = 8 * runs - 1
+    strs = lambda x: [strs(v) for v in x] if isinstance(x, list) else str(x)
+    out.append({'name': 'ledger_4_runs', 'source': open(os.path.join(AA, 'ledger.aa')).read(), 'component': 'default',
+                'options': {'hashAlgorithm': 'sha256', 'exeQueryCount': 24, 'friQueryCount': 12}, 'inputs': strs([balances, factors, deposits]), 'publicInputs': strs([deposits]),
+                'assertions': [{'step': 0, 'register': 0, 'value': str(balances[0])}, {'step': last, 'register': 2, 'value': str(model[last][2])},
+                               {'step': last, 'register': 0, 'value': str(model[last][0])}]})
+    return out
+
+
+def python_bytes(case, backend):
+    ints = lambda x: [ints(v) for v in x] if isinstance(x, list) else int(x)
+    stark = airassembly.instantiate(case['source'], case['component'], case['options'], field=PrimeField(backend=backend))
+    a = [dict(x, value=int(x['value'])) for x in case['assertions']]
+    return stark.serialize(stark.prove(a, ints(case.get('inputs', [])), ints(case['seed']) if 'seed' in case else None))
+
+
+def check_index_fixture(backend):
+    for case in index_cases(backend):
+        data = python_bytes(case, backend)
+        rec = INDEX_PROOFS[case['name']]
+        assert (len(data), hashlib.sha256(data).hexdigest()) == (rec['proofSize'], rec['proofSha256']), case['name']
+
+
+def test_python_host_reproduces_what_the_reference_index_js_proved(oracle_backend):
+    """tests/golden/reference_index_proofs.json: proofs the reference's own bin/index.js produced from AirAssembly SOURCE over the drop-in
+    modules (generated in the build container by the live test below) == what the Python host proves from the same source."""
+    check_index_fixture(oracle_backend)
+
+
+@pytest.mark.gpu
+def test_hip_backend_reproduces_what_the_reference_index_js_proved(hip_backend):
+    check_index_fixture(hip_backend)
+
+
+@needs_node_and_reference
+def test_reference_index_js_compiles_airassembly_source_live(oracle_backend, tmp_path):
+    """index.ts:18-33 unmodified: `instantiate(source)` -> `compileAirAssembly(source)` (the shim's compile(): an AirSchema from this
+    repository's loader) -> `new Stark(schema, component, options)`; prove / serialize / parse / verify are the reference's.  Bytes ==
+    the Python host's from the same source == the committed fixture; the reference's inline MiMC module (mimc128Assembly.ts:28-51) ==
+    the dedicated MiMC path."""
+    subprocess.check_call(['bash', os.path.join(ROOT, 'napi', 'build.sh')])
+    ts = open(os.path.join(REF, 'examples', 'mimc', 'mimc128Assembly.ts')).read()
+    inline = re.search(r'Buffer\.from\(`(.*?)`', ts, re.S).group(1).replace('${steps}', '256').replace('${constantCount}', '64')
+    control = ga.runMimc(PrimeField(backend=oracle_backend), 256, ga.instantiateMimc(64, MIMC_OPTS, backend=oracle_backend).air.roundConstants, 3)
+    cases = index_cases(oracle_backend) + [{'name': 'reference_inline_mimc_256', 'source': inline, 'component': 'mimc', 'options': MIMC_OPTS, 'seed': ['3'],
+                                            'assertions': [{'step': 0, 'register': 0, 'value': '3'}, {'step': 255, 'register': 0, 'value': str(control[-1])}]}]
+    cin, cout = tmp_path / 'cases.json', tmp_path / 'out.json'
+    cin.write_text(json.dumps(cases))
+    env = dict(os.environ, NODE_PATH=os.path.join(ROOT, 'js', 'shims'), GSTARK_LIB=ORACLE_LIB, GSTARK_ALLOW_TEST_DOUBLE='1')
+    r = subprocess.run(['node', os.path.join(HERE, 'golden', 'run_reference_index.js'), os.path.join(REF, 'bin'), str(cin), str(cout)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = {rec['name']: rec for rec in json.loads(cout.read_text())}
+    for case in cases:
+        rec = out[case['name']]
+        assert rec['verified'] is True and rec['tamperRejected'] is True
+        assert rec['iShapes'] == ([[4], [4], [4, 4]] if case['name'].startswith('ledger') else [])
+        data = bytes.fromhex(rec['proofHex'])
+        assert data == python_bytes(case, oracle_backend), case['name']
+        if case['name'] in INDEX_PROOFS:
+            assert (len(data), hashlib.sha256(data).hexdigest()) == (INDEX_PROOFS[case['name']]['proofSize'], INDEX_PROOFS[case['name']]['proofSha256'])
+    dedicated = ga.instantiateMimc(256, MIMC_OPTS, backend=oracle_backend)
+    a = [dict(x, value=int(x['value'])) for x in cases[-1]['assertions']]
+    assert bytes.fromhex(out['reference_inline_mimc_256']['proofHex']) == dedicated.serialize(dedicated.prove(a, [], [3]))
+    if os.environ.get('GSTARK_WRITE_FIXTURES') == '1':
+        with open(os.path.join(HERE, 'golden', 'reference_index_proofs.json'), 'w') as fh:
+            json.dump([{'name': n, 'proofSize': len(bytes.fromhex(out[n]['proofHex'])), 'proofSha256': hashlib.sha256(bytes.fromhex(out[n]['proofHex'])).hexdigest(),
+                        'securityLevel': out[n]['securityLevel'], 'friLayers': out[n]['friLayers'],
+                        'generated_by': 'tests/golden/run_reference_index.js: the reference\'s bin/index.js over js/shims (GSTARK_WRITE_FIXTURES=1 pytest tests/test_airassembly.py -k live)'}
+                       for n in out if not n.startswith('reference_')], fh, indent=1)
+
+
+@needs_node_and_reference
+@pytest.mark.parametrize('script,lib,expect', [
+    ('examples/mimc/mimc128Assembly.js', 'liboracle.so', ['STARK verified in', 'STARK security level: 96', 'Computed 48 evaluation spot checks']),
+    ('examples/assembly/lib128.js', 'liboracle.so', ['STARK verified in', 'Security level: 88', 'Computed 44 evaluation spot checks']),
+    ('examples/assembly/lib224.js', 'liboracle_p224.so', ['STARK verified in', 'Security level: 88']),
+    ('examples/elliptic/pointMul.js', 'liboracle_p224.so', ['STARK verified in', 'STARK security level: 67']),
+])
+def test_reference_example_script_runs_unmodified(oracle_backend, script, lib, expect):
+    """`node bin/examples/...js` of the genSTARK checkout, not a byte changed — every example of the reference that is written in AirAssembly:
+    requires ../../index (-> lib/Stark, and the four @guildofweavers packages = js/shims), compiles its module (inline, or assembly/*.aa /
+    pointmul.aa read from the checkout), builds its control values with the example's OWN code (the package's prng.sha256; Poseidon hash and
+    Merkle tree of examples/poseidon/utils.js; k*G of pointMul.js), proves — secret and public input registers, 12 trace registers in the
+    Merkle update, the 224-bit field in two of them — serializes where the script does, and VERIFIES with the reference's verifier against
+    those control values.  (The other twelve examples are AirScript sources: that compiler is out of scope, js/shims/.../air-script says so.)"""
+    from conftest import _build_oracle
+    _build_oracle()
+    subprocess.check_call(['bash', os.path.join(ROOT, 'napi', 'build.sh')])
+    env = dict(os.environ, NODE_PATH=os.path.join(ROOT, 'js', 'shims'), GSTARK_LIB=os.path.join(ROOT, 'oracle', lib), GSTARK_ALLOW_TEST_DOUBLE='1')
+    r = subprocess.run(['node', os.path.join(REF, 'bin', script)], env=env, cwd=os.path.join(REF, 'bin'), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for line in expect:
+        assert line in r.stdout, (line, r.stdout[-1500:])

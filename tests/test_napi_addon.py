@@ -108,7 +108,7 @@ def test_js_generic_air_rejects_bad_descriptors(addon, oracle_backend, tmp_path)
 const path = require('path'), assert = require('assert');
 const { instantiate } = require(path.join(process.argv[2], 'js', 'shims', '@guildofweavers', 'air-assembly'));
 const c = JSON.parse(require('fs').readFileSync(process.argv[3], 'utf8'));
-assert.throws(() => instantiate({}, 'default', {}), /expected an AIR descriptor/);
+assert.throws(() => instantiate({}, 'default', {}), /expected an AirSchema .* or an AIR descriptor/);
 assert.throws(() => instantiate({ generic: Object.assign({}, c.generic, { steps: 96 }) }, 'default', {}), /power of 2/);
 assert.throws(() => instantiate({ generic: c.generic }, 'default', { extensionFactor: 8 }), /Extension factor/);
 assert.throws(() => instantiate({ generic: Object.assign({}, c.generic, { modulus: '97' }) }, 'default', {}), /field of/);
@@ -116,7 +116,7 @@ const bad = JSON.parse(JSON.stringify(c.generic)); bad.transition.code[0] = 77;
 assert.throws(() => instantiate({ generic: bad }, 'default', {}), /unknown opcode/);
 const air = instantiate({ generic: c.generic }, 'default', {});
 assert.throws(() => air.initProvingContext([], [1n, 2n]), /seed values/);
-assert.throws(() => air.initProvingContext([[1n]], [1n, 2n, 3n, 4n]), /no input registers/);
+assert.throws(() => air.initProvingContext([[1n]], [1n, 2n, 3n, 4n]), /has 0 secret input registers/);
 console.log('descriptor checks OK');
 """)
     cj = tmp_path / 'case.json'
