@@ -2,8 +2,8 @@
 //
 // One rank per process and GPU.  The collectives of a distributed proof (csrc/prover_dist.h) are issued on the HIP stream of the
 // gs_ctx they concern (gs_stream), on device buffers the library owns: ncclAllGather for sub-roots, small layers, the remainder and
-// the packed query answers; a grouped ncclSend / ncclRecv exchange for the re-sharding of leaf digests (every pair of ranks talks over
-// its own xGMI link: no ring).  Nothing is staged through the host, and no call blocks it; a HIP event pair around every
+// the packed query answers; ncclAllToAll (RCCL's pairwise exchange; fallback: grouped ncclSend / ncclRecv) for the re-sharding of leaf
+// digests and trace columns (every pair of ranks talks over its own xGMI link: no ring).  Nothing is staged through the host, and no call blocks it; a HIP event pair around every
 // collective gives its device time (take_timings).  The unique id is made on rank 0 (gs_rccl_unique_id) and handed to
 // gs_rccl_comm_create on every rank by the launcher.
 #include <dlfcn.h>
@@ -23,6 +23,7 @@ struct RcclState {
     int rank = 0, size = 1, device = 0;
     void *(*stream_of)(gs_ctx *) = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, spare;
+    bool no_alltoall = false;     // ncclAllToAll was refused once: grouped ncclSend / ncclRecv from then on
     bool timings = true;          // an event pair around every collective (gs_rccl_comm_timings): each record costs the stream a few us
     char err[256] = {0};
 };
@@ -51,6 +52,13 @@ int r_all_to_all(void *self, gs_ctx *ctx, const void *send, void *recv, uint64_t
     RcclState *s = (RcclState *)self;
     hipStream_t st = (hipStream_t)s->stream_of(ctx);
     if (!begin(s, st)) return GS_ERR_DEVICE;
+    // RCCL's own all-to-all (an extension over NCCL: piece j of rank i's buffer becomes piece i of rank j's — exactly this layout; it is what
+    // torch.distributed's all_to_all_single runs on ROCm, i.e. the exercised path).  The grouped send / recv form below (which includes the
+    // pair a rank forms with itself) stays as the fallback if the call is refused.
+    if (!s->no_alltoall) {
+        if (ncclAllToAll(send, recv, bytes, ncclUint8, s->comm, st) == ncclSuccess) return end(s, st) ? GS_OK : GS_ERR_DEVICE;
+        s->no_alltoall = true;
+    }
     bool ok = ncclGroupStart() == ncclSuccess;
     for (int h = 0; h < s->size && ok; h++) {
         ok = ncclSend((const uint8_t *)send + (uint64_t)h * bytes, bytes, ncclUint8, h, s->comm, st) == ncclSuccess &&
