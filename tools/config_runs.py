@@ -25,6 +25,15 @@ CONFIGS = {   # name -> (what BASELINE.json calls it, timed proofs)
 }
 
 
+NOTES = {
+    'C3': 'measures a dependency chain, not the GPU: half of the device time is gs_jit_trace — 2 048 independent Rescue chains (x 4 registers on a 65 536-lane chip), '
+          'each step an inverse S-box of 128 dependent squarings + 13 products at the floor of one product per 0.16 us (tools/microbench5: lz_sqr chain); more lanes do not shorten it',
+    'C1_foo': 'plumbing check (64 steps, no FRI layer): every kernel is a launch latency',
+    'C2_E8': 'latency-bound: 16 dependent launches for 2^16 points; k_fri_layers (a chain of dependent BLAKE2s compressions per layer) is the largest share',
+    'C5': 'the headline: 70 % of prove_ms is the serial x^3 + k recurrence on one host core (gs_mimc_trace); the device side is 3.3 ms in 35 launches',
+}
+
+
 def child(name, reps):
     from genstark_amd._abi import MODULUS_32, Backend
     from genstark_amd.field import PrimeField
@@ -175,6 +184,8 @@ def parent(names, rocprof=True):
     for name in names:
         what, reps = CONFIGS[name]
         rec = {'name': name, 'config': what}
+        if name in NOTES:
+            rec['note'] = NOTES[name]
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), '--child', name, str(reps)], capture_output=True, text=True, timeout=180, env=env)
             rec.update(json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1]))
