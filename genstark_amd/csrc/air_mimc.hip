@@ -54,26 +54,27 @@ __global__ void k_mimc_composition(const fe *__restrict__ p, uint64_t n, uint64_
 // The MiMC recurrence x <- x^3 + k is a serial dependency chain (examples/mimc/utils.ts:7-15): like
 // the reference (generated JS over one input) it runs on one host core, here on native 64-bit limbs
 // (host_field.h), written straight into a pinned staging buffer that is then copied to the device.
-// One chunk of the chain.  The same source twice: for any x86-64, and for cores with BMI2 / AVX2 scheduled for Zen 5 (what MI355X hosts
-// are: EPYC 9005) — 2 % on the chain there (tools/trace_bench.cpp, profiles/r04_k_*); picked at run time, never assumed.
-#define GS_MIMC_CHUNK_BODY                                                                                      \
+// One chunk of the chain.  Two forms of the same step: the portable one (128-bit temporaries) for any x86-64 / any host, and for cores with
+// BMI2 — what MI355X hosts are: EPYC 9005 — the one with mulx products and the carry chains written out by rows, scheduled for Zen 5: 9 % on
+// the chain there (tools/trace_bench.cpp, profiles/r05_c_*); picked at run time, never assumed.
+#define GS_MIMC_CHUNK_BODY(STEP)                                                                                \
     for (uint64_t i = base; i < end; i++) {                                                                    \
         t[i] = hf_mimc_out(x);                /* the canonical value, beside the chain */                      \
-        x = hf_mimc_step_weak(x, rc[ri]);     /* the chain itself stays weak (host_field.h) */                 \
+        x = STEP(x, rc[ri]);                  /* the chain itself stays weak (host_field.h) */                 \
         if (++ri == nrc) ri = 0;                                                                               \
     }                                                                                                          \
     *ri_io = ri;                                                                                               \
     return x;
 static hfe mimc_chunk_generic(hfe *t, hfe x, const hfe *rc, uint32_t nrc, uint32_t *ri_io, uint64_t base, uint64_t end) {
     uint32_t ri = *ri_io;
-    GS_MIMC_CHUNK_BODY
+    GS_MIMC_CHUNK_BODY(hf_mimc_step_weak)
 }
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__) && !defined(GS_SMALL_Q) && !defined(GS_WIDE_BITS)
 #define GS_MIMC_CHUNK_V3 1
 __attribute__((target("arch=x86-64-v3,tune=znver5"))) static hfe mimc_chunk_v3(hfe *t, hfe x, const hfe *rc, uint32_t nrc, uint32_t *ri_io, uint64_t base,
                                                                                uint64_t end) {
     uint32_t ri = *ri_io;
-    GS_MIMC_CHUNK_BODY
+    GS_MIMC_CHUNK_BODY(hf_cube_add_rows)      // mulx + adc chains by rows (host_field.h): 7.3 instead of 8.0 ms per 2^20 steps on the EPYC 9575F
 }
 #endif
 extern "C" {

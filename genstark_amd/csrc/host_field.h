@@ -169,6 +169,70 @@ __attribute__((always_inline)) static inline hfe hf_cube_add_weak(hfe x, hfe k) 
     if (__builtin_expect(r < R, 0)) r += HF_C;
     return r;
 }
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+// The same step with the carry chains written out (round 5): mulx products, the 256-bit square and the 384-bit cube summed ROW by row as
+// adc chains instead of the column sums over 128-bit temporaries above — the same algorithm and the same values (any 128-bit
+// representative in, one out), but the compiler turns the 128-bit form into setc / movzx / add-adc pairs on the dependency chain, and the
+// chain is all there is: 7.3 ms instead of 8.0 ms per 2^20 steps on the GPU box's EPYC 9575F (tools/trace_bench.cpp,
+// profiles/r05_c_*; no difference on the build container's Xeon).  Needs BMI2: used by the chain's build for such cores only.
+__attribute__((always_inline, target("bmi2"))) static inline hfe hf_cube_add_rows(hfe x, hfe k) {
+    typedef unsigned long long u64;
+    const u64 C = (u64)HF_C, C20 = 0xFFFFFFEE00000001ull, C21 = 80;   // C^2 = 81*2^64 - 18*2^32 + 1 = C21*2^64 + C20
+    const u64 x0 = (u64)x, x1 = (u64)(x >> 64), k0 = (u64)k, k1 = (u64)(k >> 64);
+    u64 a0, a1, b0, b1, c0, c1;
+    a0 = _mulx_u64(x0, x0, &a1);
+    b0 = _mulx_u64(x0, x1, &b1);
+    c0 = _mulx_u64(x1, x1, &c1);
+    u64 d0, d1, d2, s1, s2, s3;
+    unsigned char cy;
+    cy = _addcarry_u64(0, b0, b0, &d0);                   // d = 2 b (129 bits)
+    cy = _addcarry_u64(cy, b1, b1, &d1);
+    d2 = cy;
+    cy = _addcarry_u64(0, a1, d0, &s1);                   // s = x^2 = a + d 2^64 + c 2^128
+    cy = _addcarry_u64(cy, c0, d1, &s2);
+    (void)_addcarry_u64(cy, c1, d2, &s3);                 // (x^2 < 2^256: no carry out)
+    const u64 s0 = a0;
+    u64 p0l, p0h, p1l, p1h, p2l, p2h, p3l, p3h, q0l, q0h, q1l, q1h, q2l, q2h, q3l, q3h;
+    p0l = _mulx_u64(s0, x0, &p0h); q0l = _mulx_u64(s0, x1, &q0h);
+    p1l = _mulx_u64(s1, x0, &p1h); q1l = _mulx_u64(s1, x1, &q1h);
+    p2l = _mulx_u64(s2, x0, &p2h); q2l = _mulx_u64(s2, x1, &q2h);
+    p3l = _mulx_u64(s3, x0, &p3h); q3l = _mulx_u64(s3, x1, &q3h);
+    u64 r1, r2, r3, r4, t2, t3, t4, t5;
+    cy = _addcarry_u64(0, p0h, p1l, &r1);                 // row 0: s * x0 = (r4 r3 r2 r1 p0l)
+    cy = _addcarry_u64(cy, p1h, p2l, &r2);
+    cy = _addcarry_u64(cy, p2h, p3l, &r3);
+    (void)_addcarry_u64(cy, p3h, 0, &r4);
+    cy = _addcarry_u64(0, q0h, q1l, &t2);                 // row 1: s * x1 = (t5 t4 t3 t2 q0l), one limb up
+    cy = _addcarry_u64(cy, q1h, q2l, &t3);
+    cy = _addcarry_u64(cy, q2h, q3l, &t4);
+    (void)_addcarry_u64(cy, q3h, 0, &t5);
+    u64 y1, y2, y3, y4, y5;
+    const u64 y0 = p0l;
+    cy = _addcarry_u64(0, r1, q0l, &y1);                  // x^3 = (y5 .. y0)
+    cy = _addcarry_u64(cy, r2, t2, &y2);
+    cy = _addcarry_u64(cy, r3, t3, &y3);
+    cy = _addcarry_u64(cy, r4, t4, &y4);
+    (void)_addcarry_u64(cy, t5, 0, &y5);
+    u64 Al, Ah, Bl, Bh, Dl, Dh, El, Eh, Gl, Gh, Hl, Hh;
+    Al = _mulx_u64(y2, C, &Ah); Bl = _mulx_u64(y3, C, &Bh);
+    Dl = _mulx_u64(y4, C20, &Dh); El = _mulx_u64(y4, C21, &Eh);
+    Gl = _mulx_u64(y5, C20, &Gh); Hl = _mulx_u64(y5, C21, &Hh);
+    // the fold of hf_cube_add_weak, the terms that arrive last added last
+    const hfe e0 = (hfe)y0 + k0 + Al, e1 = (hfe)y1 + k1 + Ah + Bl;
+    const hfe a0s = e0 + Dl;
+    const hfe a1s = e1 + Dh + El + (u64)(a0s >> 64) + Gl;
+    const hfe T = ((hfe)Bh + Eh) + (Gh + (((hfe)Hh << 64) | Hl)) + (u64)(a1s >> 64);          // < 2^73
+    const hfe R = ((hfe)(u64)a1s << 64) | (u64)a0s;
+    u64 Tl, Th;
+    Tl = _mulx_u64((u64)T, C, &Th);
+    const hfe TC = (((hfe)Th << 64) | Tl) + (((hfe)((u64)(T >> 64) * C)) << 64);
+    hfe r = R + TC;
+    if (__builtin_expect(r < R, 0)) r += HF_C;
+    return r;
+}
+#define HF_HAVE_CUBE_ADD_ROWS 1
+#endif
 __attribute__((always_inline)) static inline hfe hf_mimc_step_weak(hfe xw, hfe k) { return hf_cube_add_weak(xw, k); }
 __attribute__((always_inline)) static inline hfe hf_mimc_out(hfe xw) { return xw >= hf_p() ? xw - hf_p() : xw; }      // a weak value is below 2^128 < 2p
 // one step of the MiMC recurrence x <- x^3 + k (examples/mimc/utils.ts:7-15) on the weak cube

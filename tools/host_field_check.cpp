@@ -31,6 +31,10 @@ static void show(hfe x) {
     hf_store(b, x);
     for (int i = GS_ELT - 1; i >= 0; i--) printf("%02x", b[i]);
 }
+#if defined(HF_HAVE_CUBE_ADD_ROWS)
+// (the row form is compiled for BMI2 cores: it inlines only into a caller built for them, like the chain's own build in air_mimc.hip)
+__attribute__((target("bmi2"), noinline)) static hfe rows_step(hfe x, hfe k) { return hf_cube_add_rows(x, k); }
+#endif
 int main() {
     static char a[80], b[80], e[80];
     while (scanf("%64s %64s %64s", a, b, e) == 3) {
@@ -42,6 +46,15 @@ int main() {
         show(g[1]); printf(" ");
         show(hf_mimc_out(hf_mimc_step_weak(hf_mimc_step_weak(x, y), y))); printf(" ");
 #if !defined(GS_WIDE_BITS) && !defined(GS_SMALL_Q)
+#if defined(HF_HAVE_CUBE_ADD_ROWS)
+        // the row form of the step (BMI2 cores: what gs_mimc_trace runs on the GPU box's host) must agree with the portable one
+        if (__builtin_cpu_supports("bmi2")) {
+            const hfe m = rows_step(rows_step(~x, y), y), w = hf_mimc_step_weak(hf_mimc_step_weak(~x, y), y);
+            if (hf_mimc_out(m) != hf_mimc_out(w) || hf_mimc_out(rows_step(x, y)) != hf_mimc_out(hf_mimc_step_weak(x, y))) { printf("ROW FORM DIFFERS\n"); continue; }
+            show(hf_mimc_out(m)); printf("\n");
+            continue;
+        }
+#endif
         show(hf_mimc_out(hf_mimc_step_weak(hf_mimc_step_weak(~x, y), y))); printf("\n");
 #else
         show(hf_mimc_out(hf_mimc_step_weak(hf_mimc_step_weak(x, y), y))); printf("\n");

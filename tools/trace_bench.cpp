@@ -223,6 +223,166 @@ IFMA_TARGET static double run_ifma(uint64_t steps, const std::vector<hfe> &rc, h
 }
 #endif
 
+// ---- experiment (round 5): the product's step with the carry chains written out (mulx + adc/adcx chains by rows instead of the compiler's
+// column sums over 128-bit temporaries): same algorithm, same values
+#if defined(__x86_64__)
+__attribute__((target("bmi2,adx"))) static inline hfe hf_cube_add_rows(hfe x, hfe k) {
+    typedef unsigned long long u64;
+    const u64 C = (u64)HF_C, C20 = 0xFFFFFFEE00000001ull, C21 = 80;
+    const u64 x0 = (u64)x, x1 = (u64)(x >> 64), k0 = (u64)k, k1 = (u64)(k >> 64);
+    u64 a0, a1, b0, b1, c0, c1;
+    a0 = _mulx_u64(x0, x0, &a1);
+    b0 = _mulx_u64(x0, x1, &b1);
+    c0 = _mulx_u64(x1, x1, &c1);
+    u64 d0, d1, d2, s1, s2, s3;
+    unsigned char cy;
+    cy = _addcarry_u64(0, b0, b0, &d0);
+    cy = _addcarry_u64(cy, b1, b1, &d1);
+    d2 = cy;
+    cy = _addcarry_u64(0, a1, d0, &s1);
+    cy = _addcarry_u64(cy, c0, d1, &s2);
+    (void)_addcarry_u64(cy, c1, d2, &s3);
+    const u64 s0 = a0;
+    u64 p0l, p0h, p1l, p1h, p2l, p2h, p3l, p3h, q0l, q0h, q1l, q1h, q2l, q2h, q3l, q3h;
+    p0l = _mulx_u64(s0, x0, &p0h); q0l = _mulx_u64(s0, x1, &q0h);
+    p1l = _mulx_u64(s1, x0, &p1h); q1l = _mulx_u64(s1, x1, &q1h);
+    p2l = _mulx_u64(s2, x0, &p2h); q2l = _mulx_u64(s2, x1, &q2h);
+    p3l = _mulx_u64(s3, x0, &p3h); q3l = _mulx_u64(s3, x1, &q3h);
+    u64 r1, r2, r3, r4, t2, t3, t4, t5;
+    cy = _addcarry_u64(0, p0h, p1l, &r1);
+    cy = _addcarry_u64(cy, p1h, p2l, &r2);
+    cy = _addcarry_u64(cy, p2h, p3l, &r3);
+    (void)_addcarry_u64(cy, p3h, 0, &r4);
+    cy = _addcarry_u64(0, q0h, q1l, &t2);
+    cy = _addcarry_u64(cy, q1h, q2l, &t3);
+    cy = _addcarry_u64(cy, q2h, q3l, &t4);
+    (void)_addcarry_u64(cy, q3h, 0, &t5);
+    u64 y1, y2, y3, y4, y5;
+    const u64 y0 = p0l;
+    cy = _addcarry_u64(0, r1, q0l, &y1);
+    cy = _addcarry_u64(cy, r2, t2, &y2);
+    cy = _addcarry_u64(cy, r3, t3, &y3);
+    cy = _addcarry_u64(cy, r4, t4, &y4);
+    (void)_addcarry_u64(cy, t5, 0, &y5);
+    u64 Al, Ah, Bl, Bh, Dl, Dh, El, Eh, Gl, Gh, Hl, Hh;
+    Al = _mulx_u64(y2, C, &Ah); Bl = _mulx_u64(y3, C, &Bh);
+    Dl = _mulx_u64(y4, C20, &Dh); El = _mulx_u64(y4, C21, &Eh);
+    Gl = _mulx_u64(y5, C20, &Gh); Hl = _mulx_u64(y5, C21, &Hh);
+    hfe a0s = (hfe)y0 + k0 + Al + Dl;
+    hfe a1s = (hfe)y1 + k1 + Ah + Dh + Bl + El + Gl + (u64)(a0s >> 64);
+    hfe T = (hfe)Bh + Eh + Gh + (((hfe)Hh << 64) | Hl) + (u64)(a1s >> 64);
+    hfe R = ((hfe)(u64)a1s << 64) | (u64)a0s;
+    u64 Tl, Th;
+    Tl = _mulx_u64((u64)T, C, &Th);
+    hfe TC = (((hfe)Th << 64) | Tl) + (((hfe)((u64)(T >> 64) * C)) << 64);
+    hfe r = R + TC;
+    if (__builtin_expect(r < R, 0)) r += HF_C;
+    return r;
+}
+// the same, and the fold's sums written so that what arrives LAST is added last: the terms that wait for y4 after the ones that do not, the
+// terms that wait for y5 (the end of the carry chain) after those; FOLD = 1: additionally the part of T that does not wait for y5 is
+// multiplied by C beside the rest (T = Te + Tl, T C = Te C + Tl C: the second product starts from y5's terms alone)
+template <int FOLD>
+__attribute__((target("bmi2"))) static inline hfe hf_cube_add_rows2(hfe x, hfe k) {
+    typedef unsigned long long u64;
+    const u64 C = (u64)HF_C, C20 = 0xFFFFFFEE00000001ull, C21 = 80;
+    const u64 x0 = (u64)x, x1 = (u64)(x >> 64), k0 = (u64)k, k1 = (u64)(k >> 64);
+    u64 a0, a1, b0, b1, c0, c1;
+    a0 = _mulx_u64(x0, x0, &a1);
+    b0 = _mulx_u64(x0, x1, &b1);
+    c0 = _mulx_u64(x1, x1, &c1);
+    u64 d0, d1, d2, s1, s2, s3;
+    unsigned char cy;
+    cy = _addcarry_u64(0, b0, b0, &d0);
+    cy = _addcarry_u64(cy, b1, b1, &d1);
+    d2 = cy;
+    cy = _addcarry_u64(0, a1, d0, &s1);
+    cy = _addcarry_u64(cy, c0, d1, &s2);
+    (void)_addcarry_u64(cy, c1, d2, &s3);
+    const u64 s0 = a0;
+    u64 p0l, p0h, p1l, p1h, p2l, p2h, p3l, p3h, q0l, q0h, q1l, q1h, q2l, q2h, q3l, q3h;
+    p0l = _mulx_u64(s0, x0, &p0h); q0l = _mulx_u64(s0, x1, &q0h);
+    p1l = _mulx_u64(s1, x0, &p1h); q1l = _mulx_u64(s1, x1, &q1h);
+    p2l = _mulx_u64(s2, x0, &p2h); q2l = _mulx_u64(s2, x1, &q2h);
+    p3l = _mulx_u64(s3, x0, &p3h); q3l = _mulx_u64(s3, x1, &q3h);
+    u64 r1, r2, r3, r4, t2, t3, t4, t5;
+    cy = _addcarry_u64(0, p0h, p1l, &r1);
+    cy = _addcarry_u64(cy, p1h, p2l, &r2);
+    cy = _addcarry_u64(cy, p2h, p3l, &r3);
+    (void)_addcarry_u64(cy, p3h, 0, &r4);
+    cy = _addcarry_u64(0, q0h, q1l, &t2);
+    cy = _addcarry_u64(cy, q1h, q2l, &t3);
+    cy = _addcarry_u64(cy, q2h, q3l, &t4);
+    (void)_addcarry_u64(cy, q3h, 0, &t5);
+    u64 y1, y2, y3, y4, y5;
+    const u64 y0 = p0l;
+    cy = _addcarry_u64(0, r1, q0l, &y1);
+    cy = _addcarry_u64(cy, r2, t2, &y2);
+    cy = _addcarry_u64(cy, r3, t3, &y3);
+    cy = _addcarry_u64(cy, r4, t4, &y4);
+    (void)_addcarry_u64(cy, t5, 0, &y5);
+    u64 Al, Ah, Bl, Bh, Dl, Dh, El, Eh, Gl, Gh, Hl, Hh;
+    Al = _mulx_u64(y2, C, &Ah); Bl = _mulx_u64(y3, C, &Bh);
+    Dl = _mulx_u64(y4, C20, &Dh); El = _mulx_u64(y4, C21, &Eh);
+    Gl = _mulx_u64(y5, C20, &Gh); Hl = _mulx_u64(y5, C21, &Hh);
+    // column 0: y0 + k0 + Al | + Dl           column 1: y1 + k1 + Ah + Bl | + Dh + El | + Gl          column 2..: Bh | + Eh | + Gh + H
+    const hfe e0 = (hfe)y0 + k0 + Al;
+    const hfe e1 = (hfe)y1 + k1 + Ah + Bl;
+    const hfe a0s = e0 + Dl;
+    const hfe m1 = e1 + Dh + El + (u64)(a0s >> 64);
+    const hfe a1s = m1 + Gl;
+    const hfe R = ((hfe)(u64)a1s << 64) | (u64)a0s;
+    hfe r;
+    if (FOLD == 0) {
+        const hfe T = ((hfe)Bh + Eh) + (Gh + (((hfe)Hh << 64) | Hl)) + (u64)(a1s >> 64);
+        u64 Tl, Th;
+        Tl = _mulx_u64((u64)T, C, &Th);
+        const hfe TC = (((hfe)Th << 64) | Tl) + (((hfe)((u64)(T >> 64) * C)) << 64);
+        r = R + TC;
+    } else {
+        const hfe Te = (hfe)Bh + Eh + (u64)(m1 >> 64);                              // < 2^66: everything that does not wait for y5
+        const hfe Tl_ = (hfe)Gh + (((hfe)Hh << 64) | Hl) + (u64)(a1s >> 64) - (u64)(m1 >> 64);   // y5's terms + the carry Gl caused (0 or 1 more than m1's)
+        u64 el, eh, ll, lh;
+        el = _mulx_u64((u64)Te, C, &eh);
+        ll = _mulx_u64((u64)Tl_, C, &lh);
+        const hfe TeC = (((hfe)eh << 64) | el) + (((hfe)((u64)(Te >> 64) * C)) << 64);
+        const hfe TlC = (((hfe)lh << 64) | ll) + (((hfe)((u64)(Tl_ >> 64) * C)) << 64);
+        const hfe r1_ = R + TeC;                                                       // Te C < 2^102, Tl C < 2^110: at most one wrap in total (checked below)
+        r = r1_ + TlC;
+        if (__builtin_expect(r1_ < R, 0)) r += HF_C;
+        if (__builtin_expect(r < TlC, 0)) r += HF_C;
+        return r;
+    }
+    if (__builtin_expect(r < R, 0)) r += HF_C;
+    return r;
+}
+template <int FOLD>
+__attribute__((target("bmi2"))) static double run_rows2(uint64_t steps, const std::vector<hfe> &rc, hfe seed, std::vector<hfe> &t) {
+    auto t0 = std::chrono::steady_clock::now();
+    hfe x = seed;
+    uint32_t ri = 0, nrc = (uint32_t)rc.size();
+    for (uint64_t i = 0; i < steps; i++) {
+        t[i] = hf_mimc_out(x);
+        x = hf_cube_add_rows2<FOLD>(x, rc[ri]);
+        if (++ri == nrc) ri = 0;
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(t1 - t0).count();
+}
+__attribute__((target("bmi2,adx"))) static double run_rows(uint64_t steps, const std::vector<hfe> &rc, hfe seed, std::vector<hfe> &t) {
+    auto t0 = std::chrono::steady_clock::now();
+    hfe x = seed;
+    uint32_t ri = 0, nrc = (uint32_t)rc.size();
+    for (uint64_t i = 0; i < steps; i++) {
+        t[i] = hf_mimc_out(x);
+        x = hf_cube_add_rows(x, rc[ri]);
+        if (++ri == nrc) ri = 0;
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(t1 - t0).count();
+}
+#endif
+
 template <int V>
 static double run(uint64_t steps, const std::vector<hfe> &rc, hfe seed, std::vector<hfe> &t) {
     auto t0 = std::chrono::steady_clock::now();
@@ -273,6 +433,15 @@ int main() {
         for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
         printf("2^20 steps: cube + k in one fold, weak chain %.2f ms | + second fold started early %.2f ms | y5 in two pieces %.2f ms | doubled limb %.2f ms\n", g8, g24, g40, g72);
 #if defined(__x86_64__)
+        if (__builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx")) {
+            double gr = run_rows(steps, rc, seed, t2);
+            for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
+            double g2 = run_rows2<0>(steps, rc, seed, t2);
+            for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
+            double g3 = run_rows2<1>(steps, rc, seed, t2);
+            for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
+            printf("2^20 steps: carry chains by rows (mulx + adc) %.2f ms | + fold sums ordered by arrival %.2f ms | + second fold split early / late %.2f ms\n", gr, g2, g3);
+        }
         if (__builtin_cpu_supports("avx512ifma")) {
             double gi = run_ifma(steps, rc, seed, t2);
             for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
