@@ -223,62 +223,9 @@ IFMA_TARGET static double run_ifma(uint64_t steps, const std::vector<hfe> &rc, h
 }
 #endif
 
-// ---- experiment (round 5): the product's step with the carry chains written out (mulx + adc/adcx chains by rows instead of the compiler's
-// column sums over 128-bit temporaries): same algorithm, same values
+// ---- round 5: the chain's step with the carry chains written out by rows is hf_cube_add_rows of host_field.h (adopted for BMI2 cores);
+// the variants below start from it
 #if defined(__x86_64__)
-__attribute__((target("bmi2,adx"))) static inline hfe hf_cube_add_rows(hfe x, hfe k) {
-    typedef unsigned long long u64;
-    const u64 C = (u64)HF_C, C20 = 0xFFFFFFEE00000001ull, C21 = 80;
-    const u64 x0 = (u64)x, x1 = (u64)(x >> 64), k0 = (u64)k, k1 = (u64)(k >> 64);
-    u64 a0, a1, b0, b1, c0, c1;
-    a0 = _mulx_u64(x0, x0, &a1);
-    b0 = _mulx_u64(x0, x1, &b1);
-    c0 = _mulx_u64(x1, x1, &c1);
-    u64 d0, d1, d2, s1, s2, s3;
-    unsigned char cy;
-    cy = _addcarry_u64(0, b0, b0, &d0);
-    cy = _addcarry_u64(cy, b1, b1, &d1);
-    d2 = cy;
-    cy = _addcarry_u64(0, a1, d0, &s1);
-    cy = _addcarry_u64(cy, c0, d1, &s2);
-    (void)_addcarry_u64(cy, c1, d2, &s3);
-    const u64 s0 = a0;
-    u64 p0l, p0h, p1l, p1h, p2l, p2h, p3l, p3h, q0l, q0h, q1l, q1h, q2l, q2h, q3l, q3h;
-    p0l = _mulx_u64(s0, x0, &p0h); q0l = _mulx_u64(s0, x1, &q0h);
-    p1l = _mulx_u64(s1, x0, &p1h); q1l = _mulx_u64(s1, x1, &q1h);
-    p2l = _mulx_u64(s2, x0, &p2h); q2l = _mulx_u64(s2, x1, &q2h);
-    p3l = _mulx_u64(s3, x0, &p3h); q3l = _mulx_u64(s3, x1, &q3h);
-    u64 r1, r2, r3, r4, t2, t3, t4, t5;
-    cy = _addcarry_u64(0, p0h, p1l, &r1);
-    cy = _addcarry_u64(cy, p1h, p2l, &r2);
-    cy = _addcarry_u64(cy, p2h, p3l, &r3);
-    (void)_addcarry_u64(cy, p3h, 0, &r4);
-    cy = _addcarry_u64(0, q0h, q1l, &t2);
-    cy = _addcarry_u64(cy, q1h, q2l, &t3);
-    cy = _addcarry_u64(cy, q2h, q3l, &t4);
-    (void)_addcarry_u64(cy, q3h, 0, &t5);
-    u64 y1, y2, y3, y4, y5;
-    const u64 y0 = p0l;
-    cy = _addcarry_u64(0, r1, q0l, &y1);
-    cy = _addcarry_u64(cy, r2, t2, &y2);
-    cy = _addcarry_u64(cy, r3, t3, &y3);
-    cy = _addcarry_u64(cy, r4, t4, &y4);
-    (void)_addcarry_u64(cy, t5, 0, &y5);
-    u64 Al, Ah, Bl, Bh, Dl, Dh, El, Eh, Gl, Gh, Hl, Hh;
-    Al = _mulx_u64(y2, C, &Ah); Bl = _mulx_u64(y3, C, &Bh);
-    Dl = _mulx_u64(y4, C20, &Dh); El = _mulx_u64(y4, C21, &Eh);
-    Gl = _mulx_u64(y5, C20, &Gh); Hl = _mulx_u64(y5, C21, &Hh);
-    hfe a0s = (hfe)y0 + k0 + Al + Dl;
-    hfe a1s = (hfe)y1 + k1 + Ah + Dh + Bl + El + Gl + (u64)(a0s >> 64);
-    hfe T = (hfe)Bh + Eh + Gh + (((hfe)Hh << 64) | Hl) + (u64)(a1s >> 64);
-    hfe R = ((hfe)(u64)a1s << 64) | (u64)a0s;
-    u64 Tl, Th;
-    Tl = _mulx_u64((u64)T, C, &Th);
-    hfe TC = (((hfe)Th << 64) | Tl) + (((hfe)((u64)(T >> 64) * C)) << 64);
-    hfe r = R + TC;
-    if (__builtin_expect(r < R, 0)) r += HF_C;
-    return r;
-}
 // the same, and the fold's sums written so that what arrives LAST is added last: the terms that wait for y4 after the ones that do not, the
 // terms that wait for y5 (the end of the carry chain) after those; FOLD = 1: additionally the part of T that does not wait for y5 is
 // multiplied by C beside the rest (T = Te + Tl, T C = Te C + Tl C: the second product starts from y5's terms alone)
@@ -355,6 +302,99 @@ __attribute__((target("bmi2"))) static inline hfe hf_cube_add_rows2(hfe x, hfe k
     }
     if (__builtin_expect(r < R, 0)) r += HF_C;
     return r;
+}
+// the multiplier port is on the critical path (19 mulx + 1 imul per step, one issued per cycle): SH80 = the two products by 80 (the high
+// limb of C^2) as shifts and adds; FINAL = the small product T1 * C joins the limb it lands on before the last product arrives; SHC = the
+// two products by C = 2^35 + 2^32 - 1 of the first fold as shifts and adds too
+template <int SH80, int FINAL, int SHC>
+__attribute__((target("bmi2"))) static inline hfe hf_cube_add_rows3(hfe x, hfe k) {
+    typedef unsigned long long u64;
+    const u64 C = (u64)HF_C, C20 = 0xFFFFFFEE00000001ull, C21 = 80;
+    const u64 x0 = (u64)x, x1 = (u64)(x >> 64), k0 = (u64)k, k1 = (u64)(k >> 64);
+    u64 a0, a1, b0, b1, c0, c1;
+    a0 = _mulx_u64(x0, x0, &a1);
+    b0 = _mulx_u64(x0, x1, &b1);
+    c0 = _mulx_u64(x1, x1, &c1);
+    u64 d0, d1, d2, s1, s2, s3;
+    unsigned char cy;
+    cy = _addcarry_u64(0, b0, b0, &d0);
+    cy = _addcarry_u64(cy, b1, b1, &d1);
+    d2 = cy;
+    cy = _addcarry_u64(0, a1, d0, &s1);
+    cy = _addcarry_u64(cy, c0, d1, &s2);
+    (void)_addcarry_u64(cy, c1, d2, &s3);
+    const u64 s0 = a0;
+    u64 p0l, p0h, p1l, p1h, p2l, p2h, p3l, p3h, q0l, q0h, q1l, q1h, q2l, q2h, q3l, q3h;
+    p0l = _mulx_u64(s0, x0, &p0h); q0l = _mulx_u64(s0, x1, &q0h);
+    p1l = _mulx_u64(s1, x0, &p1h); q1l = _mulx_u64(s1, x1, &q1h);
+    p2l = _mulx_u64(s2, x0, &p2h); q2l = _mulx_u64(s2, x1, &q2h);
+    p3l = _mulx_u64(s3, x0, &p3h); q3l = _mulx_u64(s3, x1, &q3h);
+    u64 r1, r2, r3, r4, t2, t3, t4, t5;
+    cy = _addcarry_u64(0, p0h, p1l, &r1);
+    cy = _addcarry_u64(cy, p1h, p2l, &r2);
+    cy = _addcarry_u64(cy, p2h, p3l, &r3);
+    (void)_addcarry_u64(cy, p3h, 0, &r4);
+    cy = _addcarry_u64(0, q0h, q1l, &t2);
+    cy = _addcarry_u64(cy, q1h, q2l, &t3);
+    cy = _addcarry_u64(cy, q2h, q3l, &t4);
+    (void)_addcarry_u64(cy, q3h, 0, &t5);
+    u64 y1, y2, y3, y4, y5;
+    const u64 y0 = p0l;
+    cy = _addcarry_u64(0, r1, q0l, &y1);
+    cy = _addcarry_u64(cy, r2, t2, &y2);
+    cy = _addcarry_u64(cy, r3, t3, &y3);
+    cy = _addcarry_u64(cy, r4, t4, &y4);
+    (void)_addcarry_u64(cy, t5, 0, &y5);
+    u64 Al, Ah, Bl, Bh, Dl, Dh, El, Eh, Gl, Gh, Hl, Hh;
+    if (SHC) {
+        const hfe A = ((hfe)y2 << 35) + ((hfe)y2 << 32) - y2, B = ((hfe)y3 << 35) + ((hfe)y3 << 32) - y3;
+        Al = (u64)A; Ah = (u64)(A >> 64); Bl = (u64)B; Bh = (u64)(B >> 64);
+    } else {
+        Al = _mulx_u64(y2, C, &Ah); Bl = _mulx_u64(y3, C, &Bh);
+    }
+    Dl = _mulx_u64(y4, C20, &Dh);
+    Gl = _mulx_u64(y5, C20, &Gh);
+    if (SH80) {
+        const hfe E = ((hfe)y4 << 6) + ((hfe)y4 << 4), H = ((hfe)y5 << 6) + ((hfe)y5 << 4);
+        El = (u64)E; Eh = (u64)(E >> 64); Hl = (u64)H; Hh = (u64)(H >> 64);
+    } else {
+        El = _mulx_u64(y4, C21, &Eh); Hl = _mulx_u64(y5, C21, &Hh);
+    }
+    const hfe e0 = (hfe)y0 + k0 + Al, e1 = (hfe)y1 + k1 + Ah + Bl;
+    const hfe a0s = e0 + Dl;
+    const hfe a1s = e1 + Dh + El + (u64)(a0s >> 64) + Gl;
+    const hfe T = ((hfe)Bh + Eh) + (Gh + (((hfe)Hh << 64) | Hl)) + (u64)(a1s >> 64);
+    u64 Tl, Th;
+    Tl = _mulx_u64((u64)T, C, &Th);
+    if (FINAL) {
+        // r = (a1s_lo + T1 C + Th) 2^64 + (a0s_lo + Tl): the parts that do not wait for the last product are summed first
+        const u64 T1C = (u64)(T >> 64) * C;                        // T1 < 2^9: the product fits
+        u64 hi_early, lo, hi;
+        const unsigned char w1 = _addcarry_u64(0, (u64)a1s, T1C, &hi_early);
+        unsigned char c0_ = _addcarry_u64(0, (u64)a0s, Tl, &lo);
+        const unsigned char w2 = _addcarry_u64(c0_, hi_early, Th, &hi);
+        hfe r = ((hfe)hi << 64) | lo;
+        if (__builtin_expect(w1 | w2, 0)) r += HF_C;               // one wrap past 2^128 at most (R + T C < 2^128 + 2^110)
+        return r;
+    }
+    const hfe R = ((hfe)(u64)a1s << 64) | (u64)a0s;
+    const hfe TC = (((hfe)Th << 64) | Tl) + (((hfe)((u64)(T >> 64) * C)) << 64);
+    hfe r = R + TC;
+    if (__builtin_expect(r < R, 0)) r += HF_C;
+    return r;
+}
+template <int SH80, int FINAL, int SHC>
+__attribute__((target("bmi2"))) static double run_rows3(uint64_t steps, const std::vector<hfe> &rc, hfe seed, std::vector<hfe> &t) {
+    auto t0 = std::chrono::steady_clock::now();
+    hfe x = seed;
+    uint32_t ri = 0, nrc = (uint32_t)rc.size();
+    for (uint64_t i = 0; i < steps; i++) {
+        t[i] = hf_mimc_out(x);
+        x = hf_cube_add_rows3<SH80, FINAL, SHC>(x, rc[ri]);
+        if (++ri == nrc) ri = 0;
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(t1 - t0).count();
 }
 template <int FOLD>
 __attribute__((target("bmi2"))) static double run_rows2(uint64_t steps, const std::vector<hfe> &rc, hfe seed, std::vector<hfe> &t) {
@@ -441,6 +481,15 @@ int main() {
             double g3 = run_rows2<1>(steps, rc, seed, t2);
             for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
             printf("2^20 steps: carry chains by rows (mulx + adc) %.2f ms | + fold sums ordered by arrival %.2f ms | + second fold split early / late %.2f ms\n", gr, g2, g3);
+            double h1 = run_rows3<1, 0, 0>(steps, rc, seed, t2);
+            for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
+            double h2 = run_rows3<0, 1, 0>(steps, rc, seed, t2);
+            for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
+            double h3 = run_rows3<1, 1, 0>(steps, rc, seed, t2);
+            for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
+            double h4 = run_rows3<1, 1, 1>(steps, rc, seed, t2);
+            for (uint64_t i = 0; i < steps; i++) ok &= t0[i] == t2[i];
+            printf("2^20 steps: rows, x80 by shifts %.2f ms | rows, last sum reordered %.2f ms | both %.2f ms | both + xC by shifts %.2f ms\n", h1, h2, h3, h4);
         }
         if (__builtin_cpu_supports("avx512ifma")) {
             double gi = run_ifma(steps, rc, seed, t2);
