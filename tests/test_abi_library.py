@@ -175,3 +175,43 @@ def test_prover_library_exports_its_header():
         b = C.c_void_p()
         rc = drv.gs_prover_open(C.c_void_p(oracle._handle), C.byref(b))
         assert (rc == 0) == (modulus == P), (modulus, rc)
+
+
+def test_traffic_tally_is_a_no_op_on_the_oracle(oracle_backend):
+    """gs_traffic_enable / gs_traffic_read (include/gstark.h): a measurement aid of the HIP library; the checker launches no kernels."""
+    assert oracle_backend.traffic(True).traffic() == {}
+    oracle_backend.traffic(False)
+
+
+@pytest.mark.gpu
+def test_traffic_tally_counts_what_the_launches_had_to_move(hip_backend):
+    """While enabled, every launch of the hot path adds its algorithmic bytes and work units under its kernel's name (what bench.py joins
+    with a kernel trace into roofline.kernels): an NTT pass reads every element once and writes it once; a committed column costs its
+    bytes in, one digest per leaf and per node out, one compression each."""
+    import ctypes as C
+    from genstark_amd.field import PrimeField
+    be = hip_backend
+    f = PrimeField(backend=be)
+    n, rows = 1 << 16, 3
+    src, dst = f.newVector(rows * n), f.newVector(rows * n)
+    w = f.getRootOfUnity(n).to_bytes(16, 'little')
+    be.traffic(True)
+    be.call('gs_eval_polys_at_roots', C.c_void_p(src.ptr), rows, n, w, n, C.c_void_p(dst.ptr))
+    tally = be.traffic()
+    ntt = {k: v for k, v in tally.items() if k.startswith('k_ntt_')}
+    passes = sum(v['launches'] for v in ntt.values())
+    assert passes == 2 and sum(v['bytes'] for v in ntt.values()) == passes * rows * 2 * n * 16 and sum(v['units'] for v in ntt.values()) == passes * rows * n
+    be.traffic(True)                                           # a fresh tally
+    leaves, nodes = be.alloc(32 * n), be.alloc(32 * n)
+    cols = (C.c_void_p * 1)(src.ptr)
+    be.call('gs_merkle_commit_rows', 1, cols, 1, n, C.c_void_p(leaves), C.c_void_p(nodes))
+    be.sync()
+    tally = be.traffic()
+    be.traffic(False)
+    assert all('merkle' in k for k in tally) and tally
+    assert sum(v['units'] for v in tally.values()) == n + n - 1            # one compression per 16-byte leaf, one per node
+    assert sum(v['bytes'] for v in tally.values()) >= n * (16 + 32) + (n - 1) * 32
+    be.free(leaves); be.free(nodes)
+    assert be.traffic() == tally                                # reading does not clear; enable(1) does
+    assert be.traffic(True).traffic() == {}
+    be.traffic(False)
