@@ -54,6 +54,8 @@ class AssemblyAir {
         this.constraints = info.constraintDegrees.map(degree => ({ degree }));
         this._inner = info.inputRegisters ? null : this._build(ask(this._req('describe')).descriptor);
     }
+    /** the register-machine AIR of a component without input registers (what js/prover.js: proveGenericSerialized takes) */
+    get generic() { if (!this._inner) throw new Error('the component has input registers: its AIR is built when the inputs arrive'); return this._inner; }
     _req(op, more) { return Object.assign({ op, source: this.schema.source, component: this.component, extensionFactor: this._ef || null }, more || {}); }
     _build(desc) { return new GenericAir(desc, this.extensionFactor, this.field); }
     initProvingContext(inputs, seed) {

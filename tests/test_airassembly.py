@@ -346,3 +346,55 @@ def test_reference_example_script_runs_unmodified(oracle_backend, script, lib, e
     assert r.returncode == 0, r.stderr[-3000:]
     for line in expect:
         assert line in r.stdout, (line, r.stdout[-1500:])
+
+
+# ---- node: compile(source) -> the native driver through the addon (no reference code involved: runs on the GPU box as well) -------------
+NODE_COMPILE_JS = """
+const path = require('path'), fs = require('fs'), crypto = require('crypto');
+const repo = process.argv[2];
+const { compile, instantiate, AirSchema } = require(path.join(repo, 'js', 'shims', '@guildofweavers', 'air-assembly'));
+const { proveGenericSerialized, verifyGenericSerialized } = require(path.join(repo, 'js', 'prover.js'));
+const c = JSON.parse(fs.readFileSync(process.argv[3], 'utf8'));
+const schema = compile(Buffer.from(c.source));
+if (!(schema instanceof AirSchema)) throw new Error('compile() must return an AirSchema');
+const air = instantiate(schema, c.component, c.options);
+const assertions = c.assertions.map(a => ({ step: a.step, register: a.register, value: BigInt(a.value) }));
+const bytes = proveGenericSerialized(air.generic, c.options, assertions, c.seed.map(BigInt));
+if (verifyGenericSerialized(air.generic, c.options, assertions, bytes) !== true) throw new Error('native verifier refused the proof');
+let refused = false;
+try { compile('(module (field prime 97) (export x (registers 1)'); } catch (e) { refused = /AirAssembly/.test(e.message); }
+console.log(JSON.stringify({ size: bytes.length, sha256: crypto.createHash('sha256').update(bytes).digest('hex'), malformedRefused: refused }));
+"""
+
+
+def check_node_compile_to_native_driver(backend, lib, allow_double, tmp_path):
+    from shutil import which
+    if not which('node') or not os.path.exists(os.path.join(ROOT, 'napi', 'gstark_napi.node')):
+        pytest.skip('node / the addon is not available')
+    script, cj = tmp_path / 'compile.js', tmp_path / 'case.json'
+    script.write_text(NODE_COMPILE_JS)
+    for case in index_cases(backend)[:2]:
+        cj.write_text(json.dumps(case))
+        env = dict(os.environ, NODE_PATH=os.path.join(ROOT, 'js', 'shims'))
+        if lib:
+            env['GSTARK_LIB'] = lib
+        if allow_double:
+            env['GSTARK_ALLOW_TEST_DOUBLE'] = '1'
+        r = subprocess.run(['node', str(script), ROOT, str(cj)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        rec = INDEX_PROOFS[case['name']]
+        assert (out['size'], out['sha256']) == (rec['proofSize'], rec['proofSha256']) and out['malformedRefused'] is True, case['name']
+
+
+def test_node_compile_to_native_driver_on_oracle_double(oracle_backend, tmp_path):
+    """compile(source) of the air-assembly drop-in -> AirSchema -> instantiate -> ONE call of the native driver through the N-API addon:
+    the bytes the reference's bin/index.js produced for the same source (tests/golden/reference_index_proofs.json); a malformed module is
+    refused with the loader's message."""
+    subprocess.check_call(['bash', os.path.join(ROOT, 'napi', 'build.sh')])
+    check_node_compile_to_native_driver(oracle_backend, ORACLE_LIB, True, tmp_path)
+
+
+@pytest.mark.gpu
+def test_node_compile_to_native_driver_on_hip(hip_backend, tmp_path):
+    check_node_compile_to_native_driver(hip_backend, None, False, tmp_path)
