@@ -661,6 +661,8 @@ def main():
                     comm.comm.solo_below = 1
                     try:
                         ms_f, blob_f, same_f, colls_f, st_f = timed_dist(nat, a0, inputs, sd, comm, reps)
+                    except Exception as e:   # noqa: BLE001  (an extra: it must not take the statement's own record down)
+                        return {'error': repr(e)[:200]}
                     finally:
                         comm.comm.solo_below = 0
                     return {'ms_per_proof': round(ms_f, 3), 'same_bytes_as_the_single_gpu_proof_on_every_rank': bool(same_f and blob_f == single_blob),
