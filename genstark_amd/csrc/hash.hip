@@ -348,6 +348,20 @@ static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count,
     while (w > GS_MERKLE_SUBW) {                  // node layers w/2, ..., w >> lv from the digests of layer w
         int lv = 1;
         while (lv < GS_MERKLE_MAX_LV && (w >> (lv + 1)) >= GS_MERKLE_SUBW) lv++;
+        // (round 5 measured the other choice — fewer layers per launch so that a launch keeps >= 2^17 threads, one thread owning 2^lv digests
+        // depth first: trees built back to back gain 10-18 % from 2^19 digests up (tools/merkle_lv.py, profiles/r05_f_*), inside a proof
+        // the extra launches cost what the better occupancy gains: C5 3.36 -> 3.36 ms of kernels in 40 launches instead of 35, C4-long
+        // 9.53 -> 9.62.  Not adopted; the experiments build keeps the switch)
+#ifdef GS_NTT_EXPERIMENTS
+        // experiments build only (tools/merkle_lv.py): keep at least 2^K threads per node-layer launch (one thread owns 2^lv digests of
+        // layer w, depth first), i.e. fewer layers per launch while the launch would otherwise run at a wave or two per SIMD
+        if (const char *e = getenv("GSTARK_MERKLE_NODE_MIN_GROUPS")) {      // 0 = round 4's rule (as many layers as stay above 2^15 digests)
+            const int K = atoi(e);
+            lv = 1;
+            while (lv < GS_MERKLE_MAX_LV && (w >> (lv + 1)) >= GS_MERKLE_SUBW) lv++;
+            while (lv > 1 && (w >> lv) < (1ull << K)) lv--;
+        }
+#endif
         const uint64_t groups = w >> lv;
         gs_traffic(c, w * 32 + (w - (w >> lv)) * 32, w - (w >> lv), "k_merkle_fused<%d, 0>", ALG);      // reads layer w, writes layers w/2 .. w >> lv
         hipLaunchKernelGGL((k_merkle_fused<ALG, 0>), dim3(gs_grid(groups)), blk, 0, c->stream, va, 0u, cur, groups, lv, nd + 2 * (w / 2), nd, w / 2);
