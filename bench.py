@@ -291,6 +291,104 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+# ---- the ONE line the driver parses.  Round 5's line had grown to 28.7 KB and the driver could not parse it (BENCH_r05.json.parsed == null);
+# the line is now the contract keys plus one-level summaries, bounded by LINE_LIMIT; everything else is written to bench_detail.json
+LINE_LIMIT = 6000
+ROOFLINE_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'kernel', 'launch_ms', 'transform_ms',
+                 'ntt_kernel_elements_per_sec')
+CPU_KEYS = ('value', 'unit', 'cores', 'kind', 'sample', 'prove_ms', 'same_bytes_as_gpu', 'host_cpus_visible')
+CONFIG_KEYS = ('name', 'prove_ms', 'proof_bytes', 'proof_sha256', 'device_busy_ms', 'verify_native_ms')
+CONTRACT_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+                 'data', 'config')
+
+
+def _short(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 1] + '~'
+
+
+def _r(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact_line(out, detail_name='bench_detail.json'):
+    """`out` (everything this run measured) reduced to the record the driver reads: the contract keys, `roofline` and `cpu_baseline` as
+    flat objects, the reference's phase log, one row per BASELINE configuration, and (N > 1) one row per one-proof statement.  Returns
+    the JSON text, at most LINE_LIMIT bytes: optional blocks are dropped from the end of the list below until it fits."""
+    c = {k: out[k] for k in CONTRACT_KEYS if k in out}
+    c['metric'] = _short(c.get('metric'), 100)
+    c['dtype'] = _short(c.get('dtype'), 24)
+    cfg = dict(c.get('config') or {})
+    cfg.pop('ntt_points_source', None)
+    for k in ('workload', 'parallelism'):
+        if k in cfg:
+            cfg[k] = _short(cfg[k], 200)
+    c['config'] = cfg
+    c['value'], c['ms_per_step'] = _r(c.get('value'), 1), _r(c.get('ms_per_step'))
+    for k in ('prove_ms', 'driver_total_ms', 'test_double', 'rccl_ranks', 'strong', 'strong_unavailable', 'launcher_note'):
+        if k in out:
+            c[k] = _short(_r(out[k]), 240)
+    rf = out.get('roofline')
+    if rf:
+        r = {k: _short(rf.get(k), 120) for k in ROOFLINE_KEYS}
+        sr = rf.get('second_roof') or {}
+        r['second_roof'] = {'bound': sr.get('bound'), 'frac': sr.get('frac')}
+        pd = rf.get('proof_dominant_kernel')
+        if pd:
+            r['proof_dominant_kernel'] = {'kernel': _short(pd.get('kernel'), 40), 'ms_per_proof': pd.get('ms_per_proof'),
+                                          'frac_of_compression_roof': pd.get('frac_of_compression_roof'), 'frac_of_hbm_peak': pd.get('frac_of_hbm_peak')}
+        c['roofline'] = r
+    cpu = out.get('cpu_baseline')
+    if cpu:
+        c['cpu_baseline'] = {k: _short(_r(cpu.get(k), 1), 200) for k in CPU_KEYS}
+    optional = []                                        # dropped last-first when the line would not fit
+    pr = out.get('phases_readme')
+    if pr and pr.get('ms'):
+        c['phases_readme'] = {'ms': [[_short(l, 44), m] for l, m in pr['ms']], 'total_ms': pr.get('total_ms')}
+        optional.append('phases_readme')
+    if out.get('pipelined'):
+        c['pipelined'] = {k: _r(out['pipelined'].get(k), 3) for k in ('lanes', 'proofs', 'ms_per_proof')}
+        optional.append('pipelined')
+    if out.get('configs'):
+        c['configs'] = [({k: _short(x.get(k), 80) for k in CONFIG_KEYS if k in x} if 'error' not in x else {'error': _short(x['error'], 120)})
+                        for x in out['configs']]
+        optional.append('configs')
+    op = out.get('one_proof')
+    if op:
+        o = {k: _short(op[k], 160) for k in ('error', 'rccl_error', 'gpu_sharing', 'rccl_create_ms', 'rccl_selftest_ms') if k in op}
+        if 'comm' in op:
+            o['comm'] = _short(op['comm'].get('name'), 80)
+        for key in ('c4', 'c4_long', 'c5'):
+            if key in op:
+                x = op[key]
+                o[key] = {'ms_per_proof': x.get('ms_per_proof'), 'single_gpu_ms_per_proof': x.get('single_gpu_ms_per_proof'),
+                          'speedup_vs_one_gpu': x.get('speedup_vs_one_gpu'), 'mode': 'solo' if str(x.get('mode', '')).startswith('rank 0') else 'sharded',
+                          'same_bytes': x.get('same_bytes_as_the_single_gpu_proof_on_every_rank'), 'verified': x.get('verified'),
+                          'collectives': len(x.get('collectives') or []), 'collective_bytes_per_rank': x.get('collective_bytes_per_rank')}
+                if x.get('sharded_anyway') and 'ms_per_proof' in x['sharded_anyway']:
+                    o[key]['sharded_anyway_ms'] = x['sharded_anyway']['ms_per_proof']
+        c['one_proof'] = o
+        optional.insert(0, 'one_proof')                  # the scaling record goes last of all
+    c['detail'] = detail_name
+    line = json.dumps(c, separators=(',', ':'))
+    while len(line.encode()) > LINE_LIMIT and optional:
+        c.pop(optional.pop())
+        c['dropped_to_fit'] = c.get('dropped_to_fit', 0) + 1
+        line = json.dumps(c, separators=(',', ':'))
+    assert len(line.encode()) <= LINE_LIMIT, len(line)
+    return line
+
+
+def emit(out, detail_path):
+    """write everything to `detail_path` (best effort: a read-only tree must not cost the line), then print the compact record as the
+    LAST line of stdout"""
+    try:
+        with open(detail_path, 'w') as fh:
+            json.dump(out, fh, indent=1)
+    except OSError as e:
+        print(f'bench.py: could not write {detail_path}: {e}', file=sys.stderr, flush=True)
+    print(compact_line(out, os.path.basename(detail_path)), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -309,6 +407,7 @@ def main():
     ap.add_argument('--lanes', type=int, default=8, help='prover lanes of the extra throughput-mode leg (0 = skip it)')
     ap.add_argument('--lane-proofs', type=int, default=48, help='proofs pushed through the lanes in that leg')
     # test-only: drive the distributed harness on CPU (gloo) against the oracle's implementation of the C ABI
+    ap.add_argument('--detail', default=os.path.join(ROOT, 'bench_detail.json'), help='where the full record goes (the last stdout line is its summary)')
     ap.add_argument('--test-double-lib', default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     cpu_mode = args.test_double_lib is not None
@@ -552,13 +651,15 @@ def main():
                          'note': 'independent proofs in flight on one GPU (one library context + HIP stream per lane): a lane\'s '
                                  'host-side trace recurrence overlaps the other lanes\' kernels; latency of one proof is prove_ms'}
         out = {
-            'metric': 'prove() ms + NTT GF(p) elements/sec, MiMC-128 2^20 steps: value = NTT points launched per second of whole prove() (68 % of which is the serial host trace recurrence); the kernel-level figures are roofline.ntt_kernel_elements_per_sec and pipelined.ms_per_proof', 'value': points * world / (ms_per_step * 1e-3),
+            'metric': 'prove() ms + NTT GF(p) elements/sec, MiMC-128 2^20 steps', 'value': points * world / (ms_per_step * 1e-3),
             'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u128 (GF(2^128-9*2^32+1): 4x u32 limbs in memory, 5x 26-bit limbs inside the NTT networks)',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u128',
+            'metric_note': 'value = NTT points launched per second of whole prove() (two thirds of which is the serial host trace recurrence); prove_ms is the '
+                           'other half of the metric; the kernel-level figures are roofline.ntt_kernel_elements_per_sec and pipelined.ms_per_proof',
             'data': 'synthetic',
             'config': {'workload': f'MiMC-128 prove(), 2^{args.log_trace} steps, extensionFactor {ef}, exeQueryCount 48, '
                                    f'friQueryCount {fri}, blake2s256; one independent proof per GPU',
-                       'secret_registers': 0,
+                       'secret_registers': 0, 'field': 'GF(2^128-9*2^32+1): 4x u32 limbs in memory, 5x 26-bit limbs inside the NTT networks',
                        'evaluation_domain': n, 'ntt_points_per_prove': points, 'ntt_transforms_per_prove': launched[-1]['ntt_transforms'],
                        'ntt_points_source': 'gs_prover_last_stats: rows * n of every transform the timed driver launched', 'proof_bytes': len(data)},
             'prove_ms': ms_per_step, 'per_step_ms': step_ms, 'python_mirror_prove_ms': mirror_ms, 'phases_ms': phases, 'phases_source': 'native driver clock, last timed step', 'driver_total_ms': driver_total_ms, 'roofline': roofline, 'cpu_baseline': cpu,
@@ -577,6 +678,8 @@ def main():
     # ONE GPU timed in the same run; C5 (the headline statement as one proof) is reported with it.  Every collective is listed with
     # its bytes and device time.  The leg runs under a watchdog: whatever happens in it, every rank leaves within
     # --sharded-leg-timeout seconds and rank 0 still prints ONE valid line.
+    if out is not None and launcher_note:
+        out['launcher_note'] = launcher_note
     if dist is not None and args.sharded_leg_timeout > 0:
         import hashlib
         import threading
@@ -747,15 +850,13 @@ def main():
                 'speedup': snap[sk]['speedup_vs_one_gpu'], 'ranks': world, 'same_bytes': snap[sk]['same_bytes_as_the_single_gpu_proof_on_every_rank'],
                 'note': 'ONE proof across all ranks (csrc/prover_dist.h over RCCL) against the same proof on one GPU, both timed in this run; '
                         '`value` above is the replica figure (one independent proof per GPU)'}
-            if launcher_note:
-                out['launcher_note'] = launcher_note
             out['collectives'] = (snap.get('c4_long') or snap.get('c4') or snap.get('c5') or {}).get('collectives', [])
-            print(json.dumps(out), flush=True)
+            emit(out, args.detail)
         sys.stdout.flush()
         os._exit(0)      # the line is out; a rank may be stuck in (or may have bailed out of) a collective of the extra leg, so no
                          # rank waits for the others in a final barrier
     elif out is not None:
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail)
         out = None
     if dist is not None:
         dist.barrier()

@@ -1,6 +1,7 @@
-"""tools/show_bench.py <bench.json> — the fields of a bench line worth a glance."""
+"""tools/show_bench.py <bench_detail.json | bench line> — the fields of a bench record worth a glance."""
 import json, sys
-j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+text = open(sys.argv[1]).read().strip()
+j = json.loads(text) if text.startswith('{\n') else json.loads(text.splitlines()[-1])
 r = j['roofline']
 print('prove_ms', round(j['ms_per_step'], 3), 'value', round(j['value'] / 1e9, 3), 'G el/s; NTT', r['achieved'], 'GB/s frac', r['frac'], 'transform_ms', r['transform_ms'],
       'second_roof frac', r['second_roof'].get('frac'), 'traffic', r.get('traffic'))
