@@ -34,22 +34,25 @@ NOTES = {
 }
 
 
-def child(name, reps):
-    from genstark_amd._abi import MODULUS_32, Backend
+def statement(name, backend_for):
+    """The statement of configuration `name` on a backend: (backend, Prover, assertions, inputs, seed).  backend_for(modulus or None, jit)
+    -> Backend: the HIP library here, the CPU oracle's implementation of the C ABI in tests/golden/make_config_digests.py (the same
+    statements proved once on the checker: tests/golden/config_digests.json anchors every configs[].proof_sha256 of the bench line)."""
+    from genstark_amd._abi import MODULUS_32
     from genstark_amd.field import PrimeField
     from genstark_amd.prover import Prover
     opts = lambda ef, exe, fri: {'hashAlgorithm': 'blake2s256', 'extensionFactor': ef, 'exeQueryCount': exe, 'friQueryCount': fri}
     inputs = []
     if name == 'C1_foo':
         from genstark_amd.air_generic import GenericAir
-        be = Backend(device=0, modulus=MODULUS_32).jit()
+        be = backend_for(MODULUS_32, True)
         f = PrimeField(backend=be)
         air = GenericAir(64, 1, [1], [], lambda r, k: [r[0] + 2], lambda r, n, k: [n[0] - (r[0] + 2)], lambda seed: [seed[0]], None, f)
         p = Prover(air, {'hashAlgorithm': 'sha256', 'extensionFactor': air.extensionFactor})      # README.md:17-60: defaults (sha256, 80 / 40 queries)
         a, seed = [{'step': 0, 'register': 0, 'value': 1}, {'step': 63, 'register': 0, 'value': 127}], [1]
     elif name in ('C2_E8', 'C2_E16', 'C5'):
         import genstark_amd as ga
-        be = Backend(device=0)
+        be = backend_for(None, False)
         steps, ef, fri = {'C2_E8': (1 << 13, 8, 24), 'C2_E16': (1 << 13, 16, 24), 'C5': (1 << 20, 16, 64)}[name]
         st = ga.instantiateMimc(steps, opts(ef, 48, fri), backend=be)
         p = Prover(st.air, opts(ef, 48, fri))
@@ -57,7 +60,7 @@ def child(name, reps):
         tr = st.generateExecutionTrace([], [3])['dTrace']
         a, seed = [{'step': 0, 'register': 0, 'value': tr.getValue(0, 0)}, {'step': steps - 1, 'register': 0, 'value': tr.getValue(0, steps - 1)}], [3]
     else:
-        be = Backend(device=0).jit()
+        be = backend_for(None, True)
         f = PrimeField(backend=be)
         t = 1 << (20 if name == 'C4_long' else 16)
         if name == 'C3':
@@ -72,6 +75,16 @@ def child(name, reps):
             a = [{'step': 0, 'register': 0, 'value': 1}, {'step': t - 64, 'register': 2, 'value': 3 + t // 64 - 1}]
             p = Prover(air, opts(16, 48, 24))
         seed = p.pack_seed(seeds)
+    return be, p, a, inputs, seed
+
+
+def child(name, reps):
+    from genstark_amd._abi import Backend
+
+    def hip(modulus, jit):
+        be = Backend(device=0) if modulus is None else Backend(device=0, modulus=modulus)
+        return be.jit() if jit else be
+    be, p, a, inputs, seed = statement(name, hip)
     for _ in range(3):
         data = p.prove_bytes(a, inputs, seed)       # plans, block cache, compiled programs (hiprtc or the disk cache)
     be.sync()
