@@ -432,6 +432,7 @@ class AssemblyAir:
         if self.extensionFactor < 2 * cf:
             raise GstarkError('Extension factor must be a power of 2 at least 2x the constraint degree and at most 32')
         self._cache = {}
+        self._evaluationProgram = None
 
     # -- expressions
     def _run(self, algebra, r, n, k, body):
@@ -497,6 +498,35 @@ class AssemblyAir:
                 self._cache.clear()
             self._cache[key] = air
         return air
+
+    @property
+    def evaluationProgram(self):
+        """The constraint evaluator as a register-machine program (include/gstark.h opcodes).  It does not depend on the inputs' shapes:
+        static register k of the program is the k-th PUBLIC static register in declaration order, the secret ones follow — the order the
+        inner GenericAir of every shape uses.  What the native verifier runs for a proof whose shapes it reads itself (csrc/verifier.h)."""
+        if self._evaluationProgram is None:
+            from .air_generic import Program, nxt, reg, static
+            n = self.traceRegisterCount
+            k = [static(j) for j in range(len(self.export.statics))]
+            self._evaluationProgram = Program(self._run(_Exprs(self.module.modulus), [reg(i) for i in range(n)], [nxt(i) for i in range(n)],
+                                                        self._lib_order(k), self.export.evaluation), self.module.modulus)
+        return self._evaluationProgram
+
+    def staticSources(self):
+        """[(kind, index)] per static register in the programs' order (public ones in declaration order, then the secret inputs):
+        kind 0 = cyclic values, 1 = input register `index` (among the input registers), 2 = mask of input register `index`
+        (struct gs_static_source, include/gstark_prover.h); and the cyclic registers' values in the same order."""
+        sources, secret, cycles, j = [], [], [], 0
+        for s in self.export.statics:
+            if s['kind'] == 'input':
+                (secret if s['secret'] else sources).append((1, j))
+                j += 1
+            elif s['kind'] == 'mask':
+                sources.append((2, s['input']))
+            else:
+                sources.append((0, 0))
+                cycles.append(_shrink(self._cycle(s['values'])))
+        return sources + secret, cycles
 
     def _public_split(self, cols):
         return [_shrink(c) for c, (kind, _) in zip(cols, self._where) if kind == 'public']

@@ -282,6 +282,107 @@ Tree commit_rows4(Ctx &x, int alg, const void *column, uint64_t rows, bool want_
     t.root.resize(DIGEST);
     return t;
 }
+// ---- input registers of an air-assembly component: where every value of every input register sits in the trace, from the registers'
+// declarations and the SHAPES of their values alone (genstark_amd/airassembly.py: _Layout, restated).  prove() checks the shapes it
+// serializes with this; verify() sizes the trace from the shapes a proof carries (initVerificationContext(proof.iShapes, ...),
+// lib/Stark.ts:176).  Messages as the Python loader words them.
+typedef std::vector<std::vector<uint32_t>> Shapes;
+struct InputLayout {
+    std::vector<uint32_t> depth;
+    std::vector<uint64_t> span, count;      // steps one value is held; values of the register
+    uint64_t length = 0;                    // trace steps the inputs lay out
+};
+const uint64_t MAX_LAYOUT = 1ull << 40;     // products are capped here: nothing this driver proves or verifies is longer
+uint64_t capped_mul(uint64_t a, uint64_t b) {
+    if (a && b > MAX_LAYOUT / a) return MAX_LAYOUT;
+    return std::min(a * b, MAX_LAYOUT);
+}
+InputLayout input_layout(const gs_prover_air &air, const Shapes &shapes) {
+    const uint32_t n = air.ninputs;
+    const gs_input_register *in = air.inputs;
+    if (shapes.size() != n) fail(GS_ERR_ARG, "%u input registers: one entry (shape) for each is needed, got %zu", n, shapes.size());
+    InputLayout L;
+    L.depth.resize(n); L.span.assign(n, 0); L.count.resize(n);
+    for (uint32_t j = 0; j < n; j++) {
+        const int32_t ref = in[j].parent >= 0 ? in[j].parent : in[j].peer;
+        if ((in[j].parent >= 0 || in[j].peer >= 0) && !(ref >= 0 && (uint32_t)ref < j))
+            fail(GS_ERR_ARG, "input register: childof / peerof must name an earlier input register");
+        if (in[j].parent >= 0 && in[j].peer >= 0 && (uint32_t)in[j].peer >= j) fail(GS_ERR_ARG, "input register: childof / peerof must name an earlier input register");
+        L.depth[j] = (in[j].parent < 0 && in[j].peer < 0) ? 0 : L.depth[ref] + (in[j].parent >= 0 ? 1 : 0);
+        if (shapes[j].size() != (size_t)L.depth[j] + 1) fail(GS_ERR_ARG, "input register %u: values nested %u deep expected", j, L.depth[j] + 1);
+        if (in[j].peer >= 0 && shapes[j] != shapes[in[j].peer]) fail(GS_ERR_ARG, "input register %u: the shape of its peer %d expected", j, in[j].peer);
+        if (in[j].parent >= 0 && !std::equal(shapes[j].begin(), shapes[j].end() - 1, shapes[in[j].parent].begin(), shapes[in[j].parent].end()))
+            fail(GS_ERR_ARG, "input register %u: one list per value of register %d expected", j, in[j].parent);
+    }
+    // steps one value of a register is held: its own (steps n), or what its children take (0 = not known yet)
+    for (uint32_t j = 0; j < n; j++) L.span[j] = in[j].steps;
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (uint32_t j = 0; j < n; j++) {
+            if (L.span[j] && in[j].parent >= 0) {
+                const uint64_t want = capped_mul(L.span[j], shapes[j].back());
+                const uint32_t root = (uint32_t)in[j].parent;
+                if (!L.span[root]) { L.span[root] = want; changed = want != 0; }
+                else if (L.span[root] != want && !in[root].steps) fail(GS_ERR_ARG, "input registers: the children of one register take different numbers of steps");
+            }
+            if (!L.span[j] && in[j].peer >= 0 && L.span[in[j].peer]) { L.span[j] = L.span[in[j].peer]; changed = true; }
+            if (L.span[j] && in[j].peer >= 0 && !L.span[in[j].peer]) { L.span[in[j].peer] = L.span[j]; changed = true; }
+        }
+    }
+    for (uint32_t j = 0; j < n; j++)
+        if (!L.span[j]) fail(GS_ERR_ARG, "input registers: cannot tell how many steps a value is held (no (steps n) below it)");
+    for (uint32_t j = 0; j < n; j++) {
+        uint64_t count = 1;
+        for (uint32_t d : shapes[j]) count = capped_mul(count, d);
+        L.count[j] = count;
+        const uint64_t len = capped_mul(count, L.span[j]);
+        if (L.length && len != L.length) fail(GS_ERR_ARG, "input registers imply different trace lengths");
+        L.length = len;
+    }
+    if (n && (L.length < 2 || (L.length & (L.length - 1)) || L.length >= MAX_LAYOUT))
+        fail(GS_ERR_ARG, "the inputs make a trace of %llu steps: a power of 2 is required", (unsigned long long)L.length);
+    return L;
+}
+// iShapes as the job carries them (per register: rank, then the dimensions) -> Shapes
+Shapes job_shapes(const gs_prover_air &air) {
+    Shapes out(air.ninputs);
+    if (air.ninputs && !air.input_shapes) fail(GS_ERR_ARG, "an AIR with input registers needs the shapes of its inputs");
+    const uint32_t *q = air.input_shapes;
+    for (uint32_t j = 0; j < air.ninputs; j++) {
+        const uint32_t rank = *q++;
+        if (rank > 255) fail(GS_ERR_ARG, "input register %u: values nested %u deep", j, rank);
+        out[j].assign(q, q + rank);
+        q += rank;
+    }
+    return out;
+}
+// Serializer.serializeProof's last part (lib/Serializer.ts:70-78): count, then per shape its rank and the dimensions as uint32 LE
+void write_input_shapes(Bytes &out, const Shapes &shapes) {
+    if (shapes.size() > 255) fail(GS_ERR_ARG, "too many input registers");
+    out.push_back((uint8_t)shapes.size());
+    for (const auto &sh : shapes) {
+        out.push_back((uint8_t)sh.size());
+        for (uint32_t d : sh) for (int b = 0; b < 4; b++) out.push_back((uint8_t)(d >> (8 * b)));
+    }
+}
+// what prove() does with a job's input registers before any device work: the shapes must lay out exactly the trace the job states
+Shapes checked_job_shapes(const gs_prover_job &job) {
+    if (!job.air.ninputs) return Shapes();
+    if (!job.air.inputs) fail(GS_ERR_ARG, "invalid job: input registers without their declarations");
+    Shapes shapes = job_shapes(job.air);
+    const InputLayout L = input_layout(job.air, shapes);
+    if (L.length != job.steps) fail(GS_ERR_ARG, "the inputs lay out a trace of %llu steps, the job states %llu", (unsigned long long)L.length, (unsigned long long)job.steps);
+    return shapes;
+}
+// the root of unity of the evaluation domain from the job's (root_of_unity_log2: squared down from a root of higher order)
+F domain_root(const gs_prover_job &job, uint64_t N) {
+    F w = from16(job.root_of_unity);
+    if (!job.root_of_unity_log2) return w;
+    if (job.root_of_unity_log2 > 63 || N > (1ull << job.root_of_unity_log2)) fail(GS_ERR_ARG, "the field has no root of unity of order %llu", (unsigned long long)N);
+    for (uint64_t order = 1ull << job.root_of_unity_log2; order > N; order >>= 1) w = hf_mul(w, w);
+    return w;
+}
+
 std::vector<uint64_t> unique_in_order(const std::vector<uint64_t> &v) {
     std::vector<uint64_t> out;
     std::map<uint64_t, bool> seen;
@@ -563,13 +664,14 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     const uint32_t R = air.registers;
     const int alg = job.hash_alg;
     if (!T || (T & (T - 1)) || !E || (E & (E - 1)) || !R || !air.nconstraints || !job.nassertions) fail(GS_ERR_ARG, "invalid job");
+    const Shapes input_shapes = checked_job_shapes(job);          // iShapes of the proof (lib/Stark.ts:161); empty without input registers
     uint32_t max_degree = 1;
     for (uint32_t i = 0; i < air.nconstraints; i++) max_degree = std::max(max_degree, air.degrees[i]);
     uint64_t cf = 1;
     while (cf < max_degree) cf <<= 1;                              // compositionFactor = 2^ceil(log2(max degree))
     const uint64_t Nc = T * cf;
     if (E < 2 * cf) fail(GS_ERR_ARG, "extension factor must be at least 2x the composition factor");
-    const F omega = from16(job.root_of_unity);
+    const F omega = domain_root(job, N);
     const F comp_rou = hf_pow(omega, (hfe)(N / Nc)), exec_rou = hf_pow(omega, (hfe)E);
     uint8_t s16[ELEM], s16b[ELEM];
 
@@ -1078,7 +1180,7 @@ static void prove_impl(Ctx &x, const gs_prover_job &job, Bytes &out) {
     if (remainder.size() > MAX_ARRAY) fail(GS_ERR_ARG, "remainder too long");
     out.push_back(remainder.size() == MAX_ARRAY ? 0 : (uint8_t)remainder.size());
     for (F v : remainder) { uint8_t b[ELEM]; le16(v, b); out.insert(out.end(), b, b + ELEM); }
-    out.push_back(0);    // no input shapes (iShapes = [])
+    write_input_shapes(out, input_shapes);
     clock.mark("serialized");
     clock.readme(x, "Proof serialized");
 }

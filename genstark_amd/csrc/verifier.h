@@ -225,38 +225,73 @@ std::vector<F> run_program(const gs_prover_air &air, const std::vector<F> &cur, 
     return out;
 }
 
-// coefficients of the polynomial through `values` on the m-th roots of unity {g^i} (m a power of two): an inverse DFT of size m,
-// O(m^2) on host scalars (m <= a few hundred: the period of a cyclic static register)
+// coefficients of the polynomial through `values` on the m-th roots of unity {g^i} (m a power of two): an inverse DFT of size m on host
+// scalars — the O(m^2) sum for the short periods of cyclic registers, a radix-2 transform for the columns of input registers (a public
+// input register of an air-assembly component can be as long as the trace)
 std::vector<F> cyclic_poly(const std::vector<F> &values, F g) {
     const size_t m = values.size();
-    std::vector<F> pw(m);
-    const F ginv = hf_inv(g);
-    F cur = 1;
-    for (size_t i = 0; i < m; i++) { pw[i] = cur; cur = hf_mul(cur, ginv); }
-    const F minv = hf_inv((F)(uint64_t)m);
+    const F ginv = hf_inv(g), minv = hf_inv((F)(uint64_t)m);
     std::vector<F> out(m);
-    for (size_t j = 0; j < m; j++) {
-        F s = 0;
-        for (size_t i = 0; i < m; i++) s = hf_add(s, hf_mul(values[i], pw[(i * j) % m]));
-        out[j] = hf_mul(s, minv);
+    if (m <= 32) {
+        std::vector<F> pw(m);
+        F cur = 1;
+        for (size_t i = 0; i < m; i++) { pw[i] = cur; cur = hf_mul(cur, ginv); }
+        for (size_t j = 0; j < m; j++) {
+            F s = 0;
+            for (size_t i = 0; i < m; i++) s = hf_add(s, hf_mul(values[i], pw[(i * j) % m]));
+            out[j] = hf_mul(s, minv);
+        }
+        return out;
     }
+    uint32_t logm = 0;
+    while ((1ull << logm) < m) logm++;
+    for (size_t i = 0; i < m; i++) {                              // bit-reversed copy, then decimation-in-time butterflies with g^-1
+        size_t r = 0;
+        for (uint32_t b = 0; b < logm; b++) r |= ((i >> b) & 1) << (logm - 1 - b);
+        out[r] = values[i];
+    }
+    for (size_t half = 1; half < m; half <<= 1) {
+        const F wlen = hf_pow(ginv, (hfe)(uint64_t)(m / (2 * half)));
+        std::vector<F> tw(half);
+        F cur = 1;
+        for (size_t k = 0; k < half; k++) { tw[k] = cur; cur = hf_mul(cur, wlen); }
+        for (size_t base = 0; base < m; base += 2 * half)
+            for (size_t k = 0; k < half; k++) {
+                const F u = out[base + k], v = hf_mul(out[base + k + half], tw[k]);
+                out[base + k] = hf_add(u, v);
+                out[base + k + half] = hf_sub(u, v);
+            }
+    }
+    for (size_t j = 0; j < m; j++) out[j] = hf_mul(out[j], minv);
     return out;
+}
+// the shortest power-of-two period of a column (a cyclic register of that length denotes the same polynomial): airassembly.py _shrink
+void shrink_column(std::vector<F> &col) {
+    while (col.size() > 1 && col.size() % 2 == 0) {
+        const size_t half = col.size() / 2;
+        bool same = true;
+        for (size_t i = 0; i < half && same; i++) same = col[i] == col[half + i];
+        if (!same) break;
+        col.resize(half);
+    }
+}
+// a column rotated right by `shift` steps: airassembly.py _rotate (new[i] = old[(i - shift) mod len])
+void rotate_column(std::vector<F> &col, int32_t shift) {
+    if (col.empty()) return;
+    const int64_t len = (int64_t)col.size();
+    const int64_t k = (((-(int64_t)shift) % len) + len) % len;
+    std::rotate(col.begin(), col.begin() + k, col.end());
 }
 
 void verify_impl(const gs_prover_job &job, const uint8_t *proof, uint64_t proof_len) {
     const gs_prover_air &air = job.air;
-    const uint64_t T = job.steps, E = job.extension_factor, N = T * E;
+    const uint64_t E = job.extension_factor;
     const uint32_t R = air.registers, S = air.nsecret;
     const int alg = job.hash_alg;
-    if (!T || (T & (T - 1)) || !E || (E & (E - 1)) || !R || !air.nconstraints) fail(GS_ERR_ARG, "invalid job");
+    if (!E || (E & (E - 1)) || !R || !air.nconstraints) fail(GS_ERR_ARG, "invalid job");
     if (job.nassertions < 1) fail(GS_ERR_ARG, "At least one assertion must be provided");
     if (alg != GS_HASH_SHA256 && alg != GS_HASH_BLAKE2S256) fail(GS_ERR_ARG, "unknown hash algorithm");
-    const F omega = from16(job.root_of_unity);
-    uint32_t max_degree = 1;
-    for (uint32_t i = 0; i < air.nconstraints; i++) max_degree = std::max(max_degree, air.degrees[i]);
-    uint64_t cf = 1;
-    while (cf < max_degree) cf <<= 1;
-    const uint64_t combination_degree = cf * T, composition_degree = std::max(combination_degree - T, T), b_inc = composition_degree - T;
+    if (air.ninputs && (air.kind != 1 || !air.inputs)) fail(GS_ERR_ARG, "invalid job: input registers belong to a program AIR and need their declarations");
 
     // ----- parse (lib/Serializer.ts:83-144)
     Reader r{proof, proof_len};
@@ -279,14 +314,40 @@ void verify_impl(const gs_prover_job &job, const uint8_t *proof, uint64_t proof_
     if (!rlen) rlen = (uint32_t)MAX_ARRAY;
     std::vector<F> remainder(rlen);
     for (uint32_t i = 0; i < rlen; i++) remainder[i] = from16(r.take(ELEM));
-    // input shapes (lib/Serializer.ts:127-141).  The reference sizes the trace from them (initVerificationContext(proof.iShapes, ...),
-    // lib/Stark.ts:180); here the JOB states the trace length and the AIRs this verifier takes have no input registers, so a proof
-    // that carries shapes describes something this entry cannot check: refused, never verified against job.steps alone
+    // input shapes (lib/Serializer.ts:127-141) — and with them the trace length: the reference sizes the trace from the proof's shapes
+    // (initVerificationContext(proof.iShapes, publicInputs), lib/Stark.ts:176).  An AIR without input registers has a fixed trace
+    // (job.steps) and a proof of it carries no shapes.
+    Shapes shapes;
     {
         const uint32_t nshapes = r.byte();
-        for (uint32_t i = 0; i < nshapes; i++) r.take(4ull * r.byte());      // (bounds-checked either way)
-        if (nshapes) fail(GS_ERR_UNSUPPORTED, "proofs that carry input shapes (%u) are verified by the Python verifier", nshapes);
+        shapes.resize(nshapes);
+        for (auto &sh : shapes) {
+            const uint32_t rank = r.byte();
+            const uint8_t *q = r.take(4ull * rank);
+            sh.resize(rank);
+            for (uint32_t k = 0; k < rank; k++) sh[k] = (uint32_t)q[4 * k] | ((uint32_t)q[4 * k + 1] << 8) | ((uint32_t)q[4 * k + 2] << 16) | ((uint32_t)q[4 * k + 3] << 24);
+        }
     }
+    // (bytes after the shapes are ignored, as lib/Serializer.ts:83-144 ignores them)
+    uint64_t T = job.steps;
+    InputLayout layout;
+    if (air.ninputs) {
+        layout = input_layout(air, shapes);
+        if (job.steps && job.steps != layout.length)
+            fail(GS_ERR_ARG, "the proof's input shapes lay out a trace of %llu steps, the statement is about %llu", (unsigned long long)layout.length, (unsigned long long)job.steps);
+        T = layout.length;
+    } else if (!shapes.empty()) {
+        fail(GS_ERR_ARG, "malformed proof: %zu input shapes for an AIR without input registers", shapes.size());
+    }
+    if (!T || (T & (T - 1))) fail(GS_ERR_ARG, "invalid job");
+    if (T > (1ull << 32) / E) fail(GS_ERR_ARG, "a trace of %llu steps at extension factor %llu is beyond this verifier", (unsigned long long)T, (unsigned long long)E);
+    const uint64_t N = T * E;
+    const F omega = domain_root(job, N);
+    uint32_t max_degree = 1;
+    for (uint32_t i = 0; i < air.nconstraints; i++) max_degree = std::max(max_degree, air.degrees[i]);
+    uint64_t cf = 1;
+    while (cf < max_degree) cf <<= 1;
+    const uint64_t combination_degree = cf * T, composition_degree = std::max(combination_degree - T, T), b_inc = composition_degree - T;
     // the number of FRI layers is a function of the domain size alone (LowDegreeProver.ts:179: fold while more than 256 values are
     // left); a proof with any other count is malformed — in particular one with extra layers, which would floor the degree bound of
     // the remainder to zero and leave the low-degree test with nothing to check
@@ -348,13 +409,58 @@ void verify_impl(const gs_prover_job &job, const uint8_t *proof, uint64_t proof_
         static_periods.push_back(air.nrc);
     } else {
         if (air.nstatic < S) fail(GS_ERR_ARG, "static register list shorter than the secret register count");
+        if (air.ninputs && !air.static_sources) fail(GS_ERR_ARG, "invalid job: an AIR with input registers says where each static register takes its values from");
+        // which public input register's values are the k-th list of public_inputs (declaration order, lib/Stark.ts:167)
+        std::vector<int64_t> public_at(air.ninputs, -1);
+        std::vector<uint64_t> public_off;
+        if (air.ninputs) {
+            uint32_t k = 0;
+            uint64_t off = 0;
+            for (uint32_t j = 0; j < air.ninputs; j++) {
+                if (air.inputs[j].secret) continue;
+                if (k >= air.npublic_inputs || !air.public_input_counts || (!air.public_inputs && air.public_input_counts[k]))
+                    fail(GS_ERR_ARG, "the values of %u public input registers are needed", (unsigned)std::count_if(air.inputs, air.inputs + air.ninputs, [](const gs_input_register &d) { return !d.secret; }));
+                if (air.public_input_counts[k] != layout.count[j]) fail(GS_ERR_ARG, "public input register %u: %llu values expected (the shape in the proof), %llu given", j, (unsigned long long)layout.count[j], (unsigned long long)air.public_input_counts[k]);
+                public_at[j] = k++;
+                public_off.push_back(off);
+                off += layout.count[j];
+            }
+        }
         uint64_t off = 0;
+        uint32_t cyc = 0;
         for (uint32_t s = 0; s + S < air.nstatic; s++) {                     // the public ones (the secret ones follow them and arrive in the leaves)
-            const uint32_t m = air.static_periods[s];
-            if (!m || (m & (m - 1)) || T % m) fail(GS_ERR_ARG, "a static register's period must be a power of two dividing the trace length");
-            std::vector<F> vals(m);
-            for (uint32_t i = 0; i < m; i++) vals[i] = from16(air.static_values + ELEM * (off + i));
-            off += m;
+            const gs_static_source src = air.static_sources ? air.static_sources[s] : gs_static_source{GS_STATIC_CYCLE, 0};
+            std::vector<F> vals;
+            if (src.kind == GS_STATIC_CYCLE) {
+                const uint32_t m = air.static_periods[cyc++];
+                if (!m || (m & (m - 1)) || T % m) fail(GS_ERR_ARG, "a static register's period must be a power of two dividing the trace length");
+                vals.resize(m);
+                for (uint32_t i = 0; i < m; i++) vals[i] = from16(air.static_values + ELEM * (off + i));
+                off += m;
+            } else if (src.kind == GS_STATIC_INPUT || src.kind == GS_STATIC_MASK) {
+                // the column the loader lays out (airassembly.py: _Layout.column / .mask): every value held for `span` steps — or a 1
+                // on the first of them —, the whole rotated by the register's shift, then cut to its shortest period
+                const uint32_t j = src.index;
+                if (j >= air.ninputs) fail(GS_ERR_ARG, "invalid job: static register %u names input register %u of %u", s, j, air.ninputs);
+                if (T > (1ull << 26)) fail(GS_ERR_ARG, "a trace of %llu steps is beyond this verifier's input-register columns", (unsigned long long)T);
+                const uint64_t span = layout.span[j];
+                vals.resize(T);
+                if (src.kind == GS_STATIC_MASK) {
+                    for (uint64_t i = 0; i < T; i++) vals[i] = (i % span) ? (F)0 : (F)1;
+                } else {
+                    if (air.inputs[j].secret || public_at[j] < 0) fail(GS_ERR_ARG, "invalid job: static register %u is a public one, input register %u is secret", s, j);
+                    const uint8_t *src_vals = air.public_inputs + ELEM * public_off[public_at[j]];
+                    for (uint64_t v = 0; v < layout.count[j]; v++) {
+                        const F val = from16(src_vals + ELEM * v);
+                        for (uint64_t i = 0; i < span; i++) vals[v * span + i] = val;
+                    }
+                }
+                rotate_column(vals, air.inputs[j].shift);
+                shrink_column(vals);
+            } else {
+                fail(GS_ERR_ARG, "invalid job: static register %u has unknown source %u", s, src.kind);
+            }
+            const uint64_t m = vals.size();
             static_polys.push_back(cyclic_poly(vals, hf_pow(omega, (hfe)(E * (T / m)))));
             static_periods.push_back(m);
         }

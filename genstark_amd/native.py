@@ -29,6 +29,14 @@ class _Assertion(C.Structure):
     _fields_ = [('step', C.c_uint64), ('reg', C.c_uint32), ('value', C.c_uint8 * ELT_MAX)]
 
 
+class _InputRegister(C.Structure):      # struct gs_input_register
+    _fields_ = [('parent', C.c_int32), ('peer', C.c_int32), ('steps', C.c_uint32), ('shift', C.c_int32), ('secret', C.c_uint32)]
+
+
+class _StaticSource(C.Structure):       # struct gs_static_source
+    _fields_ = [('kind', C.c_uint32), ('index', C.c_uint32)]
+
+
 class _Air(C.Structure):
     _fields_ = [('kind', C.c_uint32), ('registers', C.c_uint32), ('nconstraints', C.c_uint32), ('degrees', C.POINTER(C.c_uint32)),
                 ('seed', C.c_uint8 * ELT_MAX), ('round_constants', C.c_char_p), ('nrc', C.c_uint32), ('k_table', C.c_void_p), ('k_len', C.c_uint64),
@@ -36,13 +44,16 @@ class _Air(C.Structure):
                 ('e_code', C.POINTER(C.c_uint32)), ('e_ninstr', C.c_uint32), ('consts', C.c_char_p), ('nconsts', C.c_uint32),
                 ('vm_regs', C.c_uint32), ('static_values', C.c_char_p), ('static_periods', C.POINTER(C.c_uint32)), ('nstatic', C.c_uint32),
                 ('static_tables', C.c_void_p), ('static_lens', C.POINTER(C.c_uint64)), ('first_rows', C.c_char_p), ('segments', C.c_uint64),
-                ('segment_len', C.c_uint64), ('secret_traces', C.POINTER(C.c_void_p)), ('nsecret', C.c_uint32)]
+                ('segment_len', C.c_uint64), ('secret_traces', C.POINTER(C.c_void_p)), ('nsecret', C.c_uint32),
+                ('inputs', C.POINTER(_InputRegister)), ('ninputs', C.c_uint32), ('input_shapes', C.POINTER(C.c_uint32)),
+                ('static_sources', C.POINTER(_StaticSource)), ('public_inputs', C.c_char_p), ('public_input_counts', C.POINTER(C.c_uint64)),
+                ('npublic_inputs', C.c_uint32)]
 
 
 class _Job(C.Structure):
     _fields_ = [('steps', C.c_uint64), ('extension_factor', C.c_uint32), ('exe_query_count', C.c_uint32), ('fri_query_count', C.c_uint32),
                 ('hash_alg', C.c_int32), ('root_of_unity', C.c_uint8 * ELT_MAX), ('assertions', C.POINTER(_Assertion)), ('nassertions', C.c_uint32),
-                ('air', _Air)]
+                ('root_of_unity_log2', C.c_uint32), ('air', _Air)]
 
 
 class _Stats(C.Structure):
@@ -113,6 +124,18 @@ def _driver(backend):
         return lib, _bindings[key]
 
 
+def _is_assembly(air):
+    from .airassembly import AssemblyAir        # (airassembly imports air_generic, which this module imports too: resolved at call time)
+    return isinstance(air, AssemblyAir)
+
+
+class _Shim:
+    """what NativeProver reads of a `stark`: the inner GenericAir of an AssemblyAir for one shape, with the outer prover's options"""
+
+    def __init__(self, air, exe, fri, alg):
+        self.air, self.exeQueryCount, self.friQueryCount, self.hashAlg = air, exe, fri, alg
+
+
 class PackedSeed:
     """The first rows of a statement already in the driver's wire form (registers x 16 bytes per row): `NativeProver.pack_seed(seed)`.
     Passing it as `seed` keeps the per-proof job packing out of prove_bytes — what a caller whose inputs already are bytes (a node
@@ -154,8 +177,24 @@ class NativeProver:
                 ctx = GenericProvingContext(air, rows * (air.steps // air.segmentLength if air.segmentLength else 1))
                 self._tables, self._lens = ctx._staticTables, ctx._staticLens
             self.rootOfUnity = air.rootOfUnity
+        elif _is_assembly(air):
+            # an air-assembly component (genstark_amd/airassembly.py): shape-agnostic — the trace is sized from the inputs when they
+            # arrive (prove) or from the shapes the proof carries (verify: read by the native verifier itself, csrc/verifier.h)
+            self.kind, self.degrees = 1, list(air.constraintDegrees)
+            self._inner = {}                             # id(inner GenericAir of one shape) -> its NativeProver
+            regs = air.inputRegisters
+            self._input_decl = (_InputRegister * max(len(regs), 1))()
+            for j, d in enumerate(regs):
+                self._input_decl[j].parent = -1 if d['parent'] is None else d['parent']
+                self._input_decl[j].peer = -1 if d['peer'] is None else d['peer']
+                self._input_decl[j].steps = d['steps'] or 0
+                self._input_decl[j].shift = d['shift']
+                self._input_decl[j].secret = 1 if d['secret'] else 0
+            self._ninputs = len(regs)
+            self.rootOfUnity = None
         else:
-            raise GstarkError('the native driver knows the MiMC AIR and GenericAir')
+            raise GstarkError('the native driver knows the MiMC AIR, GenericAir and AssemblyAir')
+        self._shape_args = None      # (declarations, count, shapes) of the AssemblyAir this prover is the inner prover of
 
     def prove_bytes(self, assertions, inputs=None, seed=None, comm=None):
         """The serialized proof of Stark.prove(assertions, inputs, seed): stark.serialize(stark.prove(...)) byte for byte.
@@ -166,6 +205,18 @@ class NativeProver:
             raise TypeError('Assertions parameter must be an array')
         if len(assertions) == 0:
             raise TypeError('At least one assertion must be provided')
+        if _is_assembly(air):
+            # initProvingContext(inputs, seed) (lib/Stark.ts:90): the loader lays the inputs out — the inner AIR of this shape, the secret
+            # registers' columns, the first row(s) — and the native driver proves that AIR, writing the inputs' shapes into the proof
+            inner, packed, firsts, shapes = air.plan(inputs, seed)
+            nat = self._inner.get(id(inner))
+            if nat is None:
+                if len(self._inner) > 8:
+                    self._inner.clear()
+                nat = self._inner[id(inner)] = NativeProver(_Shim(inner, self._exe, self._fri, self._alg))
+            flat = [w for sh in shapes for w in [len(sh)] + list(sh)]
+            nat._shape_args = (self._input_decl, self._ninputs, (C.c_uint32 * max(len(flat), 1))(*flat))
+            return nat.prove_bytes(assertions, packed, firsts, comm=comm)
         job = _Job()
         job.steps, job.extension_factor = air.steps, air.extensionFactor
         job.exe_query_count, job.fri_query_count = self._exe, self._fri
@@ -184,6 +235,8 @@ class NativeProver:
         degrees = (C.c_uint32 * len(self.degrees))(*self.degrees)
         ja.degrees = degrees
         keep = [arr, degrees]
+        if self._shape_args is not None:
+            ja.inputs, ja.ninputs, ja.input_shapes = self._shape_args
         if self.kind == 0:
             ja.seed[:es] = f.le((seed or [0])[0] % f.modulus)
             ja.round_constants, ja.nrc = self._rc, len(air.roundConstants)
@@ -257,18 +310,30 @@ class NativeProver:
             raise StarkError(f'native prove() failed ({rc}): {err.value.decode(errors="replace")}')
         return C.string_at(out, n.value)
 
-    def verify_bytes(self, assertions, data):
-        """Stark.verify(assertions, stark.parse(data)) natively (csrc/verifier.h: lib/Stark.ts:167-248 + LowDegreeProver.ts:70-172 on host
-        scalars, no device work): True, or StarkError with the reference's message.  AIRs whose proofs carry input shapes (AssemblyAir
-        with input registers) are verified by the Python verifier instead (GstarkError here)."""
+    def verify_bytes(self, assertions, data, publicInputs=None):
+        """Stark.verify(assertions, stark.parse(data), publicInputs) natively (csrc/verifier.h: lib/Stark.ts:167-248 +
+        LowDegreeProver.ts:70-172 on host scalars, no device work): True, or StarkError with the reference's message.  For an
+        air-assembly component with input registers the trace length is not part of the job: the verifier reads the inputs' shapes
+        from the proof, as the reference does (lib/Stark.ts:176), and lays the PUBLIC registers' values (publicInputs) out itself."""
         air, f = self.stark.air, self.field
         if not isinstance(assertions, list) or len(assertions) == 0:
             raise TypeError('At least one assertion must be provided')
         es = f.elementSize
         job = _Job()
-        job.steps, job.extension_factor = air.steps, air.extensionFactor
+        assembly = _is_assembly(air)
+        job.extension_factor = air.extensionFactor
         job.exe_query_count, job.fri_query_count, job.hash_alg = self._exe, self._fri, self._alg
-        job.root_of_unity[:es] = f.le(self.rootOfUnity)
+        if assembly:
+            # steps = 0: whatever the proof's shapes lay out; the root of unity of the field's largest power-of-two order, squared
+            # down by the driver to the evaluation domain's (root_of_unity_log2)
+            job.steps = 0
+            adicity = ((f.modulus - 1) & -(f.modulus - 1)).bit_length() - 1
+            log2 = min(adicity, 32)
+            job.root_of_unity[:es] = f.le(f.getRootOfUnity(1 << log2))
+            job.root_of_unity_log2 = log2
+        else:
+            job.steps = air.steps
+            job.root_of_unity[:es] = f.le(self.rootOfUnity)
         arr = (_Assertion * len(assertions))()
         for i, a in enumerate(assertions):
             if a['register'] < 0 or a['step'] < 0:
@@ -283,6 +348,34 @@ class NativeProver:
         keep = [arr, degrees]
         if self.kind == 0:
             ja.round_constants, ja.nrc = self._rc, len(air.roundConstants)
+        elif assembly:
+            nsec = air.secretInputCount
+            e_code, e_n, consts, nconsts, nregs = air.evaluationProgram.abi_args(es)
+            sources, cycles = air.staticSources()
+            src = (_StaticSource * max(len(sources), 1))()
+            for i, (kind, index) in enumerate(sources):
+                src[i].kind, src[i].index = kind, index
+            pub = b''.join(f.le(v % f.modulus) for values in cycles for v in values) or bytes(es)
+            periods = (C.c_uint32 * max(len(cycles), 1))(*[len(v) for v in cycles])
+            ja.e_code, ja.e_ninstr, ja.consts, ja.nconsts, ja.vm_regs = e_code, e_n, consts, nconsts, nregs
+            ja.static_values, ja.static_periods, ja.nstatic, ja.nsecret = pub, periods, len(sources), nsec
+            ja.static_sources = src
+            ja.inputs, ja.ninputs = self._input_decl, self._ninputs
+            # publicInputs: the values of the public input registers in declaration order (lib/Stark.ts:167), flattened row-major
+            given = list(publicInputs or [])
+            flat_all, counts = [], []
+            for values in given:
+                flat = values
+                while flat and isinstance(flat[0], (list, tuple)):
+                    flat = [v for group in flat for v in group]
+                if any(isinstance(v, (list, tuple)) for v in flat):
+                    raise GstarkError('input register: ragged values')
+                counts.append(len(flat))
+                flat_all.extend(flat)
+            pvals = b''.join(f.le(int(v) % f.modulus) for v in flat_all) or bytes(es)
+            pcounts = (C.c_uint64 * max(len(counts), 1))(*counts)
+            ja.public_inputs, ja.public_input_counts, ja.npublic_inputs = pvals, pcounts, len(counts)
+            keep += [e_code, consts, pub, periods, src, pvals, pcounts]
         else:
             nsec = air.secretInputCount
             e_code, e_n, consts, nconsts, nregs = air.evaluationProgram.abi_args(es)

@@ -70,10 +70,11 @@ class Prover:
     def last_collectives(self):
         return self._native.last_collectives()
 
-    def verify_native(self, assertions, data):
+    def verify_native(self, assertions, data, publicInputs=None):
         """Stark.verify of serialized proof bytes by the NATIVE verifier (csrc/verifier.h; CPU only, ~100x the Python verifier's speed):
-        True or StarkError with the reference's message."""
-        return self._native.verify_bytes(assertions, data)
+        True or StarkError with the reference's message.  publicInputs: the values of the public input registers of an air-assembly
+        component (lib/Stark.ts:167); the trace is sized from the shapes the proof carries."""
+        return self._native.verify_bytes(assertions, data, publicInputs)
 
     def verify(self, assertions, proof, publicInputs=None):
         """lib/Stark.ts:167-248 on the CPU side of the same backend (the restated caller in genstark_amd/_mirror; a verifier that

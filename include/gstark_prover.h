@@ -25,6 +25,25 @@ struct gs_assertion {          /* lib/Stark.ts:356-375: register `reg` holds `va
     uint8_t value[GS_PROVER_ELT_MAX];
 };
 
+/* An input register of an air-assembly component — `(input secret|public vector|scalar (childof n)|(peerof n) (steps n) (shift n))`,
+ * assembly/lib128.aa:81-150 — as Stark.prove / Stark.verify need it: initProvingContext(inputs) and initVerificationContext(proof.iShapes,
+ * publicInputs) (lib/Stark.ts:90,176) size the trace from the SHAPES of the inputs and lay the values out as trace-length columns
+ * (one value held for `steps` steps, or for as long as its children take; the whole column rotated by `shift`). */
+struct gs_input_register {
+    int32_t parent;             /* (childof n): an EARLIER input register whose every value this one refines into a list; -1 = none */
+    int32_t peer;               /* (peerof n): an earlier input register of the same shape; -1 = none */
+    uint32_t steps;             /* (steps n): trace steps one value is held; 0 = not stated (follows from its children or its peer) */
+    int32_t shift;              /* (shift n): the column rotated right by n steps (negative: left) */
+    uint32_t secret;            /* 1 = the prover's alone: its values reach the verifier inside the proof's leaves */
+};
+/* Where static register s of an AIR with input registers takes its values from (verifier side: the prover's job carries the columns). */
+#define GS_STATIC_CYCLE 0       /* cyclic values: the next entry of static_values / static_periods */
+#define GS_STATIC_INPUT 1       /* input register `index` (a public one: from public_inputs; a secret one: from the leaves) */
+#define GS_STATIC_MASK 2        /* 1 on the first step of every value of input register `index`, 0 elsewhere (`(mask (input n))`) */
+struct gs_static_source {
+    uint32_t kind, index;
+};
+
 /* What the AIR module contributes (lib/Stark.ts:35-58: `air`): counts, degrees and the two device routines. */
 struct gs_prover_air {
     uint32_t kind;               /* 0 = MiMC (gs_mimc_trace / gs_mimc_constraints), 1 = register-machine programs (gs_air_*) */
@@ -48,15 +67,32 @@ struct gs_prover_air {
     /* secret registers (lib/Stark.ts:113): their low-degree extensions over the evaluation domain, prepared by the caller; */
     /* static_values / static_tables then hold the public registers followed by the secret ones */
     const void *const *secret_traces; uint32_t nsecret;
+    /* input registers (ninputs = 0: an AIR without them — nothing below is read and the proof carries no shapes) */
+    const struct gs_input_register *inputs; uint32_t ninputs;
+    /* input_shapes: per input register its rank followed by that many dimensions.  prove: written into the proof (iShapes,
+     * lib/Stark.ts:161, lib/Serializer.ts:70-78) after the validation the verifier applies — they must lay out a trace of job.steps
+     * steps.  verify: ignored (the proof brings them). */
+    const uint32_t *input_shapes;
+    /* verify: one entry per static register (nstatic of them, the secret ones last); NULL = all cyclic.  static_values / static_periods
+     * then list the GS_STATIC_CYCLE registers only, in order. */
+    const struct gs_static_source *static_sources;
+    /* verify: the values of the PUBLIC input registers in declaration order (Stark.verify's publicInputs, lib/Stark.ts:167), each
+     * flattened row-major over its nesting, elements of gs_element_size() bytes back to back; public_input_counts[k] = how many
+     * values public register k holds (must equal the product of its shape in the proof) */
+    const uint8_t *public_inputs; const uint64_t *public_input_counts; uint32_t npublic_inputs;
 };
 
 struct gs_prover_job {
-    uint64_t steps;
+    uint64_t steps;              /* trace length; verify with input registers: 0 = whatever the proof's shapes lay out (otherwise they must agree) */
     uint32_t extension_factor, exe_query_count, fri_query_count;
     int32_t hash_alg;
     uint8_t root_of_unity[GS_PROVER_ELT_MAX];   /* primitive (steps*extension_factor)-th root: galois getRootOfUnity, computed by the caller */
     const gs_assertion *assertions;
     uint32_t nassertions;
+    /* 0: root_of_unity has order steps * extension_factor.  k > 0: it has order 2^k and the driver squares it down to the order of
+     * the evaluation domain (getRootOfUnity(n) = getRootOfUnity(2n)^2 for the generator galois picks) — what a verifier passes when
+     * the trace length comes with the proof */
+    uint32_t root_of_unity_log2;
     struct gs_prover_air air;
 };
 
@@ -109,8 +145,9 @@ int gs_prover_prove_on(const gs_prover_binding *b, gs_ctx *ctx, const struct gs_
  * reads of it the sizes, query counts, hash, root of unity, assertions and, of the AIR, kind / registers / nsecret / degrees and
  * (kind 0) round_constants or (kind 1) e_code, consts, vm_regs, static_values / static_periods / nstatic (public registers first;
  * the trailing nsecret entries are the secret ones, whose values come with the proof).  No gs_ctx: nothing touches a device; the
- * binding supplies the library's host-side helpers (index generator, small interpolation).  The job states the trace length: a proof that
- * carries input shapes (the reference sizes the trace from them) is GS_ERR_UNSUPPORTED, and the number of FRI layers and the remainder
+ * binding supplies the library's host-side helpers (index generator, small interpolation).  An AIR with input registers (air.ninputs,
+ * air.static_sources, air.public_inputs) is sized from the shapes the proof carries, as the reference does (lib/Stark.ts:176); for any
+ * other AIR the job states the trace length and a proof that carries shapes is malformed.  The number of FRI layers and the remainder
  * length must be the ones the domain implies (fold while more than 256 values are left) — anything else is a malformed proof. */
 int gs_prover_verify(const struct gs_prover_job *job, const uint8_t *proof, uint64_t len, char *err, uint64_t errcap);
 int gs_prover_verify_on(const gs_prover_binding *b, const struct gs_prover_job *job, const uint8_t *proof, uint64_t len, char *err, uint64_t errcap);

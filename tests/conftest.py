@@ -76,18 +76,10 @@ def native_same_bytes(stark, assertions, inputs, seed, data):
     got = nat.prove_bytes(assertions, inputs, seed)
     assert got == data, 'native driver and mirror disagree'
     # ... and the native verifier (csrc/verifier.h) accepts it, and rejects it with a bit flipped in the middle
-    if not getattr(stark.air, 'inputShapesInProof', False):
-        try:
-            assert nat.verify_bytes(assertions, got) is True
-        except Exception as e:      # noqa: BLE001
-            from genstark_amd._abi import GstarkError
-            if not isinstance(e, GstarkError):           # (proofs with input shapes go to the Python verifier)
-                raise
-        else:
-            from genstark_amd.errors import StarkError
-            import pytest
-            bad = bytearray(got)
-            bad[len(bad) // 2] ^= 0x10
-            with pytest.raises(StarkError):
-                nat.verify_bytes(assertions, bytes(bad))
+    assert nat.verify_bytes(assertions, got) is True
+    from genstark_amd.errors import StarkError
+    bad = bytearray(got)
+    bad[len(bad) // 2] ^= 0x10
+    with pytest.raises(StarkError):
+        nat.verify_bytes(assertions, bytes(bad))
     return got

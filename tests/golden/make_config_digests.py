@@ -38,8 +38,9 @@ def oracle_for(omp=False):
 
 def digest(name, omp=False):
     import config_runs
-    be, p, a, inputs, seed = config_runs.statement(name, oracle_for(omp))
+    be, p, a, inputs, seed, public = config_runs.statement(name, oracle_for(omp))
     data = p.prove_bytes(a, inputs, seed)
+    assert p.verify_native(a, data, public) is True
     return {'name': name, 'proof_bytes': len(data), 'proof_sha256': hashlib.sha256(data).hexdigest()}
 
 

@@ -32,6 +32,48 @@ def without_shapes(stark, proof):
     return stark.serialize(dict(proof, iShapes=[]))
 
 
+def check_native_shaped(stark, options, assertions, inputs, seed, public, data, sweep=60):
+    """The product entry on an air-assembly component WITH input registers (genstark_amd.prover.Prover -> csrc/prover.cc, csrc/verifier.h):
+    * prove_bytes == the mirror's serialized proof, input shapes included (lib/Stark.ts:157-162);
+    * verify_native sizes the trace from the shapes IN THE PROOF (initVerificationContext(proof.iShapes, publicInputs), lib/Stark.ts:176),
+      lays the public registers out itself and gives the mirror's verdict — and the mirror's message — on the valid proof, on wrong
+      public inputs, and on a sweep of corruptions over the whole proof, its shape bytes included."""
+    import random
+    from genstark_amd.prover import Prover
+    p = Prover(stark.air, options)
+    assert p.prove_bytes(assertions, inputs, seed) == data
+    assert p.verify_native(assertions, data, public) is True
+
+    def verdict(verify, blob):
+        try:
+            return ('ok', '') if verify(blob) else ('false', '')
+        except (StarkError, GstarkError) as e:
+            return ('rejected', str(e).split(':')[0])
+        except (IndexError, ValueError, OverflowError, MemoryError) as e:      # the mirror's parser on a truncated proof
+            return ('rejected', 'malformed')
+    mirror = lambda blob: stark.verify(assertions, stark.parse(blob), public)
+    native = lambda blob: p.verify_native(assertions, blob, public)
+    rng = random.Random(len(data))
+    offsets = sorted(set([0, 31, 32, 33, len(data) - 1] + [rng.randrange(len(data)) for _ in range(sweep)]))
+    agree = 0
+    for off in offsets:
+        bad = bytearray(data)
+        bad[off] ^= 1 << rng.randrange(8)
+        got = [verdict(v, bytes(bad)) for v in (mirror, native)]
+        assert got[0][0] == got[1][0] == 'rejected', (off, got)
+        agree += got[0][1] == got[1][1] or got[0][1].startswith('Verification of low degree failed') or 'malformed' in got[0][1] + got[1][1]
+    assert agree == len(offsets)
+    for cut in (0, 1, 40, len(data) // 2, len(data) - 1, len(data) - 5):
+        assert verdict(native, data[:cut])[0] == 'rejected'
+    return p
+
+
+def shape_bytes(stark, data):
+    """(offset, length) of the serialized input shapes at the end of a proof (lib/Serializer.ts:70-78)"""
+    n = 1 + sum(1 + 4 * len(sh) for sh in stark.parse(data)['iShapes'])
+    return len(data) - n, n
+
+
 # ---- own fixtures ---------------------------------------------------------------------------------------------------------------------
 def check_cube_chain(backend):
     f = PrimeField(backend=backend)
@@ -91,6 +133,22 @@ def check_ledger(backend, runs):
         stark.verify(assertions, stark.parse(data), [other])
     with pytest.raises(StarkError):
         stark.verify([dict(assertions[1], value=model[last][2] ^ 1)], stark.parse(data), [deposits])
+    # ---- the product entry: native prove() with the shapes in the proof, native verify() sized from them
+    opts = {'hashAlgorithm': 'sha256', 'exeQueryCount': 24, 'friQueryCount': 12}
+    p = check_native_shaped(stark, opts, assertions, inputs, None, [deposits], data)
+    for wrong, msg in (([other], 'linear combination correctness'), ([], 'public input registers are needed'), ([deposits[:-1]], 'values expected')):
+        with pytest.raises(StarkError, match=msg):
+            p.verify_native(assertions, data, wrong)
+    with pytest.raises(StarkError, match='linear combination correctness'):
+        p.verify_native([dict(assertions[1], value=model[last][2] ^ 1)], data, [deposits])
+    # every byte of the serialized shapes matters: a changed rank, dimension or count is a different layout (or none at all)
+    at, n = shape_bytes(stark, data)
+    assert n == 1 + (1 + 4) + (1 + 4) + (1 + 8)
+    for k in range(n):
+        bad = bytearray(data)
+        bad[at + k] ^= 1
+        with pytest.raises(StarkError):
+            p.verify_native(assertions, bytes(bad), [deposits])
     return data
 
 
@@ -156,6 +214,7 @@ def test_reference_lib128_source_equals_hand_transcription(oracle_backend):
     proof = stark.prove(assertions, raw)                                                  # lib128.ts:61-64: prove(assertions, inputs)
     assert without_shapes(stark, proof) == want and proof['iShapes'] == [[2]] * 4
     assert stark.verify(assertions, stark.parse(stark.serialize(proof)))
+    check_native_shaped(stark, LIB_OPTS, assertions, raw, None, None, stark.serialize(proof), sweep=25)      # four secret input registers
     # ComputeMerkleRoot with its public index-bit register (lib128.ts:97-112)
     tree, leaf, nodes, bits = merkle_case(f, 4, 5)
     air = lib128.compute_merkle_root_air(f, bits)
@@ -171,6 +230,9 @@ def test_reference_lib128_source_equals_hand_transcription(oracle_backend):
     assert stark.verify(assertions, stark.parse(data), [[bits]])                         # lib128.ts:112: verify(assertions, proof, [[indexBits]])
     with pytest.raises(StarkError):
         stark.verify(assertions, stark.parse(data), [[[bits[0], 1 - bits[1]] + bits[2:]]])
+    nat = check_native_shaped(stark, LIB_OPTS, assertions, raw, None, [[bits]], data, sweep=25)               # ... and a public one, nested
+    with pytest.raises(StarkError, match='linear combination correctness'):
+        nat.verify_native(assertions, data, [[[bits[0], 1 - bits[1]] + bits[2:]]])
     assert airassembly.AssemblyAir(src, 'ComputeMerkleUpdate', 32, f).constraintDegrees == [8] * 24 + [2]
 
 
@@ -199,6 +261,7 @@ def test_reference_224_bit_sources_equal_hand_transcriptions():
     stark = airassembly.instantiate(os.path.join(REF, 'examples', 'elliptic', 'pointmul.aa'), 'default', EC_OPTIONS, field=f)
     proof = stark.prove(assertions, raw)                                                  # pointMul.ts:39
     assert without_shapes(stark, proof) == want and proof['iShapes'] == [[1], [1], [1, 256]]
+    check_native_shaped(stark, EC_OPTIONS, assertions, raw, None, None, stark.serialize(proof), sweep=10)      # the 224-bit flavour of driver and verifier
     src = open(os.path.join(REF, 'assembly', 'lib224.aa')).read()
     degrees = {c: airassembly.AssemblyAir(src, c, 32, f).constraintDegrees for c in ('ComputePoseidonHash', 'ComputeMerkleRoot', 'ComputeMerkleUpdate', 'VerifySchnorrSignature')}
     assert degrees == {'ComputePoseidonHash': [7] * 3, 'ComputeMerkleRoot': [8] * 6, 'ComputeMerkleUpdate': [8] * 12 + [2], 'VerifySchnorrSignature': lib224.SCHNORR_DEGREES}

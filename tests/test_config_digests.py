@@ -24,7 +24,7 @@ def test_every_configuration_is_anchored():
     assert all(len(r['proof_sha256']) == 64 and r['proof_bytes'] > 0 for r in WANT.values())
 
 
-@pytest.mark.parametrize('name', ['C1_foo', 'C2_E8', 'C2_E16', 'C3', 'C4'])
+@pytest.mark.parametrize('name', ['C1_foo', 'C2_E8', 'C2_E16', 'C3', 'C4', 'X_shaped'])
 def test_digest_on_the_oracle(oracle_backend, name):
     import make_config_digests
     got = make_config_digests.digest(name)
@@ -51,8 +51,8 @@ def test_digest_on_hip(hip_backend, name):
     def hip(modulus, jit):
         be = Backend(device=0) if modulus is None else Backend(device=0, modulus=modulus)
         return be.jit() if jit else be
-    be, p, a, inputs, seed = config_runs.statement(name, hip)
+    be, p, a, inputs, seed, public = config_runs.statement(name, hip)
     data = p.prove_bytes(a, inputs, seed)
     assert (len(data), hashlib.sha256(data).hexdigest()) == (WANT[name]['proof_bytes'], WANT[name]['proof_sha256'])
     if name != 'C4_long':
-        assert p.verify_native(a, data) is True
+        assert p.verify_native(a, data, public) is True

@@ -247,8 +247,8 @@ def test_native_verifier_hip(hip_backend):
 
 def test_native_verifier_refuses_structures_the_prover_never_emits(oracle_backend):
     """the number of FRI layers and the remainder length are functions of the domain (LowDegreeProver.ts:179) — a proof
-    with appended layers (which would floor the remainder's degree bound to zero) is malformed; a proof carrying input shapes is
-    UNSUPPORTED (never checked against job.steps alone); a MiMC job whose round-constant count does not divide the trace is invalid."""
+    with appended layers (which would floor the remainder's degree bound to zero) is malformed; a proof carrying input shapes for an AIR
+    that declares no input registers is malformed (never checked against job.steps alone); a MiMC job whose round-constant count does not divide the trace is invalid."""
     import copy
     from genstark_amd._abi import GstarkError
     case = GOLDEN[0]
@@ -277,8 +277,8 @@ def test_native_verifier_refuses_structures_the_prover_never_emits(oracle_backen
         nat.verify_bytes(assertions, stark.serialize(short))
     shaped = copy.deepcopy(proof)
     shaped['iShapes'] = [[4]]
-    with pytest.raises(GstarkError, match='input shapes'):
-        nat.verify_bytes(assertions, stark.serialize(shaped))
+    with pytest.raises(StarkError, match='1 input shapes for an AIR without input registers'):      # (sized from its shapes only if the AIR
+        nat.verify_bytes(assertions, stark.serialize(shaped))                                         #  declares input registers)
     # a MiMC statement whose round constants cannot be a cyclic register of this trace
     keep = stark.air.roundConstants
     try:

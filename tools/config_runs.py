@@ -22,6 +22,10 @@ CONFIGS = {   # name -> (what BASELINE.json calls it, timed proofs)
     'C4': ('configs[3]: Poseidon 6x128, 2^16 steps = 1024 hash chains, E = 16, exe 48, fri 24, blake2s256', 20),
     'C4_long': ('configs[3] at 2^20 steps = 16384 hash chains (the strong-scaling statement of --gpus N)', 5),
     'C5': ('configs[4]: MiMC-128, 2^20 steps, extensionFactor 16, exe 48, fri 64, blake2s256 (the headline)', 5),
+    # not a BASELINE configuration: an air-assembly component WITH input registers (the shape of the reference's assembly/lib128.aa
+    # statements), so that prove_ms / verify_native_ms also cover a proof that carries input shapes (lib/Stark.ts:161,176)
+    'X_shaped': ('extra: tests/golden/aa/ledger.aa (this repository\'s module: 2 secret + 1 public input register, nested shapes, masks), 4096 runs = 2^15 steps, '
+                 'E = 16, sha256, exe 24, fri 12; the proof carries iShapes and verify_native sizes the trace from them', 10),
 }
 
 
@@ -42,8 +46,22 @@ def statement(name, backend_for):
     from genstark_amd.field import PrimeField
     from genstark_amd.prover import Prover
     opts = lambda ef, exe, fri: {'hashAlgorithm': 'blake2s256', 'extensionFactor': ef, 'exeQueryCount': exe, 'friQueryCount': fri}
-    inputs = []
-    if name == 'C1_foo':
+    inputs, public = [], None
+    if name == 'X_shaped':
+        from genstark_amd import airassembly
+        be = backend_for(None, True)
+        f = PrimeField(backend=be)
+        o = {'hashAlgorithm': 'sha256', 'exeQueryCount': 24, 'friQueryCount': 12}
+        air = airassembly.AssemblyAir(open(os.path.join(ROOT, 'tests', 'golden', 'aa', 'ledger.aa')).read(), 'default', None, f)
+        runs = 4096
+        balances, factors = [100 + 7 * i for i in range(runs)], [3 + i for i in range(runs)]
+        deposits = [[5 + i + 2 * j for j in range(4)] for i in range(runs)]
+        inputs, public, seed = [balances, factors, deposits], [deposits], None
+        tr = air.initProvingContext(inputs).generateExecutionTrace()
+        last = 8 * runs - 1
+        a = [{'step': 0, 'register': 0, 'value': balances[0]}, {'step': last, 'register': 2, 'value': tr.getValue(2, last)}]
+        p = Prover(air, o)
+    elif name == 'C1_foo':
         from genstark_amd.air_generic import GenericAir
         be = backend_for(MODULUS_32, True)
         f = PrimeField(backend=be)
@@ -75,7 +93,7 @@ def statement(name, backend_for):
             a = [{'step': 0, 'register': 0, 'value': 1}, {'step': t - 64, 'register': 2, 'value': 3 + t // 64 - 1}]
             p = Prover(air, opts(16, 48, 24))
         seed = p.pack_seed(seeds)
-    return be, p, a, inputs, seed
+    return be, p, a, inputs, seed, public
 
 
 def child(name, reps):
@@ -84,7 +102,7 @@ def child(name, reps):
     def hip(modulus, jit):
         be = Backend(device=0) if modulus is None else Backend(device=0, modulus=modulus)
         return be.jit() if jit else be
-    be, p, a, inputs, seed = statement(name, hip)
+    be, p, a, inputs, seed, public = statement(name, hip)
     for _ in range(3):
         data = p.prove_bytes(a, inputs, seed)       # plans, block cache, compiled programs (hiprtc or the disk cache)
     be.sync()
@@ -111,7 +129,7 @@ def child(name, reps):
     p.prove_bytes(a, inputs, seed)                    # (the measuring proof stays the LAST one of the child: busy_from_db steps back over it)
     tv = time.perf_counter()
     for _ in range(5):
-        assert p.verify_native(a, data) is True        # Stark.verify natively (csrc/verifier.h): CPU only
+        assert p.verify_native(a, data, public) is True        # Stark.verify natively (csrc/verifier.h): CPU only
     verify_ms = (time.perf_counter() - tv) / 5 * 1e3
     import hashlib
     print(json.dumps({'name': name, 'proof_sha256': hashlib.sha256(data).hexdigest(), 'assertions': len(a), 'traffic': traffic, 'prove_ms': round(ms, 4), 'prove_ms_min_max': [round(each[0], 4), round(each[-1], 4)], 'verify_native_ms': round(verify_ms, 4), 'driver_ms': st['total_ms'], 'proof_bytes': len(data), 'proofs_timed': reps,
