@@ -85,6 +85,8 @@ def _driver(backend):
     path = PROVER_LIB_PATHS.get(backend.modulus)
     if path is None:
         raise GstarkError(f'no build of the native driver for the field of {backend.modulus} elements')
+    if os.environ.get('GSTARK_PROVER_LIB_DIR'):       # instrumented builds of the same driver (tools/build_sanitized.sh): same file names, another directory
+        path = os.path.join(os.environ['GSTARK_PROVER_LIB_DIR'], os.path.basename(path))
     with _bound_lock:
         lib = _libs.get(path)
         if lib is None:

@@ -23,7 +23,7 @@ function native(modulus) {
         const wanted = modulus === undefined ? MODULUS : BigInt(modulus);
         if (!process.env.GSTARK_LIB && !LIBRARIES.has(wanted)) throw new TypeError(`no build of the library for the field of ${wanted} elements`);
         const lib = process.env.GSTARK_LIB || path.join(__dirname, '..', 'genstark_amd', 'csrc', LIBRARIES.get(wanted));
-        const a = require(path.join(__dirname, '..', 'napi', 'gstark_napi.node'));
+        const a = require(process.env.GSTARK_ADDON || path.join(__dirname, '..', 'napi', 'gstark_napi.node'));      // GSTARK_ADDON: an instrumented build (tools/build_sanitized.sh)
         const name = a.load(lib);
         if (name !== 'hip-gfx950' && process.env.GSTARK_ALLOW_TEST_DOUBLE !== '1') {
             throw new Error(`refusing backend ${name}: the product path runs on hip-gfx950 only (no CPU fallback)`);

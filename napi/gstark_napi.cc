@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <numeric>
 #include <string>
 #include <vector>
 
@@ -95,6 +96,14 @@ const FnDesc kFns[] = {
     {"gs_small_eval_poly", "bibio"},
 };
 
+// napi_get_buffer_info on a value that is not a Buffer ABORTS the process in node 12 (an assertion inside node::Buffer::Data, found by
+// tests/addon_validation.js): ask first
+bool buffer_info(napi_env env, napi_value v, void **data, size_t *len) {
+    bool is = false;
+    if (napi_is_buffer(env, v, &is) != napi_ok || !is) return false;
+    return napi_get_buffer_info(env, v, data, len) == napi_ok;
+}
+
 bool get_u64(napi_env env, napi_value v, uint64_t *out) {
     napi_valuetype t;
     if (napi_typeof(env, v, &t) != napi_ok) return false;
@@ -121,9 +130,10 @@ napi_value Call(napi_env env, napi_callback_info info) {
     napi_value argv[20];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     if (argc < 1) { napi_throw_type_error(env, nullptr, "call(name, ...args)"); return nullptr; }
+    if (!g_lib) { napi_throw_error(env, nullptr, "call load(path) first"); return nullptr; }
     char name[64];
     size_t len;
-    NAPI_OK(env, napi_get_value_string_utf8(env, argv[0], name, sizeof name, &len));
+    if (napi_get_value_string_utf8(env, argv[0], name, sizeof name, &len) != napi_ok) { napi_throw_type_error(env, nullptr, "call(name, ...args): the name is a string"); return nullptr; }
     const FnDesc *d = nullptr;
     for (const FnDesc &f : kFns)
         if (!strcmp(f.name, name)) d = &f;
@@ -143,7 +153,7 @@ napi_value Call(napi_env env, napi_callback_info info) {
         switch (d->sig[i]) {
             case 'c': {
                 void *p;
-                NAPI_OK(env, napi_get_value_external(env, v, &p));
+                if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_type_error(env, nullptr, (std::string(name) + ": expected a context").c_str()); return nullptr; }
                 ctx = (gs_ctx *)p;
                 a[i] = (uintptr_t)p;
                 break;
@@ -157,7 +167,7 @@ napi_value Call(napi_env env, napi_callback_info info) {
             case 'b': case 'o': {
                 void *data;
                 size_t blen;
-                if (napi_get_buffer_info(env, v, &data, &blen) != napi_ok) { napi_throw_type_error(env, nullptr, (std::string(name) + ": expected a Buffer").c_str()); return nullptr; }
+                if (!buffer_info(env, v, &data, &blen)) { napi_throw_type_error(env, nullptr, (std::string(name) + ": expected a Buffer").c_str()); return nullptr; }
                 a[i] = (uintptr_t)data;
                 break;
             }
@@ -213,7 +223,7 @@ napi_value Load(napi_env env, napi_callback_info info) {
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     char path[1024];
     size_t len;
-    NAPI_OK(env, napi_get_value_string_utf8(env, argv[0], path, sizeof path, &len));
+    if (argc < 1 || napi_get_value_string_utf8(env, argv[0], path, sizeof path, &len) != napi_ok) { napi_throw_type_error(env, nullptr, "load(path)"); return nullptr; }
     void *lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
     if (!lib) { napi_throw_error(env, nullptr, (std::string("cannot load ") + path + ": " + dlerror() + " (there is no CPU fallback)").c_str()); return nullptr; }
     typedef const char *(*namefn)(void);
@@ -271,7 +281,8 @@ napi_value CtxDestroy(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     void *p;
-    NAPI_OK(env, napi_get_value_external(env, argv[0], &p));
+    if (!g_lib) { napi_throw_error(env, nullptr, "call load(path) first"); return nullptr; }
+    if (argc < 1 || napi_get_value_external(env, argv[0], &p) != napi_ok || !p) { napi_throw_type_error(env, nullptr, "ctxDestroy(ctx)"); return nullptr; }
     typedef void (*dfn)(gs_ctx *);
     ((dfn)dlsym(g_lib, "gs_ctx_destroy"))((gs_ctx *)p);
     napi_value undef;
@@ -285,9 +296,9 @@ napi_value Alloc(napi_env env, napi_callback_info info) {
     napi_value argv[2];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     void *p;
-    NAPI_OK(env, napi_get_value_external(env, argv[0], &p));
+    if (!g_lib) { napi_throw_error(env, nullptr, "call load(path) first"); return nullptr; }
     uint64_t bytes;
-    if (!get_u64(env, argv[1], &bytes)) { napi_throw_type_error(env, nullptr, "alloc(ctx, bytes)"); return nullptr; }
+    if (argc < 2 || napi_get_value_external(env, argv[0], &p) != napi_ok || !p || !get_u64(env, argv[1], &bytes)) { napi_throw_type_error(env, nullptr, "alloc(ctx, bytes)"); return nullptr; }
     typedef int (*afn)(gs_ctx *, uint64_t, void **);
     void *d = nullptr;
     int rc = ((afn)dlsym(g_lib, "gs_alloc"))((gs_ctx *)p, bytes, &d);
@@ -303,16 +314,17 @@ napi_value MerkleProveBatch(napi_env env, napi_callback_info info) {
     napi_value argv[5];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     void *p;
-    NAPI_OK(env, napi_get_value_external(env, argv[0], &p));
+    if (!g_lib) { napi_throw_error(env, nullptr, "call load(path) first"); return nullptr; }
     uint64_t leaves, nodes, n;
-    if (!get_u64(env, argv[1], &leaves) || !get_u64(env, argv[2], &nodes) || !get_u64(env, argv[3], &n)) { napi_throw_type_error(env, nullptr, "merkleProveBatch: bad arguments"); return nullptr; }
+    if (argc < 5 || napi_get_value_external(env, argv[0], &p) != napi_ok || !p || !get_u64(env, argv[1], &leaves) || !get_u64(env, argv[2], &nodes) ||
+        !get_u64(env, argv[3], &n) || n < 2 || (n & (n - 1)) || n > (1ull << 40)) { napi_throw_type_error(env, nullptr, "merkleProveBatch: bad arguments"); return nullptr; }
     uint32_t count;
-    NAPI_OK(env, napi_get_array_length(env, argv[4], &count));
+    if (napi_get_array_length(env, argv[4], &count) != napi_ok || count > (1u << 20)) { napi_throw_type_error(env, nullptr, "merkleProveBatch: bad index list"); return nullptr; }
     std::vector<uint64_t> idx(count);
     for (uint32_t k = 0; k < count; k++) {
         napi_value e;
         NAPI_OK(env, napi_get_element(env, argv[4], k, &e));
-        if (!get_u64(env, e, &idx[k])) { napi_throw_type_error(env, nullptr, "merkleProveBatch: bad index"); return nullptr; }
+        if (!get_u64(env, e, &idx[k]) || idx[k] >= n) { napi_throw_type_error(env, nullptr, "merkleProveBatch: bad index"); return nullptr; }
     }
     int depth = 0;
     while ((1ull << depth) < n) depth++;
@@ -394,7 +406,7 @@ typedef int (*verify_on_fn)(const gs_prover_binding *, const gs_prover_job *, co
 napi_value verify_instead(napi_env env, napi_value proof_value, const gs_prover_job &job) {
     void *d;
     size_t len;
-    if (napi_get_buffer_info(env, proof_value, &d, &len) != napi_ok) { napi_throw_type_error(env, nullptr, "the proof must be a Buffer"); return nullptr; }
+    if (!buffer_info(env, proof_value, &d, &len)) { napi_throw_type_error(env, nullptr, "the proof must be a Buffer"); return nullptr; }
     char err[512] = {0};
     const int rc = ((verify_on_fn)dlsym(g_prover, "gs_prover_verify_on"))(g_binding, &job, (const uint8_t *)d, len, err, sizeof err);
     if (rc != GS_OK) { napi_throw_error(env, nullptr, err[0] ? err : "verification failed"); return nullptr; }
@@ -407,13 +419,17 @@ napi_value ProveMimcSerialized(napi_env env, napi_callback_info info) {
     napi_value argv[4];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     void *ctx;
-    NAPI_OK(env, napi_get_value_external(env, argv[0], &ctx));
     if (!g_lib) { napi_throw_error(env, nullptr, "call load(path) first"); return nullptr; }
+    napi_valuetype job_type;
+    if (argc < 3 || napi_get_value_external(env, argv[0], &ctx) != napi_ok || !ctx || napi_typeof(env, argv[2], &job_type) != napi_ok || job_type != napi_object) {
+        napi_throw_type_error(env, nullptr, "(ctx, proverLibPath, job[, proof])");
+        return nullptr;
+    }
     if (!open_driver(env, argv[1])) return nullptr;
     const size_t es = g_es;
     auto prop = [&](const char *name) { napi_value v; napi_get_named_property(env, argv[2], name, &v); return v; };
     auto u64 = [&](const char *name, uint64_t *out) { return get_u64(env, prop(name), out); };
-    auto bytes = [&](napi_value v, const uint8_t **data, size_t *len) { void *d; bool ok = napi_get_buffer_info(env, v, &d, len) == napi_ok; *data = (const uint8_t *)d; return ok; };
+    auto bytes = [&](napi_value v, const uint8_t **data, size_t *len) { void *d; bool ok = buffer_info(env, v, &d, len); *data = (const uint8_t *)d; return ok; };
     gs_prover_job job;
     memset(&job, 0, sizeof job);
     uint64_t t, ef, exe, fri, alg, klen, ktab;
@@ -472,13 +488,17 @@ napi_value ProveGenericSerialized(napi_env env, napi_callback_info info) {
     napi_value argv[4];
     NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     void *ctx;
-    NAPI_OK(env, napi_get_value_external(env, argv[0], &ctx));
     if (!g_lib) { napi_throw_error(env, nullptr, "call load(path) first"); return nullptr; }
+    napi_valuetype job_type;
+    if (argc < 3 || napi_get_value_external(env, argv[0], &ctx) != napi_ok || !ctx || napi_typeof(env, argv[2], &job_type) != napi_ok || job_type != napi_object) {
+        napi_throw_type_error(env, nullptr, "(ctx, proverLibPath, job[, proof])");
+        return nullptr;
+    }
     if (!open_driver(env, argv[1])) return nullptr;
     const size_t es = g_es;
     auto prop = [&](const char *name) { napi_value v; napi_get_named_property(env, argv[2], name, &v); return v; };
     auto u64 = [&](const char *name, uint64_t *out) { return get_u64(env, prop(name), out); };
-    auto bytes = [&](napi_value v, const uint8_t **data, size_t *len) { void *d; bool ok = napi_get_buffer_info(env, v, &d, len) == napi_ok; *data = (const uint8_t *)d; return ok; };
+    auto bytes = [&](napi_value v, const uint8_t **data, size_t *len) { void *d; bool ok = buffer_info(env, v, &d, len); *data = (const uint8_t *)d; return ok; };
     auto words = [&](const char *name, std::vector<uint32_t> &out) {
         napi_value arr = prop(name);
         uint32_t n = 0;
@@ -503,7 +523,8 @@ napi_value ProveGenericSerialized(napi_env env, napi_callback_info info) {
         !bytes(prop("rootOfUnity"), &rou, &nrou) || nrou != es || !bytes(prop("consts"), &consts, &nconsts) || nconsts % es ||
         !bytes(prop("staticValues"), &svals, &nsvals) || !bytes(prop("firstRows"), &first, &nfirst) || !words("degrees", degrees) || !words("tCode", tcode) ||
         !words("iCode", icode) || !words("eCode", ecode) || !words("staticPeriods", periods) || !words("staticLens", lens32) || tcode.size() % 4 || icode.size() % 4 ||
-        ecode.size() % 4 || lens32.size() != periods.size() || nfirst != (segments ? segments : 1) * regs * es) {
+        ecode.size() % 4 || lens32.size() != periods.size() || nfirst != (segments ? segments : 1) * regs * es ||
+        nsvals < es * std::accumulate(periods.begin(), periods.end(), (uint64_t)0)) {
         napi_throw_type_error(env, nullptr, "proveGenericSerialized: malformed job");
         return nullptr;
     }

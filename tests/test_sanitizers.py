@@ -1,0 +1,85 @@
+"""The sanitizer tier: the host-side code that parses bytes it does not control — the native verifier and driver
+(csrc/verifier.h, prover.cc, prover_dist.h: serialized proofs and caller-built job structs) and the N-API addon (napi/gstark_napi.cc:
+types and lengths chosen by JavaScript) — built with -fsanitize=address,undefined (tools/build_sanitized.sh) and driven with corrupted
+input.  The reference trusts nothing it parses either (lib/Stark.ts:167-248, lib/Serializer.ts:83-144 throw on malformed input).
+A sanitizer report aborts the child process: the tests assert exit code 0 and the workers' own summary lines.  CPU only; skipped when
+the image has no libasan."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ORACLE_LIB, ROOT, _build_oracle
+
+
+def _gcc_file(name):
+    try:
+        path = subprocess.check_output(['gcc', f'-print-file-name={name}'], text=True).strip()
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return path if os.path.isabs(path) and os.path.exists(path) else None
+
+
+ASAN, STDCPP = _gcc_file('libasan.so'), _gcc_file('libstdc++.so')
+pytestmark = pytest.mark.skipif(not (ASAN and STDCPP), reason='libasan is not in this image')
+
+
+@pytest.fixture(scope='module')
+def sanitized():
+    _build_oracle()
+    out = subprocess.check_output(['bash', os.path.join(ROOT, 'tools', 'build_sanitized.sh')], text=True).strip().splitlines()[-1]
+    assert os.path.exists(os.path.join(out, 'libgstark_prover.so')) and os.path.exists(os.path.join(out, 'libgstark_prover_q32.so'))
+    return out
+
+
+def san_env(sanitized, **extra):
+    return dict(os.environ, LD_PRELOAD=f'{ASAN}:{STDCPP}', ASAN_OPTIONS='detect_leaks=0:abort_on_error=0', UBSAN_OPTIONS='halt_on_error=1:print_stacktrace=1',
+                GSTARK_PROVER_LIB_DIR=sanitized, **extra)
+
+
+def run_clean(cmd, env, expect, timeout=900):
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0 and expect in r.stdout, tail
+    assert 'AddressSanitizer' not in r.stderr and 'runtime error:' not in r.stderr, tail
+    return r.stdout
+
+
+def test_verifier_survives_corrupted_proofs(sanitized):
+    """>= 5 000 corrupted / truncated / extended proofs per (AIR, hash algorithm) through gs_prover_verify_on of the instrumented driver:
+    MiMC, a program AIR (Poseidon), the ledger module whose proofs carry input shapes, and the 32-bit flavour — 35 000 in all; none is
+    accepted, none produces a report."""
+    out = run_clean([sys.executable, os.path.join(ROOT, 'tests', 'sanitizer_worker.py'), 'verify', '5000'], san_env(sanitized), 'sanitized verify: 35000 corrupted proofs, 0 accepted')
+    assert 'no report' in out
+
+
+def test_driver_refuses_bad_jobs_cleanly(sanitized):
+    """gs_prover_prove_on of the instrumented driver on the error cases of test_native_prover_errors (false assertions, steps / registers out
+    of range) for every statement kind, and on input shapes that lay out another trace than the job's, too few or absurdly many values."""
+    run_clean([sys.executable, os.path.join(ROOT, 'tests', 'sanitizer_worker.py'), 'prove'], san_env(sanitized), 'sanitized prove: 33 refused jobs')
+
+
+@pytest.mark.skipif(not (shutil.which('node') and os.path.exists('/usr/include/node/node_api.h')), reason='node or its headers are not in this image')
+def test_addon_argument_validation_under_sanitizers(sanitized):
+    """tests/addon_validation.js (71 malformed calls: no library, wrong types and arity, short Buffers, inconsistent job objects, garbage
+    proofs) and the façade's own smoke run (js/smoke.js: every member of the galois / merkle surface once) on the instrumented addon and
+    driver."""
+    addon = os.path.join(sanitized, 'gstark_napi.node')
+    assert os.path.exists(addon)
+    env = san_env(sanitized, GSTARK_ADDON=addon, GSTARK_LIB=ORACLE_LIB, GSTARK_PROVER_LIB=os.path.join(sanitized, 'libgstark_prover.so'), GSTARK_ALLOW_TEST_DOUBLE='1')
+    run_clean(['node', os.path.join(ROOT, 'tests', 'addon_validation.js')], env, 'addon validation OK: 71 malformed calls refused')
+    run_clean(['node', os.path.join(ROOT, 'js', 'smoke.js')], env, 'js smoke OK')
+
+
+def test_addon_argument_validation_plain_build():
+    """the same script on the shipped build of the addon (what test_napi_addon.py loads): the refusals do not depend on instrumentation"""
+    if not (shutil.which('node') and os.path.exists('/usr/include/node/node_api.h')):
+        pytest.skip('node or its headers are not in this image')
+    _build_oracle()
+    subprocess.check_call(['bash', os.path.join(ROOT, 'napi', 'build.sh')])
+    env = dict(os.environ, GSTARK_ADDON=os.path.join(ROOT, 'napi', 'gstark_napi.node'), GSTARK_LIB=ORACLE_LIB,
+               GSTARK_PROVER_LIB=os.path.join(ROOT, 'genstark_amd', 'csrc', 'libgstark_prover.so'))
+    r = subprocess.run(['node', os.path.join(ROOT, 'tests', 'addon_validation.js')], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'addon validation OK: 71' in r.stdout, (r.stdout + r.stderr)[-2000:]

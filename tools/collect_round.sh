@@ -9,6 +9,8 @@ out=$root/gpurun_out/$tag
 mkdir -p $out
 cd $root
 bash tools/checkpoint.sh $tag
+# the sanitizer tier (CPU: ASAN + UBSAN builds of driver, verifier and addon on corrupted input; tests/test_sanitizers.py)
+(time python3 -m pytest tests/test_sanitizers.py -q) > $out/sanitizer_tier.txt 2>&1; grep -E "passed|failed|skipped" $out/sanitizer_tier.txt | tail -1
 bash tools/collect_timelines.sh $tag 2>&1 | grep -E "proofs,"
 bash tools/collect_generic_timelines.sh $tag 2>&1 | grep -E "proofs,"
 cd /tmp && export TMPDIR=/tmp
