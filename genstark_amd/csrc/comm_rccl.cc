@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
 #include <vector>
 
 #include "../../include/gstark_comm.h"
@@ -23,7 +24,7 @@ struct RcclState {
     int rank = 0, size = 1, device = 0;
     void *(*stream_of)(gs_ctx *) = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, spare;
-    bool no_alltoall = false;     // ncclAllToAll was refused once: grouped ncclSend / ncclRecv from then on
+    bool no_alltoall = false;     // fixed at creation (GSTARK_RCCL_GROUPED_ALLTOALL=1): grouped ncclSend / ncclRecv instead of ncclAllToAll
     bool timings = true;          // an event pair around every collective (gs_rccl_comm_timings): each record costs the stream a few us
     char err[256] = {0};
 };
@@ -54,10 +55,12 @@ int r_all_to_all(void *self, gs_ctx *ctx, const void *send, void *recv, uint64_t
     if (!begin(s, st)) return GS_ERR_DEVICE;
     // RCCL's own all-to-all (an extension over NCCL: piece j of rank i's buffer becomes piece i of rank j's — exactly this layout; it is what
     // torch.distributed's all_to_all_single runs on ROCm, i.e. the exercised path).  The grouped send / recv form below (which includes the
-    // pair a rank forms with itself) stays as the fallback if the call is refused.
+    // pair a rank forms with itself) is the other protocol; WHICH of the two a communicator speaks is fixed when it is created
+    // (GSTARK_RCCL_GROUPED_ALLTOALL=1 in the launcher's environment, the same on every rank) — a failed call is an error, never a reason
+    // to switch protocol in the middle of a run on a communicator that is already in an error state, with ranks that may disagree.
     if (!s->no_alltoall) {
-        if (ncclAllToAll(send, recv, bytes, ncclUint8, s->comm, st) == ncclSuccess) return end(s, st) ? GS_OK : GS_ERR_DEVICE;
-        s->no_alltoall = true;
+        if (ncclAllToAll(send, recv, bytes, ncclUint8, s->comm, st) != ncclSuccess) return GS_ERR_DEVICE;
+        return end(s, st) ? GS_OK : GS_ERR_DEVICE;
     }
     bool ok = ncclGroupStart() == ncclSuccess;
     for (int h = 0; h < s->size && ok; h++) {
@@ -99,6 +102,7 @@ int gs_rccl_unique_id(uint8_t out[128]) {
 int gs_rccl_comm_create(void *abi_dl_handle, const uint8_t unique_id[128], int rank, int size, int device, gs_comm *out, char *err, uint64_t errcap) {
     if (!abi_dl_handle || !unique_id || !out || size < 1 || rank < 0 || rank >= size) return GS_ERR_ARG;
     RcclState *s = new RcclState();
+    { const char *g = getenv("GSTARK_RCCL_GROUPED_ALLTOALL"); s->no_alltoall = g && g[0] == '1'; }
     s->rank = rank; s->size = size; s->device = device;
     s->stream_of = (void *(*)(gs_ctx *))dlsym(abi_dl_handle, "gs_stream");
     auto bad = [&](const char *what, const char *detail) {

@@ -526,6 +526,8 @@ static int remainder_check_entry(const uint8_t *values, uint64_t len, uint32_t e
 void gs_prover_sync_phases(int on) { g_sync_phases = on != 0; }
 void gs_prover_member_sequence(int on) { g_member_sequence = on != 0; }
 
+int gs_prover_abi_version(void) { return GS_PROVER_ABI_VERSION; }
+
 int gs_prover_last_stats(struct gs_prover_stats *out) {
     if (!out) return GS_ERR_ARG;
     *out = g_stats;

@@ -113,6 +113,9 @@ def _driver(backend):
             lib.gs_prover_last_collectives.restype = C.c_int
             lib.gs_prover_remainder_check_on.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_char_p, C.c_int]
             lib.gs_prover_remainder_check_on.restype = C.c_int
+            lib.gs_prover_abi_version.argtypes, lib.gs_prover_abi_version.restype = [], C.c_int
+            if lib.gs_prover_abi_version() != 2:          # GS_PROVER_ABI_VERSION: the struct layouts this module mirrors (_Job, _Air, GsComm)
+                raise GstarkError(f'{path} speaks struct layout {lib.gs_prover_abi_version()}, this binding 2: rebuild (genstark_amd/csrc/build.sh)')
             if lib.gs_prover_element_size() != backend.element_size:
                 raise GstarkError(f'{path} is built for {lib.gs_prover_element_size()}-byte elements')
             _libs[path] = lib

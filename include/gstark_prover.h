@@ -134,6 +134,12 @@ typedef struct gs_prover_binding gs_prover_binding;
 int gs_prover_open(void *dl_handle, gs_prover_binding **out);
 void gs_prover_close(gs_prover_binding *b);
 int gs_prover_element_size(void);      /* of this build of the driver */
+/* Layout version of the structs of this header and of gstark_comm.h (gs_prover_job, gs_prover_air, gs_comm): a caller checks it once
+ * after loading the driver.  2: gs_prover_air gained the input-register fields and gs_prover_job root_of_unity_log2 (round 6), gs_comm
+ * solo_below (round 5).  Callers ZERO-INITIALISE every struct with sizeof of the header they were built against: a field added later
+ * reads as 0 = "not used" only if the version matches. */
+#define GS_PROVER_ABI_VERSION 2
+int gs_prover_abi_version(void);
 /* The serialized proof into out[0..cap); *len receives its size (GS_ERR_ARG with *len set when cap is too small).  On failure
  * err[0..errcap) holds the reference's message where there is one ("Assertion at step ... conflicts with execution trace"). */
 int gs_prover_prove(gs_ctx *ctx, const struct gs_prover_job *job, uint8_t *out, uint64_t cap, uint64_t *len, char *err, uint64_t errcap);

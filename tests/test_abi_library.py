@@ -148,7 +148,7 @@ def test_prover_library_exports_its_header():
     header = os.path.join(ROOT, 'include', 'gstark_prover.h')
     subprocess.check_call(['gcc', '-fsyntax-only', '-x', 'c', '-std=c11', header])
     names = set(re.findall(r'^int\s+(gs_prover_\w+)\s*\(', open(header).read(), flags=re.M))
-    assert names == {'gs_prover_bind', 'gs_prover_open', 'gs_prover_element_size', 'gs_prover_prove', 'gs_prover_prove_on', 'gs_prover_last_stats',
+    assert names == {'gs_prover_bind', 'gs_prover_open', 'gs_prover_element_size', 'gs_prover_abi_version', 'gs_prover_prove', 'gs_prover_prove_on', 'gs_prover_last_stats',
                      'gs_prover_remainder_check', 'gs_prover_remainder_check_on', 'gs_prover_verify', 'gs_prover_verify_on'}
     if not os.path.exists(PROVER_LIB_PATH):
         pytest.skip('libgstark_prover.so not built')
@@ -163,7 +163,7 @@ def test_prover_library_exports_its_header():
     n = C.c_uint64()
     assert lib.gs_prover_prove(None, None, None, C.c_uint64(0), C.byref(n), None, C.c_uint64(0)) != 0
     assert lib.gs_prover_bind(None) != 0
-    assert lib.gs_prover_element_size() == 16
+    assert lib.gs_prover_element_size() == 16 and lib.gs_prover_abi_version() == 2
     # one build of the driver per field flavour; each refuses an ABI library of another field (here: the 128-bit oracle)
     from genstark_amd.native import PROVER_LIB_PATHS
     from conftest import ORACLE_LIB
