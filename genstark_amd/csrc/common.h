@@ -88,6 +88,11 @@ struct gs_ctx {
     void *h_rb = nullptr, *h_rb_dev = nullptr;
     uint32_t rb_bytes[RB_SLOTS] = {};
     uint64_t rb_next = 0;
+    // the landing area of deferred fetches (gs_defer_end): coherent mapped pinned memory, [fl_bytes of data][one 64-bit flag].  The
+    // gathering kernel's last workgroup to finish (arrival counter d_fl_count) stores the flag = fl_seq with system-scope release and the
+    // host spins on it: the Fiat-Shamir round trip of a proof (root -> coefficients) no longer waits for a stream synchronisation
+    void *h_fl = nullptr, *h_fl_dev = nullptr, *d_fl_count = nullptr;
+    uint64_t fl_bytes = 0, fl_seq = 0;
     // upload ring (gs_push_reserve / gs_push_commit): small host payloads (programs, coefficient tables, first rows) are assembled
     // in pinned memory and copied asynchronously — no synchronisation per upload; two halves, a half is reused only after the
     // copies issued from it have completed (one event per half)

@@ -4,6 +4,7 @@
 
 #include "common.h"
 #include <chrono>
+#include <sched.h>
 #include <time.h>
 
 int gs_fail(gs_ctx *c, int code, const char *fmt, ...) {
@@ -99,6 +100,8 @@ void gs_ctx_destroy(gs_ctx *c) {
     if (c->h_up) hipHostFree(c->h_up);
     for (hipEvent_t e : c->up_done) if (e) hipEventDestroy(e);
     if (c->h_rb) hipHostFree(c->h_rb);
+    if (c->h_fl) hipHostFree(c->h_fl);
+    if (c->d_fl_count) hipFree(c->d_fl_count);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -196,6 +199,23 @@ __global__ void k_gather_words(const uint64_t *__restrict__ addr, uint64_t total
         out[t] = *reinterpret_cast<const uint4 *>(addr[t]);
 }
 
+// the same gather into coherent mapped pinned host memory, announced to a polling host: every workgroup makes its words visible at
+// system scope, then arrives at a device-scope counter; the last one to arrive resets the counter and stores the flag (release, system)
+__global__ void k_gather_words_flag(const uint64_t *__restrict__ addr, uint64_t total, uint4 *__restrict__ out, unsigned int *__restrict__ arrived,
+                                    unsigned long long *flag, unsigned long long value) {
+    for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x)
+        out[t] = *reinterpret_cast<const uint4 *>(addr[t]);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int before = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before + 1 == gridDim.x) {
+            __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 int gs_push_reserve(gs_ctx *c, uint64_t bytes, void **host) {
     const uint64_t H = gs_ctx::UP_HALF;
     bytes = (bytes + 255) & ~(uint64_t)255;
@@ -235,6 +255,34 @@ int gs_push(gs_ctx *c, void *dst, const void *host_src, uint64_t bytes) {
     // large and pageable: the runtime stages the copy; synchronise so the caller may reuse host_src at once
     GS_HIP(c, hipMemcpyAsync(dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
     GS_HIP(c, hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+// spin on a flag in coherent pinned memory until it holds `value` (posted read-backs and deferred fetches alike): a short spin, then
+// yields, naps only after 2 ms, and a look at the queue every 200 us so that a lost copy is an error, not a hang
+static int gs_poll_flag(gs_ctx *c, const volatile uint64_t *flag, uint64_t value, const char *what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    auto checked = t0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != value) {
+        const auto now = std::chrono::steady_clock::now();
+        if (now - t0 < std::chrono::microseconds(50)) {
+            __builtin_ia32_pause();                            // data that is about to land
+        } else if (now - t0 < std::chrono::milliseconds(2)) {
+            sched_yield();                                     // the device is still working towards it: let another lane's host thread run if
+                                                               // one is runnable (returns at once otherwise — a nanosleep here costs >= 50 us of
+                                                               // timer slack on top of the wait: measured, +45 us on a 0.5 ms proof)
+        } else {
+            struct timespec ts = {0, 20000};
+            nanosleep(&ts, nullptr);
+        }
+        if (now - checked > std::chrono::microseconds(200)) {
+            checked = now;
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipErrorNotReady) continue;
+            if (q != hipSuccess) return gs_fail(c, GS_ERR_DEVICE, "%s: %s", what, hipGetErrorString(q));
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != value) return gs_fail(c, GS_ERR_DEVICE, "%s: the queue drained without delivering the data", what);
+        }
+    }
     return GS_OK;
 }
 
@@ -281,27 +329,8 @@ extern "C" int gs_readback_wait(gs_ctx *c, uint64_t ticket, void *host_dst) {
     const uint32_t slot = (uint32_t)(ticket % gs_ctx::RB_SLOTS);
     const size_t data_bytes = (size_t)gs_ctx::RB_SLOTS * gs_ctx::RB_SLOT_BYTES;
     const volatile uint64_t *flag = (const volatile uint64_t *)((const uint8_t *)c->h_rb + data_bytes) + slot;
-    const auto t0 = std::chrono::steady_clock::now();
-    auto checked = t0;
-    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != ticket + 1) {
-        const auto now = std::chrono::steady_clock::now();
-        if (now - t0 < std::chrono::microseconds(20)) {
-            __builtin_ia32_pause();                                                // a copy that is about to land
-        } else {
-            // a long wait (the host is ahead of the device): give the core back to the other lanes' host threads.  Proof latency and
-            // proofs-in-flight throughput measured the same spinning, yielding and sleeping (12.5 ms, 3.5 ms per proof): the waits
-            // that matter are the short ones above
-            struct timespec ts = {0, 20000};
-            nanosleep(&ts, nullptr);
-        }
-        if (now - checked > std::chrono::microseconds(200)) {      // is the queue still alive?  (an idle queue with the flag unset: the copy was lost)
-            checked = now;
-            const hipError_t q = hipStreamQuery(c->stream);
-            if (q == hipErrorNotReady) continue;
-            if (q != hipSuccess) return gs_fail(c, GS_ERR_DEVICE, "readback_wait: %s", hipGetErrorString(q));
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != ticket + 1) return gs_fail(c, GS_ERR_DEVICE, "readback_wait: the queue drained without delivering ticket %llu", (unsigned long long)ticket);
-        }
-    }
+    const int rc = gs_poll_flag(c, flag, ticket + 1, "readback_wait");
+    if (rc) return rc;
     memcpy(host_dst, (const uint8_t *)c->h_rb + (size_t)slot * gs_ctx::RB_SLOT_BYTES, c->rb_bytes[slot]);
     return GS_OK;
 }
@@ -316,11 +345,32 @@ int gs_defer_flush(gs_ctx *c) {
     c->defer = was;
     if (rc) return rc;
     memcpy(c->h_stage, c->defer_addrs.data(), total * 8);
-    hipLaunchKernelGGL(k_gather_words, dim3(gs_grid(total)), dim3(256), 0, c->stream, (const uint64_t *)c->h_stage_dev, total,
-                       (uint4 *)((uint8_t *)c->h_stage_dev + addr_bytes));
+    // the words land in coherent pinned memory followed by a flag the host polls (no stream synchronisation: its wake-up costs more than
+    // the whole gather when the fetch is a root and two cells)
+    if (total * 16 > c->fl_bytes) {
+        uint64_t nb = 1 << 16;
+        while (nb < total * 16) nb <<= 1;
+        GS_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->h_fl) hipHostFree(c->h_fl);
+        c->h_fl = c->h_fl_dev = nullptr;
+        c->fl_bytes = 0;
+        GS_HIP(c, hipHostMalloc(&c->h_fl, nb + 64, hipHostMallocMapped | hipHostMallocCoherent));
+        memset((uint8_t *)c->h_fl + nb, 0, 64);
+        GS_HIP(c, hipHostGetDevicePointer(&c->h_fl_dev, c->h_fl, 0));
+        c->fl_bytes = nb;
+        c->fl_seq = 0;
+    }
+    if (!c->d_fl_count) {
+        GS_HIP(c, hipMalloc(&c->d_fl_count, 256));
+        GS_HIP(c, hipMemsetAsync(c->d_fl_count, 0, 256, c->stream));
+    }
+    const uint64_t seq = ++c->fl_seq;
+    hipLaunchKernelGGL(k_gather_words_flag, dim3(gs_grid(total)), dim3(256), 0, c->stream, (const uint64_t *)c->h_stage_dev, total, (uint4 *)c->h_fl_dev,
+                       (unsigned int *)c->d_fl_count, (unsigned long long *)((uint8_t *)c->h_fl_dev + c->fl_bytes), (unsigned long long)seq);
     GS_LAUNCH_CHECK(c);
-    GS_HIP(c, hipStreamSynchronize(c->stream));
-    const uint8_t *words = (const uint8_t *)c->h_stage + addr_bytes;
+    rc = gs_poll_flag(c, (const volatile uint64_t *)((const uint8_t *)c->h_fl + c->fl_bytes), seq, "defer_end");
+    if (rc) return rc;
+    const uint8_t *words = (const uint8_t *)c->h_fl;
     for (auto &d : c->defer_copies) memcpy(d.dst, words + d.first_word * 16, d.bytes);
     c->defer_addrs.clear();
     c->defer_copies.clear();

@@ -167,7 +167,7 @@ B2S_COMPRESSIONS_PER_S = 39.5e9          # chip-wide BLAKE2s compression issue r
 VALU_CLASS_NS = {'cheap': 1.1, 'vop3': 1.8, 'carry': 1.95, 'mad64': 2.0}      # profiles/r02_a_instruction_costs.txt, 4 waves per SIMD
 
 
-def kernel_table(per_kernel, traffic):
+def kernel_table(per_kernel, traffic, counters=None):
     """roofline.kernels[]: every kernel of one proof — calls, ms, the bytes it HAD to move (the library's own tally, SURVEY 8d's
     algorithmic bytes per launch), GB/s and the fraction of the 8 TB/s HBM roof; for the kernels whose own roof is known, that roof and
     the fraction of it: hash kernels against the chip's BLAKE2s compression issue rate, NTT passes against the issue time of their own
@@ -205,7 +205,52 @@ def kernel_table(per_kernel, traffic):
                     if row['frac_own_roof'] > 1.0:      # a zero-extending first pass (>= 16x) skips its first network: the static count overstates it
                         row['frac_own_roof'] = None
                         row['own_roof'] += ' (not applicable: the pruned first pass of a >= 16x extension skips the first radix-16 network)'
+        cn = (counters or {}).get(base)
+        if cn and 'valu_issue_utilisation' in cn:
+            row['valu_issue_utilisation'] = cn['valu_issue_utilisation']
+            row['valu_insts_per_launch'] = cn['valu_insts_per_launch']
+            if row.get('frac_own_roof') is None and 'own_roof' not in row:
+                # neither a hash kernel nor an NTT pass: the kernel's own roof is whichever of its two resources it uses more of — the
+                # HBM stream it has to move, or the issue slots of its own instruction stream (counters of THIS run)
+                hbm = row.get('frac_hbm') or 0.0
+                if cn['valu_issue_utilisation'] >= hbm:
+                    row['own_roof'] = 'VALU issue of its own instruction stream (SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs, this run)'
+                    row['frac_own_roof'] = min(1.0, cn['valu_issue_utilisation'])      # (the counter pass runs at its own clocks: a few % over 1 is measurement)
+                else:
+                    row['own_roof'] = 'HBM (8 TB/s)'
+                    row['frac_own_roof'] = hbm
         out.append(row)
+    if counters and 'error' in counters:
+        out.append({'kernel': '(issue counters)', 'calls': 0, 'ms': 0.0, 'error': counters['error']})
+    return out
+
+
+def issue_counters(name, reps, env):
+    """Third child of a configuration: rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE (one pass; counters alone with
+    --kernel-trace, as the pool's rule for PMC runs requires) -> per kernel name {valu_insts_per_launch, valu_issue_utilisation}:
+    SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1024 SIMDs, GRBM_GUI_ACTIVE cycles summed over the 8 XCDs, so
+    utilisation = active x 4 / 1024 / (gui / 8): the share of its own cycles a SIMD spent issuing vector instructions in that launch."""
+    import csv
+    import glob
+    import re
+    d = f'/tmp/gs_pmc_{os.getpid()}_{name}'
+    out = {}
+    try:
+        subprocess.run(['rocprofv3', '--pmc', 'SQ_INSTS_VALU', 'SQ_ACTIVE_INST_VALU', 'GRBM_GUI_ACTIVE', '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'p', '--',
+                        sys.executable, os.path.abspath(__file__), '--child', name, str(min(reps, 2))], capture_output=True, text=True, timeout=300, env=env, cwd='/tmp')
+        files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+        acc = {}
+        for row in csv.DictReader(open(files[0])) if files else []:
+            base = re.sub(r'\(.*$', '', re.sub(r'^void ', '', row['Kernel_Name'])).strip()
+            acc.setdefault(base, {}).setdefault(row['Counter_Name'], []).append(float(row['Counter_Value']))
+        for base, c in acc.items():
+            v, a, g = c.get('SQ_INSTS_VALU'), c.get('SQ_ACTIVE_INST_VALU'), c.get('GRBM_GUI_ACTIVE')
+            if v and a and g and sum(g) > 0:
+                out[base] = {'valu_insts_per_launch': round(sum(v) / len(v)), 'valu_issue_utilisation': round((sum(a) / len(a)) * 4 / 1024 / ((sum(g) / len(g)) / 8), 4),
+                             'launches_sampled': len(v)}
+    except Exception as e:   # noqa: BLE001
+        out = {'error': repr(e)[:200]}
+    subprocess.run(['rm', '-rf', d])
     return out
 
 
@@ -234,7 +279,10 @@ def parent(names, rocprof=True):
                 per_kernel = got.pop('_per_kernel', None)
                 rec.update(got)
                 if per_kernel and rec.get('traffic') is not None:
-                    rec['kernels'] = kernel_table(per_kernel, rec['traffic'])
+                    # the two long statements also get the issue-side counters of every kernel (their own roof for the kernels that are
+                    # neither hash- nor HBM-bound: how much of its own time a SIMD spent issuing vector instructions)
+                    counters = issue_counters(name, reps, env) if name in ('C5', 'C4_long') else None
+                    rec['kernels'] = kernel_table(per_kernel, rec['traffic'], counters)
             except Exception as e:   # noqa: BLE001
                 rec['rocprof_error'] = repr(e)[:200]
             subprocess.run(['rm', '-rf', d])
