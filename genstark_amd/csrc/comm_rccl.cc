@@ -25,6 +25,11 @@ struct RcclState {
     void *(*stream_of)(gs_ctx *) = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed, spare;
     bool no_alltoall = false;     // fixed at creation (GSTARK_RCCL_GROUPED_ALLTOALL=1): grouped ncclSend / ncclRecv instead of ncclAllToAll
+    // overlap (gs_comm::fork / join): between the two the collectives run on `side`, ordered behind `forked` (recorded on the context's
+    // stream at fork) and ahead of `joined` (which the context's stream waits for at join)
+    hipStream_t side = nullptr;
+    hipEvent_t forked = nullptr, joined = nullptr;
+    bool on_side = false;
     bool timings = true;          // an event pair around every collective (gs_rccl_comm_timings): each record costs the stream a few us
     char err[256] = {0};
 };
@@ -44,14 +49,14 @@ bool end(RcclState *s, hipStream_t st) { return !s->timings || hipEventRecord(s-
 
 int r_all_gather(void *self, gs_ctx *ctx, const void *send, void *recv, uint64_t bytes) {
     RcclState *s = (RcclState *)self;
-    hipStream_t st = (hipStream_t)s->stream_of(ctx);
+    hipStream_t st = s->on_side ? s->side : (hipStream_t)s->stream_of(ctx);
     if (!begin(s, st)) return GS_ERR_DEVICE;
     if (ncclAllGather(send, recv, bytes, ncclUint8, s->comm, st) != ncclSuccess) return GS_ERR_DEVICE;
     return end(s, st) ? GS_OK : GS_ERR_DEVICE;
 }
 int r_all_to_all(void *self, gs_ctx *ctx, const void *send, void *recv, uint64_t bytes) {
     RcclState *s = (RcclState *)self;
-    hipStream_t st = (hipStream_t)s->stream_of(ctx);
+    hipStream_t st = s->on_side ? s->side : (hipStream_t)s->stream_of(ctx);
     if (!begin(s, st)) return GS_ERR_DEVICE;
     // RCCL's own all-to-all (an extension over NCCL: piece j of rank i's buffer becomes piece i of rank j's — exactly this layout; it is what
     // torch.distributed's all_to_all_single runs on ROCm, i.e. the exercised path).  The grouped send / recv form below (which includes the
@@ -70,6 +75,24 @@ int r_all_to_all(void *self, gs_ctx *ctx, const void *send, void *recv, uint64_t
     ok = (ncclGroupEnd() == ncclSuccess) && ok;
     if (!ok) return GS_ERR_DEVICE;
     return end(s, st) ? GS_OK : GS_ERR_DEVICE;
+}
+int r_fork(void *self, gs_ctx *ctx) {
+    RcclState *s = (RcclState *)self;
+    if (s->on_side) return GS_ERR_ARG;                  // forks do not nest
+    if (!s->side) {
+        if (hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) != hipSuccess) return GS_ERR_DEVICE;
+        if (hipEventCreateWithFlags(&s->forked, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->joined, hipEventDisableTiming) != hipSuccess) return GS_ERR_DEVICE;
+    }
+    if (hipEventRecord(s->forked, (hipStream_t)s->stream_of(ctx)) != hipSuccess || hipStreamWaitEvent(s->side, s->forked, 0) != hipSuccess) return GS_ERR_DEVICE;
+    s->on_side = true;
+    return GS_OK;
+}
+int r_join(void *self, gs_ctx *ctx) {
+    RcclState *s = (RcclState *)self;
+    if (!s->on_side) return GS_ERR_ARG;
+    s->on_side = false;
+    if (hipEventRecord(s->joined, s->side) != hipSuccess || hipStreamWaitEvent((hipStream_t)s->stream_of(ctx), s->joined, 0) != hipSuccess) return GS_ERR_DEVICE;
+    return GS_OK;
 }
 uint32_t r_take_timings(void *self, double *ms_out, uint32_t cap) {
     RcclState *s = (RcclState *)self;
@@ -125,6 +148,7 @@ int gs_rccl_comm_create(void *abi_dl_handle, const uint8_t unique_id[128], int r
     out->all_to_all = r_all_to_all;
     out->take_timings = r_take_timings;
     out->name = "rccl";
+    { const char *o = getenv("GSTARK_RCCL_NO_OVERLAP"); if (!(o && o[0] == '1')) { out->fork = r_fork; out->join = r_join; } }
     return GS_OK;
 }
 
@@ -139,6 +163,9 @@ void gs_rccl_comm_destroy(gs_comm *c) {
     RcclState *s = (RcclState *)c->self;
     for (auto &ev : s->timed) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto &ev : s->spare) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (s->forked) (void)hipEventDestroy(s->forked);
+    if (s->joined) (void)hipEventDestroy(s->joined);
+    if (s->side) (void)hipStreamDestroy(s->side);
     if (s->comm) ncclCommDestroy(s->comm);
     delete s;
     c->self = nullptr;

@@ -66,7 +66,7 @@ class GsComm(C.Structure):
     """struct gs_comm of include/gstark_comm.h: the table of collectives gs_prover_prove_dist is handed (genstark_amd/comm.py builds them)."""
     _fields_ = [('self', C.c_void_p), ('rank', C.c_int32), ('size', C.c_int32),
                 ('all_gather', C.c_void_p), ('all_to_all', C.c_void_p), ('take_timings', C.c_void_p), ('name', C.c_char_p),
-                ('fri_gather_below', C.c_uint64), ('solo_below', C.c_uint64)]
+                ('fri_gather_below', C.c_uint64), ('solo_below', C.c_uint64), ('fork', C.c_void_p), ('join', C.c_void_p)]
 
 
 class _Collective(C.Structure):

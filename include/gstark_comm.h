@@ -36,6 +36,14 @@ struct gs_comm {
      * is a chain of dependent launches that more devices cannot shorten, and every collective of the sharded form costs more than
      * the work it would spread.  0 = the default (2^20 points per rank); 1 = always shard (tests). */
     uint64_t solo_below;
+    /* optional (both or neither; NULL = every collective stays in stream order): overlap of a collective with computation.
+     * fork(): the collectives issued from now until join() run BEHIND everything ctx's stream holds at this moment, but are not ordered
+     * with what the caller enqueues on it afterwards (RCCL: they go to the communicator's own stream, which first waits for an event
+     * recorded here); join(): ctx's stream continues only after those collectives have completed.  Between the two the caller neither
+     * reads what they write nor overwrites or frees what they read.  The driver uses it for the evaluation tree's leaf-digest
+     * all-to-all, which runs while the constraint kernels — which need none of it — occupy the device. */
+    int (*fork)(void *self, gs_ctx *ctx);
+    int (*join)(void *self, gs_ctx *ctx);
 };
 
 /* One proof of `job` across the comm->size ranks (every rank calls this with the same job; SPMD).  Every rank receives the same

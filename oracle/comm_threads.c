@@ -33,9 +33,15 @@ struct group {
     pthread_mutex_t mu;
     pthread_cond_t cv;
 };
+#define MAX_DEFERRED 8
 struct rank_state {
     struct group *grp;
     int rank;
+    /* gs_comm::fork / join: a collective issued between the two is only NOTED, and carried out at join — the latest moment the contract
+     * allows.  A driver that reads a forked collective's output before join, or frees its buffers, therefore fails the byte comparisons
+     * of the tests (an eager double would hide exactly that mistake). */
+    int forked, ndeferred;
+    struct { const void *send; void *recv; uint64_t bytes; int all_to_all; } deferred[MAX_DEFERRED];
 };
 
 static int meet(struct group *g) {
@@ -105,11 +111,39 @@ int gs_threads_comm_end(const gs_comm *c, gs_ctx *ctx) {
     meet(g);
     return rc;
 }
+static int note_or_exchange(struct rank_state *st, gs_ctx *ctx, const void *send, void *recv, uint64_t bytes, int all_to_all) {
+    if (!st->forked) return exchange(st, ctx, send, recv, bytes, all_to_all);
+    if (st->ndeferred == MAX_DEFERRED) return GS_ERR_UNSUPPORTED;
+    st->deferred[st->ndeferred].send = send;
+    st->deferred[st->ndeferred].recv = recv;
+    st->deferred[st->ndeferred].bytes = bytes;
+    st->deferred[st->ndeferred].all_to_all = all_to_all;
+    st->ndeferred++;
+    return GS_OK;
+}
 static int t_all_gather(void *self, gs_ctx *ctx, const void *send, void *recv, uint64_t bytes) {
-    return exchange((struct rank_state *)self, ctx, send, recv, bytes, 0);
+    return note_or_exchange((struct rank_state *)self, ctx, send, recv, bytes, 0);
 }
 static int t_all_to_all(void *self, gs_ctx *ctx, const void *send, void *recv, uint64_t bytes) {
-    return exchange((struct rank_state *)self, ctx, send, recv, bytes, 1);
+    return note_or_exchange((struct rank_state *)self, ctx, send, recv, bytes, 1);
+}
+static int t_fork(void *self, gs_ctx *ctx) {
+    struct rank_state *st = (struct rank_state *)self;
+    (void)ctx;
+    if (st->forked) return GS_ERR_ARG;           /* forks do not nest */
+    st->forked = 1;
+    st->ndeferred = 0;
+    return GS_OK;
+}
+static int t_join(void *self, gs_ctx *ctx) {
+    struct rank_state *st = (struct rank_state *)self;
+    if (!st->forked) return GS_ERR_ARG;
+    st->forked = 0;
+    int rc = GS_OK;
+    for (int i = 0; i < st->ndeferred && !rc; i++)
+        rc = exchange(st, ctx, st->deferred[i].send, st->deferred[i].recv, st->deferred[i].bytes, st->deferred[i].all_to_all);
+    st->ndeferred = 0;
+    return rc;
 }
 
 /* `size` communicators (one per rank thread) over the ABI library behind `abi_dl_handle`; out[r] is rank r's. */
@@ -138,6 +172,8 @@ int gs_threads_comm_create(int size, void *abi_dl_handle, gs_comm *out) {
         out[r].all_to_all = t_all_to_all;
         out[r].take_timings = NULL;
         out[r].name = "threads";
+        const char *eager = getenv("GSTARK_COMM_THREADS_NO_FORK");      /* =1: no fork / join in the table (the driver's in-order path) */
+        if (!(eager && eager[0] == '1')) { out[r].fork = t_fork; out[r].join = t_join; }
     }
     return GS_OK;
 }
