@@ -13,8 +13,26 @@ const { defaultField } = require('./context');
 
 const REPO = path.resolve(__dirname, '..');
 
+// The loader's answers are pure functions of the request (source, component, extension factor, and for plan / verify the inputs): an
+// AssemblyAir asks `info` and `describe` at construction and the same `verify` descriptor for every proof of one shape, so answers are
+// kept (64 most recent, requests under 256 KB) instead of paying a python start-up (~0.2 s) per call.
+const answers = new Map();
 function ask(request) {
-    const r = spawnSync(process.env.GSTARK_PYTHON || 'python3', ['-m', 'genstark_amd.aa_json'], { cwd: REPO, input: JSON.stringify(request), encoding: 'utf8', maxBuffer: 1 << 28 });
+    const key = JSON.stringify(request);
+    if (key.length < (1 << 18) && answers.has(key)) {
+        const hit = answers.get(key);
+        answers.delete(key); answers.set(key, hit);           // most recently used last
+        return hit;
+    }
+    const out = askLoader(key);
+    if (key.length < (1 << 18)) {
+        answers.set(key, out);
+        if (answers.size > 64) answers.delete(answers.keys().next().value);
+    }
+    return out;
+}
+function askLoader(requestJson) {
+    const r = spawnSync(process.env.GSTARK_PYTHON || 'python3', ['-m', 'genstark_amd.aa_json'], { cwd: REPO, input: requestJson, encoding: 'utf8', maxBuffer: 1 << 28 });
     if (r.error) throw new Error(`AirAssembly loader (python3 -m genstark_amd.aa_json) could not be started: ${r.error.message}`);
     let out;
     try { out = JSON.parse(r.stdout.trim().split('\n').pop()); } catch (e) { throw new Error(`AirAssembly loader: ${r.stderr.slice(-400) || 'no answer'}`); }
