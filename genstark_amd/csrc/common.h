@@ -22,6 +22,17 @@
 #include "gf128.h"
 #endif
 
+#if defined(GF_RUNTIME_MODULUS)
+// The runtime-modulus build: every translation unit owns a copy of the field constants in device constant memory (gf_wide.h) and
+// registers a function that pushes the host copy into it; gs_ctx_create (ctx.hip) runs them for the context's device.
+typedef int (*gs_rt_push_fn)(void);
+void gs_rt_register(gs_rt_push_fn fn);
+static int gs_rt_push_this_unit(void) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(gf_rt_device), &gf_rt_host(), sizeof(GfRuntime)) == hipSuccess ? 0 : -1;
+}
+namespace { struct GsRtUnit { GsRtUnit() { gs_rt_register(gs_rt_push_this_unit); } } gs_rt_unit; }
+#endif
+
 // bytes of one element in memory and on the ABI (gs_element_size()), and the same in 16-byte words
 #define GS_ELT ((uint64_t)sizeof(fe))
 #define GS_EW ((uint32_t)(sizeof(fe) / 16))

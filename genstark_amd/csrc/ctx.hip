@@ -17,6 +17,11 @@ int gs_fail(gs_ctx *c, int code, const char *fmt, ...) {
     return code;
 }
 
+#if defined(GF_RUNTIME_MODULUS)
+static std::vector<gs_rt_push_fn> &gs_rt_units() { static std::vector<gs_rt_push_fn> v; return v; }
+void gs_rt_register(gs_rt_push_fn fn) { gs_rt_units().push_back(fn); }
+#endif
+
 extern "C" {
 
 int gs_abi_version(void) { return GS_ABI_VERSION; }
@@ -35,6 +40,38 @@ int gs_field_modulus(uint8_t *out_le) {
     return GS_OK;
 }
 
+// createPrimeField(modulus) of index.ts:14 for a modulus no fixed build knows: the runtime-modulus build takes it here, ONCE per process
+// (the constants are process-wide: every context, every thread).  A fixed build accepts its own modulus and nothing else.
+int gs_set_modulus(const uint8_t *modulus_le, uint32_t bytes) {
+    if (!modulus_le || !bytes || bytes > sizeof(fe)) return GS_ERR_ARG;
+    fe want = fe_zero();
+    memcpy(&want, modulus_le, bytes);
+#if defined(GF_RUNTIME_MODULUS)
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    GfRuntime &rt = gf_rt_host();
+    if (rt.set) return memcmp(rt.p, want.w, sizeof rt.p) ? GS_ERR_UNSUPPORTED : GS_OK;      // one modulus per process
+    bool small = true;
+    for (int i = 1; i < GF_LIMBS; i++) small = small && !want.w[i];
+    if (!(want.w[0] & 1u) || (small && want.w[0] < 3)) return GS_ERR_ARG;                 // Montgomery reduction needs an odd modulus
+    GfRuntime v = {};
+    memcpy(v.p, want.w, sizeof v.p);
+    uint32_t inv = 1;                                   // p^-1 mod 2^32 by Newton's iteration (p odd), then negated
+    for (int i = 0; i < 5; i++) inv *= 2u - want.w[0] * inv;
+    v.n0inv = 0u - inv;
+    rt = v;                                             // fe_add below reads the modulus through gf_rt_host()
+    fe r = fe_one();
+    for (int i = 0; i < 2 * 32 * GF_NL; i++) r = fe_add(r, r);                            // 2^512 mod p
+    memcpy(rt.r2, r.w, sizeof rt.r2);
+    rt.set = 1;
+    return GS_OK;
+#else
+    uint8_t mine[sizeof(fe)];
+    gs_field_modulus(mine);
+    return memcmp(mine, &want, sizeof(fe)) ? GS_ERR_UNSUPPORTED : GS_OK;
+#endif
+}
+
 int gs_ctx_create(int device, void *hip_stream, gs_ctx **out) {
     if (!out) return GS_ERR_ARG;
     *out = nullptr;
@@ -44,6 +81,10 @@ int gs_ctx_create(int device, void *hip_stream, gs_ctx **out) {
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return GS_ERR_DEVICE;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return GS_ERR_DEVICE;  // kernels are built for gfx950 only
     if (hipSetDevice(device) != hipSuccess) return GS_ERR_DEVICE;
+#if defined(GF_RUNTIME_MODULUS)
+    if (!gf_rt_host().set) return GS_ERR_UNSUPPORTED;                  // gs_set_modulus first
+    for (gs_rt_push_fn push : gs_rt_units()) if (push()) return GS_ERR_DEVICE;       // this device's copies of the field constants, unit by unit
+#endif
     gs_ctx *c = new gs_ctx();
     c->device = device;
     if (hip_stream) {
@@ -54,6 +95,9 @@ int gs_ctx_create(int device, void *hip_stream, gs_ctx **out) {
     }
     const char *jit = getenv("GSTARK_AIR_JIT");     // 0: interpret, 1: compile on first use, unset / "auto": compiled when already built (air_jit.hip)
     c->air_jit = !jit || !jit[0] || jit[0] == 'a' ? 2 : (jit[0] != '0' ? 1 : 0);
+#if defined(GF_RUNTIME_MODULUS)
+    c->air_jit = 0;         // AIR programs are interpreted in this flavour (a compiled program would bake a modulus in: generic kernels only)
+#endif
     c->host_trace_segments = GS_HOST_TRACE_MAX_SEGMENTS;
     if (const char *hs = getenv("GSTARK_HOST_TRACE_SEGMENTS")) c->host_trace_segments = strtoull(hs, nullptr, 10);
     *out = c;
@@ -63,6 +107,9 @@ int gs_ctx_create(int device, void *hip_stream, gs_ctx **out) {
 int gs_air_jit(gs_ctx *c, int enable) {
     if (!c) return GS_ERR_ARG;
     c->air_jit = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
+#if defined(GF_RUNTIME_MODULUS)
+    c->air_jit = 0;
+#endif
     return GS_OK;
 }
 uint64_t gs_air_jit_launches(const gs_ctx *c) { return c ? c->jit_launches : 0; }

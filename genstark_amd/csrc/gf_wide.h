@@ -18,7 +18,7 @@
 #endif
 
 #ifndef GS_WIDE_BITS
-#error "gf_wide.h needs -DGS_WIDE_BITS=256 or 224"
+#error "gf_wide.h needs -DGS_WIDE_BITS=256, 224 or 0 (0: the modulus is set at run time, gs_set_modulus)"
 #endif
 
 #define GF_LIMBS 8                       // storage limbs of an element
@@ -36,12 +36,41 @@ struct alignas(16) fe {
 #define GF_CW 3                          // C = 2^224 - p = 2^96 - 1
 #define GF_P_LIMBS {0x00000001u, 0x00000000u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u}
 #define GF_C_LIMBS {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}
+#elif GS_WIDE_BITS == 0
+// ---- the runtime-modulus flavour (libgstark_hip_rt.so; index.ts:14 re-exports createPrimeField(modulus) for ANY prime): p is any odd
+// modulus below 2^256, fixed once per process by gs_set_modulus (include/gstark.h).  Elements stay CANONICAL in memory like every other
+// flavour's (hashes, the wire format and the host all see plain little-endian integers), so a product is two Montgomery reductions:
+// a * b * R^-1, then * R^2 * R^-1 (R = 2^256) — word-serial REDC needs nothing of p but its limbs and -p^-1 mod 2^32.  Four times the
+// multiplies of a tuned field and none of its tricks: this flavour exists so that every modulus works, not to be fast.
+#define GF_NL 8
+#define GF_RUNTIME_MODULUS 1
+struct GfRuntime {
+    uint32_t p[GF_LIMBS];        // the modulus
+    uint32_t r2[GF_LIMBS];       // R^2 mod p
+    uint32_t n0inv;              // -p^-1 mod 2^32
+    uint32_t set;                // 1 once gs_set_modulus has run
+};
+#if defined(__HIPCC__)
+// no relocatable device code: every translation unit has its own copy of the constants and pushes them itself (common.h: gs_rt_unit)
+static __constant__ GfRuntime gf_rt_device;
+#endif
+inline GfRuntime &gf_rt_host() { static GfRuntime v = {}; return v; }       // one per shared object (vague linkage)
+GF_HD const GfRuntime &gf_rt() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return gf_rt_device;
 #else
-#error "GS_WIDE_BITS must be 256 or 224"
+    return gf_rt_host();
+#endif
+}
+GF_HD uint32_t gf_p_limb(int i) { return gf_rt().p[i]; }
+#else
+#error "GS_WIDE_BITS must be 256, 224 or 0"
 #endif
 
+#if GS_WIDE_BITS != 0
 GF_HD uint32_t gf_p_limb(int i) { const uint32_t p[GF_LIMBS] = GF_P_LIMBS; return p[i]; }
 GF_HD uint32_t gf_c_limb(int i) { const uint32_t c[3] = GF_C_LIMBS; return c[i]; }
+#endif
 
 GF_HD fe fe_make(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     fe r;
@@ -125,6 +154,7 @@ GF_HD fe fe_sub(const fe &a, const fe &b) {
 }
 GF_HD fe fe_neg(const fe &a) { return fe_is_zero(a) ? a : fe_sub(fe_zero(), a); }
 
+#if GS_WIDE_BITS != 0
 // out[0 .. GF_NL + NH) (+ one carry limb) = lo[0 .. GF_NL) + hi[0 .. NH) * C
 template <int NH>
 GF_HD void gf_fold(const uint32_t *lo, const uint32_t *hi, uint32_t *out /* GF_NL + GF_CW + 1 limbs, zero-extended */) {
@@ -183,6 +213,55 @@ GF_HD fe fe_mul(const fe &a, const fe &b) {
     for (int i = 0; i < GF_LIMBS; i++) r.w[i] = i < GF_NL ? z[i] : 0u;
     return gf_cond_sub_p(r, 0);
 }
+#else
+// t (2 * NL limbs, < p * 2^256) -> t * 2^-256 mod p, canonical: word-serial Montgomery reduction
+GF_HD fe gf_redc(uint32_t *t /* 2 * GF_NL + 1 limbs, the last one 0 on entry */) {
+    const GfRuntime &rt = gf_rt();
+#pragma unroll
+    for (int i = 0; i < GF_NL; i++) {
+        const uint32_t m = t[i] * rt.n0inv;
+        uint64_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < GF_NL; j++) {
+            uint64_t x = (uint64_t)m * rt.p[j] + t[i + j] + carry;
+            t[i + j] = (uint32_t)x;
+            carry = x >> 32;
+        }
+#pragma unroll
+        for (int k = i + GF_NL; k <= 2 * GF_NL; k++) {
+            uint64_t x = (uint64_t)t[k] + carry;
+            t[k] = (uint32_t)x;
+            carry = x >> 32;
+        }
+    }
+    fe r;
+#pragma unroll
+    for (int i = 0; i < GF_LIMBS; i++) r.w[i] = t[GF_NL + i];
+    return gf_cond_sub_p(r, t[2 * GF_NL]);
+}
+GF_HD void gf_schoolbook(const fe &a, const uint32_t *b, uint32_t *t /* 2 * GF_NL + 1 limbs */) {
+#pragma unroll
+    for (int i = 0; i <= 2 * GF_NL; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < GF_NL; i++) {
+        uint64_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < GF_NL; j++) {
+            uint64_t m = (uint64_t)a.w[i] * b[j] + t[i + j] + carry;
+            t[i + j] = (uint32_t)m;
+            carry = m >> 32;
+        }
+        t[i + GF_NL] = (uint32_t)carry;
+    }
+}
+GF_HD fe fe_mul(const fe &a, const fe &b) {
+    uint32_t t[2 * GF_NL + 1];
+    gf_schoolbook(a, b.w, t);
+    const fe ab = gf_redc(t);                     // a b R^-1
+    gf_schoolbook(ab, gf_rt().r2, t);
+    return gf_redc(t);                            // a b R^-1 R^2 R^-1 = a b
+}
+#endif
 GF_HD fe fe_sqr(const fe &a) { return fe_mul(a, a); }
 
 // b^e, e given as an element's worth of limbs (little endian)

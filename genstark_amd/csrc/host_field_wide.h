@@ -37,6 +37,10 @@ static inline hfe hw_element(const uint64_t x[4]) {          // x < 2p -> canoni
     for (int i = 0; i < 4; i++) { o.v.w[2 * i] = (uint32_t)r[i]; o.v.w[2 * i + 1] = (uint32_t)(r[i] >> 32); }
     return o;
 }
+#if GS_WIDE_BITS == 0
+// runtime modulus: the device header's product (two word-serial Montgomery reductions on 32-bit limbs), as it compiles for the host
+static inline hfe hf_mul(hfe a, hfe b) { return hf_wrap(fe_mul(a.v, b.v)); }
+#else
 #if GS_WIDE_BITS == 256
 static inline void hw_reduce(const uint64_t t[8], uint64_t r[4]) {
     const uint64_t C = 351ull * 4294967296ull - 1ull;          // 2^256 mod p, 41 bits
@@ -102,6 +106,7 @@ static inline hfe hf_mul(hfe a, hfe b) {
     hw_reduce(t, r);
     return hw_element(r);
 }
+#endif
 static inline hfe hf_pow(hfe b, hfe e) {
     hfe r(1);
     int top = GF_LIMBS - 1;

@@ -31,7 +31,8 @@
  *  - The library is built once per field: libgstark_hip.so computes in GF(2^128 - 9*2^32 + 1), the flavours
  *    libgstark_hip_q64.so / _q32.so / _q17.so in GF(2^64 - 21*2^30 + 1) / GF(2^32 - 3*2^25 + 1) / GF(96769) with 16-byte elements, the flavours
  *    libgstark_hip_p256.so / _p224.so in GF(2^256 - 351*2^32 + 1) / GF(2^224 - 2^96 + 1) with 32-byte elements
- *    (gs_field_modulus / gs_element_size say which).
+ *    (gs_field_modulus / gs_element_size say which), and libgstark_hip_rt.so in whatever odd modulus below 2^256 gs_set_modulus
+ *    names (32-byte elements, generic kernels).
  *  - Every function returns GS_OK (0) or a negative gs_status; gs_last_error(ctx) describes it.
  *    There is NO CPU fallback: without a gfx950 device gs_ctx_create fails.
  */
@@ -80,6 +81,11 @@ int gs_sync(gs_ctx *ctx);
 void *gs_stream(gs_ctx *ctx);                          /* the hipStream_t the kernels run on */
 int gs_element_size(void);                             /* FiniteField.elementSize: lib/Stark.ts:260,285,299 */
 int gs_field_modulus(gs_elt *out_le);                  /* FiniteField.modulus */
+/* createPrimeField(modulus) (index.ts:14) for a modulus none of the fixed builds computes in: libgstark_hip_rt.so takes any ODD modulus
+ * below 2^256 here — `bytes` little-endian bytes, at most gs_element_size() — ONCE per process and before the first gs_ctx_create (the
+ * field constants are process-wide; a second, different modulus is GS_ERR_UNSUPPORTED; 32-byte canonical elements; generic kernels
+ * only: AIR programs are interpreted, nothing is tuned).  A fixed build answers GS_OK for its own modulus, GS_ERR_UNSUPPORTED otherwise. */
+int gs_set_modulus(const uint8_t *modulus_le, uint32_t bytes);
 
 int gs_alloc(gs_ctx *ctx, uint64_t bytes, void **dptr);
 int gs_free(gs_ctx *ctx, void *dptr);                 /* parks the block in the context's cache (no device sync) */

@@ -22,13 +22,21 @@ typedef unsigned _BitInt(512) fe2;
 typedef fe fexp;                       /* an exponent as wide as an element */
 #define FE_BYTES 32
 
+#if GS_WIDE_BITS == 0
+/* the runtime-modulus flavour (liboracle_rt.so, checker of libgstark_hip_rt.so): the modulus is whatever gs_set_modulus stored; every
+ * reduction is the language's own `%` on 512-bit integers — the definition, nothing else */
+#define GS_ORACLE_PLAIN_MOD 1
+extern fe gs_oracle_runtime_modulus;
+#endif
 static inline fe fe_p(void) {
-#if GS_WIDE_BITS == 256
+#if GS_WIDE_BITS == 0
+    return gs_oracle_runtime_modulus;
+#elif GS_WIDE_BITS == 256
     return (fe)0 - ((fe)351 << 32) + 1;                 /* 2^256 wraps to 0 */
 #elif GS_WIDE_BITS == 224
     return ((fe)1 << 224) - ((fe)1 << 96) + 1;
 #else
-#error "GS_WIDE_BITS must be 256 or 224"
+#error "GS_WIDE_BITS must be 256, 224 or 0"
 #endif
 }
 static inline fe fe_load(const uint8_t *b) {

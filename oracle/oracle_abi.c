@@ -47,6 +47,9 @@ int gs_abi_version(void) { return GS_ABI_VERSION; }
 const char *gs_backend_name(void) { return "oracle-cpu"; }
 int gs_ctx_create(int device, void *stream, gs_ctx **out) {
     (void)device; (void)stream;
+#if defined(GS_WIDE_BITS) && GS_WIDE_BITS == 0
+    if (!fe_p()) return GS_ERR_UNSUPPORTED;          /* gs_set_modulus first */
+#endif
     gs_ctx *c = (gs_ctx *)calloc(1, sizeof *c);
     if (!c) return GS_ERR_OOM;
     *out = c;
@@ -58,6 +61,26 @@ int gs_sync(gs_ctx *c) { (void)c; return GS_OK; }
 void *gs_stream(gs_ctx *c) { (void)c; return NULL; }
 int gs_element_size(void) { return FE_BYTES; }
 int gs_field_modulus(gs_elt *out) { fe_store(out, fe_p()); return GS_OK; }
+#if defined(GS_WIDE_BITS) && GS_WIDE_BITS == 0
+fe gs_oracle_runtime_modulus = 0;
+#endif
+/* include/gstark.h: the runtime-modulus flavour takes its (odd) modulus here, once per process; a fixed flavour accepts only its own */
+int gs_set_modulus(const uint8_t *modulus_le, uint32_t bytes) {
+    uint8_t buf[FE_BYTES] = {0};
+    if (!modulus_le || !bytes || bytes > FE_BYTES) return GS_ERR_ARG;
+    memcpy(buf, modulus_le, bytes);
+#if defined(GS_WIDE_BITS) && GS_WIDE_BITS == 0
+    const fe want = fe_load(buf);
+    if (gs_oracle_runtime_modulus) return gs_oracle_runtime_modulus == want ? GS_OK : GS_ERR_UNSUPPORTED;
+    if (!(want & 1) || want < 3) return GS_ERR_ARG;
+    gs_oracle_runtime_modulus = want;
+    return GS_OK;
+#else
+    uint8_t mine[FE_BYTES];
+    fe_store(mine, fe_p());
+    return memcmp(mine, buf, FE_BYTES) ? GS_ERR_UNSUPPORTED : GS_OK;
+#endif
+}
 
 int gs_alloc(gs_ctx *c, uint64_t bytes, void **p) {
     *p = malloc(bytes ? bytes : 1);
