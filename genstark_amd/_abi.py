@@ -25,6 +25,8 @@ HIP_LIB_PATHS = {MODULUS_128: HIP_LIB_PATH, MODULUS_64: os.path.join(_HERE, 'csr
                  MODULUS_17: os.path.join(_HERE, 'csrc', 'libgstark_hip_q17.so'),
                  MODULUS_256: os.path.join(_HERE, 'csrc', 'libgstark_hip_p256.so'),
                  MODULUS_224: os.path.join(_HERE, 'csrc', 'libgstark_hip_p224.so')}
+# any other (odd) modulus below 2^256: the runtime-modulus flavour (gs_set_modulus; one modulus per process; generic kernels)
+HIP_LIB_PATH_RUNTIME = os.path.join(_HERE, 'csrc', 'libgstark_hip_rt.so')
 
 GS_OK = 0
 
@@ -49,6 +51,7 @@ _SIGNATURES = {
     'gs_stream': (_vp, [_vp]),
     'gs_element_size': (_int, []),
     'gs_field_modulus': (_int, [_vp]),
+    'gs_set_modulus': (_int, [_bytes, _u32]),
     'gs_alloc': (_int, [_vp, _u64, _pvp]),
     'gs_free': (_int, [_vp, _vp]),
     'gs_cache_trim': (_int, [_vp]),
@@ -149,16 +152,26 @@ class Backend:
     def __init__(self, device=0, stream=None, lib_path=None, allow_test_double=False, modulus=None):
         """modulus: picks the library flavour built for that field (default: the 128-bit field); lib_path overrides."""
         if lib_path is None:
-            if modulus is not None and modulus not in HIP_LIB_PATHS:
-                raise GstarkError(f'no build of the library for the field of {modulus} elements (built: {sorted(HIP_LIB_PATHS)})')
-            lib_path = HIP_LIB_PATHS[modulus] if modulus is not None else HIP_LIB_PATH
+            # createPrimeField(modulus), index.ts:14: a build of the library per modulus that occurs in the reference tree, and the
+            # runtime-modulus build for every other one
+            lib_path = HIP_LIB_PATH if modulus is None else HIP_LIB_PATHS.get(modulus, HIP_LIB_PATH_RUNTIME)
         self.lib = load_library(lib_path)
-        self.element_size = self.lib.gs_element_size()          # 16, or 32 in the 256- / 224-bit flavours
+        self.element_size = self.lib.gs_element_size()          # 16, or 32 in the 256- / 224-bit and the runtime-modulus flavours
+        if modulus is not None:
+            # a fixed build answers 0 for its own modulus; the runtime-modulus build takes the value (once per process)
+            if modulus < 3 or modulus >> (8 * self.element_size):
+                raise GstarkError(f'a modulus of {modulus.bit_length()} bits does not fit {lib_path}')
+            rc = self.lib.gs_set_modulus(modulus.to_bytes(self.element_size, 'little'), self.element_size)
+            if rc != GS_OK:
+                raise GstarkError(f'{lib_path} does not compute modulo {modulus} (gs_set_modulus: {rc}'
+                                  + (': the runtime-modulus library serves ONE modulus per process, and it has been given another' if rc == -3 else '') + ')')
         buf = C.create_string_buffer(self.element_size)
         self.lib.gs_field_modulus(C.cast(buf, C.c_void_p))
         self.modulus = int.from_bytes(buf.raw, 'little')
         if modulus is not None and self.modulus != modulus:
             raise GstarkError(f'{lib_path} is built for the field of {self.modulus} elements, not {modulus}')
+        if not self.modulus:
+            raise GstarkError(f'{lib_path} takes its modulus at run time: pass modulus=')
         self.name = self.lib.gs_backend_name().decode()
         if self.name != 'hip-gfx950' and not allow_test_double:
             raise GstarkError(f'refusing backend {self.name!r}: the product path runs on hip-gfx950 only')

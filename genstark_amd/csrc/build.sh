@@ -40,6 +40,9 @@ build_flavour build_q17 libgstark_hip_q17.so "-DGS_SMALL_Q=96769ull" &        # 
 # ... and the two multi-limb fields (gf_wide.h, 32-byte elements): 2^256 - 351*2^32 + 1 (mimc/mimc256.ts), 2^224 - 2^96 + 1 (lib224.aa)
 build_flavour build_p256 libgstark_hip_p256.so "-DGS_WIDE_BITS=256" &
 build_flavour build_p224 libgstark_hip_p224.so "-DGS_WIDE_BITS=224" &
+# ... and the flavour whose modulus is given at run time (gs_set_modulus: any odd modulus below 2^256; generic kernels, two Montgomery
+# reductions per product): index.ts:14's createPrimeField(modulus) for a modulus no fixed build knows
+build_flavour build_rt libgstark_hip_rt.so "-DGS_WIDE_BITS=0" &
 wait
 # static VALU instruction mix of the NTT pass kernels (bench.py: roofline.second_roof): from the device assembly of ntt.hip
 if [ ! -f ntt_isa_mix.json ] || [ ntt.hip -nt ntt_isa_mix.json ] || [ gf128_lazy.h -nt ntt_isa_mix.json ]; then
@@ -66,6 +69,7 @@ build_driver libgstark_prover_q32.so "-DGS_SMALL_Q=4194304001ull" &
 build_driver libgstark_prover_q17.so "-DGS_SMALL_Q=96769ull" &
 build_driver libgstark_prover_p256.so "-DGS_WIDE_BITS=256" &
 build_driver libgstark_prover_p224.so "-DGS_WIDE_BITS=224" &
+build_driver libgstark_prover_rt.so "-DGS_WIDE_BITS=0" &
 wait
 echo built $(pwd)/libgstark_prover.so
 # the communicator of a distributed proof over RCCL / xGMI (include/gstark_comm.h): host code against librccl + the HIP runtime

@@ -49,22 +49,8 @@ int gs_set_modulus(const uint8_t *modulus_le, uint32_t bytes) {
 #if defined(GF_RUNTIME_MODULUS)
     static std::mutex mu;
     std::lock_guard<std::mutex> g(mu);
-    GfRuntime &rt = gf_rt_host();
-    if (rt.set) return memcmp(rt.p, want.w, sizeof rt.p) ? GS_ERR_UNSUPPORTED : GS_OK;      // one modulus per process
-    bool small = true;
-    for (int i = 1; i < GF_LIMBS; i++) small = small && !want.w[i];
-    if (!(want.w[0] & 1u) || (small && want.w[0] < 3)) return GS_ERR_ARG;                 // Montgomery reduction needs an odd modulus
-    GfRuntime v = {};
-    memcpy(v.p, want.w, sizeof v.p);
-    uint32_t inv = 1;                                   // p^-1 mod 2^32 by Newton's iteration (p odd), then negated
-    for (int i = 0; i < 5; i++) inv *= 2u - want.w[0] * inv;
-    v.n0inv = 0u - inv;
-    rt = v;                                             // fe_add below reads the modulus through gf_rt_host()
-    fe r = fe_one();
-    for (int i = 0; i < 2 * 32 * GF_NL; i++) r = fe_add(r, r);                            // 2^512 mod p
-    memcpy(rt.r2, r.w, sizeof rt.r2);
-    rt.set = 1;
-    return GS_OK;
+    const int rc = gf_rt_configure(want.w);
+    return rc == 0 ? GS_OK : (rc == -2 ? GS_ERR_UNSUPPORTED : GS_ERR_ARG);        // -2: one modulus per process
 #else
     uint8_t mine[sizeof(fe)];
     gs_field_modulus(mine);

@@ -254,7 +254,14 @@ GF_HD void gf_schoolbook(const fe &a, const uint32_t *b, uint32_t *t /* 2 * GF_N
         t[i + GF_NL] = (uint32_t)carry;
     }
 }
-GF_HD fe fe_mul(const fe &a, const fe &b) {
+// NOT inlined: a product is ~600 instructions here and the NTT butterflies alone hold hundreds of them — inlined, ntt.hip of this
+// flavour takes more than a quarter of an hour to compile; as a call it builds like the other flavours
+#if defined(__HIPCC__)
+static __host__ __device__ __noinline__
+#else
+static inline
+#endif
+fe fe_mul(const fe &a, const fe &b) {
     uint32_t t[2 * GF_NL + 1];
     gf_schoolbook(a, b.w, t);
     const fe ab = gf_redc(t);                     // a b R^-1
@@ -303,3 +310,29 @@ GF_HD fe fe_inv(const fe &a) {                 // Fermat: a^(p-2); 0 -> 0
     }
     return fe_pow(a, e);
 }
+
+#if GS_WIDE_BITS == 0
+// host: fix this shared object's copy of the field constants (gs_set_modulus of the library; the native driver when it is bound to a
+// runtime-modulus library).  0 = done (or already set to the same modulus), -1 = not an odd modulus >= 3, -2 = another modulus is set.
+inline int gf_rt_configure(const uint32_t p[GF_LIMBS]) {
+    GfRuntime &rt = gf_rt_host();
+    if (rt.set) {
+        for (int i = 0; i < GF_LIMBS; i++) if (rt.p[i] != p[i]) return -2;
+        return 0;
+    }
+    bool small = true;
+    for (int i = 1; i < GF_LIMBS; i++) small = small && !p[i];
+    if (!(p[0] & 1u) || (small && p[0] < 3)) return -1;         // Montgomery reduction needs an odd modulus
+    GfRuntime v = {};
+    for (int i = 0; i < GF_LIMBS; i++) v.p[i] = p[i];
+    uint32_t inv = 1;                                           // p^-1 mod 2^32 by Newton's iteration, then negated
+    for (int i = 0; i < 5; i++) inv *= 2u - p[0] * inv;
+    v.n0inv = 0u - inv;
+    rt = v;                                                     // fe_add below reads the modulus through gf_rt_host()
+    fe r = fe_one();
+    for (int i = 0; i < 2 * 32 * GF_NL; i++) r = fe_add(r, r); // 2^512 mod p
+    for (int i = 0; i < GF_LIMBS; i++) rt.r2[i] = r.w[i];
+    rt.set = 1;
+    return 0;
+}
+#endif

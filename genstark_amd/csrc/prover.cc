@@ -439,6 +439,11 @@ static int bind_api(Api &api, void *dl_handle) {
     if (!esize || !modulus || (uint64_t)esize() != ELEM) return GS_ERR_UNSUPPORTED;
     uint8_t m[GS_PROVER_ELT_MAX] = {0}, want[GS_PROVER_ELT_MAX] = {0};
     if (modulus(m)) return GS_ERR_UNSUPPORTED;
+#if defined(GF_RUNTIME_MODULUS)
+    // the runtime-modulus build of the driver computes in whatever field the library it is bound to was given (gs_set_modulus) — one per
+    // process, like the library's
+    { uint32_t pl[GF_LIMBS]; memcpy(pl, m, sizeof pl); if (gf_rt_configure(pl)) return GS_ERR_UNSUPPORTED; }
+#endif
 #if defined(GS_WIDE_BITS)
     for (int i = 0; i < GF_LIMBS; i++) { const uint32_t w = gf_p_limb(i); memcpy(want + 4 * i, &w, 4); }
 #else

@@ -22,6 +22,7 @@ from ._abi import MODULUS_17, MODULUS_32, MODULUS_64, MODULUS_128, MODULUS_224, 
 PROVER_LIB_PATHS = {MODULUS_128: PROVER_LIB_PATH, MODULUS_64: os.path.join(_HERE, 'csrc', 'libgstark_prover_q64.so'),
                     MODULUS_32: os.path.join(_HERE, 'csrc', 'libgstark_prover_q32.so'), MODULUS_17: os.path.join(_HERE, 'csrc', 'libgstark_prover_q17.so'),
                     MODULUS_256: os.path.join(_HERE, 'csrc', 'libgstark_prover_p256.so'), MODULUS_224: os.path.join(_HERE, 'csrc', 'libgstark_prover_p224.so')}
+PROVER_LIB_PATH_RUNTIME = os.path.join(_HERE, 'csrc', 'libgstark_prover_rt.so')
 ELT_MAX = 32          # GS_PROVER_ELT_MAX: the job's scalar fields (include/gstark_prover.h)
 
 
@@ -84,7 +85,9 @@ def _driver(backend):
     driver image."""
     path = PROVER_LIB_PATHS.get(backend.modulus)
     if path is None:
-        raise GstarkError(f'no build of the native driver for the field of {backend.modulus} elements')
+        if backend.element_size != 32:
+            raise GstarkError(f'no build of the native driver for the field of {backend.modulus} elements')
+        path = PROVER_LIB_PATH_RUNTIME         # the runtime-modulus build: it adopts the modulus of the library it is bound to
     if os.environ.get('GSTARK_PROVER_LIB_DIR'):       # instrumented builds of the same driver (tools/build_sanitized.sh): same file names, another directory
         path = os.path.join(os.environ['GSTARK_PROVER_LIB_DIR'], os.path.basename(path))
     with _bound_lock:
