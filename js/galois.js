@@ -21,12 +21,20 @@ let addon = null;
 function native(modulus) {
     if (!addon) {
         const wanted = modulus === undefined ? MODULUS : BigInt(modulus);
-        if (!process.env.GSTARK_LIB && !LIBRARIES.has(wanted)) throw new TypeError(`no build of the library for the field of ${wanted} elements`);
-        const lib = process.env.GSTARK_LIB || path.join(__dirname, '..', 'genstark_amd', 'csrc', LIBRARIES.get(wanted));
+        // a modulus none of the fixed builds knows: the runtime-modulus build (gs_set_modulus: any odd modulus below 2^256, once per process)
+        const runtime = !process.env.GSTARK_LIB && !LIBRARIES.has(wanted);
+        if (runtime && (wanted < 3n || wanted % 2n === 0n || wanted >> 256n)) throw new TypeError(`no build of the library for the field of ${wanted} elements`);
+        const lib = process.env.GSTARK_LIB || path.join(__dirname, '..', 'genstark_amd', 'csrc', runtime ? 'libgstark_hip_rt.so' : LIBRARIES.get(wanted));
         const a = require(process.env.GSTARK_ADDON || path.join(__dirname, '..', 'napi', 'gstark_napi.node'));      // GSTARK_ADDON: an instrumented build (tools/build_sanitized.sh)
         const name = a.load(lib);
         if (name !== 'hip-gfx950' && process.env.GSTARK_ALLOW_TEST_DOUBLE !== '1') {
             throw new Error(`refusing backend ${name}: the product path runs on hip-gfx950 only (no CPU fallback)`);
+        }
+        if (runtime || process.env.GSTARK_SET_MODULUS === '1') {      // (GSTARK_SET_MODULUS=1: GSTARK_LIB names a runtime-modulus library — the tests' double)
+            const bytes = Buffer.alloc(32);
+            let x = wanted;
+            for (let i = 0; i < 32; i++) { bytes[i] = Number(x & 0xFFn); x >>= 8n; }
+            a.call('gs_set_modulus', bytes, 32);
         }
         const info = a.fieldInfo();
         ELEMENT_SIZE = info.elementSize;

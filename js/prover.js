@@ -14,8 +14,8 @@ const DRIVERS = new Map([
 ]);
 function driverPath(field) {
     if (process.env.GSTARK_PROVER_LIB) return process.env.GSTARK_PROVER_LIB;
-    if (!DRIVERS.has(field.modulus)) throw new TypeError(`no build of the native driver for the field of ${field.modulus} elements`);
-    return path.join(__dirname, '..', 'genstark_amd', 'csrc', DRIVERS.get(field.modulus));
+    // (a modulus without a build of its own: the runtime-modulus driver, which adopts the modulus of the library it is bound to)
+    return path.join(__dirname, '..', 'genstark_amd', 'csrc', DRIVERS.has(field.modulus) ? DRIVERS.get(field.modulus) : 'libgstark_prover_rt.so');
 }
 
 function proveMimcSerialized(air, options, assertions, seed) {

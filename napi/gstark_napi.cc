@@ -91,6 +91,7 @@ const FnDesc kFns[] = {
     {"gs_air_trace_segments", "cwiwibiiibwibuup"},
     {"gs_air_constraints", "cwibiiiipuupxip"},
     {"gs_air_jit_check", "iwiwibiiixiou"},
+    {"gs_set_modulus", "bi"},
     {"gs_small_interpolate", "bbio"},
     {"gs_pseudorandom_indexes", "biiuio"},
     {"gs_small_eval_poly", "bibio"},

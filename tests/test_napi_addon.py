@@ -21,9 +21,9 @@ def addon():
     return os.path.join(ROOT, 'napi', 'gstark_napi.node')
 
 
-def run_node(env_extra, script='js/smoke.js'):
+def run_node(env_extra, script='js/smoke.js', args=()):
     env = dict(os.environ, **env_extra)
-    return subprocess.run([NODE, os.path.join(ROOT, script)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    return subprocess.run([NODE, os.path.join(ROOT, script), *args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
 
 
 def test_js_facade_plumbing_on_oracle_double(addon, oracle_backend):
@@ -47,6 +47,19 @@ def test_js_facade_on_hip(addon):
     r = run_node({})
     assert r.returncode == 0, r.stderr
     assert 'hip-gfx950' in r.stdout
+
+
+def test_js_create_prime_field_for_any_modulus_on_oracle_double(addon, oracle_backend):
+    """createPrimeField(modulus) for a modulus without a build of its own: the runtime-modulus library (here its checker, liboracle_rt.so)"""
+    r = run_node({'GSTARK_LIB': os.path.join(ROOT, 'oracle', 'liboracle_rt.so'), 'GSTARK_ALLOW_TEST_DOUBLE': '1', 'GSTARK_SET_MODULUS': '1'},
+                 script='tests/js_runtime_modulus.js', args=['2042167297'])
+    assert r.returncode == 0 and 'js runtime modulus OK' in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_js_create_prime_field_for_any_modulus_on_hip(addon):
+    r = run_node({}, script='tests/js_runtime_modulus.js', args=['1945555039024054273'])      # 27 * 2^56 + 1, a 61-bit prime
+    assert r.returncode == 0 and 'js runtime modulus OK' in r.stdout, r.stderr[-2000:]
 
 
 # ---- AIRs as descriptors (js/air_generic.js): the members lib/Stark.ts calls on the AIR, node vs the Python host, same library ---
