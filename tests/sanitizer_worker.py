@@ -94,7 +94,8 @@ def verify_mode(count):
         assert p.verify_native(a, data, public) is True, name
         parsed = p.parse(data)
         rng = random.Random(zlib.crc32(name.encode()) + SEED)
-        for _ in range(count):
+        # the full count for MiMC and the program AIR under both hash algorithms; 2/5 of it for the ledger (shapes) and the 32-bit flavour
+        for _ in range(count if name.startswith(('mimc', 'poseidon')) else 2 * count // 5):
             bad = mutate(rng, data)
             try:
                 ok = p.verify_native(a, bad, public)
