@@ -267,9 +267,20 @@ def comm_selftest(backend, comm, rank, world):
             return f'all_to_all returned {rc}'
         if backend.download(recv, piece * world) != b''.join(pat(r, rank) for r in range(world)):
             return 'all_to_all delivered wrong bytes'
+        if comm.fork and comm.join:
+            # the overlapped form the driver uses for the evaluation tree's digests (gs_comm::fork / join): the collective goes to the
+            # communicator's own stream behind an event, the context's stream waits for it at join
+            fj = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+            backend.upload(recv, bytes(piece * world))
+            rc = fj(comm.fork)(comm.self, backend.ctx) or ag(comm.all_to_all)(comm.self, backend.ctx, send, recv, piece) or fj(comm.join)(comm.self, backend.ctx)
+            backend.sync()
+            if rc:
+                return f'forked all_to_all returned {rc}'
+            if backend.download(recv, piece * world) != b''.join(pat(r, rank) for r in range(world)):
+                return 'forked all_to_all delivered wrong bytes'
         if comm.take_timings:
             tt = C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.POINTER(C.c_double), C.c_uint32)
-            tt(comm.take_timings)(comm.self, (C.c_double * 8)(), 8)                   # drain the two event pairs
+            tt(comm.take_timings)(comm.self, (C.c_double * 8)(), 8)                   # drain the event pairs
         return None
     finally:
         backend.free(send)
