@@ -34,8 +34,19 @@ def handle(req):
         return {'modulus': str(module.modulus), 'exports': out}
     air = AssemblyAir(module, req.get('component') or 'default', req.get('extensionFactor'), field=HostField(module.modulus))
     if req['op'] == 'info':        # what lib/Stark.ts reads of an AirModule before any input arrives (lib/Stark.ts:40-75)
-        return {'traceRegisterCount': air.traceRegisterCount, 'secretInputCount': air.secretInputCount, 'constraintDegrees': air.constraintDegrees,
-                'maxConstraintDegree': air.maxConstraintDegree, 'extensionFactor': air.extensionFactor, 'inputRegisters': len(air.inputRegisters)}
+        out = {'traceRegisterCount': air.traceRegisterCount, 'secretInputCount': air.secretInputCount, 'constraintDegrees': air.constraintDegrees,
+               'maxConstraintDegree': air.maxConstraintDegree, 'extensionFactor': air.extensionFactor, 'inputRegisters': len(air.inputRegisters)}
+        if air.inputRegisters:
+            # what the one-call native verify needs of a component with input registers (js/prover.js: verifyAssemblySerialized; struct
+            # gs_input_register / gs_static_source of include/gstark_prover.h): the declarations, where each static register of the
+            # programs takes its values from, the cyclic registers' values, and the shape-independent constraint evaluator
+            sources, cycles = air.staticSources()
+            pr = air.evaluationProgram
+            out.update({'inputDeclarations': [{'parent': d['parent'], 'peer': d['peer'], 'steps': d['steps'] or 0, 'shift': d['shift'], 'secret': bool(d['secret'])}
+                                              for d in air.inputRegisters],
+                        'staticSources': [list(x) for x in sources], 'cycles': [[str(v) for v in c] for c in cycles],
+                        'evaluation': {'code': [w for ins in pr.code for w in ins], 'consts': [str(v) for v in pr.consts], 'nregs': pr.nregs, 'nout': pr.nout}})
+        return out
     if req['op'] == 'describe':
         if air.inputRegisters:
             raise ValueError('the component has input registers: its trace is sized when the inputs arrive')

@@ -71,6 +71,7 @@ class AssemblyAir {
         this.constraintDegrees = info.constraintDegrees; this.maxConstraintDegree = info.maxConstraintDegree; this.extensionFactor = info.extensionFactor;
         this.constraints = info.constraintDegrees.map(degree => ({ degree }));
         this._inner = info.inputRegisters ? null : this._build(ask(this._req('describe')).descriptor);
+        this.info = info;          // (with input registers: declarations, static sources, cycles, the shape-independent evaluator — js/prover.js)
     }
     /** the register-machine AIR of a component without input registers (what js/prover.js: proveGenericSerialized takes) */
     get generic() { if (!this._inner) throw new Error('the component has input registers: its AIR is built when the inputs arrive'); return this._inner; }

@@ -33,9 +33,9 @@ function proveMimcSerialized(air, options, assertions, seed) {
 
 // ... and for an AIR given as register-machine programs (js/air_generic.js: the reference's Rescue / Poseidon examples): kind 1 of
 // gs_prover_air.  The two programs keep separate constant pools; the driver takes one, so the evaluator's constant indexes are rebased.
-function proveGenericSerialized(air, options, assertions, seed) {
+function genericJob(air, context, options, assertions) {
     if (!(options.hashAlgorithm in HASH_ALG)) throw new TypeError(`Hash algorithm ${options.hashAlgorithm} is not supported`);
-    const f = air.field, context = air.initProvingContext([], seed);
+    const f = air.field;
     const t = air.transitionProgram, e = air.evaluationProgram, init = air.initProgram;
     if (init && init.consts.length > t.consts.length) throw new Error('the init program extends the transition program\'s constant pool');
     const base = t.consts.length, eCode = e.code.slice();
@@ -50,11 +50,55 @@ function proveGenericSerialized(air, options, assertions, seed) {
         assertions: assertions.map(a => ({ step: a.step, register: a.register, value: le(f.mod(a.value)) })),
         registers: air.traceRegisterCount, degrees: air.constraintDegrees, tCode: t.code, iCode: init ? init.code : [], eCode,
         consts: pool.length ? Buffer.concat(pool.map(le)) : Buffer.alloc(0), vmRegs: Math.max(t.nregs, e.nregs, init ? init.nregs : 0),
-        staticValues: context.staticValuesPacked(), staticPeriods: air.staticRegisters.map(v => v.length), staticTables: context.staticTables.ptr,
+        // static registers: the public ones, then this proof's secret columns (struct gs_prover_air: static_values / static_tables hold both)
+        staticValues: context.staticValuesPacked(), staticPeriods: context.allStaticColumns().map(v => v.length), staticTables: context.staticTables.ptr,
         staticLens: context.staticLens, firstRows: Buffer.concat(context.firstRows.map(row => Buffer.concat(row.map(le)))),
         segments: air.segmentLength === null ? 0 : context.firstRows.length, segmentLen: air.segmentLength === null ? 0 : air.segmentLength,
     };
-    return native().proveGenericSerialized(f.ctx, driverPath(f), job);
+    if (context.secretRegisterTraces.length) job.secretTraces = context.secretRegisterTraces.map(v => v.ptr);
+    return job;
+}
+function proveGenericSerialized(air, options, assertions, seed) {
+    const context = air.initProvingContext([], seed);
+    return native().proveGenericSerialized(air.field.ctx, driverPath(air.field), genericJob(air, context, options, assertions));
+}
+
+// ... and for an air-assembly component WITH input registers (js/air_assembly.js: AssemblyAir): the loader lays the inputs out (the inner
+// AIR of this shape, the secret columns, the first rows), the native driver proves it and writes the inputs' shapes into the proof
+// (iShapes, lib/Stark.ts:161); the native verifier sizes the trace from the shapes the proof carries (lib/Stark.ts:176).
+const declWords = d => [d.parent === null || d.parent === undefined ? 0 : d.parent + 1, d.peer === null || d.peer === undefined ? 0 : d.peer + 1, d.steps || 0, d.shift >>> 0, d.secret ? 1 : 0];
+function proveAssemblySerialized(assemblyAir, options, assertions, inputs, seed) {
+    if (!assemblyAir.info.inputRegisters) return proveGenericSerialized(assemblyAir.generic, options, assertions, seed);
+    const context = assemblyAir.initProvingContext(inputs, seed);
+    const job = genericJob(context.air, context, options, assertions);
+    job.inputRegisters = [].concat(...assemblyAir.info.inputDeclarations.map(declWords));
+    job.inputShapes = [].concat(...context.inputShapes.map(sh => [sh.length].concat(sh)));
+    return native().proveGenericSerialized(context.air.field.ctx, driverPath(context.air.field), job);
+}
+function verifyAssemblySerialized(assemblyAir, options, assertions, proof, publicInputs) {
+    if (!(options.hashAlgorithm in HASH_ALG)) throw new TypeError(`Hash algorithm ${options.hashAlgorithm} is not supported`);
+    if (!assemblyAir.info.inputRegisters) return verifyGenericSerialized(assemblyAir.generic, options, assertions, proof);
+    const f = assemblyAir.field, info = assemblyAir.info, e = info.evaluation;
+    // the field's root of unity of the largest power-of-two order (at most 2^32): the driver squares it down to the evaluation domain's
+    let adicity = 0;
+    for (let x = f.modulus - 1n; x % 2n === 0n; x /= 2n) adicity++;
+    const log2 = Math.min(adicity, 32);
+    const flat = x => Array.isArray(x) ? [].concat(...x.map(flat)) : [x];
+    const lists = (publicInputs || []).map(flat);
+    const cycles = info.cycles.map(c => c.map(BigInt));
+    const job = {
+        steps: 0, extensionFactor: assemblyAir.extensionFactor, exeQueryCount: options.exeQueryCount, friQueryCount: options.friQueryCount,
+        hashAlg: HASH_ALG[options.hashAlgorithm], rootOfUnity: le(f.getRootOfUnity(2 ** log2)), rootOfUnityLog2: log2,
+        assertions: assertions.map(a => ({ step: a.step, register: a.register, value: le(f.mod(a.value)) })),
+        registers: assemblyAir.traceRegisterCount, degrees: assemblyAir.constraintDegrees, tCode: [], iCode: [], eCode: e.code,
+        consts: e.consts.length ? Buffer.concat(e.consts.map(v => le(BigInt(v)))) : Buffer.alloc(0), vmRegs: e.nregs,
+        staticValues: cycles.length ? Buffer.concat([].concat(...cycles).map(v => le(f.mod(v)))) : le(0n), staticPeriods: cycles.map(c => c.length),
+        staticTables: 0n, staticLens: cycles.map(() => 0), firstRows: Buffer.alloc(assemblyAir.traceRegisterCount * f.elementSize), segments: 0, segmentLen: 0,
+        nsecret: assemblyAir.secretInputCount, inputRegisters: [].concat(...info.inputDeclarations.map(declWords)),
+        staticSources: [].concat(...info.staticSources), publicInputs: lists.length ? Buffer.concat([].concat(...lists).map(v => le(f.mod(BigInt(v))))) : Buffer.alloc(0),
+        publicInputCounts: lists.map(l => l.length),
+    };
+    return native().proveGenericSerialized(f.ctx, driverPath(f), job, Buffer.from(proof));
 }
 
 // Stark.verify() of serialized proof bytes by the NATIVE verifier (genstark_amd/csrc/verifier.h; CPU only, no device work): true, or throws
@@ -85,4 +129,4 @@ function verifyGenericSerialized(air, options, assertions, proof) {
     return native().proveGenericSerialized(f.ctx, driverPath(f), job, Buffer.from(proof));
 }
 
-module.exports = { proveMimcSerialized, proveGenericSerialized, verifyMimcSerialized, verifyGenericSerialized };
+module.exports = { proveMimcSerialized, proveGenericSerialized, proveAssemblySerialized, verifyMimcSerialized, verifyGenericSerialized, verifyAssemblySerialized };

@@ -530,6 +530,57 @@ napi_value ProveGenericSerialized(napi_env env, napi_callback_info info) {
         return nullptr;
     }
     std::vector<uint64_t> lens(lens32.begin(), lens32.end());
+    // optional: secret registers and input registers (include/gstark_prover.h, round 6).  secretTraces: BigInt[] (device pointers: the secret
+    // registers' extensions; prove) or nsecret (verify); inputRegisters: 5 numbers per register {parent + 1, peer + 1 (0 = none), steps, shift
+    // as uint32, secret}; inputShapes: per register rank, dimensions...; staticSources: {kind, index} pairs; publicInputs: Buffer +
+    // publicInputCounts; rootOfUnityLog2
+    auto has = [&](const char *name) { bool h = false; return napi_has_named_property(env, argv[2], name, &h) == napi_ok && h; };
+    std::vector<uint32_t> in_regs, in_shapes, sources, pub_counts32;
+    std::vector<uint64_t> secret_ptrs, pub_counts;
+    std::vector<const void *> secret_traces;
+    std::vector<gs_input_register> decls;
+    std::vector<gs_static_source> srcs;
+    const uint8_t *pub = nullptr;
+    size_t npub = 0;
+    uint64_t nsecret = 0, root_log2 = 0;
+    bool extra_ok = true;
+    if (has("secretTraces")) {
+        napi_value arr = prop("secretTraces");
+        uint32_t n = 0;
+        extra_ok = napi_get_array_length(env, arr, &n) == napi_ok && n <= 64;
+        secret_ptrs.resize(extra_ok ? n : 0);
+        for (uint32_t i = 0; i < n && extra_ok; i++) { napi_value e; extra_ok = napi_get_element(env, arr, i, &e) == napi_ok && get_u64(env, e, &secret_ptrs[i]) && secret_ptrs[i]; }
+        for (uint64_t p : secret_ptrs) secret_traces.push_back((const void *)(uintptr_t)p);
+        nsecret = secret_ptrs.size();
+    } else if (has("nsecret")) extra_ok = u64("nsecret", &nsecret) && nsecret <= 64;
+    if (extra_ok && has("inputRegisters")) {
+        extra_ok = words("inputRegisters", in_regs) && in_regs.size() % 5 == 0 && in_regs.size() / 5 <= 255;
+        for (size_t j = 0; extra_ok && j < in_regs.size() / 5; j++) {
+            gs_input_register d;
+            d.parent = (int32_t)in_regs[5 * j] - 1; d.peer = (int32_t)in_regs[5 * j + 1] - 1; d.steps = in_regs[5 * j + 2];
+            d.shift = (int32_t)in_regs[5 * j + 3]; d.secret = in_regs[5 * j + 4] ? 1u : 0u;
+            extra_ok = d.parent < (int32_t)j && d.peer < (int32_t)j;
+            decls.push_back(d);
+        }
+    }
+    if (extra_ok && has("inputShapes")) {
+        extra_ok = words("inputShapes", in_shapes);
+        size_t at = 0, regs_seen = 0;                       // the flat list must hold exactly one (rank, dims...) group per declared register
+        while (extra_ok && at < in_shapes.size()) { extra_ok = in_shapes[at] <= 255 && at + 1 + in_shapes[at] <= in_shapes.size(); at += 1 + (extra_ok ? in_shapes[at] : 0); regs_seen++; }
+        extra_ok = extra_ok && regs_seen == decls.size();
+    }
+    if (extra_ok && has("staticSources")) {
+        extra_ok = words("staticSources", sources) && sources.size() % 2 == 0;
+        for (size_t i = 0; extra_ok && i < sources.size(); i += 2) srcs.push_back(gs_static_source{sources[i], sources[i + 1]});
+    }
+    if (extra_ok && has("publicInputs")) {
+        extra_ok = bytes(prop("publicInputs"), &pub, &npub) && words("publicInputCounts", pub_counts32);
+        uint64_t total = 0;
+        for (uint32_t c : pub_counts32) { pub_counts.push_back(c); total += c; }
+        extra_ok = extra_ok && npub >= total * es;
+    }
+    if (extra_ok && has("rootOfUnityLog2")) extra_ok = u64("rootOfUnityLog2", &root_log2) && root_log2 < 64;
+    if (!extra_ok) { napi_throw_type_error(env, nullptr, "proveGenericSerialized: malformed job (secret / input registers)"); return nullptr; }
     job.steps = t; job.extension_factor = (uint32_t)ef; job.exe_query_count = (uint32_t)exe; job.fri_query_count = (uint32_t)fri; job.hash_alg = (int32_t)alg;
     memcpy(job.root_of_unity, rou, es);
     gs_prover_air &a = job.air;
@@ -541,6 +592,21 @@ napi_value ProveGenericSerialized(napi_env env, napi_callback_info info) {
     a.static_values = svals; a.static_periods = periods.data(); a.nstatic = (uint32_t)periods.size();
     a.static_tables = (const void *)(uintptr_t)tables; a.static_lens = lens.data();
     a.first_rows = first; a.segments = segments; a.segment_len = seglen;
+    a.nsecret = (uint32_t)nsecret;
+    a.secret_traces = secret_traces.empty() ? nullptr : secret_traces.data();
+    if (!decls.empty()) {
+        a.inputs = decls.data(); a.ninputs = (uint32_t)decls.size();
+        a.input_shapes = in_shapes.empty() ? nullptr : in_shapes.data();
+        if (!srcs.empty()) {      // verify: one source per static register; staticPeriods / staticValues then list the cyclic ones only
+            uint32_t cyclic = 0;
+            for (const gs_static_source &q : srcs) cyclic += q.kind == GS_STATIC_CYCLE;
+            if (cyclic != periods.size()) { napi_throw_type_error(env, nullptr, "proveGenericSerialized: staticPeriods must list exactly the cyclic static registers"); return nullptr; }
+            a.static_sources = srcs.data();
+            a.nstatic = (uint32_t)srcs.size();
+        }
+        a.public_inputs = pub; a.public_input_counts = pub_counts.empty() ? nullptr : pub_counts.data(); a.npublic_inputs = (uint32_t)pub_counts.size();
+    }
+    job.root_of_unity_log2 = (uint32_t)root_log2;
     napi_value arr = prop("assertions");
     uint32_t na = 0;
     NAPI_OK(env, napi_get_array_length(env, arr, &na));

@@ -82,6 +82,18 @@ refuses(() => a.proveGenericSerialized(ctx, DRIVER, {}), /malformed job/);
 for (const [k, v] of [['tCode', [1, 0, 0]], ['eCode', [1]], ['iCode', [0, 0]], ['staticLens', []], ['staticValues', Buffer.alloc(es)], ['firstRows', Buffer.alloc(es * 2)],
                       ['consts', Buffer.alloc(es + 1)], ['degrees', 'x'], ['staticPeriods', [2, 'x']], ['registers', -1], ['rootOfUnity', 'x']])
     refuses(() => a.proveGenericSerialized(ctx, DRIVER, Object.assign({}, generic, { [k]: v })), /malformed job/);
+// ... and the optional secret / input register fields (round 6)
+for (const [k, v] of [['inputRegisters', [0, 0, 8]], ['inputRegisters', [2, 0, 8, 0, 0]], ['secretTraces', [0n]], ['secretTraces', 'x'], ['nsecret', 999], ['rootOfUnityLog2', 99]])
+    refuses(() => a.proveGenericSerialized(ctx, DRIVER, Object.assign({}, generic, { [k]: v })), /secret \/ input registers/);
+const shaped = Object.assign({}, generic, { inputRegisters: [0, 0, 8, 0, 1] });
+refuses(() => a.proveGenericSerialized(ctx, DRIVER, Object.assign({}, shaped, { inputShapes: [1, 8, 1] })), /secret \/ input registers/);
+refuses(() => a.proveGenericSerialized(ctx, DRIVER, Object.assign({}, shaped, { inputShapes: [3, 8] })), /secret \/ input registers/);
+refuses(() => a.proveGenericSerialized(ctx, DRIVER, Object.assign({}, shaped, { inputShapes: [1, 8], staticSources: [0] })), /secret \/ input registers/);
+refuses(() => a.proveGenericSerialized(ctx, DRIVER, Object.assign({}, shaped, { inputShapes: [1, 8], staticSources: [1, 0] })), /cyclic static registers/);
+refuses(() => a.proveGenericSerialized(ctx, DRIVER, Object.assign({}, shaped, { inputShapes: [1, 8], publicInputs: Buffer.alloc(es), publicInputCounts: [2] })), /secret \/ input registers/);
+refuses(() => a.proveGenericSerialized(ctx, DRIVER, Object.assign({}, shaped, { inputShapes: [1, 8], publicInputs: 'x', publicInputCounts: [] })), /secret \/ input registers/);
+refuses(() => a.proveGenericSerialized(ctx, DRIVER, Object.assign({}, shaped, { inputShapes: [1, 3] })), /./);          // shapes that lay out no trace: the driver's message
+refuses(() => a.proveGenericSerialized(ctx, DRIVER, Object.assign({}, shaped, { inputShapes: [1, 4], staticSources: [0, 0], steps: 0, rootOfUnityLog2: 20 }), Buffer.alloc(4000, 3)), /./);
 refuses(() => a.proveGenericSerialized(ctx, DRIVER, generic, Buffer.alloc(3000, 7)), /./);
 refuses(() => a.proveGenericSerialized(ctx, DRIVER, Object.assign({}, generic, { eCode: [77, 0, 0, 0] }), Buffer.alloc(3000, 0)), /./);
 refuses(() => a.proveGenericSerialized(ctx, DRIVER, Object.assign({}, generic, { eCode: [0, 0, 99, 0] }), Buffer.alloc(3000, 0)), /./);

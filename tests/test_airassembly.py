@@ -338,6 +338,33 @@ def check_index_fixture(backend):
         assert (len(data), hashlib.sha256(data).hexdigest()) == (rec['proofSize'], rec['proofSha256']), case['name']
 
 
+def check_js_onecall(backend, lib_env, tmp_path):
+    """js/prover.js: proveAssemblySerialized / verifyAssemblySerialized — the cube chain (no inputs) and the ledger (2 secret + 1 public
+    input register, nested shapes) through ONE native call each from node: the bytes the Python host proves from the same source
+    (shapes included), verified natively from node with the public inputs, tampering and wrong public inputs refused."""
+    cases = index_cases(backend)
+    cin, cout = tmp_path / 'cases.json', tmp_path / 'out.json'
+    cin.write_text(json.dumps(cases))
+    subprocess.check_call(['bash', os.path.join(ROOT, 'napi', 'build.sh')])
+    r = subprocess.run(['node', os.path.join(HERE, 'js_assembly_onecall.js'), str(cin), str(cout)], env=dict(os.environ, **lib_env), cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'js one-call assembly OK: 3 statements' in r.stdout, r.stderr[-3000:]
+    got = {rec['name']: rec for rec in json.loads(cout.read_text())}
+    for case in cases:
+        assert bytes.fromhex(got[case['name']]['proofHex']) == python_bytes(case, backend), case['name']
+        assert got[case['name']]['verified'] and got[case['name']]['tamperRejected']
+
+
+@pytest.mark.skipif(not (shutil.which('node') and os.path.exists('/usr/include/node/node_api.h')), reason='node or its headers are not in this image')
+def test_js_onecall_assembly_statements_on_oracle_double(oracle_backend, tmp_path):
+    check_js_onecall(oracle_backend, {'GSTARK_LIB': ORACLE_LIB, 'GSTARK_ALLOW_TEST_DOUBLE': '1'}, tmp_path)
+
+
+@pytest.mark.gpu
+def test_js_onecall_assembly_statements_on_hip(hip_backend, tmp_path):
+    check_js_onecall(hip_backend, {}, tmp_path)
+
+
 def test_python_host_reproduces_what_the_reference_index_js_proved(oracle_backend):
     """tests/golden/reference_index_proofs.json: proofs the reference's own bin/index.js produced from AirAssembly SOURCE over the drop-in
     modules (generated in the build container by the live test below) == what the Python host proves from the same source."""
