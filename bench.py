@@ -365,7 +365,7 @@ def compact_line(out, detail_name='bench_detail.json'):
         optional.append('configs')
     op = out.get('one_proof')
     if op:
-        o = {k: _short(op[k], 160) for k in ('error', 'rccl_error', 'gpu_sharing', 'rccl_create_ms', 'rccl_selftest_ms') if k in op}
+        o = {k: _short(op[k], 160) for k in ('error', 'rccl_error', 'rccl_mode', 'gpu_sharing', 'rccl_create_ms', 'rccl_selftest_ms') if k in op}
         if 'comm' in op:
             o['comm'] = _short(op['comm'].get('name'), 80)
         for key in ('c4', 'c4_long', 'c5'):
@@ -420,6 +420,8 @@ def main():
     # test-only: drive the distributed harness on CPU (gloo) against the oracle's implementation of the C ABI
     ap.add_argument('--detail', default=os.path.join(ROOT, 'bench_detail.json'), help='where the full record goes (the last stdout line is its summary)')
     ap.add_argument('--test-double-lib', default=None, help=argparse.SUPPRESS)
+    # test-only: run the N > 1 flow (process group, one-proof leg over the RCCL communicator) with ONE rank — what a one-GPU box can execute of it
+    ap.add_argument('--force-dist', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     cpu_mode = args.test_double_lib is not None
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -440,9 +442,16 @@ def main():
     ndev = 0 if cpu_mode else torch.cuda.device_count()
     shared_gpus = (not cpu_mode) and world > ndev >= 1
     device_index = local_rank % ndev if shared_gpus else local_rank
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1:        # --force-dist without a launcher: a one-rank group of this process alone
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+                so.bind(('127.0.0.1', 0))
+                os.environ.setdefault('MASTER_PORT', str(so.getsockname()[1]))
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         if cpu_mode or shared_gpus:
             dist.init_process_group('gloo')
             if not cpu_mode:
@@ -737,23 +746,42 @@ def main():
                     # the product communicator: RCCL on the library's device buffers.  It is checked with known patterns first (both
                     # collectives, every rank); if any rank cannot create it or sees wrong bytes, ALL ranks fall back to collectives
                     # staged through the host over a gloo group, so that the strong-scaling figures still exist — and say so
-                    rccl_error = None
-                    try:
-                        uid = [RcclComm.unique_id() if rank == 0 else None]
-                        dist.broadcast_object_list(uid, src=0)                          # control path: 128 bytes, once
-                        t_rccl = time.perf_counter()
-                        comm = RcclComm(backend, rank, world, uid[0])
-                        result['rccl_create_ms'] = round((time.perf_counter() - t_rccl) * 1e3, 1)
-                        t_rccl = time.perf_counter()
-                        rccl_error = comm_selftest(backend, comm.comm, rank, world)
-                        result['rccl_selftest_ms'] = round((time.perf_counter() - t_rccl) * 1e3, 1)
-                    except Exception as e:   # noqa: BLE001
-                        rccl_error = repr(e)[:200]
-                    errs = [None] * world
-                    dist.all_gather_object(errs, rccl_error)
-                    if any(errs):
-                        result['rccl_error'] = next(e for e in errs if e)
+                    # Three forms of the RCCL communicator are tried in turn, each on a fresh communicator, every rank taking the same decision
+                    # (the errors are all-gathered): as built (ncclAllToAll; collectives may be forked onto the communicator's own stream),
+                    # without the overlap, and with the grouped ncclSend / ncclRecv exchange as well.  `rccl_mode` says which one ran.
+                    attempts = [('alltoall + overlap', {}), ('alltoall, in stream order', {'GSTARK_RCCL_NO_OVERLAP': '1'}),
+                                ('grouped send/recv, in stream order', {'GSTARK_RCCL_NO_OVERLAP': '1', 'GSTARK_RCCL_GROUPED_ALLTOALL': '1'})]
+                    tried = []
+                    for mode, env_extra in attempts:
+                        rccl_error = None
+                        for k in ('GSTARK_RCCL_NO_OVERLAP', 'GSTARK_RCCL_GROUPED_ALLTOALL'):
+                            os.environ.pop(k, None)
+                        os.environ.update(env_extra)                   # (read by gs_rccl_comm_create, csrc/comm_rccl.cc)
+                        try:
+                            uid = [RcclComm.unique_id() if rank == 0 else None]
+                            dist.broadcast_object_list(uid, src=0)                          # control path: 128 bytes
+                            t_rccl = time.perf_counter()
+                            comm = RcclComm(backend, rank, world, uid[0])
+                            result['rccl_create_ms'] = round((time.perf_counter() - t_rccl) * 1e3, 1)
+                            t_rccl = time.perf_counter()
+                            rccl_error = comm_selftest(backend, comm.comm, rank, world)
+                            result['rccl_selftest_ms'] = round((time.perf_counter() - t_rccl) * 1e3, 1)
+                        except Exception as e:   # noqa: BLE001
+                            rccl_error = repr(e)[:200]
+                        errs = [None] * world
+                        dist.all_gather_object(errs, rccl_error)
+                        if not any(errs):
+                            result['rccl_mode'] = mode
+                            break
+                        tried.append(f'{mode}: {next(e for e in errs if e)}')
+                        if comm is not None:
+                            try:
+                                comm.close()
+                            except Exception:   # noqa: BLE001
+                                pass
                         comm = None
+                    if tried:
+                        result['rccl_error'] = '; '.join(tried)[:400]
                 if comm is None:
                     group = dist.new_group(backend='gloo') if not host_collectives else None
                     comm = TorchComm(backend, group=group)
