@@ -368,6 +368,14 @@ class _Layout:
             if self.length and count * span[j] != self.length:
                 raise GstarkError('input registers imply different trace lengths')
             self.length = count * span[j]
+        # (a register whose values are held for 0 steps, or that has no values, is skipped by the rule above when it comes first: every
+        #  register must fill the trace the others lay out)
+        for j in range(len(inputs)):
+            count = 1
+            for n in self.shapes[j]:
+                count *= n
+            if count * span[j] != self.length:
+                raise GstarkError('input registers imply different trace lengths')
         if inputs and (self.length < 2 or self.length & (self.length - 1)):
             raise GstarkError(f'the inputs make a trace of {self.length} steps: a power of 2 is required')
 

@@ -314,23 +314,25 @@ InputLayout input_layout(const gs_prover_air &air, const Shapes &shapes) {
         if (in[j].parent >= 0 && !std::equal(shapes[j].begin(), shapes[j].end() - 1, shapes[in[j].parent].begin(), shapes[in[j].parent].end()))
             fail(GS_ERR_ARG, "input register %u: one list per value of register %d expected", j, in[j].parent);
     }
-    // steps one value of a register is held: its own (steps n), or what its children take (0 = not known yet)
-    for (uint32_t j = 0; j < n; j++) L.span[j] = in[j].steps;
+    // steps one value of a register is held: its own (steps n), or what its children take (`known`: a span of 0 steps — a child list of
+    // zero values — is a value like any other here, as in the loader; the length rule below refuses it)
+    std::vector<char> known(n, 0);
+    for (uint32_t j = 0; j < n; j++) if (in[j].steps) { L.span[j] = in[j].steps; known[j] = 1; }
     for (bool changed = true; changed;) {
         changed = false;
         for (uint32_t j = 0; j < n; j++) {
-            if (L.span[j] && in[j].parent >= 0) {
+            if (known[j] && in[j].parent >= 0) {
                 const uint64_t want = capped_mul(L.span[j], shapes[j].back());
                 const uint32_t root = (uint32_t)in[j].parent;
-                if (!L.span[root]) { L.span[root] = want; changed = want != 0; }
+                if (!known[root]) { L.span[root] = want; known[root] = 1; changed = true; }
                 else if (L.span[root] != want && !in[root].steps) fail(GS_ERR_ARG, "input registers: the children of one register take different numbers of steps");
             }
-            if (!L.span[j] && in[j].peer >= 0 && L.span[in[j].peer]) { L.span[j] = L.span[in[j].peer]; changed = true; }
-            if (L.span[j] && in[j].peer >= 0 && !L.span[in[j].peer]) { L.span[in[j].peer] = L.span[j]; changed = true; }
+            if (!known[j] && in[j].peer >= 0 && known[in[j].peer]) { L.span[j] = L.span[in[j].peer]; known[j] = 1; changed = true; }
+            if (known[j] && in[j].peer >= 0 && !known[in[j].peer]) { L.span[in[j].peer] = L.span[j]; known[in[j].peer] = 1; changed = true; }
         }
     }
     for (uint32_t j = 0; j < n; j++)
-        if (!L.span[j]) fail(GS_ERR_ARG, "input registers: cannot tell how many steps a value is held (no (steps n) below it)");
+        if (!known[j]) fail(GS_ERR_ARG, "input registers: cannot tell how many steps a value is held (no (steps n) below it)");
     for (uint32_t j = 0; j < n; j++) {
         uint64_t count = 1;
         for (uint32_t d : shapes[j]) count = capped_mul(count, d);
@@ -339,6 +341,8 @@ InputLayout input_layout(const gs_prover_air &air, const Shapes &shapes) {
         if (L.length && len != L.length) fail(GS_ERR_ARG, "input registers imply different trace lengths");
         L.length = len;
     }
+    for (uint32_t j = 0; j < n; j++)            // (a register of no values, or of values held for 0 steps, that came first was skipped above)
+        if (capped_mul(L.count[j], L.span[j]) != L.length) fail(GS_ERR_ARG, "input registers imply different trace lengths");
     if (n && (L.length < 2 || (L.length & (L.length - 1)) || L.length >= MAX_LAYOUT))
         fail(GS_ERR_ARG, "the inputs make a trace of %llu steps: a power of 2 is required", (unsigned long long)L.length);
     return L;
@@ -532,6 +536,23 @@ void gs_prover_sync_phases(int on) { g_sync_phases = on != 0; }
 void gs_prover_member_sequence(int on) { g_member_sequence = on != 0; }
 
 int gs_prover_abi_version(void) { return GS_PROVER_ABI_VERSION; }
+
+int gs_prover_input_layout(const struct gs_input_register *inputs, uint32_t ninputs, const uint32_t *shapes, uint64_t *length, char *err, uint64_t errcap) {
+    if ((ninputs && (!inputs || !shapes)) || !length) return GS_ERR_ARG;
+    try {
+        gs_prover_air air;
+        memset(&air, 0, sizeof air);
+        air.inputs = inputs; air.ninputs = ninputs; air.input_shapes = shapes;
+        *length = input_layout(air, job_shapes(air)).length;
+        return GS_OK;
+    } catch (const Fail &f) {
+        if (err && errcap) snprintf(err, (size_t)errcap, "%s", f.msg.c_str());
+        return f.code ? f.code : GS_ERR_ARG;
+    } catch (const std::exception &e) {
+        if (err && errcap) snprintf(err, (size_t)errcap, "%s", e.what());
+        return GS_ERR_OOM;
+    }
+}
 
 int gs_prover_last_stats(struct gs_prover_stats *out) {
     if (!out) return GS_ERR_ARG;

@@ -167,6 +167,11 @@ int gs_prover_remainder_check(const uint8_t *values, uint64_t len, uint32_t exte
 int gs_prover_remainder_check_on(const gs_prover_binding *b, const uint8_t *values, uint64_t len, uint32_t extension_factor, uint64_t max_degree_plus1,
                                  const uint8_t *root_of_unity, int method);
 
+/* The layout rules of input registers on their own, for tests: the trace length the shapes lay out (`shapes`: per register its rank and
+ * dimensions, as gs_prover_air.input_shapes), or GS_ERR_ARG with the loader's message in err — the same function prove() and verify() apply
+ * (prover.cc: input_layout; genstark_amd/airassembly.py: _Layout is what it restates). */
+int gs_prover_input_layout(const struct gs_input_register *inputs, uint32_t ninputs, const uint32_t *shapes, uint64_t *length, char *err, uint64_t errcap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,7 +149,7 @@ def test_prover_library_exports_its_header():
     subprocess.check_call(['gcc', '-fsyntax-only', '-x', 'c', '-std=c11', header])
     names = set(re.findall(r'^int\s+(gs_prover_\w+)\s*\(', open(header).read(), flags=re.M))
     assert names == {'gs_prover_bind', 'gs_prover_open', 'gs_prover_element_size', 'gs_prover_abi_version', 'gs_prover_prove', 'gs_prover_prove_on', 'gs_prover_last_stats',
-                     'gs_prover_remainder_check', 'gs_prover_remainder_check_on', 'gs_prover_verify', 'gs_prover_verify_on'}
+                     'gs_prover_remainder_check', 'gs_prover_remainder_check_on', 'gs_prover_verify', 'gs_prover_verify_on', 'gs_prover_input_layout'}
     if not os.path.exists(PROVER_LIB_PATH):
         pytest.skip('libgstark_prover.so not built')
     import shutil
