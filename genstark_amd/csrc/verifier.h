@@ -444,10 +444,13 @@ void verify_impl(const gs_prover_job &job, const uint8_t *proof, uint64_t proof_
                 if (j >= air.ninputs) fail(GS_ERR_ARG, "invalid job: static register %u names input register %u of %u", s, j, air.ninputs);
                 if (T > (1ull << 26)) fail(GS_ERR_ARG, "a trace of %llu steps is beyond this verifier's input-register columns", (unsigned long long)T);
                 const uint64_t span = layout.span[j];
-                vals.resize(T);
                 if (src.kind == GS_STATIC_MASK) {
-                    for (uint64_t i = 0; i < T; i++) vals[i] = (i % span) ? (F)0 : (F)1;
+                    // one period of the mask is all there is to it (span divides the power of two T, so it is a power of two itself): a
+                    // proof cannot make the verifier build a trace-length column out of its shapes alone
+                    vals.assign(span, (F)0);
+                    vals[0] = (F)1;
                 } else {
+                    vals.resize(T);
                     if (air.inputs[j].secret || public_at[j] < 0) fail(GS_ERR_ARG, "invalid job: static register %u is a public one, input register %u is secret", s, j);
                     const uint8_t *src_vals = air.public_inputs + ELEM * public_off[public_at[j]];
                     for (uint64_t v = 0; v < layout.count[j]; v++) {
