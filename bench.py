@@ -397,6 +397,13 @@ def emit(out, detail_path):
             json.dump(out, fh, indent=1)
     except OSError as e:
         print(f'bench.py: could not write {detail_path}: {e}', file=sys.stderr, flush=True)
+    try:
+        # whatever native libraries left in C stdio's buffer (RCCL prints a version banner through printf when a communicator is
+        # created: on a pipe it would otherwise come out at exit, AFTER the line) goes out first
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:   # noqa: BLE001
+        pass
     print(compact_line(out, os.path.basename(detail_path)), flush=True)
 
 

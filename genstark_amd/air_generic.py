@@ -172,9 +172,14 @@ class Program:
 
     # ---- marshalling for the C ABI
     def abi_args(self, element_size=16):
-        flat = (C.c_uint32 * (4 * len(self.code)))(*[w for ins in self.code for w in ins])
-        consts = b''.join(int(v).to_bytes(element_size, 'little') for v in self.consts) or bytes(element_size)
-        return flat, len(self.code), consts, len(self.consts), self.nregs
+        # marshalled once per (element size, state of the program): a prover asks for these per proof
+        key = (element_size, len(self.code), len(self.consts))
+        hit = getattr(self, '_abi', None)
+        if hit is None or hit[0] != key:
+            flat = (C.c_uint32 * (4 * len(self.code)))(*[w for ins in self.code for w in ins])
+            consts = b''.join(int(v).to_bytes(element_size, 'little') for v in self.consts) or bytes(element_size)
+            hit = self._abi = (key, flat, consts)
+        return hit[1], len(self.code), hit[2], len(self.consts), self.nregs
 
     # ---- host interpreter (verifier side, Python integers)
     def run(self, cur, nxt_row, statics):
@@ -298,23 +303,28 @@ class GenericProvingContext(_Context):
                 coeffs[::stride] = poly.toValues()
                 poly = f.newVectorFrom(coeffs)
             self.secretRegisterTraces.append(f.evalPolyAtRoots(poly, self.evaluationDomain))
-        # static registers over the composition domain: K_s at the (period * compositionFactor)-th roots of unity
-        all_polys = [(len(v), f.newVectorFrom(p)) for v, p in zip(air.staticRegisters, self._static_polys())] + \
-                    [(len(c), p) for c, p in zip(self.secretValues, secret_polys)]
-        lens = [m * self.compositionFactor for m, _ in all_polys]
-        self._staticLens = lens
-        self._staticTables = Vector(f.backend, max(sum(lens), 1))
-        off = 0
-        for (m, poly), ln in zip(all_polys, lens):
+        # static registers over the composition domain: K_s at the (period * compositionFactor)-th roots of unity.  The PUBLIC registers'
+        # tables are constants of the AIR (computed once, kept on the device with it); the secret ones are this proof's
+        def table(m, poly):
+            ln = m * self.compositionFactor
             wk = f.exp(self.compositionDomain.series_base, self.traceLength // m)
-            tab = f.evalPolyAtRoots(poly, f.getPowerSeries(wk, ln))
+            return ln, f.evalPolyAtRoots(poly, f.getPowerSeries(wk, ln))
+        if getattr(air, '_publicTables', None) is None or air._publicTables[0] is not f.backend:
+            air._publicTables = (f.backend, [table(len(v), f.newVectorFrom(p)) for v, p in zip(air.staticRegisters, self._static_polys())])
+        tables = air._publicTables[1] + [table(len(c), p) for c, p in zip(self.secretValues, secret_polys)]
+        self._staticLens = [ln for ln, _ in tables]
+        self._staticTables = Vector(f.backend, max(sum(self._staticLens), 1))
+        off = 0
+        for ln, tab in tables:
             f.backend.call('gs_copy', C.c_void_p(self._staticTables.ptr + off * f.elementSize), C.c_void_p(tab.ptr), ln * f.elementSize)
             off += ln
 
     def staticValuesPacked(self):
         """(bytes, periods) of every static register's values for the trace generators: public ones, then the secret columns."""
         air, f = self.air, self.field
-        packed = b''.join(f.le(v % f.modulus) for values in air.staticRegisters for v in values) + b''.join(c.data for c in self.secretValues)
+        if getattr(air, '_publicPacked', None) is None:      # the public registers' values are constants of the AIR
+            air._publicPacked = b''.join([f.le(v % f.modulus) for values in air.staticRegisters for v in values])
+        packed = air._publicPacked + b''.join(c.data for c in self.secretValues)
         periods = [len(v) for v in air.staticRegisters] + [len(c) for c in self.secretValues]
         return packed or bytes(f.elementSize), periods
 

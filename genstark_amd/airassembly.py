@@ -403,6 +403,58 @@ def _shrink(col):
     return col
 
 
+def _shrink_packed(data, es):
+    """_shrink on a column of packed elements (canonical values: equal elements have equal bytes)."""
+    n = len(data) // es
+    while n > 1 and n % 2 == 0 and data[:n // 2 * es] == data[n // 2 * es:]:
+        n //= 2
+        data = data[:n * es]
+    return data
+
+
+class _Col:
+    """A static column in closed form: value i of `flat` is held `span` steps, the whole rotated `k` steps earlier and repeated —
+    col[t] = flat[((t + k) mod period) div span].  What plan() works on instead of trace-length lists of Python integers: an input
+    register is (its values, its span, its shift), a mask (1 0 .. 0, 1, its register's shift), a cycle (its values, 1, 0)."""
+    __slots__ = ('flat', 'span', 'k', 'period')
+
+    def __init__(self, flat, span, k):
+        self.flat, self.span, self.period = flat, span, len(flat) * span
+        self.k = k % self.period if self.period else 0
+
+    def at(self, t):
+        return self.flat[((t + self.k) % self.period) // self.span]
+
+    def packed(self, es):
+        """One period as packed little-endian elements, shrunk to its shortest power-of-2 period."""
+        vb = [v.to_bytes(es, 'little') for v in self.flat]
+        body = b''.join(vb) if self.span == 1 else b''.join([x * self.span for x in vb])
+        k = self.k * es
+        return _shrink_packed(body[k:] + body[:k] if k else body, es)
+
+
+class _Lane:
+    """One scalar per run of the computation (the init block evaluated for all runs at once)."""
+    __slots__ = ('v',)
+
+    def __init__(self, v): self.v = v
+
+
+class _Lanes(_Ints):
+    """Integers, or a _Lane of integers: element-wise, integers broadcast."""
+    def _op(self, fn, a, b):
+        la, lb = isinstance(a, _Lane), isinstance(b, _Lane)
+        if la and lb: return _Lane([fn(x, y) for x, y in zip(a.v, b.v)])
+        if la: return _Lane([fn(x, b) for x in a.v])
+        if lb: return _Lane([fn(a, y) for y in b.v])
+        return fn(a, b)
+    def add(self, a, b): return self._op(lambda x, y: (x + y) % self.p, a, b)
+    def sub(self, a, b): return self._op(lambda x, y: (x - y) % self.p, a, b)
+    def mul(self, a, b): return self._op(lambda x, y: x * y % self.p, a, b)
+    def pow(self, a, e): return _Lane([pow(x, e, self.p) for x in a.v]) if isinstance(a, _Lane) else pow(a, e, self.p)
+    def inv(self, a): return self.pow(a, self.p - 2)
+
+
 # ---- the AirModule -------------------------------------------------------------------------------------------------------------------
 class AssemblyAir:
     """The AirModule `instantiate(source, component, options)` hands to Stark (index.ts:18-33; lib/Stark.ts:40): shape-agnostic —
@@ -495,9 +547,14 @@ class AssemblyAir:
         return [_int(v) % p for v in spec]
 
     def _inner(self, length, public_cols, segment):
-        key = (length, tuple(tuple(c) for c in public_cols), segment)
+        """The GenericAir of one (trace length, public static columns, segmentation).  public_cols: lists of integers, or the same
+        columns as packed elements (bytes) — the form plan() has them in; the key is the packed form either way."""
+        es = self.field.elementSize
+        packed = tuple(c if isinstance(c, bytes) else b''.join([int(v).to_bytes(es, 'little') for v in c]) for c in public_cols)
+        key = (length, packed, segment)
         air = self._cache.get(key)
         if air is None:
+            public_cols = [[int.from_bytes(c[i:i + es], 'little') for i in range(0, len(c), es)] if isinstance(c, bytes) else c for c in public_cols]
             transition = lambda r, k: self._run(_Exprs(self.module.modulus), r, None, self._lib_order(k), self.export.transition)
             evaluation = lambda r, n, k: self._run(_Exprs(self.module.modulus), r, n, self._lib_order(k), self.export.evaluation)
             air = GenericAir(length, self.traceRegisterCount, self.constraintDegrees, public_cols, transition, evaluation, lambda seed: list(seed),
@@ -551,16 +608,45 @@ class AssemblyAir:
         context.inputShapes = shapes
         return context
 
+    def _closed_columns(self, layout, inputs, length):
+        """The static registers in lib order as _Col (plan(): every input register comes with its values)."""
+        ex, p, cols, j = self.export, self.module.modulus, [], 0
+        for s in ex.statics:
+            if s['kind'] == 'input':
+                flat = inputs[j]
+                for _ in range(layout.depth[j]):
+                    flat = [v for group in flat for v in group]
+                cols.append(_Col([v % p for v in flat], layout.span[j], -layout.inputs[j]['shift']))
+                j += 1
+            elif s['kind'] == 'mask':
+                i = s['input']
+                cols.append(_Col([1] + [0] * (layout.span[i] - 1), 1, -layout.inputs[i]['shift']))
+            else:
+                cols.append(_Col(self._cycle(s['values']), 1, 0))
+        return cols
+
+    def _first_rows(self, cols, starts):
+        """The init block on the static registers of every step in `starts` at once (no seed parameter): one row per step."""
+        ex = self.export
+        ev = _Evaluator(self.module, _Lanes(self.module.modulus))
+        row = ev.run(ex.init['body'], {'params': {}, 'locals': {}, 'static': [_Lane([c.at(t) for t in starts]) for c in cols]})
+        row = row if isinstance(row, list) else [row]
+        if len(row) != ex.registers:
+            raise GstarkError(f'{ex.name}: the init block yields {len(row)} values for {ex.registers} registers')
+        return [[x.v[i] if isinstance(x, _Lane) else x for x in row] for i in range(len(starts))]
+
     def plan(self, inputs=None, seed=None):
         """What initProvingContext decides before any device work: (the inner GenericAir for these input shapes, the secret registers'
         packed columns, the first row — or the first row of every independent run —, the input shapes).  Needs no backend: the node-side
-        compile() of js/shims/@guildofweavers/air-assembly asks for exactly this (genstark_amd/aa_json.py)."""
+        compile() of js/shims/@guildofweavers/air-assembly asks for exactly this (genstark_amd/aa_json.py).  Columns stay in closed form
+        (_Col) or packed: nothing here costs a Python-integer operation per trace step."""
         ex, p = self.export, self.module.modulus
         inputs = list(inputs or [])
         layout = _Layout(ex.statics, [_shape_of(v) for v in inputs])
         length = layout.length or self._length_without_inputs()
-        cols = self._columns(layout, inputs)
-        public = self._public_split(cols)
+        es = self.field.elementSize
+        cols = self._closed_columns(layout, inputs, length)
+        public = [c.packed(es) for c, (kind, _) in zip(cols, self._where) if kind == 'public']
         secret = [c for c, (kind, _) in zip(cols, self._where) if kind == 'secret']
         # independent runs: a mask on a top-level input means the transition restarts from init on its last step; the segments are
         # then generated side by side (one device thread each when there are many) — checked against the transition below
@@ -569,18 +655,16 @@ class AssemblyAir:
         masked = any(s['kind'] == 'mask' and layout.depth[s['input']] == 0 for s in ex.statics)
         segment = length // runs if (runs > 1 and masked and ex.init['param'] is None) else None
         air = self._inner(length, public, segment)
-        es = self.field.elementSize
-        packed = [PackedColumn(b''.join(v.to_bytes(es, 'little') for v in _shrink(c)), es) for c in secret]
-        at = lambda t: [c[t % len(c)] for c in cols]
+        packed = [PackedColumn(c.packed(es), es) for c in secret]
         if segment is None:
-            firsts = self._first_row(at(0), seed)
+            firsts = self._first_row([c.at(0) for c in cols], seed)
         else:
-            firsts = [self._first_row(at(s * segment), None) for s in range(runs)]
+            firsts = self._first_rows(cols, range(0, runs * segment, segment))
             # the restart the segmentation relies on: the row the transition produces on the last step of run 0 is run 1's first row
-            statics = list(air.staticRegisters) + [c.ints() for c in packed]
+            statics = list(air.staticRegisters)
             row = [v % p for v in firsts[0]]
             for i in range(segment):
-                row = air.transitionProgram.run(row, None, [v[i % len(v)] for v in statics])
+                row = air.transitionProgram.run(row, None, [v[i % len(v)] for v in statics] + [c.at(i) for c in secret])
             if row != [v % p for v in firsts[1]]:
                 air = self._inner(length, public, None)
                 firsts = firsts[0]

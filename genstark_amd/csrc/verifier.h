@@ -179,6 +179,27 @@ F horner(const std::vector<F> &poly, F x) {
     for (size_t k = poly.size(); k-- > 0;) r = hf_add(hf_mul(r, x), poly[k]);
     return r;
 }
+// a canonical product through the weak form where the field has one (the 128-bit flavour: no data-dependent reduction loops; the
+// other flavours: their hf_mul) — for the two loops below that run over trace-length columns
+#ifndef HF_CHAIN_MUL
+#define HF_CHAIN_MUL hf_mul
+#define HF_CHAIN_END(x) (x)
+#endif
+#ifndef HF_CHAIN_ADD
+#define HF_CHAIN_ADD hf_add
+#endif
+static inline F vf_mul(F a, F b) { return HF_CHAIN_END(HF_CHAIN_MUL(a, b)); }
+// one polynomial at many points: the coefficient loop outside, so that the points' chains are independent work for the core (a public
+// input register of an air-assembly component is a polynomial as long as the trace, and one serial chain per query is what verifying costs)
+std::vector<F> horner_many(const std::vector<F> &poly, const std::vector<F> &xs) {
+    std::vector<F> r(xs.size(), (F)0);
+    for (size_t k = poly.size(); k-- > 0;) {
+        const F c = poly[k];
+        for (size_t q = 0; q < xs.size(); q++) r[q] = HF_CHAIN_ADD(HF_CHAIN_MUL(r[q], xs[q]), c);      // weak values inside the chain
+    }
+    for (F &v : r) v = HF_CHAIN_END(v);
+    return r;
+}
 F f_div(F a, F b) { return hf_mul(a, hf_inv(b)); }
 // every element inverted with ONE field inversion (Montgomery's trick); 0 stays 0 (galois' convention)
 void batch_invert(std::vector<F> &v) {
@@ -257,12 +278,12 @@ std::vector<F> cyclic_poly(const std::vector<F> &values, F g) {
         for (size_t k = 0; k < half; k++) { tw[k] = cur; cur = hf_mul(cur, wlen); }
         for (size_t base = 0; base < m; base += 2 * half)
             for (size_t k = 0; k < half; k++) {
-                const F u = out[base + k], v = hf_mul(out[base + k + half], tw[k]);
+                const F u = out[base + k], v = vf_mul(out[base + k + half], tw[k]);
                 out[base + k] = hf_add(u, v);
                 out[base + k + half] = hf_sub(u, v);
             }
     }
-    for (size_t j = 0; j < m; j++) out[j] = hf_mul(out[j], minv);
+    for (size_t j = 0; j < m; j++) out[j] = vf_mul(out[j], minv);
     return out;
 }
 // the shortest power-of-two period of a column (a cyclic register of that length denotes the same polynomial): airassembly.py _shrink
@@ -468,9 +489,11 @@ void verify_impl(const gs_prover_job &job, const uint8_t *proof, uint64_t proof_
             static_periods.push_back(m);
         }
     }
-    auto constraints_at = [&](F x, const std::vector<F> &p, const std::vector<F> &n, const std::vector<F> &s) {
+    // statics_at[k][pi]: static register k at the pi-th queried point (filled below, once the positions are known)
+    std::vector<std::vector<F>> statics_at;
+    auto constraints_at = [&](size_t pi, const std::vector<F> &p, const std::vector<F> &n, const std::vector<F> &s) {
         std::vector<F> statics;
-        for (size_t k = 0; k < static_polys.size(); k++) statics.push_back(horner(static_polys[k], hf_pow(x, (hfe)(T / static_periods[k]))));
+        for (size_t k = 0; k < static_polys.size(); k++) statics.push_back(statics_at[k][pi]);
         if (air.kind == 0) {                                                 // examples/mimc/mimc128Assembly.ts:46-51
             const F x3 = hf_mul(hf_mul(p[0], p[0]), p[0]);
             return std::vector<F>{hf_sub(n[0], hf_add(x3, statics[0]))};
@@ -507,6 +530,11 @@ void verify_impl(const gs_prover_job &job, const uint8_t *proof, uint64_t proof_
         for (auto &d : rdata) dens.push_back(horner(d.zpoly, x));                                      // BoundaryConstraints.ts:55-69
     }
     batch_invert(dens);
+    for (size_t k = 0; k < static_polys.size(); k++) {                        // K_s(x^(T/period)) at every queried x
+        std::vector<F> at(xsq.size());
+        for (size_t pi = 0; pi < xsq.size(); pi++) at[pi] = hf_pow(xsq[pi], (hfe)(T / static_periods[k]));
+        statics_at.push_back(horner_many(static_polys[k], at));
+    }
     size_t di = 0;
     for (size_t pi = 0; pi < positions.size(); pi++) {
         const uint64_t step = positions[pi];
@@ -514,7 +542,7 @@ void verify_impl(const gs_prover_job &job, const uint8_t *proof, uint64_t proof_
         std::vector<F> p, n, s, unused;
         leaf_values(step, p, s);
         leaf_values((step + E) % N, n, unused);
-        std::vector<F> q = constraints_at(x, p, n, s);
+        std::vector<F> q = constraints_at(pi, p, n, s);
         if (q.size() != air.nconstraints) fail(GS_ERR_ARG, "constraint evaluator returned the wrong number of values");
         for (auto &g : groups) {
             if (g.first == combination_degree) continue;

@@ -380,7 +380,8 @@ class NativeProver:
                     raise GstarkError('input register: ragged values')
                 counts.append(len(flat))
                 flat_all.extend(flat)
-            pvals = b''.join(f.le(int(v) % f.modulus) for v in flat_all) or bytes(es)
+            p_ = f.modulus
+            pvals = b''.join([(v if type(v) is int and 0 <= v < p_ else int(v) % p_).to_bytes(es, 'little') for v in flat_all]) or bytes(es)
             pcounts = (C.c_uint64 * max(len(counts), 1))(*counts)
             ja.public_inputs, ja.public_input_counts, ja.npublic_inputs = pvals, pcounts, len(counts)
             keep += [e_code, consts, pub, periods, src, pvals, pcounts]
