@@ -1,13 +1,15 @@
 'use strict';
 // js/air_assembly.js — compile(source) / AirSchema / instantiate(schema, component, options) of `@guildofweavers/air-assembly` as
 // index.ts:4,18-33 and lib/Stark.ts:40 use them, for AirAssembly SOURCE (the inline module of examples/mimc/mimc128Assembly.ts:28-51,
-// assembly/*.aa).  The loader itself is genstark_amd/airassembly.py; this file asks it for a descriptor through a child process
-// (`python3 -m genstark_amd.aa_json`: one JSON request in, one JSON answer out, no device, no library) and hands the descriptor to the
-// register-machine AIR of js/air_generic.js, whose programs the device runs.  Input registers (secret and public, nested shapes) are laid
-// out by the loader when the inputs arrive: the plan it returns carries the public registers as static registers and the secret ones as
-// this proof's columns.
+// assembly/*.aa).  The loader is js/aa_loader.js (JavaScript, in this process: no Python interpreter on the node side); it answers a
+// request with a descriptor that this file hands to the register-machine AIR of js/air_generic.js, whose programs the device runs.
+// Input registers (secret and public, nested shapes) are laid out by the loader when the inputs arrive: the plan it returns carries the
+// public registers as static registers and the secret ones as this proof's columns.  GSTARK_AA_LOADER=python asks the Python loader
+// (genstark_amd/airassembly.py through `python3 -m genstark_amd.aa_json`, a child process) instead: the two give the same answers
+// object for object (tests/test_airassembly.py), the switch exists for that comparison.
 const { spawnSync } = require('child_process');
 const path = require('path');
+const loader = require('./aa_loader');
 const { GenericAir } = require('./air_generic');
 const { defaultField } = require('./context');
 
@@ -15,7 +17,7 @@ const REPO = path.resolve(__dirname, '..');
 
 // The loader's answers are pure functions of the request (source, component, extension factor, and for plan / verify the inputs): an
 // AssemblyAir asks `info` and `describe` at construction and the same `verify` descriptor for every proof of one shape, so answers are
-// kept (64 most recent, requests under 256 KB) instead of paying a python start-up (~0.2 s) per call.
+// kept (64 most recent, requests under 256 KB) instead of compiling the component's programs again per call.
 const answers = new Map();
 function ask(request) {
     const key = JSON.stringify(request);
@@ -24,7 +26,11 @@ function ask(request) {
         answers.delete(key); answers.set(key, hit);           // most recently used last
         return hit;
     }
-    const out = askLoader(key);
+    let out;
+    if (process.env.GSTARK_AA_LOADER === 'python') out = askLoader(key);
+    else {
+        try { out = loader.handle(request); } catch (e) { throw new Error(`AirAssembly: ${e.message}`); }
+    }
     if (key.length < (1 << 18)) {
         answers.set(key, out);
         if (answers.size > 64) answers.delete(answers.keys().next().value);

@@ -1,7 +1,7 @@
 'use strict';
 // replacement for the part of `@guildofweavers/air-assembly` that index.ts:4,18-33, lib/Stark.ts:40 and the examples use:
 //   compile(source) -> AirSchema            AirAssembly text (Buffer | string | path to an .aa file): js/air_assembly.js asks the loader
-//                                           of this repository (genstark_amd/airassembly.py) for the AIR's programs
+//                                           of this repository (js/aa_loader.js, in process) for the AIR's programs
 //   instantiate(schema, component, options) -> AirModule.  `schema` is an AirSchema, or a descriptor:
 //       { mimc: { steps[, modulus] } }      the MiMC AirAssembly module of examples/mimc/mimc128Assembly.ts with its dedicated kernels
 //       { generic: { ... } }                any AIR as register-machine programs — what GenericAir.descriptor() exports

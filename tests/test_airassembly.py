@@ -283,7 +283,7 @@ def test_reference_224_bit_sources_equal_hand_transcriptions():
         assert inner.evaluationProgram.run(r, n, k) == hand.evaluationProgram.run(r, n, k)
 
 
-# ---- the node side: compile(source) / AirSchema of the air-assembly drop-in (js/air_assembly.js -> python -m genstark_amd.aa_json) ------
+# ---- the node side: compile(source) / AirSchema of the air-assembly drop-in (js/air_assembly.js -> js/aa_loader.js) -------------------
 import hashlib
 import json
 import shutil
@@ -488,3 +488,107 @@ def test_node_compile_to_native_driver_on_oracle_double(oracle_backend, tmp_path
 @pytest.mark.gpu
 def test_node_compile_to_native_driver_on_hip(hip_backend, tmp_path):
     check_node_compile_to_native_driver(hip_backend, None, False, tmp_path)
+
+
+# ---- the two loaders: js/aa_loader.js (what the node side runs) against genstark_amd/airassembly.py through aa_json.handle ----------------
+def loader_requests():
+    """Every request kind of js/air_assembly.js on this repository's modules and, where the checkout is present, on the reference's own
+    assembly sources: check / info / describe / plan (random inputs, several shapes) / verify, and requests both loaders must refuse."""
+    import random
+    rnd = random.Random(11)
+    p = 340282366920938463463374607393113505793
+    S = lambda x: [S(v) for v in x] if isinstance(x, list) else str(x)
+    led, cc = (open(os.path.join(AA, name)).read() for name in ('ledger.aa', 'cube_chain.aa'))
+    reqs = []
+    for src, comp in ((led, 'default'), (cc, 'chain')):
+        reqs.append({'op': 'check', 'source': src})
+        reqs += [{'op': 'info', 'source': src, 'component': comp, 'extensionFactor': ef} for ef in (None, 16, 32)]
+    reqs.append({'op': 'describe', 'source': cc, 'component': 'chain', 'extensionFactor': None})
+    reqs.append({'op': 'plan', 'source': cc, 'component': 'chain', 'extensionFactor': None, 'inputs': [], 'seed': ['3']})
+    for runs in (1, 2, 4, 8):
+        inputs = [[rnd.randrange(p) for _ in range(runs)], [rnd.randrange(p) for _ in range(runs)], [[rnd.randrange(p) for _ in range(4)] for _ in range(runs)]]
+        if runs == 4:
+            inputs[2] = [[7, 9, 7, 9]] * runs              # a public column with a short period: it shrinks to a cyclic register of 4 values
+        reqs.append({'op': 'plan', 'source': led, 'component': 'default', 'extensionFactor': None, 'inputs': S(inputs), 'seed': None})
+        reqs.append({'op': 'verify', 'source': led, 'component': 'default', 'extensionFactor': None, 'inputShapes': [[runs], [runs], [runs, 4]], 'publicInputs': S([inputs[2]])})
+    for shift in ('', '(shift 1)', '(shift -2)'):         # other rotations of the input columns than the module's own (shift -1)
+        src = led.replace('(input secret (shift -1))', f'(input secret {shift})').replace('(steps 2) (shift -1))', f'(steps 2) {shift})')
+        inputs = [[rnd.randrange(p) for _ in range(2)], [rnd.randrange(p) for _ in range(2)], [[rnd.randrange(p) for _ in range(4)] for _ in range(2)]]
+        reqs.append({'op': 'plan', 'source': src, 'component': 'default', 'extensionFactor': None, 'inputs': S(inputs), 'seed': None})
+    # refused alike
+    reqs.append({'op': 'plan', 'source': led, 'component': 'default', 'extensionFactor': None, 'inputs': S([[1, 2], [3], [[1, 2, 3, 4], [1, 2, 3, 4]]]), 'seed': None})
+    reqs.append({'op': 'plan', 'source': led, 'component': 'default', 'extensionFactor': None, 'inputs': S([[1, 2, 3], [3, 4, 5], [[1, 2, 3, 4]] * 3]), 'seed': None})
+    reqs.append({'op': 'plan', 'source': led, 'component': 'default', 'extensionFactor': None, 'inputs': S([[1, 2], [3, 4], [[1, 2, 3, 4], [1, 2, 3]]]), 'seed': None})
+    reqs.append({'op': 'info', 'source': led, 'component': 'nope', 'extensionFactor': None})
+    reqs.append({'op': 'info', 'source': led, 'component': 'default', 'extensionFactor': 2})
+    reqs.append({'op': 'info', 'source': led.replace('(constraints 3)', '(constraints 4)'), 'component': 'default', 'extensionFactor': None})
+    reqs.append({'op': 'info', 'source': led.replace('(exp (load.local $sum) (scalar 2))', '(frobnicate (load.local $sum))'), 'component': 'default', 'extensionFactor': None})
+    reqs.append({'op': 'check', 'source': '(module (const $a scalar 1))'})
+    if os.path.isdir(os.path.join(REF, 'assembly')):
+        lib = open(os.path.join(REF, 'assembly', 'lib128.aa')).read()
+        reqs.append({'op': 'check', 'source': lib})
+        reqs += [{'op': 'info', 'source': lib, 'component': comp, 'extensionFactor': 32}
+                 for comp in ('ComputePoseidonHash', 'ComputeMerkleRoot', 'ComputeMerkleUpdate', 'VerifySchnorrSignature')]
+        for n in (1, 2):
+            reqs.append({'op': 'plan', 'source': lib, 'component': 'ComputePoseidonHash', 'extensionFactor': 32,
+                         'inputs': S([[rnd.randrange(p) for _ in range(n)] for _ in range(4)]), 'seed': None})
+            inputs = [[rnd.randrange(p) for _ in range(n)], [rnd.randrange(p) for _ in range(n)]] + \
+                     [[[rnd.randrange(p) for _ in range(4)] for _ in range(n)] for _ in range(2)] + [[[rnd.randrange(2) for _ in range(4)] for _ in range(n)]]
+            reqs.append({'op': 'plan', 'source': lib, 'component': 'ComputeMerkleRoot', 'extensionFactor': 32, 'inputs': S(inputs), 'seed': None})
+        for path in (('assembly', 'lib224.aa'), ('examples', 'elliptic', 'pointmul.aa')):
+            src = open(os.path.join(REF, *path)).read()
+            reqs.append({'op': 'check', 'source': src})
+            reqs += [{'op': 'info', 'source': src, 'component': name, 'extensionFactor': None} for name in aa_exports(src)]
+    return reqs
+
+
+def aa_exports(src):
+    from genstark_amd import airassembly
+    return list(airassembly.Module(src).exports)
+
+
+@pytest.mark.skipif(not shutil.which('node'), reason='node is not in this image')
+def test_javascript_loader_answers_like_the_python_loader(tmp_path):
+    """js/aa_loader.js — what compile() / instantiate() of the air-assembly drop-in run on the node side — gives the answers of
+    genstark_amd/aa_json.handle object for object: exports, degrees, extension factors, the register-machine programs (code words,
+    constant pools, scratch registers), static registers, first rows, secret columns, input shapes; and refuses what it refuses, with
+    its words."""
+    from genstark_amd import aa_json
+    reqs = loader_requests()
+    (tmp_path / 'reqs.json').write_text(json.dumps(reqs))
+    js = ("const { handle } = require(process.argv[1]); const reqs = JSON.parse(require('fs').readFileSync(process.argv[2], 'utf8'));"
+          "process.stdout.write(JSON.stringify(reqs.map(r => { try { return handle(r); } catch (e) { return { error: e.message }; } })));")
+    r = subprocess.run(['node', '-e', js, os.path.join(ROOT, 'js', 'aa_loader.js'), str(tmp_path / 'reqs.json')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads(r.stdout)
+    assert len(got) == len(reqs)
+    refused = 0
+    for req, g in zip(reqs, got):
+        try:
+            want = json.loads(json.dumps(aa_json.handle(req)))
+        except Exception as e:   # noqa: BLE001
+            want = {'error': f'{type(e).__name__}: {e}'}
+        refused += 'error' in want
+        if 'error' in want and want['error'].startswith('GstarkError'):
+            assert g == want, (req['op'], req.get('component'))
+        elif 'error' in want:
+            assert 'error' in g, (req['op'], want['error'], g)        # (a Python exception other than the loader's own: refused, other words)
+        else:
+            assert g == want, (req['op'], req.get('component'))
+    assert refused >= 8
+
+
+@pytest.mark.skipif(not shutil.which('node'), reason='node is not in this image')
+def test_node_side_can_still_ask_the_python_loader(tmp_path):
+    """GSTARK_AA_LOADER=python: the child-process route the node side used before it had a loader of its own gives the same schema and
+    the same AIR (kept for comparisons of the two)."""
+    js = ("const a = require(process.argv[1]); const src = require('fs').readFileSync(process.argv[2], 'utf8');"
+          "const s = a.compile(src); const air = new a.AssemblyAir(s, 'chain', {});"
+          "console.log(JSON.stringify({ modulus: String(s.modulus), exports: s.exports, degrees: air.constraintDegrees, ef: air.extensionFactor }));")
+    out = []
+    for loader in ('', 'python'):
+        r = subprocess.run(['node', '-e', js, os.path.join(ROOT, 'js', 'air_assembly.js'), os.path.join(AA, 'cube_chain.aa')],
+                           env=dict(os.environ, GSTARK_AA_LOADER=loader, GSTARK_ALLOW_TEST_DOUBLE='1', GSTARK_LIB=ORACLE_LIB), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert out[0] == out[1] and out[0]['degrees'] == [3]
