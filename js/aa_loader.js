@@ -662,8 +662,26 @@ class AssemblyAir {
 // ---- the requests of js/air_assembly.js (genstark_amd/aa_json.py: handle) --------------------------------------------------------------
 const toBig = x => isList(x) ? x.map(toBig) : BigInt(x);
 
+// parsed modules and their components' AirModules are kept (8 most recent sources): a prover asks for a plan per proof, and the
+// programs of a component do not depend on the request
+const modules = new Map();
+function moduleOf(source) {
+    const key = Buffer.isBuffer(source) ? source.toString('utf8') : String(source);
+    let hit = modules.get(key);
+    if (hit) { modules.delete(key); modules.set(key, hit); return hit; }
+    hit = { module: new Module(key), airs: new Map() };
+    modules.set(key, hit);
+    if (modules.size > 8) modules.delete(modules.keys().next().value);
+    return hit;
+}
+function airOf(source, component, extensionFactor) {
+    const hit = moduleOf(source), key = `${component}|${extensionFactor || 0}`;
+    if (!hit.airs.has(key)) hit.airs.set(key, new AssemblyAir(hit.module, component, extensionFactor));
+    return hit.airs.get(key);
+}
+
 function handle(req) {
-    const module = new Module(req.source);
+    const module = moduleOf(req.source).module;
     if (req.op === 'check') {
         const out = {};
         for (const [name, ex] of module.exports) {
@@ -672,7 +690,7 @@ function handle(req) {
         }
         return { modulus: String(module.modulus), exports: out };
     }
-    const air = new AssemblyAir(module, req.component || 'default', req.extensionFactor || null);
+    const air = airOf(req.source, req.component || 'default', req.extensionFactor || null);
     if (req.op === 'info') {
         const out = { traceRegisterCount: air.traceRegisterCount, secretInputCount: air.secretInputCount, constraintDegrees: air.constraintDegrees,
                       maxConstraintDegree: air.maxConstraintDegree, extensionFactor: air.extensionFactor, inputRegisters: air.inputRegisters.length };
