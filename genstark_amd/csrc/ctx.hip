@@ -238,9 +238,9 @@ __global__ void k_gather_words_flag(const uint64_t *__restrict__ addr, uint64_t 
                                     unsigned long long *flag, unsigned long long value) {
     for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x)
         out[t] = *reinterpret_cast<const uint4 *>(addr[t]);
-    __threadfence_system();
-    __syncthreads();
+    __syncthreads();                     // (every wave's stores have left the CU; ONE thread fences for the workgroup — hash.hip: k_merkle_subtree)
     if (threadIdx.x == 0) {
+        __threadfence_system();
         const unsigned int before = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (before + 1 == gridDim.x) {
             __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -323,8 +323,11 @@ static int gs_poll_flag(gs_ctx *c, const volatile uint64_t *flag, uint64_t value
 // the flag behind the data for the polling host)
 __global__ void k_post_words(const uint4 *__restrict__ src, uint32_t words, uint4 *__restrict__ out, unsigned long long *flag, unsigned long long value) {
     if (threadIdx.x < words) out[threadIdx.x] = src[threadIdx.x];
-    __threadfence_system();
-    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 int gs_readback_reserve(gs_ctx *c, uint32_t bytes, void **slot_dev, unsigned long long **flag_dev, unsigned long long *value, uint64_t *ticket) {

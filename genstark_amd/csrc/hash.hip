@@ -252,12 +252,16 @@ __global__ __launch_bounds__(GS_MERKLE_SUBTREE_THREADS) void k_merkle_subtree(Ha
         // One launch per tree of <= 2^15 first-layer digests instead of two.
         __shared__ int last_sh;
         const uint32_t G = gridDim.x;                 // a power of two <= 1024
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) last_sh = atomicAdd(counter, 1u) == G - 1;
+        // (the last level's barrier has passed: every store of this workgroup has reached its XCD's L2.  ONE thread then writes the L2
+        //  back — the release is cumulative over what the barrier ordered before it — counts the workgroup, and in the last workgroup
+        //  invalidates before anybody loads: sixteen waves each issuing the write-back / invalidate cost 8 us per tree top)
+        if (threadIdx.x == 0) {
+            __threadfence();
+            last_sh = atomicAdd(counter, 1u) == G - 1;
+            if (last_sh) __threadfence();
+        }
         __syncthreads();
         if (!last_sh) return;
-        __threadfence();
         for (uint32_t i = threadIdx.x; i < G; i += GS_MERKLE_SUBTREE_THREADS) {      // heap nodes G .. 2G - 1 of the tree: the subtree roots
             sh[2 * (G + i)] = nodes[2 * (G + (uint64_t)i)];
             sh[2 * (G + i) + 1] = nodes[2 * (G + (uint64_t)i) + 1];
@@ -519,12 +523,14 @@ __global__ __launch_bounds__(GS_FRI_THREADS) void k_fri_layers(FriLayersArgs a) 
         __syncthreads();
         subtree_levels<ALG>(sh, CH / 2, L >> 1, blockIdx.x, D.nodes);
         if (G > 1) {
-            __threadfence();                         // release: this workgroup's nodes (its subtree root among them) reach memory
-            __syncthreads();
-            if (tid == 0) last_sh = atomicAdd(a.counter, 1u) == G - 1;
+            // (subtree_levels ended in a barrier: every store of this workgroup — D.next, leaves, nodes — has reached its XCD's L2)
+            if (tid == 0) {
+                __threadfence();                     // release: this workgroup's nodes (its subtree root among them) reach memory
+                last_sh = atomicAdd(a.counter, 1u) == G - 1;
+                if (last_sh) __threadfence();        // acquire: the other workgroups' subtree roots, not a stale line of this XCD's L2
+            }
             __syncthreads();
             if (!last_sh) return;
-            __threadfence();                         // acquire: the other workgroups' subtree roots, not a stale line of this XCD's L2
             for (uint32_t i = tid; i < G; i += GS_FRI_THREADS) {        // heap nodes G .. 2G - 1 of the layer's tree
                 sh[2 * (G + i)] = D.nodes[2 * (G + (uint64_t)i)];
                 sh[2 * (G + i) + 1] = D.nodes[2 * (G + (uint64_t)i) + 1];
