@@ -119,7 +119,7 @@ __global__ void k_hash_values64(const uint4 *__restrict__ buf, uint64_t count, u
 //                      height would live in scratch), so a node is hashed the moment its second child exists and no layer is read
 //                      back from memory.  The code is a LOOP around two compression sites (first layer, node): unrolled, fifteen
 //                      inlined compressions would be 120 KB of straight-line code per wave against a 64 KB instruction cache.
-//   k_merkle_subtree — layers of at most 2^15 digests.  One workgroup owns `chunk` (<= 1024) consecutive digests of a layer and the
+//   k_merkle_subtree — layers of at most 2^15 digests.  One workgroup owns `chunk` (<= 1024; merkle_run gives it 256) consecutive digests of a layer and the
 //                      whole subtree above them, level by level through LDS (heap layout: levels occupy disjoint slots, one barrier
 //                      per level); with chunk = layer width it finishes the tree (root at nodes[1], nodes[0] = 0).
 // The first layer of either kernel is (SRC 0) a node layer, H(child[2i] || child[2i+1]) of the digests below, or the tree's LEAVES
@@ -196,7 +196,7 @@ __device__ __forceinline__ void subtree_levels(uint4 *sh, uint32_t first_m, uint
     for (uint32_t m = first_m; m >= 1; m >>= 1, wl >>= 1) {
         bool done = false;
         if constexpr (ALG == 1) {
-            if (m <= GS_MERKLE_SUBTREE_THREADS / 4) {
+            if (m <= blockDim.x / 4) {
                 if (threadIdx.x < 4 * m) {
                     const uint32_t i = threadIdx.x >> 2, l = threadIdx.x & 3u, s = m + i;
                     uint32_t *w = reinterpret_cast<uint32_t *>(sh);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(GS_MERKLE_SUBTREE_THREADS) void k_merkle_subtree(Ha
                                                         uint4 *__restrict__ nodes, uint64_t wA, uint32_t chunk, RootTail tail, unsigned int *counter) {
     __shared__ uint4 sh[4 * GS_MERKLE_CHUNK];   // digest of subtree-heap node s at sh[2s], sh[2s + 1]; the first layer is s in [chunk, 2 chunk)
     const uint64_t base = (uint64_t)blockIdx.x * chunk;
-    for (uint32_t i = threadIdx.x; i < chunk; i += GS_MERKLE_SUBTREE_THREADS) {
+    for (uint32_t i = threadIdx.x; i < chunk; i += blockDim.x) {
         if constexpr (SRC == 0) {
             sh[2 * (chunk + i)] = layerA[2 * (base + i)];
             sh[2 * (chunk + i) + 1] = layerA[2 * (base + i) + 1];
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(GS_MERKLE_SUBTREE_THREADS) void k_merkle_subtree(Ha
         }
         __syncthreads();
         if (!last_sh) return;
-        for (uint32_t i = threadIdx.x; i < G; i += GS_MERKLE_SUBTREE_THREADS) {      // heap nodes G .. 2G - 1 of the tree: the subtree roots
+        for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) {                     // heap nodes G .. 2G - 1 of the tree: the subtree roots
             sh[2 * (G + i)] = nodes[2 * (G + (uint64_t)i)];
             sh[2 * (G + i) + 1] = nodes[2 * (G + (uint64_t)i) + 1];
         }
@@ -313,13 +313,19 @@ static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count,
     const RootTail none = {nullptr, nullptr, 0, nullptr};
     // the launch that ends at the root: a subtree launch of one workgroup, or of several that finish the tree themselves (arrival counter)
     auto tail_for = [&](uint64_t width, uint32_t chunk) { return root_tail && (width == chunk || width / chunk <= GS_MERKLE_CHUNK) ? *root_tail : none; };
+    // digests per workgroup of a subtree launch: 256, not the 1 024 the kernel can take — every level of a subtree then runs at four lanes
+    // per node on at most two waves per SIMD (one compression deep: ~0.7-1.3 us), where a 1 024-digest subtree pays 3.8 + 2.5 us for its
+    // two widest levels on one CU; the levels moved to the tree over the subtree roots cost the same there.  Trees back to back
+    // (tools/merkle_top.py, us at 1 024 / 512 / 256 / 128 per workgroup): 2^10 digests 17.0 / 16.0 / 14.4 / 14.1, 2^13 22.2 / 19.6 /
+    // 17.8 / 17.5, 2^15 24.3 / 21.8 / 21.3 / 24.0, 2^18 41.8 / 39.3 / 38.3 / 41.3
+    const uint32_t CHUNK_X = 256;
     unsigned int *counters = nullptr;
-    if (n > GS_MERKLE_CHUNK) {
+    if (n > CHUNK_X) {
         int rc = arrival_counters(c, &counters);
         if (rc) return rc;
         counters += 1;                           // (word 0 is gs_fri_layers')
     }
-    const dim3 blk(256), sub_blk(GS_MERKLE_SUBTREE_THREADS);
+    const dim3 blk(256), sub_blk(GS_MERKLE_SUBTREE_THREADS);      // (512 threads per subtree workgroup measure the same as 1 024)
     uint64_t w = n;                              // the widest complete layer and where its digests are
     const uint4 *cur = (const uint4 *)leaves_in;
     if (src != 0) {
@@ -341,11 +347,11 @@ static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count,
             w = n >> (lv - 1);
             cur = lv == 1 ? lo : nd + 2 * w;
         } else {
-            const uint32_t chunk = (uint32_t)(n < GS_MERKLE_CHUNK ? n : GS_MERKLE_CHUNK);
+            const uint32_t chunk = (uint32_t)(n <= CHUNK_X ? n : CHUNK_X);
             gs_traffic(c, n * ((uint64_t)count * GS_ELT + 32) + n * 32, n * hash_blocks(ALG, (uint64_t)count * GS_ELT) + n - 1, "k_merkle_subtree<%d, %d>", ALG, src);
             if (src == 1) hipLaunchKernelGGL((k_merkle_subtree<ALG, 1>), dim3((unsigned)(n / chunk)), sub_blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk, tail_for(n, chunk), counters);
             else hipLaunchKernelGGL((k_merkle_subtree<ALG, 2>), dim3((unsigned)(n / chunk)), sub_blk, 0, c->stream, va, count, nullptr, lo, nd, n, chunk, tail_for(n, chunk), counters);
-            GS_LAUNCH_CHECK(c);                  // (n <= 2^15: at most 32 subtrees, whose roots the last workgroup finishes)
+            GS_LAUNCH_CHECK(c);                  // (n <= 2^15: at most 128 subtrees, whose roots the last workgroup finishes)
             return GS_OK;
         }
     }
@@ -373,7 +379,7 @@ static int merkle_run(gs_ctx *c, int src, const HashPtrArgs &va, uint32_t count,
         cur = nd + 2 * w;
     }
     while (w > 1) {                               // subtrees of <= 1024 digests, then the subtree over their roots
-        const uint32_t chunk = (uint32_t)(w < GS_MERKLE_CHUNK ? w : GS_MERKLE_CHUNK);
+        const uint32_t chunk = (uint32_t)(w <= CHUNK_X ? w : (w / CHUNK_X <= GS_MERKLE_CHUNK ? CHUNK_X : GS_MERKLE_CHUNK));
         gs_traffic(c, w * 32 + (w - 1) * 32, w - 1, "k_merkle_subtree<%d, 0>", ALG);
         hipLaunchKernelGGL((k_merkle_subtree<ALG, 0>), dim3((unsigned)(w / chunk)), sub_blk, 0, c->stream, va, 0u, cur, nullptr, nd, w, chunk, tail_for(w, chunk), counters);
         w /= chunk;
