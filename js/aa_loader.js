@@ -448,7 +448,11 @@ class Col {             // a static column in closed form: col[t] = flat[((t + k
 }
 function flatten(values, depth) {
     let flat = values;
-    for (let d = 0; d < depth; d++) flat = [].concat(...flat);
+    for (let d = 0; d < depth; d++) {           // (no spread: a register of 10^5 lists would not fit an argument list)
+        const next = [];
+        for (const group of flat) for (const v of group) next.push(v);
+        flat = next;
+    }
     return flat;
 }
 

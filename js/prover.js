@@ -83,8 +83,8 @@ function verifyAssemblySerialized(assemblyAir, options, assertions, proof, publi
     let adicity = 0;
     for (let x = f.modulus - 1n; x % 2n === 0n; x /= 2n) adicity++;
     const log2 = Math.min(adicity, 32);
-    const flat = x => Array.isArray(x) ? [].concat(...x.map(flat)) : [x];
-    const lists = (publicInputs || []).map(flat);
+    const flatInto = (x, out) => { if (Array.isArray(x)) for (const v of x) flatInto(v, out); else out.push(x); return out; };   // (no spread: 10^5 lists would not fit an argument list)
+    const lists = (publicInputs || []).map(x => flatInto(x, []));
     const cycles = info.cycles.map(c => c.map(BigInt));
     const job = {
         steps: 0, extensionFactor: assemblyAir.extensionFactor, exeQueryCount: options.exeQueryCount, friQueryCount: options.friQueryCount,
