@@ -139,13 +139,13 @@ def test_hashing(hip_backend, rng, alg, n):
 
 
 @pytest.mark.parametrize('alg,logn', [('sha256', 1), ('blake2s256', 1), ('blake2s256', 2), ('blake2s256', 4), ('sha256', 7),
-                                      ('blake2s256', 9), ('blake2s256', 10), ('sha256', 11), ('blake2s256', 13)])
+                                      ('blake2s256', 8), ('blake2s256', 9), ('blake2s256', 10), ('sha256', 11), ('blake2s256', 13), ('sha256', 15)])
 def test_merkle(hip_backend, rng, alg, logn):
     cases.check_merkle(hip_backend, rng, alg, logn)
 
 
-# every branch of the construction plan (csrc/hash.hip: merkle_run): one subtree workgroup (n <= 1024), subtrees + the tree over their
-# roots (n <= 2^15), streaming layers with 1..4 fused layers above the leaves, a second streaming launch (n >= 2^20)
+# every branch of the construction plan (csrc/hash.hip: merkle_run): one subtree workgroup (n <= 256), subtrees of 256 digests + the tree
+# over their roots built by the last workgroup to arrive (n <= 2^15), streaming layers with 1..4 fused layers above the leaves, a second streaming launch (n >= 2^20)
 @pytest.mark.parametrize('alg,logn,count', [('blake2s256', 1, 1), ('sha256', 1, 4), ('blake2s256', 3, 2), ('blake2s256', 10, 4), ('sha256', 10, 1),
                                             ('blake2s256', 11, 1), ('blake2s256', 13, 6), ('sha256', 12, 3)])
 def test_merkle_commit_rows(hip_backend, rng, alg, logn, count):
