@@ -7,7 +7,8 @@
 // The language subset, the meaning of the static-register declarations and the degree rules are those airassembly.py documents
 // (the compiler itself lives in the absent package: SURVEY 8c).  Integers are BigInt inside and decimal strings in the answers.
 //
-//     handle({op: 'check' | 'info' | 'describe' | 'plan' | 'verify', source, component, extensionFactor, ...}) -> answer object
+//     handle({op: 'check' | 'info' | 'describe' | 'plan' | 'verify', source, component, extensionFactor, ...}[, raw]) -> answer object
+//     (raw: field elements of the answer stay BigInt — for a caller in this process; inputs may be BigInt, numbers or decimal strings)
 //     errors: Error('GstarkError: ...') with the Python loader's wording
 const crypto = require('crypto');
 
@@ -232,7 +233,7 @@ class Program {
         }
         return out;
     }
-    toJSON() { return { code: this.code, consts: this.consts.map(String), nregs: this.nregs, nout: this.nout }; }
+    toJSON(raw) { return { code: this.code, consts: raw ? this.consts.slice() : this.consts.map(String), nregs: this.nregs, nout: this.nout }; }
 }
 
 // ---- evaluation over an algebra ------------------------------------------------------------------------------------------------------
@@ -483,11 +484,13 @@ class InnerAir {
         if (this.transitionProgram.nout !== registers || this.evaluationProgram.nout !== constraintDegrees.length) fail('transition must yield one value per register, evaluation one per constraint');
         rootOfUnityExists(modulus, steps * ef);
     }
-    descriptor(firstRows) {
+    /** raw: field elements stay BigInt (a caller in this process: js/air_assembly.js); otherwise decimal strings, as JSON carries them */
+    descriptor(firstRows, raw) {
+        const str = raw ? (v => v) : String;
         const d = { modulus: String(this.modulus), steps: this.steps, registers: this.registers, constraintDegrees: this.constraintDegrees.slice(),
                     extensionFactor: this.extensionFactor, secretInputCount: this.secretInputCount,
-                    staticRegisters: this.staticRegisters.map(values => values.map(String)),
-                    transition: this.transitionProgram.toJSON(), evaluation: this.evaluationProgram.toJSON(), init: null };
+                    staticRegisters: this.staticRegisters.map(values => values.map(str)),
+                    transition: this.transitionProgram.toJSON(raw), evaluation: this.evaluationProgram.toJSON(raw), init: null };
         if (this.segmentLength !== null) d.segmentLength = this.segmentLength;
         if (firstRows !== undefined) {
             let rows;
@@ -497,7 +500,7 @@ class InnerAir {
                 if (!firstRows || firstRows.length !== segments) fail(`a segmented AIR needs one seed per segment (${segments})`);
                 rows = firstRows;
             }
-            d.firstRows = rows.map(row => row.map(v => String(mod(v, this.modulus))));
+            d.firstRows = rows.map(row => row.map(v => str(mod(v, this.modulus))));
         } else d.seedWidth = this.registers;             // init(seed) of a loaded component is the seed itself
         return d;
     }
@@ -537,7 +540,7 @@ class AssemblyAir {
         const cf = 1 << bitLength(this.maxConstraintDegree - 1);
         this.extensionFactor = extensionFactor || (1 << bitLength(2 * this.maxConstraintDegree));
         if (this.extensionFactor < 2 * cf) fail('Extension factor must be a power of 2 at least 2x the constraint degree and at most 32');
-        this.cache = new Map();
+        this.cache = [];
         this.evaluation_ = null;
     }
     run(algebra, r, n, k, body) {
@@ -582,15 +585,17 @@ class AssemblyAir {
         return spec.map(v => mod(big(v), p));
     }
     inner(length, publicCols, segment) {
-        const key = JSON.stringify([length, publicCols.map(c => c.map(String)), segment]);
-        let air = this.cache.get(key);
+        // (the AIRs of the last few shapes, found by comparing the public columns themselves: a key in text would cost more than the plan)
+        const same = e => e.length === length && e.segment === segment && e.cols.length === publicCols.length && e.cols.every((c, i) => sameList(c, publicCols[i]));
+        const hit = this.cache.find(same);
+        let air = hit && hit.air;
         if (!air) {
             const p = this.module.modulus;
             const transition = (r, k) => this.run(new Exprs(p), r, null, this.libOrder(k), this.export.transition);
             const evaluation = (r, n, k) => this.run(new Exprs(p), r, n, this.libOrder(k), this.export.evaluation);
             air = new InnerAir(length, this.traceRegisterCount, this.constraintDegrees, publicCols, transition, evaluation, this.extensionFactor, p, this.secretInputCount, segment);
-            if (this.cache.size > 8) this.cache.clear();
-            this.cache.set(key, air);
+            if (this.cache.length > 8) this.cache.length = 0;
+            this.cache.push({ length, segment, cols: publicCols, air });
         }
         return air;
     }
@@ -684,8 +689,9 @@ function airOf(source, component, extensionFactor) {
     return hit.airs.get(key);
 }
 
-function handle(req) {
+function handle(req, raw) {
     const module = moduleOf(req.source).module;
+    const str = raw ? (v => v) : String;
     if (req.op === 'check') {
         const out = {};
         for (const [name, ex] of module.exports) {
@@ -701,20 +707,20 @@ function handle(req) {
         if (air.inputRegisters.length) {
             const [sources, cycles] = air.staticSources();
             Object.assign(out, { inputDeclarations: air.inputRegisters.map(d => ({ parent: d.parent, peer: d.peer, steps: d.steps || 0, shift: d.shift, secret: !!d.secret })),
-                                 staticSources: sources, cycles: cycles.map(c => c.map(String)), evaluation: air.evaluationProgram.toJSON() });
+                                 staticSources: sources, cycles: cycles.map(c => c.map(str)), evaluation: air.evaluationProgram.toJSON(raw) });
         }
         return out;
     }
     if (req.op === 'describe') {
         if (air.inputRegisters.length) throw new Error('ValueError: the component has input registers: its trace is sized when the inputs arrive');
         const layout = new Layout(air.export.statics, []);
-        return { descriptor: air.inner(air.lengthWithoutInputs(), air.publicSplit(air.columns(layout, [])), null).descriptor() };
+        return { descriptor: air.inner(air.lengthWithoutInputs(), air.publicSplit(air.columns(layout, [])), null).descriptor(undefined, raw) };
     }
     if (req.op === 'plan') {
         const seed = req.seed === null || req.seed === undefined ? null : toBig(req.seed);
         const plan = air.plan(toBig(req.inputs || []), seed);
-        const d = plan.air.descriptor(plan.firsts);
-        d.secretRegisters = plan.packed.map(col => col.map(String));            // this proof's secret columns (one period each)
+        const d = plan.air.descriptor(plan.firsts, raw);
+        d.secretRegisters = plan.packed.map(col => col.map(str));            // this proof's secret columns (one period each)
         return { descriptor: d, inputShapes: plan.shapes };
     }
     if (req.op === 'verify') {
@@ -730,7 +736,7 @@ function handle(req) {
                 values.push(given[j++]);
             }
         }
-        return { descriptor: air.inner(length, air.publicSplit(air.columns(layout, values)), null).descriptor() };
+        return { descriptor: air.inner(length, air.publicSplit(air.columns(layout, values)), null).descriptor(undefined, raw) };
     }
     throw new Error(`ValueError: unknown op '${req.op}'`);
 }

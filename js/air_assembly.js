@@ -20,6 +20,10 @@ const REPO = path.resolve(__dirname, '..');
 // kept (64 most recent, requests under 256 KB) instead of compiling the component's programs again per call.
 const answers = new Map();
 function ask(request) {
+    if (process.env.GSTARK_AA_LOADER !== 'python' && (request.op === 'plan' || request.op === 'verify')) {
+        // this proof's inputs: nothing to keep, nothing to turn into text — the loader takes the BigInts and answers in BigInts
+        try { return loader.handle(request, true); } catch (e) { throw new Error(`AirAssembly: ${e.message}`); }
+    }
     const key = JSON.stringify(request);
     if (key.length < (1 << 18) && answers.has(key)) {
         const hit = answers.get(key);
@@ -85,14 +89,16 @@ class AssemblyAir {
     _build(desc) { return new GenericAir(desc, this.extensionFactor, this.field); }
     initProvingContext(inputs, seed) {
         if (this._inner) return this._inner.initProvingContext(inputs, seed);
-        const plan = ask(this._req('plan', { inputs: toStrings(inputs || []), seed: seed === undefined || seed === null ? null : toStrings(seed) }));
+        const text = process.env.GSTARK_AA_LOADER === 'python' ? toStrings : (x => x);          // (JSON to the child process; the loader in this process takes BigInt)
+        const plan = ask(this._req('plan', { inputs: text(inputs || []), seed: seed === undefined || seed === null ? null : text(seed) }));
         const ctx = this._build(plan.descriptor).initProvingContext([], undefined);
         ctx.inputShapes = plan.inputShapes;
         return ctx;
     }
     initVerificationContext(inputShapes, publicInputs) {
         if (this._inner) return this._inner.initVerificationContext(inputShapes, publicInputs);
-        const d = ask(this._req('verify', { inputShapes: inputShapes || [], publicInputs: toStrings(publicInputs || []) })).descriptor;
+        const text = process.env.GSTARK_AA_LOADER === 'python' ? toStrings : (x => x);
+        const d = ask(this._req('verify', { inputShapes: inputShapes || [], publicInputs: text(publicInputs || []) })).descriptor;
         const ctx = this._build(d).initVerificationContext(inputShapes, publicInputs);
         ctx.inputShapes = inputShapes || [];
         return ctx;
