@@ -7,7 +7,7 @@
 // the transition / constraint / init programs in the {op, dst, a, b} encoding of include/gstark.h.  The device interprets the
 // programs (gs_air_trace, gs_air_trace_segments, gs_air_constraints through the N-API shim); the verifier side interprets the
 // constraint program on BigInt.
-const { Matrix, Vector, native, le } = require('./galois');
+const { Matrix, Vector, native, le, packLe } = require('./galois');
 
 const OP = { LOADC: 0, LOADR: 1, LOADN: 2, LOADS: 3, ADD: 4, SUB: 5, MUL: 6, POW: 7, POWC: 8, OUT: 9 };
 
@@ -23,7 +23,7 @@ class Program {
             if (!(op >= 0 && op <= OP.OUT)) throw new TypeError(`program: unknown opcode ${op}`);
         }
     }
-    constsBuffer() { return this.consts.length ? Buffer.concat(this.consts.map(le)) : le(0n); }
+    constsBuffer() { return this.consts.length ? packLe(this.consts) : le(0n); }
     run(field, cur, next, statics) {   // host interpreter, as Program.run of genstark_amd/air_generic.py
         const vm = new Array(this.nregs).fill(0n), out = new Array(this.nout).fill(0n), c = this.code;
         for (let i = 0; i < c.length; i += 4) {
@@ -112,13 +112,13 @@ class ProvingContext extends Context {
     allStaticColumns() { return this.air.staticRegisters.concat(this.secretColumns); }
     staticValuesPacked() {
         const regs = this.allStaticColumns();
-        return regs.length ? Buffer.concat(regs.map(v => Buffer.concat(v.map(le)))) : le(0n);
+        return regs.length ? Buffer.concat(regs.map(v => packLe(v))) : le(0n);
     }
     generateExecutionTrace() {   // lib/Stark.ts:97
         const air = this.air, f = this.field, t = air.transitionProgram;
         const m = new Matrix(f, air.traceRegisterCount, this.traceLength);
         const periods = this.allStaticColumns().map(v => v.length);
-        const first = Buffer.concat(this.firstRows.map(row => Buffer.concat(row.map(le))));
+        const first = Buffer.concat(this.firstRows.map(row => packLe(row)));
         if (air.segmentLength === null) {
             native().call('gs_air_trace', f.ctx, t.code, t.ninstr, t.constsBuffer(), t.consts.length, t.nregs, air.traceRegisterCount,
                 this.staticValuesPacked(), periods, periods.length, first, this.traceLength, m.ptr);

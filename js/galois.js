@@ -44,15 +44,29 @@ function native(modulus) {
     return addon;
 }
 
-function le(v) {  // bigint -> elementSize-byte little-endian Buffer (lib/utils/serialization.ts:140-146 layout)
-    const b = Buffer.alloc(ELEMENT_SIZE);
+// bigint <-> little-endian bytes (lib/utils/serialization.ts:140-146 layout), a 64-bit word at a time: a column of an input register is
+// 10^4..10^5 of these per proof, and a byte at a time they cost more than the proof (element sizes are 16 or 32 bytes)
+const M64 = (1n << 64n) - 1n;
+function putLe(b, off, v) {
     let x = BigInt(v);
-    for (let i = 0; i < ELEMENT_SIZE; i++) { b[i] = Number(x & 0xFFn); x >>= 8n; }
+    for (let i = 0; i < ELEMENT_SIZE; i += 8) { b.writeBigUInt64LE(x & M64, off + i); x >>= 64n; }
+}
+function le(v) {  // bigint -> elementSize-byte little-endian Buffer
+    const b = Buffer.allocUnsafe(ELEMENT_SIZE);
+    putLe(b, 0, v);
+    return b;
+}
+/** values (BigInt, already reduced; or anything BigInt() takes when `mod` is given) -> ONE Buffer of their little-endian elements */
+function packLe(values, mod) {
+    const b = Buffer.allocUnsafe(values.length * ELEMENT_SIZE);
+    if (mod) for (let i = 0; i < values.length; i++) putLe(b, i * ELEMENT_SIZE, mod(BigInt(values[i])));
+    else for (let i = 0; i < values.length; i++) putLe(b, i * ELEMENT_SIZE, values[i]);
     return b;
 }
 function fromLe(buf, off = 0, size) {
     if (size === undefined) size = ELEMENT_SIZE;
     let v = 0n;
+    if (size % 8 === 0) { for (let i = size - 8; i >= 0; i -= 8) v = (v << 64n) | buf.readBigUInt64LE(off + i); return v; }
     for (let i = size - 1; i >= 0; i--) v = (v << 8n) | BigInt(buf[off + i]);
     return v;
 }
@@ -182,14 +196,18 @@ class PrimeField {
     newVector(length) { return new Vector(this, length); }
     newVectorFrom(values) {
         const v = new Vector(this, values.length);
-        if (values.length) native().call('gs_upload', this.ctx, v.ptr, Buffer.concat(values.map(x => le(this.mod(BigInt(x))))), values.length * ELEMENT_SIZE);
+        if (values.length) native().call('gs_upload', this.ctx, v.ptr, packLe(values, x => this.mod(x)), values.length * ELEMENT_SIZE);
         return v;
     }
     newMatrix(rows, cols) { return new Matrix(this, rows, cols); }
     newMatrixFrom(values) {
         const rows = values.length, cols = rows ? values[0].length : 0;
         const m = new Matrix(this, rows, cols);
-        if (rows * cols) native().call('gs_upload', this.ctx, m.ptr, Buffer.concat([].concat(...values).map(x => le(this.mod(BigInt(x))))), rows * cols * ELEMENT_SIZE);
+        if (rows * cols) {
+            const flat = new Array(rows * cols);
+            for (let r = 0; r < rows; r++) for (let c = 0; c < cols; c++) flat[r * cols + c] = values[r][c];
+            native().call('gs_upload', this.ctx, m.ptr, packLe(flat, x => this.mod(x)), rows * cols * ELEMENT_SIZE);
+        }
         return m;
     }
     newMatrixFromVectors(vectors) {
@@ -235,7 +253,7 @@ class PrimeField {
     combineManyVectors(vectors, coefficients) {
         const ks = Array.isArray(coefficients) ? coefficients : coefficients.toValues();
         const out = new Vector(this, vectors[0].length);
-        native().call('gs_combine_many', this.ctx, vectors.map(v => v.ptr), Buffer.concat(ks.map(le)), vectors.length, vectors[0].length, out.ptr);
+        native().call('gs_combine_many', this.ctx, vectors.map(v => v.ptr), packLe(ks), vectors.length, vectors[0].length, out.ptr);
         return out;
     }
     getPowerSeries(base, length) {
@@ -320,4 +338,4 @@ class PrimeField {
 
 function createPrimeField(modulus, options) { return new PrimeField(modulus, options); }
 
-module.exports = { createPrimeField, PrimeField, Vector, Matrix, MODULUS, LIBRARIES, native, le, fromLe, sha256 };
+module.exports = { createPrimeField, PrimeField, Vector, Matrix, MODULUS, LIBRARIES, native, le, packLe, fromLe, sha256 };

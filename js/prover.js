@@ -3,7 +3,7 @@
 // native driver (include/gstark_prover.h, genstark_amd/csrc/prover.cc), reached through the same N-API addon that carries the
 // member-by-member galois / merkle surface.  The returned Buffer is what lib/Serializer.ts:83-144 (`stark.parse`) reads.
 const path = require('path');
-const { native, le } = require('./galois');
+const { native, le, packLe } = require('./galois');
 
 const HASH_ALG = { sha256: 0, blake2s256: 1 };
 // one build of the driver per field flavour, like the ABI library (genstark_amd/csrc/build.sh)
@@ -33,6 +33,7 @@ function proveMimcSerialized(air, options, assertions, seed) {
 
 // ... and for an AIR given as register-machine programs (js/air_generic.js: the reference's Rescue / Poseidon examples): kind 1 of
 // gs_prover_air.  The two programs keep separate constant pools; the driver takes one, so the evaluator's constant indexes are rebased.
+const flatRows = rows => { const out = []; for (const row of rows) for (const v of row) out.push(v); return out; };
 function genericJob(air, context, options, assertions) {
     if (!(options.hashAlgorithm in HASH_ALG)) throw new TypeError(`Hash algorithm ${options.hashAlgorithm} is not supported`);
     const f = air.field;
@@ -49,10 +50,10 @@ function genericJob(air, context, options, assertions) {
         hashAlg: HASH_ALG[options.hashAlgorithm], rootOfUnity: le(air.rootOfUnity),
         assertions: assertions.map(a => ({ step: a.step, register: a.register, value: le(f.mod(a.value)) })),
         registers: air.traceRegisterCount, degrees: air.constraintDegrees, tCode: t.code, iCode: init ? init.code : [], eCode,
-        consts: pool.length ? Buffer.concat(pool.map(le)) : Buffer.alloc(0), vmRegs: Math.max(t.nregs, e.nregs, init ? init.nregs : 0),
+        consts: pool.length ? packLe(pool) : Buffer.alloc(0), vmRegs: Math.max(t.nregs, e.nregs, init ? init.nregs : 0),
         // static registers: the public ones, then this proof's secret columns (struct gs_prover_air: static_values / static_tables hold both)
         staticValues: context.staticValuesPacked(), staticPeriods: context.allStaticColumns().map(v => v.length), staticTables: context.staticTables.ptr,
-        staticLens: context.staticLens, firstRows: Buffer.concat(context.firstRows.map(row => Buffer.concat(row.map(le)))),
+        staticLens: context.staticLens, firstRows: packLe(flatRows(context.firstRows)),
         segments: air.segmentLength === null ? 0 : context.firstRows.length, segmentLen: air.segmentLength === null ? 0 : air.segmentLength,
     };
     if (context.secretRegisterTraces.length) job.secretTraces = context.secretRegisterTraces.map(v => v.ptr);
@@ -95,7 +96,7 @@ function verifyAssemblySerialized(assemblyAir, options, assertions, proof, publi
         staticValues: cycles.length ? Buffer.concat([].concat(...cycles).map(v => le(f.mod(v)))) : le(0n), staticPeriods: cycles.map(c => c.length),
         staticTables: 0n, staticLens: cycles.map(() => 0), firstRows: Buffer.alloc(assemblyAir.traceRegisterCount * f.elementSize), segments: 0, segmentLen: 0,
         nsecret: assemblyAir.secretInputCount, inputRegisters: [].concat(...info.inputDeclarations.map(declWords)),
-        staticSources: [].concat(...info.staticSources), publicInputs: lists.length ? Buffer.concat([].concat(...lists).map(v => le(f.mod(BigInt(v))))) : Buffer.alloc(0),
+        staticSources: [].concat(...info.staticSources), publicInputs: lists.length ? Buffer.concat(lists.map(l => packLe(l, v => f.mod(v)))) : Buffer.alloc(0),
         publicInputCounts: lists.map(l => l.length),
     };
     return native().proveGenericSerialized(f.ctx, driverPath(f), job, Buffer.from(proof));
@@ -122,7 +123,7 @@ function verifyGenericSerialized(air, options, assertions, proof) {
         assertions: assertions.map(a => ({ step: a.step, register: a.register, value: le(f.mod(a.value)) })),
         registers: air.traceRegisterCount, degrees: air.constraintDegrees, tCode: [], iCode: [], eCode: e.code,
         consts: e.consts.length ? Buffer.concat(e.consts.map(le)) : Buffer.alloc(0), vmRegs: e.nregs,
-        staticValues: statics.length ? Buffer.concat(statics.map(v => le(f.mod(v)))) : le(0n), staticPeriods: air.staticRegisters.map(v => v.length),
+        staticValues: statics.length ? packLe(statics, v => f.mod(v)) : le(0n), staticPeriods: air.staticRegisters.map(v => v.length),
         staticTables: 0n, staticLens: air.staticRegisters.map(() => 0), firstRows: Buffer.alloc(air.traceRegisterCount * f.elementSize),
         segments: 0, segmentLen: 0,
     };
