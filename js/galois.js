@@ -58,10 +58,22 @@ function le(v) {  // bigint -> elementSize-byte little-endian Buffer
 }
 /** values (BigInt, already reduced; or anything BigInt() takes when `mod` is given) -> ONE Buffer of their little-endian elements */
 function packLe(values, mod) {
+    if (mod) { const reduced = new Array(values.length); for (let i = 0; i < values.length; i++) reduced[i] = mod(BigInt(values[i])); values = reduced; }
+    // the addon copies the BigInts' words (napi_get_value_bigint_words: ~30 ns per element); without it — or for the handful of values
+    // most calls carry — the loop below
+    if (values.length >= 64 && addon && addon.packElements) return addon.packElements(values, ELEMENT_SIZE);
     const b = Buffer.allocUnsafe(values.length * ELEMENT_SIZE);
-    if (mod) for (let i = 0; i < values.length; i++) putLe(b, i * ELEMENT_SIZE, mod(BigInt(values[i])));
-    else for (let i = 0; i < values.length; i++) putLe(b, i * ELEMENT_SIZE, values[i]);
+    for (let i = 0; i < values.length; i++) putLe(b, i * ELEMENT_SIZE, values[i]);
     return b;
+}
+/** a Buffer of little-endian elements -> BigInt[] */
+function unpackLe(raw, size) {
+    if (size === undefined) size = ELEMENT_SIZE;
+    const n = raw.length / size;
+    if (n >= 64 && (size === 16 || size === 32) && addon && addon.unpackElements) return addon.unpackElements(raw, size);
+    const out = new Array(n);
+    for (let i = 0; i < n; i++) out[i] = fromLe(raw, i * size, size);
+    return out;
 }
 function fromLe(buf, off = 0, size) {
     if (size === undefined) size = ELEMENT_SIZE;
@@ -104,11 +116,7 @@ class Vector {
         return out;
     }
     getValue(index) { return fromLe(this.toBuffer(index, 1), 0, this.elementSize); }
-    toValues() {
-        const raw = this.toBuffer(); const out = new Array(this.length);
-        for (let i = 0; i < this.length; i++) out[i] = fromLe(raw, i * this.elementSize, this.elementSize);
-        return out;
-    }
+    toValues() { return unpackLe(this.toBuffer(), this.elementSize); }
     copyValue(index, destination, offset) {  // lib/Stark.ts:290
         this.toBuffer(index, 1).copy(destination, offset);
         return this.elementSize;
@@ -139,12 +147,8 @@ class Matrix {
         return fromLe(out);
     }
     toValues() {
-        const raw = this.toBuffer(); const out = [];
-        for (let r = 0; r < this.rowCount; r++) {
-            const row = new Array(this.colCount);
-            for (let c = 0; c < this.colCount; c++) row[c] = fromLe(raw, (r * this.colCount + c) * ELEMENT_SIZE);
-            out.push(row);
-        }
+        const flat = unpackLe(this.toBuffer(), ELEMENT_SIZE), out = [];
+        for (let r = 0; r < this.rowCount; r++) out.push(flat.slice(r * this.colCount, (r + 1) * this.colCount));
         return out;
     }
     rowsToBuffers(indexes) {  // lib/components/LowDegreeProver.ts:53,214,217
@@ -338,4 +342,4 @@ class PrimeField {
 
 function createPrimeField(modulus, options) { return new PrimeField(modulus, options); }
 
-module.exports = { createPrimeField, PrimeField, Vector, Matrix, MODULUS, LIBRARIES, native, le, packLe, fromLe, sha256 };
+module.exports = { createPrimeField, PrimeField, Vector, Matrix, MODULUS, LIBRARIES, native, le, packLe, unpackLe, fromLe, sha256 };

@@ -99,4 +99,29 @@ refuses(() => a.proveGenericSerialized(ctx, DRIVER, Object.assign({}, generic, {
 refuses(() => a.proveGenericSerialized(ctx, DRIVER, Object.assign({}, generic, { eCode: [0, 0, 99, 0] }), Buffer.alloc(3000, 0)), /./);
 
 a.ctxDestroy(ctx);
+// element packing (packElements / unpackElements: BigInt words copied natively)
+refuses(() => a.packElements(), /packElements\(values/);
+refuses(() => a.packElements('x', 16), /packElements\(values/);
+refuses(() => a.packElements([1n], 8), /packElements\(values/);
+refuses(() => a.packElements([1n, 2], 16), /must be a BigInt/);
+refuses(() => a.packElements([1n, 'x'], 16), /must be a BigInt/);
+refuses(() => a.packElements([-1n], 16), /negative or wider/);
+refuses(() => a.packElements([1n << 128n], 16), /negative or wider/);
+refuses(() => a.packElements([1n << 256n], 32), /negative or wider/);
+refuses(() => a.unpackElements(), /unpackElements\(buffer/);
+refuses(() => a.unpackElements([1, 2], 16), /unpackElements\(buffer/);
+refuses(() => a.unpackElements(Buffer.alloc(16), 7), /unpackElements\(buffer/);
+refuses(() => a.unpackElements(Buffer.alloc(17), 16), /whole number of elements/);
+{
+    const values = [0n, 1n, (1n << 64n) - 1n, 1n << 64n, (1n << 128n) - 1n, 0x0123456789abcdef0fedcba987654321n];
+    const packed = a.packElements(values, 16);
+    assert.strictEqual(packed.length, 16 * values.length);
+    assert.strictEqual(packed.slice(80, 96).toString('hex'), '21436587a9cbed0fefcdab8967452301');       // little-endian bytes
+    assert.deepStrictEqual(a.unpackElements(packed, 16), values);
+    const wide = [(1n << 256n) - 1n, 1n << 200n, 5n];
+    assert.deepStrictEqual(a.unpackElements(a.packElements(wide, 32), 32), wide);
+    assert.strictEqual(a.packElements([], 16).length, 0);
+    assert.deepStrictEqual(a.unpackElements(Buffer.alloc(0), 32), []);
+}
+
 console.log(`addon validation OK: ${n} malformed calls refused`);

@@ -63,13 +63,13 @@ def test_driver_refuses_bad_jobs_cleanly(sanitized):
 
 @pytest.mark.skipif(not (shutil.which('node') and os.path.exists('/usr/include/node/node_api.h')), reason='node or its headers are not in this image')
 def test_addon_argument_validation_under_sanitizers(sanitized):
-    """tests/addon_validation.js (85 malformed calls: no library, wrong types and arity, short Buffers, inconsistent job objects, garbage
+    """tests/addon_validation.js (97 malformed calls: no library, wrong types and arity, short Buffers, inconsistent job objects, garbage
     proofs) and the façade's own smoke run (js/smoke.js: every member of the galois / merkle surface once) on the instrumented addon and
     driver."""
     addon = os.path.join(sanitized, 'gstark_napi.node')
     assert os.path.exists(addon)
     env = san_env(sanitized, GSTARK_ADDON=addon, GSTARK_LIB=ORACLE_LIB, GSTARK_PROVER_LIB=os.path.join(sanitized, 'libgstark_prover.so'), GSTARK_ALLOW_TEST_DOUBLE='1')
-    run_clean(['node', os.path.join(ROOT, 'tests', 'addon_validation.js')], env, 'addon validation OK: 85 malformed calls refused')
+    run_clean(['node', os.path.join(ROOT, 'tests', 'addon_validation.js')], env, 'addon validation OK: 97 malformed calls refused')
     run_clean(['node', os.path.join(ROOT, 'js', 'smoke.js')], env, 'js smoke OK')
 
 
@@ -82,4 +82,4 @@ def test_addon_argument_validation_plain_build():
     env = dict(os.environ, GSTARK_ADDON=os.path.join(ROOT, 'napi', 'gstark_napi.node'), GSTARK_LIB=ORACLE_LIB,
                GSTARK_PROVER_LIB=os.path.join(ROOT, 'genstark_amd', 'csrc', 'libgstark_prover.so'))
     r = subprocess.run(['node', os.path.join(ROOT, 'tests', 'addon_validation.js')], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and 'addon validation OK: 85' in r.stdout, (r.stdout + r.stderr)[-2000:]
+    assert r.returncode == 0 and 'addon validation OK: 97' in r.stdout, (r.stdout + r.stderr)[-2000:]
