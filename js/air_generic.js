@@ -83,11 +83,19 @@ class ProvingContext extends Context {
         this.executionDomain = f.getPowerSeries(f.exp(this.rootOfUnity, BigInt(this.extensionFactor)), this.traceLength);
         // secret registers: the polynomial K_s through one period of the column (degree < period m, in the variable x^(T/m)); its values
         // over the evaluation domain are what is committed — they repeat with period m * E there
-        const secretPolys = this.secretColumns.map(col => {
+        // (every column is packed ONCE: the bytes go to the device for the interpolation and to the trace generator's static values)
+        const columnPoly = (col, packed) => {           // the device vector of K's coefficients for one period `col` of a register
+            const m = col.length;
+            const g = f.exp(this.rootOfUnity, BigInt(this.extensionFactor * (this.traceLength / m)));
+            const values = new Vector(f, m);
+            native().call('gs_upload', f.ctx, values.ptr, packed, packed.length);
+            return f.interpolateRoots(f.getPowerSeries(g, m), values);
+        };
+        this.packedSecret = this.secretColumns.map(col => packLe(col));
+        const secretPolys = this.secretColumns.map((col, s) => {
             const m = col.length;
             if (!isPow2(m) || this.traceLength % m) throw new Error('a secret register column must be a power of 2 long and divide the trace length');
-            const g = f.exp(this.rootOfUnity, BigInt(this.extensionFactor * (this.traceLength / m)));
-            return f.interpolateRoots(f.getPowerSeries(g, m), f.newVectorFrom(col));
+            return columnPoly(col, this.packedSecret[s]);
         });
         this.secretRegisterTraces = secretPolys.map((poly, s) => {
             const m = this.secretColumns[s].length, period = m * this.extensionFactor;
@@ -95,7 +103,9 @@ class ProvingContext extends Context {
             return period === n ? onePeriod : f.pluckVector(onePeriod, 1, n);            // v[i mod period]
         });
         // static registers over the composition domain: K_s at the (period * compositionFactor)-th roots of unity, back to back; public, then secret
-        const all = this.staticPolys().map((poly, s) => ({ m: air.staticRegisters[s].length, poly: f.newVectorFrom(poly) }))
+        // (the public registers' coefficients stay on the device: their host copy, staticPolys(), is the verifier's)
+        if (!air._packedStatic) air._packedStatic = air.staticRegisters.map(v => packLe(v));
+        const all = air.staticRegisters.map((values, s) => ({ m: values.length, poly: columnPoly(values, air._packedStatic[s]) }))
             .concat(secretPolys.map((poly, s) => ({ m: this.secretColumns[s].length, poly })));
         this.staticLens = all.map(e => e.m * this.compositionFactor);
         const total = this.staticLens.reduce((a, b) => a + b, 0);
@@ -111,8 +121,8 @@ class ProvingContext extends Context {
     }
     allStaticColumns() { return this.air.staticRegisters.concat(this.secretColumns); }
     staticValuesPacked() {
-        const regs = this.allStaticColumns();
-        return regs.length ? Buffer.concat(regs.map(v => packLe(v))) : le(0n);
+        const parts = (this.air._packedStatic || this.air.staticRegisters.map(v => packLe(v))).concat(this.packedSecret);
+        return parts.length ? Buffer.concat(parts) : le(0n);
     }
     generateExecutionTrace() {   // lib/Stark.ts:97
         const air = this.air, f = this.field, t = air.transitionProgram;
