@@ -103,21 +103,27 @@ class ProvingContext extends Context {
             return period === n ? onePeriod : f.pluckVector(onePeriod, 1, n);            // v[i mod period]
         });
         // static registers over the composition domain: K_s at the (period * compositionFactor)-th roots of unity, back to back; public, then secret
-        // (the public registers' coefficients stay on the device: their host copy, staticPolys(), is the verifier's)
+        // The PUBLIC registers' tables are constants of the AIR: computed once and kept on the device with it (their coefficients never
+        // come back to the host: that copy, staticPolys(), is the verifier's); the secret registers' are this proof's.  An AIR without
+        // secret registers shares the finished table block between its proofs.
+        const table = (m, poly) => {
+            const ln = m * this.compositionFactor;
+            const wk = f.exp(this.compositionDomain.seriesBase, BigInt(this.traceLength / m));
+            return { ln, tab: f.evalPolyAtRoots(poly, f.getPowerSeries(wk, ln)) };
+        };
         if (!air._packedStatic) air._packedStatic = air.staticRegisters.map(v => packLe(v));
-        const all = air.staticRegisters.map((values, s) => ({ m: values.length, poly: columnPoly(values, air._packedStatic[s]) }))
-            .concat(secretPolys.map((poly, s) => ({ m: this.secretColumns[s].length, poly })));
-        this.staticLens = all.map(e => e.m * this.compositionFactor);
+        if (!air._publicTables) air._publicTables = air.staticRegisters.map((values, s) => table(values.length, columnPoly(values, air._packedStatic[s])));
+        const all = air._publicTables.concat(secretPolys.map((poly, s) => table(this.secretColumns[s].length, poly)));
+        this.staticLens = all.map(e => e.ln);
+        if (!secretPolys.length && air._tableBlock) { this.staticTables = air._tableBlock; return; }
         const total = this.staticLens.reduce((a, b) => a + b, 0);
         this.staticTables = new Vector(f, Math.max(total, 1));
         let off = 0;
-        all.forEach((e, s) => {
-            const ln = this.staticLens[s];
-            const wk = f.exp(this.compositionDomain.seriesBase, BigInt(this.traceLength / e.m));
-            const tab = f.evalPolyAtRoots(e.poly, f.getPowerSeries(wk, ln));
-            native().call('gs_copy', f.ctx, this.staticTables.ptr + BigInt(off * f.elementSize), tab.ptr, ln * f.elementSize);
-            off += ln;
+        all.forEach(e => {
+            native().call('gs_copy', f.ctx, this.staticTables.ptr + BigInt(off * f.elementSize), e.tab.ptr, e.ln * f.elementSize);
+            off += e.ln;
         });
+        if (!secretPolys.length) { air._tableBlock = this.staticTables; air._tableLens = this.staticLens; }
     }
     allStaticColumns() { return this.air.staticRegisters.concat(this.secretColumns); }
     staticValuesPacked() {
@@ -128,14 +134,15 @@ class ProvingContext extends Context {
         const air = this.air, f = this.field, t = air.transitionProgram;
         const m = new Matrix(f, air.traceRegisterCount, this.traceLength);
         const periods = this.allStaticColumns().map(v => v.length);
-        const first = Buffer.concat(this.firstRows.map(row => packLe(row)));
+        const first = this.firstRows.packedFirstRows || Buffer.concat(this.firstRows.map(row => packLe(row)));
+        const nrows = this.firstRows.packedFirstRows ? this.firstRows.rows : this.firstRows.length;
         if (air.segmentLength === null) {
             native().call('gs_air_trace', f.ctx, t.code, t.ninstr, t.constsBuffer(), t.consts.length, t.nregs, air.traceRegisterCount,
                 this.staticValuesPacked(), periods, periods.length, first, this.traceLength, m.ptr);
         } else {
             const init = air.initProgram;
             native().call('gs_air_trace_segments', f.ctx, t.code, t.ninstr, init ? init.code : [], init ? init.ninstr : 0, t.constsBuffer(), t.consts.length,
-                t.nregs, air.traceRegisterCount, this.staticValuesPacked(), periods, periods.length, first, this.firstRows.length, air.segmentLength, m.ptr);
+                t.nregs, air.traceRegisterCount, this.staticValuesPacked(), periods, periods.length, first, nrows, air.segmentLength, m.ptr);
         }
         return m;
     }
@@ -196,8 +203,11 @@ class GenericAir {
         this.fixedFirstRows = desc.firstRows ? desc.firstRows.map(r => r.map(v => field.mod(BigInt(v)))) : null;   // ... unless the descriptor pins it
         this.rootOfUnity = field.getRootOfUnity(this.steps * ef);
     }
+    /** the statement's first rows already in the driver's wire form, for many proofs of one seed (js/prover.js: packSeed) */
+    packSeed(seed) { const rows = this.firstRows(seed); const flat = []; for (const row of rows) for (const v of row) flat.push(v); return { packedFirstRows: packLe(flat), rows: rows.length }; }
     firstRows(seed) {
         if (this.fixedFirstRows) return this.fixedFirstRows;
+        if (seed && seed.packedFirstRows) return seed;            // a packed seed: nothing to lay out
         const pad = s => {
             if (!Array.isArray(s) || (this.seedWidth !== undefined && s.length !== this.seedWidth) || s.length > this.traceRegisterCount) throw new Error(`the AIR's first row takes ${this.seedWidth} seed values`);
             const row = s.map(v => this.field.mod(BigInt(v)));
@@ -208,6 +218,16 @@ class GenericAir {
         const segments = this.steps / this.segmentLength;
         if (!Array.isArray(seed) || seed.length !== segments) throw new Error(`a segmented AIR needs one seed per segment (${segments})`);
         return seed.map(pad);
+    }
+    /** what the ONE-CALL driver needs of a proving context (js/prover.js: genericJob) — first rows, the static registers' packed values
+     *  and their table block — without the domains' power series a member-by-member caller asks for: for an AIR without secret registers
+     *  all of it but the first rows is a constant of the AIR, built by the first full context */
+    jobContext(seed) {
+        if (this.secretInputCount || !this._tableBlock) return this.initProvingContext([], seed);
+        const air = this;
+        return { air, firstRows: this.firstRows(seed), staticTables: this._tableBlock, staticLens: this._tableLens, secretRegisterTraces: [],
+                 allStaticColumns() { return air.staticRegisters; },
+                 staticValuesPacked() { return air._packedStatic.length ? Buffer.concat(air._packedStatic) : le(0n); } };
     }
     initProvingContext(inputs, seed) {
         // inputs: one column per SECRET register (BigInt arrays), unless the descriptor already carries this proof's columns

@@ -51,9 +51,7 @@ class ProvingContext extends Context {
         this.compositionDomain = f.getPowerSeries(f.exp(this.rootOfUnity, BigInt(n / nc)), nc);
         this.executionDomain = f.getPowerSeries(f.exp(this.rootOfUnity, BigInt(this.extensionFactor)), this.traceLength);
         this.secretRegisterTraces = [];
-        const klen = air.roundConstants.length * this.compositionFactor;
-        const wk = f.exp(this.compositionDomain.seriesBase, BigInt(this.cycleCount));
-        this.kTable = f.evalPolyAtRoots(f.newVectorFrom(this.kPoly), f.getPowerSeries(wk, klen));
+        this.kTable = air.kTableOnDevice(this);
     }
     generateExecutionTrace() {
         const f = this.field, m = new Matrix(f, 1, this.traceLength), rc = this.air.roundConstants;
@@ -90,6 +88,19 @@ class MimcAir {
         this.maxConstraintDegree = 3; this.traceRegisterCount = 1; this.secretInputCount = 0;
         this.roundConstants = sha256Prng(Buffer.from('4d694d43', 'hex'), 64, this.field);
     }
+    /** the cyclic register over the composition domain: a constant of the AIR, kept on the device with it */
+    kTableOnDevice(context) {
+        if (!this._kTable) {
+            const f = this.field, nc = context.traceLength * context.compositionFactor, n = context.traceLength * context.extensionFactor;
+            const klen = this.roundConstants.length * context.compositionFactor;
+            const wk = f.exp(f.exp(context.rootOfUnity, BigInt(n / nc)), BigInt(context.cycleCount));
+            this._kTable = f.evalPolyAtRoots(f.newVectorFrom(context.kPoly), f.getPowerSeries(wk, klen));
+        }
+        return this._kTable;
+    }
+    /** what the ONE-CALL driver needs of a proving context (js/prover.js: proveMimcSerialized): the root of unity and the table — no
+     *  power series of the domains */
+    jobContext() { const c = new Context(this); c.kTable = this.kTableOnDevice(c); return c; }
     initProvingContext(inputs, seed) { return new ProvingContext(this, seed[0]); }
     initVerificationContext(inputShapes, publicInputs) { return new VerificationContext(this); }
 }

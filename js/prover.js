@@ -20,12 +20,12 @@ function driverPath(field) {
 
 function proveMimcSerialized(air, options, assertions, seed) {
     if (!(options.hashAlgorithm in HASH_ALG)) throw new TypeError(`Hash algorithm ${options.hashAlgorithm} is not supported`);
-    const context = air.initProvingContext([], [seed]);      // the cyclic register's table over the composition domain, root of unity
+    const context = air.jobContext ? air.jobContext() : air.initProvingContext([], [seed]);      // the cyclic register's table over the composition domain, root of unity
     const f = air.field;
     const job = {
         steps: air.steps, extensionFactor: air.extensionFactor, exeQueryCount: options.exeQueryCount, friQueryCount: options.friQueryCount,
         hashAlg: HASH_ALG[options.hashAlgorithm], rootOfUnity: le(context.rootOfUnity), seed: le(f.mod(seed)),
-        roundConstants: Buffer.concat(air.roundConstants.map(le)), kTable: context.kTable.ptr, kLen: context.kTable.length,
+        roundConstants: air._rcPacked || (air._rcPacked = packLe(air.roundConstants)), kTable: context.kTable.ptr, kLen: context.kTable.length,
         assertions: assertions.map(a => ({ step: a.step, register: a.register, value: le(f.mod(a.value)) })),
     };
     return native().proveMimcSerialized(f.ctx, driverPath(f), job);
@@ -39,28 +39,34 @@ function genericJob(air, context, options, assertions) {
     const f = air.field;
     const t = air.transitionProgram, e = air.evaluationProgram, init = air.initProgram;
     if (init && init.consts.length > t.consts.length) throw new Error('the init program extends the transition program\'s constant pool');
-    const base = t.consts.length, eCode = e.code.slice();
-    for (let i = 0; i < eCode.length; i += 4) {
-        if (eCode[i] === 0) eCode[i + 2] += base;            // LOADC: constant index
-        else if (eCode[i] === 8) eCode[i + 3] += base;       // POWC: exponent index
+    // (the programs' marshalled form is a constant of the AIR: kept with it)
+    if (!air._jobPrograms) {
+        const base = t.consts.length, code = e.code.slice();
+        for (let i = 0; i < code.length; i += 4) {
+            if (code[i] === 0) code[i + 2] += base;            // LOADC: constant index
+            else if (code[i] === 8) code[i + 3] += base;       // POWC: exponent index
+        }
+        const all = t.consts.concat(e.consts);
+        air._jobPrograms = { eCode: code, consts: all.length ? packLe(all) : Buffer.alloc(0) };
     }
-    const pool = t.consts.concat(e.consts);
+    const eCode = air._jobPrograms.eCode;
     const job = {
         steps: air.steps, extensionFactor: air.extensionFactor, exeQueryCount: options.exeQueryCount, friQueryCount: options.friQueryCount,
         hashAlg: HASH_ALG[options.hashAlgorithm], rootOfUnity: le(air.rootOfUnity),
         assertions: assertions.map(a => ({ step: a.step, register: a.register, value: le(f.mod(a.value)) })),
         registers: air.traceRegisterCount, degrees: air.constraintDegrees, tCode: t.code, iCode: init ? init.code : [], eCode,
-        consts: pool.length ? packLe(pool) : Buffer.alloc(0), vmRegs: Math.max(t.nregs, e.nregs, init ? init.nregs : 0),
+        consts: air._jobPrograms.consts, vmRegs: Math.max(t.nregs, e.nregs, init ? init.nregs : 0),
         // static registers: the public ones, then this proof's secret columns (struct gs_prover_air: static_values / static_tables hold both)
         staticValues: context.staticValuesPacked(), staticPeriods: context.allStaticColumns().map(v => v.length), staticTables: context.staticTables.ptr,
-        staticLens: context.staticLens, firstRows: packLe(flatRows(context.firstRows)),
-        segments: air.segmentLength === null ? 0 : context.firstRows.length, segmentLen: air.segmentLength === null ? 0 : air.segmentLength,
+        staticLens: context.staticLens, firstRows: context.firstRows.packedFirstRows || packLe(flatRows(context.firstRows)),
+        segments: air.segmentLength === null ? 0 : (context.firstRows.packedFirstRows ? context.firstRows.rows : context.firstRows.length),
+        segmentLen: air.segmentLength === null ? 0 : air.segmentLength,
     };
     if (context.secretRegisterTraces.length) job.secretTraces = context.secretRegisterTraces.map(v => v.ptr);
     return job;
 }
 function proveGenericSerialized(air, options, assertions, seed) {
-    const context = air.initProvingContext([], seed);
+    const context = air.jobContext ? air.jobContext(seed) : air.initProvingContext([], seed);
     return native().proveGenericSerialized(air.field.ctx, driverPath(air.field), genericJob(air, context, options, assertions));
 }
 
@@ -130,4 +136,8 @@ function verifyGenericSerialized(air, options, assertions, proof) {
     return native().proveGenericSerialized(f.ctx, driverPath(f), job, Buffer.from(proof));
 }
 
-module.exports = { proveMimcSerialized, proveGenericSerialized, proveAssemblySerialized, verifyMimcSerialized, verifyGenericSerialized, verifyAssemblySerialized };
+/** seed (as proveGenericSerialized takes it) -> the first rows packed once, for many proofs: what a caller whose inputs already are bytes
+ *  never pays per proof (the Python host's Prover.pack_seed) */
+function packSeed(air, seed) { return air.packSeed(seed); }
+
+module.exports = { packSeed, proveMimcSerialized, proveGenericSerialized, proveAssemblySerialized, verifyMimcSerialized, verifyGenericSerialized, verifyAssemblySerialized };

@@ -25,9 +25,13 @@ for (const c of JSON.parse(fs.readFileSync(process.argv[2], 'utf8'))) {
     for (let i = 0; i < air.traceRegisterCount; i++) { r.push(pEv.getValue(i, pos)); nx.push(pEv.getValue(i, (pos + ef) % n)); }
     const at = air.initVerificationContext([], []).evaluateConstraintsAt(x, r, nx, []);
     // ONE call of the native driver (js/prover.js -> N-API -> csrc/prover.cc) for the whole proof
-    const { proveGenericSerialized } = require(path.join(__dirname, 'prover.js'));
+    const { proveGenericSerialized, packSeed } = require(path.join(__dirname, 'prover.js'));
     const options = { hashAlgorithm: c.hash_algorithm, extensionFactor: c.extension_factor, exeQueryCount: c.exe_query_count, friQueryCount: c.fri_query_count };
     const proof = proveGenericSerialized(air, options, c.assertions.map(a => ({ step: a.step, register: a.register, value: BigInt(a.value) })), big(c.seed));
+    // the same statement from a seed packed once (packSeed: the first rows in the driver's wire form), and once more through the AIR's cached
+    // job context: the same bytes
+    const again = proveGenericSerialized(air, options, c.assertions.map(a => ({ step: a.step, register: a.register, value: BigInt(a.value) })), packSeed(air, big(c.seed)));
+    if (Buffer.compare(proof, again)) throw new Error(`${c.name}: a packed seed gave other proof bytes`);
     out.push({ name: c.name, proofSize: proof.length, proofSha256: sha(proof), trace: sha(trace.toBuffer()), constraints: sha(q.toBuffer()), statics: sha(statics.toBuffer()),
                constraintsAt: at.map(String), rows: [trace.rowCount, q.rowCount, statics.rowCount], cols: [trace.colCount, q.colCount] });
 }

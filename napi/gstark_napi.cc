@@ -469,7 +469,8 @@ napi_value ProveMimcSerialized(napi_env env, napi_callback_info info) {
     }
     job.assertions = as.data(); job.nassertions = na;
     if (argc >= 4) return verify_instead(env, argv[3], job);
-    std::vector<uint8_t> out(1 << 22);
+    static thread_local std::vector<uint8_t> out;      // (kept between calls: a fresh vector of this size is 4 MB of zeroing per proof)
+    if (out.size() < (1u << 22)) out.resize(1u << 22);
     uint64_t n = 0;
     char err[512] = {0};
     int rcode = ((prove_on_fn)dlsym(g_prover, "gs_prover_prove_on"))(g_binding, (gs_ctx *)ctx, &job, out.data(), out.size(), &n, err, sizeof err);
@@ -627,7 +628,8 @@ napi_value ProveGenericSerialized(napi_env env, napi_callback_info info) {
     }
     job.assertions = as.data(); job.nassertions = na;
     if (argc >= 4) return verify_instead(env, argv[3], job);
-    std::vector<uint8_t> out(1 << 22);
+    static thread_local std::vector<uint8_t> out;      // (kept between calls: a fresh vector of this size is 4 MB of zeroing per proof)
+    if (out.size() < (1u << 22)) out.resize(1u << 22);
     uint64_t n = 0;
     char err[512] = {0};
     int rcode = ((prove_on_fn)dlsym(g_prover, "gs_prover_prove_on"))(g_binding, (gs_ctx *)ctx, &job, out.data(), out.size(), &n, err, sizeof err);
