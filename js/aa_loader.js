@@ -721,7 +721,11 @@ function handle(req, raw) {
         const plan = air.plan(toBig(req.inputs || []), seed);
         const d = plan.air.descriptor(plan.firsts, raw);
         d.secretRegisters = plan.packed.map(col => col.map(str));            // this proof's secret columns (one period each)
-        return { descriptor: d, inputShapes: plan.shapes };
+        const answer = { descriptor: d, inputShapes: plan.shapes };
+        // (a caller in this process may key what it builds from the descriptor's shape-dependent part — programs, public static
+        //  registers — by the inner AIR itself: the same object for every proof of the same public columns)
+        if (raw) { answer.innerAir = plan.air; answer.firstRows = plan.air.segmentLength === null ? [plan.firsts] : plan.firsts; answer.secretColumns = plan.packed; }
+        return answer;
     }
     if (req.op === 'verify') {
         const shapes = (req.inputShapes || []).map(s => s.map(Number));

@@ -91,7 +91,22 @@ class AssemblyAir {
         if (this._inner) return this._inner.initProvingContext(inputs, seed);
         const text = process.env.GSTARK_AA_LOADER === 'python' ? toStrings : (x => x);          // (JSON to the child process; the loader in this process takes BigInt)
         const plan = ask(this._req('plan', { inputs: text(inputs || []), seed: seed === undefined || seed === null ? null : text(seed) }));
-        const ctx = this._build(plan.descriptor).initProvingContext([], undefined);
+        let ctx;
+        if (plan.innerAir) {
+            // the loader in this process: the AIR of these public columns is built once (programs, static registers, their tables on the
+            // device) and found again by the loader's own object for it; the proof's part is the first rows and the secret columns
+            if (!this._generic) this._generic = new WeakMap();
+            let g = this._generic.get(plan.innerAir);
+            if (!g) {
+                const d = Object.assign({}, plan.descriptor);
+                delete d.firstRows; delete d.secretRegisters;
+                d.seedWidth = d.registers;
+                g = this._build(d);
+                this._generic.set(plan.innerAir, g);
+            }
+            const p = this.field.modulus, red = v => (v >= 0n && v < p ? v : ((v % p) + p) % p);
+            ctx = g.contextFor(plan.firstRows.map(row => row.map(red)), plan.secretColumns);
+        } else ctx = this._build(plan.descriptor).initProvingContext([], undefined);
         ctx.inputShapes = plan.inputShapes;
         return ctx;
     }

@@ -229,6 +229,8 @@ class GenericAir {
                  allStaticColumns() { return air.staticRegisters; },
                  staticValuesPacked() { return air._packedStatic.length ? Buffer.concat(air._packedStatic) : le(0n); } };
     }
+    /** a proving context from first rows and secret columns that are already reduced field elements (the loader's plan: js/air_assembly.js) */
+    contextFor(firstRows, secretColumns) { return new ProvingContext(this, firstRows, secretColumns || []); }
     initProvingContext(inputs, seed) {
         // inputs: one column per SECRET register (BigInt arrays), unless the descriptor already carries this proof's columns
         let cols = this.secretColumns;
